@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures that pin ``oracle/att_lstm.py`` to the REAL reference.
+
+Run only in the build container (``/root/reference`` does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports the reference's own modules (``captioning.models``, ``captioning.modules.losses``)
+unmodified, runs them on CPU at a tiny size with fixed seeds and stores weights, inputs and
+outputs in ``tests/golden/*.npz``.  The fixtures are small (tens of KB) and are committed;
+``tests/test_oracle_golden.py`` replays them through the oracle.  Nothing here is copied from the
+reference -- it is only *called*.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = os.environ.get('CAPMI_REFERENCE', '/root/reference')
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def tiny_opt(caption_model, drop=0.0):
+    V = 30
+    o = argparse.Namespace(
+        caption_model=caption_model, vocab_size=V, input_encoding_size=16, rnn_size=16, num_layers=1,
+        drop_prob_lm=drop, seq_length=8, max_length=8, fc_feat_size=20, att_feat_size=20, att_hid_size=12,
+        use_bn=0, logit_layers=1, vocab={str(i): 'w%d' % i for i in range(1, V + 1)}, rnn_type='lstm')
+    return o
+
+
+def to_np(d):
+    return {k: v.detach().cpu().numpy() for k, v in d.items()}
+
+
+def main():
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    import captioning.models as models          # noqa: E402  (the reference)
+    from captioning.modules import losses        # noqa: E402
+
+    torch.manual_seed(1234)
+    B, n, K, T = 3, 2, 6, 9          # T = seq_length + 1 inputs
+    N = B * n
+
+    # ---------------------------------------------------------------- updown
+    opt = tiny_opt('updown', drop=0.0)
+    model = models.setup(opt)
+    # default inits leave biases ~0 for some layers; perturb everything so no term can hide
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    fc = torch.randn(B, opt.fc_feat_size).clamp_min(0)
+    att = torch.randn(B, K, opt.att_feat_size).clamp_min(0)
+    labels = torch.zeros(B, n, T + 1, dtype=torch.long)
+    for b in range(B):
+        for j in range(n):
+            ln = int(torch.randint(3, T - 1, (1,)))
+            labels[b, j, 1:1 + ln] = torch.randint(1, opt.vocab_size + 1, (ln,))
+    # make the longest caption short enough that the trailing all-pad-column break (AttModel.py:158) triggers
+    labels[:, :, T - 1:] = 0
+    masks = torch.zeros(B, n, T + 1)
+    for b in range(B):
+        for j in range(n):
+            nz = int((labels[b, j] > 0).sum())
+            masks[b, j, :nz + 2] = 1
+    att_masks = torch.ones(B, K)
+    att_masks[0, 4:] = 0
+    att_masks[2, 5:] = 0
+
+    out = {('P.' + k): v for k, v in to_np(model.state_dict()).items()}
+    out.update(fc=fc.numpy(), att=att.numpy(), labels=labels.numpy(), masks=masks.numpy(), att_masks=att_masks.numpy())
+
+    model.train()       # drop_prob 0 => dropout is the identity; training graph as in train.py
+    for tag, am in (('nomask', None), ('mask', att_masks)):
+        model.zero_grad()
+        logp = model(fc, att, labels[..., :-1], am)
+        crit = losses.LanguageModelCriterion()
+        loss = crit(logp, labels[..., 1:], masks[..., 1:])
+        loss.backward()
+        out['xe_logp_' + tag] = logp.detach().numpy()
+        out['xe_loss_' + tag] = loss.detach().numpy()
+        for k, p in model.named_parameters():
+            out['xe_grad_%s.%s' % (tag, k)] = p.grad.detach().numpy().copy()
+        loss_rows = crit(logp, labels[..., 1:], masks[..., 1:], reduction='none')
+        out['xe_loss_rows_' + tag] = loss_rows.detach().numpy()
+        ls = losses.LabelSmoothing(smoothing=0.2)
+        out['ls_loss_' + tag] = ls(logp, labels[..., 1:].reshape(N, -1), masks[..., 1:].reshape(N, -1)).detach().numpy()
+
+    model.eval()
+    with torch.no_grad():
+        for tag, am in (('nomask', None), ('mask', att_masks)):
+            seq, slp = model(fc, att, am, opt={'sample_method': 'greedy', 'beam_size': 1}, mode='sample')
+            out['greedy_seq_' + tag] = seq.numpy()
+            out['greedy_logp_' + tag] = slp.numpy()
+    # stochastic decode with temperature; graph retained -> RewardCriterion gradient
+    model.train()
+    model.zero_grad()
+    torch.manual_seed(7)
+    seq, slp = model(fc, att, att_masks, opt={'sample_method': 'sample', 'beam_size': 1, 'sample_n': n,
+                                              'temperature': 1.3}, mode='sample')
+    reward = torch.randn(N, 1).repeat(1, seq.shape[1])
+    rl = losses.RewardCriterion()(slp, seq.data, reward)
+    rl.backward()
+    out['sample_seq'] = seq.numpy()
+    out['sample_logp'] = slp.detach().numpy()
+    out['sample_reward'] = reward.numpy()
+    out['rl_loss'] = rl.detach().numpy()
+    for k, p in model.named_parameters():
+        out['rl_grad.' + k] = p.grad.detach().numpy().copy()
+    # new_self_critical structure loss on the same sample with given scores
+    sopt = argparse.Namespace(structure_loss_type='new_self_critical', train_sample_n=n, entropy_reward_weight=0,
+                              self_cider_reward_weight=0)
+    scores = np.random.RandomState(3).rand(N)
+    import captioning.modules.losses as L
+    saved = L.get_scores
+    L.get_scores = lambda data_gts, gen_result, o: scores      # CIDEr is external; inject the scores
+    try:
+        sl = L.StructureLosses(sopt)(slp.detach(), seq, [None] * B)
+    finally:
+        L.get_scores = saved
+    out['nsc_scores'] = scores
+    out['nsc_loss'] = sl['loss'].numpy()
+    np.savez_compressed(os.path.join(HERE, 'updown_tiny.npz'), **out)
+    print('updown_tiny.npz:', len(out), 'arrays')
+
+    # ---------------------------------------------------------------- newfc (config C1)
+    torch.manual_seed(4321)
+    opt = tiny_opt('newfc', drop=0.0)
+    model = models.setup(opt)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    out = {('P.' + k): v for k, v in to_np(model.state_dict()).items()}
+    out.update(fc=fc.numpy(), labels=labels.numpy(), masks=masks.numpy())
+    model.train()
+    model.zero_grad()
+    logp = model(fc, att, labels[..., :-1], None)
+    loss = losses.LanguageModelCriterion()(logp, labels[..., 1:], masks[..., 1:])
+    loss.backward()
+    out['xe_logp'] = logp.detach().numpy()
+    out['xe_loss'] = loss.detach().numpy()
+    for k, p in model.named_parameters():
+        out['xe_grad.' + k] = p.grad.detach().numpy().copy()
+    model.eval()
+    with torch.no_grad():
+        seq, slp = model(fc, att, None, opt={'sample_method': 'greedy', 'beam_size': 1}, mode='sample')
+    out['greedy_seq'] = seq.numpy()
+    out['greedy_logp'] = slp.numpy()
+    np.savez_compressed(os.path.join(HERE, 'newfc_tiny.npz'), **out)
+    print('newfc_tiny.npz:', len(out), 'arrays')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,99 @@
+"""Pins oracle/att_lstm.py to the REAL reference through tests/golden/*.npz (made by
+tests/golden/make_golden.py, which imports /root/reference).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import att_lstm as O
+from conftest import GOLDEN
+
+TOL = dict(rtol=1e-5, atol=2e-6)
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    P = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('P.')}
+    return z, P
+
+
+@pytest.mark.parametrize('tag', ['nomask', 'mask'])
+def test_updown_teacher_forced_logprobs_loss_and_grads(tag):
+    z, P = load('updown_tiny.npz')
+    for v in P.values():
+        v.requires_grad_(True)
+    fc, att = torch.from_numpy(z['fc']), torch.from_numpy(z['att'])
+    labels, masks = torch.from_numpy(z['labels']), torch.from_numpy(z['masks'])
+    am = torch.from_numpy(z['att_masks']) if tag == 'mask' else None
+    logp = O.forward_teacher(P, fc, att, labels[..., :-1], am)
+    np.testing.assert_allclose(logp.detach().numpy(), z['xe_logp_' + tag], **TOL)
+    # the early-break columns must be exactly zero like the reference's
+    assert (z['xe_logp_' + tag][:, -1] == 0).all() and (logp.detach().numpy()[:, -1] == 0).all()
+    loss = O.lm_criterion(logp, labels[..., 1:], masks[..., 1:])
+    np.testing.assert_allclose(loss.item(), z['xe_loss_' + tag], rtol=1e-6)
+    rows = O.lm_criterion(logp, labels[..., 1:], masks[..., 1:], reduction='none')
+    np.testing.assert_allclose(rows.detach().numpy(), z['xe_loss_rows_' + tag], rtol=1e-5)
+    ls = O.label_smoothing_criterion(logp, labels[..., 1:], masks[..., 1:], 0.2)
+    np.testing.assert_allclose(ls.item(), z['ls_loss_' + tag], rtol=1e-5)
+    loss.backward()
+    for k, p in P.items():
+        np.testing.assert_allclose(p.grad.numpy(), z['xe_grad_%s.%s' % (tag, k)], rtol=2e-4, atol=2e-7, err_msg=k)
+
+
+@pytest.mark.parametrize('tag', ['nomask', 'mask'])
+def test_updown_greedy_token_exact(tag):
+    z, P = load('updown_tiny.npz')
+    fc, att = torch.from_numpy(z['fc']), torch.from_numpy(z['att'])
+    am = torch.from_numpy(z['att_masks']) if tag == 'mask' else None
+    with torch.no_grad():
+        seq, slp = O.rollout(P, fc, att, am, method='greedy', max_len=8)
+    assert np.array_equal(seq.numpy(), z['greedy_seq_' + tag])
+    np.testing.assert_allclose(slp.numpy(), z['greedy_logp_' + tag], **TOL)
+
+
+def test_updown_sampled_rollout_forced_tokens_and_reward_grads():
+    """The reference sampled `sample_seq` with torch's generator; teacher-forcing those tokens
+    through the oracle must reproduce its dense log-probs (un-tempered although temperature 1.3
+    was used to sample), the RewardCriterion loss and every parameter gradient."""
+    z, P = load('updown_tiny.npz')
+    for v in P.values():
+        v.requires_grad_(True)
+    fc, att, am = (torch.from_numpy(z[k]) for k in ('fc', 'att', 'att_masks'))
+    forced = torch.from_numpy(z['sample_seq'])
+    seq, slp = O.rollout(P, fc, att, am, method='sample', sample_n=2, temperature=1.3, max_len=8, forced=forced)
+    assert np.array_equal(seq.numpy(), z['sample_seq'])
+    np.testing.assert_allclose(slp.detach().numpy(), z['sample_logp'], **TOL)
+    loss = O.reward_criterion(slp, seq, torch.from_numpy(z['sample_reward']))
+    np.testing.assert_allclose(loss.item(), z['rl_loss'], rtol=1e-5)
+    loss.backward()
+    for k, p in P.items():
+        np.testing.assert_allclose(p.grad.numpy(), z['rl_grad.' + k], rtol=2e-4, atol=2e-7, err_msg=k)
+    nsc = O.new_self_critical_loss(slp.detach(), seq, torch.from_numpy(z['nsc_scores']), 2)
+    np.testing.assert_allclose(nsc.item(), z['nsc_loss'], rtol=1e-5)
+
+
+def test_gumbel_sampling_is_categorical():
+    """Gumbel-max over logp/T is the distribution Categorical(logits=logp/T) (CaptionModel.py:405)."""
+    g = torch.Generator().manual_seed(0)
+    logp = torch.log_softmax(torch.randn(1, 6, generator=g), 1)
+    T = 0.7
+    u = torch.rand(200000, 6, generator=g).clamp_min(1e-20)
+    it = torch.max(logp / T - torch.log(-torch.log(u)), 1)[1]
+    freq = torch.bincount(it, minlength=6).float() / it.numel()
+    np.testing.assert_allclose(freq.numpy(), torch.softmax(logp / T, 1)[0].numpy(), atol=5e-3)
+
+
+def test_newfc_teacher_forced_and_greedy():
+    z, P = load('newfc_tiny.npz')
+    for v in P.values():
+        v.requires_grad_(True)
+    fc = torch.from_numpy(z['fc'])
+    labels, masks = torch.from_numpy(z['labels']), torch.from_numpy(z['masks'])
+    logp = O.newfc_forward_teacher(P, fc, labels[..., :-1])
+    np.testing.assert_allclose(logp.detach().numpy(), z['xe_logp'], **TOL)
+    loss = O.lm_criterion(logp, labels[..., 1:], masks[..., 1:])
+    np.testing.assert_allclose(loss.item(), z['xe_loss'], rtol=1e-6)
+    loss.backward()
+    for k, p in P.items():
+        np.testing.assert_allclose(p.grad.numpy(), z['xe_grad.' + k], rtol=2e-4, atol=2e-7, err_msg=k)
