@@ -1,0 +1,128 @@
+"""ctypes binding of libcapmi.so (the C ABI declared in include/capmi.h).
+
+The product path has NO CPU fallback: if the shared object is missing or does not export a symbol
+this module raises at import time (build it with ``python -m imagecaptioning.pytorch_amd.build``).
+``import torch`` comes first on purpose -- torch ships its own ``libamdhip64.so.7``; loading it first
+makes libcapmi resolve the same HIP runtime, so torch streams and device pointers are valid inside
+our launches.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL: shared HIP runtime)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libcapmi.so')
+MAX_SEG = 4
+EINVAL = -1
+
+c_f = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
+
+
+class GemmSeg(C.Structure):
+    _fields_ = [('A', c_f), ('B', c_f), ('lda', C.c_int), ('ldb', C.c_int), ('K', C.c_int), ('a_row_div', C.c_int)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [('seg', GemmSeg * MAX_SEG), ('nseg', C.c_int), ('a_layout', C.c_int), ('b_layout', C.c_int),
+                ('M', C.c_int), ('N', C.c_int), ('C', c_f), ('ldc', C.c_int), ('bias', c_f), ('bias2', c_f),
+                ('row_bias', c_f), ('row_bias_div', C.c_int), ('mul_mask', c_f), ('relu', C.c_int),
+                ('accumulate', C.c_int), ('partial', c_f), ('partial_capacity', C.c_int64), ('splits', C.c_int),
+                ('defer_reduce', C.c_int), ('splits_used', C.c_int)]
+
+
+class UpDownWeights(C.Structure):
+    _fields_ = [(k, c_f) for k in (
+        'embed', 'att_w_ih', 'att_w_hh', 'att_b_ih', 'att_b_hh', 'lang_w_ih', 'lang_w_hh', 'lang_b_ih', 'lang_b_hh',
+        'h2att_w', 'h2att_b', 'alpha_w', 'alpha_b', 'logit_w', 'logit_b')]
+
+
+class UpDownRollout(C.Structure):
+    _fields_ = ([(k, C.c_int) for k in ('B', 'n', 'N', 'K', 'A', 'R', 'E', 'V1', 'T', 'L')] +
+                [(k, c_f) for k in ('fc', 'att', 'p_att', 'att_mask', 'drop_xt', 'drop_out')] +
+                [('mode', C.c_int), ('row_mode', c_f), ('temperature', C.c_float), ('gumbel', c_f),
+                 ('seed', C.c_uint64), ('forced', c_f), ('forced_ld', C.c_int), ('teacher', C.c_int)] +
+                [(k, c_f) for k in ('h_att', 'c_att', 'h_lang', 'c_lang', 'xt', 'it_all', 'gates_att', 'gates_lang',
+                                    'att_h', 'alpha', 'ctx', 'h_drop', 'seq', 'seq_logp', 'sel_logp', 'live',
+                                    'fc_gates', 'logits', 'it', 'unfinished', 'partial')] +
+                [('partial_capacity', C.c_int64)])
+
+
+class UpDownGrads(C.Structure):
+    _fields_ = [(k, c_f) for k in (
+        'embed', 'att_w_ih', 'att_w_hh', 'att_b_ih', 'att_b_hh', 'lang_w_ih', 'lang_w_hh', 'lang_b_ih', 'lang_b_hh',
+        'h2att_w', 'h2att_b', 'alpha_w', 'alpha_b', 'logit_w', 'logit_b', 'd_fc', 'd_att', 'd_p_att')]
+
+
+class UpDownBwdScratch(C.Structure):
+    _fields_ = ([(k, c_f) for k in ('dlogits', 'd_hdrop', 'dg_att', 'dg_lang', 'd_x2', 'd_e_all', 'd_att_h_all',
+                                    'dh_att_attn', 'd_x1', 'dc_att', 'dc_lang', 'd_xt_all', 'sum_dg_att', 'partial')] +
+                [('partial_capacity', C.c_int64)])
+
+
+_I, _F, _P, _U64, _I64 = C.c_int, C.c_float, C.c_void_p, C.c_uint64, C.c_int64
+
+# name -> argtypes (restype is always int unless noted).  Must list EVERY symbol of include/capmi.h:
+# tests/test_abi.py cross-checks this table against the header and the built library.
+SIGNATURES = {
+    'capmi_version': [],
+    'capmi_arch': [],
+    'capmi_gemm_f32': [C.POINTER(GemmDesc), _P],
+    'capmi_attention_fwd': [_P] * 8 + [_I] * 5 + [_P],
+    'capmi_attention_bwd': [_P, _I] + [_P] * 8 + [_I] * 5 + [_P],
+    'capmi_attention_bwd_batched': [_P, _I] + [_P] * 9 + [_I] * 6 + [_P],
+    'capmi_lstm_cell_fwd': [_P, _I, _P, _P, _P, _I] + [_P] * 6 + [_I, _I, _P],
+    'capmi_lstm_cell_bwd': [_P, _I, _P, _P, _I, _P, _I] + [_P] * 6 + [_I, _I, _P],
+    'capmi_embed_fwd': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P],
+    'capmi_embed_bwd': [_P] * 5 + [_I, _I, _I, _P],
+    'capmi_logsoftmax_select': [_P, _I, _I, _I, _I, _I, _P, _F, _P, _U64, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P],
+    'capmi_logsoftmax_bwd': [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'capmi_splitk_reduce': [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P],
+    'capmi_dropout_mask': [_P, _I64, _F, _U64, _U64, _P],
+    'capmi_colsum': [_P, _I, _I, _I, _P, _I, _P],
+    'capmi_group_rowsum': [_P, _I, _I64, _I, _I, _I, _P, _P],
+    'capmi_relu_mask_bwd': [_P, _P, _P, _P, _I64, _P],
+    'capmi_adam_step': [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _I, _P],
+    'capmi_ciderd_score': [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, C.c_uint32, C.c_double, _P, _P],
+    'capmi_scst_advantage': [_P, _I, _I, _P, _P],
+    'capmi_updown_rollout_fwd': [C.POINTER(UpDownWeights), C.POINTER(UpDownRollout), _P],
+    'capmi_updown_rollout_bwd': [C.POINTER(UpDownWeights), C.POINTER(UpDownRollout), _P, C.POINTER(UpDownBwdScratch),
+                                 C.POINTER(UpDownGrads), _P],
+}
+
+
+class CapmiError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libcapmi.so not found at %s -- the HIP backend is mandatory (no CPU fallback). '
+            'Build it: python -m imagecaptioning.pytorch_amd.build' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise ImportError('libcapmi.so does not export %s (stale build?)' % name) from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == 'capmi_arch' else C.c_int
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise CapmiError('%s failed: %s' % (what, 'invalid argument' if rc == EINVAL else 'hipError %d' % rc))
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,338 @@
+// Fused additive region attention for gfx950 (AttModel.py:728-748 Attention.forward and its
+// autograd backward).
+//
+// Forward: ONE workgroup per image.  The image's projected tile p_att[b] (K x A) and feature tile
+// att[b] (K x R) are each read from HBM exactly once and reused, in registers, by the n caption rows
+// that share the image (sample_n / seq_per_img): the reference's repeat_tensors copy
+// (models/utils.py:3-14) and its n-fold re-reads do not exist here.  score -> softmax (-> mask
+// renorm) -> context run in one launch; only att_h[n,A] (16 KB) and the n x K score matrix live in
+// LDS.  HBM traffic per launch = B*K*(A+R)*4 + N*(A+R+K)*4 bytes (SURVEY.md 8d "unique bytes").
+//   phase 1  wave w owns regions k = w, w+8, ...: lanes stride A with 16-byte loads, tanh on the
+//            VALU, wave64 shuffle reduction per (row, region)
+//   phase 2  wave j normalises row j (K <= a few hundred): shuffle max/sum
+//   phase 3  each lane owns 2 feature columns and streams the K rows of att[b] with 8-byte loads
+#include "capmi_common.h"
+#include "../../../include/capmi.h"
+
+using namespace capmi;
+
+namespace {
+
+constexpr int NMAX = 8;       // rows per image handled by one workgroup
+constexpr int ATT_THREADS = 512;
+
+__global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
+    const float *__restrict__ att_h, const float *__restrict__ p_att, const float *__restrict__ att,
+    const float *__restrict__ mask, const float *__restrict__ w, const float *__restrict__ bptr,
+    float *__restrict__ ctx, float *__restrict__ alpha, int n_img, int K, int A, int R) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *s_h = lds;                    // [NMAX][A]
+    float *s_e = lds + (size_t)NMAX * A; // [NMAX][K]
+    const int b = blockIdx.x;
+    const int row0 = b * n_img + blockIdx.y * NMAX;          // first caption row of this workgroup
+    const int n = min(NMAX, n_img - (int)blockIdx.y * NMAX);   // rows handled here (<= NMAX)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+
+    for (int i = threadIdx.x; i < n * A; i += blockDim.x) s_h[i] = att_h[(size_t)row0 * A + i];
+    __syncthreads();
+
+    const float bias = bptr ? bptr[0] : 0.f;
+    const float *pb = p_att + (size_t)b * K * A;
+    const bool vecA = (A % 4 == 0) && ((reinterpret_cast<uintptr_t>(p_att) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
+    for (int k = wid; k < K; k += nw) {
+        float acc[NMAX];
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) acc[j] = 0.f;
+        const float *pk = pb + (size_t)k * A;
+        if (vecA) {
+            for (int a = lane * 4; a < A; a += 256) {
+                const f32x4 p = *reinterpret_cast<const f32x4 *>(pk + a);
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + a);
+#pragma unroll
+                for (int j = 0; j < NMAX; ++j) {
+                    if (j < n) {
+                        const f32x4 h = *reinterpret_cast<const f32x4 *>(s_h + j * A + a);
+                        acc[j] += wv[0] * tanh_f(p[0] + h[0]) + wv[1] * tanh_f(p[1] + h[1]) +
+                                  wv[2] * tanh_f(p[2] + h[2]) + wv[3] * tanh_f(p[3] + h[3]);
+                    }
+                }
+            }
+        } else {
+            for (int a = lane; a < A; a += 64) {
+                const float p = pk[a], wv = w[a];
+#pragma unroll
+                for (int j = 0; j < NMAX; ++j)
+                    if (j < n) acc[j] += wv * tanh_f(p + s_h[j * A + a]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            if (j < n) {
+                const float e = wave_sum(acc[j]) + bias;
+                if (lane == 0) s_e[j * K + k] = e;
+            }
+        }
+    }
+    __syncthreads();
+
+    // softmax over regions, one wave per row
+    for (int j = wid; j < n; j += nw) {
+        float *e = s_e + j * K;
+        float m = -INFINITY;
+        for (int k = lane; k < K; k += 64) m = fmaxf(m, e[k]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float x = __expf(e[k] - m);
+            e[k] = x;
+            s += x;
+        }
+        s = wave_sum(s);
+        const float inv = 1.f / s;
+        if (mask) {
+            const float *mb = mask + (size_t)b * K;
+            float s2 = 0.f;
+            for (int k = lane; k < K; k += 64) {
+                const float x = e[k] * inv * mb[k];
+                e[k] = x;
+                s2 += x;
+            }
+            s2 = wave_sum(s2);
+            for (int k = lane; k < K; k += 64) e[k] = e[k] / s2;
+        } else {
+            for (int k = lane; k < K; k += 64) e[k] = e[k] * inv;
+        }
+        for (int k = lane; k < K; k += 64) alpha[(size_t)(row0 + j) * K + k] = e[k];
+    }
+    __syncthreads();
+
+    // context: lane owns 2 columns, streams K rows of att[b]
+    const float *ab = att + (size_t)b * K * R;
+    const bool vecR = (R % 2 == 0) && ((reinterpret_cast<uintptr_t>(att) & 7) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(ctx) & 7) == 0);
+    if (vecR) {
+        for (int r = threadIdx.x * 2; r < R; r += blockDim.x * 2) {
+            float a0[NMAX], a1[NMAX];
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j) a0[j] = a1[j] = 0.f;
+            for (int k = 0; k < K; ++k) {
+                const float2 v = *reinterpret_cast<const float2 *>(ab + (size_t)k * R + r);
+#pragma unroll
+                for (int j = 0; j < NMAX; ++j) {
+                    if (j < n) {
+                        const float al = s_e[j * K + k];
+                        a0[j] += al * v.x;
+                        a1[j] += al * v.y;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j)
+                if (j < n) *reinterpret_cast<float2 *>(ctx + (size_t)(row0 + j) * R + r) = make_float2(a0[j], a1[j]);
+        }
+    } else {
+        for (int r = threadIdx.x; r < R; r += blockDim.x) {
+            float a0[NMAX];
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j) a0[j] = 0.f;
+            for (int k = 0; k < K; ++k) {
+                const float v = ab[(size_t)k * R + r];
+#pragma unroll
+                for (int j = 0; j < NMAX; ++j)
+                    if (j < n) a0[j] += s_e[j * K + k] * v;
+            }
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j)
+                if (j < n) ctx[(size_t)(row0 + j) * R + r] = a0[j];
+        }
+    }
+}
+
+// ---- backward, one step: d_ctx -> d_e, d_att_h ------------------------------------------------
+// With or without the mask renormalisation the softmax-input gradient is
+//   d_e[k] = alpha[k] * (dalpha[k] - sum_k' alpha[k'] dalpha[k'])   (alpha = the FINAL weights),
+// because the renorm u_k = alpha_sm,k m_k / S composes with the softmax Jacobian to the same form
+// (masked regions have alpha = 0 and receive 0).
+__global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
+    const float *__restrict__ d_ctx, int ld_dctx, const float *__restrict__ att_h, const float *__restrict__ alpha,
+    const float *__restrict__ p_att, const float *__restrict__ att, const float *__restrict__ w,
+    float *__restrict__ d_att_h, float *__restrict__ d_e, int n_img, int K, int A, int R) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *s_dc = lds;                        // [NMAX][R]
+    float *s_de = s_dc + (size_t)NMAX * R;    // [NMAX][K]  dalpha, then d_e
+    const int b = blockIdx.x;
+    const int row0 = b * n_img + blockIdx.y * NMAX;
+    const int n = min(NMAX, n_img - (int)blockIdx.y * NMAX);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int i = threadIdx.x; i < n * R; i += blockDim.x)
+        s_dc[i] = d_ctx[(size_t)(row0 + i / R) * ld_dctx + (i % R)];
+    __syncthreads();
+    const float *ab = att + (size_t)b * K * R;
+    for (int k = wid; k < K; k += nw) {
+        float acc[NMAX];
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) acc[j] = 0.f;
+        for (int r = lane; r < R; r += 64) {
+            const float v = ab[(size_t)k * R + r];
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j)
+                if (j < n) acc[j] += v * s_dc[j * R + r];
+        }
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            if (j < n) {
+                const float s = wave_sum(acc[j]);
+                if (lane == 0) s_de[j * K + k] = s;
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = wid; j < n; j += nw) {
+        const float *al = alpha + (size_t)(row0 + j) * K;
+        float c = 0.f;
+        for (int k = lane; k < K; k += 64) c += al[k] * s_de[j * K + k];
+        c = wave_sum(c);
+        for (int k = lane; k < K; k += 64) {
+            const float de = al[k] * (s_de[j * K + k] - c);
+            s_de[j * K + k] = de;
+            d_e[(size_t)(row0 + j) * K + k] = de;
+        }
+    }
+    __syncthreads();
+    const float *pb = p_att + (size_t)b * K * A;
+    for (int a = threadIdx.x; a < A; a += blockDim.x) {
+        float acc[NMAX], hh[NMAX];
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            acc[j] = 0.f;
+            hh[j] = j < n ? att_h[(size_t)(row0 + j) * A + a] : 0.f;
+        }
+        for (int k = 0; k < K; ++k) {
+            const float p = pb[(size_t)k * A + a];
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j) {
+                if (j < n) {
+                    const float t = tanh_f(p + hh[j]);
+                    acc[j] += s_de[j * K + k] * (1.f - t * t);
+                }
+            }
+        }
+        const float wa = w[a];
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j)
+            if (j < n) d_att_h[(size_t)(row0 + j) * A + a] = wa * acc[j];
+    }
+}
+
+// ---- backward, time-batched feature / parameter gradients --------------------------------------
+constexpr int KCH = 12;
+__global__ void attn_datt_kernel(const float *__restrict__ d_ctx_all, int ld_dctx, const float *__restrict__ alpha_all,
+                                 float *__restrict__ d_att, int T, int N, int n, int K, int R) {
+    // grid (B, ceil(R/256)); thread owns column r, KCH region accumulators at a time
+    const int b = blockIdx.x;
+    const int r = blockIdx.y * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    for (int kc = 0; kc < K; kc += KCH) {
+        float acc[KCH];
+#pragma unroll
+        for (int q = 0; q < KCH; ++q) acc[q] = 0.f;
+        for (int t = 0; t < T; ++t) {
+            for (int j = 0; j < n; ++j) {
+                const size_t row = (size_t)t * N + b * n + j;
+                const float d = d_ctx_all[row * ld_dctx + r];
+                const float *al = alpha_all + row * K + kc;
+#pragma unroll
+                for (int q = 0; q < KCH; ++q)
+                    if (kc + q < K) acc[q] += al[q] * d;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < KCH; ++q)
+            if (kc + q < K) d_att[((size_t)b * K + kc + q) * R + r] = acc[q];
+    }
+}
+
+__global__ void attn_dpatt_kernel(const float *__restrict__ att_h_all, const float *__restrict__ d_e_all,
+                                  const float *__restrict__ p_att, const float *__restrict__ w,
+                                  float *__restrict__ d_p_att, float *__restrict__ d_w, int T, int N, int n, int K,
+                                  int A) {
+    // grid (B*K); threads over a
+    const int b = blockIdx.x / K, k = blockIdx.x % K;
+    for (int a = threadIdx.x; a < A; a += blockDim.x) {
+        const float p = p_att[((size_t)b * K + k) * A + a];
+        float acc = 0.f, accw = 0.f;
+        for (int t = 0; t < T; ++t) {
+            for (int j = 0; j < n; ++j) {
+                const size_t row = (size_t)t * N + b * n + j;
+                const float de = d_e_all[row * K + k];
+                const float th = tanh_f(p + att_h_all[row * A + a]);
+                acc += de * (1.f - th * th);
+                accw += de * th;
+            }
+        }
+        d_p_att[((size_t)b * K + k) * A + a] = w[a] * acc;
+        atomicAdd(&d_w[a], accw);
+    }
+}
+
+__global__ void sum_all_kernel(const float *__restrict__ in, size_t count, float *__restrict__ out) {
+    __shared__ float scratch[32];
+    float s = 0.f;
+    for (size_t i = threadIdx.x; i < count; i += blockDim.x) s += in[i];
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int capmi_attention_fwd(const float *att_h, const float *p_att, const float *att, const float *mask, const float *w,
+                        const float *b, float *ctx, float *alpha, int B, int n, int K, int A, int R, void *stream) {
+    if (!att_h || !p_att || !att || !w || !ctx || !alpha || B <= 0 || n <= 0 || K <= 0 || A <= 0 || R <= 0)
+        return CAPMI_EINVAL;
+    const size_t lds = ((size_t)NMAX * A + (size_t)NMAX * K) * sizeof(float);
+    if (lds > 64 * 1024) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(B, (n + NMAX - 1) / NMAX), dim3(ATT_THREADS), lds, (hipStream_t)stream, att_h, p_att, att, mask,
+                       w, b, ctx, alpha, n, K, A, R);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_attention_bwd(const float *d_ctx, int ld_dctx, const float *att_h, const float *alpha, const float *p_att,
+                        const float *att, const float *mask, const float *w, float *d_att_h, float *d_e, int B, int n,
+                        int K, int A, int R, void *stream) {
+    (void)mask;   // the masked renorm folds into the same Jacobian (see kernel comment)
+    if (!d_ctx || !att_h || !alpha || !p_att || !att || !w || !d_att_h || !d_e || B <= 0 || n <= 0 || ld_dctx < R)
+        return CAPMI_EINVAL;
+    const size_t lds = ((size_t)NMAX * R + (size_t)NMAX * K) * sizeof(float);
+    if (lds > 64 * 1024) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3(B, (n + NMAX - 1) / NMAX), dim3(ATT_THREADS), lds, (hipStream_t)stream, d_ctx, ld_dctx, att_h, alpha,
+                       p_att, att, w, d_att_h, d_e, n, K, A, R);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_attention_bwd_batched(const float *d_ctx_all, int ld_dctx, const float *att_h_all, const float *alpha_all,
+                                const float *d_e_all, const float *p_att, const float *w, float *d_att,
+                                float *d_p_att, float *d_w, float *d_b, int T, int B, int n, int K, int A, int R,
+                                void *stream) {
+    if (!d_ctx_all || !att_h_all || !alpha_all || !d_e_all || !p_att || !w || !d_att || !d_p_att || !d_w || !d_b)
+        return CAPMI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = B * n;
+    hipLaunchKernelGGL(attn_datt_kernel, dim3(B, (R + 255) / 256), dim3(256), 0, st, d_ctx_all, ld_dctx, alpha_all, d_att, T, N, n,
+                       K, R);
+    CAPMI_CHECK_LAUNCH();
+    hipError_t e = hipMemsetAsync(d_w, 0, (size_t)A * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(attn_dpatt_kernel, dim3(B * K), dim3(A >= 512 ? 512 : 256), 0, st, att_h_all, d_e_all, p_att, w,
+                       d_p_att, d_w, T, N, n, K, A);
+    CAPMI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(1024), 0, st, d_e_all, (size_t)T * N * K, d_b);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+// Device-side helpers shared by the gfx950 kernels of libcapmi.  CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CAPMI_WAVE 64
+
+#define CAPMI_CHECK_LAUNCH()                      \
+    do {                                          \
+        hipError_t e__ = hipGetLastError();       \
+        if (e__ != hipSuccess) return (int)e__;   \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace capmi {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide reductions through a small LDS scratch (>= 32 floats); all threads get the result
+__device__ __forceinline__ float block_sum(float v, float *scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float *scratch) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    float r = scratch[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, scratch[i]);
+    return r;
+}
+
+// tanh / sigmoid with ~1 ulp-class building blocks (v_exp_f32 + IEEE divide).  Absolute error
+// ~1e-7, far inside the 1e-4 parity budget and below fp32 accumulation-order noise of the GEMMs.
+__device__ __forceinline__ float tanh_f(float x) {
+    const float ax = fabsf(x);
+    const float e = __expf(-2.0f * ax);           // in (0,1]
+    const float t = (1.0f - e) / (1.0f + e);
+    return copysignf(t, x);
+}
+__device__ __forceinline__ float sigmoid_f(float x) {
+    // stable for both signs: 1/(1+exp(-x))
+    const float e = __expf(-fabsf(x));
+    const float s = 1.0f / (1.0f + e);            // sigmoid(|x|)
+    return x >= 0.f ? s : 1.0f - s;
+}
+
+// Philox4x32-10 counter RNG (Salmon et al. 2011) -- in-kernel dropout masks and Gumbel noise.
+struct Philox {
+    uint32_t k0, k1;
+    __device__ __forceinline__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+    __device__ __forceinline__ static void round(uint32_t (&c)[4], uint32_t a, uint32_t b) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ a;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ b;
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+    __device__ __forceinline__ void gen(uint64_t ctr_lo, uint64_t ctr_hi, uint32_t (&out)[4]) const {
+        uint32_t c[4] = {(uint32_t)ctr_lo, (uint32_t)(ctr_lo >> 32), (uint32_t)ctr_hi, (uint32_t)(ctr_hi >> 32)};
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            round(c, a, b);
+            a += 0x9E3779B9u;
+            b += 0xBB67AE85u;
+        }
+        out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+    }
+};
+// uniform in (0,1): never 0 so log() is finite
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+}  // namespace capmi

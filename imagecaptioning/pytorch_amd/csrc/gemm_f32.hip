@@ -1,0 +1,353 @@
+// fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bit-equal to an fmaf
+// chain -- the only matrix path on CDNA4 that keeps the reference's fp32 numerics; there is no
+// xf32/TF32).  Replaces the addmm/mm behind nn.Linear / nn.LSTMCell and their backward on the
+// caption-decoding hot path (see include/capmi.h for the reference call sites).
+//
+// Design (MI355X-first, not a CUDA tiling):
+//  * 256-thread workgroups = 4 wave64s; each wave owns a (TM x TN) grid of 32x32 MFMA tiles.
+//  * operands are staged k-major in LDS (As[k][m], Bs[k][n]) so that an MFMA operand fetch is one
+//    conflict-free ds_read_b32 of 32 consecutive floats per half-wave (lane l reads k = l>>5,
+//    m = l&31): no swizzle needed, any leading dimension.
+//  * K-contiguous sources (activations [M][K], nn.Linear weights [N][K]) are read from HBM as full
+//    128-byte lines (8 lanes x 16 B per row) and transposed on the LDS write (row pitch BM+1 makes
+//    the 4 scattered ds_write_b32 conflict-free); M/N-contiguous sources ([K][M] for dY^T, [K][N]
+//    for W in dX = dY W) are written with ds_write_b128 (pitch BM+4).
+//  * register prefetch of tile t+1 is in flight while tile t runs on the matrix pipe.
+//  * the decode GEMMs are skinny (M = 10..64 rows against 12-38 MB of weights), i.e. HBM-bound
+//    weight streaming: split-K spreads one weight matrix over >= 2 workgroups per CU; partial sums
+//    go to a workspace that the *consumer* kernel (LSTM cell, bias/ReLU epilogue) reduces, so the
+//    gate pre-activations never make a round trip of their own.
+//  * multi-segment K loop: [h_lang | xt | h_att] x [W_ih slices | W_hh] are walked in place -- the
+//    reference's torch.cat (AttModel.py:626,632) and repeat_tensors (a_row_div) copies disappear.
+#include "capmi_common.h"
+#include "../../../include/capmi.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NT = 256;
+
+struct Seg {
+    const float *A, *B;
+    int lda, ldb, K, a_row_div;
+    int vecA, vecB;   // 16-byte vector loads legal for this segment
+};
+
+struct KArgs {
+    Seg seg[CAPMI_MAX_SEG];
+    int nseg;
+    int M, N;
+    float *C;
+    int ldc;
+    const float *bias, *bias2, *row_bias;
+    int row_bias_div;
+    const float *mul_mask;
+    int relu, accumulate;
+    float *partial;
+    int splits;
+    int to_partial;      // write raw K-slice sums to `partial` (split-K and/or fused consumer)
+    int tiles_total;     // sum over segments of ceil(K/BK)
+};
+
+// ---- global -> registers ---------------------------------------------------------------------
+// KC = true : source stored [rows][K] (K contiguous).  thread -> (row, 4 consecutive k)
+// KC = false: source stored [K][rows] (rows contiguous). thread -> (k, 4 consecutive rows)
+template <int ROWS, bool KC>
+__device__ __forceinline__ void g2r(f32x4 (&r)[ROWS * BK / 4 / NT], const float *__restrict__ src, int ld,
+                                    int row0, int nrows, int k0, int K, int row_div, int vec) {
+    constexpr int NV = ROWS * BK / 4 / NT;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+        const int idx = p * NT + threadIdx.x;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (KC) {
+            const int rr = idx / (BK / 4);
+            const int kq = (idx % (BK / 4)) * 4;
+            const int row = row0 + rr;
+            const int k = k0 + kq;
+            if (row < nrows && k < K) {
+                const float *ptr = src + (size_t)(row / row_div) * ld + k;
+                if (vec && k + 3 < K) {
+                    v = *reinterpret_cast<const f32x4 *>(ptr);
+                } else {
+                    v[0] = ptr[0];
+                    if (k + 1 < K) v[1] = ptr[1];
+                    if (k + 2 < K) v[2] = ptr[2];
+                    if (k + 3 < K) v[3] = ptr[3];
+                }
+            }
+        } else {
+            const int kk = idx / (ROWS / 4);
+            const int mq = (idx % (ROWS / 4)) * 4;
+            const int k = k0 + kk;
+            const int row = row0 + mq;
+            if (k < K && row < nrows) {
+                const float *ptr = src + (size_t)k * ld + row;
+                if (vec && row + 3 < nrows) {
+                    v = *reinterpret_cast<const f32x4 *>(ptr);
+                } else {
+                    v[0] = ptr[0];
+                    if (row + 1 < nrows) v[1] = ptr[1];
+                    if (row + 2 < nrows) v[2] = ptr[2];
+                    if (row + 3 < nrows) v[3] = ptr[3];
+                }
+            }
+        }
+        r[p] = v;
+    }
+}
+
+template <int ROWS, bool KC>
+struct Pitch {
+    static constexpr int value = KC ? ROWS + 1 : ROWS + 4;
+};
+
+template <int ROWS, bool KC>
+__device__ __forceinline__ void r2s(const f32x4 (&r)[ROWS * BK / 4 / NT], float *dst) {
+    constexpr int NV = ROWS * BK / 4 / NT;
+    constexpr int LD = Pitch<ROWS, KC>::value;
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+        const int idx = p * NT + threadIdx.x;
+        if (KC) {
+            const int rr = idx / (BK / 4);
+            const int kq = (idx % (BK / 4)) * 4;
+            dst[(kq + 0) * LD + rr] = r[p][0];
+            dst[(kq + 1) * LD + rr] = r[p][1];
+            dst[(kq + 2) * LD + rr] = r[p][2];
+            dst[(kq + 3) * LD + rr] = r[p][3];
+        } else {
+            const int kk = idx / (ROWS / 4);
+            const int mq = (idx % (ROWS / 4)) * 4;
+            *reinterpret_cast<f32x4 *>(dst + kk * LD + mq) = r[p];
+        }
+    }
+}
+
+// flat K-tile index -> (segment, k0)
+__device__ __forceinline__ void locate(const KArgs &a, int tile, int &s, int &k0) {
+    s = 0;
+    int t = tile;
+#pragma unroll
+    for (int i = 0; i < CAPMI_MAX_SEG; ++i) {
+        if (i < a.nseg - 1 && s == i) {
+            const int nt = (a.seg[i].K + BK - 1) / BK;
+            if (t >= nt) {
+                t -= nt;
+                s = i + 1;
+            }
+        }
+    }
+    k0 = t * BK;
+}
+
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
+__global__ __launch_bounds__(NT) void gemm_kernel(const KArgs a) {
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    constexpr int LDA = Pitch<BM, AKC>::value;
+    constexpr int LDB = Pitch<BN, BKC>::value;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
+    float *As = smem;
+    float *Bs = smem + BK * LDA;
+
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int z = blockIdx.z;
+    // contiguous, balanced range of flat K tiles for this split
+    const int t_begin = (int)(((long long)a.tiles_total * z) / a.splits);
+    const int t_end = (int)(((long long)a.tiles_total * (z + 1)) / a.splits);
+
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    const int wm0 = (wid / WN) * (TM * 32);
+    const int wn0 = (wid % WN) * (TN * 32);
+    const int l31 = lane & 31;
+    const int khalf = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[BM * BK / 4 / NT];
+    f32x4 rb[BN * BK / 4 / NT];
+
+    if (t_begin < t_end) {
+        int s, k0;
+        locate(a, t_begin, s, k0);
+        g2r<BM, AKC>(ra, a.seg[s].A, a.seg[s].lda, m0, a.M, k0, a.seg[s].K, AKC ? a.seg[s].a_row_div : 1, a.seg[s].vecA);
+        g2r<BN, BKC>(rb, a.seg[s].B, a.seg[s].ldb, n0, a.N, k0, a.seg[s].K, 1, a.seg[s].vecB);
+    }
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();   // previous tile fully consumed
+        r2s<BM, AKC>(ra, As);
+        r2s<BN, BKC>(rb, Bs);
+        __syncthreads();
+        if (t + 1 < t_end) {
+            int s, k0;
+            locate(a, t + 1, s, k0);
+            g2r<BM, AKC>(ra, a.seg[s].A, a.seg[s].lda, m0, a.M, k0, a.seg[s].K, AKC ? a.seg[s].a_row_div : 1, a.seg[s].vecA);
+            g2r<BN, BKC>(rb, a.seg[s].B, a.seg[s].ldb, n0, a.N, k0, a.seg[s].K, 1, a.seg[s].vecB);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int krow = 2 * kk + khalf;
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = As[krow * LDA + wm0 + 32 * i + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = Bs[krow * LDB + wn0 + 32 * j + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const bool to_partial = a.to_partial != 0;
+    float *out = to_partial ? a.partial + (size_t)z * a.M * a.N : a.C;
+    const int ldo = to_partial ? a.N : a.ldc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn0 + 32 * j + l31;
+            if (col >= a.N) continue;
+            float cb = 0.f;
+            if (!to_partial) {
+                if (a.bias) cb += a.bias[col];
+                if (a.bias2) cb += a.bias2[col];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (row >= a.M) continue;
+                float v = acc[i][j][r];
+                if (!to_partial) {
+                    v += cb;
+                    if (a.row_bias) v += a.row_bias[(size_t)(row / a.row_bias_div) * a.N + col];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (a.mul_mask) v *= a.mul_mask[(size_t)row * a.N + col];
+                    if (a.accumulate) v += out[(size_t)row * ldo + col];
+                }
+                out[(size_t)row * ldo + col] = v;
+            }
+        }
+    }
+}
+
+__global__ void splitk_reduce_kernel(const float *__restrict__ partial, int splits, float *__restrict__ C, int ldc,
+                                     int M, int N, const float *bias, const float *bias2, const float *row_bias,
+                                     int row_bias_div, const float *mul_mask, int relu, int accumulate) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / N), col = (int)(i % N);
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += partial[(size_t)s * total + i];
+        if (bias) v += bias[col];
+        if (bias2) v += bias2[col];
+        if (row_bias) v += row_bias[(size_t)(row / row_bias_div) * N + col];
+        if (relu) v = fmaxf(v, 0.f);
+        if (mul_mask) v *= mul_mask[i];
+        float *o = C + (size_t)row * ldc + col;
+        if (accumulate) v += *o;
+        *o = v;
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const KArgs &a, int al, int bl, dim3 grid, hipStream_t st) {
+    if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true>), grid, dim3(NT), 0, st, a);
+    else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false>), grid, dim3(NT), 0, st, a);
+    else if (al == 1 && bl == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false>), grid, dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true>), grid, dim3(NT), 0, st, a);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int capmi_splitk_reduce(const float *partial, int splits, float *C, int ldc, int M, int N,
+                                   const float *bias, const float *bias2, const float *row_bias, int row_bias_div,
+                                   const float *mul_mask, int relu, int accumulate, void *stream) {
+    if (!partial || !C || splits < 1 || M <= 0 || N <= 0) return CAPMI_EINVAL;
+    const size_t total = (size_t)M * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, splits, C, ldc, M,
+                       N, bias, bias2, row_bias, row_bias_div > 0 ? row_bias_div : 1, mul_mask, relu, accumulate);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
+    if (!d || d->nseg < 1 || d->nseg > CAPMI_MAX_SEG || d->M <= 0 || d->N <= 0 || !d->C) return CAPMI_EINVAL;
+    if (d->a_layout < 0 || d->a_layout > 1 || d->b_layout < 0 || d->b_layout > 1) return CAPMI_EINVAL;
+    KArgs a{};
+    a.nseg = d->nseg;
+    int tiles = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        const capmi_gemm_seg &g = d->seg[s];
+        if (!g.A || !g.B || g.K <= 0) return CAPMI_EINVAL;
+        Seg &o = a.seg[s];
+        o.A = g.A; o.B = g.B; o.lda = g.lda; o.ldb = g.ldb; o.K = g.K;
+        o.a_row_div = g.a_row_div > 0 ? g.a_row_div : 1;
+        if (d->a_layout == 1 && o.a_row_div != 1) return CAPMI_EINVAL;
+        o.vecA = aligned16(g.A) && (g.lda % 4 == 0);
+        o.vecB = aligned16(g.B) && (g.ldb % 4 == 0);
+        tiles += (g.K + BK - 1) / BK;
+    }
+    a.tiles_total = tiles;
+    a.M = d->M; a.N = d->N; a.C = d->C; a.ldc = d->ldc;
+    a.bias = d->bias; a.bias2 = d->bias2; a.row_bias = d->row_bias;
+    a.row_bias_div = d->row_bias_div > 0 ? d->row_bias_div : 1;
+    a.mul_mask = d->mul_mask; a.relu = d->relu; a.accumulate = d->accumulate;
+    a.partial = d->partial;
+
+    // tile shape by M: decode batches are skinny.
+    int BM, BN;
+    if (d->M <= 32) { BM = 32; BN = 128; }
+    else if (d->M <= 64) { BM = 64; BN = 64; }
+    else if ((long long)d->M * d->N < 128LL * 128 * 192) { BM = 64; BN = 64; }
+    else { BM = 128; BN = 128; }
+    const int gm = (d->M + BM - 1) / BM, gn = (d->N + BN - 1) / BN;
+    int splits = d->splits;
+    if (splits == 0) {
+        // aim for ~2 workgroups per CU (512) but keep >= 4 K tiles per slice
+        const int blocks = gm * gn;
+        splits = 1;
+        if (blocks < 384 && d->partial) {
+            splits = (512 + blocks - 1) / blocks;
+            if (splits > tiles / 4) splits = tiles / 4;
+            if (splits > 32) splits = 32;
+            if (splits < 1) splits = 1;
+            while (splits > 1 && (int64_t)splits * d->M * d->N > d->partial_capacity) --splits;
+        }
+    }
+    if (splits > tiles) splits = tiles;
+    if (splits > 1 && (!d->partial || (int64_t)splits * d->M * d->N > d->partial_capacity)) return CAPMI_EINVAL;
+    a.splits = splits;
+    a.to_partial = (splits > 1 || d->defer_reduce) ? 1 : 0;
+    if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > d->partial_capacity)) return CAPMI_EINVAL;
+    d->splits_used = splits;
+    dim3 grid(gn, gm, splits);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (BM == 32) rc = launch_cfg<32, 128, 1, 4>(a, d->a_layout, d->b_layout, grid, st);
+    else if (BM == 64) rc = launch_cfg<64, 64, 2, 2>(a, d->a_layout, d->b_layout, grid, st);
+    else rc = launch_cfg<128, 128, 2, 2>(a, d->a_layout, d->b_layout, grid, st);
+    if (rc) return rc;
+    if (splits > 1 && !d->defer_reduce)
+        return capmi_splitk_reduce(d->partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,
+                                   a.row_bias_div, d->mul_mask, d->relu, d->accumulate, stream);
+    return 0;
+}

@@ -1,0 +1,315 @@
+// Elementwise / small-reduction kernels of the decode step for gfx950: token embedding, the LSTM
+// cell pointwise stage (fused with the split-K reduction of the gate GEMM), their backward,
+// dropout-mask generation, column sums and the fused clip+Adam update.  All are HBM/latency bound:
+// 16-byte accesses where the layout allows, grid-stride loops capped at 2048 workgroups.
+#include "capmi_common.h"
+#include "../../../include/capmi.h"
+
+using namespace capmi;
+
+namespace {
+
+inline int grid_for(size_t work, int per_block = 256, int cap = 2048) {
+    size_t b = (work + per_block - 1) / per_block;
+    if (b > (size_t)cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------- embedding
+__global__ void embed_fwd_kernel(const int64_t *__restrict__ it, int it_stride, int64_t *__restrict__ it_save,
+                                 const float *__restrict__ E, const float *__restrict__ mask, float *__restrict__ x,
+                                 int N, int Ed, int relu) {
+    const size_t total = (size_t)N * Ed;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / Ed), c = (int)(i % Ed);
+        const int64_t tok = it[(size_t)r * it_stride];
+        if (it_save && c == 0) it_save[r] = tok;
+        float v = E[(size_t)tok * Ed + c];
+        if (relu) v = fmaxf(v, 0.f);
+        if (mask) v *= mask[i];
+        x[i] = v;
+    }
+}
+
+__global__ void embed_bwd_kernel(const int64_t *__restrict__ it, const float *__restrict__ dx,
+                                 const float *__restrict__ x_saved, const float *__restrict__ mask,
+                                 float *__restrict__ dE, int rows, int Ed, int relu) {
+    const size_t total = (size_t)rows * Ed;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / Ed), c = (int)(i % Ed);
+        float g = dx[i];
+        if (mask) g *= mask[i];
+        if (relu && !(x_saved[i] > 0.f)) {
+            // x_saved = relu(E)*mask: zero either because relu clipped or the unit was dropped; in
+            // both cases the gradient is zero (dropped units already have g*mask == 0).
+            g = 0.f;
+        }
+        if (g != 0.f) atomicAdd(&dE[(size_t)it[r] * Ed + c], g);
+    }
+}
+
+// ---------------------------------------------------------------- LSTM cell
+__global__ void lstm_cell_fwd_kernel(const float *__restrict__ partial, int splits, const float *__restrict__ b_ih,
+                                     const float *__restrict__ b_hh, const float *__restrict__ row_bias,
+                                     int row_bias_div, const float *__restrict__ c_prev, float *__restrict__ h,
+                                     float *__restrict__ c, float *__restrict__ gates_act,
+                                     const float *__restrict__ out_mask, float *__restrict__ h_drop, int N, int R) {
+    const size_t total = (size_t)N * R;
+    const size_t slab = (size_t)N * 4 * R;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / R), j = (int)(i % R);
+        float g[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t col = (size_t)q * R + j;
+            float v = 0.f;
+            for (int s = 0; s < splits; ++s) v += partial[s * slab + (size_t)r * 4 * R + col];
+            if (b_ih) v += b_ih[col];
+            if (b_hh) v += b_hh[col];
+            if (row_bias) v += row_bias[(size_t)(r / row_bias_div) * 4 * R + col];
+            g[q] = v;
+        }
+        const float ig = sigmoid_f(g[0]), fg = sigmoid_f(g[1]), gg = tanh_f(g[2]), og = sigmoid_f(g[3]);
+        const float cn = fg * c_prev[i] + ig * gg;
+        const float hn = og * tanh_f(cn);
+        c[i] = cn;
+        h[i] = hn;
+        if (gates_act) {
+            float *ga = gates_act + (size_t)r * 4 * R + j;
+            ga[0] = ig; ga[R] = fg; ga[2 * R] = gg; ga[3 * (size_t)R] = og;
+        }
+        if (h_drop) h_drop[i] = out_mask ? hn * out_mask[i] : hn;
+    }
+}
+
+__global__ void lstm_cell_bwd_kernel(const float *__restrict__ dh_a, int ld_a, const float *__restrict__ dh_a_mask,
+                                     const float *__restrict__ dh_b, int ld_b, const float *__restrict__ dh_c, int ld_c,
+                                     const float *__restrict__ dc_next, const float *__restrict__ gates_act,
+                                     const float *__restrict__ c_prev, const float *__restrict__ c_new,
+                                     float *__restrict__ d_gates, float *__restrict__ dc_prev, int N, int R) {
+    const size_t total = (size_t)N * R;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / R), j = (int)(i % R);
+        float dh = 0.f;
+        if (dh_a) {
+            const float v = dh_a[(size_t)r * ld_a + j];
+            dh += dh_a_mask ? v * dh_a_mask[i] : v;
+        }
+        if (dh_b) dh += dh_b[(size_t)r * ld_b + j];
+        if (dh_c) dh += dh_c[(size_t)r * ld_c + j];
+        const float *ga = gates_act + (size_t)r * 4 * R + j;
+        const float ig = ga[0], fg = ga[R], gg = ga[2 * R], og = ga[3 * (size_t)R];
+        const float tc = tanh_f(c_new[i]);
+        float dc = dh * og * (1.f - tc * tc);
+        if (dc_next) dc += dc_next[i];
+        float *dg = d_gates + (size_t)r * 4 * R + j;
+        dg[0] = dc * gg * ig * (1.f - ig);
+        dg[R] = dc * c_prev[i] * fg * (1.f - fg);
+        dg[2 * R] = dc * ig * (1.f - gg * gg);
+        dg[3 * (size_t)R] = dh * tc * og * (1.f - og);
+        dc_prev[i] = dc * fg;
+    }
+}
+
+// ---------------------------------------------------------------- misc
+__global__ void dropout_mask_kernel(float *__restrict__ mask, size_t count, float p, uint64_t seed, uint64_t offset) {
+    const Philox rng(seed);
+    const float scale = 1.f / (1.f - p);
+    const size_t quads = (count + 3) / 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (size_t)gridDim.x * blockDim.x) {
+        uint32_t o[4];
+        rng.gen(offset + q, 0x6d61736bULL /* "mask" stream */, o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t i = q * 4 + k;
+            if (i < count) mask[i] = (u01(o[k]) < p) ? 0.f : scale;
+        }
+    }
+}
+
+__global__ void colsum_kernel(const float *__restrict__ in, int rows, int cols, int ld, float *__restrict__ out,
+                              int accumulate) {
+    // one thread per column, 8 row-slices per block reduced through LDS: coalesced along columns
+    __shared__ float red[8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;   // 32 x 8
+    const int col = blockIdx.x * 32 + cx;
+    float s = 0.f;
+    if (col < cols)
+        for (int r = ry; r < rows; r += 8) s += in[(size_t)r * ld + col];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && col < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cx];
+        out[col] = accumulate ? out[col] + t : t;
+    }
+}
+
+__global__ void group_rowsum_kernel(const float *__restrict__ in, int T, size_t slab, int groups, int group, int cols,
+                                    float *__restrict__ out) {
+    const size_t total = (size_t)groups * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i / cols), c = (int)(i % cols);
+        float s = 0.f;
+        for (int t = 0; t < T; ++t)
+            for (int j = 0; j < group; ++j) s += in[t * slab + (size_t)(g * group + j) * cols + c];
+        out[i] = s;
+    }
+}
+
+__global__ void relu_mask_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y_ref,
+                                     const float *__restrict__ mask, float *__restrict__ dx, size_t count) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        float g = dy[i];
+        if (mask) g *= mask[i];
+        if (y_ref && !(y_ref[i] > 0.f)) g = 0.f;
+        dx[i] = g;
+    }
+}
+
+__global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                            float *__restrict__ v, size_t count, float lr, float b1, float b2, float eps, float wd,
+                            float clip, float gscale, float bc1, float bc2_sqrt) {
+    // torch.optim.Adam (non-amsgrad): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+    // p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+    const size_t quads = count / 4;
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g);
+    f32x4 *p4 = reinterpret_cast<f32x4 *>(p), *m4 = reinterpret_cast<f32x4 *>(m), *v4 = reinterpret_cast<f32x4 *>(v);
+    const float step_size = lr / bc1;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (size_t)gridDim.x * blockDim.x) {
+        f32x4 gg = g4[q], pp = p4[q], mm = m4[q], vv = v4[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float x = gg[k] * gscale;
+            if (clip > 0.f) x = fminf(fmaxf(x, -clip), clip);
+            if (wd != 0.f) x += wd * pp[k];
+            mm[k] = b1 * mm[k] + (1.f - b1) * x;
+            vv[k] = b2 * vv[k] + (1.f - b2) * x * x;
+            pp[k] -= step_size * mm[k] / (sqrtf(vv[k]) / bc2_sqrt + eps);
+        }
+        p4[q] = pp; m4[q] = mm; v4[q] = vv;
+    }
+    // tail
+    const size_t base = quads * 4;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < count - base) {
+        const size_t i = base + tid;
+        float x = g[i] * gscale;
+        if (clip > 0.f) x = fminf(fmaxf(x, -clip), clip);
+        if (wd != 0.f) x += wd * p[i];
+        const float mi = b1 * m[i] + (1.f - b1) * x;
+        const float vi = b2 * v[i] + (1.f - b2) * x * x;
+        m[i] = mi; v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+__global__ void scst_advantage_kernel(const double *__restrict__ scores, int N, int n, float *__restrict__ reward) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < N) reward[r] = (float)(scores[r] - scores[N + r / n]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int capmi_embed_fwd(const int64_t *it, int it_stride, int64_t *it_save, const float *E, const float *mask, float *x,
+                    int N, int Edim, int relu, void *stream) {
+    if (!it || !E || !x || N <= 0 || Edim <= 0 || it_stride < 1) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((size_t)N * Edim)), dim3(256), 0, (hipStream_t)stream, it,
+                       it_stride, it_save, E, mask, x, N, Edim, relu);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_embed_bwd(const int64_t *it, const float *dx, const float *x_saved, const float *mask, float *dE, int rows,
+                    int Edim, int relu, void *stream) {
+    if (!it || !dx || !dE || rows <= 0 || Edim <= 0 || (relu && !x_saved)) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((size_t)rows * Edim)), dim3(256), 0, (hipStream_t)stream, it, dx,
+                       x_saved, mask, dE, rows, Edim, relu);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_lstm_cell_fwd(const float *partial, int splits, const float *b_ih, const float *b_hh, const float *row_bias,
+                        int row_bias_div, const float *c_prev, float *h, float *c, float *gates_act,
+                        const float *out_mask, float *h_drop, int N, int R, void *stream) {
+    if (!partial || splits < 1 || !c_prev || !h || !c || N <= 0 || R <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid_for((size_t)N * R)), dim3(256), 0, (hipStream_t)stream, partial,
+                       splits, b_ih, b_hh, row_bias, row_bias_div > 0 ? row_bias_div : 1, c_prev, h, c, gates_act,
+                       out_mask, h_drop, N, R);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_lstm_cell_bwd(const float *dh_a, int ld_a, const float *dh_a_mask, const float *dh_b, int ld_b,
+                        const float *dh_c, int ld_c, const float *dc_next, const float *gates_act,
+                        const float *c_prev, const float *c_new, float *d_gates, float *dc_prev, int N, int R,
+                        void *stream) {
+    if (!gates_act || !c_prev || !c_new || !d_gates || !dc_prev || N <= 0 || R <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for((size_t)N * R)), dim3(256), 0, (hipStream_t)stream, dh_a,
+                       ld_a, dh_a_mask, dh_b, ld_b, dh_c, ld_c, dc_next, gates_act, c_prev, c_new, d_gates, dc_prev, N, R);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_dropout_mask(float *mask, int64_t count, float p, uint64_t seed, uint64_t offset, void *stream) {
+    if (!mask || count <= 0 || p < 0.f || p >= 1.f) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((size_t)(count + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       mask, (size_t)count, p, seed, offset);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_colsum(const float *in, int rows, int cols, int ld, float *out, int accumulate, void *stream) {
+    if (!in || !out || rows <= 0 || cols <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 31) / 32), dim3(256), 0, (hipStream_t)stream, in, rows, cols, ld, out,
+                       accumulate);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_group_rowsum(const float *in, int T, int64_t slab, int groups, int group, int cols, float *out,
+                       void *stream) {
+    if (!in || !out || T <= 0 || groups <= 0 || group <= 0 || cols <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(group_rowsum_kernel, dim3(grid_for((size_t)groups * cols)), dim3(256), 0, (hipStream_t)stream, in,
+                       T, (size_t)slab, groups, group, cols, out);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_relu_mask_bwd(const float *dy, const float *y_ref, const float *mask, float *dx, int64_t count,
+                        void *stream) {
+    if (!dy || !dx || count <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, (hipStream_t)stream, dy, y_ref,
+                       mask, dx, (size_t)count);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_adam_step(float *p, const float *g, float *m, float *v, int64_t count, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, float clip, float grad_scale, int step, void *stream) {
+    if (!p || !g || !m || !v || count <= 0 || step < 1) return CAPMI_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+         reinterpret_cast<uintptr_t>(v)) & 15)
+        return CAPMI_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)count / 4 + 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                       (size_t)count, lr, beta1, beta2, eps, weight_decay, clip, grad_scale, (float)bc1,
+                       (float)sqrt(bc2));
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_scst_advantage(const double *scores, int N, int n, float *reward, void *stream) {
+    if (!scores || !reward || N <= 0 || n <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(scst_advantage_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, scores, N, n,
+                       reward);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

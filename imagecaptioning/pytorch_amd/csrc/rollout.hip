@@ -1,0 +1,267 @@
+// Host-side drivers that enqueue a whole UpDown rollout (all T decoder steps, forward or BPTT) on one
+// HIP stream with no host synchronisation.  This is the native replacement of the Python time loops
+// AttModel._sample (AttModel.py:288-350) / AttModel._forward (:144-162) + UpDownCore.forward
+// (:624-640) and of the autograd graph torch would record for them.
+//
+// MI355X-first structure:
+//  * per step the recurrent GEMMs read [h_lang | xt | h_att] and [ctx | h_att | h_lang] in place as
+//    K segments (no torch.cat), image-shared tensors are indexed row/n (no repeat_tensors);
+//  * the fc-feature term of the attention LSTM is constant over time: it is one [B,4R] GEMM per
+//    rollout, added in the LSTM-cell epilogue;
+//  * everything that is not on the recurrent critical path of BPTT is TIME-BATCHED into fat MFMA
+//    GEMMs over all T*N rows after the loop: every weight gradient, the embedding gradient, the
+//    logit layer (forward-saved activations are stored time-major [T,N,...] for exactly this);
+//    only the 4 skinny "dX" GEMMs + the pointwise cells + the attention Jacobian stay in the loop.
+#include "capmi_common.h"
+#include "../../../include/capmi.h"
+
+namespace {
+
+#define RC(x)                 \
+    do {                      \
+        int rc__ = (x);       \
+        if (rc__) return rc__;\
+    } while (0)
+
+struct SegSpec {
+    const float *A;
+    int lda;
+    const float *B;
+    int ldb;
+    int K;
+    int a_row_div;
+};
+
+// C[M,N] = sum_s A_s op B_s ; thin wrapper filling capmi_gemm_desc
+int gemm(void *stream, int a_layout, int b_layout, int M, int N, float *C, int ldc, const SegSpec *segs, int nseg,
+         float *partial, int64_t cap, int defer, int *splits_used, const float *bias = nullptr,
+         const float *bias2 = nullptr, int accumulate = 0) {
+    capmi_gemm_desc d{};
+    d.nseg = nseg;
+    for (int i = 0; i < nseg; ++i) {
+        d.seg[i].A = segs[i].A; d.seg[i].lda = segs[i].lda;
+        d.seg[i].B = segs[i].B; d.seg[i].ldb = segs[i].ldb;
+        d.seg[i].K = segs[i].K; d.seg[i].a_row_div = segs[i].a_row_div > 0 ? segs[i].a_row_div : 1;
+    }
+    d.a_layout = a_layout; d.b_layout = b_layout;
+    d.M = M; d.N = N; d.C = C; d.ldc = ldc;
+    d.bias = bias; d.bias2 = bias2;
+    d.accumulate = accumulate;
+    d.partial = partial; d.partial_capacity = cap;
+    d.splits = 0; d.defer_reduce = defer;
+    const int rc = capmi_gemm_f32(&d, stream);
+    if (splits_used) *splits_used = d.splits_used;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int capmi_version(void) { return 1; }
+const char *capmi_arch(void) { return "gfx950"; }
+
+int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout *r, void *stream) {
+    if (!w || !r) return CAPMI_EINVAL;
+    const int B = r->B, n = r->n, N = r->N, K = r->K, A = r->A, R = r->R, E = r->E, V1 = r->V1, T = r->T, L = r->L;
+    if (B <= 0 || n <= 0 || N != B * n || T <= 0 || L < T || !r->partial) return CAPMI_EINVAL;
+    if ((r->mode == 2 || r->teacher) && !r->forced) return CAPMI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t NR = (size_t)N * R;
+    const int ld_att_ih = 2 * R + E;
+
+    // initial state (slot 0) and flags
+    hipError_t e;
+    if ((e = hipMemsetAsync(r->h_att, 0, NR * sizeof(float), st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(r->c_att, 0, NR * sizeof(float), st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(r->h_lang, 0, NR * sizeof(float), st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(r->c_lang, 0, NR * sizeof(float), st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(r->it, 0, (size_t)N * sizeof(int64_t), st)) != hipSuccess) return (int)e;   // bos = 0
+    if ((e = hipMemsetAsync(r->unfinished, 1, (size_t)N, st)) != hipSuccess) return (int)e;
+
+    // fc term of the attention LSTM, once: fc_gates[B,4R] = fc W_ih[:, R:2R]^T
+    {
+        SegSpec s{r->fc, R, w->att_w_ih + R, ld_att_ih, R, 1};
+        RC(gemm(stream, 0, 0, B, 4 * R, r->fc_gates, 4 * R, &s, 1, r->partial, r->partial_capacity, 0, nullptr));
+    }
+
+    for (int t = 0; t < T; ++t) {
+        float *xt = r->xt + (size_t)t * N * E;
+        const float *h_att_prev = r->h_att + (size_t)t * NR, *c_att_prev = r->c_att + (size_t)t * NR;
+        const float *h_lang_prev = r->h_lang + (size_t)t * NR, *c_lang_prev = r->c_lang + (size_t)t * NR;
+        float *h_att = r->h_att + (size_t)(t + 1) * NR, *c_att = r->c_att + (size_t)(t + 1) * NR;
+        float *h_lang = r->h_lang + (size_t)(t + 1) * NR, *c_lang = r->c_lang + (size_t)(t + 1) * NR;
+        float *att_h = r->att_h + (size_t)t * N * A;
+        float *alpha = r->alpha + (size_t)t * N * K;
+        float *ctx = r->ctx + (size_t)t * NR;
+        float *h_drop = r->h_drop + (size_t)t * NR;
+        int splits = 1;
+
+        // 1. token embedding (+ReLU +dropout)
+        if (r->teacher)
+            RC(capmi_embed_fwd(r->forced + t, r->forced_ld, r->it_all ? r->it_all + (size_t)t * N : nullptr, w->embed,
+                               r->drop_xt ? r->drop_xt + (size_t)t * N * E : nullptr, xt, N, E, 1, stream));
+        else
+            RC(capmi_embed_fwd(r->it, 1, r->it_all ? r->it_all + (size_t)t * N : nullptr, w->embed,
+                               r->drop_xt ? r->drop_xt + (size_t)t * N * E : nullptr, xt, N, E, 1, stream));
+
+        // 2-3. attention LSTM: gates = [h_lang_prev | xt | h_att_prev] . [W_ih(:, 0:R) | W_ih(:, 2R:) | W_hh]
+        {
+            SegSpec s[3] = {{h_lang_prev, R, w->att_w_ih, ld_att_ih, R, 1},
+                            {xt, E, w->att_w_ih + 2 * R, ld_att_ih, E, 1},
+                            {h_att_prev, R, w->att_w_hh, R, R, 1}};
+            RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s, 3, r->partial, r->partial_capacity, 1, &splits));
+            RC(capmi_lstm_cell_fwd(r->partial, splits, w->att_b_ih, w->att_b_hh, r->fc_gates, n, c_att_prev, h_att, c_att,
+                                   r->gates_att + (size_t)t * N * 4 * R, nullptr, nullptr, N, R, stream));
+        }
+        // 4. att_h = h_att W_h2att^T + b
+        {
+            SegSpec s{h_att, R, w->h2att_w, R, R, 1};
+            RC(gemm(stream, 0, 0, N, A, att_h, A, &s, 1, r->partial, r->partial_capacity, 0, nullptr, w->h2att_b));
+        }
+        // 5. fused region attention
+        RC(capmi_attention_fwd(att_h, r->p_att, r->att, r->att_mask, w->alpha_w, w->alpha_b, ctx, alpha, B, n, K, A, R,
+                               stream));
+        // 6-7. language LSTM: gates = [ctx | h_att | h_lang_prev] . [W_ih(:, 0:R) | W_ih(:, R:2R) | W_hh]
+        {
+            SegSpec s[3] = {{ctx, R, w->lang_w_ih, 2 * R, R, 1},
+                            {h_att, R, w->lang_w_ih + R, 2 * R, R, 1},
+                            {h_lang_prev, R, w->lang_w_hh, R, R, 1}};
+            RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s, 3, r->partial, r->partial_capacity, 1, &splits));
+            RC(capmi_lstm_cell_fwd(r->partial, splits, w->lang_b_ih, w->lang_b_hh, nullptr, 1, c_lang_prev, h_lang, c_lang,
+                                   r->gates_lang + (size_t)t * N * 4 * R,
+                                   r->drop_out ? r->drop_out + (size_t)t * NR : nullptr, h_drop, N, R, stream));
+        }
+        // 8. vocabulary projection
+        {
+            SegSpec s{h_drop, R, w->logit_w, R, R, 1};
+            RC(gemm(stream, 0, 0, N, V1, r->logits, V1, &s, 1, r->partial, r->partial_capacity, 0, nullptr, w->logit_b));
+        }
+        // 9. log-softmax + choice + bookkeeping
+        RC(capmi_logsoftmax_select(r->logits, N, V1, t, L, r->teacher ? 2 : r->mode, r->teacher ? nullptr : r->row_mode,
+                                   r->temperature, r->gumbel ? r->gumbel + (size_t)t * N * V1 : nullptr, r->seed,
+                                   r->forced, r->forced_ld, r->teacher ? 1 : 0, r->seq, L, r->it, r->unfinished,
+                                   r->seq_logp, r->sel_logp, r->live, stream));
+    }
+    return 0;
+}
+
+int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_rollout *r, const float *g_seq_logp,
+                             capmi_updown_bwd_scratch *s, capmi_updown_grads *g, void *stream) {
+    if (!w || !r || !g_seq_logp || !s || !g) return CAPMI_EINVAL;
+    const int B = r->B, n = r->n, N = r->N, K = r->K, A = r->A, R = r->R, E = r->E, V1 = r->V1, T = r->T, L = r->L;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t NR = (size_t)N * R;
+    const int TN = T * N;
+    const int ld_att_ih = 2 * R + E;
+    float *P = s->partial;
+    const int64_t cap = s->partial_capacity;
+
+    // ---- logit layer, batched over all T*N rows ----------------------------------------------
+    RC(capmi_logsoftmax_bwd(g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
+    {
+        SegSpec a{s->dlogits, V1, w->logit_w, R, V1, 1};   // d_hdrop = dlogits W_logit          [TN,R]
+        RC(gemm(stream, 0, 1, TN, R, s->d_hdrop, R, &a, 1, P, cap, 0, nullptr));
+        SegSpec b{s->dlogits, V1, r->h_drop, R, TN, 1};     // dW_logit = dlogits^T h_drop         [V1,R]
+        RC(gemm(stream, 1, 1, V1, R, g->logit_w, R, &b, 1, P, cap, 0, nullptr));
+        RC(capmi_colsum(s->dlogits, TN, V1, V1, g->logit_b, 0, stream));
+    }
+
+    // ---- BPTT over the recurrent part ----------------------------------------------------------
+    for (int t = T - 1; t >= 0; --t) {
+        const bool last = (t == T - 1);
+        float *d_x2 = s->d_x2 + (size_t)t * N * 3 * R;
+        float *d_x1 = s->d_x1 + (size_t)t * N * 2 * R;
+        const float *d_x2_next = last ? nullptr : s->d_x2 + (size_t)(t + 1) * N * 3 * R;
+        const float *d_x1_next = last ? nullptr : s->d_x1 + (size_t)(t + 1) * N * 2 * R;
+        float *dg_lang = s->dg_lang + (size_t)t * N * 4 * R;
+        float *dg_att = s->dg_att + (size_t)t * N * 4 * R;
+        float *dc_lang_in = s->dc_lang + (size_t)((t + 1) & 1) * NR, *dc_lang_out = s->dc_lang + (size_t)(t & 1) * NR;
+        float *dc_att_in = s->dc_att + (size_t)((t + 1) & 1) * NR, *dc_att_out = s->dc_att + (size_t)(t & 1) * NR;
+
+        // language LSTM cell: dh = d_hdrop*mask + dh_lang(att-LSTM input of step t+1) + dh_lang(own W_hh, t+1)
+        RC(capmi_lstm_cell_bwd(s->d_hdrop + (size_t)t * NR, R, r->drop_out ? r->drop_out + (size_t)t * NR : nullptr,
+                               d_x1_next, 2 * R, d_x2_next ? d_x2_next + 2 * R : nullptr, 3 * R,
+                               last ? nullptr : dc_lang_in, r->gates_lang + (size_t)t * N * 4 * R,
+                               r->c_lang + (size_t)t * NR, r->c_lang + (size_t)(t + 1) * NR, dg_lang, dc_lang_out, N, R,
+                               stream));
+        // d_x2 = dg_lang [W_ih | W_hh]  -> (d_ctx | dh_att | dh_lang_prev)
+        {
+            SegSpec a{dg_lang, 4 * R, w->lang_w_ih, 2 * R, 4 * R, 1};
+            RC(gemm(stream, 0, 1, N, 2 * R, d_x2, 3 * R, &a, 1, P, cap, 0, nullptr));
+            SegSpec b{dg_lang, 4 * R, w->lang_w_hh, R, 4 * R, 1};
+            RC(gemm(stream, 0, 1, N, R, d_x2 + 2 * R, 3 * R, &b, 1, P, cap, 0, nullptr));
+        }
+        // attention Jacobian: d_ctx -> d_att_h (and d_e kept for the batched pass)
+        RC(capmi_attention_bwd(d_x2, 3 * R, r->att_h + (size_t)t * N * A, r->alpha + (size_t)t * N * K, r->p_att, r->att,
+                               r->att_mask, w->alpha_w, s->d_att_h_all + (size_t)t * N * A,
+                               s->d_e_all + (size_t)t * N * K, B, n, K, A, R, stream));
+        {
+            SegSpec a{s->d_att_h_all + (size_t)t * N * A, A, w->h2att_w, R, A, 1};   // dh_att via h2att
+            RC(gemm(stream, 0, 1, N, R, s->dh_att_attn, R, &a, 1, P, cap, 0, nullptr));
+        }
+        // attention LSTM cell: dh = dh_att(lang input) + dh_att(attention) + dh_att(own W_hh, t+1)
+        RC(capmi_lstm_cell_bwd(d_x2 + R, 3 * R, nullptr, s->dh_att_attn, R, d_x1_next ? d_x1_next + R : nullptr, 2 * R,
+                               last ? nullptr : dc_att_in, r->gates_att + (size_t)t * N * 4 * R,
+                               r->c_att + (size_t)t * NR, r->c_att + (size_t)(t + 1) * NR, dg_att, dc_att_out, N, R,
+                               stream));
+        // d_x1 = dg_att [W_ih(:, 0:R) | W_hh] -> (dh_lang_prev | dh_att_prev); not needed at t = 0
+        if (t > 0) {
+            SegSpec a{dg_att, 4 * R, w->att_w_ih, ld_att_ih, 4 * R, 1};
+            RC(gemm(stream, 0, 1, N, R, d_x1, 2 * R, &a, 1, P, cap, 0, nullptr));
+            SegSpec b{dg_att, 4 * R, w->att_w_hh, R, 4 * R, 1};
+            RC(gemm(stream, 0, 1, N, R, d_x1 + R, 2 * R, &b, 1, P, cap, 0, nullptr));
+        }
+    }
+
+    // ---- time-batched parameter / feature gradients --------------------------------------------
+    // attention LSTM
+    {
+        SegSpec a{s->dg_att, 4 * R, r->h_lang, R, TN, 1};          // x h_lang_prev  (slots 0..T-1)
+        RC(gemm(stream, 1, 1, 4 * R, R, g->att_w_ih, ld_att_ih, &a, 1, P, cap, 0, nullptr));
+        SegSpec b{s->dg_att, 4 * R, r->xt, E, TN, 1};              // x xt
+        RC(gemm(stream, 1, 1, 4 * R, E, g->att_w_ih + 2 * R, ld_att_ih, &b, 1, P, cap, 0, nullptr));
+        SegSpec c{s->dg_att, 4 * R, r->h_att, R, TN, 1};           // x h_att_prev
+        RC(gemm(stream, 1, 1, 4 * R, R, g->att_w_hh, R, &c, 1, P, cap, 0, nullptr));
+        RC(capmi_colsum(s->dg_att, TN, 4 * R, 4 * R, g->att_b_ih, 0, stream));
+        hipError_t e = hipMemcpyAsync(g->att_b_hh, g->att_b_ih, (size_t)4 * R * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+        // fc columns: sum over time and over the n rows of an image first
+        RC(capmi_group_rowsum(s->dg_att, T, (int64_t)N * 4 * R, B, n, 4 * R, s->sum_dg_att, stream));
+        SegSpec d{s->sum_dg_att, 4 * R, r->fc, R, B, 1};
+        RC(gemm(stream, 1, 1, 4 * R, R, g->att_w_ih + R, ld_att_ih, &d, 1, P, cap, 0, nullptr));
+        if (g->d_fc) {
+            SegSpec f{s->sum_dg_att, 4 * R, w->att_w_ih + R, ld_att_ih, 4 * R, 1};
+            RC(gemm(stream, 0, 1, B, R, g->d_fc, R, &f, 1, P, cap, 0, nullptr));
+        }
+        // token embedding: d_xt = dg_att W_ih(:, 2R:) then scatter through ReLU/dropout
+        SegSpec x{s->dg_att, 4 * R, w->att_w_ih + 2 * R, ld_att_ih, 4 * R, 1};
+        RC(gemm(stream, 0, 1, TN, E, s->d_xt_all, E, &x, 1, P, cap, 0, nullptr));
+        e = hipMemsetAsync(g->embed, 0, (size_t)V1 * E * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+        RC(capmi_embed_bwd(r->it_all, s->d_xt_all, r->xt, r->drop_xt, g->embed, TN, E, 1, stream));
+    }
+    // language LSTM
+    {
+        SegSpec a{s->dg_lang, 4 * R, r->ctx, R, TN, 1};
+        RC(gemm(stream, 1, 1, 4 * R, R, g->lang_w_ih, 2 * R, &a, 1, P, cap, 0, nullptr));
+        SegSpec b{s->dg_lang, 4 * R, r->h_att + NR, R, TN, 1};      // h_att of the same step (slots 1..T)
+        RC(gemm(stream, 1, 1, 4 * R, R, g->lang_w_ih + R, 2 * R, &b, 1, P, cap, 0, nullptr));
+        SegSpec c{s->dg_lang, 4 * R, r->h_lang, R, TN, 1};
+        RC(gemm(stream, 1, 1, 4 * R, R, g->lang_w_hh, R, &c, 1, P, cap, 0, nullptr));
+        RC(capmi_colsum(s->dg_lang, TN, 4 * R, 4 * R, g->lang_b_ih, 0, stream));
+        hipError_t e = hipMemcpyAsync(g->lang_b_hh, g->lang_b_ih, (size_t)4 * R * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    // attention parameters / features
+    {
+        SegSpec a{s->d_att_h_all, A, r->h_att + NR, R, TN, 1};
+        RC(gemm(stream, 1, 1, A, R, g->h2att_w, R, &a, 1, P, cap, 0, nullptr));
+        RC(capmi_colsum(s->d_att_h_all, TN, A, A, g->h2att_b, 0, stream));
+        RC(capmi_attention_bwd_batched(s->d_x2, 3 * R, r->att_h, r->alpha, s->d_e_all, r->p_att, w->alpha_w, g->d_att,
+                                       g->d_p_att, g->alpha_w, g->alpha_b, T, B, n, K, A, R, stream));
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,208 @@
+"""Tensor-level wrappers over the C ABI (include/capmi.h).  Pure plumbing: they check devices/dtypes,
+pass ``data_ptr()``s and the current HIP stream, and raise on any non-zero return.  No compute happens
+in Python and nothing here falls back to torch ops.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, ptr, check, stream_ptr
+
+_f32 = torch.float32
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.CapmiError('capmi ops need device tensors (got %s)' % t.device)
+        if not t.is_contiguous():
+            raise _lib.CapmiError('capmi ops need contiguous tensors')
+
+
+class Workspace:
+    """Split-K scratch shared by the GEMM launches of one stream."""
+
+    def __init__(self, device, floats=16 * 1024 * 1024):
+        self.buf = torch.empty(floats, dtype=_f32, device=device)
+
+    @property
+    def capacity(self):
+        return self.buf.numel()
+
+
+_default_ws = {}
+
+
+def default_workspace(device):
+    key = str(device)
+    if key not in _default_ws:
+        _default_ws[key] = Workspace(device)
+    return _default_ws[key]
+
+
+def gemm(segs, M, N, out, ldc=None, a_layout=0, b_layout=0, bias=None, bias2=None, row_bias=None, row_bias_div=1,
+         mul_mask=None, relu=False, accumulate=False, ws=None, splits=0, defer_reduce=False):
+    """segs: list of (A, lda, B, ldb, K, a_row_div) with tensors (or (tensor, element_offset) pairs).
+    Returns splits_used."""
+    d = _lib.GemmDesc()
+    d.nseg = len(segs)
+    for i, (A, lda, B, ldb, K, div) in enumerate(segs):
+        d.seg[i].A = _addr(A)
+        d.seg[i].B = _addr(B)
+        d.seg[i].lda, d.seg[i].ldb, d.seg[i].K, d.seg[i].a_row_div = lda, ldb, K, div
+    d.a_layout, d.b_layout, d.M, d.N = a_layout, b_layout, M, N
+    d.C = _addr(out)
+    d.ldc = N if ldc is None else ldc
+    d.bias, d.bias2, d.row_bias = ptr(bias), ptr(bias2), ptr(row_bias)
+    d.row_bias_div = row_bias_div
+    d.mul_mask = ptr(mul_mask)
+    d.relu, d.accumulate = int(relu), int(accumulate)
+    if ws is None:
+        ws = default_workspace(_dev(out))
+    d.partial, d.partial_capacity = ws.buf.data_ptr(), ws.capacity
+    d.splits, d.defer_reduce = splits, int(defer_reduce)
+    check(lib.capmi_gemm_f32(C.byref(d), stream_ptr()), 'capmi_gemm_f32')
+    return d.splits_used
+
+
+def _addr(x):
+    if isinstance(x, tuple):
+        t, off = x
+        return t.data_ptr() + 4 * off
+    return x.data_ptr()
+
+
+def _dev(x):
+    return (x[0] if isinstance(x, tuple) else x).device
+
+
+def linear(x, weight, bias=None, relu=False, mul_mask=None, row_div=1, rows=None, ws=None):
+    """y = act(x @ weight.T + bias) (* mask); x [M0,K] read as row r -> r // row_div."""
+    _chk(x, weight, bias, mul_mask)
+    M = x.shape[0] * row_div if rows is None else rows
+    N, K = weight.shape
+    out = torch.empty(M, N, dtype=_f32, device=x.device)
+    gemm([(x, x.shape[1], weight, K, K, row_div)], M, N, out, bias=bias, relu=relu, mul_mask=mul_mask, ws=ws)
+    return out
+
+
+def matmul_nn(a, b, out=None, ws=None):
+    """a [M,K] @ b [K,N]"""
+    _chk(a, b)
+    M, K = a.shape
+    N = b.shape[1]
+    if out is None:
+        out = torch.empty(M, N, dtype=_f32, device=a.device)
+    gemm([(a, K, b, N, K, 1)], M, N, out, a_layout=0, b_layout=1, ws=ws)
+    return out
+
+
+def matmul_tn(a, b, out=None, ws=None):
+    """a [K,M]^T @ b [K,N]  (weight gradients dW = dY^T X)"""
+    _chk(a, b)
+    K, M = a.shape
+    N = b.shape[1]
+    if out is None:
+        out = torch.empty(M, N, dtype=_f32, device=a.device)
+    gemm([(a, M, b, N, K, 1)], M, N, out, a_layout=1, b_layout=1, ws=ws)
+    return out
+
+
+def attention_fwd(att_h, p_att, att, mask, w, b, n):
+    _chk(att_h, p_att, att, mask, w, b)
+    B, K, A = p_att.shape
+    R = att.shape[2]
+    N = att_h.shape[0]
+    assert N == B * n
+    ctx = torch.empty(N, R, dtype=_f32, device=att.device)
+    alpha = torch.empty(N, K, dtype=_f32, device=att.device)
+    check(lib.capmi_attention_fwd(ptr(att_h), ptr(p_att), ptr(att), ptr(mask), ptr(w), ptr(b), ptr(ctx), ptr(alpha),
+                                  B, n, K, A, R, stream_ptr()), 'capmi_attention_fwd')
+    return ctx, alpha
+
+
+def attention_bwd(d_ctx, att_h, alpha, p_att, att, mask, w, n):
+    _chk(d_ctx, att_h, alpha, p_att, att, mask, w)
+    B, K, A = p_att.shape
+    R = att.shape[2]
+    N = att_h.shape[0]
+    d_att_h = torch.empty(N, A, dtype=_f32, device=att.device)
+    d_e = torch.empty(N, K, dtype=_f32, device=att.device)
+    check(lib.capmi_attention_bwd(ptr(d_ctx), d_ctx.shape[1], ptr(att_h), ptr(alpha), ptr(p_att), ptr(att), ptr(mask),
+                                  ptr(w), ptr(d_att_h), ptr(d_e), B, n, K, A, R, stream_ptr()), 'capmi_attention_bwd')
+    return d_att_h, d_e
+
+
+def attention_bwd_batched(d_ctx_all, att_h_all, alpha_all, d_e_all, p_att, w, n, R):
+    _chk(d_ctx_all, att_h_all, alpha_all, d_e_all, p_att, w)
+    T = att_h_all.shape[0]
+    B, K, A = p_att.shape
+    dev = p_att.device
+    d_att = torch.empty(B, K, R, dtype=_f32, device=dev)
+    d_p_att = torch.empty(B, K, A, dtype=_f32, device=dev)
+    d_w = torch.empty(A, dtype=_f32, device=dev)
+    d_b = torch.empty(1, dtype=_f32, device=dev)
+    check(lib.capmi_attention_bwd_batched(ptr(d_ctx_all), d_ctx_all.shape[-1], ptr(att_h_all), ptr(alpha_all),
+                                          ptr(d_e_all), ptr(p_att), ptr(w), ptr(d_att), ptr(d_p_att), ptr(d_w), ptr(d_b),
+                                          T, B, n, K, A, R, stream_ptr()), 'capmi_attention_bwd_batched')
+    return d_att, d_p_att, d_w, d_b
+
+
+def lstm_cell_fwd(partial, splits, b_ih, b_hh, c_prev, row_bias=None, row_bias_div=1, out_mask=None, want_drop=False):
+    N, R = c_prev.shape
+    dev = c_prev.device
+    h = torch.empty(N, R, dtype=_f32, device=dev)
+    c = torch.empty(N, R, dtype=_f32, device=dev)
+    gates = torch.empty(N, 4 * R, dtype=_f32, device=dev)
+    h_drop = torch.empty(N, R, dtype=_f32, device=dev) if (want_drop or out_mask is not None) else None
+    check(lib.capmi_lstm_cell_fwd(ptr(partial), splits, ptr(b_ih), ptr(b_hh), ptr(row_bias), row_bias_div, ptr(c_prev),
+                                  ptr(h), ptr(c), ptr(gates), ptr(out_mask), ptr(h_drop), N, R, stream_ptr()),
+          'capmi_lstm_cell_fwd')
+    return h, c, gates, h_drop
+
+
+def lstm_cell_bwd(dh, dc_next, gates, c_prev, c_new, dh_mask=None, dh_b=None, dh_c=None):
+    N, R = c_prev.shape
+    dev = c_prev.device
+    dg = torch.empty(N, 4 * R, dtype=_f32, device=dev)
+    dc_prev = torch.empty(N, R, dtype=_f32, device=dev)
+    check(lib.capmi_lstm_cell_bwd(ptr(dh), R, ptr(dh_mask), ptr(dh_b), R, ptr(dh_c), R, ptr(dc_next), ptr(gates),
+                                  ptr(c_prev), ptr(c_new), ptr(dg), ptr(dc_prev), N, R, stream_ptr()),
+          'capmi_lstm_cell_bwd')
+    return dg, dc_prev
+
+
+def embed_fwd(it, E, mask=None, relu=True):
+    N = it.shape[0]
+    x = torch.empty(N, E.shape[1], dtype=_f32, device=E.device)
+    check(lib.capmi_embed_fwd(ptr(it), 1, None, ptr(E), ptr(mask), ptr(x), N, E.shape[1], int(relu), stream_ptr()),
+          'capmi_embed_fwd')
+    return x
+
+
+def dropout_mask(shape, p, seed, offset, device):
+    m = torch.empty(shape, dtype=_f32, device=device)
+    check(lib.capmi_dropout_mask(ptr(m), m.numel(), float(p), int(seed), int(offset), stream_ptr()), 'capmi_dropout_mask')
+    return m
+
+
+def colsum(x, out=None):
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty(cols, dtype=_f32, device=x.device)
+    check(lib.capmi_colsum(ptr(x), rows, cols, cols, ptr(out), 0, stream_ptr()), 'capmi_colsum')
+    return out
+
+
+def relu_mask_bwd(dy, y_ref, mask):
+    dx = torch.empty_like(dy)
+    check(lib.capmi_relu_mask_bwd(ptr(dy), ptr(y_ref), ptr(mask), ptr(dx), dy.numel(), stream_ptr()), 'capmi_relu_mask_bwd')
+    return dx
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, clip, grad_scale, step):
+    check(lib.capmi_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, clip,
+                              grad_scale, step, stream_ptr()), 'capmi_adam_step')

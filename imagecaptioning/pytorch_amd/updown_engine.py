@@ -1,0 +1,185 @@
+"""Host-side driver of the UpDown decode path on libcapmi (MI355X).
+
+Python here only owns device memory (torch tensors), fills the C structs of include/capmi.h and makes
+ONE native call per rollout (forward) / per BPTT (backward); all arithmetic is in the HIP kernels.
+
+Mirrors, for the UpDown model (AttModel.py:875-879 + UpDownCore 615-640):
+  prepare()      AttModel._prepare_feature        AttModel.py:114-124
+  Rollout.run()  AttModel._sample / _forward      AttModel.py:258-352 / 126-164
+  Rollout.backward()  the autograd graph torch would have recorded for them
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib, ops
+from ._lib import lib, ptr, check, stream_ptr
+
+_f32 = torch.float32
+
+PARAM_KEYS = ('embed.0.weight', 'fc_embed.0.weight', 'fc_embed.0.bias', 'att_embed.0.weight', 'att_embed.0.bias',
+              'ctx2att.weight', 'ctx2att.bias', 'core.att_lstm.weight_ih', 'core.att_lstm.weight_hh',
+              'core.att_lstm.bias_ih', 'core.att_lstm.bias_hh', 'core.lang_lstm.weight_ih', 'core.lang_lstm.weight_hh',
+              'core.lang_lstm.bias_ih', 'core.lang_lstm.bias_hh', 'core.attention.h2att.weight',
+              'core.attention.h2att.bias', 'core.attention.alpha_net.weight', 'core.attention.alpha_net.bias',
+              'logit.weight', 'logit.bias')
+
+_W_FIELDS = (('embed', 'embed.0.weight'), ('att_w_ih', 'core.att_lstm.weight_ih'), ('att_w_hh', 'core.att_lstm.weight_hh'),
+             ('att_b_ih', 'core.att_lstm.bias_ih'), ('att_b_hh', 'core.att_lstm.bias_hh'),
+             ('lang_w_ih', 'core.lang_lstm.weight_ih'), ('lang_w_hh', 'core.lang_lstm.weight_hh'),
+             ('lang_b_ih', 'core.lang_lstm.bias_ih'), ('lang_b_hh', 'core.lang_lstm.bias_hh'),
+             ('h2att_w', 'core.attention.h2att.weight'), ('h2att_b', 'core.attention.h2att.bias'),
+             ('alpha_w', 'core.attention.alpha_net.weight'), ('alpha_b', 'core.attention.alpha_net.bias'),
+             ('logit_w', 'logit.weight'), ('logit_b', 'logit.bias'))
+
+
+def weights_struct(P):
+    w = _lib.UpDownWeights()
+    for f, k in _W_FIELDS:
+        t = P[k]
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == _f32):
+            raise _lib.CapmiError('parameter %s must be a contiguous fp32 device tensor' % k)
+        setattr(w, f, t.data_ptr())
+    return w
+
+
+class Prepared:
+    """fc' [B,R], att' [B,K,R], p_att [B,K,A] (+ what the backward of the prefill needs)."""
+    __slots__ = ('fc', 'att', 'p_att', 'att_masks', 'fc_in', 'att_in', 'drop_fc', 'drop_att', 'K')
+
+
+def prepare(P, fc_feats, att_feats, att_masks=None, drop_fc=None, drop_att=None, ws=None):
+    """AttModel._prepare_feature (AttModel.py:114-124): three MFMA GEMMs with fused bias/ReLU/dropout
+    epilogues.  Padded regions (att_masks == 0) are zeroed like pad_packed_sequence does (44-49)."""
+    B = fc_feats.shape[0]
+    if att_masks is not None:
+        max_len = int(att_masks.long().sum(1).max())          # clip_att, AttModel.py:106-112
+        att_feats = att_feats[:, :max_len].contiguous()
+        att_masks = att_masks[:, :max_len].contiguous().float()
+        if drop_att is not None:
+            drop_att = drop_att[:, :max_len].contiguous()
+    K = att_feats.shape[1]
+    pr = Prepared()
+    pr.K = K
+    pr.fc_in, pr.att_in, pr.drop_fc = fc_feats.contiguous(), att_feats.contiguous(), drop_fc
+    pr.fc = ops.linear(pr.fc_in, P['fc_embed.0.weight'], P['fc_embed.0.bias'], relu=True, mul_mask=drop_fc, ws=ws)
+    R = pr.fc.shape[1]
+    att_mask_full = drop_att
+    if att_masks is not None:
+        m = att_masks.unsqueeze(-1).expand(B, K, R)
+        att_mask_full = (m if drop_att is None else m * drop_att).contiguous()
+    pr.drop_att = att_mask_full
+    att2d = ops.linear(pr.att_in.view(B * K, -1), P['att_embed.0.weight'], P['att_embed.0.bias'], relu=True,
+                       mul_mask=None if att_mask_full is None else att_mask_full.view(B * K, R), ws=ws)
+    pr.att = att2d.view(B, K, R)
+    pr.p_att = ops.linear(att2d, P['ctx2att.weight'], P['ctx2att.bias'], ws=ws).view(B, K, -1)
+    pr.att_masks = att_masks
+    return pr
+
+
+def prepare_backward(P, pr, d_fc, d_att, d_p_att, grads, ws=None):
+    """Backward of prepare(): fills grads[...] for fc_embed / att_embed / ctx2att (overwrite)."""
+    B, K, R = pr.att.shape
+    A = pr.p_att.shape[2]
+    dp = d_p_att.view(B * K, A)
+    att2d = pr.att.view(B * K, R)
+    # ctx2att: p_att = att W^T + b
+    ops.matmul_tn(dp, att2d, out=grads['ctx2att.weight'], ws=ws)
+    ops.colsum(dp, out=grads['ctx2att.bias'])
+    d_att_total = d_att.view(B * K, R)
+    ops.gemm([(dp, A, P['ctx2att.weight'], R, A, 1)], B * K, R, d_att_total, a_layout=0, b_layout=1, accumulate=True, ws=ws)
+    # att_embed: att = drop(relu(x W^T + b))
+    # relu gate: pre-activation > 0  <=>  relu output > 0; with dropout the saved output may be zero for kept
+    # units only if relu clipped, and for dropped units the mask already zeroes the gradient.
+    d_pre = _relu_drop_bwd(d_att_total, att2d, None if pr.drop_att is None else pr.drop_att.view(B * K, R))
+    ops.matmul_tn(d_pre, pr.att_in.view(B * K, -1), out=grads['att_embed.0.weight'], ws=ws)
+    ops.colsum(d_pre, out=grads['att_embed.0.bias'])
+    d_pre_fc = _relu_drop_bwd(d_fc, pr.fc, pr.drop_fc)
+    ops.matmul_tn(d_pre_fc, pr.fc_in, out=grads['fc_embed.0.weight'], ws=ws)
+    ops.colsum(d_pre_fc, out=grads['fc_embed.0.bias'])
+
+
+def _relu_drop_bwd(dy, y_saved, mask):
+    """dx = dy * mask * [y_saved > 0]; y_saved = relu(pre)*mask.  A unit with y_saved == 0 was either
+    clipped by the ReLU (gradient 0) or dropped (mask 0 => gradient 0)."""
+    return ops.relu_mask_bwd(dy.contiguous(), y_saved.contiguous(), mask)
+
+
+class Rollout:
+    """Device buffers + one native call for a T-step rollout of N = B*n caption rows."""
+
+    def __init__(self, P, pr, n, T, L=None, mode='greedy', temperature=1.0, drop_xt=None, drop_out=None,
+                 gumbel=None, seed=0, forced=None, teacher=False, row_mode=None, ws=None, keep_for_backward=True):
+        dev = pr.fc.device
+        B, K, R = pr.att.shape
+        A = pr.p_att.shape[2]
+        V1, E = P['embed.0.weight'].shape
+        N = B * n
+        L = T if L is None else L
+        self.P, self.pr, self.dims = P, pr, (B, n, N, K, A, R, E, V1, T, L)
+        self.ws = ws or ops.default_workspace(dev)
+        z = lambda *s: torch.empty(*s, dtype=_f32, device=dev)       # noqa: E731
+        self.h_att, self.c_att, self.h_lang, self.c_lang = (z(T + 1, N, R) for _ in range(4))
+        self.xt = z(T, N, E)
+        self.it_all = torch.empty(T, N, dtype=torch.long, device=dev)
+        self.gates_att, self.gates_lang = z(T, N, 4 * R), z(T, N, 4 * R)
+        self.att_h, self.alpha, self.ctx, self.h_drop = z(T, N, A), z(T, N, K), z(T, N, R), z(T, N, R)
+        self.seq = torch.zeros(N, L, dtype=torch.long, device=dev)
+        self.seq_logp = torch.zeros(N, L, V1, dtype=_f32, device=dev)
+        self.sel_logp = torch.zeros(N, L, dtype=_f32, device=dev)
+        self.live = torch.zeros(N, L, dtype=torch.uint8, device=dev)
+        self.fc_gates = z(B, 4 * R)
+        self.logits = z(N, V1)
+        self.it = torch.empty(N, dtype=torch.long, device=dev)
+        self.unfinished = torch.empty(N, dtype=torch.uint8, device=dev)
+        self.drop_xt, self.drop_out, self.gumbel, self.forced, self.row_mode = drop_xt, drop_out, gumbel, forced, row_mode
+
+        r = _lib.UpDownRollout()
+        r.B, r.n, r.N, r.K, r.A, r.R, r.E, r.V1, r.T, r.L = B, n, N, K, A, R, E, V1, T, L
+        r.fc, r.att, r.p_att, r.att_mask = ptr(pr.fc), ptr(pr.att), ptr(pr.p_att), ptr(pr.att_masks)
+        r.drop_xt, r.drop_out = ptr(drop_xt), ptr(drop_out)
+        r.mode = {'greedy': 0, 'sample': 1, 'forced': 2}[mode]
+        r.row_mode = ptr(row_mode)
+        r.temperature = float(temperature)
+        r.gumbel = ptr(gumbel)
+        r.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        if forced is not None:
+            assert forced.dtype == torch.long and forced.is_contiguous()
+            r.forced, r.forced_ld = ptr(forced), forced.shape[1]
+        r.teacher = int(teacher)
+        for k in ('h_att', 'c_att', 'h_lang', 'c_lang', 'xt', 'it_all', 'gates_att', 'gates_lang', 'att_h', 'alpha',
+                  'ctx', 'h_drop', 'seq', 'seq_logp', 'sel_logp', 'live', 'fc_gates', 'logits', 'it', 'unfinished'):
+            setattr(r, k, getattr(self, k).data_ptr())
+        r.partial, r.partial_capacity = self.ws.buf.data_ptr(), self.ws.capacity
+        self.r = r
+        self.w = weights_struct(P)
+
+    def run(self):
+        check(lib.capmi_updown_rollout_fwd(C.byref(self.w), C.byref(self.r), stream_ptr()), 'capmi_updown_rollout_fwd')
+        return self.seq, self.seq_logp
+
+    def backward(self, g_seq_logp, grads):
+        """g_seq_logp [N,L,V1].  grads: dict name -> preallocated fp32 tensor (overwritten) for every
+        PARAM_KEYS entry.  Also returns (d_fc, d_att, d_p_att) consumed by prepare_backward."""
+        B, n, N, K, A, R, E, V1, T, L = self.dims
+        dev = self.seq.device
+        z = lambda *s: torch.empty(*s, dtype=_f32, device=dev)       # noqa: E731
+        s = _lib.UpDownBwdScratch()
+        keep = dict(dlogits=z(T, N, V1), d_hdrop=z(T, N, R), dg_att=z(T, N, 4 * R), dg_lang=z(T, N, 4 * R),
+                    d_x2=z(T, N, 3 * R), d_e_all=z(T, N, K), d_att_h_all=z(T, N, A), dh_att_attn=z(N, R),
+                    d_x1=z(T, N, 2 * R), dc_att=z(2, N, R), dc_lang=z(2, N, R), d_xt_all=z(T, N, E),
+                    sum_dg_att=z(B, 4 * R))
+        for k, t in keep.items():
+            setattr(s, k, t.data_ptr())
+        s.partial, s.partial_capacity = self.ws.buf.data_ptr(), self.ws.capacity
+        g = _lib.UpDownGrads()
+        for f, k in _W_FIELDS:
+            setattr(g, f, grads[k].data_ptr())
+        d_fc, d_att, d_p_att = z(B, R), z(B, K, R), z(B, K, A)
+        g.d_fc, g.d_att, g.d_p_att = d_fc.data_ptr(), d_att.data_ptr(), d_p_att.data_ptr()
+        g_seq_logp = g_seq_logp.contiguous()
+        check(lib.capmi_updown_rollout_bwd(C.byref(self.w), C.byref(self.r), ptr(g_seq_logp), C.byref(s), C.byref(g),
+                                           stream_ptr()), 'capmi_updown_rollout_bwd')
+        self._bwd_keep = keep     # keep scratch alive until the stream has consumed it
+        return d_fc, d_att, d_p_att

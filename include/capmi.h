@@ -1,0 +1,323 @@
+/*
+ * capmi.h -- C ABI of libcapmi.so, the MI355X (gfx950 / CDNA4) caption-decoding backend.
+ *
+ * The reference (ruotianluo/ImageCaptioning.pytorch) has NO native/FFI boundary: its hot path is
+ * Python calling torch.nn ops.  This header is therefore the boundary a
+ * maintainer would bind with ctypes from the reference's own Python classes (INTEGRATION.md shows
+ * the stubs).  Every entry point below names the reference code it replaces (file:line under
+ * /root/reference).
+ *
+ * Conventions
+ *   - plain C: raw device pointers, explicit sizes/strides, no torch types;
+ *   - all tensors fp32 row-major unless stated; token ids int64 (torch.long) as in the reference;
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); calls only enqueue work:
+ *     they never allocate, never synchronise, never throw;
+ *   - return value: 0 on success, a hipError_t (>0) from the launch, or CAPMI_EINVAL (-1) on bad
+ *     arguments.  Nothing here falls back to the CPU.
+ */
+#ifndef CAPMI_H
+#define CAPMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAPMI_EINVAL (-1)
+#define CAPMI_MAX_SEG 4
+
+/* library / device introspection -------------------------------------------------------------- */
+int capmi_version(void);                 /* ABI version, bumped on any signature change */
+const char *capmi_arch(void);            /* "gfx950" */
+
+/* ---------------------------------------------------------------------------------------------
+ * fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32; exact-f32 products, f32 accumulate).
+ * Replaces the addmm/mm calls behind nn.Linear / nn.LSTMCell on the hot path:
+ *   AttModel.py:118-122 (fc_embed, att_embed, ctx2att), :628/:635 (LSTMCell gate GEMMs),
+ *   :733 (h2att), :172 (logit), and their autograd backward (dX = dY W, dW = dY^T X).
+ *
+ *   C[M,N] = epi( sum_s opA(A_s)[M,K_s] * opB(B_s)[K_s,N] )
+ *
+ * a_layout: 0 = A_s stored [M][K_s] (row stride lda)      1 = A_s stored [K_s][M] (row stride lda)
+ * b_layout: 0 = B_s stored [N][K_s] (nn.Linear weight)    1 = B_s stored [K_s][N]
+ * a_row_div: operand row r reads stored row r / a_row_div (image-sharing of per-image activations,
+ *            replaces models/utils.py:3-14 repeat_tensors; a_layout 0 only, >= 1).
+ * epilogue (applied when the K reduction is complete):
+ *   v = acc + bias[n] + bias2[n] + row_bias[(m / row_bias_div) * N + n]
+ *   if relu: v = max(v, 0);  if mul_mask: v *= mul_mask[m * N + n];  if accumulate: v += C[m*ldc+n]
+ * split-K: splits > 1 writes raw partial sums to `partial` ([splits][M][N], caller-provided) and,
+ *   unless defer_reduce, runs the reduce+epilogue kernel; splits == 0 lets the library choose
+ *   (needs partial_capacity floats available in `partial`, may be 0 => no split).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct capmi_gemm_seg {
+    const float *A;
+    const float *B;
+    int lda;
+    int ldb;
+    int K;
+    int a_row_div;
+} capmi_gemm_seg;
+
+typedef struct capmi_gemm_desc {
+    capmi_gemm_seg seg[CAPMI_MAX_SEG];
+    int nseg;
+    int a_layout;
+    int b_layout;
+    int M;
+    int N;
+    float *C;
+    int ldc;
+    const float *bias;
+    const float *bias2;
+    const float *row_bias;
+    int row_bias_div;
+    const float *mul_mask;
+    int relu;
+    int accumulate;
+    float *partial;
+    int64_t partial_capacity;   /* in floats */
+    int splits;                 /* 0 = auto */
+    int defer_reduce;           /* leave partials for a fused consumer (e.g. capmi_lstm_cell_fwd) */
+    int splits_used;            /* out: number of K slices actually written */
+} capmi_gemm_desc;
+
+int capmi_gemm_f32(capmi_gemm_desc *d, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused additive region attention, forward (AttModel.py:728-748 Attention.forward; the
+ * 7-9 ATen launches of SURVEY.md K5 in one kernel):
+ *   e[r,k]   = sum_a w[a] * tanh(p_att[r/n, k, a] + att_h[r, a]) + b
+ *   alpha    = softmax_k(e);  if mask: alpha = alpha*mask[r/n,k] / sum_k(alpha*mask)
+ *   ctx[r,:] = sum_k alpha[r,k] * att[r/n, k, :]
+ * One workgroup per image: its p_att / att tiles are read from HBM once and reused by the n rows
+ * of that image (no repeat_tensors copy).  att_h [N,A], p_att [B,K,A], att [B,K,R], mask [B,K] or
+ * NULL, w [A], b scalar pointer; outputs ctx [N,R], alpha [N,K].  N = B*n, n <= 8.
+ * ------------------------------------------------------------------------------------------- */
+int capmi_attention_fwd(const float *att_h, const float *p_att, const float *att, const float *mask,
+                        const float *w, const float *b, float *ctx, float *alpha,
+                        int B, int n, int K, int A, int R, void *stream);
+
+/* backward of the above for one time step.  Inputs d_ctx [N,R] plus the saved att_h/alpha.
+ * Outputs d_att_h [N,A] (feeds h2att backward) and d_e [N,K] (softmax-input gradient, kept for the
+ * time-batched parameter/feature gradients below). */
+int capmi_attention_bwd(const float *d_ctx, int ld_dctx, const float *att_h, const float *alpha,
+                        const float *p_att, const float *att, const float *mask, const float *w,
+                        float *d_att_h, float *d_e, int B, int n, int K, int A, int R, void *stream);
+
+/* time-batched feature/parameter gradients of the attention over a whole rollout of T steps:
+ *   d_att[b,k,:]   += sum_{t, r in image b} alpha[t,r,k] * d_ctx[t,r,:]
+ *   d_p_att[b,k,a] += sum_{t, r in b} d_e[t,r,k] * w[a] * (1 - tanh^2(p_att[b,k,a] + att_h[t,r,a]))
+ *   d_w[a]         += sum_{t,r,k} d_e[t,r,k] * tanh(p_att[b,k,a] + att_h[t,r,a]);  d_b += sum d_e
+ * All *_all arrays are [T,N,...] (d_ctx_all rows have pitch ld_dctx).  d_att/d_p_att/d_w/d_b are
+ * overwritten (not accumulated). */
+int capmi_attention_bwd_batched(const float *d_ctx_all, int ld_dctx, const float *att_h_all, const float *alpha_all,
+                                const float *d_e_all, const float *p_att, const float *w,
+                                float *d_att, float *d_p_att, float *d_w, float *d_b,
+                                int T, int B, int n, int K, int A, int R, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LSTM cell pointwise stage (torch.nn.LSTMCell gate math, gate order i,f,g,o; AttModel.py:628,635):
+ *   gates = sum_s partial[s] + b_ih + b_hh + row_bias[(r / row_bias_div)]   ([N,4R])
+ *   c' = sig(f)*c + sig(i)*tanh(g);  h' = sig(o)*tanh(c')
+ * Consumes the split-K partials of capmi_gemm_f32 directly (defer_reduce).  Writes h', c', the
+ * activated gates [N,4R] (saved for backward) and, if out_mask, h_drop = h' * out_mask
+ * (F.dropout at AttModel.py:637).
+ * ------------------------------------------------------------------------------------------- */
+int capmi_lstm_cell_fwd(const float *partial, int splits, const float *b_ih, const float *b_hh,
+                        const float *row_bias, int row_bias_div, const float *c_prev,
+                        float *h, float *c, float *gates_act, const float *out_mask, float *h_drop,
+                        int N, int R, void *stream);
+
+/* backward: given dh (total gradient reaching h'), dc_next (gradient reaching c' from step t+1),
+ * the saved activated gates, c_prev and c': d_gates [N,4R] (pre-activation) and dc_prev [N,R].
+ * dh may be the sum of up to three addends (dh_a + dh_b + dh_c, each optional) and dh_a may be
+ * multiplied by a dropout mask first (dropout backward of AttModel.py:637). */
+int capmi_lstm_cell_bwd(const float *dh_a, int ld_a, const float *dh_a_mask, const float *dh_b, int ld_b,
+                        const float *dh_c, int ld_c, const float *dc_next, const float *gates_act,
+                        const float *c_prev, const float *c_new, float *d_gates, float *dc_prev, int N, int R,
+                        void *stream);
+
+/* token embedding: x[r,:] = relu(E[it[r],:]) * mask[r,:]  (AttModel.py:74-76,168). relu/mask optional. */
+/* it[r*it_stride] is row r's token; it_save [N] (optional) records the tokens consumed. */
+int capmi_embed_fwd(const int64_t *it, int it_stride, int64_t *it_save, const float *E, const float *mask,
+                    float *x, int N, int Edim, int relu, void *stream);
+/* scatter-add backward into dE [V1,Edim] (caller zeroes dE): dE[it[r]] += dx[r]*mask[r]*(x[r]>0) */
+int capmi_embed_bwd(const int64_t *it, const float *dx, const float *x_saved, const float *mask,
+                    float *dE, int rows, int Edim, int relu, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * log-softmax + next-token choice + rollout bookkeeping for one step
+ * (F.log_softmax AttModel.py:172; CaptionModel.sample_next_word CaptionModel.py:370-407;
+ *  unfinished masking / seq and seqLogprobs stores AttModel.py:340-347).
+ *   logits [N,V1] -> logp = logits - logsumexp
+ *   mode 0 greedy: first maximal index (torch.max tie-break)
+ *   mode 1 sample: argmax_v(logp[v]/temperature + gumbel(v)), gumbel from `gumbel` [N,V1] if given
+ *                  else Philox(seed, step, row, v)
+ *   mode 2 forced: token = forced[r*forced_ld + step]
+ *   step > 0: token *= unfinished[r]; logp row *= unfinished[r]   (finished rows emit pad=0 / zeros)
+ *   unfinished[r] = (step==0 ? 1 : unfinished[r]) && token != 0
+ *   (mode 2 with no_finish_mask = 1: teacher forcing a_5, nothing is masked)
+ * writes seq[r*seq_ld+step], it_next[r], seq_logp[(r*L+step)*V1 + v] (dense, API parity),
+ * sel_logp[r*L+step], live[r*L+step] (1 = the row was unfinished when this step was produced).
+ * row_mode [N] (optional) overrides `mode` per row (fused greedy+sample).
+ * ------------------------------------------------------------------------------------------- */
+int capmi_logsoftmax_select(const float *logits, int N, int V1, int step, int L,
+                            int mode, const uint8_t *row_mode, float temperature,
+                            const float *gumbel, uint64_t seed,
+                            const int64_t *forced, int forced_ld, int no_finish_mask,
+                            int64_t *seq, int seq_ld, int64_t *it_next, uint8_t *unfinished,
+                            float *seq_logp, float *sel_logp, uint8_t *live, void *stream);
+
+/* gradient of the dense log-probs w.r.t. the logits for ALL steps at once:
+ *   dlogits[r,t,:] = g[r,t,:] - exp(logp[r,t,:]) * sum_v g[r,t,v]      (rows where logp was masked
+ *   to zero receive zero: `live` [N,L] uint8, 1 = the row was live when step t was produced) */
+/* g, seq_logp are [N,L,V1]; only steps t < T are produced; dlogits is written TIME-MAJOR
+ * [T,N,V1] so that it lines up with the saved [T,N,...] activations for the batched GEMMs. */
+int capmi_logsoftmax_bwd(const float *g, const float *seq_logp, const uint8_t *live, float *dlogits,
+                         int N, int L, int T, int V1, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Elementwise helpers
+ * ------------------------------------------------------------------------------------------- */
+/* out = sum_s partial[s] (+bias +bias2) then relu / mask (split-K reduce with the GEMM epilogue) */
+int capmi_splitk_reduce(const float *partial, int splits, float *C, int ldc, int M, int N,
+                        const float *bias, const float *bias2, const float *row_bias, int row_bias_div,
+                        const float *mul_mask, int relu, int accumulate, void *stream);
+/* Bernoulli keep-masks scaled by 1/(1-p): mask[i] in {0, 1/(1-p)}; Philox4x32-10(seed, offset+i) */
+int capmi_dropout_mask(float *mask, int64_t count, float p, uint64_t seed, uint64_t offset, void *stream);
+/* out[c] = sum_r in[r*ld + c]  (bias gradients) ; accumulate optional */
+int capmi_colsum(const float *in, int rows, int cols, int ld, float *out, int accumulate, void *stream);
+/* out[g, c] = sum_{j<group} in[(g*group + j)*cols + c], summed over T slabs of stride slab */
+int capmi_group_rowsum(const float *in, int T, int64_t slab, int groups, int group, int cols,
+                       float *out, void *stream);
+/* y = x * (m ? m : 1) * (gate_on_positive && ref<=0 ? 0 : 1): relu/dropout backward */
+int capmi_relu_mask_bwd(const float *dy, const float *y_ref, const float *mask, float *dx, int64_t count,
+                        void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused value-clip + Adam on one flat fp32 buffer (torch.nn.utils.clip_grad_value_ train.py:194-195
+ * + torch.optim.Adam misc.py:125-126; the flat buffer is also what the single RCCL all-reduce moves).
+ *   g = clamp(g * grad_scale, -clip, clip) (clip <= 0: none);  m,v,p updated with bias correction.
+ * ------------------------------------------------------------------------------------------- */
+int capmi_adam_step(float *p, const float *g, float *m, float *v, int64_t count, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, float clip, float grad_scale, int step,
+                    void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * CIDEr-D reward (external pyciderevalcap.ciderD -- see oracle/ciderd.py for the provenance note;
+ * call sites rewards.py:41-81, 83-114).  float64 arithmetic on device.
+ *   table: open-addressing hash of the document-frequency pickle; keys = n-gram of <= 4 token ids
+ *          packed as 4 x 16-bit (id+1), vals = document count (double); capacity power of two;
+ *          empty slot key = 0.
+ *   hyp   [H, L] int64 token rows (cut after the first 0, which is kept: rewards.py:33-39)
+ *   refs  [B, max_refs, ref_w] int32, n_refs [B]; hypothesis h scores against image hyp_img[h]
+ *   scores[H] double = 10 * mean_k( sum_refs sim_k ) / n_refs
+ * ------------------------------------------------------------------------------------------- */
+int capmi_ciderd_score(const int64_t *hyp, int H, int L, const int32_t *hyp_img,
+                       const int32_t *refs, const int32_t *n_refs, int max_refs, int ref_w,
+                       const uint64_t *table_keys, const double *table_vals, uint32_t table_cap,
+                       double log_ref_len, double *scores, void *stream);
+/* advantage + broadcast (rewards.py:76-79): reward[r] = scores[r] - scores[N + r/n]  (float32 [N]) */
+int capmi_scst_advantage(const double *scores, int N, int n, float *reward, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole-rollout drivers for the UpDown decoder (AttModel._sample AttModel.py:258-352 and
+ * AttModel._forward :126-164 with UpDownCore :615-640).  One host call enqueues every kernel of all
+ * T steps on `stream` with no host synchronisation: the reference's per-step
+ * `.sum()==0` syncs are replaced by on-device finished flags.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct capmi_updown_weights {
+    const float *embed;                                /* [V1,E]   embed.0.weight */
+    const float *att_w_ih, *att_w_hh, *att_b_ih, *att_b_hh;   /* core.att_lstm.*  [4R,2R+E],[4R,R] */
+    const float *lang_w_ih, *lang_w_hh, *lang_b_ih, *lang_b_hh; /* core.lang_lstm.* [4R,2R],[4R,R] */
+    const float *h2att_w, *h2att_b;                    /* [A,R],[A] */
+    const float *alpha_w, *alpha_b;                    /* [A],[1]   */
+    const float *logit_w, *logit_b;                    /* [V1,R],[V1] */
+} capmi_updown_weights;
+
+typedef struct capmi_updown_rollout {
+    /* sizes */
+    int B, n, N, K, A, R, E, V1;
+    int T;                  /* steps to run */
+    int L;                  /* step pitch of seq / seq_logp / sel_logp / live (>= T) */
+    /* per-image prepared features (outputs of the prefill GEMMs) */
+    const float *fc;        /* [B,R]   */
+    const float *att;       /* [B,K,R] */
+    const float *p_att;     /* [B,K,A] */
+    const float *att_mask;  /* [B,K] or NULL */
+    /* randomness / control */
+    const float *drop_xt;   /* [T,N,E] pre-scaled keep masks or NULL (eval) */
+    const float *drop_out;  /* [T,N,R] or NULL */
+    int mode;               /* 0 greedy, 1 sample, 2 forced */
+    const uint8_t *row_mode;/* optional per-row override */
+    float temperature;
+    const float *gumbel;    /* [T,N,V1] injected noise or NULL (=> Philox(seed)) */
+    uint64_t seed;
+    const int64_t *forced;  /* [N, forced_ld] */
+    int forced_ld;
+    int teacher;            /* 1: _forward semantics: inputs are forced[:,t], nothing masked */
+    /* state + saved activations, all [T+1,N,R] with slot 0 = initial zeros */
+    float *h_att, *c_att, *h_lang, *c_lang;
+    float *xt;              /* [T,N,E]  */
+    int64_t *it_all;        /* [T,N]    token fed at each step */
+    float *gates_att;       /* [T,N,4R] activated */
+    float *gates_lang;      /* [T,N,4R] */
+    float *att_h;           /* [T,N,A]  */
+    float *alpha;           /* [T,N,K]  */
+    float *ctx;             /* [T,N,R]  */
+    float *h_drop;          /* [T,N,R]  h_lang after dropout (logit input) */
+    /* outputs */
+    int64_t *seq;           /* [N,L]   */
+    float *seq_logp;        /* [N,L,V1] dense */
+    float *sel_logp;        /* [N,L]   */
+    uint8_t *live;          /* [N,L]   1 if row was unfinished when step t was computed */
+    /* scratch */
+    float *fc_gates;        /* [B,4R]  fc-term of the attention LSTM, computed once */
+    float *logits;          /* [N,V1]  */
+    int64_t *it;            /* [N]     */
+    uint8_t *unfinished;    /* [N]     */
+    float *partial;         /* split-K workspace */
+    int64_t partial_capacity;
+} capmi_updown_rollout;
+
+int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout *r, void *stream);
+
+typedef struct capmi_updown_grads {
+    float *embed;
+    float *att_w_ih, *att_w_hh, *att_b_ih, *att_b_hh;
+    float *lang_w_ih, *lang_w_hh, *lang_b_ih, *lang_b_hh;
+    float *h2att_w, *h2att_b;
+    float *alpha_w, *alpha_b;
+    float *logit_w, *logit_b;
+    float *d_fc;       /* [B,R]   gradient w.r.t. prepared fc   */
+    float *d_att;      /* [B,K,R] gradient w.r.t. prepared att (attention path only) */
+    float *d_p_att;    /* [B,K,A] */
+} capmi_updown_grads;
+
+typedef struct capmi_updown_bwd_scratch {
+    float *dlogits;     /* [T,N,V1]  time-major */
+    float *d_hdrop;     /* [T,N,R]     */
+    float *dg_att;      /* [T,N,4R]    */
+    float *dg_lang;     /* [T,N,4R]    */
+    float *d_x2;        /* [T,N,3R]  per step (d_ctx | dh_att | dh_lang_prev) = dg_lang [W_ih | W_hh] */
+    float *d_e_all;     /* [T,N,K]     */
+    float *d_att_h_all; /* [T,N,A]     */
+    float *dh_att_attn; /* [N,R]       */
+    float *d_x1;        /* [T,N,2R]  per step (dh_lang_prev | dh_att_prev) = dg_att [W_ih[:, :R] | W_hh] */
+    float *dc_att, *dc_lang;   /* [2][N,R] ping-pong */
+    float *d_xt_all;    /* [T,N,E]     */
+    float *sum_dg_att;  /* [B,4R]      */
+    float *partial;
+    int64_t partial_capacity;
+} capmi_updown_bwd_scratch;
+
+/* g_seq_logp [N,T,V1]: gradient w.r.t. the dense log-probs returned by the forward. */
+int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_rollout *r,
+                             const float *g_seq_logp, capmi_updown_bwd_scratch *s,
+                             capmi_updown_grads *g, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPMI_H */

@@ -1,0 +1,232 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point against a plain PyTorch fp32/fp64
+reference of the same op (the oracle functions where one exists)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def ops_mod():
+    from imagecaptioning.pytorch_amd import ops
+    return ops
+
+
+def rel_err(a, b):
+    a = a.double().cpu()
+    b = b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize('M,N,K', [(3, 5, 7), (10, 4000, 1000), (50, 512, 1000), (64, 64, 32), (50, 9488, 1000),
+                                   (360, 1000, 2048), (130, 257, 100), (1000, 1000, 9488)])
+def test_gemm_nt_linear(dev, M, N, K):
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    mask = (torch.rand(M, N, generator=g) < 0.5).float() * 2
+    ref = torch.relu(x.double() @ w.double().t() + b.double()) * mask.double()
+    out = ops.linear(x.to(dev), w.to(dev), b.to(dev), relu=True, mul_mask=mask.to(dev))
+    assert rel_err(out, ref) < 2e-6
+
+
+def test_gemm_multisegment_rowdiv_and_deferred_partials(dev):
+    """[h | fc(row//n) | x] x [W0 | W1 | W2] with split-K partials consumed by the LSTM-cell kernel."""
+    ops = ops_mod()
+    from oracle import att_lstm as O
+    g = torch.Generator().manual_seed(5)
+    B, n, R, E = 4, 3, 40, 24
+    N = B * n
+    h = torch.randn(N, R, generator=g)
+    fc = torch.randn(B, R, generator=g)
+    x = torch.randn(N, E, generator=g)
+    W_ih = torch.randn(4 * R, 2 * R + E, generator=g) * 0.2
+    W_hh = torch.randn(4 * R, R, generator=g) * 0.2
+    b_ih, b_hh = torch.randn(4 * R, generator=g), torch.randn(4 * R, generator=g)
+    hp, cp = torch.randn(N, R, generator=g), torch.randn(N, R, generator=g)
+    x1 = torch.cat([h, fc.repeat_interleave(n, 0), x], 1)
+    h_ref, c_ref = O.lstm_cell(x1, hp, cp, W_ih, W_hh, b_ih, b_hh)
+    d = lambda t: t.to(dev)                                   # noqa: E731
+    Wd, Whd = d(W_ih), d(W_hh)
+    ws = ops.Workspace(dev, 1 << 20)
+    segs = [(d(h), R, Wd, 2 * R + E, R, 1), (d(fc), R, (Wd, R), 2 * R + E, R, n), (d(x), E, (Wd, 2 * R), 2 * R + E, E, 1),
+            (d(hp), R, Whd, R, R, 1)]
+    splits = ops.gemm(segs, N, 4 * R, ws.buf, ws=ws, splits=3, defer_reduce=True)
+    assert splits == 3
+    hh, cc, gates, _ = ops.lstm_cell_fwd(ws.buf, splits, d(b_ih), d(b_hh), d(cp))
+    assert rel_err(hh, h_ref) < 2e-6 and rel_err(cc, c_ref) < 2e-6
+
+
+@pytest.mark.parametrize('M,N,K', [(50, 2000, 4000), (7, 9, 11), (1000, 1000, 9488), (10, 1000, 4000)])
+def test_gemm_nn(dev, M, N, K):
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(K, N, generator=g) * 0.1
+    out = ops.matmul_nn(a.to(dev), b.to(dev))
+    assert rel_err(out, a.double() @ b.double()) < 2e-6
+
+
+@pytest.mark.parametrize('M,N,K', [(4000, 3000, 1000), (13, 6, 9), (9488, 1000, 1000), (4000, 1000, 10)])
+def test_gemm_tn(dev, M, N, K):
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(K, M, generator=g)
+    b = torch.randn(K, N, generator=g) * 0.1
+    out = ops.matmul_tn(a.to(dev), b.to(dev))
+    assert rel_err(out, a.double().t() @ b.double()) < 2e-6
+
+
+@pytest.mark.parametrize('B,n,K,A,R,masked', [(3, 2, 6, 12, 16, True), (10, 5, 36, 512, 1000, False),
+                                              (2, 11, 9, 20, 31, True), (64, 1, 36, 512, 1000, False)])
+def test_attention_fwd_bwd(dev, B, n, K, A, R, masked):
+    ops = ops_mod()
+    from oracle import att_lstm as O
+    g = torch.Generator().manual_seed(B + K)
+    N = B * n
+    P = {'core.attention.h2att.weight': torch.zeros(A, R), 'core.attention.h2att.bias': torch.zeros(A),
+         'core.attention.alpha_net.weight': torch.randn(1, A, generator=g) * 0.3,
+         'core.attention.alpha_net.bias': torch.randn(1, generator=g)}
+    att_h = torch.randn(N, A, generator=g, requires_grad=True)
+    p_att = torch.randn(B, K, A, generator=g, requires_grad=True)
+    att = torch.randn(B, K, R, generator=g, requires_grad=True)
+    mask = None
+    if masked:
+        mask = torch.ones(B, K)
+        mask[0, K - 2:] = 0
+        mask[B - 1, K - 1:] = 0
+    # oracle with att_h injected: h2att(h)=att_h when W=0,b=att_h is per-row -> use the formula directly
+    dot = torch.tanh(p_att.repeat_interleave(n, 0) + att_h.unsqueeze(1))
+    e = dot @ P['core.attention.alpha_net.weight'].reshape(-1) + P['core.attention.alpha_net.bias']
+    al = torch.softmax(e, 1)
+    if mask is not None:
+        mm = mask.repeat_interleave(n, 0)
+        al = al * mm
+        al = al / al.sum(1, keepdim=True)
+    ctx_ref = torch.bmm(al.unsqueeze(1), att.repeat_interleave(n, 0)).squeeze(1)
+    d = lambda t: None if t is None else t.detach().to(dev).contiguous()   # noqa: E731
+    w = d(P['core.attention.alpha_net.weight'].reshape(-1))
+    ctx, alpha = ops.attention_fwd(d(att_h), d(p_att), d(att), d(mask), w, d(P['core.attention.alpha_net.bias']), n)
+    assert rel_err(alpha, al) < 5e-6 and rel_err(ctx, ctx_ref) < 5e-6
+    d_ctx = torch.randn(N, R, generator=g)
+    ctx_ref.backward(d_ctx)
+    d_att_h, d_e = ops.attention_bwd(d(d_ctx), d(att_h), alpha, d(p_att), d(att), d(mask), w, n)
+    assert rel_err(d_att_h, att_h.grad) < 2e-5
+    # time-batched pass with T = 1
+    d_att, d_p_att, d_w, d_b = ops.attention_bwd_batched(d(d_ctx).view(1, N, R), d(att_h).view(1, N, A),
+                                                         alpha.view(1, N, K), d_e.view(1, N, K), d(p_att), w, n, R)
+    assert rel_err(d_att, att.grad) < 2e-5
+    assert rel_err(d_p_att, p_att.grad) < 2e-5
+
+
+def test_lstm_cell_bwd(dev):
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(3)
+    N, R = 7, 33
+    gates_pre = torch.randn(N, 4 * R, generator=g, requires_grad=True)
+    c_prev = torch.randn(N, R, generator=g, requires_grad=True)
+    i, f, gg, o = gates_pre.chunk(4, 1)
+    c_new = torch.sigmoid(f) * c_prev + torch.sigmoid(i) * torch.tanh(gg)
+    h_new = torch.sigmoid(o) * torch.tanh(c_new)
+    dh, dc = torch.randn(N, R, generator=g), torch.randn(N, R, generator=g)
+    (h_new * dh).sum().add((c_new * dc).sum()).backward()
+    d = lambda t: t.detach().to(dev).contiguous()              # noqa: E731
+    hh, cc, gates, _ = ops.lstm_cell_fwd(d(gates_pre), 1, None, None, d(c_prev))
+    assert rel_err(hh, h_new) < 2e-6
+    dg, dcp = ops.lstm_cell_bwd(d(dh), d(dc), gates, d(c_prev), cc)
+    assert rel_err(dg, gates_pre.grad) < 5e-6 and rel_err(dcp, c_prev.grad) < 5e-6
+
+
+def test_logsoftmax_select_modes(dev):
+    from imagecaptioning.pytorch_amd import _lib
+    from imagecaptioning.pytorch_amd._lib import lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(4)
+    N, V1, L = 6, 9488, 3
+    logits = torch.randn(N, V1, generator=g) * 3
+    logits[2, 100] = logits[2, 7000] = 50.0            # exact tie -> lowest index
+    gum = -torch.log(-torch.log(torch.rand(N, V1, generator=g).clamp_min(1e-20)))
+    ld = logits.to(dev)
+    ref_lp = torch.log_softmax(logits.double(), 1)
+    for mode, temp in ((0, 1.0), (1, 0.8)):
+        seq = torch.zeros(N, L, dtype=torch.long, device=dev)
+        it = torch.zeros(N, dtype=torch.long, device=dev)
+        unf = torch.ones(N, dtype=torch.uint8, device=dev)
+        unf[4] = 0                                        # a finished row at step 1
+        slp = torch.zeros(N, L, V1, device=dev)
+        sel = torch.zeros(N, L, device=dev)
+        live = torch.zeros(N, L, dtype=torch.uint8, device=dev)
+        _lib.check(lib.capmi_logsoftmax_select(ptr(ld), N, V1, 1, L, mode, None, temp, ptr(gum.to(dev)) if mode else None, 0,
+                                               None, 0, 0, ptr(seq), L, ptr(it), ptr(unf), ptr(slp), ptr(sel), ptr(live),
+                                               stream_ptr()), 'select')
+        torch.cuda.synchronize()
+        if mode == 0:
+            want = torch.max(logits, 1)[1]
+            assert int(want[2]) == 100
+        else:
+            want = torch.max(ref_lp.float() / temp + gum, 1)[1]
+        want = want.clone()
+        want[4] = 0
+        assert torch.equal(seq[:, 1].cpu(), want)
+        assert torch.equal(it.cpu(), want)
+        got = slp[:, 1].cpu().double()
+        assert float((got[[0, 1, 2, 3, 5]] - ref_lp[[0, 1, 2, 3, 5]]).abs().max()) < 2e-5
+        assert float(got[4].abs().max()) == 0.0
+        assert live[:, 1].cpu().tolist() == [1, 1, 1, 1, 0, 1]
+        exp_unf = [(1 if (int(want[i]) != 0 and i != 4) else 0) for i in range(N)]
+        assert unf.cpu().tolist() == exp_unf
+
+
+def test_philox_sampling_matches_distribution(dev):
+    """In-kernel Gumbel-max sampling draws from softmax(logp/T) (CaptionModel.py:405)."""
+    from imagecaptioning.pytorch_amd import _lib
+    from imagecaptioning.pytorch_amd._lib import lib, ptr, stream_ptr
+    V1, N = 16, 4096
+    logits = torch.log_softmax(torch.randn(1, V1, generator=torch.Generator().manual_seed(9)), 1).repeat(N, 1)
+    T = 0.7
+    ld = logits.to(dev)
+    seq = torch.zeros(N, 1, dtype=torch.long, device=dev)
+    it = torch.zeros(N, dtype=torch.long, device=dev)
+    unf = torch.ones(N, dtype=torch.uint8, device=dev)
+    counts = torch.zeros(V1)
+    for s in range(8):
+        _lib.check(lib.capmi_logsoftmax_select(ptr(ld), N, V1, 0, 1, 1, None, T, None, 1234 + s, None, 0, 0, ptr(seq), 1,
+                                               ptr(it), ptr(unf), None, None, None, stream_ptr()), 'select')
+        counts += torch.bincount(seq[:, 0].cpu(), minlength=V1).float()
+    freq = counts / counts.sum()
+    want = torch.softmax(logits[0] / T, 0)
+    assert float((freq - want).abs().max()) < 0.01
+
+
+def test_adam_matches_torch(dev):
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(6)
+    n = 1003
+    p0 = torch.randn(n, generator=g)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=5e-4, betas=(0.9, 0.999), eps=1e-8)
+    p = p0.to(dev)
+    m, v = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g) * 0.3
+        p_ref.grad = gr.clamp(-0.1, 0.1)
+        opt.step()
+        ops.adam_step(p, gr.to(dev), m, v, 5e-4, 0.9, 0.999, 1e-8, 0.0, 0.1, 1.0, step)
+    assert rel_err(p, p_ref.detach()) < 1e-6
+
+
+def test_dropout_mask_rate(dev):
+    ops = ops_mod()
+    m = ops.dropout_mask((1000, 1000), 0.5, 7, 0, dev)
+    vals = torch.unique(m).cpu().tolist()
+    assert vals == [0.0, 2.0]
+    assert abs(float((m > 0).float().mean()) - 0.5) < 5e-3
+    m2 = ops.dropout_mask((1000, 1000), 0.5, 7, 0, dev)
+    assert torch.equal(m, m2)
