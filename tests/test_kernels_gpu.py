@@ -35,7 +35,7 @@ def test_gemm_nt_linear(dev, M, N, K):
     mask = (torch.rand(M, N, generator=g) < 0.5).float() * 2
     ref = torch.relu(x.double() @ w.double().t() + b.double()) * mask.double()
     out = ops.linear(x.to(dev), w.to(dev), b.to(dev), relu=True, mul_mask=mask.to(dev))
-    assert rel_err(out, ref) < 2e-6
+    assert rel_err(out, ref) < (2e-6 if K <= 4096 else 6e-6)
 
 
 def test_gemm_multisegment_rowdiv_and_deferred_partials(dev):
@@ -72,7 +72,7 @@ def test_gemm_nn(dev, M, N, K):
     a = torch.randn(M, K, generator=g)
     b = torch.randn(K, N, generator=g) * 0.1
     out = ops.matmul_nn(a.to(dev), b.to(dev))
-    assert rel_err(out, a.double() @ b.double()) < 2e-6
+    assert rel_err(out, a.double() @ b.double()) < (2e-6 if K <= 4096 else 6e-6)
 
 
 @pytest.mark.parametrize('M,N,K', [(4000, 3000, 1000), (13, 6, 9), (9488, 1000, 1000), (4000, 1000, 10)])
@@ -82,7 +82,7 @@ def test_gemm_tn(dev, M, N, K):
     a = torch.randn(K, M, generator=g)
     b = torch.randn(K, N, generator=g) * 0.1
     out = ops.matmul_tn(a.to(dev), b.to(dev))
-    assert rel_err(out, a.double().t() @ b.double()) < 2e-6
+    assert rel_err(out, a.double().t() @ b.double()) < (2e-6 if K <= 4096 else 6e-6)
 
 
 @pytest.mark.parametrize('B,n,K,A,R,masked', [(3, 2, 6, 12, 16, True), (10, 5, 36, 512, 1000, False),
