@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- captions/sec of the UpDown SCST training step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one full SCST iteration per GPU on a synthetic batch (configs[2]: bs 10 x train_sample_n 5,
+36x2048 region features, seq_len 20, vocab 9487): greedy rollout + sampled rollout (dropout on) +
+CIDEr-D reward + RewardCriterion + BPTT + (1 RCCL all-reduce of the flat gradient if N > 1) + value
+clip 0.1 + Adam.  Inputs are resident in HBM before the timed region.  Weak scaling: every rank runs its
+own 10 images.  Prints ONE JSON line (rank 0).
+
+Extra objects on the line:
+  roofline      dominant kernel (skinny weight-streaming MFMA GEMM of the decode step): algorithmic bytes
+                / average launch duration from HIP events recorded inside the timed region
+  attention     the same for the fused region-attention kernel named by north_star
+  cpu_baseline  the oracle's SCST iteration (oracle/scst_step.py, kind "port") on this box's host cores
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
+F32_MFMA_PEAK_TF = 157.3
+
+
+def prof_read(lib, cls):
+    ms, n, b, f = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+    rc = lib.capmi_prof_read(cls, C.byref(ms), C.byref(n), C.byref(b), C.byref(f))
+    assert rc == 0, rc
+    return ms.value, n.value, b.value, f.value
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prof', action='store_true', help='do not bracket kernels with HIP events (for rocprofv3 runs)')
+    ap.add_argument('--cpu-iters', type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('--gpus %d needs torch.distributed.run with %d processes' % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)     # nccl == RCCL on ROCm (xGMI)
+
+    from imagecaptioning.pytorch_amd import synthetic, _lib
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd.captioning.modules.loss_wrapper import LossWrapper
+    from imagecaptioning.pytorch_amd.captioning.utils import rewards
+    lib = _lib.lib
+
+    opt = synthetic.updown_opt()
+    torch.manual_seed(1234)                       # identical initial weights on every rank
+    model = models.setup(opt).to(dev)
+    flat = model.flatten_parameters_()
+    lw = LossWrapper(model, opt)
+    B, n, L = args.batch, opt.train_sample_n, opt.max_length
+    fc, att = synthetic.batch(B, seed=1234 + rank, device=dev)
+    corpus = synthetic.corpus(2000, seed=7)       # DF table: 2000 synthetic "images" x 5 refs
+    df, ref_len = synthetic.document_frequency(corpus)
+    rewards.reset_scorer()
+    rewards.init_scorer((df, ref_len), device=dev)
+    gts = synthetic.corpus(B, seed=100 + rank)
+    gt_indices = torch.arange(B)
+    labels = masks = None
+
+    def step():
+        out = lw(fc, att, labels, masks, None, gts, gt_indices, True, False, False)
+        loss = out['loss'].mean()
+        flat.zero_grad()
+        loss.backward()
+        flat.collect_grads()
+        scale = flat.all_reduce() if world > 1 else 1.0      # ONE collective over the flat fp32 gradient
+        flat.adam_step(opt.learning_rate, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
+                       clip_value=opt.grad_clip_value, grad_scale=scale)
+        return loss
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    lib.capmi_prof_reset()
+    lib.capmi_prof_enable(0 if args.no_prof else 1)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    lib.capmi_prof_enable(0)
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    captions = B * n * world * args.steps
+    value = captions / dt
+
+    if rank == 0:
+        g_ms, g_n, g_bytes, g_flops = prof_read(lib, 0)
+        a_ms, a_n, a_bytes, _ = prof_read(lib, 3)
+        per_class = {}
+        names = ['gemm_decode', 'gemm_bptt', 'gemm_fat', 'attention_fwd', 'attention_bwd', 'select', 'lstm_cell', 'ciderd',
+                 'adam']
+        for i, nm in enumerate(names):
+            ms, cnt, by, fl = prof_read(lib, i)
+            per_class[nm] = {'ms_per_step': round(ms / args.steps, 4), 'launches_per_step': cnt / args.steps}
+        ach = (g_bytes / g_n) / (g_ms / g_n * 1e-3) / 1e9 if g_n else 0.0
+        roofline = {'kernel': 'gemm_f32 (decode-step weight streaming, M<=64, v_mfma_f32_32x32x2_f32)', 'bound': 'hbm',
+                    'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+                    'traffic': None, 'avg_launch_us': round(g_ms / max(g_n, 1) * 1e3, 2),
+                    'algorithmic_bytes_per_launch': round(g_bytes / max(g_n, 1)),
+                    'mfma_tflops': round(g_flops / (g_ms * 1e-3) / 1e12, 2) if g_ms else 0.0}
+        a_ach = (a_bytes / a_n) / (a_ms / a_n * 1e-3) / 1e9 if a_n else 0.0
+        attention = {'kernel': 'attention_fwd (fused score+softmax+context, one workgroup per image)', 'bound': 'hbm',
+                     'achieved': round(a_ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(a_ach / HBM_PEAK_GBS, 4), 'avg_launch_us': round(a_ms / max(a_n, 1) * 1e3, 2),
+                     'algorithmic_bytes_per_launch': round(a_bytes / max(a_n, 1)),
+                     'note': 'bs10 x n5: 2.4 MB unique bytes per launch is below the HBM bandwidth-delay product; '
+                             'see DESIGN.md for the large-batch figure'}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(opt, model, B, n, L, args.cpu_iters)
+        line = {
+            'metric': 'captions/sec/node (UpDown SCST, bs10xsample_n5, 36x2048 feats)', 'value': round(value, 2),
+            'unit': 'captions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'UpDown SCST (BASELINE configs[2]): per-GPU batch 10 x train_sample_n 5, 36x2048 '
+                                   'bottom-up feats, R=E=1000 A=512, vocab 9487, seq_len 20, greedy baseline + CIDEr-D + '
+                                   'RewardCriterion + BPTT + clip 0.1 + Adam',
+                       'global_batch': B * world, 'captions_per_step': B * n * world, 'seq_len': L,
+                       'parallelism': 'dp%d (1 flat-gradient RCCL all-reduce/step)' % world},
+            'loss': float(loss.detach()), 'roofline': roofline, 'attention': attention, 'kernel_ms_per_step': per_class,
+            'cpu_baseline': cpu}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(opt, model, B, n, L, iters):
+    """The oracle's SCST iteration (a port of the reference's CPU path) on this box's host cores: a
+    bounded sample of the SAME workload (bs10 x n5, L=20), 1 warm-up + `iters` timed iterations."""
+    from oracle import scst_step, ciderd as OC
+    from imagecaptioning.pytorch_amd import synthetic
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    corpus = synthetic.corpus(2000, seed=7)
+    df, ref_len = synthetic.document_frequency(corpus)
+    oracle = scst_step.ScstOracle(P, OC.CiderD(df, ref_len), drop_prob=opt.drop_prob_lm, lr=opt.learning_rate,
+                                  clip=opt.grad_clip_value, sample_n=n, max_len=L)
+    fc, att = synthetic.batch(B, seed=1234)
+    gts = synthetic.corpus(B, seed=100)
+    sec = scst_step.time_iterations(oracle, fc, att, gts, iters=iters, warmup=1)
+    return {'value': round(B * n / sec, 2), 'unit': 'captions/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d timed SCST iterations (bs%d x n%d, L=%d) of oracle/scst_step.py after 1 warm-up, median; '
+                      'torch fp32 on %d threads' % (iters, B, n, L, cores), 'sec_per_iteration': round(sec, 3)}
+
+
+if __name__ == '__main__':
+    main()

@@ -85,6 +85,9 @@ SIGNATURES = {
     'capmi_adam_step': [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _I, _P],
     'capmi_ciderd_score': [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, C.c_uint32, C.c_double, _P, _P],
     'capmi_scst_advantage': [_P, _I, _I, _P, _P],
+    'capmi_prof_enable': [_I],
+    'capmi_prof_reset': [],
+    'capmi_prof_read': [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     'capmi_updown_rollout_fwd': [C.POINTER(UpDownWeights), C.POINTER(UpDownRollout), _P],
     'capmi_updown_rollout_bwd': [C.POINTER(UpDownWeights), C.POINTER(UpDownRollout), _P, C.POINTER(UpDownBwdScratch),
                                  C.POINTER(UpDownGrads), _P],

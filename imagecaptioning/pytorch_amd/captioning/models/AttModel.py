@@ -1,0 +1,246 @@
+"""AttModel / UpDownModel on the MI355X HIP backend.
+
+Drop-in for the reference's captioning/models/AttModel.py for the hot path: same constructor
+(``opt`` Namespace), same parameter tree (=> same ``state_dict`` keys/shapes),
+same call surface:
+
+    model(fc_feats, att_feats, seq, att_masks)                       -> logprobs [N,T,V1]   (_forward, 126-164)
+    model(fc_feats, att_feats, att_masks, opt={...}, mode='sample')  -> (seq [N,L], seqLogprobs [N,L,V1])  (_sample, 258-352)
+    model.get_logprobs_state(it, fc, att, p_att, masks, state)       -> (logprobs, state)   (166-176)
+    model._prepare_feature / init_hidden / embed / core / logit attributes
+
+The nn.Module tree below only *holds parameters* (and gives the reference's default initialisation);
+all arithmetic runs in libcapmi: one native call per rollout, no per-step host sync, no
+repeat_tensors copies, BPTT by hand-written kernels behind one autograd.Function.
+There is no CPU path: tensors must live on a HIP device.
+"""
+import torch
+import torch.nn as nn
+
+from .CaptionModel import CaptionModel
+from ... import updown_engine as engine
+from ... import ops
+from ..._lib import CapmiError
+
+bad_endings = ['a', 'an', 'the', 'in', 'for', 'at', 'of', 'with', 'before', 'after', 'on', 'upon', 'near', 'to', 'is',
+               'are', 'am', 'the']
+
+
+class _RolloutFn(torch.autograd.Function):
+    """(params..., feats) -> (seq, dense seqLogprobs); backward = hand-written BPTT + prefill backward.
+    Gradients are written into the model's flat gradient views when it has them."""
+
+    @staticmethod
+    def forward(ctx, model, cfg, fc_feats, att_feats, att_masks, *params):
+        P = dict(zip(model._param_names, [p.detach() for p in params]))
+        pr = engine.prepare(P, fc_feats, att_feats, att_masks, cfg.get('drop_fc'), cfg.get('drop_att'))
+        ro = engine.Rollout(P, pr, n=cfg['n'], T=cfg['T'], L=cfg['L'], mode=cfg['mode'],
+                            temperature=cfg.get('temperature', 1.0), drop_xt=cfg.get('drop_xt'),
+                            drop_out=cfg.get('drop_out'), gumbel=cfg.get('gumbel'), seed=cfg.get('seed', 0),
+                            forced=cfg.get('forced'), teacher=cfg.get('teacher', False), row_mode=cfg.get('row_mode'))
+        seq, seq_logp = ro.run()
+        ctx.model, ctx.ro, ctx.pr, ctx.P = model, ro, pr, P
+        ctx.mark_non_differentiable(seq)
+        model._last_rollout = ro
+        return seq, seq_logp
+
+    @staticmethod
+    def backward(ctx, _g_seq, g_logp):
+        model, ro, pr, P = ctx.model, ctx.ro, ctx.pr, ctx.P
+        grads = model._grad_targets(P)
+        d_fc, d_att, d_p_att = ro.backward(g_logp, grads)
+        engine.prepare_backward(P, pr, d_fc, d_att, d_p_att, grads)
+        return (None, None, None, None, None) + tuple(grads[k] for k in model._param_names)
+
+
+class Attention(nn.Module):
+    """Parameter holder for Attention (AttModel.py:719-726): h2att, alpha_net."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.h2att = nn.Linear(opt.rnn_size, opt.att_hid_size)
+        self.alpha_net = nn.Linear(opt.att_hid_size, 1)
+
+
+class UpDownCore(nn.Module):
+    """Parameter holder for UpDownCore (AttModel.py:615-622): att_lstm, lang_lstm, attention."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.att_lstm = nn.LSTMCell(opt.input_encoding_size + opt.rnn_size * 2, opt.rnn_size)
+        self.lang_lstm = nn.LSTMCell(opt.rnn_size * 2, opt.rnn_size)
+        self.attention = Attention(opt)
+
+
+class AttModel(CaptionModel):
+    def __init__(self, opt):
+        super().__init__()
+        self.vocab_size = opt.vocab_size
+        self.input_encoding_size = opt.input_encoding_size
+        self.rnn_size = opt.rnn_size
+        self.num_layers = opt.num_layers
+        self.drop_prob_lm = opt.drop_prob_lm
+        self.seq_length = getattr(opt, 'max_length', 20) or opt.seq_length     # AttModel.py:60
+        self.fc_feat_size = opt.fc_feat_size
+        self.att_feat_size = opt.att_feat_size
+        self.att_hid_size = opt.att_hid_size
+        self.bos_idx = getattr(opt, 'bos_idx', 0)
+        self.eos_idx = getattr(opt, 'eos_idx', 0)
+        self.pad_idx = getattr(opt, 'pad_idx', 0)
+        self.unk_idx = getattr(opt, 'unk_idx', None)
+        if (self.bos_idx, self.eos_idx, self.pad_idx) != (0, 0, 0):
+            raise NotImplementedError('capmi kernels assume bos=eos=pad=0 (the reference default, AttModel.py:65-67)')
+        if getattr(opt, 'use_bn', 0):
+            raise NotImplementedError('use_bn is outside the BASELINE configs')
+        if getattr(opt, 'logit_layers', 1) != 1:
+            raise NotImplementedError('logit_layers > 1 is broken in the reference itself (AttModel.py:92)')
+        self.ss_prob = 0.0
+        self.embed = nn.Sequential(nn.Embedding(self.vocab_size + 1, self.input_encoding_size), nn.ReLU(),
+                                   nn.Dropout(self.drop_prob_lm))
+        self.fc_embed = nn.Sequential(nn.Linear(self.fc_feat_size, self.rnn_size), nn.ReLU(), nn.Dropout(self.drop_prob_lm))
+        self.att_embed = nn.Sequential(nn.Linear(self.att_feat_size, self.rnn_size), nn.ReLU(),
+                                       nn.Dropout(self.drop_prob_lm))
+        self.logit = nn.Linear(self.rnn_size, self.vocab_size + 1)
+        self.ctx2att = nn.Linear(self.rnn_size, self.att_hid_size)
+        self.vocab = opt.vocab
+        self.bad_endings_ix = [int(k) for k, v in self.vocab.items() if v in bad_endings]
+        self._flat = None
+        self._rng_calls = 0
+        self._last_rollout = None
+
+    # ------------------------------------------------------------------ parameter plumbing
+    @property
+    def _param_names(self):
+        return [n for n, _ in self.named_parameters()]
+
+    def flatten_parameters_(self):
+        """Move all parameters into one flat buffer (+ flat grads, Adam state).  Call after .cuda()."""
+        from ...flat import FlatParams
+        self._flat = FlatParams(self)
+        return self._flat
+
+    def _grad_targets(self, P):
+        if self._flat is not None:
+            return self._flat.grad_views
+        return {k: torch.empty_like(v) for k, v in P.items()}
+
+    def _device_check(self, t):
+        if not t.is_cuda:
+            raise CapmiError('the capmi backend runs on a HIP device only (got a %s tensor); there is no CPU path'
+                             % t.device.type)
+
+    def init_hidden(self, bsz):
+        w = self.logit.weight
+        return (w.new_zeros(self.num_layers, bsz, self.rnn_size), w.new_zeros(self.num_layers, bsz, self.rnn_size))
+
+    def _next_seed(self):
+        self._rng_calls += 1
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._rng_calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    def _dropout_masks(self, B, K, N, T, dev):
+        """Philox keep-masks for one rollout (dropout is ON in train mode, also while sampling:
+        loss_wrapper.py:63).  Returns dict of pre-scaled masks or {} in eval mode / p == 0."""
+        p = self.drop_prob_lm
+        if not self.training or p <= 0:
+            return {}
+        seed = self._next_seed()
+        R, E = self.rnn_size, self.input_encoding_size
+        return dict(drop_fc=ops.dropout_mask((B, R), p, seed, 0, dev),
+                    drop_att=ops.dropout_mask((B, K, R), p, seed, 1 << 40, dev),
+                    drop_xt=ops.dropout_mask((T, N, E), p, seed, 2 << 40, dev),
+                    drop_out=ops.dropout_mask((T, N, R), p, seed, 3 << 40, dev))
+
+    def _run(self, cfg, fc_feats, att_feats, att_masks):
+        self._device_check(fc_feats)
+        params = [p for _, p in self.named_parameters()]
+        fc_feats = fc_feats.float().contiguous()
+        att_feats = att_feats.float().contiguous()
+        if att_masks is not None:
+            att_masks = att_masks.float().contiguous()
+        return _RolloutFn.apply(self, cfg, fc_feats, att_feats, att_masks, *params)
+
+    # ------------------------------------------------------------------ reference API
+    def _prepare_feature(self, fc_feats, att_feats, att_masks):
+        """AttModel.py:114-124 (eval-mode numerics; training dropout is applied inside the rollouts)."""
+        P = {k: v.detach() for k, v in self.named_parameters()}
+        pr = engine.prepare(P, fc_feats.float().contiguous(), att_feats.float().contiguous(),
+                            None if att_masks is None else att_masks.float())
+        return pr.fc, pr.att, pr.p_att, pr.att_masks
+
+    def _forward(self, fc_feats, att_feats, seq, att_masks=None):
+        """Teacher-forced log-probs [N,T,V1] (AttModel.py:126-164)."""
+        if self.training and self.ss_prob > 0:
+            raise NotImplementedError('scheduled sampling (ss_prob > 0) is inactive in the BASELINE configs')
+        self._device_check(fc_feats)
+        B = fc_feats.size(0)
+        if seq.ndim == 3:
+            seq = seq.reshape(-1, seq.shape[2])
+        seq = seq.long().contiguous()
+        N, T = seq.shape
+        n = N // B
+        # AttModel.py:158-159: stop at the first all-pad column.  The labels are an INPUT, so this is one
+        # host decision per batch made before anything is enqueued, not a per-step sync.
+        colsum = seq[:, 1:].sum(0)
+        zero_cols = (colsum == 0).nonzero()
+        T_eff = int(zero_cols[0]) + 1 if zero_cols.numel() else T
+        K = att_feats.shape[1] if att_masks is None else int(att_masks.long().sum(1).max())
+        cfg = dict(n=n, T=T_eff, L=T, mode='forced', forced=seq, teacher=True)
+        cfg.update(self._dropout_masks(B, K, N, T_eff, fc_feats.device))
+        _, logp = self._run(cfg, fc_feats, att_feats, att_masks)
+        return logp
+
+    def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
+        """Greedy / sampling rollout (AttModel.py:258-352)."""
+        self._device_check(fc_feats)
+        sample_method = opt.get('sample_method', 'greedy')
+        beam_size = opt.get('beam_size', 1)
+        temperature = opt.get('temperature', 1.0)
+        sample_n = int(opt.get('sample_n', 1))
+        group_size = opt.get('group_size', 1)
+        if beam_size > 1 and sample_method in ('greedy', 'beam_search'):
+            return self._sample_beam(fc_feats, att_feats, att_masks, opt)
+        if group_size > 1:
+            raise NotImplementedError('diverse sampling (group_size > 1) is outside the hot-path scope')
+        for k in ('decoding_constraint', 'block_trigrams', 'remove_bad_endings'):
+            if opt.get(k, 0):
+                raise NotImplementedError('%s is not part of the accelerated rollout yet' % k)
+        if not opt.get('output_logsoftmax', 1):
+            raise NotImplementedError('output_logsoftmax=0 is only used by margin structure losses')
+        if sample_method == 'greedy':
+            mode = 'greedy'
+        elif sample_method == 'sample':
+            mode = 'sample'
+        else:
+            raise NotImplementedError('sample_method %r (only greedy / sample / beam_search are accelerated)' % sample_method)
+        B = fc_feats.size(0)
+        N = B * sample_n
+        L = self.seq_length
+        K = att_feats.shape[1] if att_masks is None else int(att_masks.long().sum(1).max())
+        cfg = dict(n=sample_n, T=L, L=L, mode=mode, temperature=temperature, seed=self._next_seed())
+        cfg.update(self._dropout_masks(B, K, N, L, fc_feats.device))
+        forced = opt.get('_forced_seq')           # test hook: teacher-force a sampled sequence
+        if forced is not None:
+            cfg.update(mode='forced', forced=forced.long().contiguous())
+        gumbel = opt.get('_gumbel')               # test hook: injected noise
+        if gumbel is not None:
+            cfg['gumbel'] = gumbel
+        seq, logp = self._run(cfg, fc_feats, att_feats, att_masks)
+        return seq, logp
+
+    def _sample_beam(self, fc_feats, att_feats, att_masks=None, opt={}):
+        from ...beam import sample_beam
+        return sample_beam(self, fc_feats, att_feats, att_masks, opt)
+
+    def get_logprobs_state(self, it, fc_feats, att_feats, p_att_feats, att_masks, state, output_logsoftmax=1):
+        """One decoder step on already prepared features (AttModel.py:166-176); used by beam search."""
+        from ...step import updown_step
+        return updown_step(self, it, fc_feats, att_feats, p_att_feats, att_masks, state, output_logsoftmax)
+
+
+class UpDownModel(AttModel):
+    """AttModel.py:875-879."""
+
+    def __init__(self, opt):
+        super().__init__(opt)
+        self.num_layers = 2
+        self.core = UpDownCore(opt)

@@ -1,0 +1,68 @@
+"""LossWrapper (reference captioning/modules/loss_wrapper.py:18-75): picks XE / SCST / structure
+loss per step.  Same constructor, call signature and output dict.  Differences are all on the
+device side: the SCST reward never leaves HBM (no .cpu().numpy() round trip, rewards.py:48-49)."""
+import torch
+
+from . import losses
+from ..utils.rewards import self_critical_reward_device
+
+
+class LossWrapper(torch.nn.Module):
+    def __init__(self, model, opt):
+        super().__init__()
+        self.opt = opt
+        self.model = model
+        if getattr(opt, 'label_smoothing', 0) > 0:
+            self.crit = losses.LabelSmoothing(smoothing=opt.label_smoothing)
+        else:
+            self.crit = losses.LanguageModelCriterion()
+        self.rl_crit = losses.RewardCriterion()
+        self.struc_crit = losses.StructureLosses(opt) if getattr(opt, 'structure_loss_type', None) else None
+
+    def forward(self, fc_feats, att_feats, labels, masks, att_masks, gts, gt_indices, sc_flag, struc_flag,
+                drop_worst_flag):
+        opt = self.opt
+        out = {}
+        reduction = 'none' if drop_worst_flag else 'mean'
+        if struc_flag:
+            if getattr(opt, 'use_ppo', 0):
+                raise NotImplementedError('PPO loss is out of scope (SURVEY.md 2.1 #12)')
+            w = opt.structure_loss_weight
+            if w < 1:
+                lm_loss = self.crit(self.model(fc_feats, att_feats, labels[..., :-1], att_masks), labels[..., 1:],
+                                    masks[..., 1:], reduction=reduction)
+            else:
+                lm_loss = torch.tensor(0).type_as(fc_feats)
+            if w > 0:
+                gen_result, sample_logprobs = self.model(
+                    fc_feats, att_feats, att_masks,
+                    opt={'sample_method': opt.train_sample_method, 'beam_size': opt.train_beam_size,
+                         'output_logsoftmax': 1, 'sample_n': opt.train_sample_n}, mode='sample')
+                gts = [gts[_] for _ in gt_indices.tolist()]
+                struc_loss = self.struc_crit(sample_logprobs, gen_result, gts, reduction=reduction)
+            else:
+                struc_loss = {'loss': torch.tensor(0).type_as(fc_feats), 'reward': torch.tensor(0).type_as(fc_feats)}
+            loss = (1 - w) * lm_loss + w * struc_loss['loss']
+            out['lm_loss'] = lm_loss
+            out['struc_loss'] = struc_loss['loss']
+            out['reward'] = struc_loss['reward']
+        elif not sc_flag:
+            loss = self.crit(self.model(fc_feats, att_feats, labels[..., :-1], att_masks), labels[..., 1:], masks[..., 1:],
+                             reduction=reduction)
+        else:
+            self.model.eval()
+            with torch.no_grad():
+                greedy_res, _ = self.model(fc_feats, att_feats, att_masks, mode='sample',
+                                           opt={'sample_method': opt.sc_sample_method, 'beam_size': opt.sc_beam_size})
+            self.model.train()
+            gen_result, sample_logprobs = self.model(
+                fc_feats, att_feats, att_masks,
+                opt={'sample_method': opt.train_sample_method, 'beam_size': opt.train_beam_size,
+                     'sample_n': opt.train_sample_n}, mode='sample')
+            gts = [gts[_] for _ in gt_indices.tolist()]
+            adv, _scores = self_critical_reward_device(greedy_res, gts, gen_result, opt)      # [N] on device
+            reward = adv.unsqueeze(1).expand(-1, gen_result.shape[1])
+            loss = self.rl_crit(sample_logprobs, gen_result.data, reward, reduction=reduction)
+            out['reward'] = adv.mean()
+        out['loss'] = loss
+        return out

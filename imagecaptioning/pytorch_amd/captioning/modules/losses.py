@@ -1,0 +1,100 @@
+"""Criteria of the hot path (reference captioning/modules/losses.py).  They consume the dense
+log-prob tensor the model API returns; the arithmetic is a gather + masked mean over [N,L] values
+(K14/K15 of SURVEY.md 2.3) -- device tensor ops on the same HIP stream, no host sync."""
+import torch
+import torch.nn as nn
+
+from ..utils.rewards import get_scores
+
+
+def _shifted_mask(seq, like):
+    """position 0 on, then (seq>0) shifted right: the EOS step still counts (losses.py:28-29)."""
+    m = (seq > 0).to(like)
+    return torch.cat([m.new_ones(m.size(0), 1), m[:, :-1]], 1)
+
+
+class RewardCriterion(nn.Module):
+    """losses.py:18-37."""
+
+    def forward(self, input, seq, reward, reduction='mean'):
+        sel = input.gather(2, seq.unsqueeze(2)).squeeze(2)
+        mask = _shifted_mask(seq, sel)
+        out = -sel * reward.to(sel) * mask
+        if reduction == 'none':
+            return out.sum(1) / mask.sum(1)
+        return out.sum() / mask.sum()
+
+
+class LanguageModelCriterion(nn.Module):
+    """losses.py:204-224."""
+
+    def forward(self, input, target, mask, reduction='mean'):
+        if target.ndim == 3:
+            target = target.reshape(-1, target.shape[2])
+            mask = mask.reshape(-1, mask.shape[2])
+        T = input.size(1)
+        target = target[:, :T]
+        mask = mask[:, :T].to(input)
+        out = -input.gather(2, target.unsqueeze(2)).squeeze(2) * mask
+        if reduction == 'none':
+            return out.sum(1) / mask.sum(1)
+        return out.sum() / mask.sum()
+
+
+class LabelSmoothing(nn.Module):
+    """losses.py:227-265: KL(true_dist || p), off-target mass smoothing/(V1-1)."""
+
+    def __init__(self, size=0, padding_idx=0, smoothing=0.0):
+        super().__init__()
+        self.confidence = 1.0 - smoothing
+        self.smoothing = smoothing
+
+    def forward(self, input, target, mask, reduction='mean'):
+        if target.ndim == 3:
+            target = target.reshape(-1, target.shape[2])
+            mask = mask.reshape(-1, mask.shape[2])
+        N, T, V1 = input.shape
+        target = target[:, :T].reshape(-1)
+        mask = mask[:, :T].reshape(-1).to(input)
+        lp = input.reshape(-1, V1)
+        off = self.smoothing / (V1 - 1)
+        # sum_v q log q is a constant of (smoothing, V1); -sum_v q logp = -off*sum(lp) - (conf-off)*lp[target]
+        ent = (V1 - 1) * (off * torch.log(torch.tensor(off)) if off > 0 else 0.0) + \
+              (self.confidence * torch.log(torch.tensor(self.confidence)) if self.confidence > 0 else 0.0)
+        cross = off * lp.sum(1) + (self.confidence - off) * lp.gather(1, target.unsqueeze(1)).squeeze(1)
+        out = (ent - cross) * mask
+        if reduction == 'none':
+            return out.view(N, T).sum(1) / mask.view(N, T).sum(1)
+        return out.sum() / mask.sum()
+
+
+class StructureLosses(nn.Module):
+    """losses.py:40-202, 'new_self_critical' branch (168-187) only -- the one the *_nsc configs use."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.loss_type = opt.structure_loss_type
+
+    def forward(self, input, seq, data_gts, reduction='mean'):
+        if self.loss_type != 'new_self_critical':
+            raise NotImplementedError('structure_loss_type %r is outside the BASELINE configs' % self.loss_type)
+        if getattr(self.opt, 'entropy_reward_weight', 0) > 0 or getattr(self.opt, 'self_cider_reward_weight', 0) > 0:
+            raise NotImplementedError('entropy / self-cider rewards default to 0 and are out of scope')
+        out = {}
+        N = input.size(0)
+        n = N // len(data_gts)
+        assert n == self.opt.train_sample_n, n
+        sel = input.gather(2, seq.unsqueeze(2)).squeeze(2)
+        mask = _shifted_mask(seq, sel)
+        scores = get_scores(data_gts, seq, self.opt, as_tensor=True).to(sel).view(-1, n)
+        out['reward'] = scores
+        baseline = (scores.sum(1, keepdim=True) - scores) / (scores.shape[1] - 1)
+        adv = scores - baseline
+        output = -sel * mask * adv.reshape(-1, 1)
+        if reduction == 'none':
+            output = output.sum(1) / mask.sum(1)
+        else:
+            output = output.sum() / mask.sum()
+        out['loss'] = output
+        return out

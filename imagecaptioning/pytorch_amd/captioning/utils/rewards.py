@@ -1,0 +1,83 @@
+"""Reward plumbing of SCST (reference captioning/utils/rewards.py), CIDEr-D on the device.
+
+``init_scorer(cached_tokens)`` loads ``data/<cached_tokens>.p`` (scripts/prepro_ngrams.py:79-80) into a
+device hash table once.  ``get_self_critical_reward`` keeps the reference signature and return type
+(np.ndarray [N,L] float64, rewards.py:41-81) for drop-in callers; ``self_critical_reward_device``
+is the sync-free variant our LossWrapper uses (advantage stays in HBM).
+The CIDEr-D arithmetic restates the external pyciderevalcap package: PARITY UNPINNED (oracle/ciderd.py).
+"""
+import os
+
+import numpy as np
+import torch
+
+from ...ciderd import DeviceCiderD
+
+CiderD_scorer = None
+_ref_cache = {}
+
+
+def init_scorer(cached_tokens, device=None):
+    """rewards.py:25-31.  ``cached_tokens``: pickle stem under data/, a path, or (df dict, ref_len)."""
+    global CiderD_scorer
+    if CiderD_scorer is not None:
+        return CiderD_scorer
+    device = device or torch.device('cuda', torch.cuda.current_device())
+    if isinstance(cached_tokens, tuple):
+        CiderD_scorer = DeviceCiderD(cached_tokens[0], cached_tokens[1], device)
+    else:
+        path = cached_tokens if os.path.exists(str(cached_tokens)) else os.path.join('data', cached_tokens + '.p')
+        CiderD_scorer = DeviceCiderD.from_pickle(path, device)
+    return CiderD_scorer
+
+
+def reset_scorer():
+    global CiderD_scorer
+    CiderD_scorer = None
+    _ref_cache.clear()
+
+
+def _pack(data_gts):
+    key = tuple(id(g) for g in data_gts)
+    hit = _ref_cache.get(key)
+    if hit is None:
+        _ref_cache.clear()
+        hit = CiderD_scorer.pack_refs(data_gts)
+        _ref_cache[key] = hit
+    return hit
+
+
+def self_critical_reward_device(greedy_res, data_gts, gen_result, opt):
+    """advantage [N] float32 on device + raw scores [N+B] float64; no host synchronisation."""
+    if getattr(opt, 'bleu_reward_weight', 0) > 0:
+        raise NotImplementedError('BLEU reward (default weight 0, opts.py:185) is out of scope')
+    B = len(data_gts)
+    n = gen_result.shape[0] // B
+    refs, n_refs = _pack(data_gts)
+    reward, scores = CiderD_scorer.self_critical_reward(greedy_res.long().contiguous(), gen_result.long().contiguous(),
+                                                         refs, n_refs, n)
+    w = getattr(opt, 'cider_reward_weight', 1)
+    if w != 1:
+        reward = reward * w
+    return reward, scores
+
+
+def get_self_critical_reward(greedy_res, data_gts, gen_result, opt):
+    """Reference-compatible: np.ndarray [N, L] float64 (rewards.py:41-81)."""
+    reward, scores = self_critical_reward_device(greedy_res, data_gts, gen_result, opt)
+    N = gen_result.shape[0]
+    B = len(data_gts)
+    s = scores.cpu().numpy() * getattr(opt, 'cider_reward_weight', 1)
+    adv = s[:N].reshape(B, N // B) - s[N:][:, None]
+    return np.repeat(adv.reshape(N)[:, None], gen_result.shape[1], 1)
+
+
+def get_scores(data_gts, gen_result, opt, as_tensor=False):
+    """rewards.py:83-114: CIDEr-D of each sampled row (np.ndarray [N], or a device tensor)."""
+    B = len(data_gts)
+    N = gen_result.shape[0]
+    n = N // B
+    refs, n_refs = _pack(data_gts)
+    img = (torch.arange(N, device=gen_result.device) // n).to(torch.int32)
+    scores = CiderD_scorer.score(gen_result.long().contiguous(), img, refs, n_refs) * getattr(opt, 'cider_reward_weight', 1)
+    return scores if as_tensor else scores.cpu().numpy()

@@ -12,6 +12,7 @@
 //   phase 2  wave j normalises row j (K <= a few hundred): shuffle max/sum
 //   phase 3  each lane owns 2 feature columns and streams the K rows of att[b] with 8-byte loads
 #include "capmi_common.h"
+#include "profile.h"
 #include "../../../include/capmi.h"
 
 using namespace capmi;
@@ -294,6 +295,9 @@ int capmi_attention_fwd(const float *att_h, const float *p_att, const float *att
         return CAPMI_EINVAL;
     const size_t lds = ((size_t)NMAX * A + (size_t)NMAX * K) * sizeof(float);
     if (lds > 64 * 1024) return CAPMI_EINVAL;
+    // unique (algorithmic) bytes: image tiles once + per-row att_h in, ctx and alpha out
+    const double abytes = 4.0 * ((double)B * K * (A + R) + (double)B * n * (A + R + K));
+    capmi_prof::Scope prof(CAPMI_PROF_ATTENTION_FWD, (hipStream_t)stream, abytes, (double)B * n * K * (2.0 * A + 2.0 * R));
     hipLaunchKernelGGL(attention_fwd_kernel, dim3(B, (n + NMAX - 1) / NMAX), dim3(ATT_THREADS), lds, (hipStream_t)stream, att_h, p_att, att, mask,
                        w, b, ctx, alpha, n, K, A, R);
     CAPMI_CHECK_LAUNCH();
@@ -308,6 +312,8 @@ int capmi_attention_bwd(const float *d_ctx, int ld_dctx, const float *att_h, con
         return CAPMI_EINVAL;
     const size_t lds = ((size_t)NMAX * R + (size_t)NMAX * K) * sizeof(float);
     if (lds > 64 * 1024) return CAPMI_EINVAL;
+    const double abytes = 4.0 * ((double)B * K * (A + R) + (double)B * n * (2.0 * A + R + 2.0 * K));
+    capmi_prof::Scope prof(CAPMI_PROF_ATTENTION_BWD, (hipStream_t)stream, abytes, (double)B * n * K * (4.0 * A + 2.0 * R));
     hipLaunchKernelGGL(attention_bwd_kernel, dim3(B, (n + NMAX - 1) / NMAX), dim3(ATT_THREADS), lds, (hipStream_t)stream, d_ctx, ld_dctx, att_h, alpha,
                        p_att, att, w, d_att_h, d_e, n, K, A, R);
     CAPMI_CHECK_LAUNCH();

@@ -20,6 +20,7 @@
 //  * multi-segment K loop: [h_lang | xt | h_att] x [W_ih slices | W_hh] are walked in place -- the
 //    reference's torch.cat (AttModel.py:626,632) and repeat_tensors (a_row_div) copies disappear.
 #include "capmi_common.h"
+#include "profile.h"
 #include "../../../include/capmi.h"
 
 namespace {
@@ -341,6 +342,17 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     d->splits_used = splits;
     dim3 grid(gn, gm, splits);
     hipStream_t st = (hipStream_t)stream;
+    // algorithmic traffic of this launch: every operand element once + the output once
+    double ksum = 0, abytes = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        ksum += d->seg[s].K;
+        abytes += (double)d->seg[s].K * ((double)d->M / a.seg[s].a_row_div);
+    }
+    const double bytes = 4.0 * (abytes + ksum * d->N + (double)d->M * d->N);
+    const double flops = 2.0 * d->M * (double)d->N * ksum;
+    const int pcls = (d->M <= 64 && d->a_layout == 0) ? (d->b_layout == 0 ? CAPMI_PROF_GEMM_DECODE : CAPMI_PROF_GEMM_BPTT)
+                                                       : CAPMI_PROF_GEMM_FAT;
+    capmi_prof::Scope prof(pcls, st, bytes, flops);
     int rc;
     if (BM == 32) rc = launch_cfg<32, 128, 1, 4>(a, d->a_layout, d->b_layout, grid, st);
     else if (BM == 64) rc = launch_cfg<64, 64, 2, 2>(a, d->a_layout, d->b_layout, grid, st);

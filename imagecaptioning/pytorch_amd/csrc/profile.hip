@@ -1,0 +1,86 @@
+#include "profile.h"
+#include "../../../include/capmi.h"
+#include <vector>
+#include <mutex>
+
+namespace capmi_prof {
+namespace {
+struct Rec {
+    hipEvent_t a, b;
+};
+struct Cls {
+    std::vector<Rec> recs;
+    double bytes = 0, flops = 0;
+};
+Cls g_cls[CAPMI_PROF_NCLASS];
+std::vector<hipEvent_t> g_pool;
+bool g_on = false;
+std::mutex g_mu;
+hipEvent_t take() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+bool enabled() { return g_on; }
+void begin(int cls, hipStream_t st, double bytes, double flops) {
+    std::lock_guard<std::mutex> l(g_mu);
+    Rec r{take(), take()};
+    (void)hipEventRecord(r.a, st);
+    g_cls[cls].recs.push_back(r);
+    g_cls[cls].bytes += bytes;
+    g_cls[cls].flops += flops;
+}
+void end(int cls, hipStream_t st) {
+    std::lock_guard<std::mutex> l(g_mu);
+    (void)hipEventRecord(g_cls[cls].recs.back().b, st);
+}
+}  // namespace capmi_prof
+
+extern "C" {
+
+int capmi_prof_enable(int on) {
+    capmi_prof::g_on = on != 0;
+    return 0;
+}
+
+int capmi_prof_reset(void) {
+    std::lock_guard<std::mutex> l(capmi_prof::g_mu);
+    for (auto &c : capmi_prof::g_cls) {
+        for (auto &r : c.recs) {
+            capmi_prof::g_pool.push_back(r.a);
+            capmi_prof::g_pool.push_back(r.b);
+        }
+        c.recs.clear();
+        c.bytes = c.flops = 0;
+    }
+    return 0;
+}
+
+int capmi_prof_read(int cls, double *total_ms, int64_t *launches, double *bytes, double *flops) {
+    if (cls < 0 || cls >= CAPMI_PROF_NCLASS) return CAPMI_EINVAL;
+    std::lock_guard<std::mutex> l(capmi_prof::g_mu);
+    auto &c = capmi_prof::g_cls[cls];
+    double ms = 0;
+    for (auto &r : c.recs) {
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e != hipSuccess) return (int)e;
+        float t = 0;
+        e = hipEventElapsedTime(&t, r.a, r.b);
+        if (e != hipSuccess) return (int)e;
+        ms += t;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = (int64_t)c.recs.size();
+    if (bytes) *bytes = c.bytes;
+    if (flops) *flops = c.flops;
+    return 0;
+}
+
+}  // extern "C"

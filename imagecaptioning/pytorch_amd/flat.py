@@ -1,0 +1,68 @@
+"""Flat parameter / gradient storage.
+
+All parameters of a model live in ONE contiguous fp32 device buffer and all gradients in another:
+  * the optimizer step is one fused clip+Adam launch over the flat buffer (capmi_adam_step);
+  * data-parallel training moves the gradient with a SINGLE RCCL all-reduce per step,
+    instead of nn.DataParallel's per-step parameter broadcast + gradient reduce (train.py:86-88);
+  * the BPTT kernels write gradients straight into views of the flat buffer.
+``state_dict()`` is unchanged: every nn.Parameter keeps its name and shape, its storage is a view.
+"""
+import torch
+
+from . import ops
+
+
+class FlatParams:
+    def __init__(self, module):
+        params = [(n, p) for n, p in module.named_parameters()]
+        if not params:
+            raise ValueError('module has no parameters')
+        dev = params[0][1].device
+        self.names = [n for n, _ in params]
+        self.params = [p for _, p in params]
+        sizes = [p.numel() for p in self.params]
+        # 16-byte align every segment so the MFMA loaders can use 16-byte vector loads
+        self.offsets, off = [], 0
+        for s in sizes:
+            self.offsets.append(off)
+            off += (s + 3) // 4 * 4
+        self.total = off
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grad_views = {}
+        for n, p, o in zip(self.names, self.params, self.offsets):
+            view = self.flat[o:o + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            self.grad_views[n] = self.grad[o:o + p.numel()].view_as(p)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.step_count = 0
+
+    def collect_grads(self):
+        """Make the flat gradient buffer authoritative: parameters whose .grad is not already the flat
+        view (e.g. produced by torch autograd ops) are copied in; missing grads become zero."""
+        for n, p in zip(self.names, self.params):
+            v = self.grad_views[n]
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+            p.grad = v
+
+    def all_reduce(self, group=None, world_size=None):
+        """ONE collective for the whole model (RCCL over xGMI when backend == 'nccl'); averages."""
+        import torch.distributed as dist
+        ws = world_size or dist.get_world_size(group)
+        dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+        return 1.0 / ws
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=0.0, grad_scale=1.0):
+        """clip_grad_value_ (train.py:194-195) + Adam (misc.py:125-126) fused, one launch."""
+        self.step_count += 1
+        ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, lr, betas[0], betas[1], eps, weight_decay,
+                      clip_value, grad_scale, self.step_count)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None

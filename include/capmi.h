@@ -222,6 +222,17 @@ int capmi_ciderd_score(const int64_t *hyp, int H, int L, const int32_t *hyp_img,
 int capmi_scst_advantage(const double *scores, int N, int n, float *reward, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Launch instrumentation (counterpart of the reference's `time/batch` prints, train.py:198-208).
+ * When enabled every instrumented launch is bracketed by HIP events on its own stream and its
+ * algorithmic bytes/flops are accumulated; read returns the totals of one kernel class
+ * (0 decode GEMM, 1 BPTT GEMM, 2 fat GEMM, 3 attention fwd, 4 attention bwd, 5 select, 6 LSTM cell,
+ * 7 CIDEr-D, 8 Adam).  capmi_prof_read synchronises on the recorded events.
+ * ------------------------------------------------------------------------------------------- */
+int capmi_prof_enable(int on);
+int capmi_prof_reset(void);
+int capmi_prof_read(int cls, double *total_ms, int64_t *launches, double *bytes, double *flops);
+
+/* ---------------------------------------------------------------------------------------------
  * Whole-rollout drivers for the UpDown decoder (AttModel._sample AttModel.py:258-352 and
  * AttModel._forward :126-164 with UpDownCore :615-640).  One host call enqueues every kernel of all
  * T steps on `stream` with no host synchronisation: the reference's per-step

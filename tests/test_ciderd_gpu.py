@@ -1,0 +1,52 @@
+"""CIDEr-D kernel vs the float64 oracle (oracle/ciderd.py; parity unpinned upstream, see there)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def test_table_roundtrip_cpu_side():
+    from imagecaptioning.pytorch_amd import ciderd as D
+    df = {(1,): 3.0, (1, 2): 2.0, (5, 0): 1.0, (9, 9, 9, 9): 7.0, (0,): 4.0}
+    keys, vals = D.build_table(df)
+    for g, c in df.items():
+        k = np.uint64(D.pack_ngram(g))
+        s = int(D._mix64(np.array([k], dtype=np.uint64))[0] & np.uint64(len(keys) - 1))
+        while keys[s] != k:
+            assert keys[s] != 0
+            s = (s + 1) & (len(keys) - 1)
+        assert vals[s] == c
+
+
+@pytest.mark.parametrize('vocab,L,B,n', [(12, 6, 3, 2), (9487, 20, 10, 5), (50, 16, 7, 1)])
+def test_ciderd_kernel_matches_oracle(vocab, L, B, n):
+    from oracle import ciderd as C
+    from imagecaptioning.pytorch_amd import ciderd as D
+    rng = np.random.default_rng(vocab)
+    corpus = C.synthetic_corpus(300, vocab, 5, L, seed=3)
+    df, ref_len = C.build_document_frequency([[C.tokens_of(r) for r in g] for g in corpus])
+    oracle = C.CiderD(df, ref_len)
+    gts = corpus[:B]
+    N = B * n
+    # hypotheses: mixtures of reference fragments and noise so scores are non-trivial
+    sampled = np.zeros((N, L), dtype=np.int64)
+    for i in range(N):
+        ref = gts[i // n][rng.integers(0, 5)]
+        row = ref.astype(np.int64).copy()
+        flip = rng.random(L) < 0.3
+        row[flip] = rng.integers(0, vocab + 1, size=int(flip.sum()))
+        sampled[i] = row
+    sampled[0] = gts[0][0]                  # exact copy
+    sampled[N - 1, :] = rng.integers(1, vocab + 1, size=L)   # no EOS at all
+    greedy = np.stack([gts[i][1].astype(np.int64) for i in range(B)])
+    greedy[0, 3:] = 0
+    rewards_ref, scores_ref = C.self_critical_reward(oracle, greedy, gts, sampled)
+    dev = D.DeviceCiderD(df, ref_len, DEV)
+    refs, n_refs = dev.pack_refs(gts)
+    reward, scores = dev.self_critical_reward(torch.from_numpy(greedy).to(DEV), torch.from_numpy(sampled).to(DEV), refs,
+                                              n_refs, n)
+    np.testing.assert_allclose(scores.cpu().numpy(), scores_ref, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(reward.cpu().numpy(), rewards_ref[:, 0], rtol=1e-5, atol=1e-6)
+    assert abs(scores_ref[0] - 10.0) < 1e-9 or n_refs[0] > 1
