@@ -38,7 +38,8 @@ class UpDownWeights(C.Structure):
 
 
 class UpDownRollout(C.Structure):
-    _fields_ = ([(k, C.c_int) for k in ('B', 'n', 'N', 'K', 'A', 'R', 'E', 'V1', 'T', 'L')] +
+    _fields_ = ([(k, C.c_int) for k in ('B', 'n', 'N', 'K', 'A', 'R', 'E', 'V1', 'B_feat')] + [('row_img', c_f)] +
+                [(k, C.c_int) for k in ('T', 'L')] +
                 [(k, c_f) for k in ('fc', 'att', 'p_att', 'att_mask', 'drop_xt', 'drop_out')] +
                 [('mode', C.c_int), ('row_mode', c_f), ('temperature', C.c_float), ('gumbel', c_f),
                  ('seed', C.c_uint64), ('forced', c_f), ('forced_ld', C.c_int), ('teacher', C.c_int)] +
@@ -68,10 +69,10 @@ SIGNATURES = {
     'capmi_version': [],
     'capmi_arch': [],
     'capmi_gemm_f32': [C.POINTER(GemmDesc), _P],
-    'capmi_attention_fwd': [_P] * 8 + [_I] * 5 + [_P],
-    'capmi_attention_bwd': [_P, _I] + [_P] * 8 + [_I] * 5 + [_P],
-    'capmi_attention_bwd_batched': [_P, _I] + [_P] * 9 + [_I] * 6 + [_P],
-    'capmi_lstm_cell_fwd': [_P, _I, _P, _P, _P, _I] + [_P] * 6 + [_I, _I, _P],
+    'capmi_attention_fwd': [_P] * 8 + [_I] * 5 + [_P, _I, _P],
+    'capmi_attention_bwd': [_P, _I] + [_P] * 8 + [_I] * 5 + [_P, _I, _P],
+    'capmi_attention_bwd_batched': [_P, _I] + [_P] * 9 + [_I] * 7 + [_P],
+    'capmi_lstm_cell_fwd': [_P, _I, _P, _P, _P, _I, _P] + [_P] * 6 + [_I, _I, _P],
     'capmi_lstm_cell_bwd': [_P, _I, _P, _P, _I, _P, _I] + [_P] * 6 + [_I, _I, _P],
     'capmi_embed_fwd': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P],
     'capmi_embed_bwd': [_P] * 5 + [_I, _I, _I, _P],

@@ -34,10 +34,22 @@ class _RolloutFn(torch.autograd.Function):
     def forward(ctx, model, cfg, fc_feats, att_feats, att_masks, *params):
         P = dict(zip(model._param_names, [p.detach() for p in params]))
         pr = engine.prepare(P, fc_feats, att_feats, att_masks, cfg.get('drop_fc'), cfg.get('drop_att'))
-        ro = engine.Rollout(P, pr, n=cfg['n'], T=cfg['T'], L=cfg['L'], mode=cfg['mode'],
+        pr_run, extra = pr, {}
+        if cfg.get('fused_greedy'):
+            # fused SCST rollout: sampled rows read the train-mode (dropout) features, the greedy-baseline rows the
+            # eval-mode features of the same images -> 2B feature images, explicit row -> image map
+            pr_eval = engine.prepare(P, fc_feats, att_feats, att_masks)
+            pr_run = engine.Prepared()
+            pr_run.fc = torch.cat([pr.fc, pr_eval.fc], 0)
+            pr_run.att = torch.cat([pr.att, pr_eval.att], 0)
+            pr_run.p_att = torch.cat([pr.p_att, pr_eval.p_att], 0)
+            pr_run.att_masks = None if pr.att_masks is None else torch.cat([pr.att_masks, pr.att_masks], 0)
+            extra = dict(row_img=cfg['row_img'], B_grad=fc_feats.shape[0])
+        ro = engine.Rollout(P, pr_run, n=cfg['n'], T=cfg['T'], L=cfg['L'], mode=cfg['mode'],
                             temperature=cfg.get('temperature', 1.0), drop_xt=cfg.get('drop_xt'),
                             drop_out=cfg.get('drop_out'), gumbel=cfg.get('gumbel'), seed=cfg.get('seed', 0),
-                            forced=cfg.get('forced'), teacher=cfg.get('teacher', False), row_mode=cfg.get('row_mode'))
+                            forced=cfg.get('forced'), teacher=cfg.get('teacher', False), row_mode=cfg.get('row_mode'),
+                            **extra)
         seq, seq_logp = ro.run()
         ctx.model, ctx.ro, ctx.pr, ctx.P = model, ro, pr, P
         ctx.mark_non_differentiable(seq)
@@ -226,6 +238,34 @@ class AttModel(CaptionModel):
             cfg['gumbel'] = gumbel
         seq, logp = self._run(cfg, fc_feats, att_feats, att_masks)
         return seq, logp
+
+    def scst_rollouts(self, fc_feats, att_feats, att_masks=None, sample_n=5, temperature=1.0, _gumbel=None):
+        """Both rollouts of one self-critical step in ONE pass (MI355X-first: the decode GEMMs run on
+        64-row MFMA tiles, so the B greedy-baseline rows ride along with the B*n sampled rows for free and
+        the weights are streamed from HBM once instead of twice).
+
+        Semantics of loss_wrapper.py:57-68 are kept per row: sampled rows = train mode (dropout p, categorical
+        sampling, gradient), greedy rows = eval mode (no dropout, arg-max, no gradient).
+        Returns (greedy_res [B,L], gen_result [B*n,L], sample_logprobs [B*n,L,V1])."""
+        self._device_check(fc_feats)
+        B, n, L = fc_feats.size(0), int(sample_n), self.seq_length
+        N, dev = B * n, fc_feats.device
+        K = att_feats.shape[1] if att_masks is None else int(att_masks.long().sum(1).max())
+        was_training = self.training
+        self.train()                               # dropout masks for the sampled rows
+        cfg = dict(n=n, T=L, L=L, mode='sample', temperature=temperature, seed=self._next_seed(), fused_greedy=True)
+        cfg.update(self._dropout_masks(B, K, N + B, L, dev))
+        self.train(was_training)
+        for k in ('drop_xt', 'drop_out'):
+            if k in cfg:
+                cfg[k][:, N:] = 1.0                 # greedy rows: eval mode
+        cfg['row_img'] = torch.cat([torch.arange(N, device=dev) // n, B + torch.arange(B, device=dev)]).to(torch.int32)
+        cfg['row_mode'] = torch.cat([torch.ones(N, dtype=torch.uint8, device=dev),
+                                     torch.zeros(B, dtype=torch.uint8, device=dev)])
+        if _gumbel is not None:
+            cfg['gumbel'] = _gumbel
+        seq, logp = self._run(cfg, fc_feats, att_feats, att_masks)
+        return seq[N:], seq[:N], logp[:N]
 
     def _sample_beam(self, fc_feats, att_feats, att_masks=None, opt={}):
         from ...beam import sample_beam

@@ -50,15 +50,24 @@ class LossWrapper(torch.nn.Module):
             loss = self.crit(self.model(fc_feats, att_feats, labels[..., :-1], att_masks), labels[..., 1:], masks[..., 1:],
                              reduction=reduction)
         else:
-            self.model.eval()
-            with torch.no_grad():
-                greedy_res, _ = self.model(fc_feats, att_feats, att_masks, mode='sample',
-                                           opt={'sample_method': opt.sc_sample_method, 'beam_size': opt.sc_beam_size})
-            self.model.train()
-            gen_result, sample_logprobs = self.model(
-                fc_feats, att_feats, att_masks,
-                opt={'sample_method': opt.train_sample_method, 'beam_size': opt.train_beam_size,
-                     'sample_n': opt.train_sample_n}, mode='sample')
+            fused = (getattr(self, 'fuse_scst_rollouts', True) and hasattr(self.model, 'scst_rollouts')
+                     and opt.sc_sample_method == 'greedy' and opt.sc_beam_size == 1
+                     and opt.train_sample_method == 'sample' and opt.train_beam_size == 1)
+            if fused:
+                # greedy baseline + sampled rollouts in one pass over the weights (see AttModel.scst_rollouts)
+                self.model.train()
+                greedy_res, gen_result, sample_logprobs = self.model.scst_rollouts(
+                    fc_feats, att_feats, att_masks, sample_n=opt.train_sample_n)
+            else:
+                self.model.eval()
+                with torch.no_grad():
+                    greedy_res, _ = self.model(fc_feats, att_feats, att_masks, mode='sample',
+                                               opt={'sample_method': opt.sc_sample_method, 'beam_size': opt.sc_beam_size})
+                self.model.train()
+                gen_result, sample_logprobs = self.model(
+                    fc_feats, att_feats, att_masks,
+                    opt={'sample_method': opt.train_sample_method, 'beam_size': opt.train_beam_size,
+                         'sample_n': opt.train_sample_n}, mode='sample')
             gts = [gts[_] for _ in gt_indices.tolist()]
             adv, _scores = self_critical_reward_device(greedy_res, gts, gen_result, opt)      # [N] on device
             reward = adv.unsqueeze(1).expand(-1, gen_result.shape[1])

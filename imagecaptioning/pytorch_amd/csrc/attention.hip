@@ -1,12 +1,16 @@
 // Fused additive region attention for gfx950 (AttModel.py:728-748 Attention.forward and its
 // autograd backward).
 //
-// Forward: ONE workgroup per image.  The image's projected tile p_att[b] (K x A) and feature tile
-// att[b] (K x R) are each read from HBM exactly once and reused, in registers, by the n caption rows
-// that share the image (sample_n / seq_per_img): the reference's repeat_tensors copy
-// (models/utils.py:3-14) and its n-fold re-reads do not exist here.  score -> softmax (-> mask
-// renorm) -> context run in one launch; only att_h[n,A] (16 KB) and the n x K score matrix live in
-// LDS.  HBM traffic per launch = B*K*(A+R)*4 + N*(A+R+K)*4 bytes (SURVEY.md 8d "unique bytes").
+// Forward: a workgroup owns `rpb` (1..8) caption rows of ONE image.  The image's projected tile
+// p_att[b] (K x A) and feature tile att[b] (K x R) are read once per workgroup and reused, in
+// registers, by its rows; the reference's repeat_tensors copy (models/utils.py:3-14) does not exist.
+// rpb is chosen by the host so that the grid covers the chip: at SCST sizes (N = 60 rows) one row per
+// workgroup (60 CUs busy instead of 10), at eval/XE sizes several rows per workgroup.  Workgroups of
+// the same image are mapped to the SAME XCD (blockIdx % 8 is the observed XCD), so the n-fold reuse of
+// an image tile is served by that XCD's L2 and HBM still sees each tile once:
+// HBM traffic per launch = B*K*(A+R)*4 + N*(A+R+K)*4 bytes (SURVEY.md 8d "unique bytes").
+// score -> softmax (-> mask renorm) -> context run in one launch; only att_h and the score matrix
+// live in LDS.
 //   phase 1  wave w owns regions k = w, w+8, ...: lanes stride A with 16-byte loads, tanh on the
 //            VALU, wave64 shuffle reduction per (row, region)
 //   phase 2  wave j normalises row j (K <= a few hundred): shuffle max/sum
@@ -19,59 +23,121 @@ using namespace capmi;
 
 namespace {
 
-constexpr int NMAX = 8;       // rows per image handled by one workgroup
+constexpr int NMAX = 8;       // max rows per image handled by one workgroup
 constexpr int ATT_THREADS = 512;
+
+// XCD-aware workgroup -> (image, row chunk): ids congruent mod 8 run on the same XCD, so all chunks
+// of image b live on XCD b % 8.  Returns false for the padding ids when B % 8 != 0.
+__device__ __forceinline__ bool decode_block(int B, int chunks, int &b, int &chunk) {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    b = (slot / chunks) * 8 + xcd;
+    chunk = slot % chunks;
+    return b < B;
+}
+inline int grid_blocks(int B, int chunks) { return ((B + 7) / 8) * 8 * chunks; }
+inline int pick_rpb(int B, int n) {
+    int rpb = (int)(((long long)B * n) / 256);
+    if (rpb < 1) rpb = 1;
+    if (rpb > n) rpb = n;
+    if (rpb > NMAX) rpb = NMAX;
+    return rpb;
+}
+
+// Latency note: at decode sizes these kernels are a chain of dependent memory round trips, so every
+// phase issues ALL its loads for a group of regions before touching the data (a rolled `for k` loop
+// exposes one ~1-2 us HBM/L2 latency per region: 36 of them per launch).
+constexpr int SG = 5;     // regions a wave keeps in flight in the score phase
+constexpr int CG = 12;    // att rows a lane keeps in flight in the context phase
 
 __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
     const float *__restrict__ att_h, const float *__restrict__ p_att, const float *__restrict__ att,
     const float *__restrict__ mask, const float *__restrict__ w, const float *__restrict__ bptr,
-    float *__restrict__ ctx, float *__restrict__ alpha, int n_img, int K, int A, int R) {
+    float *__restrict__ ctx, float *__restrict__ alpha, int B, int n_img, int rpb, int chunks, int K, int A, int R,
+    const int *__restrict__ row_img) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *s_h = lds;                    // [NMAX][A]
     float *s_e = lds + (size_t)NMAX * A; // [NMAX][K]
-    const int b = blockIdx.x;
-    const int row0 = b * n_img + blockIdx.y * NMAX;          // first caption row of this workgroup
-    const int n = min(NMAX, n_img - (int)blockIdx.y * NMAX);   // rows handled here (<= NMAX)
+    int b, chunk, row0, n;
+    if (row_img) {                       // ragged grouping: one row per workgroup, image from the map
+        row0 = blockIdx.x;
+        n = 1;
+        b = row_img[row0];
+    } else {
+        if (!decode_block(B, chunks, b, chunk)) return;
+        row0 = b * n_img + chunk * rpb;          // first caption row of this workgroup
+        n = min(rpb, n_img - chunk * rpb);         // rows handled here (<= NMAX)
+    }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
 
     for (int i = threadIdx.x; i < n * A; i += blockDim.x) s_h[i] = att_h[(size_t)row0 * A + i];
-    __syncthreads();
 
     const float bias = bptr ? bptr[0] : 0.f;
     const float *pb = p_att + (size_t)b * K * A;
-    const bool vecA = (A % 4 == 0) && ((reinterpret_cast<uintptr_t>(p_att) & 15) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
-    for (int k = wid; k < K; k += nw) {
-        float acc[NMAX];
+    const bool fastA = (A % 4 == 0) && (A <= 512) && ((reinterpret_cast<uintptr_t>(p_att) & 15) == 0) &&
+                       ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
+    if (fastA) {
+        // lane covers a = 4*lane + 256*q, q in {0,1}
+        const int a0 = lane * 4, a1 = a0 + 256;
+        const bool v0 = a0 < A, v1 = a1 < A;
+        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+        if (v0) w0 = *reinterpret_cast<const f32x4 *>(w + a0);
+        if (v1) w1 = *reinterpret_cast<const f32x4 *>(w + a1);
+        for (int base = 0; base < K; base += nw * SG) {   // block-uniform trip count (barrier inside)
+            const int kb = base + wid;
+            f32x4 p0[SG], p1[SG];
 #pragma unroll
-        for (int j = 0; j < NMAX; ++j) acc[j] = 0.f;
-        const float *pk = pb + (size_t)k * A;
-        if (vecA) {
-            for (int a = lane * 4; a < A; a += 256) {
-                const f32x4 p = *reinterpret_cast<const f32x4 *>(pk + a);
-                const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + a);
+            for (int g = 0; g < SG; ++g) {
+                const int k = kb + g * nw;
+                p0[g] = p1[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (k < K) {
+                    if (v0) p0[g] = *reinterpret_cast<const f32x4 *>(pb + (size_t)k * A + a0);
+                    if (v1) p1[g] = *reinterpret_cast<const f32x4 *>(pb + (size_t)k * A + a1);
+                }
+            }
+            __syncthreads();   // s_h visible (first trip); harmless afterwards (uniform trip count per block)
+#pragma unroll
+            for (int g = 0; g < SG; ++g) {
+                const int k = kb + g * nw;
 #pragma unroll
                 for (int j = 0; j < NMAX; ++j) {
                     if (j < n) {
-                        const f32x4 h = *reinterpret_cast<const f32x4 *>(s_h + j * A + a);
-                        acc[j] += wv[0] * tanh_f(p[0] + h[0]) + wv[1] * tanh_f(p[1] + h[1]) +
-                                  wv[2] * tanh_f(p[2] + h[2]) + wv[3] * tanh_f(p[3] + h[3]);
+                        float acc = 0.f;
+                        if (v0) {
+                            const f32x4 h = *reinterpret_cast<const f32x4 *>(s_h + j * A + a0);
+                            acc += w0[0] * tanh_f(p0[g][0] + h[0]) + w0[1] * tanh_f(p0[g][1] + h[1]) +
+                                   w0[2] * tanh_f(p0[g][2] + h[2]) + w0[3] * tanh_f(p0[g][3] + h[3]);
+                        }
+                        if (v1) {
+                            const f32x4 h = *reinterpret_cast<const f32x4 *>(s_h + j * A + a1);
+                            acc += w1[0] * tanh_f(p1[g][0] + h[0]) + w1[1] * tanh_f(p1[g][1] + h[1]) +
+                                   w1[2] * tanh_f(p1[g][2] + h[2]) + w1[3] * tanh_f(p1[g][3] + h[3]);
+                        }
+                        const float e = wave_sum(acc) + bias;
+                        if (lane == 0 && k < K) s_e[j * K + k] = e;
                     }
                 }
             }
-        } else {
+        }
+    } else {
+        __syncthreads();
+        for (int k = wid; k < K; k += nw) {
+            float acc[NMAX];
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j) acc[j] = 0.f;
+            const float *pk = pb + (size_t)k * A;
             for (int a = lane; a < A; a += 64) {
                 const float p = pk[a], wv = w[a];
 #pragma unroll
                 for (int j = 0; j < NMAX; ++j)
                     if (j < n) acc[j] += wv * tanh_f(p + s_h[j * A + a]);
             }
-        }
 #pragma unroll
-        for (int j = 0; j < NMAX; ++j) {
-            if (j < n) {
-                const float e = wave_sum(acc[j]) + bias;
-                if (lane == 0) s_e[j * K + k] = e;
+            for (int j = 0; j < NMAX; ++j) {
+                if (j < n) {
+                    const float e = wave_sum(acc[j]) + bias;
+                    if (lane == 0) s_e[j * K + k] = e;
+                }
             }
         }
     }
@@ -108,7 +174,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
     }
     __syncthreads();
 
-    // context: lane owns 2 columns, streams K rows of att[b]
+    // context: lane owns 2 columns, streams K rows of att[b], CG rows in flight
     const float *ab = att + (size_t)b * K * R;
     const bool vecR = (R % 2 == 0) && ((reinterpret_cast<uintptr_t>(att) & 7) == 0) &&
                       ((reinterpret_cast<uintptr_t>(ctx) & 7) == 0);
@@ -117,14 +183,23 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
             float a0[NMAX], a1[NMAX];
 #pragma unroll
             for (int j = 0; j < NMAX; ++j) a0[j] = a1[j] = 0.f;
-            for (int k = 0; k < K; ++k) {
-                const float2 v = *reinterpret_cast<const float2 *>(ab + (size_t)k * R + r);
+            for (int k0 = 0; k0 < K; k0 += CG) {
+                float2 v[CG];
 #pragma unroll
-                for (int j = 0; j < NMAX; ++j) {
-                    if (j < n) {
-                        const float al = s_e[j * K + k];
-                        a0[j] += al * v.x;
-                        a1[j] += al * v.y;
+                for (int g = 0; g < CG; ++g)
+                    v[g] = (k0 + g < K) ? *reinterpret_cast<const float2 *>(ab + (size_t)(k0 + g) * R + r)
+                                        : make_float2(0.f, 0.f);
+#pragma unroll
+                for (int g = 0; g < CG; ++g) {
+                    if (k0 + g < K) {
+#pragma unroll
+                        for (int j = 0; j < NMAX; ++j) {
+                            if (j < n) {
+                                const float al = s_e[j * K + k0 + g];
+                                a0[j] += al * v[g].x;
+                                a1[j] += al * v[g].y;
+                            }
+                        }
                     }
                 }
             }
@@ -155,36 +230,85 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
 //   d_e[k] = alpha[k] * (dalpha[k] - sum_k' alpha[k'] dalpha[k'])   (alpha = the FINAL weights),
 // because the renorm u_k = alpha_sm,k m_k / S composes with the softmax Jacobian to the same form
 // (masked regions have alpha = 0 and receive 0).
+constexpr int DG = 2;     // regions (x4 16-byte loads) a wave keeps in flight in the dalpha phase
 __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
     const float *__restrict__ d_ctx, int ld_dctx, const float *__restrict__ att_h, const float *__restrict__ alpha,
     const float *__restrict__ p_att, const float *__restrict__ att, const float *__restrict__ w,
-    float *__restrict__ d_att_h, float *__restrict__ d_e, int n_img, int K, int A, int R) {
+    float *__restrict__ d_att_h, float *__restrict__ d_e, int B, int n_img, int rpb, int chunks, int K, int A, int R,
+    const int *__restrict__ row_img) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *s_dc = lds;                        // [NMAX][R]
-    float *s_de = s_dc + (size_t)NMAX * R;    // [NMAX][K]  dalpha, then d_e
-    const int b = blockIdx.x;
-    const int row0 = b * n_img + blockIdx.y * NMAX;
-    const int n = min(NMAX, n_img - (int)blockIdx.y * NMAX);
+    float *s_dc = lds;                        // [NMAX][R4]  (R rounded up to a multiple of 4, zero padded)
+    const int R4 = (R + 3) & ~3;
+    float *s_de = s_dc + (size_t)NMAX * R4;   // [NMAX][K]  dalpha, then d_e
+    int b, chunk, row0, n;
+    if (row_img) {
+        row0 = blockIdx.x;
+        n = 1;
+        b = row_img[row0];
+    } else {
+        if (!decode_block(B, chunks, b, chunk)) return;
+        row0 = b * n_img + chunk * rpb;
+        n = min(rpb, n_img - chunk * rpb);
+    }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int i = threadIdx.x; i < n * R; i += blockDim.x)
-        s_dc[i] = d_ctx[(size_t)(row0 + i / R) * ld_dctx + (i % R)];
+    for (int i = threadIdx.x; i < n * R4; i += blockDim.x) {
+        const int j = i / R4, r = i % R4;
+        s_dc[i] = r < R ? d_ctx[(size_t)(row0 + j) * ld_dctx + r] : 0.f;
+    }
     __syncthreads();
     const float *ab = att + (size_t)b * K * R;
-    for (int k = wid; k < K; k += nw) {
-        float acc[NMAX];
+    const bool fastR = (R % 4 == 0) && (R <= 1024) && ((reinterpret_cast<uintptr_t>(att) & 15) == 0);
+    if (fastR) {
+        for (int kb = wid; kb < K; kb += nw * DG) {
+            f32x4 v[DG][4];
 #pragma unroll
-        for (int j = 0; j < NMAX; ++j) acc[j] = 0.f;
-        for (int r = lane; r < R; r += 64) {
-            const float v = ab[(size_t)k * R + r];
+            for (int g = 0; g < DG; ++g) {
+                const int k = kb + g * nw;
 #pragma unroll
-            for (int j = 0; j < NMAX; ++j)
-                if (j < n) acc[j] += v * s_dc[j * R + r];
+                for (int q = 0; q < 4; ++q) {
+                    const int r = lane * 4 + 256 * q;
+                    v[g][q] = (k < K && r < R) ? *reinterpret_cast<const f32x4 *>(ab + (size_t)k * R + r)
+                                               : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < DG; ++g) {
+                const int k = kb + g * nw;
+#pragma unroll
+                for (int j = 0; j < NMAX; ++j) {
+                    if (j < n) {
+                        float acc = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int r = lane * 4 + 256 * q;
+                            if (r < R) {
+                                const f32x4 dcv = *reinterpret_cast<const f32x4 *>(s_dc + j * R4 + r);
+                                acc += v[g][q][0] * dcv[0] + v[g][q][1] * dcv[1] + v[g][q][2] * dcv[2] + v[g][q][3] * dcv[3];
+                            }
+                        }
+                        const float sum = wave_sum(acc);
+                        if (lane == 0 && k < K) s_de[j * K + k] = sum;
+                    }
+                }
+            }
         }
+    } else {
+        for (int k = wid; k < K; k += nw) {
+            float acc[NMAX];
 #pragma unroll
-        for (int j = 0; j < NMAX; ++j) {
-            if (j < n) {
-                const float s = wave_sum(acc[j]);
-                if (lane == 0) s_de[j * K + k] = s;
+            for (int j = 0; j < NMAX; ++j) acc[j] = 0.f;
+            for (int r = lane; r < R; r += 64) {
+                const float v = ab[(size_t)k * R + r];
+#pragma unroll
+                for (int j = 0; j < NMAX; ++j)
+                    if (j < n) acc[j] += v * s_dc[j * R4 + r];
+            }
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j) {
+                if (j < n) {
+                    const float sum = wave_sum(acc[j]);
+                    if (lane == 0) s_de[j * K + k] = sum;
+                }
             }
         }
     }
@@ -209,13 +333,20 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
             acc[j] = 0.f;
             hh[j] = j < n ? att_h[(size_t)(row0 + j) * A + a] : 0.f;
         }
-        for (int k = 0; k < K; ++k) {
-            const float p = pb[(size_t)k * A + a];
+        for (int k0 = 0; k0 < K; k0 += CG) {
+            float pv[CG];
 #pragma unroll
-            for (int j = 0; j < NMAX; ++j) {
-                if (j < n) {
-                    const float t = tanh_f(p + hh[j]);
-                    acc[j] += s_de[j * K + k] * (1.f - t * t);
+            for (int g = 0; g < CG; ++g) pv[g] = (k0 + g < K) ? pb[(size_t)(k0 + g) * A + a] : 0.f;
+#pragma unroll
+            for (int g = 0; g < CG; ++g) {
+                if (k0 + g < K) {
+#pragma unroll
+                    for (int j = 0; j < NMAX; ++j) {
+                        if (j < n) {
+                            const float t = tanh_f(pv[g] + hh[j]);
+                            acc[j] += s_de[j * K + k0 + g] * (1.f - t * t);
+                        }
+                    }
                 }
             }
         }
@@ -229,7 +360,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
 // ---- backward, time-batched feature / parameter gradients --------------------------------------
 constexpr int KCH = 12;
 __global__ void attn_datt_kernel(const float *__restrict__ d_ctx_all, int ld_dctx, const float *__restrict__ alpha_all,
-                                 float *__restrict__ d_att, int T, int N, int n, int K, int R) {
+                                 float *__restrict__ d_att, int T, int N, int n, int K, int R) {   // N = rows per time slab
     // grid (B, ceil(R/256)); thread owns column r, KCH region accumulators at a time
     const int b = blockIdx.x;
     const int r = blockIdx.y * blockDim.x + threadIdx.x;
@@ -290,44 +421,50 @@ __global__ void sum_all_kernel(const float *__restrict__ in, size_t count, float
 extern "C" {
 
 int capmi_attention_fwd(const float *att_h, const float *p_att, const float *att, const float *mask, const float *w,
-                        const float *b, float *ctx, float *alpha, int B, int n, int K, int A, int R, void *stream) {
-    if (!att_h || !p_att || !att || !w || !ctx || !alpha || B <= 0 || n <= 0 || K <= 0 || A <= 0 || R <= 0)
-        return CAPMI_EINVAL;
+                        const float *b, float *ctx, float *alpha, int B, int n, int K, int A, int R,
+                        const int32_t *row_img, int N, void *stream) {
+    if (!att_h || !p_att || !att || !w || !ctx || !alpha || B <= 0 || K <= 0 || A <= 0 || R <= 0) return CAPMI_EINVAL;
+    if (row_img ? N <= 0 : n <= 0) return CAPMI_EINVAL;
+    if (!row_img) N = B * n;
     const size_t lds = ((size_t)NMAX * A + (size_t)NMAX * K) * sizeof(float);
     if (lds > 64 * 1024) return CAPMI_EINVAL;
     // unique (algorithmic) bytes: image tiles once + per-row att_h in, ctx and alpha out
-    const double abytes = 4.0 * ((double)B * K * (A + R) + (double)B * n * (A + R + K));
-    capmi_prof::Scope prof(CAPMI_PROF_ATTENTION_FWD, (hipStream_t)stream, abytes, (double)B * n * K * (2.0 * A + 2.0 * R));
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(B, (n + NMAX - 1) / NMAX), dim3(ATT_THREADS), lds, (hipStream_t)stream, att_h, p_att, att, mask,
-                       w, b, ctx, alpha, n, K, A, R);
+    const double abytes = 4.0 * ((double)B * K * (A + R) + (double)N * (A + R + K));
+    capmi_prof::Scope prof(CAPMI_PROF_ATTENTION_FWD, (hipStream_t)stream, abytes, (double)N * K * (2.0 * A + 2.0 * R));
+    const int rpb = row_img ? 1 : pick_rpb(B, n), chunks = row_img ? 1 : (n + rpb - 1) / rpb;
+    hipLaunchKernelGGL(attention_fwd_kernel, dim3(row_img ? N : grid_blocks(B, chunks)), dim3(ATT_THREADS), lds,
+                       (hipStream_t)stream, att_h, p_att, att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K, A, R, row_img);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
 
 int capmi_attention_bwd(const float *d_ctx, int ld_dctx, const float *att_h, const float *alpha, const float *p_att,
                         const float *att, const float *mask, const float *w, float *d_att_h, float *d_e, int B, int n,
-                        int K, int A, int R, void *stream) {
+                        int K, int A, int R, const int32_t *row_img, int N, void *stream) {
     (void)mask;   // the masked renorm folds into the same Jacobian (see kernel comment)
-    if (!d_ctx || !att_h || !alpha || !p_att || !att || !w || !d_att_h || !d_e || B <= 0 || n <= 0 || ld_dctx < R)
-        return CAPMI_EINVAL;
-    const size_t lds = ((size_t)NMAX * R + (size_t)NMAX * K) * sizeof(float);
+    if (!d_ctx || !att_h || !alpha || !p_att || !att || !w || !d_att_h || !d_e || B <= 0 || ld_dctx < R) return CAPMI_EINVAL;
+    if (row_img ? N <= 0 : n <= 0) return CAPMI_EINVAL;
+    if (!row_img) N = B * n;
+    const size_t lds = ((size_t)NMAX * ((R + 3) & ~3) + (size_t)NMAX * K) * sizeof(float);
     if (lds > 64 * 1024) return CAPMI_EINVAL;
-    const double abytes = 4.0 * ((double)B * K * (A + R) + (double)B * n * (2.0 * A + R + 2.0 * K));
-    capmi_prof::Scope prof(CAPMI_PROF_ATTENTION_BWD, (hipStream_t)stream, abytes, (double)B * n * K * (4.0 * A + 2.0 * R));
-    hipLaunchKernelGGL(attention_bwd_kernel, dim3(B, (n + NMAX - 1) / NMAX), dim3(ATT_THREADS), lds, (hipStream_t)stream, d_ctx, ld_dctx, att_h, alpha,
-                       p_att, att, w, d_att_h, d_e, n, K, A, R);
+    const double abytes = 4.0 * ((double)B * K * (A + R) + (double)N * (2.0 * A + R + 2.0 * K));
+    capmi_prof::Scope prof(CAPMI_PROF_ATTENTION_BWD, (hipStream_t)stream, abytes, (double)N * K * (4.0 * A + 2.0 * R));
+    const int rpb = row_img ? 1 : pick_rpb(B, n), chunks = row_img ? 1 : (n + rpb - 1) / rpb;
+    hipLaunchKernelGGL(attention_bwd_kernel, dim3(row_img ? N : grid_blocks(B, chunks)), dim3(ATT_THREADS), lds,
+                       (hipStream_t)stream, d_ctx, ld_dctx, att_h, alpha, p_att, att, w, d_att_h, d_e, B, n, rpb, chunks, K,
+                       A, R, row_img);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
 
 int capmi_attention_bwd_batched(const float *d_ctx_all, int ld_dctx, const float *att_h_all, const float *alpha_all,
                                 const float *d_e_all, const float *p_att, const float *w, float *d_att,
-                                float *d_p_att, float *d_w, float *d_b, int T, int B, int n, int K, int A, int R,
-                                void *stream) {
+                                float *d_p_att, float *d_w, float *d_b, int T, int B, int n, int N_stride, int K, int A,
+                                int R, void *stream) {
     if (!d_ctx_all || !att_h_all || !alpha_all || !d_e_all || !p_att || !w || !d_att || !d_p_att || !d_w || !d_b)
         return CAPMI_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int N = B * n;
+    const int N = N_stride > 0 ? N_stride : B * n;
     hipLaunchKernelGGL(attn_datt_kernel, dim3(B, (R + 255) / 256), dim3(256), 0, st, d_ctx_all, ld_dctx, alpha_all, d_att, T, N, n,
                        K, R);
     CAPMI_CHECK_LAUNCH();

@@ -1,0 +1,58 @@
+// Shared argument block of the GEMM kernels (LDS-tiled fat kernel in gemm_f32.hip, direct-to-register
+// skinny kernel in gemm_skinny.hip).
+#pragma once
+#include "capmi_common.h"
+#include "../../../include/capmi.h"
+
+namespace capmi_gemm {
+
+constexpr int BK = 32;
+constexpr int NT = 256;
+
+struct Seg {
+    const float *A, *B;
+    int lda, ldb, K, a_row_div;
+    int vecA, vecB;   // 16-byte vector loads legal for this segment
+};
+
+struct KArgs {
+    Seg seg[CAPMI_MAX_SEG];
+    int nseg;
+    int M, N;
+    float *C;
+    int ldc;
+    const float *bias, *bias2, *row_bias;
+    int row_bias_div;
+    const float *mul_mask;
+    int relu, accumulate;
+    float *partial;
+    int splits;
+    int to_partial;      // write raw K-slice sums to `partial` (split-K and/or fused consumer)
+    int tiles_total;     // sum over segments of ceil(K/BK)
+    int *counters;       // per-output-tile arrival tickets (in-launch split-K reduction), zero between launches
+    int self_reduce;     // last-arriving K slice of a tile reduces all slices and applies the epilogue
+    int ablate;          // experiments only (CAPMI_GEMM_ABLATE): 1 = skip MFMA phase, 2 = skip global loads, 4 = skip LDS writes
+};
+
+// flat K-tile index -> (segment, k0)
+__device__ __forceinline__ void locate(const KArgs &a, int tile, int &s, int &k0) {
+    s = 0;
+    int t = tile;
+#pragma unroll
+    for (int i = 0; i < CAPMI_MAX_SEG; ++i) {
+        if (i < a.nseg - 1 && s == i) {
+            const int nt = (a.seg[i].K + BK - 1) / BK;
+            if (t >= nt) {
+                t -= nt;
+                s = i + 1;
+            }
+        }
+    }
+    k0 = t * BK;
+}
+
+
+// skinny (M <= 64, A stored [M][K]) direct-to-register path; defined in gemm_skinny.hip
+int launch_skinny(const KArgs &a, int b_layout, int tm, dim3 grid, hipStream_t st);
+
+}  // namespace capmi_gemm

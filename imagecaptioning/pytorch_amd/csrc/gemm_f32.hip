@@ -22,33 +22,12 @@
 #include "capmi_common.h"
 #include "profile.h"
 #include "../../../include/capmi.h"
+#include "gemm_common.h"
+#include <stdlib.h>
+
+using namespace capmi_gemm;
 
 namespace {
-
-constexpr int BK = 32;
-constexpr int NT = 256;
-
-struct Seg {
-    const float *A, *B;
-    int lda, ldb, K, a_row_div;
-    int vecA, vecB;   // 16-byte vector loads legal for this segment
-};
-
-struct KArgs {
-    Seg seg[CAPMI_MAX_SEG];
-    int nseg;
-    int M, N;
-    float *C;
-    int ldc;
-    const float *bias, *bias2, *row_bias;
-    int row_bias_div;
-    const float *mul_mask;
-    int relu, accumulate;
-    float *partial;
-    int splits;
-    int to_partial;      // write raw K-slice sums to `partial` (split-K and/or fused consumer)
-    int tiles_total;     // sum over segments of ceil(K/BK)
-};
 
 // ---- global -> registers ---------------------------------------------------------------------
 // KC = true : source stored [rows][K] (K contiguous).  thread -> (row, 4 consecutive k)
@@ -98,9 +77,15 @@ __device__ __forceinline__ void g2r(f32x4 (&r)[ROWS * BK / 4 / NT], const float 
     }
 }
 
+// LDS images.  K-contiguous sources keep their row-major shape [rows][BK+4] (pitch 36 floats: 16-byte
+// aligned rows, and 36 = 4*9 makes the 16 rows of a ds_read_b128 lane group hit 16 distinct 4-bank slots
+// => conflict free); the MFMA k index is free to permute (a sum), so a lane fetches FOUR consecutive
+// k values of its row with one ds_read_b128 and feeds four MFMAs from it.  M/N-contiguous sources are
+// stored k-major [BK][rows+4] and read with ds_read_b32 at the same (permuted) k.
 template <int ROWS, bool KC>
 struct Pitch {
-    static constexpr int value = KC ? ROWS + 1 : ROWS + 4;
+    static constexpr int value = KC ? BK + 4 : ROWS + 4;
+    static constexpr int size = KC ? ROWS * (BK + 4) : BK * (ROWS + 4);
 };
 
 template <int ROWS, bool KC>
@@ -113,10 +98,7 @@ __device__ __forceinline__ void r2s(const f32x4 (&r)[ROWS * BK / 4 / NT], float 
         if (KC) {
             const int rr = idx / (BK / 4);
             const int kq = (idx % (BK / 4)) * 4;
-            dst[(kq + 0) * LD + rr] = r[p][0];
-            dst[(kq + 1) * LD + rr] = r[p][1];
-            dst[(kq + 2) * LD + rr] = r[p][2];
-            dst[(kq + 3) * LD + rr] = r[p][3];
+            *reinterpret_cast<f32x4 *>(dst + rr * LD + kq) = r[p];
         } else {
             const int kk = idx / (ROWS / 4);
             const int mq = (idx % (ROWS / 4)) * 4;
@@ -125,33 +107,16 @@ __device__ __forceinline__ void r2s(const f32x4 (&r)[ROWS * BK / 4 / NT], float 
     }
 }
 
-// flat K-tile index -> (segment, k0)
-__device__ __forceinline__ void locate(const KArgs &a, int tile, int &s, int &k0) {
-    s = 0;
-    int t = tile;
-#pragma unroll
-    for (int i = 0; i < CAPMI_MAX_SEG; ++i) {
-        if (i < a.nseg - 1 && s == i) {
-            const int nt = (a.seg[i].K + BK - 1) / BK;
-            if (t >= nt) {
-                t -= nt;
-                s = i + 1;
-            }
-        }
-    }
-    k0 = t * BK;
-}
-
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int PF>
 __global__ __launch_bounds__(NT) void gemm_kernel(const KArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     constexpr int LDA = Pitch<BM, AKC>::value;
     constexpr int LDB = Pitch<BN, BKC>::value;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    __shared__ __attribute__((aligned(16))) float smem[BK * LDA + BK * LDB];
+    __shared__ __attribute__((aligned(16))) float smem[Pitch<BM, AKC>::size + Pitch<BN, BKC>::size];
     float *As = smem;
-    float *Bs = smem + BK * LDA;
+    float *Bs = smem + Pitch<BM, AKC>::size;
 
     const int m0 = blockIdx.y * BM;
     const int n0 = blockIdx.x * BN;
@@ -175,45 +140,73 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const KArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[BM * BK / 4 / NT];
-    f32x4 rb[BN * BK / 4 / NT];
+    // PF register sets keep PF K-tiles in flight from HBM while one tile is consumed from LDS: at decode
+    // sizes the loop is HBM-latency bound (one 16 KB tile per ~2 us round trip per workgroup otherwise).
+    f32x4 ra[PF][BM * BK / 4 / NT];
+    f32x4 rb[PF][BN * BK / 4 / NT];
 
-    if (t_begin < t_end) {
-        int s, k0;
-        locate(a, t_begin, s, k0);
-        g2r<BM, AKC>(ra, a.seg[s].A, a.seg[s].lda, m0, a.M, k0, a.seg[s].K, AKC ? a.seg[s].a_row_div : 1, a.seg[s].vecA);
-        g2r<BN, BKC>(rb, a.seg[s].B, a.seg[s].ldb, n0, a.N, k0, a.seg[s].K, 1, a.seg[s].vecB);
-    }
-    for (int t = t_begin; t < t_end; ++t) {
-        __syncthreads();   // previous tile fully consumed
-        r2s<BM, AKC>(ra, As);
-        r2s<BN, BKC>(rb, Bs);
-        __syncthreads();
-        if (t + 1 < t_end) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        if (t_begin + u < t_end) {
             int s, k0;
-            locate(a, t + 1, s, k0);
-            g2r<BM, AKC>(ra, a.seg[s].A, a.seg[s].lda, m0, a.M, k0, a.seg[s].K, AKC ? a.seg[s].a_row_div : 1, a.seg[s].vecA);
-            g2r<BN, BKC>(rb, a.seg[s].B, a.seg[s].ldb, n0, a.N, k0, a.seg[s].K, 1, a.seg[s].vecB);
+            locate(a, t_begin + u, s, k0);
+            g2r<BM, AKC>(ra[u], a.seg[s].A, a.seg[s].lda, m0, a.M, k0, a.seg[s].K, AKC ? a.seg[s].a_row_div : 1, a.seg[s].vecA);
+            g2r<BN, BKC>(rb[u], a.seg[s].B, a.seg[s].ldb, n0, a.N, k0, a.seg[s].K, 1, a.seg[s].vecB);
         }
+    }
+    for (int t0 = t_begin; t0 < t_end; t0 += PF) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const int krow = 2 * kk + khalf;
-            float av[TM], bv[TN];
+        for (int u = 0; u < PF; ++u) {
+            const int t = t0 + u;
+            if (t < t_end) {
+                __syncthreads();   // previous tile fully consumed
+                if (!(a.ablate & 4)) {
+                    r2s<BM, AKC>(ra[u], As);
+                    r2s<BN, BKC>(rb[u], Bs);
+                }
+                __syncthreads();
+                if (t + PF < t_end && !(a.ablate & 2)) {
+                    int s, k0;
+                    locate(a, t + PF, s, k0);
+                    g2r<BM, AKC>(ra[u], a.seg[s].A, a.seg[s].lda, m0, a.M, k0, a.seg[s].K, AKC ? a.seg[s].a_row_div : 1, a.seg[s].vecA);
+                    g2r<BN, BKC>(rb[u], a.seg[s].B, a.seg[s].ldb, n0, a.N, k0, a.seg[s].K, 1, a.seg[s].vecB);
+                }
+                if (a.ablate & 1) continue;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = As[krow * LDA + wm0 + 32 * i + l31];
+                for (int q = 0; q < BK / 8; ++q) {
+                    // lane (l31, khalf) supplies k = 8q + 4*khalf + e to MFMA e = 0..3 of this group
+                    const int kb = 8 * q + 4 * khalf;
+                    f32x4 av[TM], bv[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = Bs[krow * LDB + wn0 + 32 * j + l31];
+                    for (int i = 0; i < TM; ++i) {
+                        const int row = wm0 + 32 * i + l31;
+                        if (AKC) av[i] = *reinterpret_cast<const f32x4 *>(As + row * LDA + kb);
+                        else av[i] = f32x4{As[(kb + 0) * LDA + row], As[(kb + 1) * LDA + row], As[(kb + 2) * LDA + row],
+                                           As[(kb + 3) * LDA + row]};
+                    }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int j = 0; j < TN; ++j) {
+                        const int col = wn0 + 32 * j + l31;
+                        if (BKC) bv[j] = *reinterpret_cast<const f32x4 *>(Bs + col * LDB + kb);
+                        else bv[j] = f32x4{Bs[(kb + 0) * LDB + col], Bs[(kb + 1) * LDB + col], Bs[(kb + 2) * LDB + col],
+                                           Bs[(kb + 3) * LDB + col]};
+                    }
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+                }
+            }
         }
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const bool to_partial = a.to_partial != 0;
-    float *out = to_partial ? a.partial + (size_t)z * a.M * a.N : a.C;
+    const size_t MN = (size_t)a.M * a.N;
+    float *out = to_partial ? a.partial + (size_t)z * MN : a.C;
     const int ldo = to_partial ? a.N : a.ldc;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -237,11 +230,53 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const KArgs a) {
                     if (a.relu) v = fmaxf(v, 0.f);
                     if (a.mul_mask) v *= a.mul_mask[(size_t)row * a.N + col];
                     if (a.accumulate) v += out[(size_t)row * ldo + col];
+                    out[(size_t)row * ldo + col] = v;
+                } else if (a.self_reduce) {
+                    // write-through (sc1) slab store: visible to the last-arriving workgroup without a release fence
+                    __hip_atomic_store(out + (size_t)row * ldo + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    out[(size_t)row * ldo + col] = v;
                 }
-                out[(size_t)row * ldo + col] = v;
             }
         }
     }
+    if (!(to_partial && a.self_reduce)) return;
+    // in-launch split-K reduction (cdna_hip_programming.md G16): drain, ticket, last arriver acquires + reduces
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *ticket = a.counters + (blockIdx.y * gridDim.x + blockIdx.x);
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == a.splits - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    for (int e = threadIdx.x; e < BM * BN; e += NT) {
+        const int rr = e / BN, cc = e % BN;
+        const int row = m0 + rr, col = n0 + cc;
+        if (row < a.M && col < a.N) {
+            const float *pp = a.partial + (size_t)row * a.N + col;
+            float v = 0.f;
+            for (int s0 = 0; s0 < a.splits; s0 += 8) {
+                float tv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tv[u] = (s0 + u < a.splits) ? pp[(size_t)(s0 + u) * MN] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += tv[u];
+            }
+            if (a.bias) v += a.bias[col];
+            if (a.bias2) v += a.bias2[col];
+            if (a.row_bias) v += a.row_bias[(size_t)(row / a.row_bias_div) * a.N + col];
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.mul_mask) v *= a.mul_mask[(size_t)row * a.N + col];
+            if (a.accumulate) v += a.C[(size_t)row * a.ldc + col];
+            a.C[(size_t)row * a.ldc + col] = v;
+        }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
 }
 
 __global__ void splitk_reduce_kernel(const float *__restrict__ partial, int splits, float *__restrict__ C, int ldc,
@@ -263,12 +298,12 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ partial, int spli
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int PF>
 int launch_cfg(const KArgs &a, int al, int bl, dim3 grid, hipStream_t st) {
-    if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true>), grid, dim3(NT), 0, st, a);
-    else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false>), grid, dim3(NT), 0, st, a);
-    else if (al == 1 && bl == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false>), grid, dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true>), grid, dim3(NT), 0, st, a);
+    if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, PF>), grid, dim3(NT), 0, st, a);
+    else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false, PF>), grid, dim3(NT), 0, st, a);
+    else if (al == 1 && bl == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false, PF>), grid, dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, PF>), grid, dim3(NT), 0, st, a);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -308,42 +343,18 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
         tiles += (g.K + BK - 1) / BK;
     }
     a.tiles_total = tiles;
+    static const int env_ablate = [] { const char *e = getenv("CAPMI_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+    a.ablate = env_ablate;
     a.M = d->M; a.N = d->N; a.C = d->C; a.ldc = d->ldc;
     a.bias = d->bias; a.bias2 = d->bias2; a.row_bias = d->row_bias;
     a.row_bias_div = d->row_bias_div > 0 ? d->row_bias_div : 1;
     a.mul_mask = d->mul_mask; a.relu = d->relu; a.accumulate = d->accumulate;
-    a.partial = d->partial;
-
-    // tile shape by M: decode batches are skinny.
-    int BM, BN;
-    if (d->M <= 32) { BM = 32; BN = 128; }
-    else if (d->M <= 64) { BM = 64; BN = 64; }
-    else if ((long long)d->M * d->N < 128LL * 128 * 192) { BM = 64; BN = 64; }
-    else { BM = 128; BN = 128; }
-    const int gm = (d->M + BM - 1) / BM, gn = (d->N + BN - 1) / BN;
-    int splits = d->splits;
-    if (splits == 0) {
-        // aim for ~2 workgroups per CU (512) but keep >= 4 K tiles per slice
-        const int blocks = gm * gn;
-        splits = 1;
-        if (blocks < 384 && d->partial) {
-            splits = (512 + blocks - 1) / blocks;
-            if (splits > tiles / 4) splits = tiles / 4;
-            if (splits > 32) splits = 32;
-            if (splits < 1) splits = 1;
-            while (splits > 1 && (int64_t)splits * d->M * d->N > d->partial_capacity) --splits;
-        }
-    }
-    if (splits > tiles) splits = tiles;
-    if (splits > 1 && (!d->partial || (int64_t)splits * d->M * d->N > d->partial_capacity)) return CAPMI_EINVAL;
-    a.splits = splits;
-    a.to_partial = (splits > 1 || d->defer_reduce) ? 1 : 0;
-    if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > d->partial_capacity)) return CAPMI_EINVAL;
-    d->splits_used = splits;
-    dim3 grid(gn, gm, splits);
+    // workspace layout: [CAPMI_WS_COUNTER_FLOATS ints of tile tickets (zero between launches)][K-slice slabs]
+    const int64_t slab_cap = d->partial ? d->partial_capacity - CAPMI_WS_COUNTER_FLOATS : 0;
+    a.partial = d->partial ? d->partial + CAPMI_WS_COUNTER_FLOATS : nullptr;
+    a.counters = reinterpret_cast<int *>(d->partial);
     hipStream_t st = (hipStream_t)stream;
-    // algorithmic traffic of this launch: every operand element once + the output once
-    double ksum = 0, abytes = 0;
+    double ksum = 0, abytes = 0;   // algorithmic traffic of this launch: every operand element once + the output once
     for (int s = 0; s < d->nseg; ++s) {
         ksum += d->seg[s].K;
         abytes += (double)d->seg[s].K * ((double)d->M / a.seg[s].a_row_div);
@@ -352,14 +363,78 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     const double flops = 2.0 * d->M * (double)d->N * ksum;
     const int pcls = (d->M <= 64 && d->a_layout == 0) ? (d->b_layout == 0 ? CAPMI_PROF_GEMM_DECODE : CAPMI_PROF_GEMM_BPTT)
                                                        : CAPMI_PROF_GEMM_FAT;
+
+    static const int env_path = [] { const char *e = getenv("CAPMI_GEMM_PATH"); return e ? atoi(e) : 0; }();
+    static const int env_blocks = [] { const char *e = getenv("CAPMI_GEMM_BLOCKS"); return e ? atoi(e) : 512; }();
+    if (env_path == 1 && d->a_layout == 0 && d->M <= 64) {
+        // ---- skinny direct-to-register path (gemm_skinny.hip) ----
+        const int tm = d->M <= 32 ? 1 : 2;
+        const int gn = (d->N + 31) / 32, gm = (d->M + 32 * tm - 1) / (32 * tm);
+        int splits = d->splits;
+        if (splits == 0) {
+            const int blocks = gn * gm;
+            splits = (512 + blocks - 1) / blocks;
+            if (splits > tiles / 8) splits = tiles / 8;
+            if (splits > 16) splits = 16;
+            if (splits < 1) splits = 1;
+            while (splits > 1 && (int64_t)splits * d->M * d->N > slab_cap) --splits;
+        }
+        if (splits > tiles) splits = tiles;
+        a.splits = splits;
+        a.to_partial = (splits > 1 || d->defer_reduce) ? 1 : 0;
+        a.self_reduce = (splits > 1 && !d->defer_reduce) ? 1 : 0;
+        if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > slab_cap)) return CAPMI_EINVAL;
+        if (a.self_reduce && gn * gm > CAPMI_WS_COUNTER_FLOATS) return CAPMI_EINVAL;
+        d->splits_used = splits;
+        capmi_prof::Scope prof(pcls, st, bytes, flops);
+        return launch_skinny(a, d->b_layout, tm, dim3(gn, gm, splits), st);
+    }
+
+    // tile shape by M: decode batches are skinny.  Every configuration gives each wave >= 2 independent
+    // accumulator chains (a lone dependent v_mfma_f32_32x32x2 chain loses ~40 % to issue gaps).
+    static const int env_cfg = [] { const char *e = getenv("CAPMI_GEMM_CFG"); return e ? atoi(e) : 1; }();
+    int BM, BN;
+    (void)env_cfg;
+    if (d->M <= 32) { BM = 32; BN = 128; }
+    else if (d->M <= 64 || (long long)d->M * d->N < 128LL * 128 * 192) {
+        BM = 64;
+        BN = (d->b_layout == 0 && tiles >= 64 && d->N >= 1024) ? 128 : 64;   // measured: wide tile only pays on long-K weight streams
+    } else { BM = 128; BN = 128; }
+    const int gm = (d->M + BM - 1) / BM, gn = (d->N + BN - 1) / BN;
+    int splits = d->splits;
+    if (splits == 0) {
+        // aim for ~2 workgroups per CU (512) but keep >= 4 K tiles per slice
+        const int blocks = gm * gn;
+        splits = 1;
+        if (blocks < env_blocks * 3 / 4 && d->partial) {
+            splits = (env_blocks + blocks - 1) / blocks;
+            if (splits > tiles / 4) splits = tiles / 4;
+            if (splits > 32) splits = 32;
+            if (splits < 1) splits = 1;
+            while (splits > 1 && (int64_t)splits * d->M * d->N > slab_cap) --splits;
+        }
+    }
+    if (splits > tiles) splits = tiles;
+    a.splits = splits;
+    a.to_partial = (splits > 1 || d->defer_reduce) ? 1 : 0;
+    // in-launch last-arriver reduction is implemented (G16 recipe) but measured SLOWER than the follow-up reduce
+    // kernel at decode sizes (logit 33.5 vs 27.9 us, dX 34.2 vs 27-31 us): opt-in via CAPMI_GEMM_SELF_REDUCE=1.
+    static const int env_self = [] { const char *e = getenv("CAPMI_GEMM_SELF_REDUCE"); return e ? atoi(e) : 0; }();
+    a.self_reduce = (env_self && splits > 1 && !d->defer_reduce && gn * gm <= CAPMI_WS_COUNTER_FLOATS) ? 1 : 0;
+    if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > slab_cap)) return CAPMI_EINVAL;
+    d->splits_used = splits;
+    dim3 grid(gn, gm, splits);
     capmi_prof::Scope prof(pcls, st, bytes, flops);
     int rc;
-    if (BM == 32) rc = launch_cfg<32, 128, 1, 4>(a, d->a_layout, d->b_layout, grid, st);
-    else if (BM == 64) rc = launch_cfg<64, 64, 2, 2>(a, d->a_layout, d->b_layout, grid, st);
-    else rc = launch_cfg<128, 128, 2, 2>(a, d->a_layout, d->b_layout, grid, st);
+    static const int env_pf = [] { const char *e = getenv("CAPMI_GEMM_PF"); return e ? atoi(e) : 3; }();
+    (void)env_pf;
+    if (BM == 32 && BN == 128) rc = launch_cfg<32, 128, 1, 4, 3>(a, d->a_layout, d->b_layout, grid, st);
+    else if (BM == 64 && BN == 64) rc = launch_cfg<64, 64, 2, 2, 3>(a, d->a_layout, d->b_layout, grid, st);
+        else if (BM == 64 && BN == 128) rc = launch_cfg<64, 128, 1, 4, 2>(a, d->a_layout, d->b_layout, grid, st);
+    else rc = launch_cfg<128, 128, 2, 2, 2>(a, d->a_layout, d->b_layout, grid, st);
     if (rc) return rc;
-    if (splits > 1 && !d->defer_reduce)
-        return capmi_splitk_reduce(d->partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,
+    if (splits > 1 && !d->defer_reduce && !a.self_reduce)
+        return capmi_splitk_reduce(a.partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,
                                    a.row_bias_div, d->mul_mask, d->relu, d->accumulate, stream);
     return 0;
 }

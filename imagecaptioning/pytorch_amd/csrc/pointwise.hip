@@ -53,22 +53,37 @@ __global__ void embed_bwd_kernel(const int64_t *__restrict__ it, const float *__
 // ---------------------------------------------------------------- LSTM cell
 __global__ void lstm_cell_fwd_kernel(const float *__restrict__ partial, int splits, const float *__restrict__ b_ih,
                                      const float *__restrict__ b_hh, const float *__restrict__ row_bias,
-                                     int row_bias_div, const float *__restrict__ c_prev, float *__restrict__ h,
+                                     int row_bias_div, const int *__restrict__ row_bias_idx,
+                                     const float *__restrict__ c_prev, float *__restrict__ h,
                                      float *__restrict__ c, float *__restrict__ gates_act,
                                      const float *__restrict__ out_mask, float *__restrict__ h_drop, int N, int R) {
     const size_t total = (size_t)N * R;
     const size_t slab = (size_t)N * 4 * R;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / R), j = (int)(i % R);
-        float g[4];
+        float g[4] = {0.f, 0.f, 0.f, 0.f};
+        // K-slice reduction: issue 8 slabs x 4 gates of independent loads per trip (the rolled form
+        // waits for every load before the next one: 36 serial HBM latencies, 18 us per launch)
+        const float *pb = partial + (size_t)r * 4 * R + j;
+        for (int s0 = 0; s0 < splits; s0 += 8) {
+            float tv[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    tv[u][q] = (s0 + u < splits) ? pb[(size_t)(s0 + u) * slab + (size_t)q * R] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] += tv[u][q];
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const size_t col = (size_t)q * R + j;
-            float v = 0.f;
-            for (int s = 0; s < splits; ++s) v += partial[s * slab + (size_t)r * 4 * R + col];
+            float v = g[q];
             if (b_ih) v += b_ih[col];
             if (b_hh) v += b_hh[col];
-            if (row_bias) v += row_bias[(size_t)(r / row_bias_div) * 4 * R + col];
+            if (row_bias) v += row_bias[(size_t)(row_bias_idx ? row_bias_idx[r] : r / row_bias_div) * 4 * R + col];
             g[q] = v;
         }
         const float ig = sigmoid_f(g[0]), fg = sigmoid_f(g[1]), gg = tanh_f(g[2]), og = sigmoid_f(g[3]);
@@ -235,12 +250,12 @@ int capmi_embed_bwd(const int64_t *it, const float *dx, const float *x_saved, co
 }
 
 int capmi_lstm_cell_fwd(const float *partial, int splits, const float *b_ih, const float *b_hh, const float *row_bias,
-                        int row_bias_div, const float *c_prev, float *h, float *c, float *gates_act,
+                        int row_bias_div, const int32_t *row_bias_idx, const float *c_prev, float *h, float *c, float *gates_act,
                         const float *out_mask, float *h_drop, int N, int R, void *stream) {
     if (!partial || splits < 1 || !c_prev || !h || !c || N <= 0 || R <= 0) return CAPMI_EINVAL;
     capmi_prof::Scope prof(CAPMI_PROF_LSTM_CELL, (hipStream_t)stream, 4.0 * N * R * (4.0 * splits + 8), 0);
     hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid_for((size_t)N * R)), dim3(256), 0, (hipStream_t)stream, partial,
-                       splits, b_ih, b_hh, row_bias, row_bias_div > 0 ? row_bias_div : 1, c_prev, h, c, gates_act,
+                       splits, b_ih, b_hh, row_bias, row_bias_div > 0 ? row_bias_div : 1, row_bias_idx, c_prev, h, c, gates_act,
                        out_mask, h_drop, N, R);
     CAPMI_CHECK_LAUNCH();
     return 0;

@@ -64,7 +64,10 @@ const char *capmi_arch(void) { return "gfx950"; }
 int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout *r, void *stream) {
     if (!w || !r) return CAPMI_EINVAL;
     const int B = r->B, n = r->n, N = r->N, K = r->K, A = r->A, R = r->R, E = r->E, V1 = r->V1, T = r->T, L = r->L;
-    if (B <= 0 || n <= 0 || N != B * n || T <= 0 || L < T || !r->partial) return CAPMI_EINVAL;
+    const int B_feat = r->B_feat > 0 ? r->B_feat : B;
+    if (B <= 0 || n <= 0 || N <= 0 || T <= 0 || L < T || !r->partial || B_feat < B) return CAPMI_EINVAL;
+    if (!r->row_img && (N != B * n || B_feat != B)) return CAPMI_EINVAL;
+    if (r->row_img && N < B * n) return CAPMI_EINVAL;
     if ((r->mode == 2 || r->teacher) && !r->forced) return CAPMI_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const size_t NR = (size_t)N * R;
@@ -82,7 +85,7 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
     // fc term of the attention LSTM, once: fc_gates[B,4R] = fc W_ih[:, R:2R]^T
     {
         SegSpec s{r->fc, R, w->att_w_ih + R, ld_att_ih, R, 1};
-        RC(gemm(stream, 0, 0, B, 4 * R, r->fc_gates, 4 * R, &s, 1, r->partial, r->partial_capacity, 0, nullptr));
+        RC(gemm(stream, 0, 0, B_feat, 4 * R, r->fc_gates, 4 * R, &s, 1, r->partial, r->partial_capacity, 0, nullptr));
     }
 
     for (int t = 0; t < T; ++t) {
@@ -111,7 +114,7 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
                             {xt, E, w->att_w_ih + 2 * R, ld_att_ih, E, 1},
                             {h_att_prev, R, w->att_w_hh, R, R, 1}};
             RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s, 3, r->partial, r->partial_capacity, 1, &splits));
-            RC(capmi_lstm_cell_fwd(r->partial, splits, w->att_b_ih, w->att_b_hh, r->fc_gates, n, c_att_prev, h_att, c_att,
+            RC(capmi_lstm_cell_fwd(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, w->att_b_ih, w->att_b_hh, r->fc_gates, n, r->row_img, c_att_prev, h_att, c_att,
                                    r->gates_att + (size_t)t * N * 4 * R, nullptr, nullptr, N, R, stream));
         }
         // 4. att_h = h_att W_h2att^T + b
@@ -120,15 +123,15 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
             RC(gemm(stream, 0, 0, N, A, att_h, A, &s, 1, r->partial, r->partial_capacity, 0, nullptr, w->h2att_b));
         }
         // 5. fused region attention
-        RC(capmi_attention_fwd(att_h, r->p_att, r->att, r->att_mask, w->alpha_w, w->alpha_b, ctx, alpha, B, n, K, A, R,
-                               stream));
+        RC(capmi_attention_fwd(att_h, r->p_att, r->att, r->att_mask, w->alpha_w, w->alpha_b, ctx, alpha, B_feat, n, K, A, R,
+                               r->row_img, N, stream));
         // 6-7. language LSTM: gates = [ctx | h_att | h_lang_prev] . [W_ih(:, 0:R) | W_ih(:, R:2R) | W_hh]
         {
             SegSpec s[3] = {{ctx, R, w->lang_w_ih, 2 * R, R, 1},
                             {h_att, R, w->lang_w_ih + R, 2 * R, R, 1},
                             {h_lang_prev, R, w->lang_w_hh, R, R, 1}};
             RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s, 3, r->partial, r->partial_capacity, 1, &splits));
-            RC(capmi_lstm_cell_fwd(r->partial, splits, w->lang_b_ih, w->lang_b_hh, nullptr, 1, c_lang_prev, h_lang, c_lang,
+            RC(capmi_lstm_cell_fwd(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, w->lang_b_ih, w->lang_b_hh, nullptr, 1, nullptr, c_lang_prev, h_lang, c_lang,
                                    r->gates_lang + (size_t)t * N * 4 * R,
                                    r->drop_out ? r->drop_out + (size_t)t * NR : nullptr, h_drop, N, R, stream));
         }
@@ -195,7 +198,8 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
         // attention Jacobian: d_ctx -> d_att_h (and d_e kept for the batched pass)
         RC(capmi_attention_bwd(d_x2, 3 * R, r->att_h + (size_t)t * N * A, r->alpha + (size_t)t * N * K, r->p_att, r->att,
                                r->att_mask, w->alpha_w, s->d_att_h_all + (size_t)t * N * A,
-                               s->d_e_all + (size_t)t * N * K, B, n, K, A, R, stream));
+                               s->d_e_all + (size_t)t * N * K, r->B_feat > 0 ? r->B_feat : B, n, K, A, R, r->row_img, N,
+                               stream));
         {
             SegSpec a{s->d_att_h_all + (size_t)t * N * A, A, w->h2att_w, R, A, 1};   // dh_att via h2att
             RC(gemm(stream, 0, 1, N, R, s->dh_att_attn, R, &a, 1, P, cap, 0, nullptr));
@@ -259,7 +263,7 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
         RC(gemm(stream, 1, 1, A, R, g->h2att_w, R, &a, 1, P, cap, 0, nullptr));
         RC(capmi_colsum(s->d_att_h_all, TN, A, A, g->h2att_b, 0, stream));
         RC(capmi_attention_bwd_batched(s->d_x2, 3 * R, r->att_h, r->alpha, s->d_e_all, r->p_att, w->alpha_w, g->d_att,
-                                       g->d_p_att, g->alpha_w, g->alpha_b, T, B, n, K, A, R, stream));
+                                       g->d_p_att, g->alpha_w, g->alpha_b, T, B, n, N, K, A, R, stream));
     }
     return 0;
 }

@@ -25,8 +25,14 @@ def _chk(*ts):
 class Workspace:
     """Split-K scratch shared by the GEMM launches of one stream."""
 
+    COUNTER_FLOATS = 16384      # CAPMI_WS_COUNTER_FLOATS: tile tickets live in front of the slabs, zero-initialised
+
     def __init__(self, device, floats=16 * 1024 * 1024):
-        self.buf = torch.empty(floats, dtype=_f32, device=device)
+        self.buf = torch.zeros(floats + self.COUNTER_FLOATS, dtype=_f32, device=device)
+
+    @property
+    def slabs(self):
+        return self.buf[self.COUNTER_FLOATS:]
 
     @property
     def capacity(self):
@@ -111,20 +117,20 @@ def matmul_tn(a, b, out=None, ws=None):
     return out
 
 
-def attention_fwd(att_h, p_att, att, mask, w, b, n):
+def attention_fwd(att_h, p_att, att, mask, w, b, n, row_img=None):
     _chk(att_h, p_att, att, mask, w, b)
     B, K, A = p_att.shape
     R = att.shape[2]
     N = att_h.shape[0]
-    assert N == B * n
+    assert row_img is not None or N == B * n
     ctx = torch.empty(N, R, dtype=_f32, device=att.device)
     alpha = torch.empty(N, K, dtype=_f32, device=att.device)
     check(lib.capmi_attention_fwd(ptr(att_h), ptr(p_att), ptr(att), ptr(mask), ptr(w), ptr(b), ptr(ctx), ptr(alpha),
-                                  B, n, K, A, R, stream_ptr()), 'capmi_attention_fwd')
+                                  B, n, K, A, R, ptr(row_img), N, stream_ptr()), 'capmi_attention_fwd')
     return ctx, alpha
 
 
-def attention_bwd(d_ctx, att_h, alpha, p_att, att, mask, w, n):
+def attention_bwd(d_ctx, att_h, alpha, p_att, att, mask, w, n, row_img=None):
     _chk(d_ctx, att_h, alpha, p_att, att, mask, w)
     B, K, A = p_att.shape
     R = att.shape[2]
@@ -132,7 +138,8 @@ def attention_bwd(d_ctx, att_h, alpha, p_att, att, mask, w, n):
     d_att_h = torch.empty(N, A, dtype=_f32, device=att.device)
     d_e = torch.empty(N, K, dtype=_f32, device=att.device)
     check(lib.capmi_attention_bwd(ptr(d_ctx), d_ctx.shape[1], ptr(att_h), ptr(alpha), ptr(p_att), ptr(att), ptr(mask),
-                                  ptr(w), ptr(d_att_h), ptr(d_e), B, n, K, A, R, stream_ptr()), 'capmi_attention_bwd')
+                                  ptr(w), ptr(d_att_h), ptr(d_e), B, n, K, A, R, ptr(row_img), N, stream_ptr()),
+          'capmi_attention_bwd')
     return d_att_h, d_e
 
 
@@ -147,7 +154,7 @@ def attention_bwd_batched(d_ctx_all, att_h_all, alpha_all, d_e_all, p_att, w, n,
     d_b = torch.empty(1, dtype=_f32, device=dev)
     check(lib.capmi_attention_bwd_batched(ptr(d_ctx_all), d_ctx_all.shape[-1], ptr(att_h_all), ptr(alpha_all),
                                           ptr(d_e_all), ptr(p_att), ptr(w), ptr(d_att), ptr(d_p_att), ptr(d_w), ptr(d_b),
-                                          T, B, n, K, A, R, stream_ptr()), 'capmi_attention_bwd_batched')
+                                          T, B, n, att_h_all.shape[1], K, A, R, stream_ptr()), 'capmi_attention_bwd_batched')
     return d_att, d_p_att, d_w, d_b
 
 
@@ -158,7 +165,7 @@ def lstm_cell_fwd(partial, splits, b_ih, b_hh, c_prev, row_bias=None, row_bias_d
     c = torch.empty(N, R, dtype=_f32, device=dev)
     gates = torch.empty(N, 4 * R, dtype=_f32, device=dev)
     h_drop = torch.empty(N, R, dtype=_f32, device=dev) if (want_drop or out_mask is not None) else None
-    check(lib.capmi_lstm_cell_fwd(ptr(partial), splits, ptr(b_ih), ptr(b_hh), ptr(row_bias), row_bias_div, ptr(c_prev),
+    check(lib.capmi_lstm_cell_fwd(ptr(partial), splits, ptr(b_ih), ptr(b_hh), ptr(row_bias), row_bias_div, None, ptr(c_prev),
                                   ptr(h), ptr(c), ptr(gates), ptr(out_mask), ptr(h_drop), N, R, stream_ptr()),
           'capmi_lstm_cell_fwd')
     return h, c, gates, h_drop

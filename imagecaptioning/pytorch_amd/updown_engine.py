@@ -110,12 +110,18 @@ class Rollout:
     """Device buffers + one native call for a T-step rollout of N = B*n caption rows."""
 
     def __init__(self, P, pr, n, T, L=None, mode='greedy', temperature=1.0, drop_xt=None, drop_out=None,
-                 gumbel=None, seed=0, forced=None, teacher=False, row_mode=None, ws=None, keep_for_backward=True):
+                 gumbel=None, seed=0, forced=None, teacher=False, row_mode=None, ws=None, keep_for_backward=True,
+                 row_img=None, B_grad=None):
+        """row_img (int32 [N]) + B_grad: ragged grouping for the fused SCST rollout -- the first B_grad
+        feature images own rows b*n..b*n+n-1 (sampled, with gradient), the remaining rows (greedy baseline)
+        point at further feature images through row_img."""
         dev = pr.fc.device
-        B, K, R = pr.att.shape
+        B_feat, K, R = pr.att.shape
         A = pr.p_att.shape[2]
         V1, E = P['embed.0.weight'].shape
-        N = B * n
+        B = B_feat if B_grad is None else B_grad
+        N = B * n if row_img is None else row_img.shape[0]
+        self.row_img = row_img
         L = T if L is None else L
         self.P, self.pr, self.dims = P, pr, (B, n, N, K, A, R, E, V1, T, L)
         self.ws = ws or ops.default_workspace(dev)
@@ -129,7 +135,7 @@ class Rollout:
         self.seq_logp = torch.zeros(N, L, V1, dtype=_f32, device=dev)
         self.sel_logp = torch.zeros(N, L, dtype=_f32, device=dev)
         self.live = torch.zeros(N, L, dtype=torch.uint8, device=dev)
-        self.fc_gates = z(B, 4 * R)
+        self.fc_gates = z(B_feat, 4 * R)
         self.logits = z(N, V1)
         self.it = torch.empty(N, dtype=torch.long, device=dev)
         self.unfinished = torch.empty(N, dtype=torch.uint8, device=dev)
@@ -137,6 +143,7 @@ class Rollout:
 
         r = _lib.UpDownRollout()
         r.B, r.n, r.N, r.K, r.A, r.R, r.E, r.V1, r.T, r.L = B, n, N, K, A, R, E, V1, T, L
+        r.B_feat, r.row_img = B_feat, ptr(row_img)
         r.fc, r.att, r.p_att, r.att_mask = ptr(pr.fc), ptr(pr.att), ptr(pr.p_att), ptr(pr.att_masks)
         r.drop_xt, r.drop_out = ptr(drop_xt), ptr(drop_out)
         r.mode = {'greedy': 0, 'sample': 1, 'forced': 2}[mode]

@@ -26,6 +26,10 @@ extern "C" {
 
 #define CAPMI_EINVAL (-1)
 #define CAPMI_MAX_SEG 4
+/* GEMM workspace layout: the first CAPMI_WS_COUNTER_FLOATS 4-byte words are per-tile arrival tickets for
+ * the in-launch split-K reduction (must be ZERO when a workspace is first used; kernels re-arm them),
+ * K-slice slabs follow.  A fused consumer of deferred slices reads them at partial + this offset. */
+#define CAPMI_WS_COUNTER_FLOATS 16384
 
 /* library / device introspection -------------------------------------------------------------- */
 int capmi_version(void);                 /* ABI version, bumped on any signature change */
@@ -46,9 +50,10 @@ const char *capmi_arch(void);            /* "gfx950" */
  * epilogue (applied when the K reduction is complete):
  *   v = acc + bias[n] + bias2[n] + row_bias[(m / row_bias_div) * N + n]
  *   if relu: v = max(v, 0);  if mul_mask: v *= mul_mask[m * N + n];  if accumulate: v += C[m*ldc+n]
- * split-K: splits > 1 writes raw partial sums to `partial` ([splits][M][N], caller-provided) and,
- *   unless defer_reduce, runs the reduce+epilogue kernel; splits == 0 lets the library choose
- *   (needs partial_capacity floats available in `partial`, may be 0 => no split).
+ * split-K: splits > 1 writes raw K-slice sums to the workspace `partial` (layout: see
+ *   CAPMI_WS_COUNTER_FLOATS; slabs are [splits][M][N]).  Unless defer_reduce, the slices are combined
+ *   and the epilogue applied INSIDE the launch by the last-arriving workgroup of each tile (skinny
+ *   path) or by a follow-up reduce kernel (fat path).  splits == 0 lets the library choose.
  * ------------------------------------------------------------------------------------------- */
 typedef struct capmi_gemm_seg {
     const float *A;
@@ -94,27 +99,32 @@ int capmi_gemm_f32(capmi_gemm_desc *d, void *stream);
  * of that image (no repeat_tensors copy).  att_h [N,A], p_att [B,K,A], att [B,K,R], mask [B,K] or
  * NULL, w [A], b scalar pointer; outputs ctx [N,R], alpha [N,K].  N = B*n, n <= 8.
  * ------------------------------------------------------------------------------------------- */
+/* row_img (optional, int32 [N]): explicit row -> image map for ragged groupings (the fused
+ * greedy+sample SCST rollout: B*n sampled rows on train-mode features followed by B greedy rows on
+ * eval-mode features).  With row_img the call takes N rows (n is ignored) and one row per workgroup. */
 int capmi_attention_fwd(const float *att_h, const float *p_att, const float *att, const float *mask,
                         const float *w, const float *b, float *ctx, float *alpha,
-                        int B, int n, int K, int A, int R, void *stream);
+                        int B, int n, int K, int A, int R, const int32_t *row_img, int N, void *stream);
 
 /* backward of the above for one time step.  Inputs d_ctx [N,R] plus the saved att_h/alpha.
  * Outputs d_att_h [N,A] (feeds h2att backward) and d_e [N,K] (softmax-input gradient, kept for the
  * time-batched parameter/feature gradients below). */
 int capmi_attention_bwd(const float *d_ctx, int ld_dctx, const float *att_h, const float *alpha,
                         const float *p_att, const float *att, const float *mask, const float *w,
-                        float *d_att_h, float *d_e, int B, int n, int K, int A, int R, void *stream);
+                        float *d_att_h, float *d_e, int B, int n, int K, int A, int R,
+                        const int32_t *row_img, int N, void *stream);
 
 /* time-batched feature/parameter gradients of the attention over a whole rollout of T steps:
  *   d_att[b,k,:]   += sum_{t, r in image b} alpha[t,r,k] * d_ctx[t,r,:]
  *   d_p_att[b,k,a] += sum_{t, r in b} d_e[t,r,k] * w[a] * (1 - tanh^2(p_att[b,k,a] + att_h[t,r,a]))
  *   d_w[a]         += sum_{t,r,k} d_e[t,r,k] * tanh(p_att[b,k,a] + att_h[t,r,a]);  d_b += sum d_e
- * All *_all arrays are [T,N,...] (d_ctx_all rows have pitch ld_dctx).  d_att/d_p_att/d_w/d_b are
- * overwritten (not accumulated). */
+ * All *_all arrays are [T,N_stride,...] (d_ctx_all rows have pitch ld_dctx); image b owns rows
+ * b*n .. b*n+n-1 of every time slab (rows >= B*n, e.g. greedy rows, are ignored).  d_att/d_p_att/d_w/d_b
+ * are overwritten (not accumulated). */
 int capmi_attention_bwd_batched(const float *d_ctx_all, int ld_dctx, const float *att_h_all, const float *alpha_all,
                                 const float *d_e_all, const float *p_att, const float *w,
                                 float *d_att, float *d_p_att, float *d_w, float *d_b,
-                                int T, int B, int n, int K, int A, int R, void *stream);
+                                int T, int B, int n, int N_stride, int K, int A, int R, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LSTM cell pointwise stage (torch.nn.LSTMCell gate math, gate order i,f,g,o; AttModel.py:628,635):
@@ -124,8 +134,9 @@ int capmi_attention_bwd_batched(const float *d_ctx_all, int ld_dctx, const float
  * activated gates [N,4R] (saved for backward) and, if out_mask, h_drop = h' * out_mask
  * (F.dropout at AttModel.py:637).
  * ------------------------------------------------------------------------------------------- */
+/* row_bias_idx (optional int32 [N]) replaces r / row_bias_div as the row_bias row index. */
 int capmi_lstm_cell_fwd(const float *partial, int splits, const float *b_ih, const float *b_hh,
-                        const float *row_bias, int row_bias_div, const float *c_prev,
+                        const float *row_bias, int row_bias_div, const int32_t *row_bias_idx, const float *c_prev,
                         float *h, float *c, float *gates_act, const float *out_mask, float *h_drop,
                         int N, int R, void *stream);
 
@@ -248,8 +259,11 @@ typedef struct capmi_updown_weights {
 } capmi_updown_weights;
 
 typedef struct capmi_updown_rollout {
-    /* sizes */
+    /* sizes: B images carry gradients and own rows b*n..b*n+n-1; B_feat >= B feature images exist in
+     * fc/att/p_att (B_feat > B only with row_img); N rows in total (N == B*n unless row_img is given) */
     int B, n, N, K, A, R, E, V1;
+    int B_feat;
+    const int32_t *row_img; /* [N] row -> feature image, or NULL (= row / n) */
     int T;                  /* steps to run */
     int L;                  /* step pitch of seq / seq_logp / sel_logp / live (>= T) */
     /* per-image prepared features (outputs of the prefill GEMMs) */

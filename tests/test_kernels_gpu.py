@@ -24,7 +24,7 @@ def rel_err(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
-@pytest.mark.parametrize('M,N,K', [(3, 5, 7), (10, 4000, 1000), (50, 512, 1000), (64, 64, 32), (50, 9488, 1000),
+@pytest.mark.parametrize('M,N,K', [(3, 5, 7), (10, 4000, 1000), (50, 512, 1000), (64, 64, 32), (50, 9488, 1000), (60, 4000, 3000), (33, 70, 50),
                                    (360, 1000, 2048), (130, 257, 100), (1000, 1000, 9488)])
 def test_gemm_nt_linear(dev, M, N, K):
     ops = ops_mod()
@@ -61,7 +61,7 @@ def test_gemm_multisegment_rowdiv_and_deferred_partials(dev):
             (d(hp), R, Whd, R, R, 1)]
     splits = ops.gemm(segs, N, 4 * R, ws.buf, ws=ws, splits=3, defer_reduce=True)
     assert splits == 3
-    hh, cc, gates, _ = ops.lstm_cell_fwd(ws.buf, splits, d(b_ih), d(b_hh), d(cp))
+    hh, cc, gates, _ = ops.lstm_cell_fwd(ws.slabs, splits, d(b_ih), d(b_hh), d(cp))
     assert rel_err(hh, h_ref) < 2e-6 and rel_err(cc, c_ref) < 2e-6
 
 

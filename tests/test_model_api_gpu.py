@@ -125,3 +125,62 @@ def test_scst_step_end_to_end_matches_oracle_reward_and_updates():
     adv, _ = rewards.self_critical_reward_device(greedy, gts, ro.seq, opt)
     np.testing.assert_allclose(adv.cpu().numpy(), rew_ref[:, 0], rtol=1e-5, atol=1e-6)
     rewards.reset_scorer()
+
+
+def test_fused_scst_rollouts_equal_separate_rollouts():
+    """The fused (greedy rows riding in the sampled rollout's MFMA tile) pass must reproduce, row for row,
+    what the reference's two separate calls produce: greedy tokens of an eval-mode decode and, with the same
+    dropout masks and Gumbel noise, the sampled tokens / log-probs / gradients of a train-mode decode."""
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import RewardCriterion
+    opt = tiny_opt(drop_prob_lm=0.5)
+    torch.manual_seed(11)
+    model = models.setup(opt).to(DEV)
+    B, n, L, K = 5, 3, 8, 6
+    V1 = opt.vocab_size + 1
+    g = torch.Generator().manual_seed(5)
+    fc = torch.randn(B, 20, generator=g).clamp_min(0).to(DEV)
+    att = torch.randn(B, K, 20, generator=g).clamp_min(0).to(DEV)
+    am = torch.ones(B, K)
+    am[1, 4:] = 0
+    am = am.to(DEV)
+    N = B * n
+    gum = -torch.log(-torch.log(torch.rand(L, N + B, V1, generator=g).clamp_min(1e-20))).to(DEV)
+    reward = torch.randn(N, 1, generator=g).repeat(1, L).to(DEV)
+
+    # fixed dropout masks for both paths
+    R, E = opt.rnn_size, opt.input_encoding_size
+    keep = lambda *s: ((torch.rand(*s, generator=g) < 0.5).float() * 2).to(DEV)     # noqa: E731
+    m_fc, m_att, m_xt, m_out = keep(B, R), keep(B, K, R), keep(L, N + B, E), keep(L, N + B, R)
+
+    def masks_for(rows):
+        def f(B_, K_, N_, T_, dev):
+            if not model.training:
+                return {}
+            return dict(drop_fc=m_fc, drop_att=m_att, drop_xt=m_xt[:, :N_].contiguous().clone(),
+                        drop_out=m_out[:, :N_].contiguous().clone())
+        return f
+
+    model._dropout_masks = masks_for(None)
+    model.train()
+    greedy_f, gen_f, logp_f = model.scst_rollouts(fc, att, am, sample_n=n, _gumbel=gum)
+    loss_f = RewardCriterion()(logp_f, gen_f, reward)
+    model.zero_grad()
+    loss_f.backward()
+    grads_f = {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    model.eval()
+    with torch.no_grad():
+        greedy_s, _ = model(fc, att, am, opt={'sample_method': 'greedy'}, mode='sample')
+    model.train()
+    gen_s, logp_s = model(fc, att, am, opt={'sample_method': 'sample', 'sample_n': n, '_gumbel': gum[:, :N].contiguous()},
+                          mode='sample')
+    assert torch.equal(greedy_f, greedy_s)
+    assert torch.equal(gen_f, gen_s)
+    assert float((logp_f - logp_s).abs().max()) < 1e-5
+    loss_s = RewardCriterion()(logp_s, gen_s, reward)
+    model.zero_grad()
+    loss_s.backward()
+    for k, p in model.named_parameters():
+        ref = p.grad
+        assert float((grads_f[k] - ref).abs().max()) <= 1e-5 + 1e-4 * float(ref.abs().max()), k

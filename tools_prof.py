@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 results .db (kernel trace) as a markdown table: python tools_prof.py db [steps] [title]"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+    title = sys.argv[3] if len(sys.argv) > 3 else sys.argv[1]
+    rows = db.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, "
+                      "max(end-start)/1e3 from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    print('# %s\n' % title)
+    print('kernel time %.3f ms/step over %g steps\n' % (tot / steps / 1e3, steps))
+    print('| kernel | calls/step | us/step | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|')
+    for r in rows[:32]:
+        print('| `%s` | %.1f | %.0f | %.2f | %.2f | %.2f | %.1f |' % (r[0][:100], r[1] / steps, r[2] / steps, r[3], r[4], r[5],
+                                                                   100 * r[2] / tot))
+
+
+if __name__ == '__main__':
+    main()
