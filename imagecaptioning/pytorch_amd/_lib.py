@@ -12,7 +12,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL: shared HIP runtime)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libcapmi.so')
+LIB_PATH = os.environ.get('CAPMI_LIB') or os.path.join(HERE, 'libcapmi.so')   # CAPMI_LIB: experiment builds only
 MAX_SEG = 4
 EINVAL = -1
 
@@ -57,7 +57,8 @@ class UpDownGrads(C.Structure):
 
 class UpDownBwdScratch(C.Structure):
     _fields_ = ([(k, c_f) for k in ('dlogits', 'd_hdrop', 'dg_att', 'dg_lang', 'd_x2', 'd_e_all', 'd_att_h_all',
-                                    'dh_att_attn', 'd_x1', 'dc_att', 'dc_lang', 'd_xt_all', 'sum_dg_att', 'partial')] +
+                                    'dh_att_attn', 'd_x1', 'dc_att', 'dc_lang', 'd_xt_all', 'sum_dg_att', 'w_lang_cat',
+                                    'w_att_cat', 'partial')] +
                 [('partial_capacity', C.c_int64)])
 
 

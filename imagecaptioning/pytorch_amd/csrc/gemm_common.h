@@ -6,7 +6,10 @@
 
 namespace capmi_gemm {
 
-constexpr int BK = 32;
+#ifndef CAPMI_BK
+#define CAPMI_BK 32
+#endif
+constexpr int BK = CAPMI_BK;
 constexpr int NT = 256;
 
 struct Seg {

@@ -286,7 +286,13 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ partial, int spli
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(i / N), col = (int)(i % N);
         float v = 0.f;
-        for (int s = 0; s < splits; ++s) v += partial[(size_t)s * total + i];
+        for (int s0 = 0; s0 < splits; s0 += 8) {   // 8 independent loads in flight (a rolled loop serialises the latencies)
+            float tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tv[u] = (s0 + u < splits) ? partial[(size_t)(s0 + u) * total + i] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += tv[u];
+        }
         if (bias) v += bias[col];
         if (bias2) v += bias2[col];
         if (row_bias) v += row_bias[(size_t)(row / row_bias_div) * N + col];
@@ -396,7 +402,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     int BM, BN;
     (void)env_cfg;
     if (d->M <= 32) { BM = 32; BN = 128; }
-    else if (d->M <= 64 || (long long)d->M * d->N < 128LL * 128 * 192) {
+    else if (d->M <= 64 || (long long)d->M * d->N < 256LL * 1024) {
         BM = 64;
         BN = (d->b_layout == 0 && tiles >= 64 && d->N >= 1024) ? 128 : 64;   // measured: wide tile only pays on long-K weight streams
     } else { BM = 128; BN = 128; }

@@ -170,6 +170,22 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
         RC(capmi_colsum(s->dlogits, TN, V1, V1, g->logit_b, 0, stream));
     }
 
+    // ---- pack the recurrent weight slices once: [W_ih | W_hh] side by side, so that each step needs ONE
+    //      dX GEMM per LSTM instead of two (+ their split-K reductions): 80 MB of copies per BPTT buys back
+    //      ~80 launches.
+    {
+        hipError_t e;
+        const size_t fb = sizeof(float);
+        if ((e = hipMemcpy2DAsync(s->w_lang_cat, 3 * R * fb, w->lang_w_ih, 2 * R * fb, 2 * R * fb, 4 * R,
+                                  hipMemcpyDeviceToDevice, st)) != hipSuccess) return (int)e;
+        if ((e = hipMemcpy2DAsync(s->w_lang_cat + 2 * R, 3 * R * fb, w->lang_w_hh, R * fb, R * fb, 4 * R,
+                                  hipMemcpyDeviceToDevice, st)) != hipSuccess) return (int)e;
+        if ((e = hipMemcpy2DAsync(s->w_att_cat, 2 * R * fb, w->att_w_ih, (size_t)ld_att_ih * fb, R * fb, 4 * R,
+                                  hipMemcpyDeviceToDevice, st)) != hipSuccess) return (int)e;
+        if ((e = hipMemcpy2DAsync(s->w_att_cat + R, 2 * R * fb, w->att_w_hh, R * fb, R * fb, 4 * R,
+                                  hipMemcpyDeviceToDevice, st)) != hipSuccess) return (int)e;
+    }
+
     // ---- BPTT over the recurrent part ----------------------------------------------------------
     for (int t = T - 1; t >= 0; --t) {
         const bool last = (t == T - 1);
@@ -190,10 +206,8 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
                                stream));
         // d_x2 = dg_lang [W_ih | W_hh]  -> (d_ctx | dh_att | dh_lang_prev)
         {
-            SegSpec a{dg_lang, 4 * R, w->lang_w_ih, 2 * R, 4 * R, 1};
-            RC(gemm(stream, 0, 1, N, 2 * R, d_x2, 3 * R, &a, 1, P, cap, 0, nullptr));
-            SegSpec b{dg_lang, 4 * R, w->lang_w_hh, R, 4 * R, 1};
-            RC(gemm(stream, 0, 1, N, R, d_x2 + 2 * R, 3 * R, &b, 1, P, cap, 0, nullptr));
+            SegSpec a{dg_lang, 4 * R, s->w_lang_cat, 3 * R, 4 * R, 1};
+            RC(gemm(stream, 0, 1, N, 3 * R, d_x2, 3 * R, &a, 1, P, cap, 0, nullptr));
         }
         // attention Jacobian: d_ctx -> d_att_h (and d_e kept for the batched pass)
         RC(capmi_attention_bwd(d_x2, 3 * R, r->att_h + (size_t)t * N * A, r->alpha + (size_t)t * N * K, r->p_att, r->att,
@@ -211,10 +225,8 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
                                stream));
         // d_x1 = dg_att [W_ih(:, 0:R) | W_hh] -> (dh_lang_prev | dh_att_prev); not needed at t = 0
         if (t > 0) {
-            SegSpec a{dg_att, 4 * R, w->att_w_ih, ld_att_ih, 4 * R, 1};
-            RC(gemm(stream, 0, 1, N, R, d_x1, 2 * R, &a, 1, P, cap, 0, nullptr));
-            SegSpec b{dg_att, 4 * R, w->att_w_hh, R, 4 * R, 1};
-            RC(gemm(stream, 0, 1, N, R, d_x1 + R, 2 * R, &b, 1, P, cap, 0, nullptr));
+            SegSpec a{dg_att, 4 * R, s->w_att_cat, 2 * R, 4 * R, 1};
+            RC(gemm(stream, 0, 1, N, 2 * R, d_x1, 2 * R, &a, 1, P, cap, 0, nullptr));
         }
     }
 

@@ -176,7 +176,7 @@ class Rollout:
         keep = dict(dlogits=z(T, N, V1), d_hdrop=z(T, N, R), dg_att=z(T, N, 4 * R), dg_lang=z(T, N, 4 * R),
                     d_x2=z(T, N, 3 * R), d_e_all=z(T, N, K), d_att_h_all=z(T, N, A), dh_att_attn=z(N, R),
                     d_x1=z(T, N, 2 * R), dc_att=z(2, N, R), dc_lang=z(2, N, R), d_xt_all=z(T, N, E),
-                    sum_dg_att=z(B, 4 * R))
+                    sum_dg_att=z(B, 4 * R), w_lang_cat=z(4 * R, 3 * R), w_att_cat=z(4 * R, 2 * R))
         for k, t in keep.items():
             setattr(s, k, t.data_ptr())
         s.partial, s.partial_capacity = self.ws.buf.data_ptr(), self.ws.capacity

@@ -333,6 +333,8 @@ typedef struct capmi_updown_bwd_scratch {
     float *dc_att, *dc_lang;   /* [2][N,R] ping-pong */
     float *d_xt_all;    /* [T,N,E]     */
     float *sum_dg_att;  /* [B,4R]      */
+    float *w_lang_cat;  /* [4R,3R]  = [lang W_ih | lang W_hh], packed once per BPTT: one dX GEMM per step */
+    float *w_att_cat;   /* [4R,2R]  = [att W_ih(:, 0:R) | att W_hh] */
     float *partial;
     int64_t partial_capacity;
 } capmi_updown_bwd_scratch;
