@@ -62,6 +62,27 @@ class UpDownBwdScratch(C.Structure):
                 [('partial_capacity', C.c_int64)])
 
 
+class NewFCWeights(C.Structure):
+    _fields_ = [(k, c_f) for k in ('embed', 'i2h_w', 'i2h_b', 'h2h_w', 'h2h_b', 'logit_w', 'logit_b')]
+
+
+class NewFCRollout(C.Structure):
+    _fields_ = ([(k, C.c_int) for k in ('B', 'n', 'N', 'R', 'E', 'V1', 'T', 'L')] + [('fc_emb', c_f), ('drop_out', c_f)] +
+                [('mode', C.c_int), ('temperature', C.c_float), ('gumbel', c_f), ('seed', C.c_uint64), ('forced', c_f),
+                 ('forced_ld', C.c_int), ('teacher', C.c_int)] +
+                [(k, c_f) for k in ('h', 'c', 'x', 'it_all', 'saved', 'h_drop', 'seq', 'seq_logp', 'sel_logp', 'live',
+                                    'logits', 'it', 'unfinished', 'partial')] + [('partial_capacity', C.c_int64)])
+
+
+class NewFCGrads(C.Structure):
+    _fields_ = [(k, c_f) for k in ('embed', 'i2h_w', 'i2h_b', 'h2h_w', 'h2h_b', 'logit_w', 'logit_b', 'd_fc_emb')]
+
+
+class NewFCBwdScratch(C.Structure):
+    _fields_ = ([(k, c_f) for k in ('dlogits', 'd_hdrop', 'd_sums', 'dh_prev', 'dc', 'd_x_all', 'd_ximg', 'partial')] +
+                [('partial_capacity', C.c_int64)])
+
+
 _I, _F, _P, _U64, _I64 = C.c_int, C.c_float, C.c_void_p, C.c_uint64, C.c_int64
 
 # name -> argtypes (restype is always int unless noted).  Must list EVERY symbol of include/capmi.h:
@@ -90,6 +111,11 @@ SIGNATURES = {
     'capmi_prof_enable': [_I],
     'capmi_prof_reset': [],
     'capmi_prof_read': [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    'capmi_maxout_cell_fwd': [_P, _I] + [_P] * 8 + [_I, _I, _P],
+    'capmi_maxout_cell_bwd': [_P] * 9 + [_I, _I, _P],
+    'capmi_newfc_rollout_fwd': [C.POINTER(NewFCWeights), C.POINTER(NewFCRollout), _P],
+    'capmi_newfc_rollout_bwd': [C.POINTER(NewFCWeights), C.POINTER(NewFCRollout), _P, C.POINTER(NewFCBwdScratch),
+                                C.POINTER(NewFCGrads), _P],
     'capmi_updown_rollout_fwd': [C.POINTER(UpDownWeights), C.POINTER(UpDownRollout), _P],
     'capmi_updown_rollout_bwd': [C.POINTER(UpDownWeights), C.POINTER(UpDownRollout), _P, C.POINTER(UpDownBwdScratch),
                                  C.POINTER(UpDownGrads), _P],

@@ -1,0 +1,101 @@
+"""NewFCModel (reference AttModel.py:904-945 over FCModel.LSTMCore 13-42) on the HIP backend -- BASELINE
+configs[0] (configs/fc.yml).  Same parameter names as the reference: embed.weight, fc_embed.{weight,bias},
+_core.i2h/h2h.{weight,bias}, logit.{weight,bias}."""
+import torch
+import torch.nn as nn
+
+from .CaptionModel import CaptionModel
+from ... import newfc_engine as engine
+from ... import ops
+from ..._lib import CapmiError
+
+
+class LSTMCore(nn.Module):
+    """Parameter holder for FCModel.LSTMCore (FCModel.py:13-23)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.i2h = nn.Linear(opt.input_encoding_size, 5 * opt.rnn_size)
+        self.h2h = nn.Linear(opt.rnn_size, 5 * opt.rnn_size)
+
+
+class _RolloutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, cfg, fc_feats, *params):
+        P = dict(zip(model._param_names, [p.detach() for p in params]))
+        ro = engine.Rollout(P, fc_feats, **cfg)
+        seq, logp = ro.run()
+        ctx.model, ctx.ro, ctx.P = model, ro, P
+        ctx.mark_non_differentiable(seq)
+        return seq, logp
+
+    @staticmethod
+    def backward(ctx, _g, g_logp):
+        model, ro, P = ctx.model, ctx.ro, ctx.P
+        grads = model._flat.grad_views if model._flat is not None else {k: torch.empty_like(v) for k, v in P.items()}
+        ro.backward(g_logp, grads)
+        return (None, None, None) + tuple(grads[k] for k in model._param_names)
+
+
+class NewFCModel(CaptionModel):
+    def __init__(self, opt):
+        super().__init__()
+        self.vocab_size = opt.vocab_size
+        self.input_encoding_size = opt.input_encoding_size
+        self.rnn_size = opt.rnn_size
+        self.num_layers = 1
+        self.drop_prob_lm = opt.drop_prob_lm
+        self.seq_length = getattr(opt, 'max_length', 20) or opt.seq_length
+        self.fc_feat_size = opt.fc_feat_size
+        self.ss_prob = 0.0
+        self.vocab = opt.vocab
+        self.fc_embed = nn.Linear(self.fc_feat_size, self.input_encoding_size)
+        self.embed = nn.Embedding(self.vocab_size + 1, self.input_encoding_size)
+        self._core = LSTMCore(opt)
+        self.logit = nn.Linear(self.rnn_size, self.vocab_size + 1)
+        self._flat = None
+        self._rng_calls = 0
+
+    @property
+    def _param_names(self):
+        return [n for n, _ in self.named_parameters()]
+
+    def flatten_parameters_(self):
+        from ...flat import FlatParams
+        self._flat = FlatParams(self)
+        return self._flat
+
+    def _next_seed(self):
+        self._rng_calls += 1
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._rng_calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    def _run(self, cfg, fc_feats):
+        if not fc_feats.is_cuda:
+            raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
+        N, T = fc_feats.shape[0] * cfg['n'], cfg['T']
+        if self.training and self.drop_prob_lm > 0:
+            cfg['drop_out'] = ops.dropout_mask((T, N, self.rnn_size), self.drop_prob_lm, self._next_seed(), 0,
+                                               fc_feats.device)
+        params = [p for _, p in self.named_parameters()]
+        return _RolloutFn.apply(self, cfg, fc_feats.float().contiguous(), *params)
+
+    def _forward(self, fc_feats, att_feats, seq, att_masks=None):
+        B = fc_feats.size(0)
+        if seq.ndim == 3:
+            seq = seq.reshape(-1, seq.shape[2])
+        seq = seq.long().contiguous()
+        N, T = seq.shape
+        zero_cols = (seq[:, 1:].sum(0) == 0).nonzero()
+        T_eff = int(zero_cols[0]) + 1 if zero_cols.numel() else T
+        _, logp = self._run(dict(n=N // B, T=T_eff, L=T, mode='forced', forced=seq, teacher=True), fc_feats)
+        return logp
+
+    def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
+        method = opt.get('sample_method', 'greedy')
+        if opt.get('beam_size', 1) > 1:
+            raise NotImplementedError('beam search for newfc is not accelerated')
+        if method not in ('greedy', 'sample'):
+            raise NotImplementedError('sample_method %r' % method)
+        cfg = dict(n=int(opt.get('sample_n', 1)), T=self.seq_length, L=self.seq_length, mode=method,
+                   temperature=opt.get('temperature', 1.0), seed=self._next_seed())
+        return self._run(cfg, fc_feats)

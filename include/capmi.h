@@ -344,6 +344,66 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
                              const float *g_seq_logp, capmi_updown_bwd_scratch *s,
                              capmi_updown_grads *g, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * NewFC decoder (BASELINE configs[0], configs/fc.yml): NewFCModel (AttModel.py:904-945) over the maxout
+ * LSTMCore (FCModel.py:13-42).  The image embedding is fed as a first LSTM step when the state is all
+ * zero (AttModel.py:925-927), then one word per step; log-softmax / choice / bookkeeping are shared
+ * with the UpDown path (capmi_logsoftmax_select).
+ * ------------------------------------------------------------------------------------------- */
+/* maxout cell: sums = sum_s partial[s] + b_i2h + b_h2h ([N,5R]: in, forget, out, cand_a, cand_b);
+ * c' = sig(f)*c + sig(in)*max(cand_a,cand_b); h' = sig(out)*tanh(c').  saved [N,5R] = (sig(in), sig(f),
+ * sig(out), cand_a, cand_b). */
+int capmi_maxout_cell_fwd(const float *partial, int splits, const float *b_i2h, const float *b_h2h,
+                          const float *c_prev, float *h, float *c, float *saved, const float *out_mask,
+                          float *h_drop, int N, int R, void *stream);
+/* dh = dh_a (* dh_a_mask) + dh_b; d_sums [N,5R]; dc_prev [N,R] */
+int capmi_maxout_cell_bwd(const float *dh_a, const float *dh_a_mask, const float *dh_b, const float *dc_next,
+                          const float *saved, const float *c_prev, const float *c_new, float *d_sums,
+                          float *dc_prev, int N, int R, void *stream);
+
+typedef struct capmi_newfc_weights {
+    const float *embed;            /* [V1,E]  embed.weight (plain Embedding, AttModel.py:908) */
+    const float *i2h_w, *i2h_b;    /* [5R,E],[5R]  _core.i2h */
+    const float *h2h_w, *h2h_b;    /* [5R,R],[5R]  _core.h2h */
+    const float *logit_w, *logit_b;
+} capmi_newfc_weights;
+
+typedef struct capmi_newfc_rollout {
+    int B, n, N, R, E, V1, T, L;
+    const float *fc_emb;    /* [B,E]  fc_embed(fc_feats) (no ReLU / dropout: AttModel.py:907) */
+    const float *drop_out;  /* [T,N,R] keep masks for the LSTMCore output dropout, or NULL */
+    int mode; float temperature; const float *gumbel; uint64_t seed;
+    const int64_t *forced; int forced_ld; int teacher;
+    float *h, *c;           /* [T+2,N,R]  slot 0 zeros, slot 1 after the image step, slot t+2 after word t */
+    float *x;               /* [T,N,E]   word embeddings */
+    int64_t *it_all;        /* [T,N] */
+    float *saved;           /* [T+1,N,5R] cell activations, slot 0 = image step */
+    float *h_drop;          /* [T,N,R] */
+    int64_t *seq; float *seq_logp; float *sel_logp; uint8_t *live;   /* [N,L], [N,L,V1], [N,L], [N,L] */
+    float *logits; int64_t *it; uint8_t *unfinished;
+    float *partial; int64_t partial_capacity;
+} capmi_newfc_rollout;
+
+typedef struct capmi_newfc_grads {
+    float *embed, *i2h_w, *i2h_b, *h2h_w, *h2h_b, *logit_w, *logit_b;
+    float *d_fc_emb;   /* [B,E] */
+} capmi_newfc_grads;
+
+typedef struct capmi_newfc_bwd_scratch {
+    float *dlogits;   /* [T,N,V1] */
+    float *d_hdrop;   /* [T,N,R]  */
+    float *d_sums;    /* [T+1,N,5R] slot 0 = image step */
+    float *dh_prev;   /* [2][N,R] ping-pong */
+    float *dc;        /* [2][N,R] */
+    float *d_x_all;   /* [T,N,E]  */
+    float *d_ximg;    /* [N,E]    */
+    float *partial; int64_t partial_capacity;
+} capmi_newfc_bwd_scratch;
+
+int capmi_newfc_rollout_fwd(const capmi_newfc_weights *w, capmi_newfc_rollout *r, void *stream);
+int capmi_newfc_rollout_bwd(const capmi_newfc_weights *w, const capmi_newfc_rollout *r, const float *g_seq_logp,
+                            capmi_newfc_bwd_scratch *s, capmi_newfc_grads *g, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

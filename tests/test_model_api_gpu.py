@@ -184,3 +184,29 @@ def test_fused_scst_rollouts_equal_separate_rollouts():
     for k, p in model.named_parameters():
         ref = p.grad
         assert float((grads_f[k] - ref).abs().max()) <= 1e-5 + 1e-4 * float(ref.abs().max()), k
+
+
+def test_newfc_golden_xe_grads_and_greedy():
+    """BASELINE configs[0] (newfc, configs/fc.yml) against the real reference's fixture."""
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import LanguageModelCriterion
+    z = np.load(os.path.join(GOLDEN, 'newfc_tiny.npz'))
+    model = models.setup(tiny_opt(caption_model='newfc'))
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('P.')})
+    model = model.to(DEV)
+    model.train()
+    fc = torch.from_numpy(z['fc']).to(DEV)
+    labels, masks = torch.from_numpy(z['labels']).to(DEV), torch.from_numpy(z['masks']).to(DEV)
+    logp = model(fc, None, labels[..., :-1], None)
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), z['xe_logp'], rtol=2e-5, atol=5e-6)
+    loss = LanguageModelCriterion()(logp, labels[..., 1:], masks[..., 1:])
+    np.testing.assert_allclose(loss.item(), z['xe_loss'], rtol=1e-5)
+    loss.backward()
+    for k, p in model.named_parameters():
+        ref = z['xe_grad.' + k]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=5e-4, atol=1e-6 + 2e-5 * np.abs(ref).max(), err_msg=k)
+    model.eval()
+    with torch.no_grad():
+        seq, slp = model(fc, None, None, opt={'sample_method': 'greedy'}, mode='sample')
+    assert np.array_equal(seq.cpu().numpy(), z['greedy_seq'])
+    np.testing.assert_allclose(slp.cpu().numpy(), z['greedy_logp'], rtol=2e-5, atol=5e-6)

@@ -97,3 +97,11 @@ def test_newfc_teacher_forced_and_greedy():
     loss.backward()
     for k, p in P.items():
         np.testing.assert_allclose(p.grad.numpy(), z['xe_grad.' + k], rtol=2e-4, atol=2e-7, err_msg=k)
+
+
+def test_newfc_greedy_token_exact():
+    z, P = load('newfc_tiny.npz')
+    with torch.no_grad():
+        seq, slp = O.newfc_rollout_greedy(P, torch.from_numpy(z['fc']), max_len=8)
+    assert np.array_equal(seq.numpy(), z['greedy_seq'])
+    np.testing.assert_allclose(slp.numpy(), z['greedy_logp'], **TOL)
