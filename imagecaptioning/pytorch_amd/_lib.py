@@ -62,6 +62,14 @@ class UpDownBwdScratch(C.Structure):
                 [('partial_capacity', C.c_int64)])
 
 
+class UpDownBeam(C.Structure):
+    _fields_ = ([(k, C.c_int) for k in ('B', 'bd', 'K', 'A', 'R', 'E', 'V1', 'L')] +
+                [(k, c_f) for k in ('fc', 'att', 'p_att', 'att_mask')] + [('temperature', C.c_float), ('unk_col', C.c_int)] +
+                [(k, c_f) for k in ('state', 'xt', 'gates', 'att_h', 'alpha', 'ctx', 'fc_gates', 'logits', 'it', 'sums',
+                                    'logp_rows', 'parent', 'token', 'score', 'ended', 'partial')] +
+                [('partial_capacity', C.c_int64)])
+
+
 class NewFCWeights(C.Structure):
     _fields_ = [(k, c_f) for k in ('embed', 'i2h_w', 'i2h_b', 'h2h_w', 'h2h_b', 'logit_w', 'logit_b')]
 
@@ -111,6 +119,10 @@ SIGNATURES = {
     'capmi_prof_enable': [_I],
     'capmi_prof_reset': [],
     'capmi_prof_read': [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    'capmi_beam_select': [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    'capmi_beam_reorder': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'capmi_beam_logsoftmax': [_P, _P, _I, _I, _F, _I, _P],
+    'capmi_updown_beam_search': [C.POINTER(UpDownWeights), C.POINTER(UpDownBeam), _P],
     'capmi_maxout_cell_fwd': [_P, _I] + [_P] * 8 + [_I, _I, _P],
     'capmi_maxout_cell_bwd': [_P] * 9 + [_I, _I, _P],
     'capmi_newfc_rollout_fwd': [C.POINTER(NewFCWeights), C.POINTER(NewFCRollout), _P],

@@ -345,6 +345,51 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
                              capmi_updown_grads *g, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Batched beam search for the UpDown decoder, entirely on the device (AttModel._sample_beam
+ * AttModel.py:218-256 + CaptionModel.beam_search CaptionModel.py:35-209, group_size 1).
+ * Replaces, per step: the full torch.sort over [B, b*V1] (:80) by a segmented top-b selection, the O(t)
+ * re-gather of beam histories (:90-103) by parent pointers, the state gather (:105-109) by one reorder
+ * kernel, and the 2*B*b `.item()` host syncs of the finished-beam loop (:183-198) by device flags.
+ * ------------------------------------------------------------------------------------------- */
+/* one selection step.  logp [B*cur, V1] (rows of image b: b*cur .. b*cur+cur-1), sums [B,cur] ->
+ * top `bd` candidates per image sorted by descending score (ties: lowest flat index):
+ * parent [B,bd] (beam the candidate extends), token [B,bd], score [B,bd] (= joint log-prob, recorded for
+ * the finished-beam table), next_sums [B,bd] (= score, minus 1000 where the beam ended: token == 0 or
+ * force_end), ended [B,bd]. */
+int capmi_beam_select(const float *logp, const float *sums, int B, int cur, int bd, int V1, int force_end,
+                      int32_t *parent, int64_t *token, float *score, float *next_sums, uint8_t *ended,
+                      void *stream);
+/* dst[a][b*bd + j][:] = src[a][b*cur + parent[b,j]][:] for `arrays` stacked [rows,R] arrays */
+int capmi_beam_reorder(const float *src, float *dst, const int32_t *parent, int arrays, int B, int cur, int bd,
+                       int R, void *stream);
+/* out = log_softmax(log_softmax(logits) / temperature)  (CaptionModel.py:203-204 applies it to the already
+ * normalised output); optionally out[:, unk_col] -= 1000 (suppress_UNK, :159-160; unk_col < 0: off). */
+int capmi_beam_logsoftmax(const float *logits, float *out, int N, int V1, float temperature, int unk_col,
+                          void *stream);
+
+typedef struct capmi_updown_beam {
+    int B, bd, K, A, R, E, V1, L;
+    const float *fc, *att, *p_att, *att_mask;   /* prepared features of the B images */
+    float temperature;
+    int unk_col;            /* column to suppress by -1000, or -1 */
+    /* work: state ping-pong [2][4][B*bd,R] (h_att,c_att,h_lang,c_lang), per-step scratch */
+    float *state;
+    float *xt, *gates, *att_h, *alpha, *ctx, *fc_gates, *logits;   /* [B*bd,*] scratch, fc_gates [B,4R] */
+    int64_t *it;            /* [B*bd] */
+    float *sums;            /* [2][B,bd] ping-pong */
+    /* outputs, per step t */
+    float *logp_rows;       /* [L][B*bd][V1]  normalised rows the selection of step t was made from
+                               (step 0 uses only rows b*bd + 0) */
+    int32_t *parent;        /* [L][B,bd] */
+    int64_t *token;         /* [L][B,bd] */
+    float *score;           /* [L][B,bd] */
+    uint8_t *ended;         /* [L][B,bd] */
+    float *partial; int64_t partial_capacity;
+} capmi_updown_beam;
+
+int capmi_updown_beam_search(const capmi_updown_weights *w, capmi_updown_beam *b, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * NewFC decoder (BASELINE configs[0], configs/fc.yml): NewFCModel (AttModel.py:904-945) over the maxout
  * LSTMCore (FCModel.py:13-42).  The image embedding is fed as a first LSTM step when the state is all
  * zero (AttModel.py:925-927), then one word per step; log-softmax / choice / bookkeeping are shared

@@ -153,5 +153,38 @@ def main():
     print('newfc_tiny.npz:', len(out), 'arrays')
 
 
+def main_beam():
+    """Beam-search fixture (reference AttModel._sample_beam / CaptionModel.beam_search) on the SAME weights
+    and inputs as updown_tiny.npz: beam sizes 3 and 2, with and without att_masks, plus sample_n == beam_size."""
+    sys.path.insert(0, REF)
+    import captioning.models as models
+    z = np.load(os.path.join(HERE, 'updown_tiny.npz'))
+    opt = tiny_opt('updown', drop=0.0)
+    model = models.setup(opt)
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('P.')})
+    model.eval()
+    fc, att, am = (torch.from_numpy(z[k]) for k in ('fc', 'att', 'att_masks'))
+    out = {}
+    with torch.no_grad():
+        for tag, bs, masks, kw in (('b3', 3, None, {}), ('b2m', 2, am, {}), ('b3n', 3, None, {'sample_n': 3}),
+                                   ('b3lp', 3, am, {'length_penalty': 'avg_0'})):
+            o = {'sample_method': 'beam_search', 'beam_size': bs, 'sample_n': 1}
+            o.update(kw)
+            seq, slp = model(fc, att, masks, opt=o, mode='sample')
+            out[tag + '_seq'] = seq.numpy()
+            out[tag + '_logp'] = slp.numpy()
+            for k, beams in enumerate(model.done_beams):
+                out['%s_n%d' % (tag, k)] = np.array(len(beams))
+                for j, bm in enumerate(beams):
+                    out['%s_%d_%d_seq' % (tag, k, j)] = bm['seq'].numpy()
+                    out['%s_%d_%d_p' % (tag, k, j)] = np.array(bm['p'])
+                    out['%s_%d_%d_unaug' % (tag, k, j)] = np.array(bm['unaug_p'])
+    np.savez_compressed(os.path.join(HERE, 'updown_tiny_beam.npz'), **out)
+    print('updown_tiny_beam.npz:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'beam':
+        main_beam()
+    else:
+        main()

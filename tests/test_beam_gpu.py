@@ -1,0 +1,59 @@
+"""Device beam search vs the fixture produced by the real reference (tests/golden/updown_tiny_beam.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from test_model_api_gpu import golden_model, DEV
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('tag,bs,masked,kw', [('b3', 3, False, {}), ('b2m', 2, True, {}), ('b3n', 3, False, {'sample_n': 3}),
+                                              ('b3lp', 3, True, {'length_penalty': 'avg_0'})])
+def test_beam_search_matches_reference(tag, bs, masked, kw):
+    z, model = golden_model(False)
+    g = np.load(os.path.join(GOLDEN, 'updown_tiny_beam.npz'))
+    model.eval()
+    fc, att = torch.from_numpy(z['fc']).to(DEV), torch.from_numpy(z['att']).to(DEV)
+    am = torch.from_numpy(z['att_masks']).to(DEV) if masked else None
+    o = {'sample_method': 'beam_search', 'beam_size': bs, 'sample_n': 1}
+    o.update(kw)
+    with torch.no_grad():
+        seq, slp = model(fc, att, am, opt=o, mode='sample')
+    assert np.array_equal(seq.cpu().numpy(), g[tag + '_seq'])
+    np.testing.assert_allclose(slp.cpu().numpy(), g[tag + '_logp'], rtol=2e-5, atol=1e-5)
+    for k, beams in enumerate(model.done_beams):
+        assert len(beams) == int(g['%s_n%d' % (tag, k)])
+        for j, bm in enumerate(beams):
+            assert np.array_equal(bm['seq'].cpu().numpy(), g['%s_%d_%d_seq' % (tag, k, j)]), (k, j)
+            np.testing.assert_allclose(bm['p'], g['%s_%d_%d_p' % (tag, k, j)], rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(bm['unaug_p'], g['%s_%d_%d_unaug' % (tag, k, j)], rtol=1e-4)
+            assert bm['logps'].shape == (bm['seq'].shape[0], slp.shape[2])
+
+
+def test_beam_select_properties():
+    """The invariants the reference asserts every step (CaptionModel.py:89,97,100): scores are the sorted top-b of
+    sum + logp, parents/tokens decode the flat index, ended beams are pushed down by 1000."""
+    from imagecaptioning.pytorch_amd import _lib
+    from imagecaptioning.pytorch_amd._lib import lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(0)
+    B, cur, bd, V1 = 4, 5, 5, 9488
+    logp = torch.log_softmax(torch.randn(B * cur, V1, generator=g) * 2, 1).to(DEV)
+    sums = (torch.randn(B, bd, generator=g) * 3).to(DEV)
+    parent = torch.empty(B, bd, dtype=torch.int32, device=DEV)
+    token = torch.empty(B, bd, dtype=torch.long, device=DEV)
+    score = torch.empty(B, bd, device=DEV)
+    nxt = torch.empty(B, bd, device=DEV)
+    ended = torch.empty(B, bd, dtype=torch.uint8, device=DEV)
+    logp[3, 0] = 5.0        # force an EOS candidate to win for image 0 (row 3 = image 0, beam 3)
+    _lib.check(lib.capmi_beam_select(ptr(logp), ptr(sums), B, cur, bd, V1, 0, ptr(parent), ptr(token), ptr(score), ptr(nxt),
+                                     ptr(ended), stream_ptr()), 'select')
+    cand = (sums[:, :cur].unsqueeze(-1) + logp.view(B, cur, V1)).reshape(B, -1)
+    ys, ix = torch.sort(cand, -1, True)
+    assert torch.equal(score, ys[:, :bd])
+    assert torch.equal(parent.long(), ix[:, :bd] // V1) and torch.equal(token, ix[:, :bd] % V1)
+    assert int(token[0, 0]) == 0 and int(ended[0, 0]) == 1
+    assert torch.allclose(nxt, score - 1000.0 * ended.float())
