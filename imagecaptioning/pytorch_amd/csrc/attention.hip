@@ -17,6 +17,7 @@
 //   phase 3  each lane owns 2 feature columns and streams the K rows of att[b] with 8-byte loads
 #include "capmi_common.h"
 #include "profile.h"
+#include <hip/hip_ext.h>
 #include "../../../include/capmi.h"
 
 using namespace capmi;
@@ -430,10 +431,15 @@ int capmi_attention_fwd(const float *att_h, const float *p_att, const float *att
     if (lds > 64 * 1024) return CAPMI_EINVAL;
     // unique (algorithmic) bytes: image tiles once + per-row att_h in, ctx and alpha out
     const double abytes = 4.0 * ((double)B * K * (A + R) + (double)N * (A + R + K));
-    capmi_prof::Scope prof(CAPMI_PROF_ATTENTION_FWD, (hipStream_t)stream, abytes, (double)N * K * (2.0 * A + 2.0 * R));
     const int rpb = row_img ? 1 : pick_rpb(B, n), chunks = row_img ? 1 : (n + rpb - 1) / rpb;
-    hipLaunchKernelGGL(attention_fwd_kernel, dim3(row_img ? N : grid_blocks(B, chunks)), dim3(ATT_THREADS), lds,
-                       (hipStream_t)stream, att_h, p_att, att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K, A, R, row_img);
+    hipEvent_t e0, e1;
+    if (capmi_prof::take_events(CAPMI_PROF_ATTENTION_FWD, &e0, &e1, abytes, (double)N * K * (2.0 * A + 2.0 * R)))
+        hipExtLaunchKernelGGL(attention_fwd_kernel, dim3(row_img ? N : grid_blocks(B, chunks)), dim3(ATT_THREADS), lds,
+                              (hipStream_t)stream, e0, e1, 0, att_h, p_att, att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K,
+                              A, R, row_img);
+    else
+        hipLaunchKernelGGL(attention_fwd_kernel, dim3(row_img ? N : grid_blocks(B, chunks)), dim3(ATT_THREADS), lds,
+                           (hipStream_t)stream, att_h, p_att, att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K, A, R, row_img);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -448,8 +454,8 @@ int capmi_attention_bwd(const float *d_ctx, int ld_dctx, const float *att_h, con
     const size_t lds = ((size_t)NMAX * ((R + 3) & ~3) + (size_t)NMAX * K) * sizeof(float);
     if (lds > 64 * 1024) return CAPMI_EINVAL;
     const double abytes = 4.0 * ((double)B * K * (A + R) + (double)N * (2.0 * A + R + 2.0 * K));
-    capmi_prof::Scope prof(CAPMI_PROF_ATTENTION_BWD, (hipStream_t)stream, abytes, (double)N * K * (4.0 * A + 2.0 * R));
     const int rpb = row_img ? 1 : pick_rpb(B, n), chunks = row_img ? 1 : (n + rpb - 1) / rpb;
+    (void)abytes;
     hipLaunchKernelGGL(attention_bwd_kernel, dim3(row_img ? N : grid_blocks(B, chunks)), dim3(ATT_THREADS), lds,
                        (hipStream_t)stream, d_ctx, ld_dctx, att_h, alpha, p_att, att, w, d_att_h, d_e, B, n, rpb, chunks, K,
                        A, R, row_img);

@@ -157,7 +157,6 @@ extern "C" int capmi_ciderd_score(const int64_t *hyp, int H, int L, const int32_
     if (!hyp || !hyp_img || !refs || !n_refs || !table_keys || !table_vals || !scores) return CAPMI_EINVAL;
     if (H <= 0 || L <= 0 || L > LMAX || ref_w <= 0 || ref_w > LMAX || max_refs <= 0) return CAPMI_EINVAL;
     if (table_cap == 0 || (table_cap & (table_cap - 1))) return CAPMI_EINVAL;
-    capmi_prof::Scope prof(CAPMI_PROF_CIDERD, (hipStream_t)stream, 0, 0);
     hipLaunchKernelGGL(ciderd_kernel, dim3(H), dim3(CT), 0, (hipStream_t)stream, hyp, L, hyp_img, refs, n_refs, max_refs,
                        ref_w, table_keys, table_vals, table_cap, log_ref_len, scores);
     CAPMI_CHECK_LAUNCH();

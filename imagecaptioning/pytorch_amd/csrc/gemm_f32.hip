@@ -24,6 +24,7 @@
 #include "../../../include/capmi.h"
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <hip/hip_ext.h>
 
 using namespace capmi_gemm;
 
@@ -304,12 +305,24 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ partial, int spli
     }
 }
 
+struct ProfInfo {
+    int cls;
+    double bytes, flops;
+};
+template <typename K>
+void launch_one(K kernel, dim3 grid, hipStream_t st, const KArgs &a, const ProfInfo &pi) {
+    hipEvent_t e0, e1;
+    if (capmi_prof::take_events(pi.cls, &e0, &e1, pi.bytes, pi.flops))
+        hipExtLaunchKernelGGL(kernel, grid, dim3(NT), 0, st, e0, e1, 0, a);
+    else
+        hipLaunchKernelGGL(kernel, grid, dim3(NT), 0, st, a);
+}
 template <int BM, int BN, int WM, int WN, int PF>
-int launch_cfg(const KArgs &a, int al, int bl, dim3 grid, hipStream_t st) {
-    if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, true, PF>), grid, dim3(NT), 0, st, a);
-    else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true, false, PF>), grid, dim3(NT), 0, st, a);
-    else if (al == 1 && bl == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, false, PF>), grid, dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false, true, PF>), grid, dim3(NT), 0, st, a);
+int launch_cfg(const KArgs &a, int al, int bl, dim3 grid, hipStream_t st, const ProfInfo &pi) {
+    if (al == 0 && bl == 0) launch_one(gemm_kernel<BM, BN, WM, WN, true, true, PF>, grid, st, a, pi);
+    else if (al == 0 && bl == 1) launch_one(gemm_kernel<BM, BN, WM, WN, true, false, PF>, grid, st, a, pi);
+    else if (al == 1 && bl == 1) launch_one(gemm_kernel<BM, BN, WM, WN, false, false, PF>, grid, st, a, pi);
+    else launch_one(gemm_kernel<BM, BN, WM, WN, false, true, PF>, grid, st, a, pi);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -430,14 +443,14 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > slab_cap)) return CAPMI_EINVAL;
     d->splits_used = splits;
     dim3 grid(gn, gm, splits);
-    capmi_prof::Scope prof(pcls, st, bytes, flops);
+    const ProfInfo pi{pcls, bytes, flops};
     int rc;
     static const int env_pf = [] { const char *e = getenv("CAPMI_GEMM_PF"); return e ? atoi(e) : 3; }();
     (void)env_pf;
-    if (BM == 32 && BN == 128) rc = launch_cfg<32, 128, 1, 4, 3>(a, d->a_layout, d->b_layout, grid, st);
-    else if (BM == 64 && BN == 64) rc = launch_cfg<64, 64, 2, 2, 3>(a, d->a_layout, d->b_layout, grid, st);
-        else if (BM == 64 && BN == 128) rc = launch_cfg<64, 128, 1, 4, 2>(a, d->a_layout, d->b_layout, grid, st);
-    else rc = launch_cfg<128, 128, 2, 2, 2>(a, d->a_layout, d->b_layout, grid, st);
+    if (BM == 32 && BN == 128) rc = launch_cfg<32, 128, 1, 4, 3>(a, d->a_layout, d->b_layout, grid, st, pi);
+    else if (BM == 64 && BN == 64) rc = launch_cfg<64, 64, 2, 2, 3>(a, d->a_layout, d->b_layout, grid, st, pi);
+        else if (BM == 64 && BN == 128) rc = launch_cfg<64, 128, 1, 4, 2>(a, d->a_layout, d->b_layout, grid, st, pi);
+    else rc = launch_cfg<128, 128, 2, 2, 2>(a, d->a_layout, d->b_layout, grid, st, pi);
     if (rc) return rc;
     if (splits > 1 && !d->defer_reduce && !a.self_reduce)
         return capmi_splitk_reduce(a.partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,

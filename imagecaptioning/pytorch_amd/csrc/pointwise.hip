@@ -253,7 +253,6 @@ int capmi_lstm_cell_fwd(const float *partial, int splits, const float *b_ih, con
                         int row_bias_div, const int32_t *row_bias_idx, const float *c_prev, float *h, float *c, float *gates_act,
                         const float *out_mask, float *h_drop, int N, int R, void *stream) {
     if (!partial || splits < 1 || !c_prev || !h || !c || N <= 0 || R <= 0) return CAPMI_EINVAL;
-    capmi_prof::Scope prof(CAPMI_PROF_LSTM_CELL, (hipStream_t)stream, 4.0 * N * R * (4.0 * splits + 8), 0);
     hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid_for((size_t)N * R)), dim3(256), 0, (hipStream_t)stream, partial,
                        splits, b_ih, b_hh, row_bias, row_bias_div > 0 ? row_bias_div : 1, row_bias_idx, c_prev, h, c, gates_act,
                        out_mask, h_drop, N, R);
@@ -314,7 +313,6 @@ int capmi_adam_step(float *p, const float *g, float *m, float *v, int64_t count,
         return CAPMI_EINVAL;
     const double bc1 = 1.0 - pow((double)beta1, step);
     const double bc2 = 1.0 - pow((double)beta2, step);
-    capmi_prof::Scope prof(CAPMI_PROF_ADAM, (hipStream_t)stream, 28.0 * count, 0);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)count / 4 + 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
                        (size_t)count, lr, beta1, beta2, eps, weight_decay, clip, grad_scale, (float)bc1,
                        (float)sqrt(bc2));

@@ -21,6 +21,11 @@ enum CapmiProfClass {
 };
 
 namespace capmi_prof {
+// Preferred form for the roofline kernels: the launch itself carries the event pair
+// (hipExtLaunchKernelGGL(start, stop)): the timestamps come from the dispatch packet, no extra barrier
+// packets are queued, so the timed region of bench.py is not perturbed.  Returns false when the class
+// is not being profiled (then launch normally).
+bool take_events(int cls, hipEvent_t *start, hipEvent_t *stop, double bytes, double flops);
 bool enabled();
 void begin(int cls, hipStream_t st, double bytes, double flops);
 void end(int cls, hipStream_t st);

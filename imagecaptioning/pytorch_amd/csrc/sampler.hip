@@ -155,7 +155,6 @@ int capmi_logsoftmax_select(const float *logits, int N, int V1, int step, int L,
     if (!no_finish_mask && !unfinished) return CAPMI_EINVAL;
     if ((mode == 2 || row_mode) && !forced && mode == 2) return CAPMI_EINVAL;
     if (mode == 1 && !(temperature > 0.f)) return CAPMI_EINVAL;
-    capmi_prof::Scope prof(CAPMI_PROF_SELECT, (hipStream_t)stream, 4.0 * N * (double)V1 * (seq_logp ? 2 : 1), 0);
     hipLaunchKernelGGL(logsoftmax_select_kernel, dim3(N), dim3(SEL_THREADS), 0, (hipStream_t)stream, logits, V1, step, L,
                        mode, row_mode, temperature, gumbel, seed, forced, forced_ld, no_finish_mask, seq, seq_ld,
                        it_next, unfinished, seq_logp, sel_logp, live);

@@ -234,12 +234,14 @@ int capmi_scst_advantage(const double *scores, int N, int n, float *reward, void
 
 /* ---------------------------------------------------------------------------------------------
  * Launch instrumentation (counterpart of the reference's `time/batch` prints, train.py:198-208).
- * When enabled every instrumented launch is bracketed by HIP events on its own stream and its
- * algorithmic bytes/flops are accumulated; read returns the totals of one kernel class
- * (0 decode GEMM, 1 BPTT GEMM, 2 fat GEMM, 3 attention fwd, 4 attention bwd, 5 select, 6 LSTM cell,
- * 7 CIDEr-D, 8 Adam).  capmi_prof_read synchronises on the recorded events.
+ * capmi_prof_enable(class_mask): launches of the selected kernel classes carry a HIP event pair in the
+ * dispatch itself (hipExtLaunchKernelGGL start/stop events on the kernel's own stream: no extra queue
+ * packets, negligible perturbation) and their algorithmic bytes/flops are accumulated; read returns the
+ * totals of one class.  Classes with in-dispatch events: 0 decode GEMM (M <= 64, x W^T), 1 BPTT GEMM
+ * (M <= 64, dG W), 2 fat GEMM, 3 attention fwd, 4 attention bwd.  capmi_prof_read synchronises on the
+ * recorded events.
  * ------------------------------------------------------------------------------------------- */
-int capmi_prof_enable(int on);
+int capmi_prof_enable(int class_mask);
 int capmi_prof_reset(void);
 int capmi_prof_read(int cls, double *total_ms, int64_t *launches, double *bytes, double *flops);
 
