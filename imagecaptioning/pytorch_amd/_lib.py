@@ -123,6 +123,13 @@ SIGNATURES = {
     'capmi_beam_reorder': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'capmi_beam_logsoftmax': [_P, _P, _I, _I, _F, _I, _P],
     'capmi_updown_beam_search': [C.POINTER(UpDownWeights), C.POINTER(UpDownBeam), _P],
+    'capmi_layernorm_fwd': [_P] * 6 + [_I, _I, _F, _P],
+    'capmi_layernorm_bwd': [_P] * 6 + [_I, _P, _I, _I, _F, _P],
+    'capmi_mha_fwd': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'capmi_mha_bwd': [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'capmi_embed_pe_fwd': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'capmi_embed_pe_bwd': [_P, _I, _P, _P, _P, _I, _I, _I, _P],
+    'capmi_log_softmax_rows': [_P, _P, _I, _I, _P],
     'capmi_maxout_cell_fwd': [_P, _I] + [_P] * 8 + [_I, _I, _P],
     'capmi_maxout_cell_bwd': [_P] * 9 + [_I, _I, _P],
     'capmi_newfc_rollout_fwd': [C.POINTER(NewFCWeights), C.POINTER(NewFCRollout), _P],

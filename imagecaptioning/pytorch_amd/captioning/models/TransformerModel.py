@@ -1,0 +1,217 @@
+"""TransformerModel (reference captioning/models/TransformerModel.py:237-362) on the HIP backend -- BASELINE
+configs[3].  The module tree below only holds parameters under the reference's names;
+the arithmetic is transformer_engine.py + csrc/transformer.hip + the MFMA GEMM."""
+import copy
+import math
+
+import torch
+import torch.nn as nn
+
+from .CaptionModel import CaptionModel
+from ... import transformer_engine as engine
+from ..._lib import CapmiError
+
+
+def _clones(m, n):
+    return nn.ModuleList([copy.deepcopy(m) for _ in range(n)])
+
+
+class _LayerNorm(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.a_2 = nn.Parameter(torch.ones(d))
+        self.b_2 = nn.Parameter(torch.zeros(d))
+
+
+class _Sublayer(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.norm = _LayerNorm(d)
+
+
+class _MHA(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.linears = _clones(nn.Linear(d, d), 4)
+
+
+class _FF(nn.Module):
+    def __init__(self, d, dff):
+        super().__init__()
+        self.w_1 = nn.Linear(d, dff)
+        self.w_2 = nn.Linear(dff, d)
+
+
+class _EncLayer(nn.Module):
+    def __init__(self, d, dff):
+        super().__init__()
+        self.self_attn = _MHA(d)
+        self.feed_forward = _FF(d, dff)
+        self.sublayer = _clones(_Sublayer(d), 2)
+
+
+class _DecLayer(nn.Module):
+    def __init__(self, d, dff):
+        super().__init__()
+        self.self_attn = _MHA(d)
+        self.src_attn = _MHA(d)
+        self.feed_forward = _FF(d, dff)
+        self.sublayer = _clones(_Sublayer(d), 3)
+
+
+class _Stack(nn.Module):
+    def __init__(self, layer, n, d):
+        super().__init__()
+        self.layers = _clones(layer, n)
+        self.norm = _LayerNorm(d)
+
+
+class _Emb(nn.Module):
+    def __init__(self, d, vocab):
+        super().__init__()
+        self.lut = nn.Embedding(vocab, d)
+
+
+class _PE(nn.Module):
+    def __init__(self, d, max_len=5000):
+        super().__init__()
+        pe = torch.zeros(max_len, d)
+        position = torch.arange(0, max_len).unsqueeze(1).float()
+        div_term = torch.exp(torch.arange(0, d, 2).float() * -(math.log(10000.0) / d))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer('pe', pe.unsqueeze(0))
+
+
+class _Gen(nn.Module):
+    def __init__(self, d, vocab):
+        super().__init__()
+        self.proj = nn.Linear(d, vocab)
+
+
+class _EncDec(nn.Module):
+    def __init__(self, d, dff, n_enc, n_dec, vocab):
+        super().__init__()
+        self.encoder = _Stack(_EncLayer(d, dff), n_enc, d)
+        self.decoder = _Stack(_DecLayer(d, dff), n_dec, d)
+        self.tgt_embed = nn.Sequential(_Emb(d, vocab), _PE(d))
+        self.generator = _Gen(d, vocab)
+
+
+class _Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, att_feats, att_masks, seq, n, *params):
+        P = model._pdict(params)
+        grads = model._grad_targets(P)
+        g = engine.TransformerGraph(P, grads, model.h, model.N_enc, model.N_dec, model.drop_prob_lm, model.dropout,
+                                    model.training, model._next_seed())
+        g.encode(att_feats, att_masks)
+        logp = g.decode(seq, n)
+        ctx.g, ctx.model, ctx.grads = g, model, grads
+        return logp
+
+    @staticmethod
+    def backward(ctx, g_logp):
+        ctx.g.backward(g_logp)
+        return (None, None, None, None, None) + tuple(ctx.grads[k] for k in ctx.model._param_names)
+
+
+class TransformerModel(CaptionModel):
+    def __init__(self, opt):
+        super().__init__()
+        self.vocab_size = opt.vocab_size
+        self.seq_length = getattr(opt, 'max_length', 20) or opt.seq_length
+        self.att_feat_size = opt.att_feat_size
+        self.drop_prob_lm = opt.drop_prob_lm
+        self.N_enc = getattr(opt, 'N_enc', opt.num_layers)
+        self.N_dec = getattr(opt, 'N_dec', opt.num_layers)
+        self.d_model = getattr(opt, 'd_model', opt.input_encoding_size)
+        self.d_ff = getattr(opt, 'd_ff', opt.rnn_size)
+        self.h = getattr(opt, 'num_att_heads', 8)
+        self.dropout = getattr(opt, 'dropout', 0.1)
+        self.vocab = opt.vocab
+        self.ss_prob = 0.0
+        if getattr(opt, 'use_bn', 0):
+            raise NotImplementedError('use_bn is outside the BASELINE configs')
+        self.att_embed = nn.Sequential(nn.Linear(self.att_feat_size, self.d_model), nn.ReLU(), nn.Dropout(self.drop_prob_lm))
+        self.model = _EncDec(self.d_model, self.d_ff, self.N_enc, self.N_dec, self.vocab_size + 1)
+        for p in self.model.parameters():              # TransformerModel.py:256-258
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self._flat = None
+        self._rng_calls = 0
+
+    # ---- plumbing
+    @property
+    def _param_names(self):
+        return [n for n, _ in self.named_parameters()]
+
+    def _pdict(self, params):
+        P = dict(zip(self._param_names, [p.detach() for p in params]))
+        P['model.tgt_embed.1.pe'] = self.model.tgt_embed[1].pe[0].contiguous()      # [max_len, D]
+        return P
+
+    def _grad_targets(self, P):
+        if self._flat is not None:
+            return self._flat.grad_views
+        return {k: torch.empty_like(v) for k, v in P.items() if k != 'model.tgt_embed.1.pe'}
+
+    def flatten_parameters_(self):
+        from ...flat import FlatParams
+        self._flat = FlatParams(self)
+        return self._flat
+
+    def _next_seed(self):
+        self._rng_calls += 1
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._rng_calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    def logit(self, x):
+        return torch.nn.functional.linear(x, self.model.generator.proj.weight, self.model.generator.proj.bias)
+
+    def init_hidden(self, bsz):
+        return []
+
+    def _clip(self, att_feats, att_masks):
+        if att_masks is not None:
+            ml = int(att_masks.long().sum(1).max())
+            att_feats, att_masks = att_feats[:, :ml].contiguous(), att_masks[:, :ml].contiguous().float()
+        return att_feats.float().contiguous(), att_masks
+
+    # ---- reference API
+    def _forward(self, fc_feats, att_feats, seq, att_masks=None):
+        """TransformerModel._forward (:340-348): log-probs [N,T,V1]."""
+        if not att_feats.is_cuda:
+            raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
+        if seq.ndim == 3:
+            seq = seq.reshape(-1, seq.shape[2])
+        seq = seq.long().contiguous()
+        att_feats, att_masks = self._clip(att_feats, att_masks)
+        n = seq.shape[0] // att_feats.shape[0]
+        params = [p for _, p in self.named_parameters()]
+        return _Fn.apply(self, att_feats, att_masks, seq, n, *params)
+
+    def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
+        """AttModel._sample for the Transformer.  Tokens are drawn with the KV-cached decoder under no_grad; when a
+        gradient is needed (SCST) the log-probs of the drawn tokens are recomputed by ONE teacher-forced pass, which
+        equals the reference's step-by-step graph whenever dropout is off."""
+        if not att_feats.is_cuda:
+            raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
+        method = opt.get('sample_method', 'greedy')
+        if opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search'):
+            raise NotImplementedError('beam search for the transformer is not accelerated yet')
+        if method not in ('greedy', 'sample'):
+            raise NotImplementedError('sample_method %r' % method)
+        n = int(opt.get('sample_n', 1))
+        att_feats, att_masks = self._clip(att_feats, att_masks)
+        with torch.no_grad():
+            P = self._pdict([p for _, p in self.named_parameters()])
+            seq, logp = engine.sample(P, att_feats, att_masks, self.h, self.N_enc, self.N_dec, self.seq_length, sample_n=n,
+                                      mode=method, temperature=opt.get('temperature', 1.0), seed=self._next_seed(),
+                                      gumbel=opt.get('_gumbel'))
+        if not (torch.is_grad_enabled() and self.training):
+            return seq, logp
+        # differentiable log-probs of the drawn tokens: inputs [bos, w_0 .. w_{L-2}]
+        inp = torch.cat([seq.new_zeros(seq.shape[0], 1), seq[:, :-1]], 1)
+        logp_g = self._forward(None, att_feats, inp, att_masks)
+        live = torch.cat([seq.new_ones(seq.shape[0], 1), (seq[:, :-1] > 0).long()], 1).cumprod(1)     # unfinished-before-step
+        return seq, logp_g * live.unsqueeze(-1).to(logp_g)

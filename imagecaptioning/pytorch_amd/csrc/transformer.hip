@@ -1,0 +1,348 @@
+// Non-GEMM kernels of the Transformer captioner on gfx950 (TransformerModel.py): the reference's own
+// LayerNorm formula, short-sequence multi-head attention (Tq <= 32 queries x Tk <= 128 keys per head fit one
+// workgroup's LDS; K = 36 regions / T <= 21 tokens in the BASELINE configs), token embedding + sinusoidal
+// position, row log-softmax.  Cross-attention reads the per-image memory K/V once per image and serves the n
+// caption rows of that image from LDS (no repeat_tensors, TransformerModel.py:330-334).
+#include "capmi_common.h"
+#include "../../../include/capmi.h"
+
+using namespace capmi;
+
+namespace {
+
+// ---------------------------------------------------------------- LayerNorm (one wave per row)
+__global__ void layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ a, const float *__restrict__ b,
+                                     float *__restrict__ y, float *__restrict__ mean, float *__restrict__ inv, int M, int D,
+                                     float eps) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int r = blockIdx.x * nw + wid; r < M; r += gridDim.x * nw) {
+        const float *xr = x + (size_t)r * D;
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += xr[c];
+        const float mu = wave_sum(s) / D;
+        float v = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float d = xr[c] - mu;
+            v += d * d;
+        }
+        const float sd = sqrtf(wave_sum(v) / (D - 1));      // torch.std: unbiased
+        const float iv = 1.f / (sd + eps);                   // eps OUTSIDE the sqrt (TransformerModel.py:87)
+        for (int c = lane; c < D; c += 64) y[(size_t)r * D + c] = a[c] * (xr[c] - mu) * iv + b[c];
+        if (lane == 0) {
+            mean[r] = mu;
+            inv[r] = iv;
+        }
+    }
+}
+
+__global__ void layernorm_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ a,
+                                     const float *__restrict__ mean, const float *__restrict__ inv, float *__restrict__ dx,
+                                     int accumulate, float *__restrict__ g_scaled, int M, int D, float eps) {
+    // y = a * xc * iv + b, iv = 1/(s+eps), s = sqrt(sum xc^2/(D-1)):
+    // dx_j = iv (g_j - mean(g)) - iv^2 xc_j / ((D-1) s) * sum_i g_i xc_i,   g = dy * a
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int r = blockIdx.x * nw + wid; r < M; r += gridDim.x * nw) {
+        const float mu = mean[r], iv = inv[r];
+        const float sd = 1.f / iv - eps;
+        float sg = 0.f, sgx = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float g = dy[(size_t)r * D + c] * a[c];
+            const float xc = x[(size_t)r * D + c] - mu;
+            sg += g;
+            sgx += g * xc;
+        }
+        sg = wave_sum(sg);
+        sgx = wave_sum(sgx);
+        const float mg = sg / D;
+        const float k2 = sd > 0.f ? iv * iv / ((D - 1) * sd) * sgx : 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const size_t i = (size_t)r * D + c;
+            const float xc = x[i] - mu;
+            const float v = iv * (dy[i] * a[c] - mg) - k2 * xc;
+            dx[i] = accumulate ? dx[i] + v : v;
+            if (g_scaled) g_scaled[i] = dy[i] * xc * iv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- short-sequence MHA
+constexpr int MHA_T = 256;
+
+// workgroup = (kv row, head).  LDS: K [Tk][dk+1], V [Tk][dk+1], then per query row: Q [Tq][dk+1], S [Tq][Tk+1]
+__global__ __launch_bounds__(MHA_T) void mha_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                       const float *__restrict__ v, int ldkv,
+                                                       const uint8_t *__restrict__ mask, int mask_tq, int mask_per_q,
+                                                       int causal, int q_pos0, const float *__restrict__ drop,
+                                                       float *__restrict__ o, float *__restrict__ p, int q_per_kv, int Tq,
+                                                       int Tk, int h, int dk) {
+    extern __shared__ float lds[];
+    const int D = h * dk, P1 = dk + 1;
+    float *sK = lds, *sV = sK + Tk * P1, *sQ = sV + Tk * P1, *sS = sQ + Tq * P1;
+    const int kvr = blockIdx.x, hd = blockIdx.y;
+    const float scale = rsqrtf((float)dk);
+    for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {
+        const int j = i / dk, c = i % dk;
+        sK[j * P1 + c] = k[(size_t)kvr * ldkv + (size_t)j * D + hd * dk + c];
+        sV[j * P1 + c] = v[(size_t)kvr * ldkv + (size_t)j * D + hd * dk + c];
+    }
+    for (int rq = 0; rq < q_per_kv; ++rq) {
+        const int r = kvr * q_per_kv + rq;
+        __syncthreads();
+        for (int i = threadIdx.x; i < Tq * dk; i += blockDim.x) {
+            const int t = i / dk, c = i % dk;
+            sQ[t * P1 + c] = q[((size_t)r * Tq + t) * D + hd * dk + c];
+        }
+        __syncthreads();
+        const uint8_t *mrow = mask ? mask + (size_t)(mask_per_q ? r : kvr) * mask_tq * Tk : nullptr;
+        for (int i = threadIdx.x; i < Tq * Tk; i += blockDim.x) {
+            const int t = i / Tk, j = i % Tk;
+            float s = 0.f;
+            for (int c = 0; c < dk; ++c) s += sQ[t * P1 + c] * sK[j * P1 + c];
+            s *= scale;
+            bool ok = true;
+            if (mrow) ok = mrow[(size_t)(mask_tq > 1 ? t : 0) * Tk + j] != 0;
+            if (causal && j > q_pos0 + t) ok = false;
+            sS[t * (Tk + 1) + j] = ok ? s : -INFINITY;
+        }
+        __syncthreads();
+        // softmax per query row: one wave per row
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        for (int t = wid; t < Tq; t += nw) {
+            float *row = sS + t * (Tk + 1);
+            float m = -INFINITY;
+            for (int j = lane; j < Tk; j += 64) m = fmaxf(m, row[j]);
+            m = wave_max(m);
+            float s = 0.f;
+            for (int j = lane; j < Tk; j += 64) {
+                const float e = __expf(row[j] - m);
+                row[j] = e;
+                s += e;
+            }
+            s = wave_sum(s);
+            const float is = 1.f / s;
+            for (int j = lane; j < Tk; j += 64) {
+                float pr = row[j] * is;
+                const size_t pi = (((size_t)r * h + hd) * Tq + t) * Tk + j;
+                if (p) p[pi] = pr;
+                if (drop) pr *= drop[pi];
+                row[j] = pr;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < Tq * dk; i += blockDim.x) {
+            const int t = i / dk, c = i % dk;
+            float acc = 0.f;
+            for (int j = 0; j < Tk; ++j) acc += sS[t * (Tk + 1) + j] * sV[j * P1 + c];
+            o[((size_t)r * Tq + t) * D + hd * dk + c] = acc;
+        }
+    }
+}
+
+// backward, same decomposition; dK/dV accumulated over the q_per_kv rows in LDS and written once
+__global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict__ d_o, const float *__restrict__ q,
+                                                       const float *__restrict__ k, const float *__restrict__ v, int ldkv,
+                                                       const float *__restrict__ p, const float *__restrict__ drop,
+                                                       float *__restrict__ dq, float *__restrict__ dk_out,
+                                                       float *__restrict__ dv_out, int q_per_kv, int Tq, int Tk, int h,
+                                                       int dk) {
+    extern __shared__ float lds[];
+    const int D = h * dk, P1 = dk + 1, S1 = Tk + 1;
+    float *sK = lds, *sV = sK + Tk * P1, *sdK = sV + Tk * P1, *sdV = sdK + Tk * P1;
+    float *sQ = sdV + Tk * P1, *sdO = sQ + Tq * P1, *sP = sdO + Tq * P1, *sdS = sP + Tq * S1;
+    const int kvr = blockIdx.x, hd = blockIdx.y;
+    const float scale = rsqrtf((float)dk);
+    for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {
+        const int j = i / dk, c = i % dk;
+        sK[j * P1 + c] = k[(size_t)kvr * ldkv + (size_t)j * D + hd * dk + c];
+        sV[j * P1 + c] = v[(size_t)kvr * ldkv + (size_t)j * D + hd * dk + c];
+        sdK[j * P1 + c] = 0.f;
+        sdV[j * P1 + c] = 0.f;
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int rq = 0; rq < q_per_kv; ++rq) {
+        const int r = kvr * q_per_kv + rq;
+        __syncthreads();
+        for (int i = threadIdx.x; i < Tq * dk; i += blockDim.x) {
+            const int t = i / dk, c = i % dk;
+            sQ[t * P1 + c] = q[((size_t)r * Tq + t) * D + hd * dk + c];
+            sdO[t * P1 + c] = d_o[((size_t)r * Tq + t) * D + hd * dk + c];
+        }
+        for (int i = threadIdx.x; i < Tq * Tk; i += blockDim.x) {
+            const int t = i / Tk, j = i % Tk;
+            sP[t * S1 + j] = p[(((size_t)r * h + hd) * Tq + t) * Tk + j];
+        }
+        __syncthreads();
+        // dP_drop = dO V^T ; dP = dP_drop * drop ; dV += (P*drop)^T dO
+        for (int i = threadIdx.x; i < Tq * Tk; i += blockDim.x) {
+            const int t = i / Tk, j = i % Tk;
+            float acc = 0.f;
+            for (int c = 0; c < dk; ++c) acc += sdO[t * P1 + c] * sV[j * P1 + c];
+            const float dm = drop ? drop[(((size_t)r * h + hd) * Tq + t) * Tk + j] : 1.f;
+            sdS[t * S1 + j] = acc * dm;          // dP (w.r.t. the pre-dropout probabilities)
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {
+            const int j = i / dk, c = i % dk;
+            float acc = 0.f;
+            for (int t = 0; t < Tq; ++t) {
+                const float dm = drop ? drop[(((size_t)r * h + hd) * Tq + t) * Tk + j] : 1.f;
+                acc += sP[t * S1 + j] * dm * sdO[t * P1 + c];
+            }
+            sdV[j * P1 + c] += acc;
+        }
+        // softmax backward per row: dS = P * (dP - sum_j P dP) * scale
+        for (int t = wid; t < Tq; t += nw) {
+            float s = 0.f;
+            for (int j = lane; j < Tk; j += 64) s += sP[t * S1 + j] * sdS[t * S1 + j];
+            s = wave_sum(s);
+            for (int j = lane; j < Tk; j += 64) sdS[t * S1 + j] = sP[t * S1 + j] * (sdS[t * S1 + j] - s) * scale;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < Tq * dk; i += blockDim.x) {     // dQ = dS K
+            const int t = i / dk, c = i % dk;
+            float acc = 0.f;
+            for (int j = 0; j < Tk; ++j) acc += sdS[t * S1 + j] * sK[j * P1 + c];
+            dq[((size_t)r * Tq + t) * D + hd * dk + c] = acc;
+        }
+        for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {     // dK += dS^T Q
+            const int j = i / dk, c = i % dk;
+            float acc = 0.f;
+            for (int t = 0; t < Tq; ++t) acc += sdS[t * S1 + j] * sQ[t * P1 + c];
+            sdK[j * P1 + c] += acc;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {
+        const int j = i / dk, c = i % dk;
+        dk_out[((size_t)kvr * Tk + j) * D + hd * dk + c] = sdK[j * P1 + c];
+        dv_out[((size_t)kvr * Tk + j) * D + hd * dk + c] = sdV[j * P1 + c];
+    }
+}
+
+__global__ void embed_pe_fwd_kernel(const int64_t *__restrict__ tok, int tok_ld, const float *__restrict__ E,
+                                    const float *__restrict__ pe, const float *__restrict__ drop, float *__restrict__ x,
+                                    int N, int T, int D, int pos0, float scale) {
+    const size_t total = (size_t)N * T * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        const size_t rt = i / D;
+        const int t = (int)(rt % T), r = (int)(rt / T);
+        float v = E[(size_t)tok[(size_t)r * tok_ld + t] * D + c] * scale + pe[(size_t)(pos0 + t) * D + c];
+        if (drop) v *= drop[i];
+        x[i] = v;
+    }
+}
+
+__global__ void embed_pe_bwd_kernel(const int64_t *__restrict__ tok, int tok_ld, const float *__restrict__ dx,
+                                    const float *__restrict__ drop, float *__restrict__ dE, int N, int T, int D,
+                                    float scale) {
+    const size_t total = (size_t)N * T * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        const size_t rt = i / D;
+        const int t = (int)(rt % T), r = (int)(rt / T);
+        float g = dx[i] * scale;
+        if (drop) g *= drop[i];
+        if (g != 0.f) atomicAdd(&dE[(size_t)tok[(size_t)r * tok_ld + t] * D + c], g);
+    }
+}
+
+__global__ __launch_bounds__(1024) void log_softmax_rows_kernel(const float *__restrict__ logits, float *__restrict__ out,
+                                                                int V1) {
+    __shared__ float s_f[32];
+    const size_t r = blockIdx.x;
+    const float *x = logits + r * V1;
+    float m = -INFINITY;
+    for (int v = threadIdx.x; v < V1; v += blockDim.x) m = fmaxf(m, x[v]);
+    m = block_max(m, s_f);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V1; v += blockDim.x) s += __expf(x[v] - m);
+    s = block_sum(s, s_f);
+    const float lse = m + __logf(s);
+    for (int v = threadIdx.x; v < V1; v += blockDim.x) out[r * V1 + v] = x[v] - lse;
+}
+
+inline int grid_for(size_t work) {
+    size_t b = (work + 255) / 256;
+    if (b > 4096) b = 4096;
+    return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+extern "C" {
+
+int capmi_layernorm_fwd(const float *x, const float *a, const float *b, float *y, float *mean, float *inv, int M, int D,
+                        float eps, void *stream) {
+    if (!x || !a || !b || !y || !mean || !inv || M <= 0 || D < 2) return CAPMI_EINVAL;
+    int blocks = (M + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, a, b, y, mean, inv, M, D, eps);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_layernorm_bwd(const float *dy, const float *x, const float *a, const float *mean, const float *inv, float *dx,
+                        int accumulate, float *g_scaled, int M, int D, float eps, void *stream) {
+    if (!dy || !x || !a || !mean || !inv || !dx || M <= 0 || D < 2) return CAPMI_EINVAL;
+    int blocks = (M + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, a, mean, inv, dx,
+                       accumulate, g_scaled, M, D, eps);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, const uint8_t *mask, int mask_tq,
+                  int mask_per_q, int causal, int q_pos0, const float *drop, float *o, float *p, int Nq, int q_per_kv,
+                  int Tq, int Tk, int h, int dk, void *stream) {
+    if (!q || !k || !v || !o || Nq <= 0 || q_per_kv <= 0 || Nq % q_per_kv || Tq <= 0 || Tk <= 0 || h <= 0 || dk <= 0)
+        return CAPMI_EINVAL;
+    if (mask && mask_tq != 1 && mask_tq != Tq) return CAPMI_EINVAL;
+    const size_t lds = ((size_t)2 * Tk * (dk + 1) + (size_t)Tq * (dk + 1) + (size_t)Tq * (Tk + 1)) * sizeof(float);
+    if (lds > 64 * 1024) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(mha_fwd_kernel, dim3(Nq / q_per_kv, h), dim3(MHA_T), lds, (hipStream_t)stream, q, k, v, ldkv, mask,
+                       mask_tq, mask_per_q, causal, q_pos0, drop, o, p, q_per_kv, Tq, Tk, h, dk);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float *v, int ldkv, const float *p,
+                  const float *drop, float *dq, float *dk_out, float *dv_out, int Nq, int q_per_kv, int Tq, int Tk, int h,
+                  int dk, void *stream) {
+    if (!d_o || !q || !k || !v || !p || !dq || !dk_out || !dv_out || Nq <= 0 || q_per_kv <= 0 || Nq % q_per_kv)
+        return CAPMI_EINVAL;
+    const size_t lds = ((size_t)4 * Tk * (dk + 1) + (size_t)2 * Tq * (dk + 1) + (size_t)2 * Tq * (Tk + 1)) * sizeof(float);
+    if (lds > 64 * 1024) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(mha_bwd_kernel, dim3(Nq / q_per_kv, h), dim3(MHA_T), lds, (hipStream_t)stream, d_o, q, k, v, ldkv, p,
+                       drop, dq, dk_out, dv_out, q_per_kv, Tq, Tk, h, dk);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_embed_pe_fwd(const int64_t *tok, int tok_ld, const float *E, const float *pe, const float *drop, float *x, int N,
+                       int T, int D, int pos0, void *stream) {
+    if (!tok || !E || !pe || !x || N <= 0 || T <= 0 || D <= 0 || pos0 < 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(embed_pe_fwd_kernel, dim3(grid_for((size_t)N * T * D)), dim3(256), 0, (hipStream_t)stream, tok, tok_ld,
+                       E, pe, drop, x, N, T, D, pos0, sqrtf((float)D));
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_embed_pe_bwd(const int64_t *tok, int tok_ld, const float *dx, const float *drop, float *dE, int N, int T, int D,
+                       void *stream) {
+    if (!tok || !dx || !dE || N <= 0 || T <= 0 || D <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(embed_pe_bwd_kernel, dim3(grid_for((size_t)N * T * D)), dim3(256), 0, (hipStream_t)stream, tok, tok_ld,
+                       dx, drop, dE, N, T, D, sqrtf((float)D));
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_log_softmax_rows(const float *logits, float *out, int rows, int V1, void *stream) {
+    if (!logits || !out || rows <= 0 || V1 <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, out, V1);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -392,6 +392,42 @@ typedef struct capmi_updown_beam {
 int capmi_updown_beam_search(const capmi_updown_weights *w, capmi_updown_beam *b, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Transformer captioner building blocks (BASELINE configs[3]; TransformerModel.py).  The contractions
+ * (QKV / output projections, FFN, generator) run on capmi_gemm_f32 with fused bias / ReLU / dropout /
+ * residual epilogues; these are the non-GEMM pieces.
+ * ------------------------------------------------------------------------------------------- */
+/* custom LayerNorm of the reference (TransformerModel.py:76-87): y = a*(x-mean)/(std_unbiased+eps)+b.
+ * x,y [M,D]; saves mean[M] and inv[M] = 1/(std+eps) for the backward. */
+int capmi_layernorm_fwd(const float *x, const float *a, const float *b, float *y, float *mean, float *inv,
+                        int M, int D, float eps, void *stream);
+/* dx [M,D] (accumulate: dx += ... for the residual branch), g_scaled [M,D] = dy*(x-mean)*inv (column-sum it
+ * for d_a; column-sum dy for d_b). */
+int capmi_layernorm_bwd(const float *dy, const float *x, const float *a, const float *mean, const float *inv,
+                        float *dx, int accumulate, float *g_scaled, int M, int D, float eps, void *stream);
+/* multi-head scaled-dot-product attention for short sequences (TransformerModel.py:152-195), one workgroup
+ * per (key/value batch row, head).  q [Nq,Tq,D], k,v rows of pitch ldkv floats ([Nkv,Tk,D] or a KV cache
+ * [Nkv,Lmax,D]), D = h*dk, heads interleaved along D exactly like `.view(N,-1,h,dk)`.  Query row r attends
+ * key/value batch row r / q_per_kv (cross-attention over per-image memory: no repeat_tensors copy).
+ * mask: uint8 [Nq or Nkv-broadcast, mask_tq (1 or Tq), Tk] (0 = -inf), or NULL; causal != 0 additionally
+ * masks key j > query position (q_pos0 + i).  drop: optional pre-scaled keep mask [Nq,h,Tq,Tk] applied to the
+ * probabilities.  Outputs o [Nq,Tq,D] and p [Nq,h,Tq,Tk] (softmax probabilities BEFORE dropout, saved). */
+int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, const uint8_t *mask, int mask_tq,
+                  int mask_per_q, int causal, int q_pos0, const float *drop, float *o, float *p, int Nq, int q_per_kv,
+                  int Tq, int Tk, int h, int dk, void *stream);
+/* backward: d_o [Nq,Tq,D] -> dq [Nq,Tq,D], dk/dv [Nkv,Tk,D] (summed over the q_per_kv query rows of a kv row) */
+int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float *v, int ldkv, const float *p,
+                  const float *drop, float *dq, float *dk_out, float *dv_out, int Nq, int q_per_kv, int Tq, int Tk, int h,
+                  int dk, void *stream);
+/* x[r,t,:] = E[tok[r,t]]*sqrt(D) + pe[pos0+t,:], then * drop (TransformerModel.py:215, 231-233) */
+int capmi_embed_pe_fwd(const int64_t *tok, int tok_ld, const float *E, const float *pe, const float *drop, float *x,
+                       int N, int T, int D, int pos0, void *stream);
+/* dE[tok] += dx*drop*sqrt(D)  (caller zeroes dE) */
+int capmi_embed_pe_bwd(const int64_t *tok, int tok_ld, const float *dx, const float *drop, float *dE, int N, int T, int D,
+                       void *stream);
+/* out = log_softmax(logits) row-wise (Generator, TransformerModel.py:50-57) */
+int capmi_log_softmax_rows(const float *logits, float *out, int rows, int V1, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * NewFC decoder (BASELINE configs[0], configs/fc.yml): NewFCModel (AttModel.py:904-945) over the maxout
  * LSTMCore (FCModel.py:13-42).  The image embedding is fed as a first LSTM step when the state is all
  * zero (AttModel.py:925-927), then one word per step; log-softmax / choice / bookkeeping are shared

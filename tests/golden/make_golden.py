@@ -183,8 +183,47 @@ def main_beam():
     print('updown_tiny_beam.npz:', len(out), 'arrays')
 
 
+def main_transformer():
+    """Transformer fixture (reference TransformerModel, configs/transformer analogue at tiny size): teacher-forced
+    log-probs, XE loss + every gradient (dropout 0), greedy decode, with and without att_masks."""
+    sys.path.insert(0, REF)
+    import captioning.models as models
+    from captioning.modules import losses
+    z = np.load(os.path.join(HERE, 'updown_tiny.npz'))
+    torch.manual_seed(99)
+    opt = tiny_opt('transformer', drop=0.0)
+    opt.N_enc, opt.N_dec, opt.d_model, opt.d_ff, opt.num_att_heads, opt.dropout = 2, 2, 16, 32, 2, 0.0
+    model = models.setup(opt)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    fc, att, am = (torch.from_numpy(z[k]) for k in ('fc', 'att', 'att_masks'))
+    labels, masks = torch.from_numpy(z['labels']), torch.from_numpy(z['masks'])
+    out = {('P.' + k): v.detach().numpy() for k, v in model.state_dict().items()}
+    model.train()
+    for tag, m in (('nomask', None), ('mask', am)):
+        model.zero_grad()
+        logp = model(fc, att, labels[..., :-1], m)
+        loss = losses.LanguageModelCriterion()(logp, labels[..., 1:], masks[..., 1:])
+        loss.backward()
+        out['xe_logp_' + tag] = logp.detach().numpy()
+        out['xe_loss_' + tag] = loss.detach().numpy()
+        for k, p in model.named_parameters():
+            out['xe_grad_%s.%s' % (tag, k)] = p.grad.detach().numpy().copy()
+    model.eval()
+    with torch.no_grad():
+        for tag, m in (('nomask', None), ('mask', am)):
+            seq, slp = model(fc, att, m, opt={'sample_method': 'greedy', 'beam_size': 1}, mode='sample')
+            out['greedy_seq_' + tag] = seq.numpy()
+            out['greedy_logp_' + tag] = slp.numpy()
+    np.savez_compressed(os.path.join(HERE, 'transformer_tiny.npz'), **out)
+    print('transformer_tiny.npz:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'beam':
         main_beam()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'transformer':
+        main_transformer()
     else:
         main()

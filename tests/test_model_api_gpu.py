@@ -210,3 +210,35 @@ def test_newfc_golden_xe_grads_and_greedy():
         seq, slp = model(fc, None, None, opt={'sample_method': 'greedy'}, mode='sample')
     assert np.array_equal(seq.cpu().numpy(), z['greedy_seq'])
     np.testing.assert_allclose(slp.cpu().numpy(), z['greedy_logp'], rtol=2e-5, atol=5e-6)
+
+
+@pytest.mark.parametrize('tag', ['nomask', 'mask'])
+def test_transformer_golden_xe_grads_and_greedy(tag):
+    """BASELINE configs[3] model family against the real reference's fixture (tiny size)."""
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import LanguageModelCriterion
+    z = np.load(os.path.join(GOLDEN, 'transformer_tiny.npz'))
+    u = np.load(os.path.join(GOLDEN, 'updown_tiny.npz'))
+    opt = tiny_opt(caption_model='transformer', N_enc=2, N_dec=2, d_model=16, d_ff=32, num_att_heads=2, dropout=0.0)
+    model = models.setup(opt)
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('P.')}
+    assert set(sd.keys()) == set(model.state_dict().keys())
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    model.train()
+    att = torch.from_numpy(u['att']).to(DEV)
+    am = torch.from_numpy(u['att_masks']).to(DEV) if tag == 'mask' else None
+    labels, masks = torch.from_numpy(u['labels']).to(DEV), torch.from_numpy(u['masks']).to(DEV)
+    logp = model(None, att, labels[..., :-1], am)
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), z['xe_logp_' + tag], rtol=3e-5, atol=1e-5)
+    loss = LanguageModelCriterion()(logp, labels[..., 1:], masks[..., 1:])
+    np.testing.assert_allclose(loss.item(), z['xe_loss_' + tag], rtol=1e-5)
+    loss.backward()
+    for k, p in model.named_parameters():
+        ref = z['xe_grad_%s.%s' % (tag, k)]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-3, atol=1e-6 + 5e-5 * np.abs(ref).max(), err_msg=k)
+    model.eval()
+    with torch.no_grad():
+        seq, slp = model(None, att, am, opt={'sample_method': 'greedy'}, mode='sample')
+    assert np.array_equal(seq.cpu().numpy(), z['greedy_seq_' + tag])
+    np.testing.assert_allclose(slp.cpu().numpy(), z['greedy_logp_' + tag], rtol=3e-5, atol=1e-5)

@@ -105,3 +105,29 @@ def test_newfc_greedy_token_exact():
         seq, slp = O.newfc_rollout_greedy(P, torch.from_numpy(z['fc']), max_len=8)
     assert np.array_equal(seq.numpy(), z['greedy_seq'])
     np.testing.assert_allclose(slp.numpy(), z['greedy_logp'], **TOL)
+
+
+@pytest.mark.parametrize('tag', ['nomask', 'mask'])
+def test_transformer_teacher_forced_loss_grads_and_greedy(tag):
+    from oracle import transformer as T
+    z = np.load(os.path.join(GOLDEN, 'transformer_tiny.npz'))
+    u = np.load(os.path.join(GOLDEN, 'updown_tiny.npz'))
+    P = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('P.')}
+    for k, v in P.items():
+        if v.is_floating_point() and not k.endswith('.pe'):
+            v.requires_grad_(True)
+    att = torch.from_numpy(u['att'])
+    am = torch.from_numpy(u['att_masks']) if tag == 'mask' else None
+    labels, masks = torch.from_numpy(u['labels']), torch.from_numpy(u['masks'])
+    logp = T.forward_teacher(P, att, labels[..., :-1], am, h=2, n_enc=2, n_dec=2)
+    np.testing.assert_allclose(logp.detach().numpy(), z['xe_logp_' + tag], rtol=1e-5, atol=3e-6)
+    loss = O.lm_criterion(logp, labels[..., 1:], masks[..., 1:])
+    np.testing.assert_allclose(loss.item(), z['xe_loss_' + tag], rtol=1e-6)
+    loss.backward()
+    for k, p in P.items():
+        if p.requires_grad:
+            np.testing.assert_allclose(p.grad.numpy(), z['xe_grad_%s.%s' % (tag, k)], rtol=3e-4, atol=3e-7, err_msg=k)
+    with torch.no_grad():
+        seq, slp = T.greedy(P, att, am, h=2, n_enc=2, n_dec=2, max_len=8)
+    assert np.array_equal(seq.numpy(), z['greedy_seq_' + tag])
+    np.testing.assert_allclose(slp.numpy(), z['greedy_logp_' + tag], rtol=1e-5, atol=3e-6)
