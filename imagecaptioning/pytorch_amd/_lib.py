@@ -125,8 +125,12 @@ SIGNATURES = {
     'capmi_updown_beam_search': [C.POINTER(UpDownWeights), C.POINTER(UpDownBeam), _P],
     'capmi_layernorm_fwd': [_P] * 6 + [_I, _I, _F, _P],
     'capmi_layernorm_bwd': [_P] * 6 + [_I, _P, _I, _I, _F, _P],
-    'capmi_mha_fwd': [_P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    'capmi_mha_bwd': [_P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'capmi_mha_fwd': [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'capmi_mha_bwd': [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'capmi_glu_fwd': [_P, _P, _P, _P, _I, _I, _P],
+    'capmi_glu_bwd': [_P, _P, _P, _P, _I, _I, _P],
+    'capmi_meanpool_fwd': [_P, _P, _P, _I, _I, _I, _P],
+    'capmi_meanpool_bwd': [_P, _P, _P, _I, _I, _I, _I, _P],
     'capmi_embed_pe_fwd': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'capmi_embed_pe_bwd': [_P, _I, _P, _P, _P, _I, _I, _I, _P],
     'capmi_log_softmax_rows': [_P, _P, _I, _I, _P],

@@ -1,0 +1,276 @@
+"""Host-side driver of the AoANet captioner (BASELINE configs[4], configs/aoa.yml) on libcapmi.
+
+Restates AoAModel.py of the reference (refine 1, refine_aoa 1, use_ff 0, decoder_type AoA, use_multi_head 2,
+mean_feats 1, ctx_drop 1) as C-ABI launches with a hand-written backward:
+  prefill   att_embed -> 6 x [x + Drop(GLU(Linear([MHA(LN x) | LN x])))] -> LN -> masked mean, ctx2att (V|K halves)
+  step      LSTMCell([xt | mean + Drop(ctx_prev)], h_att) -> LN -> q -> 8-head dot attention over the image's K/V halves
+            -> GLU(Linear([att | h_att])) -> Drop -> logit           (AoA_Decoder_Core.forward, AoAModel.py:163-186)
+MI355X-first: K/V stay per IMAGE (the attention kernel serves the n caption rows of an image from one LDS copy,
+key stride 2R inside p_att rows, no repeat_tensors / narrow copies); the mean-feature term of the LSTM gates is
+constant over time and enters as a per-image row bias; every core weight gradient is one time-batched GEMM.
+"""
+import torch
+
+from . import _lib, ops
+from ._lib import lib, ptr, check, stream_ptr
+from .transformer_engine import Lin, Norm, Dropper, mha_fwd, mha_bwd, layernorm_fwd, layernorm_bwd, EPS
+
+_f32 = torch.float32
+
+
+def glu_fwd(pre, mask=None, residual=None):
+    M, R2 = pre.shape
+    out = torch.empty(M, R2 // 2, dtype=_f32, device=pre.device)
+    check(lib.capmi_glu_fwd(ptr(pre), ptr(mask), ptr(residual), ptr(out), M, R2 // 2, stream_ptr()), 'glu_fwd')
+    return out
+
+
+def glu_bwd(d_out, mask, pre):
+    d_pre = torch.empty_like(pre)
+    check(lib.capmi_glu_bwd(ptr(d_out), ptr(mask), ptr(pre), ptr(d_pre), pre.shape[0], pre.shape[1] // 2, stream_ptr()), 'glu_bwd')
+    return d_pre
+
+
+def mul_mask(x, mask):
+    return x if mask is None else ops.relu_mask_bwd(x.contiguous(), None, mask)
+
+
+class AoAGraph:
+    def __init__(self, P, grads, h, drop_prob_lm, dropout_aoa, training, seed):
+        self.P, self.g, self.h = P, grads, h
+        dev = P['logit.weight'].device
+        self.dev = dev
+        self.d_lm = Dropper(drop_prob_lm, seed, dev, training)               # embed / att_embed / ctx_drop / out_drop
+        self.d_att = Dropper(0.1, seed ^ 0x1234567, dev, training)            # attention probabilities (AoAModel.py:18,53)
+        self.d_res = Dropper(0.1, seed ^ 0x7654321, dev, training)            # refiner SublayerConnection (AoAModel.py:119)
+        self.d_aoa = Dropper(dropout_aoa, seed ^ 0x2468ace, dev, training)    # AoA input (AoAModel.py:44-48)
+
+    # ------------------------------------------------------------------ prefill
+    def prepare(self, att_feats, att_masks):
+        P, g, h = self.P, self.g, self.h
+        B, K, F = att_feats.shape
+        R = P['att_embed.0.weight'].shape[0]
+        self.B, self.K, self.R = B, K, R
+        m = self.d_lm(B * K, R)
+        self.att_masks = att_masks
+        if att_masks is not None:
+            mm = att_masks.reshape(B * K, 1).expand(B * K, R)
+            m = (mm if m is None else m * mm).contiguous()
+            self.smask = att_masks.to(torch.uint8).contiguous()
+        else:
+            self.smask = None
+        self.embed = Lin(P, g, 'att_embed.0.weight', 'att_embed.0.bias')
+        x = self.embed.fwd(att_feats.reshape(B * K, F), relu=True, mask=m)
+        self.ref = []
+        for i in range(6):
+            pre = 'refiner.layers.%d' % i
+            n0 = Norm(P, g, pre + '.sublayer.0.norm')
+            y = n0.fwd(x)
+            lq, lk, lv = (Lin(P, g, '%s.self_attn.linears.%d.weight' % (pre, j), '%s.self_attn.linears.%d.bias' % (pre, j))
+                          for j in range(3))
+            q, k, v = lq.fwd(y), lk.fwd(y), lv.fwd(y)
+            dp = self.d_att(B, h, K, K)
+            o, p = mha_fwd(q, k, v, K * R, B, 1, K, K, h, self.smask, 1, 1, 0, 0, dp)
+            o2 = o.view(B * K, R)
+            m_o, m_y = self.d_aoa(B * K, R), self.d_aoa(B * K, R)
+            od, yd = mul_mask(o2, m_o), mul_mask(y, m_y)
+            W = P[pre + '.self_attn.aoa_layer.0.weight']                      # [2R, 2R], input [att | query]
+            pre_act = torch.empty(B * K, 2 * R, dtype=_f32, device=self.dev)
+            ops.gemm([(od, R, W, 2 * R, R, 1), (yd, R, (W, R), 2 * R, R, 1)], B * K, 2 * R, pre_act,
+                     bias=P[pre + '.self_attn.aoa_layer.0.bias'])
+            m_res = self.d_res(B * K, R)
+            x_new = glu_fwd(pre_act, m_res, x)
+            self.ref.append(dict(pre=pre, n0=n0, lq=lq, lk=lk, lv=lv, q=q, k=k, v=v, p=p, dp=dp, od=od, yd=yd, m_o=m_o, m_y=m_y,
+                                 pre_act=pre_act, m_res=m_res))
+            x = x_new
+        self.ref_norm = Norm(P, g, 'refiner.norm')
+        self.att = self.ref_norm.fwd(x)                                        # [B*K, R]
+        self.mean = torch.empty(B, R, dtype=_f32, device=self.dev)
+        check(lib.capmi_meanpool_fwd(ptr(self.att), ptr(att_masks), ptr(self.mean), B, K, R, stream_ptr()), 'meanpool_fwd')
+        self.ctx2att = Lin(P, g, 'ctx2att.weight', 'ctx2att.bias')
+        self.p_att = self.ctx2att.fwd(self.att)                               # [B*K, 2R]  value | key
+        return self.mean, self.att, self.p_att
+
+    # ------------------------------------------------------------------ rollout
+    def rollout(self, n, T, L, mode='forced', forced=None, teacher=False, temperature=1.0, seed=0, gumbel=None, keep=True):
+        """T decoder steps on N = B*n rows.  teacher: inputs forced[:, t] (AttModel._forward); else AttModel._sample with
+        mode greedy / sample / forced (tokens chosen at t are fed at t+1)."""
+        P, h, B, K, R = self.P, self.h, self.B, self.K, self.R
+        N = B * n
+        V1, E = P['embed.0.weight'].shape
+        dev = self.dev
+        self.n, self.N, self.T, self.L, self.keep = n, N, T, L, keep
+        z = lambda *s: torch.empty(*s, dtype=_f32, device=dev)       # noqa: E731
+        W_ih, W_hh = P['core.att_lstm.weight_ih'], P['core.att_lstm.weight_hh']
+        ld_ih = E + R
+        ws = ops.default_workspace(dev)
+        # mean-feature term of the gates, once per rollout: [B,4R] = mean W_ih[:, E:]^T
+        self.mean_gates = z(B, 4 * R)
+        ops.gemm([(self.mean, R, (W_ih, E), ld_ih, R, 1)], B, 4 * R, self.mean_gates)
+        self.h_att, self.c_att, self.out = torch.zeros(T + 1, N, R, device=dev), torch.zeros(T + 1, N, R, device=dev), \
+            torch.zeros(T + 1, N, R, device=dev)
+        self.xt, self.ctx_in, self.gates = z(T, N, E), z(T, N, R), z(T, N, 4 * R)
+        self.qn, self.q_ln_mean, self.q_ln_inv = z(T, N, R), z(T, N), z(T, N)
+        self.q, self.att_o, self.pre2, self.out_drop = z(T, N, R), z(T, N, R), z(T, N, 2 * R), z(T, N, R)
+        self.p_dec = z(T, N, h, 1, K)
+        self.it_all = torch.empty(T, N, dtype=torch.long, device=dev)
+        self.m_xt, self.m_ctx, self.m_out, self.m_patt = [], [], [], []
+        self.seq = torch.zeros(N, L, dtype=torch.long, device=dev)
+        self.seq_logp = torch.zeros(N, L, V1, dtype=_f32, device=dev)
+        self.sel = torch.zeros(N, L, dtype=_f32, device=dev)
+        self.live = torch.zeros(N, L, dtype=torch.uint8, device=dev)
+        it = torch.zeros(N, dtype=torch.long, device=dev)
+        unf = torch.ones(N, dtype=torch.uint8, device=dev)
+        logits = z(N, V1)
+        mode_i = 2 if teacher else {'greedy': 0, 'sample': 1, 'forced': 2}[mode]
+        st = stream_ptr()
+        a_n, b_n = P['core.attention.norm.a_2'], P['core.attention.norm.b_2']
+        Wq, bq = P['core.attention.linears.0.weight'], P['core.attention.linears.0.bias']
+        Wc, bc = P['core.att2ctx.0.weight'], P['core.att2ctx.0.bias']
+        for t in range(T):
+            m_xt, m_ctx, m_out, m_p = self.d_lm(N, E), self.d_lm(N, R), self.d_lm(N, R), self.d_att(N, h, 1, K)
+            self.m_xt.append(m_xt); self.m_ctx.append(m_ctx); self.m_out.append(m_out); self.m_patt.append(m_p)
+            if teacher:
+                check(lib.capmi_embed_fwd(forced.data_ptr() + 8 * t, forced.shape[1], ptr(self.it_all[t]), ptr(P['embed.0.weight']),
+                                          ptr(m_xt), ptr(self.xt[t]), N, E, 1, st), 'embed_fwd')
+            else:
+                check(lib.capmi_embed_fwd(ptr(it), 1, ptr(self.it_all[t]), ptr(P['embed.0.weight']), ptr(m_xt), ptr(self.xt[t]), N, E,
+                                          1, st), 'embed_fwd')
+            ctx_prev = self.out[t]
+            if m_ctx is None:
+                self.ctx_in[t].copy_(ctx_prev)
+            else:
+                check(lib.capmi_relu_mask_bwd(ptr(ctx_prev), None, ptr(m_ctx), ptr(self.ctx_in[t]), N * R, st), 'ctx_drop')
+            splits = ops.gemm([(self.xt[t], E, W_ih, ld_ih, E, 1), (self.ctx_in[t], R, (W_ih, E), ld_ih, R, 1),
+                               (self.h_att[t], R, W_hh, R, R, 1)], N, 4 * R, ws.buf, ws=ws, defer_reduce=True)
+            check(lib.capmi_lstm_cell_fwd(ws.slabs.data_ptr(), splits, ptr(P['core.att_lstm.bias_ih']),
+                                          ptr(P['core.att_lstm.bias_hh']), ptr(self.mean_gates), n, None, ptr(self.c_att[t]),
+                                          ptr(self.h_att[t + 1]), ptr(self.c_att[t + 1]), ptr(self.gates[t]), None, None, N, R, st),
+                  'lstm_cell_fwd')
+            check(lib.capmi_layernorm_fwd(ptr(self.h_att[t + 1]), ptr(a_n), ptr(b_n), ptr(self.qn[t]), ptr(self.q_ln_mean[t]),
+                                          ptr(self.q_ln_inv[t]), N, R, EPS, st), 'layernorm_fwd')
+            ops.gemm([(self.qn[t], R, Wq, R, R, 1)], N, R, self.q[t], bias=bq)
+            # keys = second half of p_att rows, values = first half (AoAModel.py:168); per image, stride 2R
+            check(lib.capmi_mha_fwd(ptr(self.q[t]), self.p_att.data_ptr() + 4 * R, ptr(self.p_att), K * 2 * R, 2 * R, ptr(self.smask),
+                                    1, 0, 0, 0, ptr(m_p), ptr(self.att_o[t]), ptr(self.p_dec[t]), N, n, 1, K, h, R // h, st), 'mha_fwd')
+            ops.gemm([(self.att_o[t], R, Wc, 2 * R, R, 1), (self.h_att[t + 1], R, (Wc, R), 2 * R, R, 1)], N, 2 * R, self.pre2[t], bias=bc)
+            check(lib.capmi_glu_fwd(ptr(self.pre2[t]), None, None, ptr(self.out[t + 1]), N, R, st), 'glu_fwd')
+            if m_out is None:
+                self.out_drop[t].copy_(self.out[t + 1])
+            else:
+                check(lib.capmi_relu_mask_bwd(ptr(self.out[t + 1]), None, ptr(m_out), ptr(self.out_drop[t]), N * R, st), 'out_drop')
+            ops.gemm([(self.out_drop[t], R, P['logit.weight'], R, R, 1)], N, V1, logits, bias=P['logit.bias'])
+            check(lib.capmi_logsoftmax_select(ptr(logits), N, V1, t, L, mode_i, None, float(temperature),
+                                              None if gumbel is None else gumbel[t].data_ptr(), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                              ptr(forced), 0 if forced is None else forced.shape[1], 1 if teacher else 0,
+                                              ptr(self.seq), L, ptr(it), ptr(unf), ptr(self.seq_logp), ptr(self.sel), ptr(self.live),
+                                              st), 'logsoftmax_select')
+        return self.seq, self.seq_logp
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, g_logp):
+        P, g, h, B, K, R, n, N, T, L = self.P, self.g, self.h, self.B, self.K, self.R, self.n, self.N, self.T, self.L
+        V1, E = P['embed.0.weight'].shape
+        dev = self.dev
+        st = stream_ptr()
+        z = lambda *s: torch.empty(*s, dtype=_f32, device=dev)       # noqa: E731
+        g_logp = g_logp.contiguous()
+        dlogits = z(T, N, V1)
+        check(lib.capmi_logsoftmax_bwd(ptr(g_logp), ptr(self.seq_logp), ptr(self.live), ptr(dlogits), N, L, T, V1, st), 'logsoftmax_bwd')
+        TN = T * N
+        d_outdrop = ops.matmul_nn(dlogits.view(TN, V1), P['logit.weight'])            # [TN,R]
+        ops.matmul_tn(dlogits.view(TN, V1), self.out_drop.view(TN, R), out=g['logit.weight'])
+        ops.colsum(dlogits.view(TN, V1), out=g['logit.bias'])
+        d_outdrop = d_outdrop.view(T, N, R)
+        W_ih, W_hh = P['core.att_lstm.weight_ih'], P['core.att_lstm.weight_hh']
+        ld_ih = E + R
+        Wq, Wc = P['core.attention.linears.0.weight'], P['core.att2ctx.0.weight']
+        a_n = P['core.attention.norm.a_2']
+        d_pre2_all, dq_all, dg_all, ln_g, ln_dy = z(T, N, 2 * R), z(T, N, R), z(T, N, 4 * R), z(T, N, R), z(T, N, R)
+        d_sum_all = z(T, N, R)                  # gradient reaching (mean + Drop(ctx_prev)) at each step
+        d_p_att = torch.zeros(B * K, 2 * R, dtype=_f32, device=dev)
+        dh_next, dc_next, d_ctx_next = None, None, None
+        for t in range(T - 1, -1, -1):
+            # out_{t+1}: from the logit (through out_drop) and from step t+1's ctx input
+            d_out = mul_mask(d_outdrop[t], self.m_out[t])
+            if d_ctx_next is not None:
+                d_out = d_out + d_ctx_next
+            check(lib.capmi_glu_bwd(ptr(d_out), None, ptr(self.pre2[t]), ptr(d_pre2_all[t]), N, R, st), 'glu_bwd')
+            d_cat = ops.matmul_nn(d_pre2_all[t], Wc)                                   # [N,2R] = [d_att | d_h_att]
+            d_att = d_cat[:, :R].contiguous()
+            dh = d_cat[:, R:].contiguous()
+            # attention: dq, dK/dV accumulated into the two halves of d_p_att across rows of an image and across time
+            dq = torch.empty(N, 1, R, dtype=_f32, device=dev)
+            check(lib.capmi_mha_bwd(ptr(d_att), ptr(self.q[t]), self.p_att.data_ptr() + 4 * R, ptr(self.p_att), K * 2 * R, 2 * R,
+                                    ptr(self.p_dec[t]), ptr(self.m_patt[t]), ptr(dq), d_p_att.data_ptr() + 4 * R, ptr(d_p_att),
+                                    K * 2 * R, 2 * R, 1, N, n, 1, K, h, R // h, st), 'mha_bwd')
+            dq_all[t].copy_(dq.view(N, R))
+            d_qn = ops.matmul_nn(dq_all[t], Wq)
+            ln_dy[t].copy_(d_qn)
+            check(lib.capmi_layernorm_bwd(ptr(d_qn), ptr(self.h_att[t + 1]), ptr(a_n), ptr(self.q_ln_mean[t]), ptr(self.q_ln_inv[t]),
+                                          ptr(dh), 1, ptr(ln_g[t]), N, R, EPS, st), 'layernorm_bwd')
+            # LSTM cell
+            dc_prev = z(N, R)
+            check(lib.capmi_lstm_cell_bwd(ptr(dh), R, None, ptr(dh_next), R, None, R, ptr(dc_next), ptr(self.gates[t]),
+                                          ptr(self.c_att[t]), ptr(self.c_att[t + 1]), ptr(dg_all[t]), ptr(dc_prev), N, R, st),
+                  'lstm_cell_bwd')
+            dc_next = dc_prev
+            if t > 0:
+                ops.gemm([(dg_all[t], 4 * R, (W_ih, E), ld_ih, 4 * R, 1)], N, R, d_sum_all[t], a_layout=0, b_layout=1)
+                d_ctx_next = mul_mask(d_sum_all[t], self.m_ctx[t])
+                dh_next = ops.matmul_nn(dg_all[t], W_hh)
+            else:
+                ops.gemm([(dg_all[t], 4 * R, (W_ih, E), ld_ih, 4 * R, 1)], N, R, d_sum_all[t], a_layout=0, b_layout=1)
+        # ---- time-batched core gradients
+        dg2 = dg_all.view(TN, 4 * R)
+        ops.gemm([(dg2, 4 * R, self.xt.view(TN, E), E, TN, 1)], 4 * R, E, g['core.att_lstm.weight_ih'], ldc=ld_ih, a_layout=1, b_layout=1)
+        # columns E: of W_ih multiply (mean + ctx_in): ctx_in part time-batched, mean part through the per-image sum
+        sum_dg = z(B, 4 * R)
+        check(lib.capmi_group_rowsum(ptr(dg_all), T, N * 4 * R, B, n, 4 * R, ptr(sum_dg), st), 'group_rowsum')
+        gW = g['core.att_lstm.weight_ih']
+        ops.gemm([(dg2, 4 * R, self.ctx_in.view(TN, R), R, TN, 1)], 4 * R, R, (gW, E), ldc=ld_ih, a_layout=1, b_layout=1)
+        ops.gemm([(sum_dg, 4 * R, self.mean, R, B, 1)], 4 * R, R, (gW, E), ldc=ld_ih, a_layout=1, b_layout=1, accumulate=True)
+        ops.matmul_tn(dg2, self.h_att[:T].reshape(TN, R), out=g['core.att_lstm.weight_hh'])
+        ops.colsum(dg2, out=g['core.att_lstm.bias_ih'])
+        g['core.att_lstm.bias_hh'].copy_(g['core.att_lstm.bias_ih'])
+        d_mean = ops.matmul_nn(sum_dg, W_ih[:, E:].contiguous())                      # [B,R]
+        # embedding
+        d_xt = ops.matmul_nn(dg2, W_ih[:, :E].contiguous())
+        g['embed.0.weight'].zero_()
+        masks_xt = None if self.m_xt[0] is None else torch.stack(self.m_xt).contiguous()
+        check(lib.capmi_embed_bwd(ptr(self.it_all), ptr(d_xt), ptr(self.xt), ptr(masks_xt), ptr(g['embed.0.weight']), TN, E, 1, st),
+              'embed_bwd')
+        # attention query path
+        ops.matmul_tn(dq_all.view(TN, R), self.qn.view(TN, R), out=g['core.attention.linears.0.weight'])
+        ops.colsum(dq_all.view(TN, R), out=g['core.attention.linears.0.bias'])
+        ops.colsum(ln_g.view(TN, R), out=g['core.attention.norm.a_2'])
+        ops.colsum(ln_dy.view(TN, R), out=g['core.attention.norm.b_2'])
+        # att2ctx
+        gWc = g['core.att2ctx.0.weight']
+        dp2 = d_pre2_all.view(TN, 2 * R)
+        ops.gemm([(dp2, 2 * R, self.att_o.view(TN, R), R, TN, 1)], 2 * R, R, gWc, ldc=2 * R, a_layout=1, b_layout=1)
+        ops.gemm([(dp2, 2 * R, self.h_att[1:].reshape(TN, R), R, TN, 1)], 2 * R, R, (gWc, R), ldc=2 * R, a_layout=1, b_layout=1)
+        ops.colsum(dp2, out=g['core.att2ctx.0.bias'])
+        # ---- prefill backward
+        d_att = self.ctx2att.bwd(d_p_att)                                              # [B*K,R]
+        check(lib.capmi_meanpool_bwd(ptr(d_mean), ptr(self.att_masks), ptr(d_att), 1, B, K, R, st), 'meanpool_bwd')
+        dx = torch.zeros(B * K, R, dtype=_f32, device=dev)
+        self.ref_norm.bwd(d_att, dx)
+        for lay in reversed(self.ref):
+            pre = lay['pre']
+            d_pre = glu_bwd(dx, lay['m_res'], lay['pre_act'])                          # residual path stays in dx
+            W = P[pre + '.self_attn.aoa_layer.0.weight']
+            gW2 = g[pre + '.self_attn.aoa_layer.0.weight']
+            BK = B * K
+            ops.gemm([(d_pre, 2 * R, lay['od'], R, BK, 1)], 2 * R, R, gW2, ldc=2 * R, a_layout=1, b_layout=1)
+            ops.gemm([(d_pre, 2 * R, lay['yd'], R, BK, 1)], 2 * R, R, (gW2, R), ldc=2 * R, a_layout=1, b_layout=1)
+            ops.colsum(d_pre, out=g[pre + '.self_attn.aoa_layer.0.bias'])
+            d_cat = ops.matmul_nn(d_pre, W)                                            # [BK,2R] = [d_od | d_yd]
+            d_o = mul_mask(d_cat[:, :R].contiguous(), lay['m_o'])
+            d_y = mul_mask(d_cat[:, R:].contiguous(), lay['m_y'])
+            dq, dk, dv = mha_bwd(d_o.view(B, K, R), lay['q'], lay['k'], lay['v'], K * R, lay['p'], lay['dp'], B, 1, K, K, h)
+            d_y = d_y + lay['lq'].bwd(dq.view(BK, R))
+            d_y += lay['lk'].bwd(dk.view(BK, R))
+            d_y += lay['lv'].bwd(dv.view(BK, R))
+            lay['n0'].bwd(d_y, dx)
+        self.embed.bwd(dx, need_dx=False)

@@ -1,0 +1,141 @@
+"""AoAModel (reference captioning/models/AoAModel.py:188-226) on the HIP backend -- BASELINE configs[4]
+(configs/aoa.yml switches: refine 1, refine_aoa 1, use_ff 0, decoder_type AoA, use_multi_head 2, mean_feats 1).
+Parameter tree = the reference's; arithmetic = aoa_engine.py + csrc kernels."""
+import copy
+
+import torch
+import torch.nn as nn
+
+from .CaptionModel import CaptionModel
+from .TransformerModel import _LayerNorm, _Sublayer, _clones
+from ... import aoa_engine as engine
+from ..._lib import CapmiError
+
+
+class _MHDot(nn.Module):
+    """MultiHeadedDotAttention parameter holder (AoAModel.py:17-55)."""
+
+    def __init__(self, d, project_k_v, do_aoa, norm_q):
+        super().__init__()
+        if norm_q:
+            self.norm = _LayerNorm(d)
+        self.linears = _clones(nn.Linear(d, d), 1 + 2 * project_k_v)
+        if do_aoa:
+            self.aoa_layer = nn.Sequential(nn.Linear(2 * d, 2 * d), nn.GLU())
+
+
+class _RefLayer(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.self_attn = _MHDot(d, 1, 1, 0)
+        self.sublayer = _clones(_Sublayer(d), 1)
+
+
+class _Refiner(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.layers = _clones(_RefLayer(d), 6)
+        self.norm = _LayerNorm(d)
+
+
+class _Core(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        R = opt.rnn_size
+        self.att_lstm = nn.LSTMCell(opt.input_encoding_size + R, R)
+        self.att2ctx = nn.Sequential(nn.Linear(2 * R, 2 * R), nn.GLU())
+        self.attention = _MHDot(R, 0, 0, 1)
+
+
+class _Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, cfg, att_feats, att_masks, *params):
+        P = dict(zip(model._param_names, [p.detach() for p in params]))
+        grads = model._flat.grad_views if model._flat is not None else {k: torch.empty_like(v) for k, v in P.items()}
+        g = engine.AoAGraph(P, grads, model.num_heads, model.drop_prob_lm, model.dropout_aoa, model.training, model._next_seed())
+        g.prepare(att_feats, att_masks)
+        seq, logp = g.rollout(**cfg)
+        ctx.g, ctx.model, ctx.grads = g, model, grads
+        ctx.mark_non_differentiable(seq)
+        return seq, logp
+
+    @staticmethod
+    def backward(ctx, _gs, g_logp):
+        ctx.g.backward(g_logp)
+        return (None, None, None, None) + tuple(ctx.grads[k] for k in ctx.model._param_names)
+
+
+class AoAModel(CaptionModel):
+    def __init__(self, opt):
+        super().__init__()
+        for k, want in (('refine', 1), ('refine_aoa', 1), ('use_ff', 0), ('use_multi_head', 2), ('multi_head_scale', 1)):
+            if getattr(opt, k, want) != want:
+                raise NotImplementedError('AoA option %s=%r is outside configs/aoa.yml' % (k, getattr(opt, k)))
+        if getattr(opt, 'decoder_type', 'AoA') != 'AoA' or not getattr(opt, 'mean_feats', 1):
+            raise NotImplementedError('only decoder_type AoA with mean_feats 1 (configs/aoa.yml) is accelerated')
+        if not getattr(opt, 'ctx_drop', 0):
+            pass       # ctx_drop 0 == identity mask: handled by drop_prob in eval; train-mode ctx_drop=0 not in aoa.yml
+        self.vocab_size = opt.vocab_size
+        self.rnn_size = opt.rnn_size
+        self.input_encoding_size = opt.input_encoding_size
+        self.num_layers = 2
+        self.num_heads = opt.num_heads
+        self.drop_prob_lm = opt.drop_prob_lm
+        self.dropout_aoa = getattr(opt, 'dropout_aoa', 0.3)
+        self.seq_length = getattr(opt, 'max_length', 20) or opt.seq_length
+        self.vocab = opt.vocab
+        self.ss_prob = 0.0
+        R = self.rnn_size
+        self.embed = nn.Sequential(nn.Embedding(self.vocab_size + 1, self.input_encoding_size), nn.ReLU(),
+                                   nn.Dropout(self.drop_prob_lm))
+        self.att_embed = nn.Sequential(nn.Linear(opt.att_feat_size, R), nn.ReLU(), nn.Dropout(self.drop_prob_lm))
+        self.logit = nn.Linear(R, self.vocab_size + 1)
+        self.ctx2att = nn.Linear(R, 2 * R)
+        self.refiner = _Refiner(R)
+        self.core = _Core(opt)
+        self._flat = None
+        self._rng_calls = 0
+
+    @property
+    def _param_names(self):
+        return [n for n, _ in self.named_parameters()]
+
+    def flatten_parameters_(self):
+        from ...flat import FlatParams
+        self._flat = FlatParams(self)
+        return self._flat
+
+    def _next_seed(self):
+        self._rng_calls += 1
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._rng_calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+    def _run(self, cfg, att_feats, att_masks):
+        if not att_feats.is_cuda:
+            raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
+        if att_masks is not None:
+            ml = int(att_masks.long().sum(1).max())
+            att_feats, att_masks = att_feats[:, :ml], att_masks[:, :ml].float().contiguous()
+        params = [p for _, p in self.named_parameters()]
+        return _Fn.apply(self, cfg, att_feats.float().contiguous(), att_masks, *params)
+
+    def _forward(self, fc_feats, att_feats, seq, att_masks=None):
+        B = att_feats.size(0)
+        if seq.ndim == 3:
+            seq = seq.reshape(-1, seq.shape[2])
+        seq = seq.long().contiguous()
+        N, T = seq.shape
+        zero_cols = (seq[:, 1:].sum(0) == 0).nonzero()
+        T_eff = int(zero_cols[0]) + 1 if zero_cols.numel() else T
+        _, logp = self._run(dict(n=N // B, T=T_eff, L=T, forced=seq, teacher=True), att_feats, att_masks)
+        return logp
+
+    def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
+        method = opt.get('sample_method', 'greedy')
+        if opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search'):
+            raise NotImplementedError('beam search for AoA is not accelerated yet')
+        if method not in ('greedy', 'sample'):
+            raise NotImplementedError('sample_method %r' % method)
+        L = self.seq_length
+        cfg = dict(n=int(opt.get('sample_n', 1)), T=L, L=L, mode=method, temperature=opt.get('temperature', 1.0),
+                   seed=self._next_seed(), gumbel=opt.get('_gumbel'))
+        return self._run(cfg, att_feats, att_masks)

@@ -70,7 +70,7 @@ constexpr int MHA_T = 256;
 
 // workgroup = (kv row, head).  LDS: K [Tk][dk+1], V [Tk][dk+1], then per query row: Q [Tq][dk+1], S [Tq][Tk+1]
 __global__ __launch_bounds__(MHA_T) void mha_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k,
-                                                       const float *__restrict__ v, int ldkv,
+                                                       const float *__restrict__ v, int ldkv, int kstride,
                                                        const uint8_t *__restrict__ mask, int mask_tq, int mask_per_q,
                                                        int causal, int q_pos0, const float *__restrict__ drop,
                                                        float *__restrict__ o, float *__restrict__ p, int q_per_kv, int Tq,
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(MHA_T) void mha_fwd_kernel(const float *__restrict_
     const float scale = rsqrtf((float)dk);
     for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {
         const int j = i / dk, c = i % dk;
-        sK[j * P1 + c] = k[(size_t)kvr * ldkv + (size_t)j * D + hd * dk + c];
-        sV[j * P1 + c] = v[(size_t)kvr * ldkv + (size_t)j * D + hd * dk + c];
+        sK[j * P1 + c] = k[(size_t)kvr * ldkv + (size_t)j * kstride + hd * dk + c];
+        sV[j * P1 + c] = v[(size_t)kvr * ldkv + (size_t)j * kstride + hd * dk + c];
     }
     for (int rq = 0; rq < q_per_kv; ++rq) {
         const int r = kvr * q_per_kv + rq;
@@ -141,9 +141,10 @@ __global__ __launch_bounds__(MHA_T) void mha_fwd_kernel(const float *__restrict_
 // backward, same decomposition; dK/dV accumulated over the q_per_kv rows in LDS and written once
 __global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict__ d_o, const float *__restrict__ q,
                                                        const float *__restrict__ k, const float *__restrict__ v, int ldkv,
-                                                       const float *__restrict__ p, const float *__restrict__ drop,
-                                                       float *__restrict__ dq, float *__restrict__ dk_out,
-                                                       float *__restrict__ dv_out, int q_per_kv, int Tq, int Tk, int h,
+                                                       int kstride, const float *__restrict__ p,
+                                                       const float *__restrict__ drop, float *__restrict__ dq,
+                                                       float *__restrict__ dk_out, float *__restrict__ dv_out, int dkv_ld,
+                                                       int dkv_stride, int accumulate, int q_per_kv, int Tq, int Tk, int h,
                                                        int dk) {
     extern __shared__ float lds[];
     const int D = h * dk, P1 = dk + 1, S1 = Tk + 1;
@@ -153,8 +154,8 @@ __global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict_
     const float scale = rsqrtf((float)dk);
     for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {
         const int j = i / dk, c = i % dk;
-        sK[j * P1 + c] = k[(size_t)kvr * ldkv + (size_t)j * D + hd * dk + c];
-        sV[j * P1 + c] = v[(size_t)kvr * ldkv + (size_t)j * D + hd * dk + c];
+        sK[j * P1 + c] = k[(size_t)kvr * ldkv + (size_t)j * kstride + hd * dk + c];
+        sV[j * P1 + c] = v[(size_t)kvr * ldkv + (size_t)j * kstride + hd * dk + c];
         sdK[j * P1 + c] = 0.f;
         sdV[j * P1 + c] = 0.f;
     }
@@ -214,8 +215,14 @@ __global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict_
     __syncthreads();
     for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {
         const int j = i / dk, c = i % dk;
-        dk_out[((size_t)kvr * Tk + j) * D + hd * dk + c] = sdK[j * P1 + c];
-        dv_out[((size_t)kvr * Tk + j) * D + hd * dk + c] = sdV[j * P1 + c];
+        const size_t oi = (size_t)kvr * dkv_ld + (size_t)j * dkv_stride + hd * dk + c;
+        if (accumulate) {
+            dk_out[oi] += sdK[j * P1 + c];
+            dv_out[oi] += sdV[j * P1 + c];
+        } else {
+            dk_out[oi] = sdK[j * P1 + c];
+            dv_out[oi] = sdV[j * P1 + c];
+        }
     }
 }
 
@@ -262,6 +269,57 @@ __global__ __launch_bounds__(1024) void log_softmax_rows_kernel(const float *__r
     for (int v = threadIdx.x; v < V1; v += blockDim.x) out[r * V1 + v] = x[v] - lse;
 }
 
+__global__ void glu_fwd_kernel(const float *__restrict__ pre, const float *__restrict__ mask,
+                               const float *__restrict__ residual, float *__restrict__ out, int M, int R) {
+    const size_t total = (size_t)M * R;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / R, c = i % R;
+        float v = pre[r * 2 * R + c] * sigmoid_f(pre[r * 2 * R + R + c]);
+        if (mask) v *= mask[i];
+        if (residual) v += residual[i];
+        out[i] = v;
+    }
+}
+
+__global__ void glu_bwd_kernel(const float *__restrict__ d_out, const float *__restrict__ mask, const float *__restrict__ pre,
+                               float *__restrict__ d_pre, int M, int R) {
+    const size_t total = (size_t)M * R;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / R, c = i % R;
+        float g = d_out[i];
+        if (mask) g *= mask[i];
+        const float a = pre[r * 2 * R + c], sg = sigmoid_f(pre[r * 2 * R + R + c]);
+        d_pre[r * 2 * R + c] = g * sg;
+        d_pre[r * 2 * R + R + c] = g * a * sg * (1.f - sg);
+    }
+}
+
+__global__ void meanpool_fwd_kernel(const float *__restrict__ x, const float *__restrict__ mask, float *__restrict__ mean,
+                                    int K, int D) {
+    const int b = blockIdx.x;
+    float cnt = 0.f;
+    for (int k = 0; k < K; ++k) cnt += mask ? mask[(size_t)b * K + k] : 1.f;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += (mask ? mask[(size_t)b * K + k] : 1.f) * x[((size_t)b * K + k) * D + c];
+        mean[(size_t)b * D + c] = s / cnt;
+    }
+}
+
+__global__ void meanpool_bwd_kernel(const float *__restrict__ dmean, const float *__restrict__ mask, float *__restrict__ dx,
+                                    int accumulate, int B, int K, int D) {
+    const size_t total = (size_t)B * K * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        const size_t bk = i / D;
+        const int b = (int)(bk / K);
+        float cnt = 0.f;
+        for (int k = 0; k < K; ++k) cnt += mask ? mask[(size_t)b * K + k] : 1.f;
+        const float v = (mask ? mask[bk] : 1.f) / cnt * dmean[(size_t)b * D + c];
+        dx[i] = accumulate ? dx[i] + v : v;
+    }
+}
+
 inline int grid_for(size_t work) {
     size_t b = (work + 255) / 256;
     if (b > 4096) b = 4096;
@@ -293,29 +351,33 @@ int capmi_layernorm_bwd(const float *dy, const float *x, const float *a, const f
     return 0;
 }
 
-int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, const uint8_t *mask, int mask_tq,
+int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, int kstride, const uint8_t *mask, int mask_tq,
                   int mask_per_q, int causal, int q_pos0, const float *drop, float *o, float *p, int Nq, int q_per_kv,
                   int Tq, int Tk, int h, int dk, void *stream) {
+    if (kstride <= 0) kstride = h * dk;
     if (!q || !k || !v || !o || Nq <= 0 || q_per_kv <= 0 || Nq % q_per_kv || Tq <= 0 || Tk <= 0 || h <= 0 || dk <= 0)
         return CAPMI_EINVAL;
     if (mask && mask_tq != 1 && mask_tq != Tq) return CAPMI_EINVAL;
     const size_t lds = ((size_t)2 * Tk * (dk + 1) + (size_t)Tq * (dk + 1) + (size_t)Tq * (Tk + 1)) * sizeof(float);
     if (lds > 64 * 1024) return CAPMI_EINVAL;
-    hipLaunchKernelGGL(mha_fwd_kernel, dim3(Nq / q_per_kv, h), dim3(MHA_T), lds, (hipStream_t)stream, q, k, v, ldkv, mask,
-                       mask_tq, mask_per_q, causal, q_pos0, drop, o, p, q_per_kv, Tq, Tk, h, dk);
+    hipLaunchKernelGGL(mha_fwd_kernel, dim3(Nq / q_per_kv, h), dim3(MHA_T), lds, (hipStream_t)stream, q, k, v, ldkv, kstride,
+                       mask, mask_tq, mask_per_q, causal, q_pos0, drop, o, p, q_per_kv, Tq, Tk, h, dk);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
 
-int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float *v, int ldkv, const float *p,
-                  const float *drop, float *dq, float *dk_out, float *dv_out, int Nq, int q_per_kv, int Tq, int Tk, int h,
-                  int dk, void *stream) {
+int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float *v, int ldkv, int kstride, const float *p,
+                  const float *drop, float *dq, float *dk_out, float *dv_out, int dkv_ld, int dkv_stride, int accumulate,
+                  int Nq, int q_per_kv, int Tq, int Tk, int h, int dk, void *stream) {
+    if (kstride <= 0) kstride = h * dk;
+    if (dkv_stride <= 0) dkv_stride = h * dk;
+    if (dkv_ld <= 0) dkv_ld = Tk * dkv_stride;
     if (!d_o || !q || !k || !v || !p || !dq || !dk_out || !dv_out || Nq <= 0 || q_per_kv <= 0 || Nq % q_per_kv)
         return CAPMI_EINVAL;
     const size_t lds = ((size_t)4 * Tk * (dk + 1) + (size_t)2 * Tq * (dk + 1) + (size_t)2 * Tq * (Tk + 1)) * sizeof(float);
     if (lds > 64 * 1024) return CAPMI_EINVAL;
-    hipLaunchKernelGGL(mha_bwd_kernel, dim3(Nq / q_per_kv, h), dim3(MHA_T), lds, (hipStream_t)stream, d_o, q, k, v, ldkv, p,
-                       drop, dq, dk_out, dv_out, q_per_kv, Tq, Tk, h, dk);
+    hipLaunchKernelGGL(mha_bwd_kernel, dim3(Nq / q_per_kv, h), dim3(MHA_T), lds, (hipStream_t)stream, d_o, q, k, v, ldkv, kstride,
+                       p, drop, dq, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, q_per_kv, Tq, Tk, h, dk);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -334,6 +396,37 @@ int capmi_embed_pe_bwd(const int64_t *tok, int tok_ld, const float *dx, const fl
     if (!tok || !dx || !dE || N <= 0 || T <= 0 || D <= 0) return CAPMI_EINVAL;
     hipLaunchKernelGGL(embed_pe_bwd_kernel, dim3(grid_for((size_t)N * T * D)), dim3(256), 0, (hipStream_t)stream, tok, tok_ld,
                        dx, drop, dE, N, T, D, sqrtf((float)D));
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_glu_fwd(const float *pre, const float *mask, const float *residual, float *out, int M, int R, void *stream) {
+    if (!pre || !out || M <= 0 || R <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(glu_fwd_kernel, dim3(grid_for((size_t)M * R)), dim3(256), 0, (hipStream_t)stream, pre, mask, residual, out,
+                       M, R);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_glu_bwd(const float *d_out, const float *mask, const float *pre, float *d_pre, int M, int R, void *stream) {
+    if (!d_out || !pre || !d_pre || M <= 0 || R <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for((size_t)M * R)), dim3(256), 0, (hipStream_t)stream, d_out, mask, pre, d_pre,
+                       M, R);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_meanpool_fwd(const float *x, const float *mask, float *mean, int B, int K, int D, void *stream) {
+    if (!x || !mean || B <= 0 || K <= 0 || D <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(meanpool_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, mask, mean, K, D);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_meanpool_bwd(const float *dmean, const float *mask, float *dx, int accumulate, int B, int K, int D, void *stream) {
+    if (!dmean || !dx || B <= 0 || K <= 0 || D <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(meanpool_bwd_kernel, dim3(grid_for((size_t)B * K * D)), dim3(256), 0, (hipStream_t)stream, dmean, mask, dx,
+                       accumulate, B, K, D);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

@@ -44,24 +44,33 @@ def layernorm_bwd(dy, x, a, mean, inv, dx_accum):
 
 
 def mha_fwd(q, k, v, ldkv, Nq, q_per_kv, Tq, Tk, h, mask=None, mask_tq=1, mask_per_q=0, causal=0, q_pos0=0, drop=None,
-            want_p=True):
+            want_p=True, kstride=0):
     D = q.shape[-1]
     o = torch.empty(Nq, Tq, D, dtype=_f32, device=q.device)
     p = torch.empty(Nq, h, Tq, Tk, dtype=_f32, device=q.device) if want_p else None
-    check(lib.capmi_mha_fwd(ptr(q), ptr(k), ptr(v), ldkv, ptr(mask), mask_tq, mask_per_q, causal, q_pos0, ptr(drop), ptr(o),
+    check(lib.capmi_mha_fwd(_a(q), _a(k), _a(v), ldkv, kstride, ptr(mask), mask_tq, mask_per_q, causal, q_pos0, ptr(drop), ptr(o),
                             ptr(p), Nq, q_per_kv, Tq, Tk, h, D // h, stream_ptr()), 'mha_fwd')
     return o, p
 
 
-def mha_bwd(d_o, q, k, v, ldkv, p, drop, Nq, q_per_kv, Tq, Tk, h):
+def _a(x):
+    """tensor or (tensor, element offset) -> device address"""
+    if isinstance(x, tuple):
+        return x[0].data_ptr() + 4 * x[1]
+    return None if x is None else x.data_ptr()
+
+
+def mha_bwd(d_o, q, k, v, ldkv, p, drop, Nq, q_per_kv, Tq, Tk, h, kstride=0, dk_out=None, dv_out=None, dkv_ld=0, dkv_stride=0,
+            accumulate=False):
     D = q.shape[-1]
     Nkv = Nq // q_per_kv
     dq = torch.empty(Nq, Tq, D, dtype=_f32, device=q.device)
-    dk = torch.empty(Nkv, Tk, D, dtype=_f32, device=q.device)
-    dv = torch.empty(Nkv, Tk, D, dtype=_f32, device=q.device)
-    check(lib.capmi_mha_bwd(ptr(d_o), ptr(q), ptr(k), ptr(v), ldkv, ptr(p), ptr(drop), ptr(dq), ptr(dk), ptr(dv), Nq,
-                            q_per_kv, Tq, Tk, h, D // h, stream_ptr()), 'mha_bwd')
-    return dq, dk, dv
+    if dk_out is None:
+        dk_out = torch.empty(Nkv, Tk, D, dtype=_f32, device=q.device)
+        dv_out = torch.empty(Nkv, Tk, D, dtype=_f32, device=q.device)
+    check(lib.capmi_mha_bwd(ptr(d_o), _a(q), _a(k), _a(v), ldkv, kstride, ptr(p), ptr(drop), ptr(dq), _a(dk_out), _a(dv_out),
+                            dkv_ld, dkv_stride, int(accumulate), Nq, q_per_kv, Tq, Tk, h, D // h, stream_ptr()), 'mha_bwd')
+    return dq, dk_out, dv_out
 
 
 class Lin:

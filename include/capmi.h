@@ -408,22 +408,32 @@ int capmi_layernorm_bwd(const float *dy, const float *x, const float *a, const f
  * per (key/value batch row, head).  q [Nq,Tq,D], k,v rows of pitch ldkv floats ([Nkv,Tk,D] or a KV cache
  * [Nkv,Lmax,D]), D = h*dk, heads interleaved along D exactly like `.view(N,-1,h,dk)`.  Query row r attends
  * key/value batch row r / q_per_kv (cross-attention over per-image memory: no repeat_tensors copy).
- * mask: uint8 [Nq or Nkv-broadcast, mask_tq (1 or Tq), Tk] (0 = -inf), or NULL; causal != 0 additionally
+ * kstride: floats between consecutive keys of one kv row (D for packed [Tk,D]; 2R when K and V are the two halves of
+ * AoA's p_att rows, AoAModel.py:168).  mask: uint8 [Nq or Nkv-broadcast, mask_tq (1 or Tq), Tk] (0 = -inf), or NULL; causal != 0 additionally
  * masks key j > query position (q_pos0 + i).  drop: optional pre-scaled keep mask [Nq,h,Tq,Tk] applied to the
  * probabilities.  Outputs o [Nq,Tq,D] and p [Nq,h,Tq,Tk] (softmax probabilities BEFORE dropout, saved). */
-int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, const uint8_t *mask, int mask_tq,
+int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, int kstride, const uint8_t *mask, int mask_tq,
                   int mask_per_q, int causal, int q_pos0, const float *drop, float *o, float *p, int Nq, int q_per_kv,
                   int Tq, int Tk, int h, int dk, void *stream);
-/* backward: d_o [Nq,Tq,D] -> dq [Nq,Tq,D], dk/dv [Nkv,Tk,D] (summed over the q_per_kv query rows of a kv row) */
-int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float *v, int ldkv, const float *p,
-                  const float *drop, float *dq, float *dk_out, float *dv_out, int Nq, int q_per_kv, int Tq, int Tk, int h,
-                  int dk, void *stream);
+/* backward: d_o [Nq,Tq,D] -> dq [Nq,Tq,D], dk/dv summed over the q_per_kv query rows of a kv row, written at
+ * out + kv_row*dkv_ld + key*dkv_stride (+= when accumulate: BPTT over time steps) */
+int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float *v, int ldkv, int kstride, const float *p,
+                  const float *drop, float *dq, float *dk_out, float *dv_out, int dkv_ld, int dkv_stride, int accumulate,
+                  int Nq, int q_per_kv, int Tq, int Tk, int h, int dk, void *stream);
 /* x[r,t,:] = E[tok[r,t]]*sqrt(D) + pe[pos0+t,:], then * drop (TransformerModel.py:215, 231-233) */
 int capmi_embed_pe_fwd(const int64_t *tok, int tok_ld, const float *E, const float *pe, const float *drop, float *x,
                        int N, int T, int D, int pos0, void *stream);
 /* dE[tok] += dx*drop*sqrt(D)  (caller zeroes dE) */
 int capmi_embed_pe_bwd(const int64_t *tok, int tok_ld, const float *dx, const float *drop, float *dE, int N, int T, int D,
                        void *stream);
+/* AoA / GLU blocks (AoAModel.py:44, 143): out = [residual +] mask * (pre[:, :R] * sigmoid(pre[:, R:2R])), pre [M,2R] */
+int capmi_glu_fwd(const float *pre, const float *mask, const float *residual, float *out, int M, int R, void *stream);
+/* d_pre [M,2R] from d_out [M,R] (mask applied first) */
+int capmi_glu_bwd(const float *d_out, const float *mask, const float *pre, float *d_pre, int M, int R, void *stream);
+/* masked mean over regions (AoAModel.py:214-219): mean[b,:] = sum_k m[b,k] x[b,k,:] / sum_k m[b,k] (m NULL = ones) */
+int capmi_meanpool_fwd(const float *x, const float *mask, float *mean, int B, int K, int D, void *stream);
+/* dx[b,k,:] (+)= m[b,k]/cnt * dmean[b,:] */
+int capmi_meanpool_bwd(const float *dmean, const float *mask, float *dx, int accumulate, int B, int K, int D, void *stream);
 /* out = log_softmax(logits) row-wise (Generator, TransformerModel.py:50-57) */
 int capmi_log_softmax_rows(const float *logits, float *out, int rows, int V1, void *stream);
 

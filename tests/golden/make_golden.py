@@ -220,8 +220,47 @@ def main_transformer():
     print('transformer_tiny.npz:', len(out), 'arrays')
 
 
+def main_aoa():
+    """AoANet fixture (reference AoAModel with the configs/aoa.yml switches at tiny size), eval mode so that the
+    hard-coded 0.1 dropouts (AoAModel.py:18,119) are off: teacher-forced log-probs, XE loss + gradients, greedy."""
+    sys.path.insert(0, REF)
+    import captioning.models as models
+    from captioning.modules import losses
+    z = np.load(os.path.join(HERE, 'updown_tiny.npz'))
+    torch.manual_seed(77)
+    opt = tiny_opt('aoa', drop=0.0)
+    opt.refine, opt.refine_aoa, opt.use_ff, opt.decoder_type, opt.use_multi_head = 1, 1, 0, 'AoA', 2
+    opt.num_heads, opt.multi_head_scale, opt.mean_feats, opt.ctx_drop, opt.dropout_aoa = 2, 1, 1, 1, 0.3
+    opt.num_layers = 2
+    model = models.setup(opt)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    fc, att, am = (torch.from_numpy(z[k]) for k in ('fc', 'att', 'att_masks'))
+    labels, masks = torch.from_numpy(z['labels']), torch.from_numpy(z['masks'])
+    out = {('P.' + k): v.detach().numpy() for k, v in model.state_dict().items()}
+    model.eval()
+    for tag, m in (('nomask', None), ('mask', am)):
+        model.zero_grad()
+        logp = model(fc, att, labels[..., :-1], m)
+        loss = losses.LanguageModelCriterion()(logp, labels[..., 1:], masks[..., 1:])
+        loss.backward()
+        out['xe_logp_' + tag] = logp.detach().numpy()
+        out['xe_loss_' + tag] = loss.detach().numpy()
+        for k, p in model.named_parameters():
+            out['xe_grad_%s.%s' % (tag, k)] = p.grad.detach().numpy().copy()
+        with torch.no_grad():
+            seq, slp = model(fc, att, m, opt={'sample_method': 'greedy', 'beam_size': 1}, mode='sample')
+        out['greedy_seq_' + tag] = seq.numpy()
+        out['greedy_logp_' + tag] = slp.numpy()
+    np.savez_compressed(os.path.join(HERE, 'aoa_tiny.npz'), **out)
+    print('aoa_tiny.npz:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'beam':
+    if len(sys.argv) > 1 and sys.argv[1] == 'aoa':
+        main_aoa()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'beam':
         main_beam()
     elif len(sys.argv) > 1 and sys.argv[1] == 'transformer':
         main_transformer()

@@ -242,3 +242,35 @@ def test_transformer_golden_xe_grads_and_greedy(tag):
         seq, slp = model(None, att, am, opt={'sample_method': 'greedy'}, mode='sample')
     assert np.array_equal(seq.cpu().numpy(), z['greedy_seq_' + tag])
     np.testing.assert_allclose(slp.cpu().numpy(), z['greedy_logp_' + tag], rtol=3e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('tag', ['nomask', 'mask'])
+def test_aoa_golden_xe_grads_and_greedy(tag):
+    """BASELINE configs[4] model family (AoANet, configs/aoa.yml switches) against the real reference's fixture."""
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import LanguageModelCriterion
+    z = np.load(os.path.join(GOLDEN, 'aoa_tiny.npz'))
+    u = np.load(os.path.join(GOLDEN, 'updown_tiny.npz'))
+    opt = tiny_opt(caption_model='aoa', refine=1, refine_aoa=1, use_ff=0, decoder_type='AoA', use_multi_head=2, num_heads=2,
+                   multi_head_scale=1, mean_feats=1, ctx_drop=1, dropout_aoa=0.3, num_layers=2)
+    model = models.setup(opt)
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('P.')}
+    assert set(sd.keys()) == set(model.state_dict().keys())
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    model.eval()                      # fixture was made in eval mode (hard-coded 0.1 dropouts of the reference off)
+    att = torch.from_numpy(u['att']).to(DEV)
+    am = torch.from_numpy(u['att_masks']).to(DEV) if tag == 'mask' else None
+    labels, masks = torch.from_numpy(u['labels']).to(DEV), torch.from_numpy(u['masks']).to(DEV)
+    logp = model(None, att, labels[..., :-1], am)
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), z['xe_logp_' + tag], rtol=3e-5, atol=1e-5)
+    loss = LanguageModelCriterion()(logp, labels[..., 1:], masks[..., 1:])
+    np.testing.assert_allclose(loss.item(), z['xe_loss_' + tag], rtol=1e-5)
+    loss.backward()
+    for k, p in model.named_parameters():
+        ref = z['xe_grad_%s.%s' % (tag, k)]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-3, atol=1e-6 + 5e-5 * np.abs(ref).max(), err_msg=k)
+    with torch.no_grad():
+        seq, slp = model(None, att, am, opt={'sample_method': 'greedy'}, mode='sample')
+    assert np.array_equal(seq.cpu().numpy(), z['greedy_seq_' + tag])
+    np.testing.assert_allclose(slp.cpu().numpy(), z['greedy_logp_' + tag], rtol=3e-5, atol=1e-5)

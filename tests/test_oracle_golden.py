@@ -131,3 +131,25 @@ def test_transformer_teacher_forced_loss_grads_and_greedy(tag):
         seq, slp = T.greedy(P, att, am, h=2, n_enc=2, n_dec=2, max_len=8)
     assert np.array_equal(seq.numpy(), z['greedy_seq_' + tag])
     np.testing.assert_allclose(slp.numpy(), z['greedy_logp_' + tag], rtol=1e-5, atol=3e-6)
+
+
+@pytest.mark.parametrize('tag', ['nomask', 'mask'])
+def test_aoa_teacher_forced_loss_grads_and_greedy(tag):
+    from oracle import aoa as A
+    z = np.load(os.path.join(GOLDEN, 'aoa_tiny.npz'))
+    u = np.load(os.path.join(GOLDEN, 'updown_tiny.npz'))
+    P = {k[2:]: torch.from_numpy(z[k]).requires_grad_(True) for k in z.files if k.startswith('P.')}
+    att = torch.from_numpy(u['att'])
+    am = torch.from_numpy(u['att_masks']) if tag == 'mask' else None
+    labels, masks = torch.from_numpy(u['labels']), torch.from_numpy(u['masks'])
+    logp = A.forward_teacher(P, att, labels[..., :-1], am, h=2)
+    np.testing.assert_allclose(logp.detach().numpy(), z['xe_logp_' + tag], rtol=1e-5, atol=3e-6)
+    loss = O.lm_criterion(logp, labels[..., 1:], masks[..., 1:])
+    np.testing.assert_allclose(loss.item(), z['xe_loss_' + tag], rtol=1e-6)
+    loss.backward()
+    for k, p in P.items():
+        np.testing.assert_allclose(p.grad.numpy(), z['xe_grad_%s.%s' % (tag, k)], rtol=3e-4, atol=3e-7, err_msg=k)
+    with torch.no_grad():
+        seq, slp = A.greedy(P, att, am, h=2, max_len=8)
+    assert np.array_equal(seq.numpy(), z['greedy_seq_' + tag])
+    np.testing.assert_allclose(slp.numpy(), z['greedy_logp_' + tag], rtol=1e-5, atol=3e-6)
