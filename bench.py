@@ -57,13 +57,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('--gpus %d needs torch.distributed.run with %d processes' % (args.gpus, args.gpus))
+    if os.environ.get('CAPMI_DIST_BACKEND') == 'gloo':
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)     # nccl == RCCL on ROCm (xGMI)
+        # nccl == RCCL on ROCm (xGMI).  CAPMI_DIST_BACKEND=gloo only exists to exercise the multi-process path on a
+        # single-GPU box (two ranks sharing cuda:0), never for measurements.
+        dist.init_process_group(os.environ.get('CAPMI_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
 
     from imagecaptioning.pytorch_amd import synthetic, _lib
     from imagecaptioning.pytorch_amd.captioning import models

@@ -57,8 +57,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
     float *__restrict__ ctx, float *__restrict__ alpha, int B, int n_img, int rpb, int chunks, int K, int A, int R,
     const int *__restrict__ row_img) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *s_h = lds;                    // [NMAX][A]
-    float *s_e = lds + (size_t)NMAX * A; // [NMAX][K]
+    const int AH = A > 1024 ? A : 1024;  // s_h doubles as the [NMAX][1024] combine buffer of the context phase
+    float *s_h = lds;                    // [NMAX][AH]
+    float *s_e = lds + (size_t)NMAX * AH; // [NMAX][K]
     int b, chunk, row0, n;
     if (row_img) {                       // ragged grouping: one row per workgroup, image from the map
         row0 = blockIdx.x;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
         f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
         if (v0) w0 = *reinterpret_cast<const f32x4 *>(w + a0);
         if (v1) w1 = *reinterpret_cast<const f32x4 *>(w + a1);
+#pragma unroll 1
         for (int base = 0; base < K; base += nw * SG) {   // block-uniform trip count (barrier inside)
             const int kb = base + wid;
             f32x4 p0[SG], p1[SG];
@@ -175,38 +177,60 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
     }
     __syncthreads();
 
-    // context: lane owns 2 columns, streams K rows of att[b], CG rows in flight
+    // context: 16-byte loads (8-byte accesses run at 0.54-0.70x the 16-byte rate on gfx950): the two halves of the
+    // workgroup take alternate regions for the same 4-column group, then combine through LDS.
     const float *ab = att + (size_t)b * K * R;
-    const bool vecR = (R % 2 == 0) && ((reinterpret_cast<uintptr_t>(att) & 7) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(ctx) & 7) == 0);
+    const bool vecR = (R % 4 == 0) && (R <= 1024) && ((reinterpret_cast<uintptr_t>(att) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(ctx) & 15) == 0);
     if (vecR) {
-        for (int r = threadIdx.x * 2; r < R; r += blockDim.x * 2) {
-            float a0[NMAX], a1[NMAX];
+        const int cg = threadIdx.x & 255, half = threadIdx.x >> 8;      // ATT_THREADS == 512
+        const int r = cg * 4;
+        float c0[NMAX], c1[NMAX], c2[NMAX], c3[NMAX];
 #pragma unroll
-            for (int j = 0; j < NMAX; ++j) a0[j] = a1[j] = 0.f;
-            for (int k0 = 0; k0 < K; k0 += CG) {
-                float2 v[CG];
-#pragma unroll
-                for (int g = 0; g < CG; ++g)
-                    v[g] = (k0 + g < K) ? *reinterpret_cast<const float2 *>(ab + (size_t)(k0 + g) * R + r)
-                                        : make_float2(0.f, 0.f);
-#pragma unroll
-                for (int g = 0; g < CG; ++g) {
-                    if (k0 + g < K) {
-#pragma unroll
-                        for (int j = 0; j < NMAX; ++j) {
-                            if (j < n) {
-                                const float al = s_e[j * K + k0 + g];
-                                a0[j] += al * v[g].x;
-                                a1[j] += al * v[g].y;
-                            }
-                        }
-                    }
-                }
+        for (int j = 0; j < NMAX; ++j) c0[j] = c1[j] = c2[j] = c3[j] = 0.f;
+        if (r < R) {
+            constexpr int CG4 = 6;               // 6 x 16 B in flight per lane
+#pragma unroll 1
+            for (int k0 = half; k0 < K; k0 += 2 * CG4) {
+                f32x4 v0, v1, v2, v3, v4, v5;
+                const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
+                v0 = (k0 + 0 < K) ? *reinterpret_cast<const f32x4 *>(ab + (size_t)(k0 + 0) * R + r) : zz;
+                v1 = (k0 + 2 < K) ? *reinterpret_cast<const f32x4 *>(ab + (size_t)(k0 + 2) * R + r) : zz;
+                v2 = (k0 + 4 < K) ? *reinterpret_cast<const f32x4 *>(ab + (size_t)(k0 + 4) * R + r) : zz;
+                v3 = (k0 + 6 < K) ? *reinterpret_cast<const f32x4 *>(ab + (size_t)(k0 + 6) * R + r) : zz;
+                v4 = (k0 + 8 < K) ? *reinterpret_cast<const f32x4 *>(ab + (size_t)(k0 + 8) * R + r) : zz;
+                v5 = (k0 + 10 < K) ? *reinterpret_cast<const f32x4 *>(ab + (size_t)(k0 + 10) * R + r) : zz;
+#define CAPMI_CTX_ACC(V, KK)                                                            \
+    if ((KK) < K) {                                                                     \
+        _Pragma("unroll") for (int j = 0; j < NMAX; ++j) {                              \
+            if (j < n) {                                                                \
+                const float al = s_e[j * K + (KK)];                                     \
+                c0[j] += al * V[0]; c1[j] += al * V[1]; c2[j] += al * V[2]; c3[j] += al * V[3]; \
+            }                                                                           \
+        }                                                                               \
+    }
+                CAPMI_CTX_ACC(v0, k0 + 0) CAPMI_CTX_ACC(v1, k0 + 2) CAPMI_CTX_ACC(v2, k0 + 4)
+                CAPMI_CTX_ACC(v3, k0 + 6) CAPMI_CTX_ACC(v4, k0 + 8) CAPMI_CTX_ACC(v5, k0 + 10)
+#undef CAPMI_CTX_ACC
             }
+        }
+        __syncthreads();                       // all reads of s_h done; reuse it as the combine buffer [NMAX][1024]
+        float *s_c = s_h;
+        if (half == 1 && r < R) {
 #pragma unroll
             for (int j = 0; j < NMAX; ++j)
-                if (j < n) *reinterpret_cast<float2 *>(ctx + (size_t)(row0 + j) * R + r) = make_float2(a0[j], a1[j]);
+                if (j < n) *reinterpret_cast<f32x4 *>(s_c + j * 1024 + r) = f32x4{c0[j], c1[j], c2[j], c3[j]};
+        }
+        __syncthreads();
+        if (half == 0 && r < R) {
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j) {
+                if (j < n) {
+                    const f32x4 o = *reinterpret_cast<const f32x4 *>(s_c + j * 1024 + r);
+                    *reinterpret_cast<f32x4 *>(ctx + (size_t)(row0 + j) * R + r) =
+                        f32x4{c0[j] + o[0], c1[j] + o[1], c2[j] + o[2], c3[j] + o[3]};
+                }
+            }
         }
     } else {
         for (int r = threadIdx.x; r < R; r += blockDim.x) {
@@ -427,7 +451,7 @@ int capmi_attention_fwd(const float *att_h, const float *p_att, const float *att
     if (!att_h || !p_att || !att || !w || !ctx || !alpha || B <= 0 || K <= 0 || A <= 0 || R <= 0) return CAPMI_EINVAL;
     if (row_img ? N <= 0 : n <= 0) return CAPMI_EINVAL;
     if (!row_img) N = B * n;
-    const size_t lds = ((size_t)NMAX * A + (size_t)NMAX * K) * sizeof(float);
+    const size_t lds = ((size_t)NMAX * (A > 1024 ? A : 1024) + (size_t)NMAX * K) * sizeof(float);
     if (lds > 64 * 1024) return CAPMI_EINVAL;
     // unique (algorithmic) bytes: image tiles once + per-row att_h in, ctx and alpha out
     const double abytes = 4.0 * ((double)B * K * (A + R) + (double)N * (A + R + K));

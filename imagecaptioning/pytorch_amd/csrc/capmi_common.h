@@ -54,18 +54,20 @@ __device__ __forceinline__ float block_max(float v, float *scratch) {
     return r;
 }
 
-// tanh / sigmoid with ~1 ulp-class building blocks (v_exp_f32 + IEEE divide).  Absolute error
-// ~1e-7, far inside the 1e-4 parity budget and below fp32 accumulation-order noise of the GEMMs.
+// tanh / sigmoid from 1-ulp hardware building blocks: v_exp_f32 and v_rcp_f32 (an IEEE divide expands to ~10
+// VALU instructions and made the attention score phase VALU-bound at XE sizes).  Absolute error ~2e-7, far inside
+// the 1e-4 parity budget and below the fp32 accumulation-order noise of the GEMMs.
+__device__ __forceinline__ float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float tanh_f(float x) {
     const float ax = fabsf(x);
     const float e = __expf(-2.0f * ax);           // in (0,1]
-    const float t = (1.0f - e) / (1.0f + e);
+    const float t = (1.0f - e) * rcp_f(1.0f + e);
     return copysignf(t, x);
 }
 __device__ __forceinline__ float sigmoid_f(float x) {
     // stable for both signs: 1/(1+exp(-x))
     const float e = __expf(-fabsf(x));
-    const float s = 1.0f / (1.0f + e);            // sigmoid(|x|)
+    const float s = rcp_f(1.0f + e);              // sigmoid(|x|)
     return x >= 0.f ? s : 1.0f - s;
 }
 

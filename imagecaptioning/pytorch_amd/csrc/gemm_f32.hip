@@ -418,6 +418,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     else if (d->M <= 64 || (long long)d->M * d->N < 256LL * 1024) {
         BM = 64;
         BN = (d->b_layout == 0 && tiles >= 64 && d->N >= 1024) ? 128 : 64;   // measured: wide tile only pays on long-K weight streams
+        if (env_cfg == 64 || env_cfg == 128) BN = env_cfg;                    // experiments: CAPMI_GEMM_CFG=64|128
     } else { BM = 128; BN = 128; }
     const int gm = (d->M + BM - 1) / BM, gn = (d->N + BN - 1) / BN;
     int splits = d->splits;
@@ -428,7 +429,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
         if (blocks < env_blocks * 3 / 4 && d->partial) {
             splits = (env_blocks + blocks - 1) / blocks;
             if (splits > tiles / 4) splits = tiles / 4;
-            if (splits > 32) splits = 32;
+            if (splits > 64) splits = 64;
             if (splits < 1) splits = 1;
             while (splits > 1 && (int64_t)splits * d->M * d->N > slab_cap) --splits;
         }

@@ -23,7 +23,7 @@ def timeit(fn, iters=50):
     return a.elapsed_time(b) / iters * 1e3
 
 
-ws = ops.Workspace(dev, 32 << 20)
+ws = ops.Workspace(dev, 64 << 20)
 h = torch.randn(M, R, device=dev)
 x = torch.randn(M, E, device=dev)
 W_ih = torch.randn(4 * R, 2 * R + E, device=dev) * 0.03
