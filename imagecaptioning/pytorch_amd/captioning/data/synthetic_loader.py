@@ -1,0 +1,57 @@
+"""Synthetic stand-in for captioning/data/dataloader.py (h5py / lmdbdict loaders are outside the hot path and not
+installable here).  It produces batches with EXACTLY the reference's batch-dict contract (dataloader.py:229-258):
+``fc_feats [B,F]``, ``att_feats [B,K,F]``, ``att_masks`` (None when all images have K regions, :240-241),
+``labels [B,n,L+2]`` int64 with BOS/EOS columns 0, ``masks [B,n,L+2]`` (nonzeros+2 ones, :245-249),
+``gts`` list of uint32 [n_ref,L], ``bounds``, ``infos``."""
+import numpy as np
+import torch
+
+from imagecaptioning.pytorch_amd import synthetic
+
+
+class SyntheticLoader:
+    def __init__(self, opt):
+        self.opt = opt
+        self.batch_size = opt.batch_size
+        self.seq_per_img = opt.seq_per_img
+        self.seq_length = opt.seq_length
+        self.vocab_size = opt.vocab_size
+        self.ix_to_word = {str(i): ('w%d' % i) for i in range(1, self.vocab_size)}
+        self.ix_to_word[str(self.vocab_size)] = 'UNK'
+        rng = np.random.default_rng(opt.seed)
+        n_img = opt.synthetic_images
+        self.refs = [synthetic.zipf_rows(rng, 5, self.seq_length, vocab=self.vocab_size) for _ in range(n_img)]
+        self.seeds = rng.integers(0, 2 ** 31, size=n_img)
+        self.pos = {'train': 0, 'val': 0, 'test': 0}
+        self.epoch_wrapped = False
+
+    def get_vocab(self):
+        return self.ix_to_word
+
+    def document_frequency(self):
+        return synthetic.document_frequency(self.refs)
+
+    def get_batch(self, split, batch_size=None):
+        B = batch_size or self.batch_size
+        n, L, opt = self.seq_per_img, self.seq_length, self.opt
+        idx = [(self.pos[split] + i) % len(self.refs) for i in range(B)]
+        wrapped = self.pos[split] + B >= len(self.refs)
+        self.pos[split] = (self.pos[split] + B) % len(self.refs)
+        fc = np.zeros((B, opt.fc_feat_size), dtype=np.float32)
+        att = np.zeros((B, opt.synthetic_regions, opt.att_feat_size), dtype=np.float32)
+        labels = np.zeros((B, n, L + 2), dtype=np.int64)
+        masks = np.zeros((B, n, L + 2), dtype=np.float32)
+        gts, infos = [], []
+        for b, ix in enumerate(idx):
+            g = np.random.default_rng(int(self.seeds[ix]))
+            att[b] = np.clip(g.standard_normal(att[b].shape) * 0.5, 0, None)
+            fc[b] = att[b].mean(0)
+            rows = self.refs[ix][g.integers(0, 5, size=n)]
+            labels[b, :, 1:L + 1] = rows
+            for j in range(n):
+                masks[b, j, :int((rows[j] > 0).sum()) + 2] = 1
+            gts.append(self.refs[ix])
+            infos.append({'ix': ix, 'id': ix, 'file_path': 'synthetic/%d' % ix})
+        return {'fc_feats': torch.from_numpy(fc), 'att_feats': torch.from_numpy(att), 'att_masks': None,
+                'labels': torch.from_numpy(labels), 'masks': torch.from_numpy(masks), 'gts': gts,
+                'bounds': {'it_pos_now': self.pos[split], 'it_max': len(self.refs), 'wrapped': wrapped}, 'infos': infos}

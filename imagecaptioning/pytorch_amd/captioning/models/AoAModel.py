@@ -8,8 +8,8 @@ import torch.nn as nn
 
 from .CaptionModel import CaptionModel
 from .TransformerModel import _LayerNorm, _Sublayer, _clones
-from ... import aoa_engine as engine
-from ..._lib import CapmiError
+from imagecaptioning.pytorch_amd import aoa_engine as engine
+from imagecaptioning.pytorch_amd._lib import CapmiError
 
 
 class _MHDot(nn.Module):
@@ -101,7 +101,7 @@ class AoAModel(CaptionModel):
         return [n for n, _ in self.named_parameters()]
 
     def flatten_parameters_(self):
-        from ...flat import FlatParams
+        from imagecaptioning.pytorch_amd.flat import FlatParams
         self._flat = FlatParams(self)
         return self._flat
 

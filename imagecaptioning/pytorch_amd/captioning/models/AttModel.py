@@ -18,9 +18,9 @@ import torch
 import torch.nn as nn
 
 from .CaptionModel import CaptionModel
-from ... import updown_engine as engine
-from ... import ops
-from ..._lib import CapmiError
+from imagecaptioning.pytorch_amd import updown_engine as engine
+from imagecaptioning.pytorch_amd import ops
+from imagecaptioning.pytorch_amd._lib import CapmiError
 
 bad_endings = ['a', 'an', 'the', 'in', 'for', 'at', 'of', 'with', 'before', 'after', 'on', 'upon', 'near', 'to', 'is',
                'are', 'am', 'the']
@@ -127,7 +127,7 @@ class AttModel(CaptionModel):
 
     def flatten_parameters_(self):
         """Move all parameters into one flat buffer (+ flat grads, Adam state).  Call after .cuda()."""
-        from ...flat import FlatParams
+        from imagecaptioning.pytorch_amd.flat import FlatParams
         self._flat = FlatParams(self)
         return self._flat
 
@@ -268,12 +268,12 @@ class AttModel(CaptionModel):
         return seq[N:], seq[:N], logp[:N]
 
     def _sample_beam(self, fc_feats, att_feats, att_masks=None, opt={}):
-        from ...beam import sample_beam
+        from imagecaptioning.pytorch_amd.beam import sample_beam
         return sample_beam(self, fc_feats, att_feats, att_masks, opt)
 
     def get_logprobs_state(self, it, fc_feats, att_feats, p_att_feats, att_masks, state, output_logsoftmax=1):
         """One decoder step on already prepared features (AttModel.py:166-176); used by beam search."""
-        from ...step import updown_step
+        from imagecaptioning.pytorch_amd.step import updown_step
         return updown_step(self, it, fc_feats, att_feats, p_att_feats, att_masks, state, output_logsoftmax)
 
 

@@ -5,9 +5,9 @@ import torch
 import torch.nn as nn
 
 from .CaptionModel import CaptionModel
-from ... import newfc_engine as engine
-from ... import ops
-from ..._lib import CapmiError
+from imagecaptioning.pytorch_amd import newfc_engine as engine
+from imagecaptioning.pytorch_amd import ops
+from imagecaptioning.pytorch_amd._lib import CapmiError
 
 
 class LSTMCore(nn.Module):
@@ -61,7 +61,7 @@ class NewFCModel(CaptionModel):
         return [n for n, _ in self.named_parameters()]
 
     def flatten_parameters_(self):
-        from ...flat import FlatParams
+        from imagecaptioning.pytorch_amd.flat import FlatParams
         self._flat = FlatParams(self)
         return self._flat
 

@@ -8,8 +8,8 @@ import torch
 import torch.nn as nn
 
 from .CaptionModel import CaptionModel
-from ... import transformer_engine as engine
-from ..._lib import CapmiError
+from imagecaptioning.pytorch_amd import transformer_engine as engine
+from imagecaptioning.pytorch_amd._lib import CapmiError
 
 
 def _clones(m, n):
@@ -157,7 +157,7 @@ class TransformerModel(CaptionModel):
         return {k: torch.empty_like(v) for k, v in P.items() if k != 'model.tgt_embed.1.pe'}
 
     def flatten_parameters_(self):
-        from ...flat import FlatParams
+        from imagecaptioning.pytorch_amd.flat import FlatParams
         self._flat = FlatParams(self)
         return self._flat
 

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import torch
 
-from ...ciderd import DeviceCiderD
+from imagecaptioning.pytorch_amd.ciderd import DeviceCiderD
 
 CiderD_scorer = None
 _ref_cache = {}

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Training entrypoint on the MI355X backend -- the control flow of the reference's tools/train.py:32-292 for the
+hot path: XE / self-critical / new-self-critical scheduling (:144-161), LossWrapper call (:185), backward, value
+clip + Adam (:193-196), `time/batch` print (:198-208), periodic checkpoint (:279-285), one flat-gradient RCCL
+all-reduce per step when launched with torch.distributed.run.
+
+    python -m imagecaptioning.pytorch_amd.tools.train --caption_model updown --rnn_size 1000 --input_encoding_size 1000 \
+        --self_critical_after 0 --train_sample_n 5 --max_iters 50
+    python -m imagecaptioning.pytorch_amd.tools.train --cfg /path/to/reference/configs/updown/updown.yml --max_iters 20
+"""
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))           # so that `captioning` resolves to the mirror package
+
+
+def train(opt):
+    import torch.distributed as dist
+    from captioning import models
+    from captioning.data.synthetic_loader import SyntheticLoader
+    from captioning.modules.loss_wrapper import LossWrapper
+    from captioning.utils import rewards, misc
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    if not opt.input_synthetic:
+        raise SystemExit('only --input_synthetic 1 is available: the h5/lmdb loaders of the reference are outside the hot path')
+    opt.seed = opt.seed + rank                        # each rank draws its own images
+    loader = SyntheticLoader(opt)
+    opt.vocab = loader.get_vocab()
+    torch.manual_seed(1234)                           # identical weights on every rank
+    model = models.setup(opt).to(dev)
+    if opt.start_from:
+        model.load_state_dict(torch.load(os.path.join(opt.start_from, 'model.pth'), map_location=dev))
+    flat = model.flatten_parameters_()
+    lw_model = LossWrapper(model, opt)
+    model.train()
+    sc_ready = False
+    it, epoch = 0, 0
+    while it < opt.max_iters:
+        sc_flag = opt.self_critical_after != -1 and epoch >= opt.self_critical_after
+        struc_flag = opt.structure_after != -1 and epoch >= opt.structure_after
+        if (sc_flag or struc_flag) and not sc_ready:
+            rewards.init_scorer(loader.document_frequency(), device=dev)     # train.py:152,159 init_scorer(cached_tokens)
+            sc_ready = True
+        t0 = time.time()
+        data = loader.get_batch('train')
+        fc, att, labels, masks = (data[k].to(dev) for k in ('fc_feats', 'att_feats', 'labels', 'masks'))
+        att_masks = None if data['att_masks'] is None else data['att_masks'].to(dev)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        out = lw_model(fc, att, labels, masks, att_masks, data['gts'], torch.arange(len(data['gts'])), sc_flag, struc_flag, False)
+        loss = out['loss'].mean()
+        flat.zero_grad()
+        loss.backward()
+        flat.collect_grads()
+        scale = flat.all_reduce() if world > 1 else 1.0
+        flat.adam_step(opt.learning_rate, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
+                       clip_value=opt.grad_clip_value if opt.grad_clip_mode == 'value' else 0.0, grad_scale=scale)
+        train_loss = loss.item()
+        torch.cuda.synchronize()
+        t2 = time.time()
+        if rank == 0 and it % opt.losses_log_every == 0:
+            if struc_flag:
+                print('iter %d (epoch %d), train_loss = %.3f, lm_loss = %.3f, struc_loss = %.3f, time/batch = %.3f'
+                      % (it, epoch, train_loss, out['lm_loss'].mean().item(), out['struc_loss'].mean().item(), t2 - t1))
+            elif not sc_flag:
+                print('iter %d (epoch %d), train_loss = %.3f, time/batch = %.3f' % (it, epoch, train_loss, t2 - t1))
+            else:
+                print('iter %d (epoch %d), avg_reward = %.3f, time/batch = %.3f' % (it, epoch, out['reward'].mean().item(), t2 - t1))
+            print('Read data:', t1 - t0)
+        it += 1
+        if data['bounds']['wrapped']:
+            epoch += 1
+        if rank == 0 and opt.save_checkpoint_every and it % opt.save_checkpoint_every == 0:
+            misc.save_checkpoint(opt, model, {'iter': it, 'epoch': epoch, 'opt': opt, 'vocab': opt.vocab})
+    if rank == 0 and opt.save_checkpoint_every:
+        misc.save_checkpoint(opt, model, {'iter': it, 'epoch': epoch, 'opt': opt, 'vocab': opt.vocab})
+    if world > 1:
+        dist.destroy_process_group()
+    return train_loss
+
+
+if __name__ == '__main__':
+    from captioning.utils import opts
+    train(opts.parse_opt())
