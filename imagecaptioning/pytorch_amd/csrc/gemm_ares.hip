@@ -1,0 +1,286 @@
+// "A-resident" skinny fp32 MFMA GEMM for gfx950: C[M<=64, N] = sum_s A_s[M,K_s] * op(B_s), the decode-step
+// shape (60 caption rows against 12-64 MB of weights).
+//
+// Why: the LDS-tiled kernel (gemm_f32.hip) spends a barrier pair, an LDS write pass and an LDS read pass on the
+// WEIGHT tile of every 32-wide K step although each weight element is used by exactly one wave, and its MFMA
+// phase never overlaps its loads (ablation: memory-only 15 us, MFMA-only 22 us, both 28 us for the 48 MB gate
+// GEMM whose co-limit is ~12 us).  Here
+//  * a workgroup (8 waves) owns ONE K slice of the activations for all 64 rows and keeps it RESIDENT in LDS
+//    (<= 145 KB of the CU's 160 KB: 64 x (18*32 + 4) floats), staged once, read with conflict-free ds_read_b128;
+//  * weights never touch LDS: each wave streams its own 32 output columns x half of the slice's K chunks straight
+//    into VGPRs, 3 chunks (12 x 16 B per lane) in flight, so the main loop has NO barrier and the only LDS
+//    traffic is the A operand; the two K halves of a column group sit on the same SIMD and hide each other's
+//    waits, and meet through LDS at the end (half the slabs of a pure split-K);
+//  * the MFMA k index is a free permutation: lane (l&31, l>>5) takes k = 16*(l>>5) + 4q + e of each 32-wide
+//    chunk, i.e. 64 contiguous bytes of its weight row per chunk ([N][K] weights), or 16 coalesced 128-byte
+//    rows per half-wave ([K][N] weights of dX = dG W);
+//  * 2 independent accumulator chains per wave (rows 0-31 / 32-63) keep the matrix pipe issuing back to back;
+//  * the grid is (N/128 column blocks) x (K slices) ~ 256 workgroups = one per CU; K slices leave as slabs for the
+//    fused consumer / reduce kernel exactly like the tiled kernel.
+#include "gemm_common.h"
+#include "profile.h"
+#include <hip/hip_ext.h>
+
+namespace capmi_gemm {
+namespace {
+
+constexpr int AR_BN = 128;        // 4 waves x 32 columns
+#ifndef CAPMI_AR_PF
+#define CAPMI_AR_PF 3
+#endif
+constexpr int AR_PF = CAPMI_AR_PF;          // weight chunks in flight per wave
+constexpr int AR_TSMAX = 9;       // K chunks (of 32) per wave; the 2*9-chunk slice of 64 rows is 145 KB of LDS
+constexpr int AR_NT = 512;        // 8 waves: 4 column groups x 2 K halves
+
+// One 32-wide K chunk of the slice, resolved once per workgroup into LDS so neither the staging loop nor the
+// weight stream indexes the kernel-argument segment table per lane (that became dependent global loads).
+struct TileRef {
+    const float *A, *B;     // segment base + k0 (A: column offset; B: column offset [N][K] / row offset [K][N])
+    int lda, ldb;
+    int rdiv;               // ceil(65536 / a_row_div): row / a_row_div == (row * rdiv) >> 16 for row < 64
+    int arem;               // activations valid for k < arem within the chunk (<= 0: padding slot, all zero)
+    int brem;               // weights: K_s - k0 (>= 4), offsets clamp to brem - 4 / brem - 1
+};
+
+// pointers that round-trip through LDS lose their address space; without this the loads become flat_load (which
+// also ticks lgkmcnt and forces vmcnt(0)/lgkmcnt(0) pairs)
+typedef const float __attribute__((address_space(1))) *gcf;
+typedef const f32x4 __attribute__((address_space(1))) *gcf4;
+__device__ __forceinline__ gcf as_global(const float *p) { return (gcf)(uintptr_t)p; }
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const float *uni(const float *p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<const float *>(((uint64_t)hi << 32) | lo);
+}
+
+// Branch-free weight fetch of one 32-wide K chunk for this lane: always exactly 4 x 16-byte (or 16 x 4-byte) loads,
+// out-of-range rows / k clamped to valid memory.  Static load counts keep the compiler's s_waitcnt vmcnt(n) precise:
+// with guarded loads every wait degenerated to vmcnt(0) and the prefetch ring was serialised (43 us for 48 MB).
+// Clamped k positions meet a ZERO activation in LDS, clamped columns are never stored.
+template <bool BKC>
+__device__ __forceinline__ void load_b(float (&b)[16], const TileRef *tp, int colc, int half) {
+    const float *B = uni(tp->B);
+    const int ldb = uni(tp->ldb), brem = uni(tp->brem);
+    if (BKC) {
+        gcf p = as_global(B) + (size_t)colc * ldb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kk = min(16 * half + 4 * q, brem - 4);
+            const f32x4 v = *(gcf4)(p + kk);
+            b[4 * q] = v[0]; b[4 * q + 1] = v[1]; b[4 * q + 2] = v[2]; b[4 * q + 3] = v[3];
+        }
+    } else {
+        gcf p = as_global(B) + colc;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) b[j] = p[(size_t)min(16 * half + j, brem - 1) * ldb];
+    }
+}
+
+// TM = 1: M <= 32 (one accumulator chain, 32 staged rows); TM = 2: M <= 64
+template <bool BKC, int TS, int TM>
+__global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
+    constexpr int ROWS = 32 * TM;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int SL = 2 * TS;                  // K chunks per workgroup slice: waves 0-3 take [0,TS), waves 4-7 [TS,2TS)
+    constexpr int pitch = SL * 32 + 4;
+    float *As = lds;                                            // [ROWS][pitch]
+    TileRef *tiles = reinterpret_cast<TileRef *>(lds + ROWS * pitch);   // [SL]
+    const int n0 = blockIdx.x * AR_BN, z = blockIdx.y;
+    const int t0 = z * SL;          // every slice runs exactly SL chunks; slots past the last K tile are zero padded
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int cg = wid & 3, kh = wid >> 2;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int col = n0 + 32 * cg + l31;
+    const int colc = min(col, a.N - 1);
+
+    if (threadIdx.x < SL) {
+        int s = 0, k0 = 0;
+        const bool real = t0 + (int)threadIdx.x < a.tiles_total;
+        if (real) locate(a, t0 + threadIdx.x, s, k0);
+        TileRef t;
+        // per-lane dynamic segment index resolved with selects over the (<= 4) segments
+        const float *sA = a.seg[0].A, *sB = a.seg[0].B;
+        int lda = a.seg[0].lda, ldb = a.seg[0].ldb, K = a.seg[0].K, div = a.seg[0].a_row_div;
+#pragma unroll
+        for (int i = 1; i < CAPMI_MAX_SEG; ++i)
+            if (s == i) { sA = a.seg[i].A; sB = a.seg[i].B; lda = a.seg[i].lda; ldb = a.seg[i].ldb; K = a.seg[i].K; div = a.seg[i].a_row_div; }
+        t.A = sA + k0;
+        t.B = BKC ? sB + k0 : sB + (size_t)k0 * ldb;
+        t.lda = lda; t.ldb = ldb;
+        t.arem = real ? K - k0 : 0;
+        t.brem = K - k0;
+        t.rdiv = (65536 + div - 1) / div;
+        tiles[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const TileRef *mine = tiles + kh * TS;
+
+    // weight prefetch ring first: HBM latency overlaps the activation staging below
+    constexpr int PF = AR_PF < TS ? AR_PF : TS;
+    float b[PF + 1][16];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) load_b<BKC>(b[u], &mine[u], colc, half);
+
+    // stage the activation slice: 64 rows x SL*32 k in 16-byte pieces (rows >= M and k >= K_s zero filled): SL pieces
+    // per thread, every load issued before the first LDS store = one L2 round trip for the whole slice.
+    constexpr int quads = SL * 8;               // ROWS * quads pieces / 512 threads = TS * TM per thread
+    constexpr int NP = TS * TM;
+    {
+        f32x4 v[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int idx = j * AR_NT + (int)threadIdx.x;
+            const int row = idx / quads, c4 = idx - row * quads;
+            const TileRef *tp = &tiles[c4 >> 3];
+            const int k = (c4 & 7) * 4;
+            const bool ok = row < a.M && k < tp->arem;
+            gcf p = as_global(tp->A) + (ok ? (size_t)((row * tp->rdiv) >> 16) * tp->lda + k : 0);
+            v[j] = *(gcf4)p;
+            const float keep = ok ? 1.f : 0.f;     // multiply (not select) so the load stays unconditional
+            v[j] *= keep;
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int idx = j * AR_NT + (int)threadIdx.x;
+            const int row = idx / quads, c4 = idx - row * quads;
+            *reinterpret_cast<f32x4 *>(As + row * pitch + c4 * 4) = v[j];
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    const float *a_lo = As + l31 * pitch + 16 * half + kh * TS * 32;
+    const float *a_hi = a_lo + 32 * pitch;
+
+    auto mma = [&](const float (&bb)[16], int c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4 *>(a_lo + c * 32 + 4 * q);
+            f32x4 x1 = x0;
+            if (TM == 2) x1 = *reinterpret_cast<const f32x4 *>(a_hi + c * 32 + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], bb[4 * q + e], acc0, 0, 0, 0);
+                if (TM == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], bb[4 * q + e], acc1, 0, 0, 0);
+            }
+        }
+    };
+    // fully unrolled ring of PF + 1 slots: chunk c's MFMAs read slot c % (PF+1) while the slot chunk c-1 just
+    // released is refilled with chunk c + PF.  Straight-line code with static load counts keeps s_waitcnt vmcnt(n)
+    // exact (inside a loop the compiler parked a vmcnt(0) at the loop head); the sched_barriers stop the machine
+    // scheduler from sinking each refill down to its consumer (which exposed the full HBM latency).
+#pragma unroll
+    for (int c = 0; c < TS; ++c) {
+        if (c + PF < TS) load_b<BKC>(b[(c + PF) % (PF + 1)], &mine[c + PF], colc, half);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(b[c % (PF + 1)], c);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // K halves meet in LDS (the activation slice is dead): waves 4-7 park their 64x32 sums, waves 0-3 add and store.
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    constexpr int RP = AR_BN + 4;
+    __syncthreads();
+    float *red = lds;                                           // [64][RP]
+    if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[row * RP + 32 * cg + l31] = acc0[r];
+            if (TM == 2) red[(32 + row) * RP + 32 * cg + l31] = acc1[r];
+        }
+    }
+    __syncthreads();
+    if (kh == 1 || col >= a.N) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        acc0[r] += red[row * RP + 32 * cg + l31];
+        if (TM == 2) acc1[r] += red[(32 + row) * RP + 32 * cg + l31];
+    }
+    if (a.to_partial) {
+        float *out = a.partial + (size_t)z * a.M * a.N + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row < a.M) out[(size_t)row * a.N] = acc0[r];
+            if (TM == 2 && row + 32 < a.M) out[(size_t)(row + 32) * a.N] = acc1[r];
+        }
+        return;
+    }
+    float cb = 0.f;
+    if (a.bias) cb += a.bias[col];
+    if (a.bias2) cb += a.bias2[col];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row >= a.M) continue;
+            float v = (i == 0 ? acc0[r] : acc1[r]) + cb;
+            if (a.row_bias) v += a.row_bias[(size_t)(row / a.row_bias_div) * a.N + col];
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.mul_mask) v *= a.mul_mask[(size_t)row * a.N + col];
+            if (a.accumulate) v += a.C[(size_t)row * a.ldc + col];
+            a.C[(size_t)row * a.ldc + col] = v;
+        }
+    }
+}
+
+}  // namespace
+
+// plan: K chunks per wave (1..AR_TSMAX); a workgroup slice is 2 of those; *splits slices cover `tiles`
+int ares_plan(int N, int tiles, int want_blocks, int *splits) {
+    const int nblk = (N + AR_BN - 1) / AR_BN;
+    int s = want_blocks / nblk;
+    if (s < 1) s = 1;
+    if (s > tiles) s = tiles;
+    int ts = ((tiles + s - 1) / s + 1) / 2;
+    if (ts < 1) ts = 1;
+    if (ts > AR_TSMAX) ts = AR_TSMAX;
+    *splits = (tiles + 2 * ts - 1) / (2 * ts);
+    return ts;
+}
+
+template <bool BKC, int TS, int TM>
+static int launch_ts(const KArgs &a, hipStream_t st, int pcls, double bytes, double flops) {
+    static bool attr_set = false;
+    constexpr size_t slice = ((size_t)32 * TM * (2 * TS * 32 + 4)) * sizeof(float) + (size_t)2 * TS * sizeof(TileRef);
+    constexpr size_t red = (size_t)32 * TM * (AR_BN + 4) * sizeof(float);
+    constexpr size_t lds = slice > red ? slice : red;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_ares_kernel<BKC, TS, TM>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid((a.N + AR_BN - 1) / AR_BN, a.splits);
+    hipEvent_t e0, e1;
+    const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
+    if (prof) hipExtLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM>), grid, dim3(AR_NT), lds, st, e0, e1, 0, a);
+    else hipLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM>), grid, dim3(AR_NT), lds, st, a);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+template <bool BKC>
+static int launch_layout(const KArgs &a, int ts, hipStream_t st, int pcls, double bytes, double flops) {
+    switch (ts) {
+#define CAPMI_TS(T) case T: return a.M <= 32 ? launch_ts<BKC, T, 1>(a, st, pcls, bytes, flops) : launch_ts<BKC, T, 2>(a, st, pcls, bytes, flops);
+        CAPMI_TS(1) CAPMI_TS(2) CAPMI_TS(3) CAPMI_TS(4) CAPMI_TS(5) CAPMI_TS(6) CAPMI_TS(7) CAPMI_TS(8) CAPMI_TS(9)
+#undef CAPMI_TS
+    }
+    return CAPMI_EINVAL;
+}
+
+// a.splits * 2 * ts must cover a.tiles_total
+int launch_ares(const KArgs &a, int b_layout, int ts, hipStream_t st, int pcls, double bytes, double flops) {
+    if (ts < 1 || ts > AR_TSMAX || (long long)a.splits * 2 * ts < a.tiles_total) return CAPMI_EINVAL;
+    return b_layout == 0 ? launch_layout<true>(a, ts, st, pcls, bytes, flops)
+                         : launch_layout<false>(a, ts, st, pcls, bytes, flops);
+}
+
+}  // namespace capmi_gemm

@@ -58,4 +58,8 @@ __device__ __forceinline__ void locate(const KArgs &a, int tile, int &s, int &k0
 // skinny (M <= 64, A stored [M][K]) direct-to-register path; defined in gemm_skinny.hip
 int launch_skinny(const KArgs &a, int b_layout, int tm, dim3 grid, hipStream_t st);
 
+// A-resident skinny path (M <= 64, A stored [M][K]); defined in gemm_ares.hip
+int ares_plan(int N, int tiles, int want_blocks, int *splits);
+int launch_ares(const KArgs &a, int b_layout, int ts_max, hipStream_t st, int pcls, double bytes, double flops);
+
 }  // namespace capmi_gemm

@@ -409,6 +409,30 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
         return launch_skinny(a, d->b_layout, tm, dim3(gn, gm, splits), st);
     }
 
+    bool ares_ok = d->a_layout == 0 && d->M <= 64 && BK == 32;
+    for (int s = 0; s < d->nseg && ares_ok; ++s)     // branch-free 16-byte operand fetch: aligned, K % 4 == 0
+        ares_ok = a.seg[s].vecA && (a.seg[s].K % 4 == 0) && (d->b_layout == 1 || a.seg[s].vecB);
+    if ((env_path == 2 || env_path == 0) && ares_ok) {     // CAPMI_GEMM_PATH=3 forces the LDS-tiled kernel
+        // ---- A-resident path (gemm_ares.hip): activations stay in LDS, weights stream straight to VGPRs ----
+        static const int env_ab = [] { const char *e = getenv("CAPMI_ARES_BLOCKS"); return e ? atoi(e) : 256; }();
+        int splits = 0;
+        int ts_max = ares_plan(d->N, tiles, d->splits > 0 ? ((d->N + 127) / 128) * d->splits : env_ab, &splits);
+        if ((splits > 1 || d->defer_reduce) && (int64_t)splits * d->M * d->N > slab_cap) ts_max = 99;   // slabs do not fit
+        if (ts_max <= 9) {
+            a.splits = splits;
+            a.to_partial = (splits > 1 || d->defer_reduce) ? 1 : 0;
+            a.self_reduce = 0;
+            if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > slab_cap)) return CAPMI_EINVAL;
+            d->splits_used = splits;
+            int rc = launch_ares(a, d->b_layout, ts_max, st, pcls, bytes, flops);
+            if (rc) return rc;
+            if (splits > 1 && !d->defer_reduce)
+                return capmi_splitk_reduce(a.partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,
+                                           a.row_bias_div, d->mul_mask, d->relu, d->accumulate, stream);
+            return 0;
+        }
+    }
+
     // tile shape by M: decode batches are skinny.  Every configuration gives each wave >= 2 independent
     // accumulator chains (a lone dependent v_mfma_f32_32x32x2 chain loses ~40 % to issue gaps).
     static const int env_cfg = [] { const char *e = getenv("CAPMI_GEMM_CFG"); return e ? atoi(e) : 1; }();

@@ -60,7 +60,7 @@ def test_gemm_multisegment_rowdiv_and_deferred_partials(dev):
     segs = [(d(h), R, Wd, 2 * R + E, R, 1), (d(fc), R, (Wd, R), 2 * R + E, R, n), (d(x), E, (Wd, 2 * R), 2 * R + E, E, 1),
             (d(hp), R, Whd, R, R, 1)]
     splits = ops.gemm(segs, N, 4 * R, ws.buf, ws=ws, splits=3, defer_reduce=True)
-    assert splits == 3
+    assert 1 <= splits <= 3      # the library reports how many K-slice slabs it actually wrote
     hh, cc, gates, _ = ops.lstm_cell_fwd(ws.slabs, splits, d(b_ih), d(b_hh), d(cp))
     assert rel_err(hh, h_ref) < 2e-6 and rel_err(cc, c_ref) < 2e-6
 
