@@ -30,6 +30,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA (v_mfma_f32_32x32x2_f32), 155 TF measured
+
+
+def pmc_traffic():
+    """HBM bytes per decode-GEMM launch from the PMC passes of this same command (FETCH_SIZE and WRITE_SIZE need
+    separate rocprofv3 --pmc runs, so they cannot be sampled inside this process): profiles/r01_pmc_traffic.json,
+    written by tools_pmc_traffic.py with the gfx950 corrections of MI355X_MICROARCH.md.  None if absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            return round(json.load(f)['decode_gemm']['traffic_bytes'])
+    except (OSError, KeyError, ValueError):
+        return None
 F32_MFMA_PEAK_TF = 157.3
 
 
@@ -131,11 +144,23 @@ def main():
                      'attention_fwd': {'ms_per_step': round(a_ms / args.steps, 4), 'launches_per_step': a_n / args.steps},
                      'note': 'full per-kernel table: profiles/r01*_scst_kernel_stats.md (rocprofv3 --kernel-trace --stats)'}
         ach = (g_bytes / g_n) / (g_ms / g_n * 1e-3) / 1e9 if g_n else 0.0
-        roofline = {'kernel': 'gemm_f32 (decode-step weight streaming, M<=64, v_mfma_f32_32x32x2_f32)', 'bound': 'hbm',
-                    'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                    'traffic': None, 'avg_launch_us': round(g_ms / max(g_n, 1) * 1e3, 2),
+        tfl = g_flops / (g_ms * 1e-3) / 1e12 if g_ms else 0.0
+        # which roof bounds this launch mix: fp32 MFMA runs at 1/16 of the bf16 rate (157.3 TFLOP/s dense), so at
+        # 60 caption rows the weight stream's 30 flop/byte is already above the 19.7 flop/byte machine balance
+        ai = g_flops / g_bytes if g_bytes else 0.0
+        mfma_bound = ai > MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        roofline = {'kernel': 'gemm_ares (decode-step weight streaming, M<=64, activations resident in LDS, '
+                              'v_mfma_f32_32x32x2_f32)',
+                    'bound': 'mfma' if mfma_bound else 'hbm',
+                    'achieved': round(tfl if mfma_bound else ach, 2),
+                    'peak': MFMA_F32_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
+                    'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
+                    'frac': round(tfl / MFMA_F32_PEAK_TFLOPS if mfma_bound else ach / HBM_PEAK_GBS, 4),
+                    'traffic': pmc_traffic(), 'avg_launch_us': round(g_ms / max(g_n, 1) * 1e3, 2),
                     'algorithmic_bytes_per_launch': round(g_bytes / max(g_n, 1)),
-                    'mfma_tflops': round(g_flops / (g_ms * 1e-3) / 1e12, 2) if g_ms else 0.0}
+                    'algorithmic_flops_per_launch': round(g_flops / max(g_n, 1)),
+                    'flop_per_byte': round(ai, 2), 'hbm_gbs': round(ach, 1), 'hbm_frac': round(ach / HBM_PEAK_GBS, 4),
+                    'mfma_tflops': round(tfl, 2), 'mfma_frac': round(tfl / MFMA_F32_PEAK_TFLOPS, 4)}
         a_ach = (a_bytes / a_n) / (a_ms / a_n * 1e-3) / 1e9 if a_n else 0.0
         attention = {'kernel': 'attention_fwd (fused score+softmax+context, one workgroup per image)', 'bound': 'hbm',
                      'achieved': round(a_ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -61,7 +61,12 @@ class _Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, _gs, g_logp):
+        flat = ctx.model._flat
+        stash = flat.begin_backward() if flat is not None else None
         ctx.g.backward(g_logp)
+        if flat is not None:
+            flat.end_backward(stash)
+            return (None,) * (4 + len(ctx.model._param_names))
         return (None, None, None, None) + tuple(ctx.grads[k] for k in ctx.model._param_names)
 
 

@@ -59,9 +59,14 @@ class _RolloutFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _g_seq, g_logp):
         model, ro, pr, P = ctx.model, ctx.ro, ctx.pr, ctx.P
+        flat = model._flat
+        stash = flat.begin_backward() if flat is not None else None
         grads = model._grad_targets(P)
         d_fc, d_att, d_p_att = ro.backward(g_logp, grads)
         engine.prepare_backward(P, pr, d_fc, d_att, d_p_att, grads)
+        if flat is not None:
+            flat.end_backward(stash)
+            return (None,) * (5 + len(model._param_names))
         return (None, None, None, None, None) + tuple(grads[k] for k in model._param_names)
 
 

@@ -32,8 +32,13 @@ class _RolloutFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _g, g_logp):
         model, ro, P = ctx.model, ctx.ro, ctx.P
-        grads = model._flat.grad_views if model._flat is not None else {k: torch.empty_like(v) for k, v in P.items()}
+        flat = model._flat
+        stash = flat.begin_backward() if flat is not None else None
+        grads = flat.grad_views if flat is not None else {k: torch.empty_like(v) for k, v in P.items()}
         ro.backward(g_logp, grads)
+        if flat is not None:
+            flat.end_backward(stash)
+            return (None,) * (3 + len(model._param_names))
         return (None, None, None) + tuple(grads[k] for k in model._param_names)
 
 

@@ -39,6 +39,25 @@ class FlatParams:
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_count = 0
 
+    def begin_backward(self):
+        """Called by a native backward BEFORE it overwrites the flat gradient views.  Returns a stash of gradients
+        that already exist (a second backward pass within one step accumulates, like autograd would)."""
+        stash = None
+        for n, p in zip(self.names, self.params):
+            if p.grad is not None:
+                stash = stash or {}
+                stash[n] = p.grad.clone()
+        return stash
+
+    def end_backward(self, stash=None):
+        """Adopt the freshly written flat views as the parameters' .grad -- no copy.  (Handing the views back to
+        autograd made AccumulateGrad clone every one of them: ~50 device copies / 0.35 ms per SCST step.)"""
+        for n, p in zip(self.names, self.params):
+            v = self.grad_views[n]
+            if stash is not None and n in stash:
+                v.add_(stash[n])
+            p.grad = v
+
     def collect_grads(self):
         """Make the flat gradient buffer authoritative: parameters whose .grad is not already the flat
         view (e.g. produced by torch autograd ops) are copied in; missing grads become zero."""
