@@ -161,11 +161,11 @@ int capmi_newfc_rollout_fwd(const capmi_newfc_weights *w, capmi_newfc_rollout *r
         RC(capmi_maxout_cell_fwd(slabs, splits, w->i2h_b, w->h2h_b, c_prev, h, c, r->saved + (size_t)(t + 1) * N * 5 * R,
                                  r->drop_out ? r->drop_out + (size_t)t * NR : nullptr, h_drop, N, R, stream));
         SegSpec sl{h_drop, R, w->logit_w, R, R, 1};
-        RC(gemm(stream, 0, 0, N, V1, r->logits, V1, &sl, 1, r->partial, r->partial_capacity, 0, nullptr, w->logit_b));
-        RC(capmi_logsoftmax_select(r->logits, N, V1, t, L, r->teacher ? 2 : r->mode, nullptr, r->temperature,
-                                   r->gumbel ? r->gumbel + (size_t)t * N * V1 : nullptr, r->seed, r->forced, r->forced_ld,
-                                   r->teacher ? 1 : 0, r->seq, L, r->it, r->unfinished, r->seq_logp, r->sel_logp, r->live,
-                                   stream));
+        RC(gemm(stream, 0, 0, N, V1, r->partial, V1, &sl, 1, r->partial, r->partial_capacity, 1, &splits));
+        RC(capmi_logsoftmax_select_partial(slabs, splits, (int64_t)N * V1, w->logit_b, N, V1, t, L, r->teacher ? 2 : r->mode,
+                                           nullptr, r->temperature, r->gumbel ? r->gumbel + (size_t)t * N * V1 : nullptr,
+                                           r->seed, r->forced, r->forced_ld, r->teacher ? 1 : 0, r->seq, L, r->it,
+                                           r->unfinished, r->seq_logp, r->sel_logp, r->live, stream));
     }
     return 0;
 }

@@ -135,16 +135,17 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
                                    r->gates_lang + (size_t)t * N * 4 * R,
                                    r->drop_out ? r->drop_out + (size_t)t * NR : nullptr, h_drop, N, R, stream));
         }
-        // 8. vocabulary projection
+        // 8-9. vocabulary projection left as K-slice slabs; log-softmax + choice + bookkeeping assemble the row
+        //      (slabs + bias) in registers: no split-K reduce launch, no logits round trip
         {
             SegSpec s{h_drop, R, w->logit_w, R, R, 1};
-            RC(gemm(stream, 0, 0, N, V1, r->logits, V1, &s, 1, r->partial, r->partial_capacity, 0, nullptr, w->logit_b));
+            RC(gemm(stream, 0, 0, N, V1, r->partial, V1, &s, 1, r->partial, r->partial_capacity, 1, &splits));
         }
-        // 9. log-softmax + choice + bookkeeping
-        RC(capmi_logsoftmax_select(r->logits, N, V1, t, L, r->teacher ? 2 : r->mode, r->teacher ? nullptr : r->row_mode,
-                                   r->temperature, r->gumbel ? r->gumbel + (size_t)t * N * V1 : nullptr, r->seed,
-                                   r->forced, r->forced_ld, r->teacher ? 1 : 0, r->seq, L, r->it, r->unfinished,
-                                   r->seq_logp, r->sel_logp, r->live, stream));
+        RC(capmi_logsoftmax_select_partial(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, (int64_t)N * V1, w->logit_b, N, V1, t,
+                                           L, r->teacher ? 2 : r->mode, r->teacher ? nullptr : r->row_mode, r->temperature,
+                                           r->gumbel ? r->gumbel + (size_t)t * N * V1 : nullptr, r->seed, r->forced,
+                                           r->forced_ld, r->teacher ? 1 : 0, r->seq, L, r->it, r->unfinished, r->seq_logp,
+                                           r->sel_logp, r->live, stream));
     }
     return 0;
 }

@@ -38,7 +38,8 @@ __device__ __forceinline__ ArgMax wave_argmax(ArgMax x) {
 }
 
 __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
-    const float *__restrict__ logits, int V1, int step, int L, int mode, const uint8_t *__restrict__ row_mode,
+    const float *__restrict__ logits, int splits, size_t slab_stride, const float *__restrict__ bias, int V1, int step,
+    int L, int mode, const uint8_t *__restrict__ row_mode,
     float temperature, const float *__restrict__ gumbel, uint64_t seed, const int64_t *__restrict__ forced,
     int forced_ld, int no_finish_mask, int64_t *__restrict__ seq, int seq_ld, int64_t *__restrict__ it_next,
     uint8_t *__restrict__ unfinished, float *__restrict__ seq_logp, float *__restrict__ sel_logp,
@@ -46,7 +47,18 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
     __shared__ float s_f[32];
     __shared__ int s_i[32];
     const int r = blockIdx.x;
-    const float *x = logits + (size_t)r * V1;
+    // any vocabulary size / alignment: the row is re-assembled (slabs + bias) on every pass
+    struct Row {
+        const float *p, *bias;
+        int splits;
+        size_t stride;
+        __device__ __forceinline__ float operator[](int v) const {
+            float a = p[v];
+            for (int s = 1; s < splits; ++s) a += p[s * stride + v];
+            return bias ? a + bias[v] : a;
+        }
+    };
+    const Row x{logits + (size_t)r * V1, bias, splits, slab_stride};
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int my_mode = row_mode ? (int)row_mode[r] : mode;
 
@@ -122,6 +134,136 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
     }
 }
 
+// Register-resident variant: the row (<= NQ*4096 logits, V1 % 4 == 0) is assembled ONCE into registers as
+// sum of the logit GEMM's K-slice slabs + bias (so the split-K reduce launch and the logits round trip disappear),
+// then max / sum-exp / choice / dense log-prob write all run from registers.  Same thread->vocabulary-quad map as
+// the streaming kernel above, hence identical Philox counters and identical samples.
+template <int NQ>
+__global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
+    const float *__restrict__ src, int splits, size_t slab_stride, const float *__restrict__ bias, int V1, int step, int L,
+    int mode, const uint8_t *__restrict__ row_mode, float temperature, const float *__restrict__ gumbel, uint64_t seed,
+    const int64_t *__restrict__ forced, int forced_ld, int no_finish_mask, int64_t *__restrict__ seq, int seq_ld,
+    int64_t *__restrict__ it_next, uint8_t *__restrict__ unfinished, float *__restrict__ seq_logp,
+    float *__restrict__ sel_logp, uint8_t *__restrict__ live) {
+    __shared__ float s_f[32];
+    __shared__ int s_i[32];
+    __shared__ float s_tok;
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = SEL_THREADS >> 6;
+    const int my_mode = row_mode ? (int)row_mode[r] : mode;
+    const int nq = V1 >> 2;
+
+    f32x4 x[NQ];
+    {
+        // all slab loads of a thread are independent: issue them together
+        f32x4 part[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int q = threadIdx.x + j * SEL_THREADS;
+            x[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (q < nq) {
+                x[j] = *reinterpret_cast<const f32x4 *>(src + (size_t)r * V1 + 4 * q);
+                if (bias) x[j] += *reinterpret_cast<const f32x4 *>(bias + 4 * q);
+            }
+        }
+        for (int sidx = 1; sidx < splits; ++sidx) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const int q = threadIdx.x + j * SEL_THREADS;
+                part[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (q < nq) part[j] = *reinterpret_cast<const f32x4 *>(src + sidx * slab_stride + (size_t)r * V1 + 4 * q);
+            }
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) x[j] += part[j];
+        }
+    }
+
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) m = fmaxf(m, fmaxf(fmaxf(x[j][0], x[j][1]), fmaxf(x[j][2], x[j][3])));
+    m = block_max(m, s_f);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sum += __expf(x[j][k] - m);      // padding lanes hold -inf -> exp = 0
+    sum = block_sum(sum, s_f);
+    const float lse = m + __logf(sum);
+
+    int token;
+    if (my_mode == 2) {
+        token = (int)forced[(size_t)r * forced_ld + step];
+    } else {
+        ArgMax best{-INFINITY, 0x7fffffff};
+        if (my_mode == 0) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const int q = threadIdx.x + j * SEL_THREADS;
+                if (q < nq)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) best = better(best, ArgMax{x[j][k], 4 * q + k});
+            }
+        } else {
+            const float invT = 1.f / temperature;
+            const Philox rng(seed);
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const int q = threadIdx.x + j * SEL_THREADS;
+                if (q < nq) {
+                    float gn[4];
+                    if (gumbel) {
+                        const f32x4 g = *reinterpret_cast<const f32x4 *>(gumbel + (size_t)r * V1 + 4 * q);
+                        gn[0] = g[0]; gn[1] = g[1]; gn[2] = g[2]; gn[3] = g[3];
+                    } else {
+                        uint32_t o[4];
+                        rng.gen(((uint64_t)step << 32) | (uint32_t)r, (uint64_t)q, o);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) gn[k] = -__logf(-__logf(u01(o[k])));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) best = better(best, ArgMax{(x[j][k] - lse) * invT + gn[k], 4 * q + k});
+                }
+            }
+        }
+        best = wave_argmax(best);
+        __syncthreads();
+        if (lane == 0) {
+            s_f[wid] = best.v;
+            s_i[wid] = best.i;
+        }
+        __syncthreads();
+        ArgMax t{s_f[0], s_i[0]};
+        for (int i = 1; i < nw; ++i) t = better(t, ArgMax{s_f[i], s_i[i]});
+        token = t.i;
+    }
+
+    // bookkeeping (AttModel.py:340-347)
+    const bool was_unf = (step == 0 || no_finish_mask) ? true : (unfinished[r] != 0);
+    if (!was_unf) token = 0;
+    const float keep = was_unf ? 1.f : 0.f;
+    float *out = seq_logp ? seq_logp + ((size_t)r * L + step) * V1 : nullptr;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int q = threadIdx.x + j * SEL_THREADS;
+        if (q < nq) {
+            if (out) {
+                f32x4 o = x[j] - lse;
+                if (!was_unf) o = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4 *>(out + 4 * q) = o;
+            }
+            if (q == (token >> 2)) s_tok = x[j][token & 3];     // the owner of the chosen logit publishes it
+        }
+    }
+    __syncthreads();   // s_tok visible; all reads of unfinished[r] done before thread 0 rewrites it
+    if (threadIdx.x == 0) {
+        seq[(size_t)r * seq_ld + step] = token;
+        it_next[r] = token;
+        if (sel_logp) sel_logp[(size_t)r * L + step] = keep * (s_tok - lse);
+        if (live) live[(size_t)r * L + step] = was_unf ? 1 : 0;
+        if (!no_finish_mask) unfinished[r] = (was_unf && token != 0) ? 1 : 0;
+    }
+}
+
 __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_bwd_kernel(const float *__restrict__ g,
                                                                       const float *__restrict__ seq_logp,
                                                                       const uint8_t *__restrict__ live,
@@ -147,19 +289,46 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_bwd_kernel(const float
 
 extern "C" {
 
+int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t slab_stride, const float *bias, int N,
+                                    int V1, int step, int L, int mode, const uint8_t *row_mode, float temperature,
+                                    const float *gumbel, uint64_t seed, const int64_t *forced, int forced_ld,
+                                    int no_finish_mask, int64_t *seq, int seq_ld, int64_t *it_next, uint8_t *unfinished,
+                                    float *seq_logp, float *sel_logp, uint8_t *live, void *stream) {
+    if (!partial || splits < 1 || N <= 0 || V1 <= 0 || step < 0 || step >= L || !seq || !it_next) return CAPMI_EINVAL;
+    if (!no_finish_mask && !unfinished) return CAPMI_EINVAL;
+    if ((mode == 2 || row_mode) && !forced && mode == 2) return CAPMI_EINVAL;
+    if (mode == 1 && !(temperature > 0.f)) return CAPMI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const bool al = ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(bias) |
+                      reinterpret_cast<uintptr_t>(gumbel) | reinterpret_cast<uintptr_t>(seq_logp)) & 15) == 0 &&
+                    (slab_stride % 4 == 0);
+    if (al && V1 % 4 == 0 && V1 <= 3 * 4 * SEL_THREADS) {
+#define CAPMI_SEL(NQ)                                                                                                   \
+    hipLaunchKernelGGL(logsoftmax_select_reg_kernel<NQ>, dim3(N), dim3(SEL_THREADS), 0, st, partial, splits,           \
+                       (size_t)slab_stride, bias, V1, step, L, mode, row_mode, temperature, gumbel, seed, forced,       \
+                       forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live)
+        if (V1 <= 4 * SEL_THREADS) CAPMI_SEL(1);
+        else if (V1 <= 8 * SEL_THREADS) CAPMI_SEL(2);
+        else CAPMI_SEL(3);
+#undef CAPMI_SEL
+        CAPMI_CHECK_LAUNCH();
+        return 0;
+    }
+    hipLaunchKernelGGL(logsoftmax_select_kernel, dim3(N), dim3(SEL_THREADS), 0, st, partial, splits, (size_t)slab_stride, bias,
+                       V1, step, L, mode, row_mode,
+                       temperature, gumbel, seed, forced, forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished,
+                       seq_logp, sel_logp, live);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
 int capmi_logsoftmax_select(const float *logits, int N, int V1, int step, int L, int mode, const uint8_t *row_mode,
                             float temperature, const float *gumbel, uint64_t seed, const int64_t *forced,
                             int forced_ld, int no_finish_mask, int64_t *seq, int seq_ld, int64_t *it_next,
                             uint8_t *unfinished, float *seq_logp, float *sel_logp, uint8_t *live, void *stream) {
-    if (!logits || N <= 0 || V1 <= 0 || step < 0 || step >= L || !seq || !it_next) return CAPMI_EINVAL;
-    if (!no_finish_mask && !unfinished) return CAPMI_EINVAL;
-    if ((mode == 2 || row_mode) && !forced && mode == 2) return CAPMI_EINVAL;
-    if (mode == 1 && !(temperature > 0.f)) return CAPMI_EINVAL;
-    hipLaunchKernelGGL(logsoftmax_select_kernel, dim3(N), dim3(SEL_THREADS), 0, (hipStream_t)stream, logits, V1, step, L,
-                       mode, row_mode, temperature, gumbel, seed, forced, forced_ld, no_finish_mask, seq, seq_ld,
-                       it_next, unfinished, seq_logp, sel_logp, live);
-    CAPMI_CHECK_LAUNCH();
-    return 0;
+    return capmi_logsoftmax_select_partial(logits, 1, 0, nullptr, N, V1, step, L, mode, row_mode, temperature, gumbel,
+                                           seed, forced, forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished,
+                                           seq_logp, sel_logp, live, stream);
 }
 
 int capmi_logsoftmax_bwd(const float *g, const float *seq_logp, const uint8_t *live, float *dlogits, int N, int L,

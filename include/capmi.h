@@ -180,6 +180,18 @@ int capmi_logsoftmax_select(const float *logits, int N, int V1, int step, int L,
                             int64_t *seq, int seq_ld, int64_t *it_next, uint8_t *unfinished,
                             float *seq_logp, float *sel_logp, uint8_t *live, void *stream);
 
+/* Same, fed straight from the vocabulary GEMM's K-slice slabs (capmi_gemm_f32 with defer_reduce = 1):
+ * logits[r,:] = sum_{s<splits} partial[s*slab_stride + r*V1 + :] + bias (bias may be NULL).  With V1 % 4 == 0,
+ * V1 <= 12288 and 16-byte aligned buffers the row lives in registers (no split-K reduce launch, no logits
+ * round trip); any other size / alignment runs a streaming kernel that re-assembles the row per pass. */
+int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t slab_stride, const float *bias,
+                                    int N, int V1, int step, int L,
+                                    int mode, const uint8_t *row_mode, float temperature,
+                                    const float *gumbel, uint64_t seed,
+                                    const int64_t *forced, int forced_ld, int no_finish_mask,
+                                    int64_t *seq, int seq_ld, int64_t *it_next, uint8_t *unfinished,
+                                    float *seq_logp, float *sel_logp, uint8_t *live, void *stream);
+
 /* gradient of the dense log-probs w.r.t. the logits for ALL steps at once:
  *   dlogits[r,t,:] = g[r,t,:] - exp(logp[r,t,:]) * sum_v g[r,t,v]      (rows where logp was masked
  *   to zero receive zero: `live` [N,L] uint8, 1 = the row was live when step t was produced) */
