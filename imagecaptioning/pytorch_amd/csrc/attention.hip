@@ -55,7 +55,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
     const float *__restrict__ att_h, const float *__restrict__ p_att, const float *__restrict__ att,
     const float *__restrict__ mask, const float *__restrict__ w, const float *__restrict__ bptr,
     float *__restrict__ ctx, float *__restrict__ alpha, int B, int n_img, int rpb, int chunks, int K, int A, int R,
-    const int *__restrict__ row_img) {
+    const int *__restrict__ row_img, int h_splits, size_t h_stride, const float *__restrict__ h_bias,
+    float *__restrict__ att_h_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int AH = A > 1024 ? A : 1024;  // s_h doubles as the [NMAX][1024] combine buffer of the context phase
     float *s_h = lds;                    // [NMAX][AH]
@@ -72,7 +73,25 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
 
-    for (int i = threadIdx.x; i < n * A; i += blockDim.x) s_h[i] = att_h[(size_t)row0 * A + i];
+    if (h_splits > 0) {
+        // att_h arrives as the h2att GEMM's K-slice slabs: finish the reduction (+ bias) here and keep the
+        // finished rows for the backward pass (no split-K reduce launch between the GEMM and this kernel)
+        for (int i = threadIdx.x; i < n * A; i += blockDim.x) {
+            const float *p = att_h + (size_t)row0 * A + i;
+            float v = 0.f;
+            for (int s0 = 0; s0 < h_splits; s0 += 8) {      // 8 independent slab loads in flight
+                float part[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) part[u] = (s0 + u < h_splits) ? p[(s0 + u) * h_stride] : 0.f;
+                v += ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+            }
+            if (h_bias) v += h_bias[i % A];
+            s_h[i] = v;
+            if (att_h_out) att_h_out[(size_t)row0 * A + i] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n * A; i += blockDim.x) s_h[i] = att_h[(size_t)row0 * A + i];
+    }
 
     const float bias = bptr ? bptr[0] : 0.f;
     const float *pb = p_att + (size_t)b * K * A;
@@ -462,9 +481,10 @@ __global__ void sum_all_kernel(const float *__restrict__ in, size_t count, float
 
 extern "C" {
 
-int capmi_attention_fwd(const float *att_h, const float *p_att, const float *att, const float *mask, const float *w,
-                        const float *b, float *ctx, float *alpha, int B, int n, int K, int A, int R,
-                        const int32_t *row_img, int N, void *stream) {
+static int attention_fwd_launch(const float *att_h, int h_splits, int64_t h_stride, const float *h_bias, float *att_h_out,
+                                const float *p_att, const float *att, const float *mask, const float *w, const float *b,
+                                float *ctx, float *alpha, int B, int n, int K, int A, int R, const int32_t *row_img, int N,
+                                void *stream) {
     if (!att_h || !p_att || !att || !w || !ctx || !alpha || B <= 0 || K <= 0 || A <= 0 || R <= 0) return CAPMI_EINVAL;
     if (row_img ? N <= 0 : n <= 0) return CAPMI_EINVAL;
     if (!row_img) N = B * n;
@@ -477,12 +497,29 @@ int capmi_attention_fwd(const float *att_h, const float *p_att, const float *att
     if (capmi_prof::take_events(CAPMI_PROF_ATTENTION_FWD, &e0, &e1, abytes, (double)N * K * (2.0 * A + 2.0 * R)))
         hipExtLaunchKernelGGL(attention_fwd_kernel, dim3(row_img ? N : grid_blocks(B, chunks)), dim3(ATT_THREADS), lds,
                               (hipStream_t)stream, e0, e1, 0, att_h, p_att, att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K,
-                              A, R, row_img);
+                              A, R, row_img, h_splits, (size_t)h_stride, h_bias, att_h_out);
     else
         hipLaunchKernelGGL(attention_fwd_kernel, dim3(row_img ? N : grid_blocks(B, chunks)), dim3(ATT_THREADS), lds,
-                           (hipStream_t)stream, att_h, p_att, att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K, A, R, row_img);
+                           (hipStream_t)stream, att_h, p_att, att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K, A, R, row_img,
+                           h_splits, (size_t)h_stride, h_bias, att_h_out);
     CAPMI_CHECK_LAUNCH();
     return 0;
+}
+
+int capmi_attention_fwd(const float *att_h, const float *p_att, const float *att, const float *mask, const float *w,
+                        const float *b, float *ctx, float *alpha, int B, int n, int K, int A, int R,
+                        const int32_t *row_img, int N, void *stream) {
+    return attention_fwd_launch(att_h, 0, 0, nullptr, nullptr, p_att, att, mask, w, b, ctx, alpha, B, n, K, A, R, row_img, N,
+                                stream);
+}
+
+int capmi_attention_fwd_partial(const float *h_partial, int h_splits, int64_t h_stride, const float *h_bias,
+                                float *att_h_out, const float *p_att, const float *att, const float *mask, const float *w,
+                                const float *b, float *ctx, float *alpha, int B, int n, int K, int A, int R,
+                                const int32_t *row_img, int N, void *stream) {
+    if (h_splits < 1) return CAPMI_EINVAL;
+    return attention_fwd_launch(h_partial, h_splits, h_stride, h_bias, att_h_out, p_att, att, mask, w, b, ctx, alpha, B, n, K,
+                                A, R, row_img, N, stream);
 }
 
 int capmi_attention_bwd(const float *d_ctx, int ld_dctx, const float *att_h, const float *alpha, const float *p_att,

@@ -99,8 +99,11 @@ __global__ void lstm_cell_fwd_kernel(const float *__restrict__ partial, int spli
     }
 }
 
+// dh_b / dh_c may arrive as split-K slabs of the dX GEMMs of the previous BPTT step (b_splits / c_splits > 1,
+// slab s at + s * stride): the cell finishes those reductions itself, so the dX GEMMs need no reduce launch.
 __global__ void lstm_cell_bwd_kernel(const float *__restrict__ dh_a, int ld_a, const float *__restrict__ dh_a_mask,
-                                     const float *__restrict__ dh_b, int ld_b, const float *__restrict__ dh_c, int ld_c,
+                                     const float *__restrict__ dh_b, int ld_b, int b_splits, size_t b_stride,
+                                     const float *__restrict__ dh_c, int ld_c, int c_splits, size_t c_stride,
                                      const float *__restrict__ dc_next, const float *__restrict__ gates_act,
                                      const float *__restrict__ c_prev, const float *__restrict__ c_new,
                                      float *__restrict__ d_gates, float *__restrict__ dc_prev, int N, int R) {
@@ -112,8 +115,24 @@ __global__ void lstm_cell_bwd_kernel(const float *__restrict__ dh_a, int ld_a, c
             const float v = dh_a[(size_t)r * ld_a + j];
             dh += dh_a_mask ? v * dh_a_mask[i] : v;
         }
-        if (dh_b) dh += dh_b[(size_t)r * ld_b + j];
-        if (dh_c) dh += dh_c[(size_t)r * ld_c + j];
+        if (dh_b) {
+            const float *p = dh_b + (size_t)r * ld_b + j;
+            for (int s0 = 0; s0 < b_splits; s0 += 8) {     // 8 independent slab loads in flight
+                float part[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) part[u] = (s0 + u < b_splits) ? p[(s0 + u) * b_stride] : 0.f;
+                dh += ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+            }
+        }
+        if (dh_c) {
+            const float *p = dh_c + (size_t)r * ld_c + j;
+            for (int s0 = 0; s0 < c_splits; s0 += 8) {     // 8 independent slab loads in flight
+                float part[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) part[u] = (s0 + u < c_splits) ? p[(s0 + u) * c_stride] : 0.f;
+                dh += ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+            }
+        }
         const float *ga = gates_act + (size_t)r * 4 * R + j;
         const float ig = ga[0], fg = ga[R], gg = ga[2 * R], og = ga[3 * (size_t)R];
         const float tc = tanh_f(c_new[i]);
@@ -289,15 +308,25 @@ int capmi_lstm_cell_fwd(const float *partial, int splits, const float *b_ih, con
     return 0;
 }
 
+int capmi_lstm_cell_bwd_partial(const float *dh_a, int ld_a, const float *dh_a_mask, const float *dh_b, int ld_b,
+                                int b_splits, int64_t b_stride, const float *dh_c, int ld_c, int c_splits,
+                                int64_t c_stride, const float *dc_next, const float *gates_act, const float *c_prev,
+                                const float *c_new, float *d_gates, float *dc_prev, int N, int R, void *stream) {
+    if (!gates_act || !c_prev || !c_new || !d_gates || !dc_prev || N <= 0 || R <= 0) return CAPMI_EINVAL;
+    if ((dh_b && b_splits < 1) || (dh_c && c_splits < 1)) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for((size_t)N * R)), dim3(256), 0, (hipStream_t)stream, dh_a,
+                       ld_a, dh_a_mask, dh_b, ld_b, b_splits, (size_t)b_stride, dh_c, ld_c, c_splits, (size_t)c_stride,
+                       dc_next, gates_act, c_prev, c_new, d_gates, dc_prev, N, R);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
 int capmi_lstm_cell_bwd(const float *dh_a, int ld_a, const float *dh_a_mask, const float *dh_b, int ld_b,
                         const float *dh_c, int ld_c, const float *dc_next, const float *gates_act,
                         const float *c_prev, const float *c_new, float *d_gates, float *dc_prev, int N, int R,
                         void *stream) {
-    if (!gates_act || !c_prev || !c_new || !d_gates || !dc_prev || N <= 0 || R <= 0) return CAPMI_EINVAL;
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for((size_t)N * R)), dim3(256), 0, (hipStream_t)stream, dh_a,
-                       ld_a, dh_a_mask, dh_b, ld_b, dh_c, ld_c, dc_next, gates_act, c_prev, c_new, d_gates, dc_prev, N, R);
-    CAPMI_CHECK_LAUNCH();
-    return 0;
+    return capmi_lstm_cell_bwd_partial(dh_a, ld_a, dh_a_mask, dh_b, ld_b, 1, 0, dh_c, ld_c, 1, 0, dc_next, gates_act,
+                                       c_prev, c_new, d_gates, dc_prev, N, R, stream);
 }
 
 int capmi_dropout_mask(float *mask, int64_t count, float p, uint64_t seed, uint64_t offset, void *stream) {

@@ -117,14 +117,15 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
             RC(capmi_lstm_cell_fwd(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, w->att_b_ih, w->att_b_hh, r->fc_gates, n, r->row_img, c_att_prev, h_att, c_att,
                                    r->gates_att + (size_t)t * N * 4 * R, nullptr, nullptr, N, R, stream));
         }
-        // 4. att_h = h_att W_h2att^T + b
+        // 4-5. att_h = h_att W_h2att^T + b left as K-slice slabs; the fused region attention finishes the reduction
+        //      (+ bias), keeps att_h for the backward pass and runs score + softmax + context
         {
             SegSpec s{h_att, R, w->h2att_w, R, R, 1};
-            RC(gemm(stream, 0, 0, N, A, att_h, A, &s, 1, r->partial, r->partial_capacity, 0, nullptr, w->h2att_b));
+            RC(gemm(stream, 0, 0, N, A, r->partial, A, &s, 1, r->partial, r->partial_capacity, 1, &splits));
         }
-        // 5. fused region attention
-        RC(capmi_attention_fwd(att_h, r->p_att, r->att, r->att_mask, w->alpha_w, w->alpha_b, ctx, alpha, B_feat, n, K, A, R,
-                               r->row_img, N, stream));
+        RC(capmi_attention_fwd_partial(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, (int64_t)N * A, w->h2att_b, att_h,
+                                       r->p_att, r->att, r->att_mask, w->alpha_w, w->alpha_b, ctx, alpha, B_feat, n, K, A, R,
+                                       r->row_img, N, stream));
         // 6-7. language LSTM: gates = [ctx | h_att | h_lang_prev] . [W_ih(:, 0:R) | W_ih(:, R:2R) | W_hh]
         {
             SegSpec s[3] = {{ctx, R, w->lang_w_ih, 2 * R, R, 1},
@@ -188,27 +189,40 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
     }
 
     // ---- BPTT over the recurrent part ----------------------------------------------------------
+    // Workspace carved in three: the d_x1 and dh_att(attention) GEMMs leave their K-slice slabs in regions of their own
+    // and the LSTM-cell kernels of the following launches finish those reductions (2 of the 3 split-K reduce launches
+    // per step disappear; d_x1 is never materialised).  d_x2 keeps its reduce: three kernels and the batched pass read it.
+    const int64_t cap1 = (cap / 4) & ~(int64_t)1023, caph = (cap / 8) & ~(int64_t)1023, capm = cap - cap1 - caph;
+    float *P1 = P + capm, *Ph = P + capm + cap1;
+    if (capm <= CAPMI_WS_COUNTER_FLOATS || cap1 <= CAPMI_WS_COUNTER_FLOATS || caph <= CAPMI_WS_COUNTER_FLOATS) return CAPMI_EINVAL;
+    {   // ticket words of the carved regions start zeroed like the main one
+        hipError_t e = hipMemsetAsync(P1, 0, CAPMI_WS_COUNTER_FLOATS * sizeof(float), st);
+        if (e == hipSuccess) e = hipMemsetAsync(Ph, 0, CAPMI_WS_COUNTER_FLOATS * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    const float *x1_slabs = P1 + CAPMI_WS_COUNTER_FLOATS, *h_slabs = Ph + CAPMI_WS_COUNTER_FLOATS;
+    const int64_t x1_stride = (int64_t)N * 2 * R, h_stride = (int64_t)NR;
+    int x1_splits = 1, h_splits = 1;
     for (int t = T - 1; t >= 0; --t) {
         const bool last = (t == T - 1);
         float *d_x2 = s->d_x2 + (size_t)t * N * 3 * R;
-        float *d_x1 = s->d_x1 + (size_t)t * N * 2 * R;
         const float *d_x2_next = last ? nullptr : s->d_x2 + (size_t)(t + 1) * N * 3 * R;
-        const float *d_x1_next = last ? nullptr : s->d_x1 + (size_t)(t + 1) * N * 2 * R;
         float *dg_lang = s->dg_lang + (size_t)t * N * 4 * R;
         float *dg_att = s->dg_att + (size_t)t * N * 4 * R;
         float *dc_lang_in = s->dc_lang + (size_t)((t + 1) & 1) * NR, *dc_lang_out = s->dc_lang + (size_t)(t & 1) * NR;
         float *dc_att_in = s->dc_att + (size_t)((t + 1) & 1) * NR, *dc_att_out = s->dc_att + (size_t)(t & 1) * NR;
 
-        // language LSTM cell: dh = d_hdrop*mask + dh_lang(att-LSTM input of step t+1) + dh_lang(own W_hh, t+1)
-        RC(capmi_lstm_cell_bwd(s->d_hdrop + (size_t)t * NR, R, r->drop_out ? r->drop_out + (size_t)t * NR : nullptr,
-                               d_x1_next, 2 * R, d_x2_next ? d_x2_next + 2 * R : nullptr, 3 * R,
-                               last ? nullptr : dc_lang_in, r->gates_lang + (size_t)t * N * 4 * R,
-                               r->c_lang + (size_t)t * NR, r->c_lang + (size_t)(t + 1) * NR, dg_lang, dc_lang_out, N, R,
-                               stream));
+        // language LSTM cell: dh = d_hdrop*mask + dh_lang(att-LSTM input of step t+1: d_x1 slabs, columns 0..R)
+        //                          + dh_lang(own W_hh, t+1)
+        RC(capmi_lstm_cell_bwd_partial(s->d_hdrop + (size_t)t * NR, R, r->drop_out ? r->drop_out + (size_t)t * NR : nullptr,
+                                       last ? nullptr : x1_slabs, 2 * R, x1_splits, x1_stride,
+                                       d_x2_next ? d_x2_next + 2 * R : nullptr, 3 * R, 1, 0, last ? nullptr : dc_lang_in,
+                                       r->gates_lang + (size_t)t * N * 4 * R, r->c_lang + (size_t)t * NR,
+                                       r->c_lang + (size_t)(t + 1) * NR, dg_lang, dc_lang_out, N, R, stream));
         // d_x2 = dg_lang [W_ih | W_hh]  -> (d_ctx | dh_att | dh_lang_prev)
         {
             SegSpec a{dg_lang, 4 * R, s->w_lang_cat, 3 * R, 4 * R, 1};
-            RC(gemm(stream, 0, 1, N, 3 * R, d_x2, 3 * R, &a, 1, P, cap, 0, nullptr));
+            RC(gemm(stream, 0, 1, N, 3 * R, d_x2, 3 * R, &a, 1, P, capm, 0, nullptr));
         }
         // attention Jacobian: d_ctx -> d_att_h (and d_e kept for the batched pass)
         RC(capmi_attention_bwd(d_x2, 3 * R, r->att_h + (size_t)t * N * A, r->alpha + (size_t)t * N * K, r->p_att, r->att,
@@ -216,18 +230,20 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
                                s->d_e_all + (size_t)t * N * K, r->B_feat > 0 ? r->B_feat : B, n, K, A, R, r->row_img, N,
                                stream));
         {
-            SegSpec a{s->d_att_h_all + (size_t)t * N * A, A, w->h2att_w, R, A, 1};   // dh_att via h2att
-            RC(gemm(stream, 0, 1, N, R, s->dh_att_attn, R, &a, 1, P, cap, 0, nullptr));
+            SegSpec a{s->d_att_h_all + (size_t)t * N * A, A, w->h2att_w, R, A, 1};   // dh_att via h2att, left as slabs
+            RC(gemm(stream, 0, 1, N, R, Ph, R, &a, 1, Ph, caph, 1, &h_splits));
         }
-        // attention LSTM cell: dh = dh_att(lang input) + dh_att(attention) + dh_att(own W_hh, t+1)
-        RC(capmi_lstm_cell_bwd(d_x2 + R, 3 * R, nullptr, s->dh_att_attn, R, d_x1_next ? d_x1_next + R : nullptr, 2 * R,
-                               last ? nullptr : dc_att_in, r->gates_att + (size_t)t * N * 4 * R,
-                               r->c_att + (size_t)t * NR, r->c_att + (size_t)(t + 1) * NR, dg_att, dc_att_out, N, R,
-                               stream));
-        // d_x1 = dg_att [W_ih(:, 0:R) | W_hh] -> (dh_lang_prev | dh_att_prev); not needed at t = 0
+        // attention LSTM cell: dh = dh_att(lang input) + dh_att(attention: slabs) + dh_att(own W_hh, t+1: d_x1 slabs,
+        // columns R..2R)
+        RC(capmi_lstm_cell_bwd_partial(d_x2 + R, 3 * R, nullptr, h_slabs, R, h_splits, h_stride,
+                                       last ? nullptr : x1_slabs + R, 2 * R, x1_splits, x1_stride,
+                                       last ? nullptr : dc_att_in, r->gates_att + (size_t)t * N * 4 * R,
+                                       r->c_att + (size_t)t * NR, r->c_att + (size_t)(t + 1) * NR, dg_att, dc_att_out, N, R,
+                                       stream));
+        // d_x1 = dg_att [W_ih(:, 0:R) | W_hh] -> (dh_lang_prev | dh_att_prev) as slabs for step t-1; not needed at t = 0
         if (t > 0) {
             SegSpec a{dg_att, 4 * R, s->w_att_cat, 2 * R, 4 * R, 1};
-            RC(gemm(stream, 0, 1, N, 2 * R, d_x1, 2 * R, &a, 1, P, cap, 0, nullptr));
+            RC(gemm(stream, 0, 1, N, 2 * R, P1, 2 * R, &a, 1, P1, cap1, 1, &x1_splits));
         }
     }
 

@@ -155,8 +155,6 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
 
     f32x4 x[NQ];
     {
-        // all slab loads of a thread are independent: issue them together
-        f32x4 part[NQ];
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             const int q = threadIdx.x + j * SEL_THREADS;
@@ -166,15 +164,19 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
                 if (bias) x[j] += *reinterpret_cast<const f32x4 *>(bias + 4 * q);
             }
         }
-        for (int sidx = 1; sidx < splits; ++sidx) {
+        for (int s0 = 1; s0 < splits; s0 += 3) {          // 3 slabs x NQ quads of independent loads in flight
+            f32x4 p3[3][NQ];
 #pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                const int q = threadIdx.x + j * SEL_THREADS;
-                part[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (q < nq) part[j] = *reinterpret_cast<const f32x4 *>(src + sidx * slab_stride + (size_t)r * V1 + 4 * q);
-            }
+            for (int u = 0; u < 3; ++u)
 #pragma unroll
-            for (int j = 0; j < NQ; ++j) x[j] += part[j];
+                for (int j = 0; j < NQ; ++j) {
+                    const int q = threadIdx.x + j * SEL_THREADS;
+                    p3[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (q < nq && s0 + u < splits)
+                        p3[u][j] = *reinterpret_cast<const f32x4 *>(src + (s0 + u) * slab_stride + (size_t)r * V1 + 4 * q);
+                }
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) x[j] += (p3[0][j] + p3[1][j]) + p3[2][j];
         }
     }
 

@@ -106,6 +106,14 @@ int capmi_attention_fwd(const float *att_h, const float *p_att, const float *att
                         const float *w, const float *b, float *ctx, float *alpha,
                         int B, int n, int K, int A, int R, const int32_t *row_img, int N, void *stream);
 
+/* Same, with att_h delivered as the h2att GEMM's K-slice slabs (capmi_gemm_f32, defer_reduce = 1):
+ * att_h[r,:] = sum_{s<h_splits} h_partial[s*h_stride + r*A + :] + h_bias.  The finished rows are also written to
+ * att_h_out [N,A] when given (the backward pass needs them). */
+int capmi_attention_fwd_partial(const float *h_partial, int h_splits, int64_t h_stride, const float *h_bias,
+                                float *att_h_out, const float *p_att, const float *att, const float *mask,
+                                const float *w, const float *b, float *ctx, float *alpha,
+                                int B, int n, int K, int A, int R, const int32_t *row_img, int N, void *stream);
+
 /* backward of the above for one time step.  Inputs d_ctx [N,R] plus the saved att_h/alpha.
  * Outputs d_att_h [N,A] (feeds h2att backward) and d_e [N,K] (softmax-input gradient, kept for the
  * time-batched parameter/feature gradients below). */
@@ -148,6 +156,13 @@ int capmi_lstm_cell_bwd(const float *dh_a, int ld_a, const float *dh_a_mask, con
                         const float *dh_c, int ld_c, const float *dc_next, const float *gates_act,
                         const float *c_prev, const float *c_new, float *d_gates, float *dc_prev, int N, int R,
                         void *stream);
+/* Same, with dh_b and/or dh_c delivered as split-K slabs of the dX GEMMs (capmi_gemm_f32, defer_reduce = 1):
+ * dh_b[r,j] = sum_{s<b_splits} dh_b[s*b_stride + r*ld_b + j] (likewise dh_c); splits = 1 is a plain matrix. */
+int capmi_lstm_cell_bwd_partial(const float *dh_a, int ld_a, const float *dh_a_mask,
+                                const float *dh_b, int ld_b, int b_splits, int64_t b_stride,
+                                const float *dh_c, int ld_c, int c_splits, int64_t c_stride,
+                                const float *dc_next, const float *gates_act, const float *c_prev,
+                                const float *c_new, float *d_gates, float *dc_prev, int N, int R, void *stream);
 
 /* token embedding: x[r,:] = relu(E[it[r],:]) * mask[r,:]  (AttModel.py:74-76,168). relu/mask optional. */
 /* it[r*it_stride] is row r's token; it_save [N] (optional) records the tokens consumed. */
