@@ -62,4 +62,7 @@ int launch_skinny(const KArgs &a, int b_layout, int tm, dim3 grid, hipStream_t s
 int ares_plan(int N, int tiles, int want_blocks, int *splits);
 int launch_ares(const KArgs &a, int b_layout, int ts_max, hipStream_t st, int pcls, double bytes, double flops);
 
+// fat GEMMs through the bf16 pipe by exact 3-way operand splitting; defined in gemm_x3.hip
+int launch_x3(const KArgs &a, int a_layout, int b_layout, dim3 grid, hipStream_t st, int pcls, double bytes, double flops);
+
 }  // namespace capmi_gemm

@@ -445,8 +445,31 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
         if (env_cfg == 64 || env_cfg == 128) BN = env_cfg;                    // experiments: CAPMI_GEMM_CFG=64|128
     } else { BM = 128; BN = 128; }
     const int gm = (d->M + BM - 1) / BM, gn = (d->N + BN - 1) / BN;
+    // fat GEMMs (time-batched BPTT): fp32 through the bf16 pipe by exact 3-way splitting (gemm_x3.hip);
+    // CAPMI_GEMM_X3=0 keeps them on the exact-fp32 MFMA
+    static const int env_x3 = [] { const char *e = getenv("CAPMI_GEMM_X3"); return e ? atoi(e) : 1; }();
+    bool x3_ok = env_x3 && BM == 128 && BN == 128 && BK == 32 && d->nseg == 1 &&
+                 (d->a_layout == 0 || d->M % 4 == 0) && (d->b_layout == 0 || d->N % 4 == 0);   // 4-row quads of [K][rows] operands
+    for (int s = 0; s < d->nseg && x3_ok; ++s)      // branch-free 16-byte staging loads: aligned operands, K % 4 == 0
+        x3_ok = a.seg[s].a_row_div == 1 && a.seg[s].vecA && a.seg[s].vecB && a.seg[s].K % 4 == 0 &&
+                // 32-bit per-lane byte offsets in the staging loads
+                (uint64_t)(d->a_layout == 0 ? d->M : 1) * (uint64_t)a.seg[s].lda * 4 < (1ull << 32) &&
+                (uint64_t)(d->b_layout == 0 ? d->N : 1) * (uint64_t)a.seg[s].ldb * 4 < (1ull << 32);
     int splits = d->splits;
-    if (splits == 0) {
+    if (splits == 0 && x3_ok) {
+        // persistent kernel, one workgroup per CU: pick the K split that minimises (rounds x K tiles per unit) plus the
+        // slab traffic it causes, in units of one K-tile step (~1.5 us; slabs move at ~4 TB/s)
+        const int out_tiles = gm * gn;
+        double best = 1e30;
+        splits = 1;
+        for (int sp = 1; sp <= 16 && sp <= tiles; ++sp) {
+            if (sp > 1 && (!d->partial || (int64_t)sp * d->M * d->N > slab_cap)) break;
+            const double rounds = (double)((out_tiles * sp + 255) / 256);
+            const double slab_us = sp > 1 ? (2.0 * sp + 1.0) * d->M * (double)d->N * 4.0 / 4.0e6 : 0.0;
+            const double cost = rounds * ((tiles + sp - 1) / sp) + slab_us / 1.5;
+            if (cost < best) { best = cost; splits = sp; }
+        }
+    } else if (splits == 0) {
         // aim for ~2 workgroups per CU (512) but keep >= 4 K tiles per slice
         const int blocks = gm * gn;
         splits = 1;
@@ -465,6 +488,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     // kernel at decode sizes (logit 33.5 vs 27.9 us, dX 34.2 vs 27-31 us): opt-in via CAPMI_GEMM_SELF_REDUCE=1.
     static const int env_self = [] { const char *e = getenv("CAPMI_GEMM_SELF_REDUCE"); return e ? atoi(e) : 0; }();
     a.self_reduce = (env_self && splits > 1 && !d->defer_reduce && gn * gm <= CAPMI_WS_COUNTER_FLOATS) ? 1 : 0;
+    if (x3_ok) a.self_reduce = 0;      // the persistent kernel always leaves plain slabs
     if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > slab_cap)) return CAPMI_EINVAL;
     d->splits_used = splits;
     dim3 grid(gn, gm, splits);
@@ -472,7 +496,8 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     int rc;
     static const int env_pf = [] { const char *e = getenv("CAPMI_GEMM_PF"); return e ? atoi(e) : 3; }();
     (void)env_pf;
-    if (BM == 32 && BN == 128) rc = launch_cfg<32, 128, 1, 4, 3>(a, d->a_layout, d->b_layout, grid, st, pi);
+    if (x3_ok) rc = launch_x3(a, d->a_layout, d->b_layout, grid, st, pcls, bytes, flops);
+    else if (BM == 32 && BN == 128) rc = launch_cfg<32, 128, 1, 4, 3>(a, d->a_layout, d->b_layout, grid, st, pi);
     else if (BM == 64 && BN == 64) rc = launch_cfg<64, 64, 2, 2, 3>(a, d->a_layout, d->b_layout, grid, st, pi);
         else if (BM == 64 && BN == 128) rc = launch_cfg<64, 128, 1, 4, 2>(a, d->a_layout, d->b_layout, grid, st, pi);
     else rc = launch_cfg<128, 128, 2, 2, 2>(a, d->a_layout, d->b_layout, grid, st, pi);

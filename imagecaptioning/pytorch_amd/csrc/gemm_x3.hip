@@ -1,0 +1,370 @@
+// fp32 GEMM on the bf16 matrix pipe of gfx950 by exact 3-way operand splitting ("bf16x3"), for the FAT GEMMs of the
+// BPTT (time-batched weight gradients dW = dG^T X and batched input gradients dX = dG W: M, N >= 128, K >= 1000).
+//
+// Why: CDNA4 has no xf32/TF32; v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate (157 TFLOP/s, 1/16 of the bf16
+// rate).  Every fp32 number is EXACTLY the sum of three bf16 numbers obtained by truncation,
+//     x = h + m + l,   h = top 8 mantissa bits of x,  m = top 8 bits of (x - h),  l = x - h - m  (<= 8 bits left),
+// and a product of two bf16 values is exact in fp32, so
+//     a*b = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh) + [am*bl + al*bm + al*bl],
+// where the bracket is <= 3 * 2^-24 |a||b| -- the size of ONE fp32 rounding of the product.  Dropping it and feeding
+// the other six terms to v_mfma_f32_32x32x16_bf16 (fp32 accumulate) gives fp32-grade results (measured against an
+// fp64 reference in tests/test_kernels_gpu.py: same error as the exact-fp32 MFMA kernel) at 6/16 of the
+// matrix-pipe time.  The split costs ~7 VALU ops per element and is done ONCE per element per workgroup, on the way
+// from HBM to LDS; the decode-step GEMMs (each weight used by one wave only) stay on the exact fp32 pipe.
+//
+// Layout: 128x128x32 tile per 256-thread workgroup (4 waves, 64x64 each).  LDS holds three bf16 planes per operand,
+// [128 rows][32 k] with an 80-byte row pitch: a lane's MFMA operand (8 consecutive k of one row) is one
+// conflict-free ds_read_b128; a staged quad (4 consecutive k of one row, 3 planes) is three ds_write_b64.
+// K-major sources ([K][M] gradients / activations of dW = dG^T X) are fetched as 4 k-rows x 1 column per thread
+// (lanes along the contiguous dimension) so the same row-quad store applies without an LDS transpose.
+#include "gemm_common.h"
+#include "profile.h"
+#include <hip/hip_ext.h>
+#include <stdlib.h>
+
+namespace capmi_gemm {
+namespace {
+
+constexpr int XBM = 128, XBN = 128, XP = 40;       // row pitch in bf16 elements (80 bytes)
+constexpr int XPLANE = 128 * XP;                    // bf16 elements per plane
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+static_assert(BK == 32, "gemm_x3 assumes 32-wide K tiles");
+
+// ---- HBM -> registers: 4 quads (row, 4 consecutive k) per thread and operand ----------------------------
+// BRANCH-FREE: out-of-range rows / k are clamped to valid addresses and zeroed by a multiply, so every thread issues
+// exactly 4 (or 16) loads per tile and operand and the compiler keeps them all in flight (guarded loads become
+// branches with an s_waitcnt vmcnt(0) behind each).  Requires 16-byte aligned operands and K % 4 == 0 (host checks).
+// The staging waves share their SIMD's issue slots with the MFMA waves (~5 filler slots per 32-cycle MFMA), so the
+// per-tile instruction count matters: row clamps / validity are computed ONCE (Stager), interior tiles (the common
+// case) skip the zeroing multiplies entirely.
+typedef const float __attribute__((address_space(1))) *gcf;
+typedef const f32x4 __attribute__((address_space(1))) *gcf4;
+
+typedef const char __attribute__((address_space(1))) *gcb;
+
+// Addresses are (workgroup-uniform base: src + k0 ...) + (per-lane 32-bit byte offset fixed per output tile), which the
+// compiler turns into SGPR-base global loads: no per-load 64-bit VALU address arithmetic.
+template <bool KC>
+struct Stager {
+    gcb src;
+    unsigned voff[4];     // KC: byte offset of (clamped row, in-tile k) per quad; k-major: voff[0] = clamped column * 4
+    float keep[4];        // row validity (1 / 0) per quad (k-major: keep[0])
+    int ld, K, kq0;
+    bool edge_rows;       // workgroup-uniform: some rows of this operand tile are out of range
+    __device__ __forceinline__ void init(const float *src_, int ld_, int K_) {
+        src = (gcb)(uintptr_t)src_;      // kernel-argument pointers copied around lose their address space otherwise
+        ld = ld_; K = K_;
+    }
+    __device__ __forceinline__ void set_tile(int row0, int nrows, int tid) {
+        edge_rows = row0 + 128 > nrows;
+        if (KC) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int idx = p * NT + tid;
+                const int row = row0 + idx / 8;
+                voff[p] = ((unsigned)min(row, nrows - 1) * (unsigned)ld + (unsigned)(idx % 8) * 4u) * 4u;
+                keep[p] = row < nrows ? 1.f : 0.f;
+            }
+            kq0 = (tid & 7) * 4;      // NT % 8 == 0: every quad of a thread sits at the same in-tile k
+        } else {
+            // [K][rows] source: thread (kg, mq) takes the 4x4 block k = 4kg..4kg+3, rows 4mq..4mq+3 as four 16-byte loads
+            // along the contiguous dimension (8 lanes = 128 contiguous bytes per k row) and transposes it in registers
+            // into four (row, 4 k) quads.  rows % 4 == 0 (host checks): a quad of rows is entirely valid or invalid.
+            const int lane = tid & 63, kg = lane >> 3, mq = (tid >> 6) * 8 + (lane & 7);
+            const int row = row0 + 4 * mq;
+            voff[0] = ((unsigned)(4 * kg) * (unsigned)ld + (unsigned)min(row, nrows - 4)) * 4u;
+            keep[0] = row < nrows ? 1.f : 0.f;
+            kq0 = 4 * kg;
+        }
+    }
+    __device__ __forceinline__ void fetch(float (&r)[16], int k0) const {
+        const bool interior = !edge_rows && k0 + BK <= K;      // workgroup-uniform
+        if (KC) {
+            if (interior) {
+                gcb b = src + (size_t)k0 * 4;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const f32x4 v = *(gcf4)(b + voff[p]);
+                    r[4 * p] = v[0]; r[4 * p + 1] = v[1]; r[4 * p + 2] = v[2]; r[4 * p + 3] = v[3];
+                }
+            } else {
+                const int over = max(k0 + kq0 - (K - 4), 0);              // clamp this thread's quads to K-4
+                const float kk = (k0 + kq0 < K) ? 1.f : 0.f;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const f32x4 v = *(gcf4)(src + (size_t)(k0 - over) * 4 + voff[p]);
+                    const float kp = kk * keep[p];
+                    r[4 * p] = v[0] * kp; r[4 * p + 1] = v[1] * kp; r[4 * p + 2] = v[2] * kp; r[4 * p + 3] = v[3] * kp;
+                }
+            }
+        } else {
+            f32x4 v[4];
+            if (interior) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = *(gcf4)(src + (size_t)(k0 + j) * ld * 4 + voff[0]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + kq0 + j;
+                    const int back = max(k - (K - 1), 0);                 // clamp the k row to K-1
+                    v[j] = *(gcf4)(src + ((size_t)(k0 + j) - back) * ld * 4 + voff[0]);
+                    v[j] *= (k < K ? keep[0] : 0.f);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[4 * i + j] = v[j][i];       // quad i = row 4mq+i, k = 4kg..4kg+3
+        }
+    }
+};
+
+__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float bfloat(uint32_t b) { return __builtin_bit_cast(float, b); }
+__device__ __forceinline__ uint32_t pack2(uint32_t lo, uint32_t hi) { return (lo >> 16) | (hi & 0xffff0000u); }
+
+// registers -> three bf16 planes in LDS
+template <bool KC>
+__device__ __forceinline__ void x3_r2s(const float (&r)[16], unsigned short *dst, int tid) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int row, kq;
+        if (KC) {
+            const int idx = p * NT + tid;
+            row = idx / 8;
+            kq = (idx % 8) * 4;
+        } else {
+            const int lane = tid & 63;
+            row = 4 * ((tid >> 6) * 8 + (lane & 7)) + p;
+            kq = 4 * (lane >> 3);
+        }
+        uint32_t h[4], m[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = r[4 * p + j];
+            h[j] = fbits(x) & 0xffff0000u;
+            const float r1 = x - bfloat(h[j]);            // exact
+            m[j] = fbits(r1) & 0xffff0000u;
+            l[j] = fbits(r1 - bfloat(m[j]));               // exact, <= 8 significant bits: truncation is lossless
+        }
+        unsigned short *o = dst + row * XP + kq;
+        *reinterpret_cast<u32x2 *>(o) = u32x2{pack2(h[0], h[1]), pack2(h[2], h[3])};
+        *reinterpret_cast<u32x2 *>(o + XPLANE) = u32x2{pack2(m[0], m[1]), pack2(m[2], m[3])};
+        *reinterpret_cast<u32x2 *>(o + 2 * XPLANE) = u32x2{pack2(l[0], l[1]), pack2(l[2], l[3])};
+    }
+}
+
+// 512 threads: waves 0-3 are MFMA waves (64x64 each), waves 4-7 are STAGING waves (HBM -> split -> LDS).  One of
+// each kind sits on every SIMD, so the staging VALU work runs in the shadow of the other wave's MFMAs; two LDS stages
+// ping-pong and ONE workgroup barrier per K tile hands a stage over.  The workgroups are PERSISTENT (one per CU, 120 KB
+// of LDS): each walks a list of (output tile, K slice) units and the staging waves run ahead across unit boundaries,
+// so the HBM latency of a unit's first tiles and the MFMA waves' epilogue stores overlap with useful work.
+constexpr int XNT = 512;
+constexpr int XSTAGE = 6 * XPLANE;            // bf16 elements per stage: 3 planes x (A, B) = 60 KB
+
+struct Unit {
+    int m0, n0, z, t_begin, nt;
+};
+__device__ __forceinline__ Unit unit_of(const KArgs &a, int u, int gm, int gn) {
+    const int per = gm * gn;
+    const int z = u / per, tile = u - z * per;
+    Unit r;
+    r.z = z;
+    r.m0 = (tile / gn) * XBM;
+    r.n0 = (tile % gn) * XBN;
+    r.t_begin = (int)(((long long)a.tiles_total * z) / a.splits);
+    r.nt = (int)(((long long)a.tiles_total * (z + 1)) / a.splits) - r.t_begin;
+    return r;
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(XNT) void gemm_x3_kernel(const KArgs a, int gm, int gn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];      // 2 stages = 120 KB
+    const int units = gm * gn * a.splits;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+
+    if (wid >= 4) {
+        // ---------------- staging waves ----------------
+        const int tid = threadIdx.x - NT;
+        float ra0[16], rb0[16], ra1[16], rb1[16];          // pipeline step g lives in register set g & 1
+        // single K segment (host checks): a dynamically indexed segment table would be spilled to scratch
+        Stager<AKC> sa;
+        Stager<BKC> sb;
+        sa.init(a.seg[0].A, a.seg[0].lda, a.seg[0].K);
+        sb.init(a.seg[0].B, a.seg[0].ldb, a.seg[0].K);
+        // fetch cursor: runs up to 3 steps ahead of the step being consumed, across unit boundaries
+        int fu = blockIdx.x, ft = 0, f_t0 = 0, f_nt = 0;
+        if (fu < units) {
+            const Unit un = unit_of(a, fu, gm, gn);
+            f_t0 = un.t_begin; f_nt = un.nt;
+            sa.set_tile(un.m0, a.M, tid);
+            sb.set_tile(un.n0, a.N, tid);
+        }
+        auto fetch = [&](float (&xa)[16], float (&xb)[16]) {
+            if (fu >= units) return;
+            if (!(a.ablate & 2)) {
+                sa.fetch(xa, (f_t0 + ft) * BK);
+                sb.fetch(xb, (f_t0 + ft) * BK);
+            }
+            if (++ft == f_nt) {
+                fu += gridDim.x;
+                ft = 0;
+                if (fu < units) {
+                    const Unit un = unit_of(a, fu, gm, gn);
+                    f_t0 = un.t_begin; f_nt = un.nt;
+                    sa.set_tile(un.m0, a.M, tid);
+                    sb.set_tile(un.n0, a.N, tid);
+                }
+            }
+        };
+        int steps = 0;
+        for (int u = blockIdx.x; u < units; u += gridDim.x) steps += unit_of(a, u, gm, gn).nt;
+        auto store = [&](const float (&xa)[16], const float (&xb)[16], int g) {
+            if (a.ablate & 4) return;
+            unsigned short *st = smem + (g & 1) * XSTAGE;
+            x3_r2s<AKC>(xa, st, tid);
+            x3_r2s<BKC>(xb, st + 3 * XPLANE, tid);
+        };
+        fetch(ra0, rb0);                                   // step 0
+        fetch(ra1, rb1);                                   // step 1
+        if (steps > 0) store(ra0, rb0, 0);
+        fetch(ra0, rb0);                                   // step 2
+        __syncthreads();                                   // stage 0 ready
+        // while the MFMA waves consume step g (stage g&1) we publish step g+1 and fetch step g+3 into its registers
+        for (int g = 0; g < steps; g += 2) {
+            if (g + 1 < steps) store(ra1, rb1, g + 1);
+            fetch(ra1, rb1);
+            __syncthreads();
+            if (g + 1 < steps) {
+                if (g + 2 < steps) store(ra0, rb0, g + 2);
+                fetch(ra0, rb0);
+                __syncthreads();
+            }
+        }
+        return;
+    }
+
+    // ---------------- MFMA waves ----------------
+    const int wm0 = ((wid >> 1) & 1) * 64, wn0 = (wid & 1) * 64;
+    const int l31 = lane & 31, half = lane >> 5;
+    __syncthreads();                                       // stage 0 ready
+    int g = 0;
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        const Unit un = unit_of(a, u, gm, gn);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int i = 0; i < un.nt; ++i, ++g) {
+            const unsigned short *As = smem + (g & 1) * XSTAGE, *Bs = As + 3 * XPLANE;
+            if (!(a.ablate & 1))
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 av[2][3], bv[2][3];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        av[q][pl] = *reinterpret_cast<const bf16x8 *>(As + pl * XPLANE + (wm0 + 32 * q + l31) * XP + 16 * ks + 8 * half);
+                        bv[q][pl] = *reinterpret_cast<const bf16x8 *>(Bs + pl * XPLANE + (wn0 + 32 * q + l31) * XP + 16 * ks + 8 * half);
+                    }
+                // six of the nine cross terms, small ones first (planes: 0 = h, 1 = m, 2 = l)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][2], bv[j][0], acc[q][j], 0, 0, 0);
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][2], acc[q][j], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][1], acc[q][j], 0, 0, 0);
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][0], acc[q][j], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][1], acc[q][j], 0, 0, 0);
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][0], acc[q][j], 0, 0, 0);
+                    }
+            }
+            __syncthreads();                               // stage g&1 released, stage (g+1)&1 ready
+        }
+
+        // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        const bool to_partial = a.to_partial != 0;
+        float *out = to_partial ? a.partial + (size_t)un.z * a.M * a.N : a.C;
+        const int ldo = to_partial ? a.N : a.ldc;
+        const bool plain = to_partial || !(a.bias || a.bias2 || a.row_bias || a.relu || a.mul_mask || a.accumulate);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = un.n0 + wn0 + 32 * j + l31;
+                if (col >= a.N) continue;
+                if (plain) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = un.m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (row < a.M) out[(size_t)row * ldo + col] = acc[i][j][r];
+                    }
+                    continue;
+                }
+                float cb = 0.f;
+                if (a.bias) cb += a.bias[col];
+                if (a.bias2) cb += a.bias2[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = un.m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row >= a.M) continue;
+                    float v = acc[i][j][r] + cb;
+                    if (a.row_bias) v += a.row_bias[(size_t)(row / a.row_bias_div) * a.N + col];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    if (a.mul_mask) v *= a.mul_mask[(size_t)row * a.N + col];
+                    if (a.accumulate) v += out[(size_t)row * ldo + col];
+                    out[(size_t)row * ldo + col] = v;
+                }
+            }
+    }
+}
+
+}  // namespace
+
+int launch_x3(const KArgs &a, int a_layout, int b_layout, dim3 tiles, hipStream_t st, int pcls, double bytes, double flops) {
+    // tiles = (gn, gm, splits) of the 128x128 tiling; persistent grid: one workgroup per CU walks the unit list
+    const int gn = tiles.x, gm = tiles.y;
+    const int units = gn * gm * a.splits;
+    static const int env_wg = [] { const char *e = getenv("CAPMI_X3_WGS"); return e ? atoi(e) : 256; }();
+    const dim3 grid(units < env_wg ? units : env_wg);
+    hipEvent_t e0, e1;
+    const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
+    constexpr size_t lds = 2 * (size_t)XSTAGE * sizeof(unsigned short);
+#define CAPMI_X3(AK, BK_)                                                                                       \
+    do {                                                                                                        \
+        static bool attr_set = false;                                                                           \
+        if (!attr_set) {                                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_x3_kernel<AK, BK_>),                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+            attr_set = true;                                                                                    \
+        }                                                                                                       \
+        if (prof) hipExtLaunchKernelGGL((gemm_x3_kernel<AK, BK_>), grid, dim3(XNT), lds, st, e0, e1, 0, a, gm, gn);     \
+        else hipLaunchKernelGGL((gemm_x3_kernel<AK, BK_>), grid, dim3(XNT), lds, st, a, gm, gn);                        \
+    } while (0)
+    if (a_layout == 0 && b_layout == 0) CAPMI_X3(true, true);
+    else if (a_layout == 0 && b_layout == 1) CAPMI_X3(true, false);
+    else if (a_layout == 1 && b_layout == 1) CAPMI_X3(false, false);
+    else CAPMI_X3(false, true);
+#undef CAPMI_X3
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace capmi_gemm
