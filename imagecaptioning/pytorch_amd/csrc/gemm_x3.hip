@@ -7,16 +7,18 @@
 // and a product of two bf16 values is exact in fp32, so
 //     a*b = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh) + [am*bl + al*bm + al*bl],
 // where the bracket is <= 3 * 2^-24 |a||b| -- the size of ONE fp32 rounding of the product.  Dropping it and feeding
-// the other six terms to v_mfma_f32_32x32x16_bf16 (fp32 accumulate) gives fp32-grade results (measured against an
-// fp64 reference in tests/test_kernels_gpu.py: same error as the exact-fp32 MFMA kernel) at 6/16 of the
-// matrix-pipe time.  The split costs ~7 VALU ops per element and is done ONCE per element per workgroup, on the way
-// from HBM to LDS; the decode-step GEMMs (each weight used by one wave only) stay on the exact fp32 pipe.
+// the other six terms to v_mfma_f32_32x32x16_bf16 (fp32 accumulate) gives fp32-grade results: against an fp64 reference
+// the error is the same as the exact-fp32 MFMA kernel's and below the vendor fp32 matmul's, also on operands with a
+// wide dynamic range (tests/test_kernels_gpu.py::test_gemm_fat_bf16x3_is_fp32_grade, tools_x3_accuracy.py) -- at 6/16
+// of the matrix-pipe time.  The split costs ~5 VALU ops per element and is done ONCE per element per workgroup, on the
+// way from HBM to LDS; the decode-step GEMMs (each weight used by one wave only) stay on the exact fp32 pipe.
+// CAPMI_GEMM_X3=0 routes the fat GEMMs back to the exact-fp32 kernel.
 //
-// Layout: 128x128x32 tile per 256-thread workgroup (4 waves, 64x64 each).  LDS holds three bf16 planes per operand,
-// [128 rows][32 k] with an 80-byte row pitch: a lane's MFMA operand (8 consecutive k of one row) is one
-// conflict-free ds_read_b128; a staged quad (4 consecutive k of one row, 3 planes) is three ds_write_b64.
-// K-major sources ([K][M] gradients / activations of dW = dG^T X) are fetched as 4 k-rows x 1 column per thread
-// (lanes along the contiguous dimension) so the same row-quad store applies without an LDS transpose.
+// Layout: 128x128x32 tile per 512-thread workgroup.  LDS holds three bf16 planes per operand, [128 rows][32 k] with
+// an 80-byte row pitch: a lane's MFMA operand (8 consecutive k of one row) is one conflict-free ds_read_b128; a staged
+// quad (4 consecutive k of one row, 3 planes) is three ds_write_b64.  K-major sources ([K][M] gradients / activations
+// of dW = dG^T X) are fetched as 4x4 blocks (16-byte loads along the contiguous dimension) and transposed in
+// registers, so the same row-quad store applies without an LDS transpose.
 #include "gemm_common.h"
 #include "profile.h"
 #include <hip/hip_ext.h>

@@ -38,6 +38,27 @@ def test_gemm_nt_linear(dev, M, N, K):
     assert rel_err(out, ref) < (2e-6 if K <= 4096 else 6e-6)
 
 
+@pytest.mark.parametrize('M,N,K,al,bl', [(4000, 1000, 1200, 1, 1), (1200, 1000, 4000, 0, 1), (512, 768, 4096, 0, 0),
+                                        (520, 260, 1028, 1, 0)])
+def test_gemm_fat_bf16x3_is_fp32_grade(dev, M, N, K, al, bl):
+    """Fat GEMMs (M, N >= 128) run on the bf16 pipe through the exact 3-way operand split (gemm_x3.hip).  Against an
+    fp64 reference, and on operands with a wide dynamic range, the error must be that of an fp32 GEMM: we allow
+    1.5x the error of the vendor fp32 matmul on the same inputs (measured: 0.3x - 0.8x)."""
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn((K, M) if al else (M, K), generator=g)
+    A = (A * torch.exp(2.0 * torch.randn(A.shape, generator=g))).to(dev)
+    B = torch.randn((K, N) if bl else (N, K), generator=g).to(dev)
+    out = torch.empty(M, N, device=dev)
+    ops.gemm([(A, M if al else K, B, N if bl else K, K, 1)], M, N, out, a_layout=al, b_layout=bl)
+    A2, B2 = (A.t() if al else A), (B if bl else B.t())
+    ref = A2.double() @ B2.double()
+    mag = A2.double().abs() @ B2.double().abs()
+    e_ours = float(((out.double() - ref).abs() / mag).max())
+    e_fp32 = float((((A2 @ B2).double() - ref).abs() / mag).max())
+    assert e_ours <= 1.5 * e_fp32 + 1e-7, (e_ours, e_fp32)
+
+
 def test_gemm_multisegment_rowdiv_and_deferred_partials(dev):
     """[h | fc(row//n) | x] x [W0 | W1 | W2] with split-K partials consumed by the LSTM-cell kernel."""
     ops = ops_mod()
