@@ -146,6 +146,8 @@ SIGNATURES = {
     'capmi_updown_rollout_fwd': [C.POINTER(UpDownWeights), C.POINTER(UpDownRollout), _P],
     'capmi_updown_rollout_bwd': [C.POINTER(UpDownWeights), C.POINTER(UpDownRollout), _P, C.POINTER(UpDownBwdScratch),
                                  C.POINTER(UpDownGrads), _P],
+    'capmi_updown_rollout_bwd_phases': [C.POINTER(UpDownWeights), C.POINTER(UpDownRollout), _P, C.POINTER(UpDownBwdScratch),
+                                 C.POINTER(UpDownGrads), _I, _P],
 }
 
 

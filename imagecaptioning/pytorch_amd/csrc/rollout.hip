@@ -153,7 +153,12 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
 
 int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_rollout *r, const float *g_seq_logp,
                              capmi_updown_bwd_scratch *s, capmi_updown_grads *g, void *stream) {
-    if (!w || !r || !g_seq_logp || !s || !g) return CAPMI_EINVAL;
+    return capmi_updown_rollout_bwd_phases(w, r, g_seq_logp, s, g, CAPMI_BWD_ALL, stream);
+}
+
+int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_updown_rollout *r, const float *g_seq_logp,
+                                    capmi_updown_bwd_scratch *s, capmi_updown_grads *g, int phases, void *stream) {
+    if (!w || !r || !g_seq_logp || !s || !g || !(phases & CAPMI_BWD_ALL)) return CAPMI_EINVAL;
     const int B = r->B, n = r->n, N = r->N, K = r->K, A = r->A, R = r->R, E = r->E, V1 = r->V1, T = r->T, L = r->L;
     hipStream_t st = (hipStream_t)stream;
     const size_t NR = (size_t)N * R;
@@ -163,8 +168,8 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
     const int64_t cap = s->partial_capacity;
 
     // ---- logit layer, batched over all T*N rows ----------------------------------------------
-    RC(capmi_logsoftmax_bwd(g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
-    {
+    if (phases & CAPMI_BWD_LOGIT) {
+        RC(capmi_logsoftmax_bwd(g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
         SegSpec a{s->dlogits, V1, w->logit_w, R, V1, 1};   // d_hdrop = dlogits W_logit          [TN,R]
         RC(gemm(stream, 0, 1, TN, R, s->d_hdrop, R, &a, 1, P, cap, 0, nullptr));
         SegSpec b{s->dlogits, V1, r->h_drop, R, TN, 1};     // dW_logit = dlogits^T h_drop         [V1,R]
@@ -175,7 +180,7 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
     // ---- pack the recurrent weight slices once: [W_ih | W_hh] side by side, so that each step needs ONE
     //      dX GEMM per LSTM instead of two (+ their split-K reductions): 80 MB of copies per BPTT buys back
     //      ~80 launches.
-    {
+    if (phases & CAPMI_BWD_RECURRENT) {
         hipError_t e;
         const size_t fb = sizeof(float);
         if ((e = hipMemcpy2DAsync(s->w_lang_cat, 3 * R * fb, w->lang_w_ih, 2 * R * fb, 2 * R * fb, 4 * R,
@@ -194,6 +199,7 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
     // per step disappear; d_x1 is never materialised).  d_x2 keeps its reduce: three kernels and the batched pass read it.
     const int64_t cap1 = (cap / 4) & ~(int64_t)1023, caph = (cap / 8) & ~(int64_t)1023, capm = cap - cap1 - caph;
     float *P1 = P + capm, *Ph = P + capm + cap1;
+    if (phases & CAPMI_BWD_RECURRENT) {
     if (capm <= CAPMI_WS_COUNTER_FLOATS || cap1 <= CAPMI_WS_COUNTER_FLOATS || caph <= CAPMI_WS_COUNTER_FLOATS) return CAPMI_EINVAL;
     {   // ticket words of the carved regions start zeroed like the main one
         hipError_t e = hipMemsetAsync(P1, 0, CAPMI_WS_COUNTER_FLOATS * sizeof(float), st);
@@ -247,9 +253,11 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
         }
     }
 
+    }   // CAPMI_BWD_RECURRENT
+
     // ---- time-batched parameter / feature gradients --------------------------------------------
     // attention LSTM
-    {
+    if (phases & CAPMI_BWD_ATT_LSTM) {
         SegSpec a{s->dg_att, 4 * R, r->h_lang, R, TN, 1};          // x h_lang_prev  (slots 0..T-1)
         RC(gemm(stream, 1, 1, 4 * R, R, g->att_w_ih, ld_att_ih, &a, 1, P, cap, 0, nullptr));
         SegSpec b{s->dg_att, 4 * R, r->xt, E, TN, 1};              // x xt
@@ -275,7 +283,7 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
         RC(capmi_embed_bwd(r->it_all, s->d_xt_all, r->xt, r->drop_xt, g->embed, TN, E, 1, stream));
     }
     // language LSTM
-    {
+    if (phases & CAPMI_BWD_LANG_LSTM) {
         SegSpec a{s->dg_lang, 4 * R, r->ctx, R, TN, 1};
         RC(gemm(stream, 1, 1, 4 * R, R, g->lang_w_ih, 2 * R, &a, 1, P, cap, 0, nullptr));
         SegSpec b{s->dg_lang, 4 * R, r->h_att + NR, R, TN, 1};      // h_att of the same step (slots 1..T)
@@ -287,7 +295,7 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
         if (e != hipSuccess) return (int)e;
     }
     // attention parameters / features
-    {
+    if (phases & CAPMI_BWD_ATTENTION) {
         SegSpec a{s->d_att_h_all, A, r->h_att + NR, R, TN, 1};
         RC(gemm(stream, 1, 1, A, R, g->h2att_w, R, &a, 1, P, cap, 0, nullptr));
         RC(capmi_colsum(s->d_att_h_all, TN, A, A, g->h2att_b, 0, stream));

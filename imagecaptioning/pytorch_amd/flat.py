@@ -38,6 +38,7 @@ class FlatParams:
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_count = 0
+        self.on_grads_ready = None      # set by begin_overlap(); native backwards call it per finished bucket
 
     def begin_backward(self):
         """Called by a native backward BEFORE it overwrites the flat gradient views.  Returns a stash of gradients
@@ -68,6 +69,48 @@ class FlatParams:
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
             p.grad = v
+
+    # ---- bucketed all-reduce overlapped with the backward ------------------------------------------------------
+    # The BPTT finishes its gradients in a known order (logit layer first, recurrent weights after the time loop).
+    # Each finished bucket is a contiguous slice of the flat buffer; its all-reduce is launched asynchronously (RCCL
+    # runs it on its own stream, after the launches enqueued so far) while the remaining backward phases compute.
+    def begin_overlap(self, group=None, world_size=None):
+        import torch.distributed as dist
+        self._ov = dict(group=group, ws=world_size or dist.get_world_size(group), works=[], done=[])
+        self.on_grads_ready = self._bucket_ready
+
+    def _bucket_ready(self, names):
+        """all-reduce the flat ranges covering `names` (all final): parameters adjacent in the buffer share a launch."""
+        import torch.distributed as dist
+        ov = self._ov
+        idx = sorted(self.names.index(n) for n in names)
+        run = [idx[0]]
+        for i in idx[1:] + [None]:
+            if i is not None and i == run[-1] + 1:
+                run.append(i)
+                continue
+            lo = self.offsets[run[0]]
+            hi = self.offsets[run[-1]] + (self.params[run[-1]].numel() + 3) // 4 * 4
+            ov['works'].append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=ov['group'], async_op=True))
+            ov['done'].append((lo, hi))
+            run = [i]
+
+    def finish_overlap(self):
+        """Reduce whatever no bucket covered, wait for all collectives (stream-side), return the 1/world scale."""
+        import torch.distributed as dist
+        ov = self._ov
+        pos = 0
+        for lo, hi in sorted(ov['done']) + [(self.total, self.total)]:
+            if lo > pos:
+                ov['works'].append(dist.all_reduce(self.grad[pos:lo], op=dist.ReduceOp.SUM, group=ov['group'],
+                                                   async_op=True))
+            pos = max(pos, hi)
+        for w in ov['works']:
+            w.wait()
+        n_coll = len(ov['works'])
+        ov['works'], ov['done'] = [], []
+        self.last_collectives = n_coll
+        return 1.0 / ov['ws']
 
     def all_reduce(self, group=None, world_size=None):
         """ONE collective for the whole model (RCCL over xGMI when backend == 'nccl'); averages."""

@@ -41,6 +41,8 @@ def train(opt):
     if opt.start_from:
         model.load_state_dict(torch.load(os.path.join(opt.start_from, 'model.pth'), map_location=dev))
     flat = model.flatten_parameters_()
+    if world > 1:
+        flat.begin_overlap()
     lw_model = LossWrapper(model, opt)
     model.train()
     sc_ready = False
@@ -62,7 +64,7 @@ def train(opt):
         flat.zero_grad()
         loss.backward()
         flat.collect_grads()
-        scale = flat.all_reduce() if world > 1 else 1.0
+        scale = flat.finish_overlap() if world > 1 else 1.0     # buckets finished by the backward are already in flight
         flat.adam_step(opt.learning_rate, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
                        clip_value=opt.grad_clip_value if opt.grad_clip_mode == 'value' else 0.0, grad_scale=scale)
         train_loss = loss.item()

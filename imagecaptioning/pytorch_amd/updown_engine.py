@@ -166,16 +166,28 @@ class Rollout:
         check(lib.capmi_updown_rollout_fwd(C.byref(self.w), C.byref(self.r), stream_ptr()), 'capmi_updown_rollout_fwd')
         return self.seq, self.seq_logp
 
-    def backward(self, g_seq_logp, grads):
+    # backward phases in launch order with the parameter gradients each one completes (capmi.h CAPMI_BWD_*)
+    BWD_PHASES = ((1, ('logit.weight', 'logit.bias')),
+                  (2, ()),
+                  (4, ('core.lang_lstm.weight_ih', 'core.lang_lstm.weight_hh', 'core.lang_lstm.bias_ih',
+                       'core.lang_lstm.bias_hh')),
+                  (8, ('core.att_lstm.weight_ih', 'core.att_lstm.weight_hh', 'core.att_lstm.bias_ih',
+                       'core.att_lstm.bias_hh', 'embed.0.weight')),
+                  (16, ('core.attention.h2att.weight', 'core.attention.h2att.bias', 'core.attention.alpha_net.weight',
+                        'core.attention.alpha_net.bias')))
+
+    def backward(self, g_seq_logp, grads, on_ready=None):
         """g_seq_logp [N,L,V1].  grads: dict name -> preallocated fp32 tensor (overwritten) for every
-        PARAM_KEYS entry.  Also returns (d_fc, d_att, d_p_att) consumed by prepare_backward."""
+        PARAM_KEYS entry.  Also returns (d_fc, d_att, d_p_att) consumed by prepare_backward.
+        on_ready(names): called after the launches that complete the gradients `names` have been enqueued, so a
+        data-parallel trainer can start reducing that bucket while the later phases still run."""
         B, n, N, K, A, R, E, V1, T, L = self.dims
         dev = self.seq.device
         z = lambda *s: torch.empty(*s, dtype=_f32, device=dev)       # noqa: E731
         s = _lib.UpDownBwdScratch()
         keep = dict(dlogits=z(T, N, V1), d_hdrop=z(T, N, R), dg_att=z(T, N, 4 * R), dg_lang=z(T, N, 4 * R),
                     d_x2=z(T, N, 3 * R), d_e_all=z(T, N, K), d_att_h_all=z(T, N, A), dh_att_attn=z(N, R),
-                    d_x1=z(T, N, 2 * R), dc_att=z(2, N, R), dc_lang=z(2, N, R), d_xt_all=z(T, N, E),
+                    d_x1=z(4), dc_att=z(2, N, R), dc_lang=z(2, N, R), d_xt_all=z(T, N, E),
                     sum_dg_att=z(B, 4 * R), w_lang_cat=z(4 * R, 3 * R), w_att_cat=z(4 * R, 2 * R))
         for k, t in keep.items():
             setattr(s, k, t.data_ptr())
@@ -186,7 +198,14 @@ class Rollout:
         d_fc, d_att, d_p_att = z(B, R), z(B, K, R), z(B, K, A)
         g.d_fc, g.d_att, g.d_p_att = d_fc.data_ptr(), d_att.data_ptr(), d_p_att.data_ptr()
         g_seq_logp = g_seq_logp.contiguous()
-        check(lib.capmi_updown_rollout_bwd(C.byref(self.w), C.byref(self.r), ptr(g_seq_logp), C.byref(s), C.byref(g),
-                                           stream_ptr()), 'capmi_updown_rollout_bwd')
+        if on_ready is None:
+            check(lib.capmi_updown_rollout_bwd(C.byref(self.w), C.byref(self.r), ptr(g_seq_logp), C.byref(s), C.byref(g),
+                                               stream_ptr()), 'capmi_updown_rollout_bwd')
+        else:
+            for mask, names in self.BWD_PHASES:
+                check(lib.capmi_updown_rollout_bwd_phases(C.byref(self.w), C.byref(self.r), ptr(g_seq_logp), C.byref(s),
+                                                          C.byref(g), mask, stream_ptr()), 'capmi_updown_rollout_bwd_phases')
+                if names:
+                    on_ready(names)
         self._bwd_keep = keep     # keep scratch alive until the stream has consumed it
         return d_fc, d_att, d_p_att

@@ -373,6 +373,24 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
                              const float *g_seq_logp, capmi_updown_bwd_scratch *s,
                              capmi_updown_grads *g, void *stream);
 
+/* The same backward in separately callable phases, in this order, so that a data-parallel caller can start the
+ * all-reduce of a gradient bucket while later phases still compute (phases is a bit mask; a full backward is
+ * CAPMI_BWD_ALL or the five phases one after the other on the same stream):
+ *   LOGIT      -> g->logit_w, logit_b (and d_hdrop for the recurrent part)
+ *   RECURRENT  -> the BPTT loop (no parameter gradient yet)
+ *   LANG_LSTM  -> g->lang_w_ih, lang_w_hh, lang_b_ih, lang_b_hh
+ *   ATT_LSTM   -> g->att_w_ih, att_w_hh, att_b_ih, att_b_hh, embed, d_fc
+ *   ATTENTION  -> g->h2att_w, h2att_b, alpha_w, alpha_b, d_att, d_p_att */
+#define CAPMI_BWD_LOGIT 1
+#define CAPMI_BWD_RECURRENT 2
+#define CAPMI_BWD_LANG_LSTM 4
+#define CAPMI_BWD_ATT_LSTM 8
+#define CAPMI_BWD_ATTENTION 16
+#define CAPMI_BWD_ALL 31
+int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_updown_rollout *r,
+                                    const float *g_seq_logp, capmi_updown_bwd_scratch *s,
+                                    capmi_updown_grads *g, int phases, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Batched beam search for the UpDown decoder, entirely on the device (AttModel._sample_beam
  * AttModel.py:218-256 + CaptionModel.beam_search CaptionModel.py:35-209, group_size 1).

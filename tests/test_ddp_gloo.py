@@ -52,6 +52,52 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_buckets(rank, world, port, q):
+    """bucketed variant: buckets announced out of buffer order (as the BPTT finishes them), leftovers reduced at the
+    end; the result must equal the single flat all-reduce and no element may be reduced twice."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from imagecaptioning.pytorch_amd.flat import FlatParams
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    flat = FlatParams(net)
+    flat.begin_overlap()
+    g = torch.Generator().manual_seed(100 + rank)
+    for n, p in zip(flat.names, flat.params):          # a native backward writes straight into the flat views
+        flat.grad_views[n].copy_(torch.randn(p.shape, generator=g) * (rank + 1))
+    local = flat.grad.clone()
+    flat.end_backward()
+    flat.on_grads_ready(['2.weight', '2.bias'])        # last layer first (adjacent -> one collective)
+    flat.on_grads_ready(['0.bias', '1.bias'])          # two non-adjacent parameters -> two collectives
+    flat.collect_grads()
+    scale = flat.finish_overlap()                      # leftovers: 0.weight, 1.weight
+    q.put((rank, local, flat.grad.clone() * scale, flat.last_collectives))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlapped_allreduce_equals_flat_allreduce():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_buckets, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, local, avg, n_coll = q.get(timeout=120)
+        got[rank] = (local, avg, n_coll)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = (got[0][0] + got[1][0]) / 2
+    for r in range(world):
+        assert torch.allclose(got[r][1], want, atol=1e-6)
+        assert got[r][2] == 5            # 1 + 2 announced buckets, 2 leftover gaps
+
+
 def test_single_flat_allreduce_averages_gradients():
     world = 2
     port = _free_port()

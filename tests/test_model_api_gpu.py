@@ -58,6 +58,31 @@ def test_xe_forward_backward_through_autograd(flatten):
     assert set(sd.keys()) == {k[2:] for k in z.files if k.startswith('P.')}
 
 
+def test_phased_backward_announces_buckets_and_equals_single_call():
+    """Data-parallel overlap hook: the BPTT run phase by phase (capmi_updown_rollout_bwd_phases) must give the same
+    gradients as the single call and announce every bucket exactly once, logit layer first."""
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import LanguageModelCriterion
+    grads, seen = [], []
+    for phased in (False, True):
+        z, model = golden_model(True)
+        model.train()
+        if phased:
+            model._flat.on_grads_ready = lambda names: seen.append(tuple(names))
+        fc, att = torch.from_numpy(z['fc']).to(DEV), torch.from_numpy(z['att']).to(DEV)
+        am = torch.from_numpy(z['att_masks']).to(DEV)
+        labels, masks = torch.from_numpy(z['labels']).to(DEV), torch.from_numpy(z['masks']).to(DEV)
+        loss = LanguageModelCriterion()(model(fc, att, labels[..., :-1], am), labels[..., 1:], masks[..., 1:])
+        loss.backward()
+        grads.append(model._flat.grad.clone())
+    # (the embedding scatter and the alpha_net reduction use fp32 atomics: equal up to summation order)
+    torch.testing.assert_close(grads[0], grads[1], rtol=1e-5, atol=1e-7)
+    assert seen[0] == ('logit.weight', 'logit.bias')
+    flat_names = [n for names in seen for n in names]
+    assert len(flat_names) == len(set(flat_names))
+    assert {'core.att_lstm.weight_ih', 'core.lang_lstm.weight_hh', 'embed.0.weight',
+            'core.attention.h2att.weight'} <= set(flat_names)
+
+
 def test_greedy_sample_api_and_label_smoothing():
     from imagecaptioning.pytorch_amd.captioning.modules.losses import LabelSmoothing
     z, model = golden_model(False)
