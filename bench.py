@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA (v_mfma_f32_32x32x2_f32), 155 TF measured
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (32x32x16), 2495 TF measured
 
 
 def pmc_traffic():
@@ -149,22 +150,26 @@ def main():
                      'note': 'full per-kernel table: profiles/r01*_scst_kernel_stats.md (rocprofv3 --kernel-trace --stats)'}
         ach = (g_bytes / g_n) / (g_ms / g_n * 1e-3) / 1e9 if g_n else 0.0
         tfl = g_flops / (g_ms * 1e-3) / 1e12 if g_ms else 0.0
-        # which roof bounds this launch mix: fp32 MFMA runs at 1/16 of the bf16 rate (157.3 TFLOP/s dense), so at
-        # 60 caption rows the weight stream's 30 flop/byte is already above the 19.7 flop/byte machine balance
+        # which roof bounds this launch mix.  The decode GEMMs compute fp32 through the bf16 pipe by the exact 3-way
+        # split (6 bf16 MFMAs per fp32 MAC tile): fp32-equivalent matrix peak = 2500 / 6 = 417 TFLOP/s, machine balance
+        # 52 flop/byte, above the 30 flop/byte of a 60-row weight stream -> HBM-bound.  With CAPMI_ARES_X3=0 they run on
+        # the exact-fp32 MFMA (157.3 TFLOP/s, balance 19.7 flop/byte) and are MFMA-bound.
+        x3 = os.environ.get('CAPMI_ARES_X3', '1') != '0'
+        mfma_peak = MFMA_BF16_PEAK_TFLOPS / 6.0 if x3 else MFMA_F32_PEAK_TFLOPS
         ai = g_flops / g_bytes if g_bytes else 0.0
-        mfma_bound = ai > MFMA_F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-        roofline = {'kernel': 'gemm_ares (decode-step weight streaming, M<=64, activations resident in LDS, '
-                              'v_mfma_f32_32x32x2_f32)',
+        mfma_bound = ai > mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+        roofline = {'kernel': 'gemm_ares (decode-step weight streaming, M<=64, activations resident in LDS, %s)'
+                              % ('fp32 via exact bf16x3 split, v_mfma_f32_32x32x16_bf16' if x3 else 'v_mfma_f32_32x32x2_f32'),
                     'bound': 'mfma' if mfma_bound else 'hbm',
                     'achieved': round(tfl if mfma_bound else ach, 2),
-                    'peak': MFMA_F32_PEAK_TFLOPS if mfma_bound else HBM_PEAK_GBS,
+                    'peak': round(mfma_peak, 1) if mfma_bound else HBM_PEAK_GBS,
                     'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
-                    'frac': round(tfl / MFMA_F32_PEAK_TFLOPS if mfma_bound else ach / HBM_PEAK_GBS, 4),
+                    'frac': round(tfl / mfma_peak if mfma_bound else ach / HBM_PEAK_GBS, 4),
                     'traffic': pmc_traffic(), 'avg_launch_us': round(g_ms / max(g_n, 1) * 1e3, 2),
                     'algorithmic_bytes_per_launch': round(g_bytes / max(g_n, 1)),
                     'algorithmic_flops_per_launch': round(g_flops / max(g_n, 1)),
                     'flop_per_byte': round(ai, 2), 'hbm_gbs': round(ach, 1), 'hbm_frac': round(ach / HBM_PEAK_GBS, 4),
-                    'mfma_tflops': round(tfl, 2), 'mfma_frac': round(tfl / MFMA_F32_PEAK_TFLOPS, 4)}
+                    'mfma_tflops': round(tfl, 2), 'mfma_frac': round(tfl / mfma_peak, 4), 'mfma_peak_tflops': round(mfma_peak, 1)}
         a_ach = (a_bytes / a_n) / (a_ms / a_n * 1e-3) / 1e9 if a_n else 0.0
         attention = {'kernel': 'attention_fwd (fused score+softmax+context, one workgroup per image)', 'bound': 'hbm',
                      'achieved': round(a_ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -180,6 +185,8 @@ def main():
             'unit': 'captions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'numerics': 'fp32 storage and accumulation; GEMMs on the bf16 matrix pipe through an exact 3-way operand split '
+                        '(fp32-grade error, DESIGN.md 4); CAPMI_GEMM_X3=0 CAPMI_ARES_X3=0 selects the exact-fp32 MFMA',
             'config': {'workload': 'UpDown SCST (BASELINE configs[2]): per-GPU batch 10 x train_sample_n 5, 36x2048 '
                                    'bottom-up feats, R=E=1000 A=512, vocab 9487, seq_len 20, greedy baseline + CIDEr-D + '
                                    'RewardCriterion + BPTT + clip 0.1 + Adam',

@@ -34,6 +34,10 @@ constexpr int AR_NT = 512;        // 8 waves: 4 column groups x 2 K halves
 
 // One 32-wide K chunk of the slice, resolved once per workgroup into LDS so neither the staging loop nor the
 // weight stream indexes the kernel-argument segment table per lane (that became dependent global loads).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 struct TileRef {
     const float *A, *B;     // segment base + k0 (A: column offset; B: column offset [N][K] / row offset [K][N])
     int lda, ldb;
@@ -79,14 +83,17 @@ __device__ __forceinline__ void load_b(float (&b)[16], const TileRef *tp, int co
 }
 
 // TM = 1: M <= 32 (one accumulator chain, 32 staged rows); TM = 2: M <= 64
-template <bool BKC, int TS, int TM>
+template <bool BKC, int TS, int TM, bool X3>
 __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
     constexpr int ROWS = 32 * TM;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SL = 2 * TS;                  // K chunks per workgroup slice: waves 0-3 take [0,TS), waves 4-7 [TS,2TS)
-    constexpr int pitch = SL * 32 + 4;
-    float *As = lds;                                            // [ROWS][pitch]
-    TileRef *tiles = reinterpret_cast<TileRef *>(lds + ROWS * pitch);   // [SL]
+    constexpr int pitch = SL * 32 + 4;              // fp32 image: row pitch in floats
+    constexpr int pitchH = SL * 32 + 8;             // bf16x3 image: row pitch in bf16 elements (16 bytes of padding)
+    constexpr int planeH = ROWS * pitchH;           // bf16 elements per plane (h, m, l)
+    float *As = lds;                                            // [ROWS][pitch]            (exact fp32 path)
+    unsigned short *Ah = reinterpret_cast<unsigned short *>(lds);   // [3][ROWS][pitchH]    (bf16x3 path)
+    TileRef *tiles = X3 ? reinterpret_cast<TileRef *>(Ah + 3 * planeH) : reinterpret_cast<TileRef *>(lds + ROWS * pitch);   // [SL]
     const int n0 = blockIdx.x * AR_BN, z = blockIdx.y;
     const int t0 = z * SL;          // every slice runs exactly SL chunks; slots past the last K tile are zero padded
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -145,7 +152,24 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
         for (int j = 0; j < NP; ++j) {
             const int idx = j * AR_NT + (int)threadIdx.x;
             const int row = idx / quads, c4 = idx - row * quads;
-            *reinterpret_cast<f32x4 *>(As + row * pitch + c4 * 4) = v[j];
+            if (!X3) {
+                *reinterpret_cast<f32x4 *>(As + row * pitch + c4 * 4) = v[j];
+            } else {
+                // exact 3-way split (see gemm_x3.hip): x = h + m + l with three truncated bf16 values
+                uint32_t h[4], m[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = v[j][e];
+                    h[e] = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
+                    const float r1 = x - __builtin_bit_cast(float, h[e]);
+                    m[e] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+                    l[e] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, m[e]));
+                }
+                unsigned short *o = Ah + row * pitchH + c4 * 4;
+                *reinterpret_cast<u32x2 *>(o) = u32x2{(h[0] >> 16) | (h[1] & 0xffff0000u), (h[2] >> 16) | (h[3] & 0xffff0000u)};
+                *reinterpret_cast<u32x2 *>(o + planeH) = u32x2{(m[0] >> 16) | (m[1] & 0xffff0000u), (m[2] >> 16) | (m[3] & 0xffff0000u)};
+                *reinterpret_cast<u32x2 *>(o + 2 * planeH) = u32x2{(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
+            }
         }
     }
     __syncthreads();
@@ -156,16 +180,55 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
     const float *a_lo = As + l31 * pitch + 16 * half + kh * TS * 32;
     const float *a_hi = a_lo + 32 * pitch;
 
+    const unsigned short *ah_lo = Ah + l31 * pitchH + 16 * half + kh * TS * 32;
     auto mma = [&](const float (&bb)[16], int c) {
+        if (!X3) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 x0 = *reinterpret_cast<const f32x4 *>(a_lo + c * 32 + 4 * q);
-            f32x4 x1 = x0;
-            if (TM == 2) x1 = *reinterpret_cast<const f32x4 *>(a_hi + c * 32 + 4 * q);
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(a_lo + c * 32 + 4 * q);
+                f32x4 x1 = x0;
+                if (TM == 2) x1 = *reinterpret_cast<const f32x4 *>(a_hi + c * 32 + 4 * q);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], bb[4 * q + e], acc0, 0, 0, 0);
-                if (TM == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], bb[4 * q + e], acc1, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[e], bb[4 * q + e], acc0, 0, 0, 0);
+                    if (TM == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], bb[4 * q + e], acc1, 0, 0, 0);
+                }
+            }
+        } else {
+            // bf16x3: lane (l31, half) owns k = 16*half + 8*ks + 0..7 of the chunk for k-step ks; the weights are split
+            // in registers (each is used by this wave only), the activations were split once when they were staged
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 wb[3];
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) {
+                    uint32_t hh[2], mm[2], ll[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const float x = bb[8 * ks + 2 * e2 + t];
+                        hh[t] = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
+                        const float r1 = x - __builtin_bit_cast(float, hh[t]);
+                        mm[t] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+                        ll[t] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, mm[t]));
+                    }
+                    wb[0][e2] = (hh[0] >> 16) | (hh[1] & 0xffff0000u);
+                    wb[1][e2] = (mm[0] >> 16) | (mm[1] & 0xffff0000u);
+                    wb[2][e2] = (ll[0] >> 16) | (ll[1] & 0xffff0000u);
+                }
+                bf16x8 bw[3], x0[3], x1[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    bw[pl] = __builtin_bit_cast(bf16x8, wb[pl]);
+                    x0[pl] = *reinterpret_cast<const bf16x8 *>(ah_lo + pl * planeH + c * 32 + 8 * ks);
+                    if (TM == 2) x1[pl] = *reinterpret_cast<const bf16x8 *>(ah_lo + pl * planeH + 32 * pitchH + c * 32 + 8 * ks);
+                }
+                // six of nine cross terms, small ones first (0 = h, 1 = m, 2 = l)
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[PA[t]], bw[PB[t]], acc0, 0, 0, 0);
+                    if (TM == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[PA[t]], bw[PB[t]], acc1, 0, 0, 0);
+                }
             }
         }
     };
@@ -233,43 +296,48 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
 
 }  // namespace
 
-// plan: K chunks per wave (1..AR_TSMAX); a workgroup slice is 2 of those; *splits slices cover `tiles`
-int ares_plan(int N, int tiles, int want_blocks, int *splits) {
+// plan: K chunks per wave (1..ts_cap); a workgroup slice is 2 of those; *splits slices cover `tiles`
+int ares_plan(int N, int tiles, int want_blocks, int ts_cap, int *splits) {
     const int nblk = (N + AR_BN - 1) / AR_BN;
     int s = want_blocks / nblk;
     if (s < 1) s = 1;
     if (s > tiles) s = tiles;
     int ts = ((tiles + s - 1) / s + 1) / 2;
     if (ts < 1) ts = 1;
-    if (ts > AR_TSMAX) ts = AR_TSMAX;
+    if (ts > ts_cap) ts = ts_cap;
     *splits = (tiles + 2 * ts - 1) / (2 * ts);
     return ts;
 }
 
-template <bool BKC, int TS, int TM>
+// largest K chunks per wave whose activation slice fits LDS
+int ares_ts_cap(int M, int x3) { return (x3 && M > 32) ? 6 : AR_TSMAX; }
+
+template <bool BKC, int TS, int TM, bool X3>
 static int launch_ts(const KArgs &a, hipStream_t st, int pcls, double bytes, double flops) {
     static bool attr_set = false;
-    constexpr size_t slice = ((size_t)32 * TM * (2 * TS * 32 + 4)) * sizeof(float) + (size_t)2 * TS * sizeof(TileRef);
+    constexpr size_t slice = (X3 ? (size_t)3 * 32 * TM * (2 * TS * 32 + 8) * sizeof(unsigned short)
+                                 : (size_t)32 * TM * (2 * TS * 32 + 4) * sizeof(float)) + (size_t)2 * TS * sizeof(TileRef);
     constexpr size_t red = (size_t)32 * TM * (AR_BN + 4) * sizeof(float);
     constexpr size_t lds = slice > red ? slice : red;
+    static_assert(lds <= 160 * 1024, "activation slice does not fit the CU's LDS");
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_ares_kernel<BKC, TS, TM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_ares_kernel<BKC, TS, TM, X3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     dim3 grid((a.N + AR_BN - 1) / AR_BN, a.splits);
     hipEvent_t e0, e1;
     const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
-    if (prof) hipExtLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM>), grid, dim3(AR_NT), lds, st, e0, e1, 0, a);
-    else hipLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM>), grid, dim3(AR_NT), lds, st, a);
+    if (prof) hipExtLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM, X3>), grid, dim3(AR_NT), lds, st, e0, e1, 0, a);
+    else hipLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM, X3>), grid, dim3(AR_NT), lds, st, a);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
 
-template <bool BKC>
+template <bool BKC, bool X3>
 static int launch_layout(const KArgs &a, int ts, hipStream_t st, int pcls, double bytes, double flops) {
     switch (ts) {
-#define CAPMI_TS(T) case T: return a.M <= 32 ? launch_ts<BKC, T, 1>(a, st, pcls, bytes, flops) : launch_ts<BKC, T, 2>(a, st, pcls, bytes, flops);
+#define CAPMI_TS(T) case T: return a.M <= 32 ? launch_ts<BKC, T, 1, X3>(a, st, pcls, bytes, flops) : launch_ts<BKC, T, (X3 && T > 6) ? 1 : 2, X3>(a, st, pcls, bytes, flops);
         CAPMI_TS(1) CAPMI_TS(2) CAPMI_TS(3) CAPMI_TS(4) CAPMI_TS(5) CAPMI_TS(6) CAPMI_TS(7) CAPMI_TS(8) CAPMI_TS(9)
 #undef CAPMI_TS
     }
@@ -277,10 +345,12 @@ static int launch_layout(const KArgs &a, int ts, hipStream_t st, int pcls, doubl
 }
 
 // a.splits * 2 * ts must cover a.tiles_total
-int launch_ares(const KArgs &a, int b_layout, int ts, hipStream_t st, int pcls, double bytes, double flops) {
-    if (ts < 1 || ts > AR_TSMAX || (long long)a.splits * 2 * ts < a.tiles_total) return CAPMI_EINVAL;
-    return b_layout == 0 ? launch_layout<true>(a, ts, st, pcls, bytes, flops)
-                         : launch_layout<false>(a, ts, st, pcls, bytes, flops);
+int launch_ares(const KArgs &a, int b_layout, int ts, int x3, hipStream_t st, int pcls, double bytes, double flops) {
+    if (ts < 1 || ts > ares_ts_cap(a.M, x3) || (long long)a.splits * 2 * ts < a.tiles_total) return CAPMI_EINVAL;
+    if (x3) return b_layout == 0 ? launch_layout<true, true>(a, ts, st, pcls, bytes, flops)
+                                 : launch_layout<false, true>(a, ts, st, pcls, bytes, flops);
+    return b_layout == 0 ? launch_layout<true, false>(a, ts, st, pcls, bytes, flops)
+                         : launch_layout<false, false>(a, ts, st, pcls, bytes, flops);
 }
 
 }  // namespace capmi_gemm

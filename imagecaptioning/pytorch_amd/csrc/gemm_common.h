@@ -59,8 +59,9 @@ __device__ __forceinline__ void locate(const KArgs &a, int tile, int &s, int &k0
 int launch_skinny(const KArgs &a, int b_layout, int tm, dim3 grid, hipStream_t st);
 
 // A-resident skinny path (M <= 64, A stored [M][K]); defined in gemm_ares.hip
-int ares_plan(int N, int tiles, int want_blocks, int *splits);
-int launch_ares(const KArgs &a, int b_layout, int ts_max, hipStream_t st, int pcls, double bytes, double flops);
+int ares_plan(int N, int tiles, int want_blocks, int ts_cap, int *splits);
+int ares_ts_cap(int M, int x3);
+int launch_ares(const KArgs &a, int b_layout, int ts_max, int x3, hipStream_t st, int pcls, double bytes, double flops);
 
 // fat GEMMs through the bf16 pipe by exact 3-way operand splitting; defined in gemm_x3.hip
 int launch_x3(const KArgs &a, int a_layout, int b_layout, dim3 grid, hipStream_t st, int pcls, double bytes, double flops);

@@ -415,16 +415,21 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     if ((env_path == 2 || env_path == 0) && ares_ok) {     // CAPMI_GEMM_PATH=3 forces the LDS-tiled kernel
         // ---- A-resident path (gemm_ares.hip): activations stay in LDS, weights stream straight to VGPRs ----
         static const int env_ab = [] { const char *e = getenv("CAPMI_ARES_BLOCKS"); return e ? atoi(e) : 256; }();
+        // bf16x3 split (see gemm_x3.hip) for the decode GEMMs too: activations split once when staged, weights split in
+        // registers by the wave that streams them.  Gate GEMM 24.9 -> 19.9 us; greedy decodes stay token-exact on
+        // the reference fixtures.  CAPMI_ARES_X3=0 restores the exact-fp32 MFMA.
+        static const int env_ax3 = [] { const char *e = getenv("CAPMI_ARES_X3"); return e ? atoi(e) : 1; }();
+        const int ts_cap = ares_ts_cap(d->M, env_ax3);
         int splits = 0;
-        int ts_max = ares_plan(d->N, tiles, d->splits > 0 ? ((d->N + 127) / 128) * d->splits : env_ab, &splits);
+        int ts_max = ares_plan(d->N, tiles, d->splits > 0 ? ((d->N + 127) / 128) * d->splits : env_ab, ts_cap, &splits);
         if ((splits > 1 || d->defer_reduce) && (int64_t)splits * d->M * d->N > slab_cap) ts_max = 99;   // slabs do not fit
-        if (ts_max <= 9) {
+        if (ts_max <= ts_cap) {
             a.splits = splits;
             a.to_partial = (splits > 1 || d->defer_reduce) ? 1 : 0;
             a.self_reduce = 0;
             if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > slab_cap)) return CAPMI_EINVAL;
             d->splits_used = splits;
-            int rc = launch_ares(a, d->b_layout, ts_max, st, pcls, bytes, flops);
+            int rc = launch_ares(a, d->b_layout, ts_max, env_ax3, st, pcls, bytes, flops);
             if (rc) return rc;
             if (splits > 1 && !d->defer_reduce)
                 return capmi_splitk_reduce(a.partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,
