@@ -419,9 +419,20 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
         // registers by the wave that streams them.  Gate GEMM 24.9 -> 19.9 us; greedy decodes stay token-exact on
         // the reference fixtures.  CAPMI_ARES_X3=0 restores the exact-fp32 MFMA.
         static const int env_ax3 = [] { const char *e = getenv("CAPMI_ARES_X3"); return e ? atoi(e) : 1; }();
-        const int ts_cap = ares_ts_cap(d->M, env_ax3);
+        int use_x3 = env_ax3;
+        const int want = d->splits > 0 ? ((d->N + 127) / 128) * d->splits : env_ab;
         int splits = 0;
-        int ts_max = ares_plan(d->N, tiles, d->splits > 0 ? ((d->N + 127) / 128) * d->splits : env_ab, ts_cap, &splits);
+        int ts_cap = ares_ts_cap(d->M, use_x3);
+        int ts_max = ares_plan(d->N, tiles, want, ts_cap, &splits);
+        if (use_x3 && ((d->N + 127) / 128) * splits > want) {
+            // the bf16 planes of 64 rows cap a slice at 12 chunks; if that pushes the grid past one workgroup per CU
+            // (a second, mostly empty round) the exact-fp32 image with its longer slices wins (30.2 vs 26.8 us)
+            int splits32 = 0;
+            const int ts32 = ares_plan(d->N, tiles, want, ares_ts_cap(d->M, 0), &splits32);
+            if (((d->N + 127) / 128) * splits32 <= want) {
+                use_x3 = 0; ts_cap = ares_ts_cap(d->M, 0); ts_max = ts32; splits = splits32;
+            }
+        }
         if ((splits > 1 || d->defer_reduce) && (int64_t)splits * d->M * d->N > slab_cap) ts_max = 99;   // slabs do not fit
         if (ts_max <= ts_cap) {
             a.splits = splits;
@@ -429,7 +440,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
             a.self_reduce = 0;
             if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > slab_cap)) return CAPMI_EINVAL;
             d->splits_used = splits;
-            int rc = launch_ares(a, d->b_layout, ts_max, env_ax3, st, pcls, bytes, flops);
+            int rc = launch_ares(a, d->b_layout, ts_max, use_x3, st, pcls, bytes, flops);
             if (rc) return rc;
             if (splits > 1 && !d->defer_reduce)
                 return capmi_splitk_reduce(a.partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,
