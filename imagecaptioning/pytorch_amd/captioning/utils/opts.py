@@ -13,6 +13,10 @@ DEFAULTS = dict(
     structure_loss_weight=1.0, structure_loss_type='seqnll', train_sample_n=16, train_sample_method='sample', train_beam_size=1,
     sc_sample_method='greedy', sc_beam_size=1, cider_reward_weight=1.0, bleu_reward_weight=0.0, cached_tokens='coco-train-idxs',
     use_ppo=0, entropy_reward_weight=0.0, self_cider_reward_weight=0.0, drop_worst_after=-1, drop_worst_rate=0.0,
+    learning_rate_decay_start=-1, learning_rate_decay_every=3, learning_rate_decay_rate=0.8, noamopt=0, noamopt_warmup=2000,
+    noamopt_factor=1.0, use_warmup=0, reduce_on_plateau=0, reduce_on_plateau_factor=0.5, reduce_on_plateau_patience=3,
+    scheduled_sampling_start=-1, scheduled_sampling_increase_every=5, scheduled_sampling_increase_prob=0.05,
+    scheduled_sampling_max_prob=0.25, val_every=0, val_images=0,
     checkpoint_path='log_capmi', id='capmi', save_checkpoint_every=0, losses_log_every=10, start_from=None, seed=1234,
     # transformer / aoa
     N_enc=6, N_dec=6, d_model=512, d_ff=2048, num_att_heads=8, dropout=0.1, refine=1, refine_aoa=1, use_ff=0, decoder_type='AoA',

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Training entrypoint on the MI355X backend -- the control flow of the reference's tools/train.py:32-292 for the
-hot path: XE / self-critical / new-self-critical scheduling (:144-161), LossWrapper call (:185), backward, value
-clip + Adam (:193-196), `time/batch` print (:198-208), periodic checkpoint (:279-285), one flat-gradient RCCL
-all-reduce per step when launched with torch.distributed.run.
+hot path: learning-rate decay / warm-up / Noam / reduce-on-plateau (:94-102, :132-141, :171-173, :253-256), XE /
+self-critical / new-self-critical scheduling (:144-161), LossWrapper call (:185), backward, value clip + Adam
+(:193-196), `time/batch` print (:198-208), periodic validation loss and checkpoint (:228-285), bucketed flat-gradient
+RCCL all-reduce overlapped with the backward when launched with torch.distributed.run.
 
     python -m imagecaptioning.pytorch_amd.tools.train --caption_model updown --rnn_size 1000 --input_encoding_size 1000 \
         --self_critical_after 0 --train_sample_n 5 --max_iters 50
@@ -16,6 +17,23 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))           # so that `captioning` resolves to the mirror package
+
+
+def validation_loss(lw_model, loader, opt, dev):
+    """XE loss over `val_images` images of the val split, teacher forced, eval mode (eval_utils.py:150-160)."""
+    model = lw_model.model
+    model.eval()
+    tot, n = 0.0, 0
+    with torch.no_grad():
+        while n < max(opt.val_images, opt.batch_size):
+            data = loader.get_batch('val')
+            fc, att, labels, masks = (data[k].to(dev) for k in ('fc_feats', 'att_feats', 'labels', 'masks'))
+            att_masks = None if data['att_masks'] is None else data['att_masks'].to(dev)
+            logp = model(fc, att, labels[..., :-1], att_masks)
+            tot += float(lw_model.crit(logp, labels[..., 1:], masks[..., 1:])) * fc.shape[0]
+            n += fc.shape[0]
+    model.train()
+    return tot / n
 
 
 def train(opt):
@@ -45,9 +63,16 @@ def train(opt):
         flat.begin_overlap()
     lw_model = LossWrapper(model, opt)
     model.train()
+    sched = misc.LRSchedule(opt, model_size=getattr(model, 'd_model', None))
+    if misc.scheduled_sampling_prob(opt, 10 ** 6) > 0:
+        raise NotImplementedError('scheduled sampling (scheduled_sampling_start >= 0) is off in every BASELINE config')
     sc_ready = False
     it, epoch = 0, 0
+    epoch_done = True
     while it < opt.max_iters:
+        if epoch_done:
+            sched.epoch_start(epoch)
+            epoch_done = False
         sc_flag = opt.self_critical_after != -1 and epoch >= opt.self_critical_after
         struc_flag = opt.structure_after != -1 and epoch >= opt.structure_after
         if (sc_flag or struc_flag) and not sc_ready:
@@ -65,7 +90,8 @@ def train(opt):
         loss.backward()
         flat.collect_grads()
         scale = flat.finish_overlap() if world > 1 else 1.0     # buckets finished by the backward are already in flight
-        flat.adam_step(opt.learning_rate, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
+        opt.current_lr = sched.rate(it)
+        flat.adam_step(opt.current_lr, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
                        clip_value=opt.grad_clip_value if opt.grad_clip_mode == 'value' else 0.0, grad_scale=scale)
         train_loss = loss.item()
         torch.cuda.synchronize()
@@ -82,6 +108,12 @@ def train(opt):
         it += 1
         if data['bounds']['wrapped']:
             epoch += 1
+            epoch_done = True
+        if opt.val_every and it % opt.val_every == 0:
+            val_loss = validation_loss(lw_model, loader, opt, dev)          # eval_utils.eval_split's loss half (:228-256)
+            sched.plateau_step(val_loss)
+            if rank == 0:
+                print('validation loss: %.3f (lr %.2e)' % (val_loss, sched.current_lr))
         if rank == 0 and opt.save_checkpoint_every and it % opt.save_checkpoint_every == 0:
             misc.save_checkpoint(opt, model, {'iter': it, 'epoch': epoch, 'opt': opt, 'vocab': opt.vocab})
     if rank == 0 and opt.save_checkpoint_every:

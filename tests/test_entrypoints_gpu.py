@@ -26,7 +26,9 @@ def test_train_xe_then_scst_then_eval_beam(tmp_path):
              '--max_length', '8', '--batch_size', '4', '--seq_per_img', '3', '--synthetic_images', '16', '--losses_log_every', '2',
              '--checkpoint_path', str(tmp_path)]
     l0 = T.train(_opts(small + ['--max_iters', '1']))
-    l1 = T.train(_opts(small + ['--max_iters', '25', '--save_checkpoint_every', '25', '--learning_rate', '0.01']))
+    l1 = T.train(_opts(small + ['--max_iters', '25', '--save_checkpoint_every', '25', '--learning_rate', '0.01',
+                                '--learning_rate_decay_start', '0', '--learning_rate_decay_every', '2', '--val_every', '10',
+                                '--val_images', '8', '--reduce_on_plateau', '0']))
     assert l1 < l0, 'XE loss should fall on a 16-image synthetic set (%.3f -> %.3f)' % (l0, l1)
     rewards.reset_scorer()
     T.train(_opts(small + ['--max_iters', '3', '--self_critical_after', '0', '--train_sample_n', '3', '--start_from', str(tmp_path)]))
@@ -35,6 +37,21 @@ def test_train_xe_then_scst_then_eval_beam(tmp_path):
                                          '--start_from', str(tmp_path)]))
     assert len(preds) == 8 and all(isinstance(p['caption'], str) for p in preds)
     assert loss == loss
+
+
+def test_transformer_noam_schedule_runs(tmp_path):
+    sys.path.insert(0, PKG)
+    from imagecaptioning.pytorch_amd.tools import train as T
+    small = ['--caption_model', 'transformer', '--d_model', '32', '--d_ff', '64', '--N_enc', '1', '--N_dec', '1',
+             '--num_att_heads', '4', '--input_encoding_size', '32', '--rnn_size', '32', '--fc_feat_size', '24', '--att_feat_size', '24',
+             '--vocab_size', '40', '--synthetic_regions', '5', '--seq_length', '6', '--max_length', '6', '--batch_size', '4',
+             '--seq_per_img', '2', '--synthetic_images', '8', '--noamopt', '1', '--noamopt_warmup', '5', '--noamopt_factor', '1.0',
+             '--checkpoint_path', str(tmp_path)]
+    opt = _opts(small + ['--max_iters', '8'])
+    loss = T.train(opt)
+    assert loss == loss
+    # NoamOpt.rate at the last step (8): past the 5-step warm-up, so step^-0.5 applies
+    assert opt.current_lr == pytest.approx(32 ** -0.5 * 8 ** -0.5, rel=1e-9)
 
 
 def test_yaml_base_inheritance(tmp_path):

@@ -1,0 +1,71 @@
+"""Host-side training-loop logic mirrored from the reference's tools/train.py / captioning/utils/misc.py (no GPU)."""
+import argparse
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'imagecaptioning', 'pytorch_amd'))
+
+
+def _misc():
+    from imagecaptioning.pytorch_amd.captioning.utils import misc
+    return misc
+
+
+def test_epoch_decay_matches_train_py_formula():
+    misc = _misc()
+    opt = argparse.Namespace(learning_rate=5e-4, learning_rate_decay_start=0, learning_rate_decay_every=3,
+                             learning_rate_decay_rate=0.8)
+    s = misc.LRSchedule(opt)
+    for epoch in range(0, 12):
+        want = 5e-4 * 0.8 ** ((epoch - 0) // 3) if epoch > 0 else 5e-4        # tools/train.py:134-141
+        assert s.epoch_start(epoch) == pytest.approx(want, rel=1e-12)
+        assert s.rate(epoch * 100) == pytest.approx(want, rel=1e-12)
+
+
+def test_noam_rate_matches_noamopt():
+    """misc.py:159-185: NoamOpt.step() increments _step, then lr = factor * d^-0.5 * min(step^-0.5, step * warmup^-1.5)."""
+    misc = _misc()
+    opt = argparse.Namespace(learning_rate=1.0, noamopt=1, noamopt_factor=1.0, noamopt_warmup=20000, d_model=512)
+    s = misc.LRSchedule(opt)
+    for it in (0, 1, 99, 19999, 20000, 123456):
+        step = it + 1
+        want = 1.0 * (512 ** -0.5) * min(step ** -0.5, step * 20000 ** -1.5)
+        assert s.rate(it) == pytest.approx(want, rel=1e-12)
+    assert s.rate(19999) == pytest.approx(max(s.rate(i) for i in (0, 5000, 19999, 40000)), rel=1e-12)   # peak at warm-up end
+
+
+def test_linear_warmup():
+    misc = _misc()
+    opt = argparse.Namespace(learning_rate=2e-4, use_warmup=1, noamopt_warmup=10)
+    s = misc.LRSchedule(opt)
+    s.epoch_start(0)
+    rates = [s.rate(i) for i in range(12)]                # tools/train.py:171-173, evaluated every iteration
+    assert rates[:3] == pytest.approx([2e-5, 4e-5, 6e-5])
+    assert rates[9] == pytest.approx(2e-4) and rates[11] == pytest.approx(2e-4)
+
+
+def test_reduce_on_plateau_matches_torch_scheduler():
+    misc = _misc()
+    opt = argparse.Namespace(learning_rate=1e-3, reduce_on_plateau=1, reduce_on_plateau_factor=0.5, reduce_on_plateau_patience=2)
+    s = misc.LRSchedule(opt)
+    p = torch.nn.Parameter(torch.zeros(1))
+    ref_opt = torch.optim.Adam([p], lr=1e-3)
+    ref = torch.optim.lr_scheduler.ReduceLROnPlateau(ref_opt, mode='min', factor=0.5, patience=2, threshold=1e-4,
+                                                     threshold_mode='rel', cooldown=0, min_lr=0, eps=1e-8)
+    vals = [3.0, 2.5, 2.6, 2.55, 2.7, 2.49, 2.5, 2.5, 2.5, 2.5, 2.4999, 2.6, 2.6, 2.6]
+    for v in vals:
+        ref.step(v)
+        assert s.plateau_step(v) == pytest.approx(ref_opt.param_groups[0]['lr'], rel=1e-12), v
+
+
+def test_scheduled_sampling_probability():
+    misc = _misc()
+    opt = argparse.Namespace(scheduled_sampling_start=0, scheduled_sampling_increase_every=5,
+                             scheduled_sampling_increase_prob=0.05, scheduled_sampling_max_prob=0.25)
+    assert misc.scheduled_sampling_prob(opt, 0) == 0.0
+    assert misc.scheduled_sampling_prob(opt, 11) == pytest.approx(0.10)
+    assert misc.scheduled_sampling_prob(opt, 500) == pytest.approx(0.25)
+    assert misc.scheduled_sampling_prob(argparse.Namespace(), 500) == 0.0
