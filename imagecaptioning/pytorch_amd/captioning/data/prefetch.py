@@ -1,0 +1,56 @@
+"""Device-resident batches: the next batch is staged through pinned host buffers and copied on a side
+stream while the current iteration computes, so the hot path starts every step with its inputs already in HBM (the
+reference does a synchronous `.cuda()` of each tensor inside the loop, tools/train.py:178-181).
+
+Wraps any loader with the reference's `get_batch(split)` dict contract (captioning/data/dataloader.py:262-299): tensor
+entries come back as device tensors, everything else (gts, infos, bounds) is passed through untouched.
+"""
+import torch
+
+TENSOR_KEYS = ('fc_feats', 'att_feats', 'labels', 'masks', 'att_masks')
+
+
+class DevicePrefetcher:
+    def __init__(self, loader, device, depth=2):
+        self.loader, self.device, self.depth = loader, torch.device(device), max(1, int(depth))
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._pinned = {}          # (split, slot, key) -> pinned host buffer, reused while shapes do not change
+        self._queue = {}           # split -> list of (batch dict, ready event)
+        self._slot = {}
+
+    def __getattr__(self, name):   # vocabulary, document_frequency(), ... of the wrapped loader
+        return getattr(self.loader, name)
+
+    def _pin(self, split, slot, key, t):
+        buf = self._pinned.get((split, slot, key))
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self._pinned[(split, slot, key)] = buf
+        buf.copy_(t)
+        return buf
+
+    def _issue(self, split):
+        data = self.loader.get_batch(split)
+        slot = self._slot.get(split, 0)
+        self._slot[split] = (slot + 1) % (self.depth + 1)
+        out = dict(data)
+        with torch.cuda.stream(self.stream):
+            for k in TENSOR_KEYS:
+                t = data.get(k)
+                if torch.is_tensor(t):
+                    out[k] = self._pin(split, slot, k, t).to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._queue.setdefault(split, []).append((out, ev))
+
+    def get_batch(self, split):
+        q = self._queue.setdefault(split, [])
+        while len(q) < self.depth:
+            self._issue(split)
+        out, ev = q.pop(0)
+        torch.cuda.current_stream(self.device).wait_event(ev)      # stream-side wait, the host does not block
+        for k in TENSOR_KEYS:
+            if torch.is_tensor(out.get(k)):
+                out[k].record_stream(torch.cuda.current_stream(self.device))
+        self._issue(split)                                          # keep `depth` batches in flight
+        return out

@@ -40,6 +40,7 @@ def train(opt):
     import torch.distributed as dist
     from captioning import models
     from captioning.data.synthetic_loader import SyntheticLoader
+    from captioning.data.prefetch import DevicePrefetcher
     from captioning.modules.loss_wrapper import LossWrapper
     from captioning.utils import rewards, misc
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -54,6 +55,7 @@ def train(opt):
     opt.seed = opt.seed + rank                        # each rank draws its own images
     loader = SyntheticLoader(opt)
     opt.vocab = loader.get_vocab()
+    loader = DevicePrefetcher(loader, dev)             # batches arrive already resident in HBM (pinned, side stream)
     torch.manual_seed(1234)                           # identical weights on every rank
     model = models.setup(opt).to(dev)
     if opt.start_from:
@@ -80,9 +82,7 @@ def train(opt):
             sc_ready = True
         t0 = time.time()
         data = loader.get_batch('train')
-        fc, att, labels, masks = (data[k].to(dev) for k in ('fc_feats', 'att_feats', 'labels', 'masks'))
-        att_masks = None if data['att_masks'] is None else data['att_masks'].to(dev)
-        torch.cuda.synchronize()
+        fc, att, labels, masks, att_masks = (data[k] for k in ('fc_feats', 'att_feats', 'labels', 'masks', 'att_masks'))
         t1 = time.time()
         out = lw_model(fc, att, labels, masks, att_masks, data['gts'], torch.arange(len(data['gts'])), sc_flag, struc_flag, False)
         loss = out['loss'].mean()

@@ -54,6 +54,24 @@ def test_transformer_noam_schedule_runs(tmp_path):
     assert opt.current_lr == pytest.approx(32 ** -0.5 * 8 ** -0.5, rel=1e-9)
 
 
+def test_device_prefetcher_delivers_the_same_batches_on_device():
+    sys.path.insert(0, PKG)
+    from captioning.data.synthetic_loader import SyntheticLoader
+    from captioning.data.prefetch import DevicePrefetcher
+    argv = ['--fc_feat_size', '16', '--att_feat_size', '16', '--vocab_size', '30', '--synthetic_regions', '4', '--seq_length', '6',
+            '--max_length', '6', '--batch_size', '3', '--seq_per_img', '2', '--synthetic_images', '7']
+    plain = SyntheticLoader(_opts(argv))
+    pre = DevicePrefetcher(SyntheticLoader(_opts(argv)), 'cuda:0', depth=2)
+    for _ in range(6):                                   # crosses the epoch boundary (7 images, batches of 3)
+        a, b = plain.get_batch('train'), pre.get_batch('train')
+        for k in ('fc_feats', 'att_feats', 'labels', 'masks'):
+            assert b[k].is_cuda
+            assert torch.equal(a[k], b[k].cpu()), k
+        assert b['att_masks'] is None and a['bounds'] == b['bounds']
+        assert all((x == y).all() for x, y in zip(a['gts'], b['gts']))
+    assert pre.get_vocab() == plain.get_vocab()
+
+
 def test_yaml_base_inheritance(tmp_path):
     sys.path.insert(0, PKG)
     from captioning.utils import config
