@@ -18,7 +18,8 @@ _ref_cache = {}
 
 
 def init_scorer(cached_tokens, device=None):
-    """rewards.py:25-31.  ``cached_tokens``: pickle stem under data/, a path, or (df dict, ref_len)."""
+    """rewards.py:25-31.  ``cached_tokens``: pickle stem under data/, a path to the pickle or to a converted
+    flat image (.npz, tools/convert_df.py), or (df dict, ref_len)."""
     global CiderD_scorer
     if CiderD_scorer is not None:
         return CiderD_scorer
@@ -27,7 +28,11 @@ def init_scorer(cached_tokens, device=None):
         CiderD_scorer = DeviceCiderD(cached_tokens[0], cached_tokens[1], device)
     else:
         path = cached_tokens if os.path.exists(str(cached_tokens)) else os.path.join('data', cached_tokens + '.p')
-        CiderD_scorer = DeviceCiderD.from_pickle(path, device)
+        image = path if str(path).endswith('.npz') else os.path.splitext(str(path))[0] + '.capmi.npz'
+        if os.path.exists(image):
+            CiderD_scorer = DeviceCiderD.from_image(image, device)       # pre-hashed table: two array reads
+        else:
+            CiderD_scorer = DeviceCiderD.from_pickle(path, device)
     return CiderD_scorer
 
 

@@ -69,14 +69,36 @@ def build_table(document_frequency, load_factor=0.5):
     return keys, vals
 
 
+def save_df_image(document_frequency, ref_len, path):
+    """One-time conversion of the scripts/prepro_ngrams.py pickle content into the flat hash image the
+    kernel probes: an .npz with `keys` uint64[cap], `vals` float64[cap], `ref_len`.  Loading it is two array reads
+    instead of unpickling and re-hashing a few million tuple keys at every start-up."""
+    keys, vals = build_table(document_frequency)
+    np.savez(path, keys=keys, vals=vals, ref_len=np.float64(ref_len), n=np.int64(len(document_frequency)))
+    return path if str(path).endswith('.npz') else str(path) + '.npz'
+
+
+def load_df_image(path):
+    z = np.load(path)
+    keys, vals = z['keys'], z['vals']
+    if keys.dtype != np.uint64 or vals.dtype != np.float64 or keys.shape != vals.shape or keys.shape[0] & (keys.shape[0] - 1):
+        raise ValueError('%s is not a capmi document-frequency image' % path)
+    return keys, vals, float(z['ref_len'])
+
+
 class DeviceCiderD:
-    def __init__(self, document_frequency, ref_len, device):
-        keys, vals = build_table(document_frequency)
+    def __init__(self, document_frequency, ref_len, device, _table=None):
+        keys, vals = _table if _table is not None else build_table(document_frequency)
         self.cap = int(keys.shape[0])
         self.keys = torch.from_numpy(keys.view(np.int64)).to(device)     # bit pattern preserved
         self.vals = torch.from_numpy(vals).to(device)
         self.log_ref_len = math.log(float(ref_len))
         self.device = device
+
+    @classmethod
+    def from_image(cls, path, device):
+        keys, vals, ref_len = load_df_image(path)
+        return cls(None, ref_len, device, _table=(keys, vals))
 
     @classmethod
     def from_pickle(cls, path, device):

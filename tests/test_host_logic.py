@@ -69,3 +69,37 @@ def test_scheduled_sampling_probability():
     assert misc.scheduled_sampling_prob(opt, 11) == pytest.approx(0.10)
     assert misc.scheduled_sampling_prob(opt, 500) == pytest.approx(0.25)
     assert misc.scheduled_sampling_prob(argparse.Namespace(), 500) == 0.0
+
+
+def test_df_image_roundtrip(tmp_path):
+    """pickle (scripts/prepro_ngrams.py format) -> flat hash image -> same table as hashing the dict directly."""
+    import pickle
+    import numpy as np
+    pytest.importorskip('ctypes')
+    try:
+        from imagecaptioning.pytorch_amd import ciderd
+    except OSError:
+        pytest.skip('libcapmi.so not built')
+    from imagecaptioning.pytorch_amd.tools import convert_df
+    rng = np.random.default_rng(0)
+    df = {}
+    for _ in range(500):
+        n = int(rng.integers(1, 5))
+        df[tuple(str(int(t)) for t in rng.integers(1, 200, size=n))] = float(rng.integers(1, 50))
+    src = tmp_path / 'toy-idxs.p'
+    with open(src, 'wb') as f:
+        pickle.dump({'document_frequency': df, 'ref_len': 123}, f)
+    dst = convert_df.convert(str(src))
+    assert dst.endswith('toy-idxs.capmi.npz')
+    keys, vals, ref_len = ciderd.load_df_image(dst)
+    k2, v2 = ciderd.build_table(df)
+    assert ref_len == 123.0 and np.array_equal(keys, k2) and np.array_equal(vals, v2)
+    # every n-gram is found by linear probing from its home slot
+    cap = keys.shape[0]
+    for g, c in list(df.items())[:50]:
+        key = np.uint64(ciderd.pack_ngram([int(t) for t in g]))
+        s = int(ciderd._mix64(np.array([key], dtype=np.uint64))[0] & np.uint64(cap - 1))
+        while keys[s] != key:
+            assert keys[s] != 0
+            s = (s + 1) & (cap - 1)
+        assert vals[s] == c
