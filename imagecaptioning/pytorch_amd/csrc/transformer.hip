@@ -359,7 +359,12 @@ int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, int 
         return CAPMI_EINVAL;
     if (mask && mask_tq != 1 && mask_tq != Tq) return CAPMI_EINVAL;
     const size_t lds = ((size_t)2 * Tk * (dk + 1) + (size_t)Tq * (dk + 1) + (size_t)Tq * (Tk + 1)) * sizeof(float);
-    if (lds > 64 * 1024) return CAPMI_EINVAL;
+    if (lds > 160 * 1024) return CAPMI_EINVAL;
+    static bool attr_f = false;      // more than 64 KB of dynamic LDS needs the opt-in (36 regions x 64 dims already do in bwd)
+    if (!attr_f) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mha_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_f = true;
+    }
     hipLaunchKernelGGL(mha_fwd_kernel, dim3(Nq / q_per_kv, h), dim3(MHA_T), lds, (hipStream_t)stream, q, k, v, ldkv, kstride,
                        mask, mask_tq, mask_per_q, causal, q_pos0, drop, o, p, q_per_kv, Tq, Tk, h, dk);
     CAPMI_CHECK_LAUNCH();
@@ -375,7 +380,12 @@ int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float 
     if (!d_o || !q || !k || !v || !p || !dq || !dk_out || !dv_out || Nq <= 0 || q_per_kv <= 0 || Nq % q_per_kv)
         return CAPMI_EINVAL;
     const size_t lds = ((size_t)4 * Tk * (dk + 1) + (size_t)2 * Tq * (dk + 1) + (size_t)2 * Tq * (Tk + 1)) * sizeof(float);
-    if (lds > 64 * 1024) return CAPMI_EINVAL;
+    if (lds > 160 * 1024) return CAPMI_EINVAL;
+    static bool attr_b = false;
+    if (!attr_b) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mha_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_b = true;
+    }
     hipLaunchKernelGGL(mha_bwd_kernel, dim3(Nq / q_per_kv, h), dim3(MHA_T), lds, (hipStream_t)stream, d_o, q, k, v, ldkv, kstride,
                        p, drop, dq, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, q_per_kv, Tq, Tk, h, dk);
     CAPMI_CHECK_LAUNCH();
