@@ -15,7 +15,7 @@ from imagecaptioning.pytorch_amd.captioning.modules.losses import LanguageModelC
 dev = torch.device('cuda:0')
 
 
-def run(name, opt, B, n=5, L=20, steps=5, warm=2):
+def run(name, opt, B, n=5, L=20, steps=10, warm=4):
     torch.manual_seed(1234)
     model = models.setup(opt).to(dev)
     flat = model.flatten_parameters_()
