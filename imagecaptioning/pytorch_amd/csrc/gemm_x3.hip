@@ -171,6 +171,14 @@ struct Unit {
 };
 __device__ __forceinline__ Unit unit_of(const KArgs &a, int u, int gm, int gn) {
     const int per = gm * gn;
+    // XCD-aware order: workgroup b runs on XCD b % 8 (each XCD has its own L2).  Within a full round of the grid,
+    // hand every XCD a CONTIGUOUS run of output tiles (same A panel, neighbouring B panels) instead of every 8th one:
+    // the dW GEMMs fetched their [K x 128] gradient panel through all 8 L2s (139 MB per launch for 25 MB of operands).
+    {
+        const int G = gridDim.x, total = per * a.splits;
+        const int b = u % G, r = u / G;
+        if ((G & 7) == 0 && (r + 1) * G <= total) u = (b & 7) * (G >> 3) + (b >> 3) + r * G;
+    }
     const int z = u / per, tile = u - z * per;
     Unit r;
     r.z = z;
