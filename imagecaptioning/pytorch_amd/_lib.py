@@ -110,7 +110,7 @@ SIGNATURES = {
     'capmi_embed_bwd': [_P] * 5 + [_I, _I, _I, _P],
     'capmi_logsoftmax_select': [_P, _I, _I, _I, _I, _I, _P, _F, _P, _U64, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P],
     'capmi_logsoftmax_select_partial': [_P, _I, _I64, _P, _I, _I, _I, _I, _I, _P, _F, _P, _U64, _P, _I, _I, _P, _I, _P, _P, _P,
-                                        _P, _P, _P],
+                                        _P, _P, _P, _P],
     'capmi_logsoftmax_bwd': [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     'capmi_splitk_reduce': [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P],
     'capmi_dropout_mask': [_P, _I64, _F, _U64, _U64, _P],

@@ -100,11 +100,12 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
         float *h_drop = r->h_drop + (size_t)t * NR;
         int splits = 1;
 
-        // 1. token embedding (+ReLU +dropout)
+        // 1. token embedding (+ReLU +dropout).  Free-running rollouts: only step 0 launches it (BOS); afterwards the
+        //    select kernel of step t-1 has already written xt (the workgroup that chose the token embeds it).
         if (r->teacher)
             RC(capmi_embed_fwd(r->forced + t, r->forced_ld, r->it_all ? r->it_all + (size_t)t * N : nullptr, w->embed,
                                r->drop_xt ? r->drop_xt + (size_t)t * N * E : nullptr, xt, N, E, 1, stream));
-        else
+        else if (t == 0)
             RC(capmi_embed_fwd(r->it, 1, r->it_all ? r->it_all + (size_t)t * N : nullptr, w->embed,
                                r->drop_xt ? r->drop_xt + (size_t)t * N * E : nullptr, xt, N, E, 1, stream));
 
@@ -142,11 +143,18 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
             SegSpec s{h_drop, R, w->logit_w, R, R, 1};
             RC(gemm(stream, 0, 0, N, V1, r->partial, V1, &s, 1, r->partial, r->partial_capacity, 1, &splits));
         }
+        capmi_next_embed ne{};
+        if (!r->teacher && t + 1 < T) {
+            ne.E = w->embed; ne.Edim = E; ne.relu = 1;
+            ne.mask = r->drop_xt ? r->drop_xt + (size_t)(t + 1) * N * E : nullptr;
+            ne.x = r->xt + (size_t)(t + 1) * N * E;
+            ne.it_save = r->it_all ? r->it_all + (size_t)(t + 1) * N : nullptr;
+        }
         RC(capmi_logsoftmax_select_partial(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, (int64_t)N * V1, w->logit_b, N, V1, t,
                                            L, r->teacher ? 2 : r->mode, r->teacher ? nullptr : r->row_mode, r->temperature,
                                            r->gumbel ? r->gumbel + (size_t)t * N * V1 : nullptr, r->seed, r->forced,
                                            r->forced_ld, r->teacher ? 1 : 0, r->seq, L, r->it, r->unfinished, r->seq_logp,
-                                           r->sel_logp, r->live, stream));
+                                           r->sel_logp, r->live, &ne, stream));
     }
     return 0;
 }

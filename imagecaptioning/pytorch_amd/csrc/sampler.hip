@@ -37,13 +37,33 @@ __device__ __forceinline__ ArgMax wave_argmax(ArgMax x) {
     return x;
 }
 
+// next step's token embedding written by the workgroup that just chose the token (saves the embed launch of every
+// step but the first): x_next[r,:] = relu?(E[token,:]) * mask[r,:], it_save[r] = token
+struct NextEmbed {
+    const float *E, *mask;
+    float *x;
+    int64_t *it_save;
+    int Edim, relu;
+};
+__device__ __forceinline__ void emit_next_embed(const NextEmbed &ne, int r, int token) {
+    if (!ne.x) return;
+    const float *e = ne.E + (size_t)token * ne.Edim;
+    for (int c = threadIdx.x; c < ne.Edim; c += blockDim.x) {
+        float v = e[c];
+        if (ne.relu) v = fmaxf(v, 0.f);
+        if (ne.mask) v *= ne.mask[(size_t)r * ne.Edim + c];
+        ne.x[(size_t)r * ne.Edim + c] = v;
+    }
+    if (threadIdx.x == 0 && ne.it_save) ne.it_save[r] = token;
+}
+
 __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
     const float *__restrict__ logits, int splits, size_t slab_stride, const float *__restrict__ bias, int V1, int step,
     int L, int mode, const uint8_t *__restrict__ row_mode,
     float temperature, const float *__restrict__ gumbel, uint64_t seed, const int64_t *__restrict__ forced,
     int forced_ld, int no_finish_mask, int64_t *__restrict__ seq, int seq_ld, int64_t *__restrict__ it_next,
     uint8_t *__restrict__ unfinished, float *__restrict__ seq_logp, float *__restrict__ sel_logp,
-    uint8_t *__restrict__ live) {
+    uint8_t *__restrict__ live, const NextEmbed ne) {
     __shared__ float s_f[32];
     __shared__ int s_i[32];
     const int r = blockIdx.x;
@@ -124,6 +144,7 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
         else
             for (int v = threadIdx.x; v < V1; v += blockDim.x) out[v] = 0.f;
     }
+    emit_next_embed(ne, r, token);
     __syncthreads();   // all reads of unfinished[r] done before thread 0 rewrites it
     if (threadIdx.x == 0) {
         seq[(size_t)r * seq_ld + step] = token;
@@ -144,7 +165,7 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
     int mode, const uint8_t *__restrict__ row_mode, float temperature, const float *__restrict__ gumbel, uint64_t seed,
     const int64_t *__restrict__ forced, int forced_ld, int no_finish_mask, int64_t *__restrict__ seq, int seq_ld,
     int64_t *__restrict__ it_next, uint8_t *__restrict__ unfinished, float *__restrict__ seq_logp,
-    float *__restrict__ sel_logp, uint8_t *__restrict__ live) {
+    float *__restrict__ sel_logp, uint8_t *__restrict__ live, const NextEmbed ne) {
     __shared__ float s_f[32];
     __shared__ int s_i[32];
     __shared__ float s_tok;
@@ -256,6 +277,7 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
             if (q == (token >> 2)) s_tok = x[j][token & 3];     // the owner of the chosen logit publishes it
         }
     }
+    emit_next_embed(ne, r, token);
     __syncthreads();   // s_tok visible; all reads of unfinished[r] done before thread 0 rewrites it
     if (threadIdx.x == 0) {
         seq[(size_t)r * seq_ld + step] = token;
@@ -295,12 +317,17 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
                                     int V1, int step, int L, int mode, const uint8_t *row_mode, float temperature,
                                     const float *gumbel, uint64_t seed, const int64_t *forced, int forced_ld,
                                     int no_finish_mask, int64_t *seq, int seq_ld, int64_t *it_next, uint8_t *unfinished,
-                                    float *seq_logp, float *sel_logp, uint8_t *live, void *stream) {
+                                    float *seq_logp, float *sel_logp, uint8_t *live, const capmi_next_embed *next, void *stream) {
     if (!partial || splits < 1 || N <= 0 || V1 <= 0 || step < 0 || step >= L || !seq || !it_next) return CAPMI_EINVAL;
     if (!no_finish_mask && !unfinished) return CAPMI_EINVAL;
     if ((mode == 2 || row_mode) && !forced && mode == 2) return CAPMI_EINVAL;
     if (mode == 1 && !(temperature > 0.f)) return CAPMI_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    NextEmbed ne{};
+    if (next && next->x) {
+        if (!next->E || next->Edim <= 0) return CAPMI_EINVAL;
+        ne = NextEmbed{next->E, next->mask, next->x, next->it_save, next->Edim, next->relu};
+    }
     const bool al = ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(bias) |
                       reinterpret_cast<uintptr_t>(gumbel) | reinterpret_cast<uintptr_t>(seq_logp)) & 15) == 0 &&
                     (slab_stride % 4 == 0);
@@ -308,7 +335,7 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
 #define CAPMI_SEL(NQ)                                                                                                   \
     hipLaunchKernelGGL(logsoftmax_select_reg_kernel<NQ>, dim3(N), dim3(SEL_THREADS), 0, st, partial, splits,           \
                        (size_t)slab_stride, bias, V1, step, L, mode, row_mode, temperature, gumbel, seed, forced,       \
-                       forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live)
+                       forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live, ne)
         if (V1 <= 4 * SEL_THREADS) CAPMI_SEL(1);
         else if (V1 <= 8 * SEL_THREADS) CAPMI_SEL(2);
         else CAPMI_SEL(3);
@@ -319,7 +346,7 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
     hipLaunchKernelGGL(logsoftmax_select_kernel, dim3(N), dim3(SEL_THREADS), 0, st, partial, splits, (size_t)slab_stride, bias,
                        V1, step, L, mode, row_mode,
                        temperature, gumbel, seed, forced, forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished,
-                       seq_logp, sel_logp, live);
+                       seq_logp, sel_logp, live, ne);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -330,7 +357,7 @@ int capmi_logsoftmax_select(const float *logits, int N, int V1, int step, int L,
                             uint8_t *unfinished, float *seq_logp, float *sel_logp, uint8_t *live, void *stream) {
     return capmi_logsoftmax_select_partial(logits, 1, 0, nullptr, N, V1, step, L, mode, row_mode, temperature, gumbel,
                                            seed, forced, forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished,
-                                           seq_logp, sel_logp, live, stream);
+                                           seq_logp, sel_logp, live, nullptr, stream);
 }
 
 int capmi_logsoftmax_bwd(const float *g, const float *seq_logp, const uint8_t *live, float *dlogits, int N, int L,

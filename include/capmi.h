@@ -195,6 +195,17 @@ int capmi_logsoftmax_select(const float *logits, int N, int V1, int step, int L,
                             int64_t *seq, int seq_ld, int64_t *it_next, uint8_t *unfinished,
                             float *seq_logp, float *sel_logp, uint8_t *live, void *stream);
 
+/* Optional tail of capmi_logsoftmax_select_partial: the workgroup that chose row r's token also writes the NEXT step's
+ * input embedding x[r,:] = relu?(E[token,:]) * mask[r,:] and it_save[r] = token (capmi_embed_fwd of step t+1 folded in). */
+typedef struct {
+    const float *E;      /* [V1, Edim] embedding table */
+    const float *mask;   /* [N, Edim] dropout mask of the next step or NULL */
+    float *x;            /* [N, Edim] out; NULL disables the tail */
+    int64_t *it_save;    /* [N] or NULL */
+    int Edim;
+    int relu;
+} capmi_next_embed;
+
 /* Same, fed straight from the vocabulary GEMM's K-slice slabs (capmi_gemm_f32 with defer_reduce = 1):
  * logits[r,:] = sum_{s<splits} partial[s*slab_stride + r*V1 + :] + bias (bias may be NULL).  With V1 % 4 == 0,
  * V1 <= 12288 and 16-byte aligned buffers the row lives in registers (no split-K reduce launch, no logits
@@ -205,7 +216,8 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
                                     const float *gumbel, uint64_t seed,
                                     const int64_t *forced, int forced_ld, int no_finish_mask,
                                     int64_t *seq, int seq_ld, int64_t *it_next, uint8_t *unfinished,
-                                    float *seq_logp, float *sel_logp, uint8_t *live, void *stream);
+                                    float *seq_logp, float *sel_logp, uint8_t *live,
+                                    const capmi_next_embed *next, void *stream);
 
 /* gradient of the dense log-probs w.r.t. the logits for ALL steps at once:
  *   dlogits[r,t,:] = g[r,t,:] - exp(logp[r,t,:]) * sum_v g[r,t,v]      (rows where logp was masked
