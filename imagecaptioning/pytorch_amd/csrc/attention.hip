@@ -279,7 +279,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
     const float *__restrict__ d_ctx, int ld_dctx, const float *__restrict__ att_h, const float *__restrict__ alpha,
     const float *__restrict__ p_att, const float *__restrict__ att, const float *__restrict__ w,
     float *__restrict__ d_att_h, float *__restrict__ d_e, int B, int n_img, int rpb, int chunks, int K, int A, int R,
-    const int *__restrict__ row_img) {
+    const int *__restrict__ row_img, const float *__restrict__ x_slabs, int x_splits, size_t x_stride, int x_cols,
+    float *__restrict__ x_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *s_dc = lds;                        // [NMAX][R4]  (R rounded up to a multiple of 4, zero padded)
     const int R4 = (R + 3) & ~3;
@@ -295,9 +296,35 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
         n = min(rpb, n_img - chunk * rpb);
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int i = threadIdx.x; i < n * R4; i += blockDim.x) {
-        const int j = i / R4, r = i % R4;
-        s_dc[i] = r < R ? d_ctx[(size_t)(row0 + j) * ld_dctx + r] : 0.f;
+    if (x_slabs) {
+        // d_ctx is the first R of x_cols columns of a dX GEMM left as K-slice slabs: finish the reduction for this
+        // workgroup's rows over ALL x_cols columns (the other columns feed the LSTM-cell backward), publish the rows to
+        // x_out [N, x_cols] (= d_ctx, ld_dctx) and keep the d_ctx part in LDS.  x_cols % 4 == 0, 16-byte aligned.
+        const int q4 = x_cols >> 2;
+        for (int i = threadIdx.x; i < n * q4; i += blockDim.x) {
+            const int j = i / q4, c = (i - j * q4) * 4;
+            const float *p = x_slabs + (size_t)(row0 + j) * x_cols + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int s0 = 0; s0 < x_splits; s0 += 4) {      // 4 independent 16-byte slab loads in flight
+                f32x4 part[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    part[u] = (s0 + u < x_splits) ? *reinterpret_cast<const f32x4 *>(p + (size_t)(s0 + u) * x_stride)
+                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+                v += (part[0] + part[1]) + (part[2] + part[3]);
+            }
+            *reinterpret_cast<f32x4 *>(x_out + (size_t)(row0 + j) * x_cols + c) = v;
+            if (c < R) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < R4) s_dc[j * R4 + c + e] = (c + e < R) ? v[e] : 0.f;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < n * R4; i += blockDim.x) {
+            const int j = i / R4, r = i % R4;
+            s_dc[i] = r < R ? d_ctx[(size_t)(row0 + j) * ld_dctx + r] : 0.f;
+        }
     }
     __syncthreads();
     const float *ab = att + (size_t)b * K * R;
@@ -522,23 +549,41 @@ int capmi_attention_fwd_partial(const float *h_partial, int h_splits, int64_t h_
                                 A, R, row_img, N, stream);
 }
 
-int capmi_attention_bwd(const float *d_ctx, int ld_dctx, const float *att_h, const float *alpha, const float *p_att,
-                        const float *att, const float *mask, const float *w, float *d_att_h, float *d_e, int B, int n,
-                        int K, int A, int R, const int32_t *row_img, int N, void *stream) {
-    (void)mask;   // the masked renorm folds into the same Jacobian (see kernel comment)
-    if (!d_ctx || !att_h || !alpha || !p_att || !att || !w || !d_att_h || !d_e || B <= 0 || ld_dctx < R) return CAPMI_EINVAL;
+static int attention_bwd_launch(const float *d_ctx, int ld_dctx, const float *x_slabs, int x_splits, int64_t x_stride, int x_cols,
+                                float *x_out, const float *att_h, const float *alpha, const float *p_att, const float *att,
+                                const float *w, float *d_att_h, float *d_e, int B, int n, int K, int A, int R,
+                                const int32_t *row_img, int N, void *stream) {
+    if (!att_h || !alpha || !p_att || !att || !w || !d_att_h || !d_e || B <= 0) return CAPMI_EINVAL;
     if (row_img ? N <= 0 : n <= 0) return CAPMI_EINVAL;
     if (!row_img) N = B * n;
     const size_t lds = ((size_t)NMAX * ((R + 3) & ~3) + (size_t)NMAX * K) * sizeof(float);
     if (lds > 64 * 1024) return CAPMI_EINVAL;
-    const double abytes = 4.0 * ((double)B * K * (A + R) + (double)N * (2.0 * A + R + 2.0 * K));
     const int rpb = row_img ? 1 : pick_rpb(B, n), chunks = row_img ? 1 : (n + rpb - 1) / rpb;
-    (void)abytes;
     hipLaunchKernelGGL(attention_bwd_kernel, dim3(row_img ? N : grid_blocks(B, chunks)), dim3(ATT_THREADS), lds,
                        (hipStream_t)stream, d_ctx, ld_dctx, att_h, alpha, p_att, att, w, d_att_h, d_e, B, n, rpb, chunks, K,
-                       A, R, row_img);
+                       A, R, row_img, x_slabs, x_splits, (size_t)x_stride, x_cols, x_out);
     CAPMI_CHECK_LAUNCH();
     return 0;
+}
+
+int capmi_attention_bwd(const float *d_ctx, int ld_dctx, const float *att_h, const float *alpha, const float *p_att,
+                        const float *att, const float *mask, const float *w, float *d_att_h, float *d_e, int B, int n,
+                        int K, int A, int R, const int32_t *row_img, int N, void *stream) {
+    (void)mask;   // the masked renorm folds into the same Jacobian (see kernel comment)
+    if (!d_ctx || ld_dctx < R) return CAPMI_EINVAL;
+    return attention_bwd_launch(d_ctx, ld_dctx, nullptr, 0, 0, 0, nullptr, att_h, alpha, p_att, att, w, d_att_h, d_e, B, n, K, A,
+                                R, row_img, N, stream);
+}
+
+int capmi_attention_bwd_partial(const float *x_slabs, int x_splits, int64_t x_stride, int x_cols, float *x_out,
+                                const float *att_h, const float *alpha, const float *p_att, const float *att,
+                                const float *w, float *d_att_h, float *d_e, int B, int n, int K, int A, int R,
+                                const int32_t *row_img, int N, void *stream) {
+    if (!x_slabs || !x_out || x_splits < 1 || x_cols < R || (x_cols & 3) || (x_stride & 3) ||
+        ((reinterpret_cast<uintptr_t>(x_slabs) | reinterpret_cast<uintptr_t>(x_out)) & 15))
+        return CAPMI_EINVAL;
+    return attention_bwd_launch(x_out, x_cols, x_slabs, x_splits, x_stride, x_cols, x_out, att_h, alpha, p_att, att, w, d_att_h,
+                                d_e, B, n, K, A, R, row_img, N, stream);
 }
 
 int capmi_attention_bwd_batched(const float *d_ctx_all, int ld_dctx, const float *att_h_all, const float *alpha_all,

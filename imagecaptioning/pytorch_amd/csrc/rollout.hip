@@ -204,7 +204,8 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
     // ---- BPTT over the recurrent part ----------------------------------------------------------
     // Workspace carved in three: the d_x1 and dh_att(attention) GEMMs leave their K-slice slabs in regions of their own
     // and the LSTM-cell kernels of the following launches finish those reductions (2 of the 3 split-K reduce launches
-    // per step disappear; d_x1 is never materialised).  d_x2 keeps its reduce: three kernels and the batched pass read it.
+    // per step disappear; d_x1 is never materialised).  d_x2 (read by three kernels and the batched pass) is finished and
+    // published by the attention Jacobian kernel, its first consumer.
     const int64_t cap1 = (cap / 4) & ~(int64_t)1023, caph = (cap / 8) & ~(int64_t)1023, capm = cap - cap1 - caph;
     float *P1 = P + capm, *Ph = P + capm + cap1;
     if (phases & CAPMI_BWD_RECURRENT) {
@@ -233,16 +234,17 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
                                        d_x2_next ? d_x2_next + 2 * R : nullptr, 3 * R, 1, 0, last ? nullptr : dc_lang_in,
                                        r->gates_lang + (size_t)t * N * 4 * R, r->c_lang + (size_t)t * NR,
                                        r->c_lang + (size_t)(t + 1) * NR, dg_lang, dc_lang_out, N, R, stream));
-        // d_x2 = dg_lang [W_ih | W_hh]  -> (d_ctx | dh_att | dh_lang_prev)
+        // d_x2 = dg_lang [W_ih | W_hh]  -> (d_ctx | dh_att | dh_lang_prev), left as slabs; the attention Jacobian
+        // (d_ctx -> d_att_h, and d_e kept for the batched pass) finishes the reduction of its rows and publishes d_x2
+        int x2_splits = 1;
         {
             SegSpec a{dg_lang, 4 * R, s->w_lang_cat, 3 * R, 4 * R, 1};
-            RC(gemm(stream, 0, 1, N, 3 * R, d_x2, 3 * R, &a, 1, P, capm, 0, nullptr));
+            RC(gemm(stream, 0, 1, N, 3 * R, P, 3 * R, &a, 1, P, capm, 1, &x2_splits));
         }
-        // attention Jacobian: d_ctx -> d_att_h (and d_e kept for the batched pass)
-        RC(capmi_attention_bwd(d_x2, 3 * R, r->att_h + (size_t)t * N * A, r->alpha + (size_t)t * N * K, r->p_att, r->att,
-                               r->att_mask, w->alpha_w, s->d_att_h_all + (size_t)t * N * A,
-                               s->d_e_all + (size_t)t * N * K, r->B_feat > 0 ? r->B_feat : B, n, K, A, R, r->row_img, N,
-                               stream));
+        RC(capmi_attention_bwd_partial(P + CAPMI_WS_COUNTER_FLOATS, x2_splits, (int64_t)N * 3 * R, 3 * R, d_x2,
+                                       r->att_h + (size_t)t * N * A, r->alpha + (size_t)t * N * K, r->p_att, r->att,
+                                       w->alpha_w, s->d_att_h_all + (size_t)t * N * A, s->d_e_all + (size_t)t * N * K,
+                                       r->B_feat > 0 ? r->B_feat : B, n, K, A, R, r->row_img, N, stream));
         {
             SegSpec a{s->d_att_h_all + (size_t)t * N * A, A, w->h2att_w, R, A, 1};   // dh_att via h2att, left as slabs
             RC(gemm(stream, 0, 1, N, R, Ph, R, &a, 1, Ph, caph, 1, &h_splits));

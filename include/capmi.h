@@ -121,6 +121,14 @@ int capmi_attention_bwd(const float *d_ctx, int ld_dctx, const float *att_h, con
                         const float *p_att, const float *att, const float *mask, const float *w,
                         float *d_att_h, float *d_e, int B, int n, int K, int A, int R,
                         const int32_t *row_img, int N, void *stream);
+/* Same, with d_ctx delivered as the first R of x_cols columns of a dX GEMM left as K-slice slabs (capmi_gemm_f32,
+ * defer_reduce = 1): x[r,:] = sum_{s<x_splits} x_slabs[s*x_stride + r*x_cols + :].  Every workgroup finishes the
+ * reduction of its rows over all x_cols columns and publishes them to x_out [N, x_cols] (so the LSTM-cell backward and
+ * the time-batched pass read finished rows) -- the dX GEMM needs no reduce launch.  x_cols % 4 == 0, 16-byte aligned. */
+int capmi_attention_bwd_partial(const float *x_slabs, int x_splits, int64_t x_stride, int x_cols, float *x_out,
+                                const float *att_h, const float *alpha, const float *p_att, const float *att,
+                                const float *w, float *d_att_h, float *d_e, int B, int n, int K, int A, int R,
+                                const int32_t *row_img, int N, void *stream);
 
 /* time-batched feature/parameter gradients of the attention over a whole rollout of T steps:
  *   d_att[b,k,:]   += sum_{t, r in image b} alpha[t,r,k] * d_ctx[t,r,:]
