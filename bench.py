@@ -34,6 +34,21 @@ MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA (v_mf
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (32x32x16), 2495 TF measured
 
 
+def measured_copy_gbs(dev, mb=1024, iters=8):
+    """second denominator: what a plain device-to-device copy moves on THIS box, read + write bytes."""
+    src = torch.empty(mb << 18, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        dst.copy_(src)
+    b.record()
+    torch.cuda.synchronize()
+    return 2.0 * src.numel() * 4 * iters / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
 def pmc_traffic():
     """HBM bytes per decode-GEMM launch from the PMC passes of this same command (FETCH_SIZE and WRITE_SIZE need
     separate rocprofv3 --pmc runs, so they cannot be sampled inside this process): profiles/r01_pmc_traffic.json,
@@ -143,6 +158,7 @@ def main():
     value = captions / dt
 
     if rank == 0:
+        copy_gbs = measured_copy_gbs(dev)
         g_ms, g_n, g_bytes, g_flops = prof_read(lib, 0)
         a_ms, a_n, a_bytes, _ = prof_read(lib, 3)
         per_class = {'gemm_decode': {'ms_per_step': round(g_ms / args.steps, 4), 'launches_per_step': g_n / args.steps},
@@ -165,7 +181,8 @@ def main():
                     'peak': round(mfma_peak, 1) if mfma_bound else HBM_PEAK_GBS,
                     'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
                     'frac': round(tfl / mfma_peak if mfma_bound else ach / HBM_PEAK_GBS, 4),
-                    'traffic': pmc_traffic(), 'avg_launch_us': round(g_ms / max(g_n, 1) * 1e3, 2),
+                    'traffic': pmc_traffic(), 'hbm_copy_measured_gbs': round(copy_gbs, 1),
+                    'hbm_frac_of_measured_copy': round(ach / copy_gbs, 4) if copy_gbs else None, 'avg_launch_us': round(g_ms / max(g_n, 1) * 1e3, 2),
                     'algorithmic_bytes_per_launch': round(g_bytes / max(g_n, 1)),
                     'algorithmic_flops_per_launch': round(g_flops / max(g_n, 1)),
                     'flop_per_byte': round(ai, 2), 'hbm_gbs': round(ach, 1), 'hbm_frac': round(ach / HBM_PEAK_GBS, 4),
