@@ -274,3 +274,75 @@ class AoAGraph:
             d_y += lay['lv'].bwd(dv.view(BK, R))
             lay['n0'].bwd(d_y, dx)
         self.embed.bwd(dx, need_dx=False)
+
+
+# --------------------------------------------------------------------------- beam search (eval)
+class BeamDecoder:
+    """One AoA decoder step at a time for beam search (AoA_Decoder_Core, AoAModel.py:128-186, eval numerics): the
+    state of every hypothesis is (h_att, c_att, previous output) = three [N, R] arrays stacked so that a beam reorder is
+    one launch; the beam_size hypotheses of an image share its refined features (no repeat_tensors copy)."""
+
+    def __init__(self, graph, rows_per_image_max):
+        self.g = g = graph
+        P, B, R = g.P, g.B, g.R
+        self.B, self.R = B, R
+        self.N = N = B * rows_per_image_max
+        dev = g.dev
+        self.V1, self.E = P['embed.0.weight'].shape
+        z = lambda *s: torch.empty(*s, dtype=_f32, device=dev)       # noqa: E731
+        self.z = z
+        self.state = torch.zeros(3, N, R, dtype=_f32, device=dev)   # h_att, c_att, out (ctx of the previous step)
+        self.state_alt = torch.empty_like(self.state)
+        W_ih = P['core.att_lstm.weight_ih']
+        self.mean_gates = z(B, 4 * R)                                # mean-feature term of the gates, once per image
+        ops.gemm([(g.mean, R, (W_ih, self.E), self.E + R, R, 1)], B, 4 * R, self.mean_gates)
+        self.logits = z(N, self.V1)
+
+    def step(self, t, it, rows_per_image):
+        g = self.g
+        P, h, B, K, R, E, V1 = g.P, g.h, g.B, g.K, self.R, self.E, self.V1
+        rows = B * rows_per_image
+        z, st = self.z, stream_ptr()
+        ws = ops.default_workspace(g.dev)
+        W_ih, W_hh = P['core.att_lstm.weight_ih'], P['core.att_lstm.weight_hh']
+        h_prev, c_prev, ctx_prev = self.state[0, :rows], self.state[1, :rows], self.state[2, :rows]
+        new = self.state_alt
+        xt = z(rows, E)
+        check(lib.capmi_embed_fwd(ptr(it), 1, None, ptr(P['embed.0.weight']), None, ptr(xt), rows, E, 1, st), 'embed_fwd')
+        splits = ops.gemm([(xt, E, W_ih, E + R, E, 1), (ctx_prev, R, (W_ih, E), E + R, R, 1), (h_prev, R, W_hh, R, R, 1)], rows,
+                          4 * R, ws.buf, ws=ws, defer_reduce=True)
+        check(lib.capmi_lstm_cell_fwd(ws.slabs.data_ptr(), splits, ptr(P['core.att_lstm.bias_ih']), ptr(P['core.att_lstm.bias_hh']),
+                                      ptr(self.mean_gates), rows_per_image, None, ptr(c_prev), ptr(new[0]), ptr(new[1]), None, None,
+                                      None, rows, R, st), 'lstm_cell_fwd')
+        h_new = new[0, :rows]
+        qn, mu, inv = z(rows, R), z(rows), z(rows)
+        check(lib.capmi_layernorm_fwd(ptr(h_new), ptr(P['core.attention.norm.a_2']), ptr(P['core.attention.norm.b_2']), ptr(qn),
+                                      ptr(mu), ptr(inv), rows, R, EPS, st), 'layernorm_fwd')
+        q = z(rows, R)
+        ops.gemm([(qn, R, P['core.attention.linears.0.weight'], R, R, 1)], rows, R, q, bias=P['core.attention.linears.0.bias'])
+        att_o = z(rows, R)
+        # keys = second half of p_att rows, values = first half (AoAModel.py:168); per image, stride 2R
+        check(lib.capmi_mha_fwd(ptr(q), g.p_att.data_ptr() + 4 * R, ptr(g.p_att), K * 2 * R, 2 * R, ptr(g.smask), 1, 0, 0, 0, None,
+                                ptr(att_o), None, rows, rows_per_image, 1, K, h, R // h, st), 'mha_fwd')
+        Wc = P['core.att2ctx.0.weight']
+        pre2 = z(rows, 2 * R)
+        ops.gemm([(att_o, R, Wc, 2 * R, R, 1), (h_new, R, (Wc, R), 2 * R, R, 1)], rows, 2 * R, pre2, bias=P['core.att2ctx.0.bias'])
+        check(lib.capmi_glu_fwd(ptr(pre2), None, None, ptr(new[2]), rows, R, st), 'glu_fwd')
+        logits = self.logits[:rows]
+        ops.gemm([(new[2, :rows], R, P['logit.weight'], R, R, 1)], rows, V1, logits, bias=P['logit.bias'])
+        self.state, self.state_alt = new, self.state
+        self._keep = (xt, qn, mu, inv, q, att_o, pre2)           # scratch stays alive until the stream has used it
+        return logits
+
+    def reorder(self, parent, cur):
+        from . import beam
+        beam.reorder_rows(self.state, self.state_alt, parent, self.B, cur, self.N // self.B)
+        self.state, self.state_alt = self.state_alt, self.state
+
+
+def sample_beam(model, P, att_feats, att_masks, h, L, opt):
+    from . import beam
+    g = AoAGraph(P, {}, h, 0.0, 0.0, False, 0)
+    g.prepare(att_feats, att_masks)
+    dec = BeamDecoder(g, opt.get('beam_size', 10))
+    return beam.beam_search_steps(model, dec.step, dec.reorder, g.B, dec.V1, L, opt, att_feats.device)

@@ -71,15 +71,18 @@ def sample_beam(model, fc_feats, att_feats, att_masks, opt):
     w = engine.weights_struct(P)
     check(lib.capmi_updown_beam_search(C.byref(w), C.byref(b), stream_ptr()), 'capmi_updown_beam_search')
 
-    # ---- one device->host transfer of the small tables, then the bookkeeping of CaptionModel.py:183-209
-    parent = bufs['parent'].cpu().numpy()
-    token = bufs['token'].cpu().numpy()
-    score = bufs['score'].cpu().numpy()
-    ended = bufs['ended'].cpu().numpy()
+    return assemble_done_beams(model, bufs['parent'], bufs['token'], bufs['score'], bufs['ended'], bufs['logp_rows'], B, bd, L, V1,
+                               sample_n, beam_size, opt)
+
+
+def assemble_done_beams(model, parent, token, score, ended, logp_rows, B, bd, L, V1, sample_n, beam_size, opt):
+    """One device->host transfer of the small [L,B,bd] tables, then the bookkeeping of CaptionModel.py:183-209."""
+    dev = logp_rows.device
+    N = B * bd
+    parent, token, score, ended = (t.cpu().numpy() for t in (parent, token, score, ended))
     penalty = _penalty(opt.get('length_penalty', ''))
     seq = torch.zeros(B * sample_n, L, dtype=torch.long, device=dev)
     seq_logp = torch.zeros(B * sample_n, L, V1, dtype=_f32, device=dev)
-    logp_rows = bufs['logp_rows']
     done_beams = []
     gather_idx, gather_meta = [], []
     for k in range(B):
@@ -129,3 +132,62 @@ def sample_beam(model, fc_feats, att_feats, att_masks, opt):
             seq[k, :ln] = done_beams[k][0]['seq']
             seq_logp[k, :ln] = done_beams[k][0]['logps']
     return seq, seq_logp
+
+
+def unk_column(model, opt, V1):
+    """CaptionModel.py:159-162: the column pushed down by 1000 when suppress_UNK is on."""
+    if opt.get('suppress_UNK', 0) and hasattr(model, 'vocab') and model.vocab.get(str(V1 - 1)) == 'UNK':
+        return V1 - 1
+    if getattr(model, 'unk_idx', None) is not None:
+        return int(model.unk_idx)
+    return -1
+
+
+def beam_search_steps(model, step, reorder, B, V1, L, opt, dev):
+    """Beam search (CaptionModel.beam_search, group_size 1) for decoders whose step is orchestrated from the host
+    (Transformer, AoA): the selection / reordering / normalisation kernels and the finished-beam assembly are the ones of
+    the UpDown path, only the decoder step is a callback.
+
+    step(t, it, rows_per_image) -> logits [B*rows_per_image, V1]: consumes tokens `it` (BOS zeros at t = 0, one row per
+        image; afterwards beam_size rows per image) and advances the decoder state held by the caller.
+    reorder(parent [B,bd] int32, cur): state row b*cur + parent[b,j] becomes row b*bd + j.
+    """
+    beam_size = opt.get('beam_size', 10)
+    sample_n = opt.get('sample_n', 10)
+    if opt.get('group_size', 1) != 1:
+        raise NotImplementedError('diverse beam search (group_size > 1) is outside the hot-path scope')
+    for k in ('decoding_constraint', 'remove_bad_endings'):
+        if opt.get(k, 0):
+            raise NotImplementedError('%s is not part of the accelerated beam search' % k)
+    assert sample_n == 1 or sample_n == beam_size, 'when beam search, sample_n == 1 or beam search'
+    bd = beam_size
+    N = B * bd
+    temperature = float(opt.get('temperature', 1))
+    unk = unk_column(model, opt, V1)
+    logp_rows = torch.zeros(L, N, V1, dtype=_f32, device=dev)
+    parent = torch.zeros(L, B, bd, dtype=torch.int32, device=dev)
+    token = torch.zeros(L, B, bd, dtype=torch.long, device=dev)
+    score = torch.zeros(L, B, bd, dtype=_f32, device=dev)
+    ended = torch.zeros(L, B, bd, dtype=torch.uint8, device=dev)
+    sums = torch.zeros(2, B, bd, dtype=_f32, device=dev)
+    st = stream_ptr()
+    it = torch.zeros(B, dtype=torch.long, device=dev)                       # BOS
+    logits = step(0, it, 1)
+    check(lib.capmi_beam_logsoftmax(ptr(logits), ptr(logp_rows[0]), B, V1, temperature, unk, st), 'beam_logsoftmax')
+    cur = 1
+    for t in range(L):
+        check(lib.capmi_beam_select(ptr(logp_rows[t]), ptr(sums[t & 1]), B, cur, bd, V1, 1 if t == L - 1 else 0, ptr(parent[t]),
+                                    ptr(token[t]), ptr(score[t]), ptr(sums[(t + 1) & 1]), ptr(ended[t]), st), 'beam_select')
+        if t == L - 1:
+            break
+        reorder(parent[t], cur)
+        logits = step(t + 1, token[t].reshape(N), bd)
+        check(lib.capmi_beam_logsoftmax(ptr(logits), ptr(logp_rows[t + 1]), N, V1, temperature, unk, st), 'beam_logsoftmax')
+        cur = bd
+    return assemble_done_beams(model, parent, token, score, ended, logp_rows, B, bd, L, V1, sample_n, beam_size, opt)
+
+
+def reorder_rows(src, dst, parent, B, cur, bd):
+    """dst[a, b*bd + j, :] = src[a, b*cur + parent[b,j], :] for stacked state arrays [arrays, rows, R] (capmi_beam_reorder)."""
+    arrays, _, R = src.shape
+    check(lib.capmi_beam_reorder(ptr(src), ptr(dst), ptr(parent), arrays, B, cur, bd, R, stream_ptr()), 'beam_reorder')

@@ -137,7 +137,14 @@ class AoAModel(CaptionModel):
     def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
         method = opt.get('sample_method', 'greedy')
         if opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search'):
-            raise NotImplementedError('beam search for AoA is not accelerated yet')
+            if not att_feats.is_cuda:
+                raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
+            if att_masks is not None:
+                ml = int(att_masks.long().sum(1).max())
+                att_feats, att_masks = att_feats[:, :ml], att_masks[:, :ml].float().contiguous()
+            with torch.no_grad():
+                P = dict(zip(self._param_names, [p.detach() for _, p in self.named_parameters()]))
+                return engine.sample_beam(self, P, att_feats.float().contiguous(), att_masks, self.num_heads, self.seq_length, opt)
         if method not in ('greedy', 'sample'):
             raise NotImplementedError('sample_method %r' % method)
         L = self.seq_length

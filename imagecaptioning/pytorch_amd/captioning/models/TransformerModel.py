@@ -203,7 +203,10 @@ class TransformerModel(CaptionModel):
             raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
         method = opt.get('sample_method', 'greedy')
         if opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search'):
-            raise NotImplementedError('beam search for the transformer is not accelerated yet')
+            att_feats, att_masks = self._clip(att_feats, att_masks)
+            with torch.no_grad():
+                P = self._pdict([p for _, p in self.named_parameters()])
+                return engine.sample_beam(self, P, att_feats, att_masks, self.h, self.N_enc, self.N_dec, self.seq_length, opt)
         if method not in ('greedy', 'sample'):
             raise NotImplementedError('sample_method %r' % method)
         n = int(opt.get('sample_n', 1))

@@ -287,73 +287,116 @@ class TransformerGraph:
 
 
 # --------------------------------------------------------------------------- KV-cached sampling
+class Decoder:
+    """Incremental Transformer decoder (eval numerics) with a real KV cache written in place by the K/V GEMMs
+    (ldc = L*D), instead of TransformerModel.core's re-decode of the whole prefix (TransformerModel.py:351-362).
+    Holds the state of `rows` = B * rows_per_image hypotheses; used by greedy/sampling rollouts and by beam search
+    (the self-attention caches of all layers are ONE stacked [2*n_dec, N, L*D] array so that a beam reorder is one
+    launch)."""
+
+    def __init__(self, P, att_feats, att_masks, h, n_enc, n_dec, L, rows_per_image_max):
+        self.P, self.h, self.n_dec, self.L = P, h, n_dec, L
+        dev = att_feats.device
+        self.g = g = TransformerGraph(P, {}, h, n_enc, n_dec, 0.0, 0.0, False, 0)
+        memory = g.encode(att_feats, att_masks)            # eval-mode encoder; Lin objects keep refs only
+        self.B, self.K, self.D = g.B, g.K, g.D
+        self.N = N = self.B * rows_per_image_max
+        D = self.D
+        self.V1 = P['model.generator.proj.weight'].shape[0]
+        z = lambda *s: torch.empty(*s, dtype=_f32, device=dev)       # noqa: E731
+        self.z = z
+        self.mem_k, self.mem_v = [], []
+        for i in range(n_dec):
+            pre = 'model.decoder.layers.%d.src_attn' % i
+            self.mem_k.append(ops.linear(memory, P[pre + '.linears.1.weight'], P[pre + '.linears.1.bias']))
+            self.mem_v.append(ops.linear(memory, P[pre + '.linears.2.weight'], P[pre + '.linears.2.bias']))
+        self.kv = z(2 * n_dec, N, L * D)                   # [2i] = K cache, [2i+1] = V cache of layer i
+        self.kv_alt = None                                  # ping-pong partner, allocated on the first beam reorder
+        self.logits = z(N, self.V1)
+        self.x = z(N, D)
+
+    def _lin(self, xx, wname, bname, out=None, ldc=None, relu=False, residual=None):
+        P = self.P
+        W = P[wname]
+        M, Kd = xx.shape
+        Nn = W.shape[0]
+        if residual is not None:
+            ops.gemm([(xx, Kd, W, Kd, Kd, 1)], M, Nn, residual, bias=P[bname], accumulate=True)
+            return residual
+        if out is None:
+            out = self.z(M, Nn)
+        ops.gemm([(xx, Kd, W, Kd, Kd, 1)], M, Nn, out, ldc=ldc, bias=P[bname], relu=relu)
+        return out
+
+    def step(self, t, it, rows_per_image):
+        """token ids `it` [rows] at position t -> logits [rows, V1] (a view of an internal buffer)."""
+        P, h, L, D, K = self.P, self.h, self.L, self.D, self.K
+        rows = self.B * rows_per_image
+        lin = self._lin
+        st = stream_ptr()
+        x = self.x[:rows]
+        check(lib.capmi_embed_pe_fwd(ptr(it), 1, ptr(P['model.tgt_embed.0.lut.weight']), ptr(P['model.tgt_embed.1.pe']), None, ptr(x),
+                                     rows, 1, D, t, st), 'embed_pe_fwd')
+        xs = x.clone()
+        for i in range(self.n_dec):
+            pre = 'model.decoder.layers.%d' % i
+            kc, vc = self.kv[2 * i], self.kv[2 * i + 1]
+            y, _, _ = layernorm_fwd(xs, P[pre + '.sublayer.0.norm.a_2'], P[pre + '.sublayer.0.norm.b_2'])
+            q = lin(y, pre + '.self_attn.linears.0.weight', pre + '.self_attn.linears.0.bias')
+            lin(y, pre + '.self_attn.linears.1.weight', pre + '.self_attn.linears.1.bias', out=(kc, t * D), ldc=L * D)
+            lin(y, pre + '.self_attn.linears.2.weight', pre + '.self_attn.linears.2.bias', out=(vc, t * D), ldc=L * D)
+            o, _ = mha_fwd(q, kc, vc, L * D, rows, 1, 1, t + 1, h, want_p=False)
+            xs = lin(o.view(rows, D), pre + '.self_attn.linears.3.weight', pre + '.self_attn.linears.3.bias', residual=xs)
+            y, _, _ = layernorm_fwd(xs, P[pre + '.sublayer.1.norm.a_2'], P[pre + '.sublayer.1.norm.b_2'])
+            q = lin(y, pre + '.src_attn.linears.0.weight', pre + '.src_attn.linears.0.bias')
+            o, _ = mha_fwd(q, self.mem_k[i], self.mem_v[i], K * D, rows, rows_per_image, 1, K, h, mask=self.g.smask, mask_tq=1,
+                           mask_per_q=0, want_p=False)
+            xs = lin(o.view(rows, D), pre + '.src_attn.linears.3.weight', pre + '.src_attn.linears.3.bias', residual=xs)
+            y, _, _ = layernorm_fwd(xs, P[pre + '.sublayer.2.norm.a_2'], P[pre + '.sublayer.2.norm.b_2'])
+            hdn = lin(y, pre + '.feed_forward.w_1.weight', pre + '.feed_forward.w_1.bias', relu=True)
+            xs = lin(hdn, pre + '.feed_forward.w_2.weight', pre + '.feed_forward.w_2.bias', residual=xs)
+        y, _, _ = layernorm_fwd(xs, P['model.decoder.norm.a_2'], P['model.decoder.norm.b_2'])
+        logits = self.logits[:rows]
+        lin(y, 'model.generator.proj.weight', 'model.generator.proj.bias', out=logits)
+        return logits
+
+    def reorder(self, parent, cur):
+        """beam search: cache row b*cur + parent[b,j] -> row b*bd + j, all layers in one launch."""
+        from . import beam
+        bd = self.N // self.B
+        if self.kv_alt is None:
+            self.kv_alt = torch.empty_like(self.kv)
+        beam.reorder_rows(self.kv, self.kv_alt, parent, self.B, cur, bd)
+        self.kv, self.kv_alt = self.kv_alt, self.kv
+
+
 def sample(P, att_feats, att_masks, h, n_enc, n_dec, L, sample_n=1, mode='greedy', temperature=1.0, seed=0, forced=None,
            gumbel=None):
     """AttModel._sample with TransformerModel.core semantics (eval numerics), KV cache instead of prefix re-decode.
     Returns (seq [N,L], seq_logp [N,L,V1])."""
     dev = att_feats.device
-    g = TransformerGraph(P, {}, h, n_enc, n_dec, 0.0, 0.0, False, 0)
-    memory = g.encode(att_feats, att_masks)            # eval-mode encoder; Lin objects keep refs only
-    B, K, D = g.B, g.K, g.D
-    n = sample_n
-    N = B * n
-    V1 = P['model.generator.proj.weight'].shape[0]
-    z = lambda *s: torch.empty(*s, dtype=_f32, device=dev)       # noqa: E731
-    # per-layer memory K/V (per image) and self-attention caches
-    mem_k, mem_v, kc, vc = [], [], [], []
-    for i in range(n_dec):
-        pre = 'model.decoder.layers.%d.src_attn' % i
-        mem_k.append(ops.linear(memory, P[pre + '.linears.1.weight'], P[pre + '.linears.1.bias']))
-        mem_v.append(ops.linear(memory, P[pre + '.linears.2.weight'], P[pre + '.linears.2.bias']))
-        kc.append(z(N, L, D))
-        vc.append(z(N, L, D))
+    dec = Decoder(P, att_feats, att_masks, h, n_enc, n_dec, L, sample_n)
+    N, V1, n = dec.N, dec.V1, sample_n
     seq = torch.zeros(N, L, dtype=torch.long, device=dev)
     seq_logp = torch.zeros(N, L, V1, dtype=_f32, device=dev)
     sel = torch.zeros(N, L, dtype=_f32, device=dev)
     live = torch.zeros(N, L, dtype=torch.uint8, device=dev)
     it = torch.zeros(N, dtype=torch.long, device=dev)
     unf = torch.ones(N, dtype=torch.uint8, device=dev)
-    logits = z(N, V1)
-    x = z(N, D)
     mode_i = {'greedy': 0, 'sample': 1, 'forced': 2}[mode]
-    lut, pe = P['model.tgt_embed.0.lut.weight'], P['model.tgt_embed.1.pe']
     st = stream_ptr()
-
-    def lin(xx, wname, bname, out=None, ldc=None, relu=False, residual=None):
-        W = P[wname]
-        M, Kd = xx.shape
-        Nn = W.shape[0]
-        if residual is not None:
-            out = residual
-            ops.gemm([(xx, Kd, W, Kd, Kd, 1)], M, Nn, out, bias=P[bname], accumulate=True)
-            return out
-        if out is None:
-            out = z(M, Nn)
-        ops.gemm([(xx, Kd, W, Kd, Kd, 1)], M, Nn, out, ldc=ldc, bias=P[bname], relu=relu)
-        return out
-
     for t in range(L):
-        check(lib.capmi_embed_pe_fwd(ptr(it), 1, ptr(lut), ptr(pe), None, ptr(x), N, 1, D, t, st), 'embed_pe_fwd')
-        xs = x.clone()
-        for i in range(n_dec):
-            pre = 'model.decoder.layers.%d' % i
-            y, _, _ = layernorm_fwd(xs, P[pre + '.sublayer.0.norm.a_2'], P[pre + '.sublayer.0.norm.b_2'])
-            q = lin(y, pre + '.self_attn.linears.0.weight', pre + '.self_attn.linears.0.bias')
-            lin(y, pre + '.self_attn.linears.1.weight', pre + '.self_attn.linears.1.bias', out=(kc[i], t * D), ldc=L * D)
-            lin(y, pre + '.self_attn.linears.2.weight', pre + '.self_attn.linears.2.bias', out=(vc[i], t * D), ldc=L * D)
-            o, _ = mha_fwd(q, kc[i], vc[i], L * D, N, 1, 1, t + 1, h, want_p=False)
-            xs = lin(o.view(N, D), pre + '.self_attn.linears.3.weight', pre + '.self_attn.linears.3.bias', residual=xs)
-            y, _, _ = layernorm_fwd(xs, P[pre + '.sublayer.1.norm.a_2'], P[pre + '.sublayer.1.norm.b_2'])
-            q = lin(y, pre + '.src_attn.linears.0.weight', pre + '.src_attn.linears.0.bias')
-            o, _ = mha_fwd(q, mem_k[i], mem_v[i], K * D, N, n, 1, K, h, mask=g.smask, mask_tq=1, mask_per_q=0, want_p=False)
-            xs = lin(o.view(N, D), pre + '.src_attn.linears.3.weight', pre + '.src_attn.linears.3.bias', residual=xs)
-            y, _, _ = layernorm_fwd(xs, P[pre + '.sublayer.2.norm.a_2'], P[pre + '.sublayer.2.norm.b_2'])
-            hdn = lin(y, pre + '.feed_forward.w_1.weight', pre + '.feed_forward.w_1.bias', relu=True)
-            xs = lin(hdn, pre + '.feed_forward.w_2.weight', pre + '.feed_forward.w_2.bias', residual=xs)
-        y, _, _ = layernorm_fwd(xs, P['model.decoder.norm.a_2'], P['model.decoder.norm.b_2'])
-        lin(y, 'model.generator.proj.weight', 'model.generator.proj.bias', out=logits)
+        logits = dec.step(t, it, n)
         check(lib.capmi_logsoftmax_select(ptr(logits), N, V1, t, L, mode_i, None, float(temperature),
                                           None if gumbel is None else gumbel[t].data_ptr(), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                           ptr(forced), 0 if forced is None else forced.shape[1], 0, ptr(seq), L, ptr(it),
                                           ptr(unf), ptr(seq_logp), ptr(sel), ptr(live), st), 'logsoftmax_select')
     return seq, seq_logp
+
+
+def sample_beam(model, P, att_feats, att_masks, h, n_enc, n_dec, L, opt):
+    """AttModel._sample_beam (AttModel.py:218-256) for the Transformer: beam_size hypotheses per image share the image's
+    encoder memory (no repeat_tensors copy), the KV caches follow the beams by parent pointer."""
+    from . import beam
+    dec = Decoder(P, att_feats, att_masks, h, n_enc, n_dec, L, opt.get('beam_size', 10))
+    return beam.beam_search_steps(model, dec.step, dec.reorder, dec.B, dec.V1, L, opt, att_feats.device)

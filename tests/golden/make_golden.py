@@ -257,8 +257,52 @@ def main_aoa():
     print('aoa_tiny.npz:', len(out), 'arrays')
 
 
+def _dump_beams(model, out, tag, seq, slp):
+    out[tag + '_seq'] = seq.numpy()
+    out[tag + '_logp'] = slp.numpy()
+    for k, beams in enumerate(model.done_beams):
+        out['%s_n%d' % (tag, k)] = np.array(len(beams))
+        for j, bm in enumerate(beams):
+            out['%s_%d_%d_seq' % (tag, k, j)] = bm['seq'].numpy()
+            out['%s_%d_%d_p' % (tag, k, j)] = np.array(bm['p'])
+            out['%s_%d_%d_unaug' % (tag, k, j)] = np.array(bm['unaug_p'])
+
+
+def main_beam2():
+    """Beam-search fixtures for the Transformer and AoA models (BASELINE configs[4] evaluates with beam_size 5): the
+    reference's AttModel._sample_beam / CaptionModel.beam_search on the weights of transformer_tiny.npz / aoa_tiny.npz."""
+    sys.path.insert(0, REF)
+    import captioning.models as models
+    z = np.load(os.path.join(HERE, 'updown_tiny.npz'))
+    fc, att, am = (torch.from_numpy(z[k]) for k in ('fc', 'att', 'att_masks'))
+    for name in ('transformer', 'aoa'):
+        zz = np.load(os.path.join(HERE, name + '_tiny.npz'))
+        opt = tiny_opt(name, drop=0.0)
+        if name == 'transformer':
+            opt.N_enc, opt.N_dec, opt.d_model, opt.d_ff, opt.num_att_heads, opt.dropout = 2, 2, 16, 32, 2, 0.0
+        else:
+            opt.refine, opt.refine_aoa, opt.use_ff, opt.decoder_type, opt.use_multi_head = 1, 1, 0, 'AoA', 2
+            opt.num_heads, opt.multi_head_scale, opt.mean_feats, opt.ctx_drop, opt.dropout_aoa = 2, 1, 1, 1, 0.3
+            opt.num_layers = 2
+        model = models.setup(opt)
+        model.load_state_dict({k[2:]: torch.from_numpy(zz[k]) for k in zz.files if k.startswith('P.')})
+        model.eval()
+        out = {}
+        with torch.no_grad():
+            for tag, bs, masks, kw in (('b3', 3, None, {}), ('b2m', 2, am, {}), ('b3n', 3, None, {'sample_n': 3}),
+                                       ('b3lp', 3, am, {'length_penalty': 'avg_0'})):
+                o = {'sample_method': 'beam_search', 'beam_size': bs, 'sample_n': 1}
+                o.update(kw)
+                seq, slp = model(fc, att, masks, opt=o, mode='sample')
+                _dump_beams(model, out, tag, seq, slp)
+        np.savez_compressed(os.path.join(HERE, name + '_tiny_beam.npz'), **out)
+        print(name + '_tiny_beam.npz:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'aoa':
+    if len(sys.argv) > 1 and sys.argv[1] == 'beam2':
+        main_beam2()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'aoa':
         main_aoa()
     elif len(sys.argv) > 1 and sys.argv[1] == 'beam':
         main_beam()

@@ -57,3 +57,43 @@ def test_beam_select_properties():
     assert torch.equal(parent.long(), ix[:, :bd] // V1) and torch.equal(token, ix[:, :bd] % V1)
     assert int(token[0, 0]) == 0 and int(ended[0, 0]) == 1
     assert torch.allclose(nxt, score - 1000.0 * ended.float())
+
+
+def _family_model(name):
+    from imagecaptioning.pytorch_amd.captioning import models
+    from test_model_api_gpu import tiny_opt
+    z = np.load(os.path.join(GOLDEN, name + '_tiny.npz'))
+    if name == 'transformer':
+        opt = tiny_opt(caption_model='transformer', N_enc=2, N_dec=2, d_model=16, d_ff=32, num_att_heads=2, dropout=0.0)
+    else:
+        opt = tiny_opt(caption_model='aoa', refine=1, refine_aoa=1, use_ff=0, decoder_type='AoA', use_multi_head=2, num_heads=2,
+                       multi_head_scale=1, mean_feats=1, ctx_drop=1, dropout_aoa=0.3, num_layers=2)
+    model = models.setup(opt)
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('P.')})
+    return model.to(DEV).eval()
+
+
+@pytest.mark.parametrize('name', ['transformer', 'aoa'])
+@pytest.mark.parametrize('tag,bs,masked,kw', [('b3', 3, False, {}), ('b2m', 2, True, {}), ('b3n', 3, False, {'sample_n': 3}),
+                                              ('b3lp', 3, True, {'length_penalty': 'avg_0'})])
+def test_beam_search_transformer_aoa_match_reference(name, tag, bs, masked, kw):
+    """BASELINE configs[4] evaluates AoA with beam_size 5: the host-stepped beam search (native selection / reorder /
+    normalisation kernels, KV caches or LSTM state following the beams by parent pointer) against fixtures produced by
+    the real reference's CaptionModel.beam_search on the same weights."""
+    model = _family_model(name)
+    u = np.load(os.path.join(GOLDEN, 'updown_tiny.npz'))
+    g = np.load(os.path.join(GOLDEN, name + '_tiny_beam.npz'))
+    att = torch.from_numpy(u['att']).to(DEV)
+    am = torch.from_numpy(u['att_masks']).to(DEV) if masked else None
+    o = {'sample_method': 'beam_search', 'beam_size': bs, 'sample_n': 1}
+    o.update(kw)
+    with torch.no_grad():
+        seq, slp = model(None, att, am, opt=o, mode='sample')
+    assert np.array_equal(seq.cpu().numpy(), g[tag + '_seq'])
+    np.testing.assert_allclose(slp.cpu().numpy(), g[tag + '_logp'], rtol=5e-5, atol=2e-5)
+    for k, beams in enumerate(model.done_beams):
+        assert len(beams) == int(g['%s_n%d' % (tag, k)])
+        for j, bm in enumerate(beams):
+            assert np.array_equal(bm['seq'].cpu().numpy(), g['%s_%d_%d_seq' % (tag, k, j)]), (k, j)
+            np.testing.assert_allclose(bm['p'], g['%s_%d_%d_p' % (tag, k, j)], rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(bm['unaug_p'], g['%s_%d_%d_unaug' % (tag, k, j)], rtol=1e-4)
