@@ -46,7 +46,11 @@ class UpDownRollout(C.Structure):
                 [(k, c_f) for k in ('h_att', 'c_att', 'h_lang', 'c_lang', 'xt', 'it_all', 'gates_att', 'gates_lang',
                                     'att_h', 'alpha', 'ctx', 'h_drop', 'seq', 'seq_logp', 'sel_logp', 'live',
                                     'fc_gates', 'logits', 'it', 'unfinished', 'partial')] +
-                [('partial_capacity', C.c_int64)])
+                [('partial_capacity', C.c_int64), ('top_k', C.c_int), ('top_p', C.c_float)])
+
+
+class SampleFilter(C.Structure):
+    _fields_ = [('top_k', C.c_int), ('top_p', C.c_float)]
 
 
 class UpDownGrads(C.Structure):
@@ -111,7 +115,7 @@ SIGNATURES = {
     'capmi_embed_bwd': [_P] * 5 + [_I, _I, _I, _P],
     'capmi_logsoftmax_select': [_P, _I, _I, _I, _I, _I, _P, _F, _P, _U64, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P],
     'capmi_logsoftmax_select_partial': [_P, _I, _I64, _P, _I, _I, _I, _I, _I, _P, _F, _P, _U64, _P, _I, _I, _P, _I, _P, _P, _P,
-                                        _P, _P, _P, _P],
+                                        _P, _P, _P, _P, _P],
     'capmi_logsoftmax_bwd': [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     'capmi_splitk_reduce': [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P],
     'capmi_dropout_mask': [_P, _I64, _F, _U64, _U64, _P],

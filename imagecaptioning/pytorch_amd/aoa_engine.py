@@ -92,7 +92,8 @@ class AoAGraph:
         return self.mean, self.att, self.p_att
 
     # ------------------------------------------------------------------ rollout
-    def rollout(self, n, T, L, mode='forced', forced=None, teacher=False, temperature=1.0, seed=0, gumbel=None, keep=True):
+    def rollout(self, n, T, L, mode='forced', forced=None, teacher=False, temperature=1.0, seed=0, gumbel=None, keep=True,
+                top_k=0, top_p=0.0):
         """T decoder steps on N = B*n rows.  teacher: inputs forced[:, t] (AttModel._forward); else AttModel._sample with
         mode greedy / sample / forced (tokens chosen at t are fed at t+1)."""
         P, h, B, K, R = self.P, self.h, self.B, self.K, self.R
@@ -160,11 +161,8 @@ class AoAGraph:
             else:
                 check(lib.capmi_relu_mask_bwd(ptr(self.out[t + 1]), None, ptr(m_out), ptr(self.out_drop[t]), N * R, st), 'out_drop')
             ops.gemm([(self.out_drop[t], R, P['logit.weight'], R, R, 1)], N, V1, logits, bias=P['logit.bias'])
-            check(lib.capmi_logsoftmax_select(ptr(logits), N, V1, t, L, mode_i, None, float(temperature),
-                                              None if gumbel is None else gumbel[t].data_ptr(), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                                              ptr(forced), 0 if forced is None else forced.shape[1], 1 if teacher else 0,
-                                              ptr(self.seq), L, ptr(it), ptr(unf), ptr(self.seq_logp), ptr(self.sel), ptr(self.live),
-                                              st), 'logsoftmax_select')
+            ops.logsoftmax_select(logits, t, L, mode_i, temperature, None if gumbel is None else gumbel[t], seed, forced,
+                                  1 if teacher else 0, self.seq, it, unf, self.seq_logp, self.sel, self.live, top_k, top_p)
         return self.seq, self.seq_logp
 
     # ------------------------------------------------------------------ backward

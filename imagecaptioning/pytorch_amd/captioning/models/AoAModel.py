@@ -145,9 +145,9 @@ class AoAModel(CaptionModel):
             with torch.no_grad():
                 P = dict(zip(self._param_names, [p.detach() for _, p in self.named_parameters()]))
                 return engine.sample_beam(self, P, att_feats.float().contiguous(), att_masks, self.num_heads, self.seq_length, opt)
-        if method not in ('greedy', 'sample'):
-            raise NotImplementedError('sample_method %r' % method)
+        from .utils import parse_sample_method
+        mode, temperature, top_k, top_p = parse_sample_method(method, opt.get('temperature', 1.0))
         L = self.seq_length
-        cfg = dict(n=int(opt.get('sample_n', 1)), T=L, L=L, mode=method, temperature=opt.get('temperature', 1.0),
-                   seed=self._next_seed(), gumbel=opt.get('_gumbel'))
+        cfg = dict(n=int(opt.get('sample_n', 1)), T=L, L=L, mode=mode, temperature=temperature,
+                   seed=self._next_seed(), gumbel=opt.get('_gumbel'), top_k=top_k, top_p=top_p)
         return self._run(cfg, att_feats, att_masks)

@@ -26,6 +26,9 @@ bad_endings = ['a', 'an', 'the', 'in', 'for', 'at', 'of', 'with', 'before', 'aft
                'are', 'am', 'the']
 
 
+from .utils import parse_sample_method      # noqa: E402
+
+
 class _RolloutFn(torch.autograd.Function):
     """(params..., feats) -> (seq, dense seqLogprobs); backward = hand-written BPTT + prefill backward.
     Gradients are written into the model's flat gradient views when it has them."""
@@ -49,7 +52,7 @@ class _RolloutFn(torch.autograd.Function):
                             temperature=cfg.get('temperature', 1.0), drop_xt=cfg.get('drop_xt'),
                             drop_out=cfg.get('drop_out'), gumbel=cfg.get('gumbel'), seed=cfg.get('seed', 0),
                             forced=cfg.get('forced'), teacher=cfg.get('teacher', False), row_mode=cfg.get('row_mode'),
-                            **extra)
+                            top_k=cfg.get('top_k', 0), top_p=cfg.get('top_p', 0.0), **extra)
         seq, seq_logp = ro.run()
         ctx.model, ctx.ro, ctx.pr, ctx.P = model, ro, pr, P
         ctx.mark_non_differentiable(seq)
@@ -223,17 +226,12 @@ class AttModel(CaptionModel):
                 raise NotImplementedError('%s is not part of the accelerated rollout yet' % k)
         if not opt.get('output_logsoftmax', 1):
             raise NotImplementedError('output_logsoftmax=0 is only used by margin structure losses')
-        if sample_method == 'greedy':
-            mode = 'greedy'
-        elif sample_method == 'sample':
-            mode = 'sample'
-        else:
-            raise NotImplementedError('sample_method %r (only greedy / sample / beam_search are accelerated)' % sample_method)
+        mode, temperature, top_k, top_p = parse_sample_method(sample_method, temperature)
         B = fc_feats.size(0)
         N = B * sample_n
         L = self.seq_length
         K = att_feats.shape[1] if att_masks is None else int(att_masks.long().sum(1).max())
-        cfg = dict(n=sample_n, T=L, L=L, mode=mode, temperature=temperature, seed=self._next_seed())
+        cfg = dict(n=sample_n, T=L, L=L, mode=mode, temperature=temperature, seed=self._next_seed(), top_k=top_k, top_p=top_p)
         cfg.update(self._dropout_masks(B, K, N, L, fc_feats.device))
         forced = opt.get('_forced_seq')           # test hook: teacher-force a sampled sequence
         if forced is not None:

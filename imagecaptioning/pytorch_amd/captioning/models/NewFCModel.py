@@ -99,8 +99,10 @@ class NewFCModel(CaptionModel):
         method = opt.get('sample_method', 'greedy')
         if opt.get('beam_size', 1) > 1:
             raise NotImplementedError('beam search for newfc is not accelerated')
-        if method not in ('greedy', 'sample'):
-            raise NotImplementedError('sample_method %r' % method)
-        cfg = dict(n=int(opt.get('sample_n', 1)), T=self.seq_length, L=self.seq_length, mode=method,
-                   temperature=opt.get('temperature', 1.0), seed=self._next_seed())
+        from .utils import parse_sample_method
+        mode, temperature, top_k, top_p = parse_sample_method(method, opt.get('temperature', 1.0))
+        if top_k or top_p:
+            raise NotImplementedError('top-k / nucleus sampling is not wired into the newfc rollout (plumbing config)')
+        cfg = dict(n=int(opt.get('sample_n', 1)), T=self.seq_length, L=self.seq_length, mode=mode,
+                   temperature=temperature, seed=self._next_seed())
         return self._run(cfg, fc_feats)

@@ -207,15 +207,15 @@ class TransformerModel(CaptionModel):
             with torch.no_grad():
                 P = self._pdict([p for _, p in self.named_parameters()])
                 return engine.sample_beam(self, P, att_feats, att_masks, self.h, self.N_enc, self.N_dec, self.seq_length, opt)
-        if method not in ('greedy', 'sample'):
-            raise NotImplementedError('sample_method %r' % method)
+        from .utils import parse_sample_method
+        mode, temperature, top_k, top_p = parse_sample_method(method, opt.get('temperature', 1.0))
         n = int(opt.get('sample_n', 1))
         att_feats, att_masks = self._clip(att_feats, att_masks)
         with torch.no_grad():
             P = self._pdict([p for _, p in self.named_parameters()])
             seq, logp = engine.sample(P, att_feats, att_masks, self.h, self.N_enc, self.N_dec, self.seq_length, sample_n=n,
-                                      mode=method, temperature=opt.get('temperature', 1.0), seed=self._next_seed(),
-                                      gumbel=opt.get('_gumbel'))
+                                      mode=mode, temperature=temperature, seed=self._next_seed(),
+                                      gumbel=opt.get('_gumbel'), top_k=top_k, top_p=top_p)
         if not (torch.is_grad_enabled() and self.training):
             return seq, logp
         # differentiable log-probs of the drawn tokens: inputs [bos, w_0 .. w_{L-2}]

@@ -24,3 +24,20 @@ def split_tensors(n, x):
     if x is None:
         return [None] * n
     return x
+
+
+def parse_sample_method(sample_method, temperature):
+    """CaptionModel.sample_next_word (CaptionModel.py:370-407) -> (kernel mode, temperature, top_k, top_p).
+    'gumbel': arg-max of (logp + Gumbel) / T is a categorical draw from softmax(logp) -- the temperature cancels in the
+    arg-max -- i.e. the 'sample' kernel at temperature 1.  'top<k>' keeps the k most probable tokens, 'top<p>' (0<p<1)
+    the nucleus of softmax(logp / T)."""
+    if sample_method == 'greedy':
+        return 'greedy', temperature, 0, 0.0
+    if sample_method == 'sample':
+        return 'sample', temperature, 0, 0.0
+    if sample_method == 'gumbel':
+        return 'sample', 1.0, 0, 0.0
+    if sample_method.startswith('top'):
+        num = float(sample_method[3:])
+        return ('sample', temperature, 0, num) if 0 < num < 1 else ('sample', temperature, int(num), 0.0)
+    raise NotImplementedError('sample_method %r' % sample_method)

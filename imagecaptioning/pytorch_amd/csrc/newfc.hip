@@ -165,7 +165,7 @@ int capmi_newfc_rollout_fwd(const capmi_newfc_weights *w, capmi_newfc_rollout *r
         RC(capmi_logsoftmax_select_partial(slabs, splits, (int64_t)N * V1, w->logit_b, N, V1, t, L, r->teacher ? 2 : r->mode,
                                            nullptr, r->temperature, r->gumbel ? r->gumbel + (size_t)t * N * V1 : nullptr,
                                            r->seed, r->forced, r->forced_ld, r->teacher ? 1 : 0, r->seq, L, r->it,
-                                           r->unfinished, r->seq_logp, r->sel_logp, r->live, nullptr, stream));
+                                           r->unfinished, r->seq_logp, r->sel_logp, r->live, nullptr, nullptr, stream));
     }
     return 0;
 }

@@ -143,6 +143,7 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
             SegSpec s{h_drop, R, w->logit_w, R, R, 1};
             RC(gemm(stream, 0, 0, N, V1, r->partial, V1, &s, 1, r->partial, r->partial_capacity, 1, &splits));
         }
+        capmi_sample_filter flt{r->top_k, r->top_p};
         capmi_next_embed ne{};
         if (!r->teacher && t + 1 < T) {
             ne.E = w->embed; ne.Edim = E; ne.relu = 1;
@@ -154,7 +155,7 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
                                            L, r->teacher ? 2 : r->mode, r->teacher ? nullptr : r->row_mode, r->temperature,
                                            r->gumbel ? r->gumbel + (size_t)t * N * V1 : nullptr, r->seed, r->forced,
                                            r->forced_ld, r->teacher ? 1 : 0, r->seq, L, r->it, r->unfinished, r->seq_logp,
-                                           r->sel_logp, r->live, &ne, stream));
+                                           r->sel_logp, r->live, &ne, (r->top_k > 0 || r->top_p > 0.f) ? &flt : nullptr, stream));
     }
     return 0;
 }

@@ -37,6 +37,12 @@ __device__ __forceinline__ ArgMax wave_argmax(ArgMax x) {
     return x;
 }
 
+// order-preserving map float -> uint32 (a < b  <=>  key(a) < key(b); -inf -> smallest)
+__device__ __forceinline__ uint32_t order_key(float f) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
 // next step's token embedding written by the workgroup that just chose the token (saves the embed launch of every
 // step but the first): x_next[r,:] = relu?(E[token,:]) * mask[r,:], it_save[r] = token
 struct NextEmbed {
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
     float temperature, const float *__restrict__ gumbel, uint64_t seed, const int64_t *__restrict__ forced,
     int forced_ld, int no_finish_mask, int64_t *__restrict__ seq, int seq_ld, int64_t *__restrict__ it_next,
     uint8_t *__restrict__ unfinished, float *__restrict__ seq_logp, float *__restrict__ sel_logp,
-    uint8_t *__restrict__ live, const NextEmbed ne) {
+    uint8_t *__restrict__ live, const NextEmbed ne, int top_k, float top_p) {
     __shared__ float s_f[32];
     __shared__ int s_i[32];
     const int r = blockIdx.x;
@@ -100,10 +106,39 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
             for (int v = threadIdx.x; v < V1; v += blockDim.x) best = better(best, ArgMax{x[v], v});
         } else {
             const float invT = 1.f / temperature;
+            // top-k / nucleus threshold: same radix descent as the register-resident kernel (see there)
+            uint32_t thr_key = 0;
+            if (top_k > 0 || top_p > 0.f) {
+                float lse_t = 0.f;
+                if (top_p > 0.f) {
+                    float mt = -INFINITY, st = 0.f;
+                    for (int v = threadIdx.x; v < V1; v += blockDim.x) mt = fmaxf(mt, (x[v] - lse) * invT);
+                    mt = block_max(mt, s_f);
+                    for (int v = threadIdx.x; v < V1; v += blockDim.x) st += __expf((x[v] - lse) * invT - mt);
+                    st = block_sum(st, s_f);
+                    lse_t = mt + __logf(st);
+                }
+                uint32_t cur = 0;
+                for (int bit = 31; bit >= 0; --bit) {
+                    const uint32_t cand = cur | (1u << bit);
+                    float acc = 0.f;
+                    for (int v = threadIdx.x; v < V1; v += blockDim.x) {
+                        const float xt_ = (x[v] - lse) * invT;
+                        const uint32_t key = order_key(xt_);
+                        if (top_k > 0) acc += key >= cand ? 1.f : 0.f;
+                        else acc += key > cand ? __expf(xt_ - lse_t) : 0.f;
+                    }
+                    acc = block_sum(acc, s_f);
+                    if (top_k > 0 ? acc >= (float)top_k : acc >= top_p) cur = cand;
+                }
+                thr_key = top_k > 0 ? cur : cur + 1;
+            }
             if (gumbel) {
                 const float *g = gumbel + (size_t)r * V1;
-                for (int v = threadIdx.x; v < V1; v += blockDim.x)
-                    best = better(best, ArgMax{(x[v] - lse) * invT + g[v], v});
+                for (int v = threadIdx.x; v < V1; v += blockDim.x) {
+                    const float xt_ = (x[v] - lse) * invT;
+                    if (order_key(xt_) >= thr_key) best = better(best, ArgMax{xt_ + g[v], v});
+                }
             } else {
                 const Philox rng(seed);
                 // one Philox call yields 4 uniforms: thread handles quads of vocabulary entries
@@ -115,7 +150,8 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
                         const int v = q * 4 + k;
                         if (v < V1) {
                             const float gn = -__logf(-__logf(u01(o[k])));
-                            best = better(best, ArgMax{(x[v] - lse) * invT + gn, v});
+                            const float xt_ = (x[v] - lse) * invT;
+                            if (order_key(xt_) >= thr_key) best = better(best, ArgMax{xt_ + gn, v});
                         }
                     }
                 }
@@ -165,7 +201,7 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
     int mode, const uint8_t *__restrict__ row_mode, float temperature, const float *__restrict__ gumbel, uint64_t seed,
     const int64_t *__restrict__ forced, int forced_ld, int no_finish_mask, int64_t *__restrict__ seq, int seq_ld,
     int64_t *__restrict__ it_next, uint8_t *__restrict__ unfinished, float *__restrict__ seq_logp,
-    float *__restrict__ sel_logp, uint8_t *__restrict__ live, const NextEmbed ne) {
+    float *__restrict__ sel_logp, uint8_t *__restrict__ live, const NextEmbed ne, int top_k, float top_p) {
     __shared__ float s_f[32];
     __shared__ int s_i[32];
     __shared__ float s_tok;
@@ -228,6 +264,50 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
             }
         } else {
             const float invT = 1.f / temperature;
+            // top-k / nucleus filtering (CaptionModel.py:388-404): both keep the tokens whose tempered logit is >= a
+            // threshold, then sample among them -- a restricted Gumbel-max (renormalisation does not move the arg-max).
+            // The threshold is found by a 32-step radix descent over the order-preserving integer image of the floats,
+            // one block-wide count (top-k) or probability mass (nucleus) per bit.
+            uint32_t thr_key = 0;
+            if (top_k > 0 || top_p > 0.f) {
+                float lse_t = 0.f;
+                if (top_p > 0.f) {                 // softmax of the TEMPERED log-probs
+                    float mt = -INFINITY, st = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) mt = fmaxf(mt, (x[j][k] - lse) * invT);
+                    mt = block_max(mt, s_f);
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) st += __expf((x[j][k] - lse) * invT - mt);
+                    st = block_sum(st, s_f);
+                    lse_t = mt + __logf(st);
+                }
+                uint32_t cur = 0;
+                for (int bit = 31; bit >= 0; --bit) {
+                    const uint32_t cand = cur | (1u << bit);
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const int q = threadIdx.x + j * SEL_THREADS;
+                        if (q < nq)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float xt_ = (x[j][k] - lse) * invT;
+                                const uint32_t key = order_key(xt_);
+                                if (top_k > 0) acc += key >= cand ? 1.f : 0.f;            // how many are >= cand
+                                else acc += key > cand ? __expf(xt_ - lse_t) : 0.f;       // mass strictly above cand
+                            }
+                    }
+                    acc = block_sum(acc, s_f);
+                    if (top_k > 0 ? acc >= (float)top_k : acc >= top_p) cur = cand;
+                }
+                // top-k: cur = key of the k-th largest.  nucleus: cur = largest key whose strictly-greater mass is still
+                // >= p, so the kept set starts right above it ... unless even the largest token alone has it (cur stays 0)
+                thr_key = top_k > 0 ? cur : cur + 1;
+            }
             const Philox rng(seed);
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
@@ -244,7 +324,10 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
                         for (int k = 0; k < 4; ++k) gn[k] = -__logf(-__logf(u01(o[k])));
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) best = better(best, ArgMax{(x[j][k] - lse) * invT + gn[k], 4 * q + k});
+                    for (int k = 0; k < 4; ++k) {
+                        const float xt_ = (x[j][k] - lse) * invT;
+                        if (order_key(xt_) >= thr_key) best = better(best, ArgMax{xt_ + gn[k], 4 * q + k});
+                    }
                 }
             }
         }
@@ -317,12 +400,16 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
                                     int V1, int step, int L, int mode, const uint8_t *row_mode, float temperature,
                                     const float *gumbel, uint64_t seed, const int64_t *forced, int forced_ld,
                                     int no_finish_mask, int64_t *seq, int seq_ld, int64_t *it_next, uint8_t *unfinished,
-                                    float *seq_logp, float *sel_logp, uint8_t *live, const capmi_next_embed *next, void *stream) {
+                                    float *seq_logp, float *sel_logp, uint8_t *live, const capmi_next_embed *next,
+                                    const capmi_sample_filter *filter, void *stream) {
     if (!partial || splits < 1 || N <= 0 || V1 <= 0 || step < 0 || step >= L || !seq || !it_next) return CAPMI_EINVAL;
     if (!no_finish_mask && !unfinished) return CAPMI_EINVAL;
     if ((mode == 2 || row_mode) && !forced && mode == 2) return CAPMI_EINVAL;
     if (mode == 1 && !(temperature > 0.f)) return CAPMI_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    const int top_k = filter ? filter->top_k : 0;
+    const float top_p = filter ? filter->top_p : 0.f;
+    if (top_k < 0 || top_p < 0.f || top_p >= 1.f || (top_k > 0 && top_p > 0.f)) return CAPMI_EINVAL;
     NextEmbed ne{};
     if (next && next->x) {
         if (!next->E || next->Edim <= 0) return CAPMI_EINVAL;
@@ -335,7 +422,7 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
 #define CAPMI_SEL(NQ)                                                                                                   \
     hipLaunchKernelGGL(logsoftmax_select_reg_kernel<NQ>, dim3(N), dim3(SEL_THREADS), 0, st, partial, splits,           \
                        (size_t)slab_stride, bias, V1, step, L, mode, row_mode, temperature, gumbel, seed, forced,       \
-                       forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live, ne)
+                       forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live, ne, top_k, top_p)
         if (V1 <= 4 * SEL_THREADS) CAPMI_SEL(1);
         else if (V1 <= 8 * SEL_THREADS) CAPMI_SEL(2);
         else CAPMI_SEL(3);
@@ -346,7 +433,7 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
     hipLaunchKernelGGL(logsoftmax_select_kernel, dim3(N), dim3(SEL_THREADS), 0, st, partial, splits, (size_t)slab_stride, bias,
                        V1, step, L, mode, row_mode,
                        temperature, gumbel, seed, forced, forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished,
-                       seq_logp, sel_logp, live, ne);
+                       seq_logp, sel_logp, live, ne, top_k, top_p);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -357,7 +444,7 @@ int capmi_logsoftmax_select(const float *logits, int N, int V1, int step, int L,
                             uint8_t *unfinished, float *seq_logp, float *sel_logp, uint8_t *live, void *stream) {
     return capmi_logsoftmax_select_partial(logits, 1, 0, nullptr, N, V1, step, L, mode, row_mode, temperature, gumbel,
                                            seed, forced, forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished,
-                                           seq_logp, sel_logp, live, nullptr, stream);
+                                           seq_logp, sel_logp, live, nullptr, nullptr, stream);
 }
 
 int capmi_logsoftmax_bwd(const float *g, const float *seq_logp, const uint8_t *live, float *dlogits, int N, int L,

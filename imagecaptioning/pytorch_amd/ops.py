@@ -213,3 +213,17 @@ def relu_mask_bwd(dy, y_ref, mask):
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, clip, grad_scale, step):
     check(lib.capmi_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, clip,
                               grad_scale, step, stream_ptr()), 'capmi_adam_step')
+
+
+def logsoftmax_select(logits, step, L, mode, temperature, gumbel, seed, forced, no_finish_mask, seq, it_next, unfinished,
+                      seq_logp, sel_logp, live, top_k=0, top_p=0.0):
+    """capmi_logsoftmax_select_partial on finished logits [N,V1] (one slab, no bias) with the optional top-k / nucleus
+    filter; used by the host-stepped decoders (Transformer, AoA)."""
+    N, V1 = logits.shape
+    flt = _lib.SampleFilter(int(top_k), float(top_p))
+    check(lib.capmi_logsoftmax_select_partial(ptr(logits), 1, 0, None, N, V1, step, L, mode, None, float(temperature),
+                                              ptr(gumbel), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(forced),
+                                              0 if forced is None else forced.shape[1], int(no_finish_mask), ptr(seq), L,
+                                              ptr(it_next), ptr(unfinished), ptr(seq_logp), ptr(sel_logp), ptr(live), None,
+                                              C.byref(flt) if (top_k or top_p) else None, stream_ptr()),
+          'capmi_logsoftmax_select_partial')

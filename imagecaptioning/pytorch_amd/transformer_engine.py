@@ -371,7 +371,7 @@ class Decoder:
 
 
 def sample(P, att_feats, att_masks, h, n_enc, n_dec, L, sample_n=1, mode='greedy', temperature=1.0, seed=0, forced=None,
-           gumbel=None):
+           gumbel=None, top_k=0, top_p=0.0):
     """AttModel._sample with TransformerModel.core semantics (eval numerics), KV cache instead of prefix re-decode.
     Returns (seq [N,L], seq_logp [N,L,V1])."""
     dev = att_feats.device
@@ -387,10 +387,8 @@ def sample(P, att_feats, att_masks, h, n_enc, n_dec, L, sample_n=1, mode='greedy
     st = stream_ptr()
     for t in range(L):
         logits = dec.step(t, it, n)
-        check(lib.capmi_logsoftmax_select(ptr(logits), N, V1, t, L, mode_i, None, float(temperature),
-                                          None if gumbel is None else gumbel[t].data_ptr(), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                                          ptr(forced), 0 if forced is None else forced.shape[1], 0, ptr(seq), L, ptr(it),
-                                          ptr(unf), ptr(seq_logp), ptr(sel), ptr(live), st), 'logsoftmax_select')
+        ops.logsoftmax_select(logits, t, L, mode_i, temperature, None if gumbel is None else gumbel[t], seed, forced, 0, seq, it, unf,
+                              seq_logp, sel, live, top_k, top_p)
     return seq, seq_logp
 
 

@@ -111,7 +111,7 @@ class Rollout:
 
     def __init__(self, P, pr, n, T, L=None, mode='greedy', temperature=1.0, drop_xt=None, drop_out=None,
                  gumbel=None, seed=0, forced=None, teacher=False, row_mode=None, ws=None, keep_for_backward=True,
-                 row_img=None, B_grad=None):
+                 row_img=None, B_grad=None, top_k=0, top_p=0.0):
         """row_img (int32 [N]) + B_grad: ragged grouping for the fused SCST rollout -- the first B_grad
         feature images own rows b*n..b*n+n-1 (sampled, with gradient), the remaining rows (greedy baseline)
         point at further feature images through row_img."""
@@ -149,6 +149,7 @@ class Rollout:
         r.mode = {'greedy': 0, 'sample': 1, 'forced': 2}[mode]
         r.row_mode = ptr(row_mode)
         r.temperature = float(temperature)
+        r.top_k, r.top_p = int(top_k), float(top_p)
         r.gumbel = ptr(gumbel)
         r.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         if forced is not None:

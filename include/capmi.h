@@ -214,6 +214,14 @@ typedef struct {
     int relu;
 } capmi_next_embed;
 
+/* Optional top-k / nucleus filter of the sampling modes (CaptionModel.sample_next_word, CaptionModel.py:388-404,
+ * sample_method 'top<k>' / 'top<p>'): only the top_k most probable tokens, or the smallest set of most probable tokens
+ * whose probability (softmax of logp / temperature) reaches top_p, can be drawn.  At most one of the two is non-zero. */
+typedef struct {
+    int top_k;      /* 0 = off */
+    float top_p;    /* 0 = off, else in (0,1) */
+} capmi_sample_filter;
+
 /* Same, fed straight from the vocabulary GEMM's K-slice slabs (capmi_gemm_f32 with defer_reduce = 1):
  * logits[r,:] = sum_{s<splits} partial[s*slab_stride + r*V1 + :] + bias (bias may be NULL).  With V1 % 4 == 0,
  * V1 <= 12288 and 16-byte aligned buffers the row lives in registers (no split-K reduce launch, no logits
@@ -225,7 +233,7 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
                                     const int64_t *forced, int forced_ld, int no_finish_mask,
                                     int64_t *seq, int seq_ld, int64_t *it_next, uint8_t *unfinished,
                                     float *seq_logp, float *sel_logp, uint8_t *live,
-                                    const capmi_next_embed *next, void *stream);
+                                    const capmi_next_embed *next, const capmi_sample_filter *filter, void *stream);
 
 /* gradient of the dense log-probs w.r.t. the logits for ALL steps at once:
  *   dlogits[r,t,:] = g[r,t,:] - exp(logp[r,t,:]) * sum_v g[r,t,v]      (rows where logp was masked
@@ -353,6 +361,9 @@ typedef struct capmi_updown_rollout {
     uint8_t *unfinished;    /* [N]     */
     float *partial;         /* split-K workspace */
     int64_t partial_capacity;
+    /* sampling filter (mode 1 rows only): see capmi_sample_filter */
+    int top_k;
+    float top_p;
 } capmi_updown_rollout;
 
 int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout *r, void *stream);

@@ -346,3 +346,67 @@ def test_baseline_size_xe_step_and_incremental_decode_consistency(which):
         live = torch.cat([seq.new_ones(B, 1), (seq[:, :-1] > 0).long()], 1).cumprod(1).bool()   # up to and incl. first EOS
         err = ((sel - tf_sel).abs() * live).max()
         assert float(err) < 2e-3, float(err)
+        if which == 'updown':
+            # top-k / nucleus sampling through the register-resident select kernel (V1 = 9488): every emitted token lies
+            # inside the filter support of the distribution it was drawn from
+            for method, num in (('top5', 5), ('top0.8', 0.8)):
+                sq, lp = model(fc, att, None, opt={'sample_method': method, 'temperature': 1.0, 'sample_n': 4}, mode='sample')
+                p = torch.softmax(lp.double(), 2)
+                sp, order = torch.sort(p, descending=True, dim=2)
+                rank = (order == sq.unsqueeze(2)).float().argmax(2)
+                alive = torch.cat([sq.new_ones(sq.shape[0], 1), (sq[:, :-1] > 0).long()], 1).cumprod(1).bool()
+                if num >= 1:
+                    ok = rank < num
+                else:
+                    before = torch.cumsum(sp, 2) - sp
+                    ok = before.gather(2, rank.unsqueeze(2)).squeeze(2) < num + 1e-6
+                assert bool((ok | ~alive).all()), method
+                assert sq[:, 0].unique().numel() > 1            # it does sample
+
+
+def test_sample_methods_gumbel_topk_nucleus():
+    """CaptionModel.sample_next_word variants (CaptionModel.py:374-404).  'gumbel' is the categorical draw at temperature 1
+    (same kernel path and Philox stream as 'sample'); 'top<k>' / 'top<p>' may only emit tokens of the k most probable /
+    of the nucleus of the step distribution they were drawn from, and must emit ALL of them over many draws."""
+    z, model = golden_model(False)
+    model.eval()
+    fc, att = torch.from_numpy(z['fc']).to(DEV), torch.from_numpy(z['att']).to(DEV)
+    n = 64
+    with torch.no_grad():
+        model._rng_calls = 100                    # same Philox seed for both calls (seed = f(initial_seed, call count))
+        s1, _ = model(fc, att, None, opt={'sample_method': 'sample', 'temperature': 1.0, 'sample_n': 2}, mode='sample')
+        model._rng_calls = 100
+        s2, _ = model(fc, att, None, opt={'sample_method': 'gumbel', 'temperature': 0.3, 'sample_n': 2}, mode='sample')
+        assert torch.equal(s1, s2)
+        for method, T in (('top3', 1.0), ('top0.6', 1.0), ('top5', 2.0), ('top0.9', 0.7)):
+            seq, logp = model(fc, att, None, opt={'sample_method': method, 'temperature': T, 'sample_n': n}, mode='sample')
+            num = float(method[3:])
+            # step 0: every row of an image sees the same distribution (input BOS): logp[:, 0] is that distribution
+            B = fc.shape[0]
+            for b in range(B):
+                lp0 = logp[b * n, 0].double()
+                p = torch.softmax(lp0 / T, 0)
+                order = torch.argsort(p, descending=True)
+                if num >= 1:
+                    allowed = set(order[:int(num)].tolist())
+                else:
+                    cs = torch.cumsum(p[order], 0)
+                    keep = torch.cat([torch.ones(1, dtype=torch.bool, device=cs.device), cs[:-1] < num])
+                    allowed = set(order[keep].tolist())
+                drawn = set(seq[b * n:(b + 1) * n, 0].tolist())
+                assert drawn <= allowed, (method, b, drawn - allowed)
+                if len(allowed) <= 3:
+                    assert drawn == allowed, (method, b, allowed - drawn)     # 64 draws cover a <= 3-token support
+            # later steps: the emitted token is always inside the filter support of ITS row's distribution
+            for t in range(1, seq.shape[1]):
+                lp = logp[:, t].double()
+                live = seq[:, t - 1] > 0
+                p = torch.softmax(lp / T, 1)
+                sp, order = torch.sort(p, descending=True, dim=1)
+                rank = (order == seq[:, t:t + 1]).float().argmax(1)
+                if num >= 1:
+                    ok = rank < int(num)
+                else:
+                    before = torch.cumsum(sp, 1) - sp                          # mass strictly above each sorted entry
+                    ok = before.gather(1, rank[:, None]).squeeze(1) < num + 1e-6
+                assert bool((ok | ~live).all()), (method, t)
