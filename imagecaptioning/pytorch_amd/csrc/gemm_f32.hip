@@ -464,7 +464,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     // fat GEMMs (time-batched BPTT): fp32 through the bf16 pipe by exact 3-way splitting (gemm_x3.hip);
     // CAPMI_GEMM_X3=0 keeps them on the exact-fp32 MFMA
     static const int env_x3 = [] { const char *e = getenv("CAPMI_GEMM_X3"); return e ? atoi(e) : 1; }();
-    bool x3_ok = env_x3 && BM == 128 && BN == 128 && BK == 32 && d->nseg == 1 &&
+    bool x3_ok = env_x3 && BM == 128 && BN == 128 && BK == 32 &&
                  (d->a_layout == 0 || d->M % 4 == 0) && (d->b_layout == 0 || d->N % 4 == 0);   // 4-row quads of [K][rows] operands
     for (int s = 0; s < d->nseg && x3_ok; ++s)      // branch-free 16-byte staging loads: aligned operands, K % 4 == 0
         x3_ok = a.seg[s].a_row_div == 1 && a.seg[s].vecA && a.seg[s].vecB && a.seg[s].K % 4 == 0 &&

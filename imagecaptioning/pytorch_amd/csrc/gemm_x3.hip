@@ -199,33 +199,48 @@ __global__ __launch_bounds__(XNT) void gemm_x3_kernel(const KArgs a, int gm, int
         // ---------------- staging waves ----------------
         const int tid = threadIdx.x - NT;
         float ra0[16], rb0[16], ra1[16], rb1[16];          // pipeline step g lives in register set g & 1
-        // single K segment (host checks): a dynamically indexed segment table would be spilled to scratch
+        // K segments ([h | x | ...] x [W slices]) are walked in place.  The segment of a K tile is workgroup-uniform; its
+        // fields are picked with STATIC indices behind a uniform switch (a dynamically indexed kernel-argument table
+        // would be copied to scratch), and the per-lane offsets are rebuilt only when the segment or the unit changes.
         Stager<AKC> sa;
         Stager<BKC> sb;
-        sa.init(a.seg[0].A, a.seg[0].lda, a.seg[0].K);
-        sb.init(a.seg[0].B, a.seg[0].ldb, a.seg[0].K);
+        int cur_seg = -1, cur_m0 = 0, cur_n0 = 0;
+        auto bind = [&](int sidx, int m0_, int n0_) {
+#define CAPMI_X3_SEG(I)                                                   \
+    case I:                                                               \
+        sa.init(a.seg[I].A, a.seg[I].lda, a.seg[I].K);                    \
+        sb.init(a.seg[I].B, a.seg[I].ldb, a.seg[I].K);                    \
+        break;
+            switch (sidx) {
+                CAPMI_X3_SEG(0) CAPMI_X3_SEG(1) CAPMI_X3_SEG(2) CAPMI_X3_SEG(3)
+            }
+#undef CAPMI_X3_SEG
+            sa.set_tile(m0_, a.M, tid);
+            sb.set_tile(n0_, a.N, tid);
+            cur_seg = sidx; cur_m0 = m0_; cur_n0 = n0_;
+        };
         // fetch cursor: runs up to 3 steps ahead of the step being consumed, across unit boundaries
-        int fu = blockIdx.x, ft = 0, f_t0 = 0, f_nt = 0;
+        int fu = blockIdx.x, ft = 0, f_t0 = 0, f_nt = 0, f_m0 = 0, f_n0 = 0;
         if (fu < units) {
             const Unit un = unit_of(a, fu, gm, gn);
-            f_t0 = un.t_begin; f_nt = un.nt;
-            sa.set_tile(un.m0, a.M, tid);
-            sb.set_tile(un.n0, a.N, tid);
+            f_t0 = un.t_begin; f_nt = un.nt; f_m0 = un.m0; f_n0 = un.n0;
         }
         auto fetch = [&](float (&xa)[16], float (&xb)[16]) {
             if (fu >= units) return;
+            int sidx, k0;
+            locate(a, f_t0 + ft, sidx, k0);
+            sidx = __builtin_amdgcn_readfirstlane(sidx);
+            if (sidx != cur_seg || f_m0 != cur_m0 || f_n0 != cur_n0) bind(sidx, f_m0, f_n0);
             if (!(a.ablate & 2)) {
-                sa.fetch(xa, (f_t0 + ft) * BK);
-                sb.fetch(xb, (f_t0 + ft) * BK);
+                sa.fetch(xa, k0);
+                sb.fetch(xb, k0);
             }
             if (++ft == f_nt) {
                 fu += gridDim.x;
                 ft = 0;
                 if (fu < units) {
                     const Unit un = unit_of(a, fu, gm, gn);
-                    f_t0 = un.t_begin; f_nt = un.nt;
-                    sa.set_tile(un.m0, a.M, tid);
-                    sb.set_tile(un.n0, a.N, tid);
+                    f_t0 = un.t_begin; f_nt = un.nt; f_m0 = un.m0; f_n0 = un.n0;
                 }
             }
         };

@@ -59,6 +59,24 @@ def test_gemm_fat_bf16x3_is_fp32_grade(dev, M, N, K, al, bl):
     assert e_ours <= 1.5 * e_fp32 + 1e-7, (e_ours, e_fp32)
 
 
+def test_gemm_fat_multisegment_bf16x3(dev):
+    """XE-sized gate GEMM (320 caption rows): [h_lang | xt | h_att] x [W_ih(:, 0:R) | W_ih(:, 2R:) | W_hh] walked in
+    place through the persistent bf16x3 kernel (segment switch inside the staging waves), bias epilogue."""
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(3)
+    M, R, E = 320, 200, 136
+    h1, x, h2 = (torch.randn(M, d, generator=g).to(dev) for d in (R, E, R))
+    W_ih = (torch.randn(4 * R, 2 * R + E, generator=g) * 0.1).to(dev)
+    W_hh = (torch.randn(4 * R, R, generator=g) * 0.1).to(dev)
+    b = torch.randn(4 * R, generator=g).to(dev)
+    out = torch.empty(M, 4 * R, device=dev)
+    ld = 2 * R + E
+    ops.gemm([(h1, R, W_ih, ld, R, 1), (x, E, (W_ih, 2 * R), ld, E, 1), (h2, R, W_hh, R, R, 1)], M, 4 * R, out, bias=b)
+    ref = (h1.double() @ W_ih[:, :R].double().t() + x.double() @ W_ih[:, 2 * R:].double().t() + h2.double() @ W_hh.double().t()
+           + b.double())
+    assert rel_err(out, ref) < 3e-6
+
+
 def test_gemm_multisegment_rowdiv_and_deferred_partials(dev):
     """[h | fc(row//n) | x] x [W0 | W1 | W2] with split-K partials consumed by the LSTM-cell kernel."""
     ops = ops_mod()
