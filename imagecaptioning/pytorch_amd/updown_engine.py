@@ -132,7 +132,9 @@ class Rollout:
         self.gates_att, self.gates_lang = z(T, N, 4 * R), z(T, N, 4 * R)
         self.att_h, self.alpha, self.ctx, self.h_drop = z(T, N, A), z(T, N, K), z(T, N, R), z(T, N, R)
         self.seq = torch.zeros(N, L, dtype=torch.long, device=dev)
-        self.seq_logp = torch.zeros(N, L, V1, dtype=_f32, device=dev)
+        # the select kernel writes every (row, step < T) slice of the dense log-probs, zeros included: a 45 MB memset per
+        # rollout is only needed when fewer steps than the pitch are run (XE with an early all-pad column)
+        self.seq_logp = (torch.empty if T == L else torch.zeros)(N, L, V1, dtype=_f32, device=dev)
         self.sel_logp = torch.zeros(N, L, dtype=_f32, device=dev)
         self.live = torch.zeros(N, L, dtype=torch.uint8, device=dev)
         self.fc_gates = z(B_feat, 4 * R)
