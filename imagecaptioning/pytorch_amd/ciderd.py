@@ -117,6 +117,11 @@ class DeviceCiderD:
         for i, g in enumerate(gts):
             g = np.asarray(g).astype(np.int32)
             refs[i, :g.shape[0], :g.shape[1]] = g
+            # rows of a NARROWER array that are completely filled carry no terminating 0 (array_to_str, rewards.py:33-39):
+            # mark the first padded column with -1 so the kernel does not read the zero padding as an EOS token
+            if g.shape[1] < w:
+                full = (g != 0).all(1)
+                refs[i, :g.shape[0], g.shape[1]][full] = -1
             n_refs[i] = g.shape[0]
         return torch.from_numpy(refs).to(self.device), torch.from_numpy(n_refs).to(self.device)
 

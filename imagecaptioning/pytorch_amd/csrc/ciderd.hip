@@ -56,8 +56,10 @@ __device__ void cook(const int *tok, int w, Cooked &c, const uint64_t *keys, con
     const int k = tid / LMAX, i = tid % LMAX;
     if (tid == 0) {
         int len = w;
-        for (int j = 0; j < w; ++j)
+        for (int j = 0; j < w; ++j) {
             if (tok[j] == 0) { len = j + 1; break; }     // rewards.py:33-39: the first 0 is kept
+            if (tok[j] < 0) { len = j; break; }          // packing sentinel: the source row was narrower and had no 0
+        }
         c.len = len;
     }
     __syncthreads();

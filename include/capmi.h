@@ -277,7 +277,9 @@ int capmi_adam_step(float *p, const float *g, float *m, float *v, int64_t count,
  *          packed as 4 x 16-bit (id+1), vals = document count (double); capacity power of two;
  *          empty slot key = 0.
  *   hyp   [H, L] int64 token rows (cut after the first 0, which is kept: rewards.py:33-39)
- *   refs  [B, max_refs, ref_w] int32, n_refs [B]; hypothesis h scores against image hyp_img[h]
+ *   refs  [B, max_refs, ref_w] int32, n_refs [B]; hypothesis h scores against image hyp_img[h];
+ *          a negative entry ends a reference WITHOUT an EOS token (a completely filled row of a narrower
+ *          source array padded to ref_w: the zero padding must not read as its terminating 0)
  *   scores[H] double = 10 * mean_k( sum_refs sim_k ) / n_refs
  * ------------------------------------------------------------------------------------------- */
 int capmi_ciderd_score(const int64_t *hyp, int H, int L, const int32_t *hyp_img,

@@ -50,3 +50,45 @@ def test_ciderd_kernel_matches_oracle(vocab, L, B, n):
     np.testing.assert_allclose(scores.cpu().numpy(), scores_ref, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(reward.cpu().numpy(), rewards_ref[:, 0], rtol=1e-5, atol=1e-6)
     assert abs(scores_ref[0] - 10.0) < 1e-9 or n_refs[0] > 1
+
+
+def test_ciderd_edge_cases_empty_ragged_and_full_length():
+    """Edge cases of the reward path (rewards.py:33-81): a hypothesis that is EOS at step 0 (array_to_str keeps the first
+    0, so it is the one-token caption "0"), hypotheses without any EOS (full length), images with a ragged number of
+    references (1..5) of different widths, a hypothesis identical to its only reference, and n-grams absent from the
+    document-frequency table."""
+    from oracle import ciderd as C
+    from imagecaptioning.pytorch_amd import ciderd as D
+    vocab, L, B, n = 40, 12, 5, 3
+    rng = np.random.default_rng(5)
+    corpus = C.synthetic_corpus(100, vocab, 5, L, seed=9)
+    df, ref_len = C.build_document_frequency([[C.tokens_of(r) for r in g] for g in corpus])
+    oracle = C.CiderD(df, ref_len)
+    gts = []
+    for i in range(B):
+        k = 1 + i % 5                                            # 1..5 references
+        w = L - (i % 3)                                          # different widths
+        g = np.zeros((k, w), dtype=np.uint32)
+        for j in range(k):
+            ln = int(rng.integers(1, w + 1))
+            g[j, :ln] = rng.integers(1, vocab + 1, size=ln)
+        gts.append(g)
+    N = B * n
+    sampled = np.zeros((N, L), dtype=np.int64)                   # rows left at zero: EOS at step 0
+    sampled[1] = rng.integers(1, vocab + 1, size=L)              # no EOS at all
+    sampled[2, :gts[0].shape[1]] = gts[0][0]                     # identical to image 0's only reference
+    sampled[4, :5] = [vocab + 7, vocab + 8, vocab + 9, 1, 2]     # tokens never seen by the DF table
+    for i in range(6, N):
+        ln = int(rng.integers(1, L + 1))
+        sampled[i, :ln] = rng.integers(1, vocab + 1, size=ln)
+    greedy = np.zeros((B, L), dtype=np.int64)
+    greedy[1, :4] = [3, 1, 4, 1]
+    rewards_ref, scores_ref = C.self_critical_reward(oracle, greedy, gts, sampled)
+    dev = D.DeviceCiderD(df, ref_len, DEV)
+    refs, n_refs = dev.pack_refs(gts)
+    assert n_refs.tolist() == [1, 2, 3, 4, 5]
+    reward, scores = dev.self_critical_reward(torch.from_numpy(greedy).to(DEV), torch.from_numpy(sampled).to(DEV), refs,
+                                              n_refs, n)
+    np.testing.assert_allclose(scores.cpu().numpy(), scores_ref, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(reward.cpu().numpy(), rewards_ref[:, 0], rtol=1e-5, atol=1e-6)
+    assert np.isfinite(scores_ref).all()
