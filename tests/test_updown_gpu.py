@@ -198,3 +198,44 @@ def test_full_size_scst_sample_and_grads_vs_oracle():
         if k == 'core.attention.alpha_net.bias':
             continue       # mathematically zero (softmax shift invariance): pure rounding noise on both sides
         assert rel(grads[k], Pg[k].grad) < 1e-3, k
+
+
+def test_rollout_edge_cases_immediate_eos_and_mixed_lengths():
+    """Edge cases of AttModel._sample (:340-350): rows that emit EOS at step 0 (only step 0 carries log-probs, everything
+    after is pad / zero rows), rows that never finish, and a mixture, against the oracle on the golden weights -- plus
+    the BPTT through such a batch (finished steps contribute no gradient)."""
+    from oracle import att_lstm as O
+    E = eng()
+    z, P = load_golden()
+    Pd = to_dev(P)
+    fc, att = (torch.from_numpy(z[k]) for k in ('fc', 'att'))
+    B, n, L = fc.shape[0], 2, 8
+    N = B * n
+    g = torch.Generator().manual_seed(4)
+    forced = torch.randint(1, 30, (N, L), generator=g)
+    forced[0] = 0                      # EOS immediately
+    forced[1, 3:] = 0                  # stops after 3 words
+    forced[2, 0] = 5
+    forced[2, 1:] = 0                  # one word
+    # forced[3:] never emit EOS
+    seq_o, logp_o = O.rollout(P, fc, att, None, sample_n=n, max_len=L, forced=forced)
+    pr = E.prepare(Pd, fc.to(DEV), att.to(DEV), None)
+    ro = E.Rollout(Pd, pr, n=n, T=L, mode='forced', forced=forced.to(DEV))
+    seq, slp = ro.run()
+    assert np.array_equal(seq.cpu().numpy(), seq_o.numpy())
+    assert seq[0].sum() == 0 and float(slp[0, 1:].abs().max()) == 0.0 and float(slp[0, 0].abs().max()) > 0
+    assert float(slp[2, 2:].abs().max()) == 0.0
+    np.testing.assert_allclose(slp.cpu().numpy(), logp_o.detach().numpy(), rtol=2e-5, atol=5e-6)
+    # gradient of a reward criterion through the ragged batch
+    reward = torch.randn(N, generator=g)[:, None].expand(N, L).contiguous()
+    lp = slp.detach().cpu().requires_grad_(True)
+    O.reward_criterion(lp, seq.cpu(), reward).backward()
+    grads = alloc_grads(Pd)
+    d_fc, d_att, d_p_att = ro.backward(lp.grad.to(DEV), grads)
+    E.prepare_backward(Pd, pr, d_fc, d_att, d_p_att, grads)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    _, logp_g = O.rollout(Pg, fc, att, None, sample_n=n, max_len=L, forced=forced)
+    O.reward_criterion(logp_g, seq_o, reward).backward()
+    for k in Pd:
+        ref = Pg[k].grad.numpy()
+        np.testing.assert_allclose(grads[k].cpu().numpy(), ref, rtol=1e-3, atol=1e-6 + 5e-5 * np.abs(ref).max(), err_msg=k)
