@@ -239,3 +239,52 @@ def test_rollout_edge_cases_immediate_eos_and_mixed_lengths():
     for k in Pd:
         ref = Pg[k].grad.numpy()
         np.testing.assert_allclose(grads[k].cpu().numpy(), ref, rtol=1e-3, atol=1e-6 + 5e-5 * np.abs(ref).max(), err_msg=k)
+
+
+@pytest.mark.parametrize('smoothing', [0.0, 0.2])
+def test_full_size_xe_loss_and_grads_vs_oracle(smoothing):
+    """BASELINE configs[1] shapes (R=E=1000, V1=9488, K=36), teacher forcing with dropout 0.5 masks injected on both
+    sides, LanguageModelCriterion and LabelSmoothing (losses.py:204-265): loss within 1e-4, gradients within 1e-3
+    relative.  Rows of different lengths: the padded tail carries no loss and no gradient."""
+    from oracle import att_lstm as O
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import LanguageModelCriterion, LabelSmoothing
+    E = eng()
+    P = full_size_params(seed=7)
+    g = torch.Generator().manual_seed(3)
+    B, n, K, L = 3, 2, 36, 7
+    N, R, Ed, V1 = B * n, 1000, 1000, 9488
+    fc = (torch.randn(B, 2048, generator=g) * 0.5).clamp_min(0)
+    att = (torch.randn(B, K, 2048, generator=g) * 0.5).clamp_min(0)
+    T = L + 1                                             # inputs [BOS, w_0 .. w_{L-1}]
+    labels = torch.zeros(N, L + 2, dtype=torch.long)
+    masks = torch.zeros(N, L + 2)
+    for r in range(N):
+        ln = L if r == 0 else int(torch.randint(2, L + 1, (1,), generator=g))     # row 0 full length: no early break
+        labels[r, 1:ln + 1] = torch.randint(1, V1, (ln,), generator=g)
+        masks[r, :ln + 2] = 1
+    drops = O.make_drops(0.5, B, K, N, T, Ed, R, g)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    logp_ref = O.forward_teacher(Pg, fc, att, labels[:, :-1].view(B, n, -1), None, drops)
+    crit_ref = (lambda lp: O.lm_criterion(lp, labels[:, 1:], masks[:, 1:])) if smoothing == 0 else \
+        (lambda lp: O.label_smoothing_criterion(lp, labels[:, 1:], masks[:, 1:], smoothing))
+    loss_ref = crit_ref(logp_ref)
+    loss_ref.backward()
+    Pd = to_dev(P)
+    d = lambda t: t.to(DEV).contiguous()                                 # noqa: E731
+    pr = E.prepare(Pd, d(fc), d(att), None, drop_fc=d(drops.fc), drop_att=d(drops.att))
+    ro = E.Rollout(Pd, pr, n=n, T=T, L=T, mode='forced', forced=d(labels[:, :-1]), teacher=True, drop_xt=d(drops.xt),
+                   drop_out=d(drops.out))
+    _, slp = ro.run()
+    assert float((slp.cpu() - logp_ref.detach()).abs().max()) < 1e-4
+    lp = slp.detach().requires_grad_(True)
+    crit = LanguageModelCriterion() if smoothing == 0 else LabelSmoothing(smoothing=smoothing)
+    loss = crit(lp, d(labels[:, 1:]), d(masks[:, 1:]))
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * max(1.0, abs(loss_ref.item()))
+    loss.backward()
+    grads = alloc_grads(Pd)
+    d_fc, d_att, d_p_att = ro.backward(lp.grad, grads)
+    E.prepare_backward(Pd, pr, d_fc, d_att, d_p_att, grads)
+    for k in Pd:
+        if k == 'core.attention.alpha_net.bias':
+            continue
+        assert rel(grads[k], Pg[k].grad) < 1e-3, k
