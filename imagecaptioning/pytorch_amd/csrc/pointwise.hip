@@ -169,25 +169,29 @@ __global__ void dropout_mask_kernel(float *__restrict__ mask, size_t count, floa
 // the 64 slices meet in LDS in a fixed order (deterministic, no atomics).
 constexpr int CS_Q = 16, CS_R = 64;
 __global__ __launch_bounds__(CS_Q * CS_R) void colsum_kernel(const float *__restrict__ in, int rows, int cols, int ld,
-                                                            float *__restrict__ out, int accumulate, int vec) {
+                                                            float *__restrict__ out, int accumulate, int vec, int rsplit) {
+    // gridDim.y = rsplit row ranges per column block (narrow matrices: d_model-wide bias gradients over thousands of rows
+    // would otherwise run on cols/64 workgroups); with rsplit > 1 the partial sums meet in `out` by atomicAdd (zeroed by
+    // the host unless accumulating)
     __shared__ f32x4 red[CS_R][CS_Q];
     const int cq = threadIdx.x % CS_Q, ry = threadIdx.x / CS_Q;
     const int col = (blockIdx.x * CS_Q + cq) * 4;
+    const int r_lo = (int)(((long long)rows * blockIdx.y) / rsplit), r_hi = (int)(((long long)rows * (blockIdx.y + 1)) / rsplit);
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (col < cols) {
         if (vec) {
             const float *p = in + col;
-            int r = ry;
-            for (; r + 3 * CS_R < rows; r += 4 * CS_R) {
+            int r = r_lo + ry;
+            for (; r + 3 * CS_R < r_hi; r += 4 * CS_R) {
                 const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (size_t)r * ld);
                 const f32x4 b = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + CS_R) * ld);
                 const f32x4 c = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + 2 * CS_R) * ld);
                 const f32x4 d = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + 3 * CS_R) * ld);
                 s += (a + b) + (c + d);
             }
-            for (; r < rows; r += CS_R) s += *reinterpret_cast<const f32x4 *>(p + (size_t)r * ld);
+            for (; r < r_hi; r += CS_R) s += *reinterpret_cast<const f32x4 *>(p + (size_t)r * ld);
         } else {
-            for (int r = ry; r < rows; r += CS_R)
+            for (int r = r_lo + ry; r < r_hi; r += CS_R)
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (col + k < cols) s[k] += in[(size_t)r * ld + col + k];
@@ -207,7 +211,10 @@ __global__ __launch_bounds__(CS_Q * CS_R) void colsum_kernel(const float *__rest
         const f32x4 t = (red[0][cq] + red[16][cq]) + (red[32][cq] + red[48][cq]);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (col + k < cols) out[col + k] = accumulate ? out[col + k] + t[k] : t[k];
+            if (col + k < cols) {
+                if (rsplit > 1) atomicAdd(&out[col + k], t[k]);
+                else out[col + k] = accumulate ? out[col + k] + t[k] : t[k];
+            }
     }
 }
 
@@ -340,8 +347,20 @@ int capmi_dropout_mask(float *mask, int64_t count, float p, uint64_t seed, uint6
 int capmi_colsum(const float *in, int rows, int cols, int ld, float *out, int accumulate, void *stream) {
     if (!in || !out || rows <= 0 || cols <= 0) return CAPMI_EINVAL;
     const int vec = ((reinterpret_cast<uintptr_t>(in) & 15) == 0 && ld % 4 == 0 && cols % 4 == 0) ? 1 : 0;
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 4 * CS_Q - 1) / (4 * CS_Q)), dim3(CS_Q * CS_R), 0, (hipStream_t)stream, in,
-                       rows, cols, ld, out, accumulate, vec);
+    const int cblocks = (cols + 4 * CS_Q - 1) / (4 * CS_Q);
+    int rsplit = 1;
+    if (cblocks < 64 && rows >= 4 * CS_R * 4) {            // narrow and tall: spread the rows over more workgroups
+        rsplit = 128 / cblocks;
+        const int max_by_rows = rows / (CS_R * 4);
+        if (rsplit > max_by_rows) rsplit = max_by_rows;
+        if (rsplit < 1) rsplit = 1;
+    }
+    if (rsplit > 1 && !accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(colsum_kernel, dim3(cblocks, rsplit), dim3(CS_Q * CS_R), 0, (hipStream_t)stream, in, rows, cols, ld, out,
+                       accumulate, vec, rsplit);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

@@ -196,11 +196,11 @@ def dropout_mask(shape, p, seed, offset, device):
     return m
 
 
-def colsum(x, out=None):
+def colsum(x, out=None, accumulate=False):
     rows, cols = x.shape
     if out is None:
         out = torch.empty(cols, dtype=_f32, device=x.device)
-    check(lib.capmi_colsum(ptr(x), rows, cols, cols, ptr(out), 0, stream_ptr()), 'capmi_colsum')
+    check(lib.capmi_colsum(ptr(x), rows, cols, cols, ptr(out), int(accumulate), stream_ptr()), 'capmi_colsum')
     return out
 
 

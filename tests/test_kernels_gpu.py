@@ -269,3 +269,17 @@ def test_dropout_mask_rate(dev):
     assert abs(float((m > 0).float().mean()) - 0.5) < 5e-3
     m2 = ops.dropout_mask((1000, 1000), 0.5, 7, 0, dev)
     assert torch.equal(m, m2)
+
+
+@pytest.mark.parametrize('rows,cols,accumulate', [(1200, 4000, False), (6720, 512, False), (6720, 512, True), (1200, 9488, False),
+                                                  (37, 5, False), (300, 64, True)])
+def test_colsum_bias_gradients(dev, rows, cols, accumulate):
+    """bias gradients = column sums over all T*N rows: wide (one pass) and narrow/tall (row ranges over several
+    workgroups meeting by atomicAdd) variants, aligned and unaligned, overwrite and accumulate."""
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g).to(dev)
+    out = torch.randn(cols, generator=g).to(dev)
+    ref = x.double().sum(0) + (out.double() if accumulate else 0)
+    ops.colsum(x, out, accumulate=accumulate)
+    assert rel_err(out, ref) < 2e-6
