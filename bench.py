@@ -127,11 +127,15 @@ def main():
         flat.zero_grad()
         loss.backward()
         flat.collect_grads()
-        # world > 1: the backward has already launched the all-reduce of every gradient bucket it finished (logit layer
-        # before the BPTT loop, LSTM weights before the attention/prefill gradients); this reduces the rest and waits
-        scale = flat.finish_overlap() if world > 1 else 1.0
-        flat.adam_step(opt.learning_rate, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
-                       clip_value=opt.grad_clip_value, grad_scale=scale)
+        if world > 1:
+            # the backward has already launched the all-reduce of every gradient bucket it finished (logit layer before
+            # the BPTT loop, LSTM weights before the attention/prefill gradients); reduce the rest and run clip+Adam
+            # bucket by bucket as the collectives land
+            flat.finish_overlap_and_step(opt.learning_rate, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon,
+                                         opt.weight_decay, clip_value=opt.grad_clip_value)
+        else:
+            flat.adam_step(opt.learning_rate, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
+                           clip_value=opt.grad_clip_value, grad_scale=1.0)
         return loss
 
     def sync():

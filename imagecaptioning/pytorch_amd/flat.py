@@ -95,22 +95,42 @@ class FlatParams:
             ov['done'].append((lo, hi))
             run = [i]
 
-    def finish_overlap(self):
-        """Reduce whatever no bucket covered, wait for all collectives (stream-side), return the 1/world scale."""
+    def _launch_leftovers(self):
         import torch.distributed as dist
         ov = self._ov
         pos = 0
         for lo, hi in sorted(ov['done']) + [(self.total, self.total)]:
             if lo > pos:
-                ov['works'].append(dist.all_reduce(self.grad[pos:lo], op=dist.ReduceOp.SUM, group=ov['group'],
-                                                   async_op=True))
+                ov['works'].append(dist.all_reduce(self.grad[pos:lo], op=dist.ReduceOp.SUM, group=ov['group'], async_op=True))
+                ov['done'].append((pos, lo))
             pos = max(pos, hi)
+
+    def finish_overlap(self):
+        """Reduce whatever no bucket covered, wait for all collectives (stream-side), return the 1/world scale."""
+        ov = self._ov
+        self._launch_leftovers()
         for w in ov['works']:
             w.wait()
-        n_coll = len(ov['works'])
+        self.last_collectives = len(ov['works'])
         ov['works'], ov['done'] = [], []
-        self.last_collectives = n_coll
         return 1.0 / ov['ws']
+
+    def finish_overlap_and_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=0.0):
+        """finish_overlap() + adam_step() pipelined per bucket: the fused clip+Adam of a bucket runs as soon as ITS
+        all-reduce has landed, while the collectives of the later buckets are still in flight (the update is elementwise,
+        so applying it range by range is the same update)."""
+        ov = self._ov
+        self._launch_leftovers()
+        self.step_count += 1
+        scale = 1.0 / ov['ws']
+        ranges = ov['done'][:len(ov['works'])]
+        for w, (lo, hi) in zip(ov['works'], ranges):
+            w.wait()                                   # stream-side: the compute stream waits for this bucket only
+            ops.adam_step(self.flat[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], lr, betas[0],
+                          betas[1], eps, weight_decay, clip_value, scale, self.step_count)
+        self.last_collectives = len(ov['works'])
+        ov['works'], ov['done'] = [], []
+        return scale
 
     def all_reduce(self, group=None, world_size=None):
         """ONE collective for the whole model (RCCL over xGMI when backend == 'nccl'); averages."""

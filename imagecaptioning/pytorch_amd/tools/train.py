@@ -89,10 +89,14 @@ def train(opt):
         flat.zero_grad()
         loss.backward()
         flat.collect_grads()
-        scale = flat.finish_overlap() if world > 1 else 1.0     # buckets finished by the backward are already in flight
         opt.current_lr = sched.rate(it)
-        flat.adam_step(opt.current_lr, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
-                       clip_value=opt.grad_clip_value if opt.grad_clip_mode == 'value' else 0.0, grad_scale=scale)
+        clip = opt.grad_clip_value if opt.grad_clip_mode == 'value' else 0.0
+        if world > 1:      # buckets finished by the backward are already in flight; clip+Adam follows each as it lands
+            flat.finish_overlap_and_step(opt.current_lr, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
+                                         clip_value=clip)
+        else:
+            flat.adam_step(opt.current_lr, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
+                           clip_value=clip, grad_scale=1.0)
         train_loss = loss.item()
         torch.cuda.synchronize()
         t2 = time.time()

@@ -50,11 +50,11 @@ def _worker(rank, world, port, overlap, q):
         loss.backward()
         flat.collect_grads()
         if overlap:
-            scale = flat.finish_overlap()
+            flat.finish_overlap_and_step(1e-2, clip_value=0.1)          # clip+Adam per bucket as its collective lands
             n_coll.append(flat.last_collectives)
         else:
             scale = flat.all_reduce()
-        flat.adam_step(1e-2, clip_value=0.1, grad_scale=scale)
+            flat.adam_step(1e-2, clip_value=0.1, grad_scale=scale)
     torch.cuda.synchronize()
     q.put((rank, flat.flat.cpu().numpy().copy(), n_coll))
     dist.barrier()
