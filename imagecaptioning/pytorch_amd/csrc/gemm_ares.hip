@@ -194,41 +194,47 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
                     if (TM == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[e], bb[4 * q + e], acc1, 0, 0, 0);
                 }
             }
-        } else {
-            // bf16x3: lane (l31, half) owns k = 16*half + 8*ks + 0..7 of the chunk for k-step ks; the weights are split
-            // in registers (each is used by this wave only), the activations were split once when they were staged
+        }
+    };
+    // bf16x3: lane (l31, half) owns k = 16*half + 8*ks + 0..7 of the chunk for k-step ks.  The weights are split in
+    // registers (each is used by this wave only), ONE CHUNK AHEAD of their MFMAs so that the split's dependent VALU
+    // chains sit in the shadow of the previous chunk's MFMAs (PMC: 39 % of the wave cycles were issue stalls with the
+    // split directly in front of its own MFMAs); the activations were split once when they were staged.
+    auto wsplit = [&](const float (&bb)[16], u32x4 (&wb)[2][3]) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                u32x4 wb[3];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int e2 = 0; e2 < 4; ++e2) {
-                    uint32_t hh[2], mm[2], ll[2];
+            for (int e2 = 0; e2 < 4; ++e2) {
+                uint32_t hh[2], mm[2], ll[2];
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const float x = bb[8 * ks + 2 * e2 + t];
-                        hh[t] = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
-                        const float r1 = x - __builtin_bit_cast(float, hh[t]);
-                        mm[t] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
-                        ll[t] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, mm[t]));
-                    }
-                    wb[0][e2] = (hh[0] >> 16) | (hh[1] & 0xffff0000u);
-                    wb[1][e2] = (mm[0] >> 16) | (mm[1] & 0xffff0000u);
-                    wb[2][e2] = (ll[0] >> 16) | (ll[1] & 0xffff0000u);
+                for (int t = 0; t < 2; ++t) {
+                    const float x = bb[8 * ks + 2 * e2 + t];
+                    hh[t] = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
+                    const float r1 = x - __builtin_bit_cast(float, hh[t]);
+                    mm[t] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+                    ll[t] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, mm[t]));
                 }
-                bf16x8 bw[3], x0[3], x1[3];
+                wb[ks][0][e2] = (hh[0] >> 16) | (hh[1] & 0xffff0000u);
+                wb[ks][1][e2] = (mm[0] >> 16) | (mm[1] & 0xffff0000u);
+                wb[ks][2][e2] = (ll[0] >> 16) | (ll[1] & 0xffff0000u);
+            }
+    };
+    auto mma3 = [&](const u32x4 (&wb)[2][3], int c) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    bw[pl] = __builtin_bit_cast(bf16x8, wb[pl]);
-                    x0[pl] = *reinterpret_cast<const bf16x8 *>(ah_lo + pl * planeH + c * 32 + 8 * ks);
-                    if (TM == 2) x1[pl] = *reinterpret_cast<const bf16x8 *>(ah_lo + pl * planeH + 32 * pitchH + c * 32 + 8 * ks);
-                }
-                // six of nine cross terms, small ones first (0 = h, 1 = m, 2 = l)
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bw[3], x0[3], x1[3];
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[PA[t]], bw[PB[t]], acc0, 0, 0, 0);
-                    if (TM == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[PA[t]], bw[PB[t]], acc1, 0, 0, 0);
-                }
+            for (int pl = 0; pl < 3; ++pl) {
+                bw[pl] = __builtin_bit_cast(bf16x8, wb[ks][pl]);
+                x0[pl] = *reinterpret_cast<const bf16x8 *>(ah_lo + pl * planeH + c * 32 + 8 * ks);
+                if (TM == 2) x1[pl] = *reinterpret_cast<const bf16x8 *>(ah_lo + pl * planeH + 32 * pitchH + c * 32 + 8 * ks);
+            }
+            // six of nine cross terms, small ones first (0 = h, 1 = m, 2 = l)
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[PA[t]], bw[PB[t]], acc0, 0, 0, 0);
+                if (TM == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[PA[t]], bw[PB[t]], acc1, 0, 0, 0);
             }
         }
     };
@@ -236,12 +242,31 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
     // released is refilled with chunk c + PF.  Straight-line code with static load counts keeps s_waitcnt vmcnt(n)
     // exact (inside a loop the compiler parked a vmcnt(0) at the loop head); the sched_barriers stop the machine
     // scheduler from sinking each refill down to its consumer (which exposed the full HBM latency).
+    if (!X3) {
 #pragma unroll
-    for (int c = 0; c < TS; ++c) {
-        if (c + PF < TS) load_b<BKC>(b[(c + PF) % (PF + 1)], &mine[c + PF], colc, half);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(b[c % (PF + 1)], c);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < TS; ++c) {
+            if (c + PF < TS) load_b<BKC>(b[(c + PF) % (PF + 1)], &mine[c + PF], colc, half);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(b[c % (PF + 1)], c);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        u32x4 w0[2][3], w1[2][3];                      // split weights of the even / odd chunks
+        wsplit(b[0], w0);
+#pragma unroll
+        for (int c = 0; c < TS; ++c) {
+            if (c + PF < TS) load_b<BKC>(b[(c + PF) % (PF + 1)], &mine[c + PF], colc, half);
+            __builtin_amdgcn_sched_barrier(0);
+            // the scheduler may interleave these two: MFMAs of chunk c, VALU split of chunk c + 1
+            if (c & 1) {
+                if (c + 1 < TS) wsplit(b[(c + 1) % (PF + 1)], w0);
+                mma3(w1, c);
+            } else {
+                if (c + 1 < TS) wsplit(b[(c + 1) % (PF + 1)], w1);
+                mma3(w0, c);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // K halves meet in LDS (the activation slice is dead): waves 4-7 park their 64x32 sums, waves 0-3 add and store.
