@@ -124,12 +124,12 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
     __syncthreads();
     const TileRef *mine = tiles + kh * TS;
 
-    // weight prefetch ring first: HBM latency overlaps the activation staging below
+    // Loads return IN ORDER (vmcnt counts them so): the activation loads (L2 hits, all workgroups of a K slice read the
+    // same rows) are issued FIRST and the weight prefetch ring right behind them, so the staging below waits for the
+    // activations only while the first weight chunks are still on their way from HBM.  (Ring first made the staging
+    // wait for 24 MB of weights to land before the first MFMA could start.)
     constexpr int PF = AR_PF < TS ? AR_PF : TS;
     float b[PF + 1][16];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) load_b<BKC>(b[u], &mine[u], colc, half);
-
     // stage the activation slice: 64 rows x SL*32 k in 16-byte pieces (rows >= M and k >= K_s zero filled): SL pieces
     // per thread, every load issued before the first LDS store = one L2 round trip for the whole slice.
     constexpr int quads = SL * 8;               // ROWS * quads pieces / 512 threads = TS * TM per thread
@@ -145,8 +145,17 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
             const bool ok = row < a.M && k < tp->arem;
             gcf p = as_global(tp->A) + (ok ? (size_t)((row * tp->rdiv) >> 16) * tp->lda + k : 0);
             v[j] = *(gcf4)p;
-            const float keep = ok ? 1.f : 0.f;     // multiply (not select) so the load stays unconditional
-            v[j] *= keep;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) load_b<BKC>(b[u], &mine[u], colc, half);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int idx = j * AR_NT + (int)threadIdx.x;
+            const int row = idx / quads, c4 = idx - row * quads;
+            const bool ok = row < a.M && (c4 & 7) * 4 < tiles[c4 >> 3].arem;
+            v[j] *= ok ? 1.f : 0.f;                // multiply (not select) so the load stays unconditional
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
