@@ -114,10 +114,10 @@ class AoAModel(CaptionModel):
         self._rng_calls += 1
         return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._rng_calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
-    def _run(self, cfg, att_feats, att_masks):
+    def _run(self, cfg, att_feats, att_masks, clipped=False):
         if not att_feats.is_cuda:
             raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
-        if att_masks is not None:
+        if att_masks is not None and not clipped:
             ml = int(att_masks.long().sum(1).max())
             att_feats, att_masks = att_feats[:, :ml], att_masks[:, :ml].float().contiguous()
         params = [p for _, p in self.named_parameters()]
@@ -150,4 +150,15 @@ class AoAModel(CaptionModel):
         L = self.seq_length
         cfg = dict(n=int(opt.get('sample_n', 1)), T=L, L=L, mode=mode, temperature=temperature,
                    seed=self._next_seed(), gumbel=opt.get('_gumbel'), top_k=top_k, top_p=top_p)
+        if mode == 'greedy' and not self.training and not torch.is_grad_enabled() and opt.get('_graph', True) and att_feats.is_cuda:
+            # deterministic, no gradient, launch-bound on the host: replay a captured hipGraph (graphs.py)
+            if not hasattr(self, '_graphs'):
+                from imagecaptioning.pytorch_amd.graphs import GraphedDecode
+                self._graphs = GraphedDecode()
+            gcfg = dict(cfg, seed=0)
+            if att_masks is not None:                 # the data-dependent clip (a host sync) stays outside the graph
+                ml = int(att_masks.long().sum(1).max())
+                att_feats, att_masks = att_feats[:, :ml], att_masks[:, :ml].float().contiguous()
+            return self._graphs(('greedy', cfg['n'], L), lambda a, m: self._run(gcfg, a, m, clipped=True),
+                                (att_feats.float().contiguous(), att_masks))
         return self._run(cfg, att_feats, att_masks)

@@ -213,9 +213,19 @@ class TransformerModel(CaptionModel):
         att_feats, att_masks = self._clip(att_feats, att_masks)
         with torch.no_grad():
             P = self._pdict([p for _, p in self.named_parameters()])
-            seq, logp = engine.sample(P, att_feats, att_masks, self.h, self.N_enc, self.N_dec, self.seq_length, sample_n=n,
-                                      mode=mode, temperature=temperature, seed=self._next_seed(),
-                                      gumbel=opt.get('_gumbel'), top_k=top_k, top_p=top_p)
+            if mode == 'greedy' and opt.get('_graph', True) and not self.training:
+                # deterministic and launch-bound on the host (~1300 launches): replay a captured hipGraph
+                if not hasattr(self, '_graphs'):
+                    from imagecaptioning.pytorch_amd.graphs import GraphedDecode
+                    self._graphs = GraphedDecode()
+                seq, logp = self._graphs(('greedy', n, self.seq_length),
+                                         lambda a, m: engine.sample(P, a, m, self.h, self.N_enc, self.N_dec, self.seq_length,
+                                                                    sample_n=n, mode='greedy'),
+                                         (att_feats.contiguous(), att_masks))
+            else:
+                seq, logp = engine.sample(P, att_feats, att_masks, self.h, self.N_enc, self.N_dec, self.seq_length, sample_n=n,
+                                          mode=mode, temperature=temperature, seed=self._next_seed(),
+                                          gumbel=opt.get('_gumbel'), top_k=top_k, top_p=top_p)
         if not (torch.is_grad_enabled() and self.training):
             return seq, logp
         # differentiable log-probs of the drawn tokens: inputs [bos, w_0 .. w_{L-2}]
