@@ -74,7 +74,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=10, help='per-GPU images (weak scaling, the default)')
+    ap.add_argument('--global-batch', type=int, default=0,
+                    help='strong scaling (SURVEY 8d: global bs 80): total images per step, split evenly over the ranks')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not bracket kernels with HIP events (for rocprofv3 runs)')
     ap.add_argument('--cpu-iters', type=int, default=5)
@@ -111,6 +113,10 @@ def main():
     if world > 1:
         flat.begin_overlap()
     lw = LossWrapper(model, opt)
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit('--global-batch must be divisible by the number of ranks')
+        args.batch = args.global_batch // world
     B, n, L = args.batch, opt.train_sample_n, opt.max_length
     fc, att = synthetic.batch(B, seed=1234 + rank, device=dev)
     corpus = synthetic.corpus(2000, seed=7)       # DF table: 2000 synthetic "images" x 5 refs
@@ -204,7 +210,8 @@ def main():
         line = {
             'metric': 'captions/sec/node (UpDown SCST, bs10xsample_n5, 36x2048 feats)', 'value': round(value, 2),
             'unit': 'captions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'strong' if args.global_batch else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'numerics': 'fp32 storage and accumulation; GEMMs on the bf16 matrix pipe through an exact 3-way operand split '
                         '(fp32-grade error, DESIGN.md 4); CAPMI_GEMM_X3=0 CAPMI_ARES_X3=0 selects the exact-fp32 MFMA',
