@@ -49,6 +49,31 @@ def measured_copy_gbs(dev, mb=1024, iters=8):
     return 2.0 * src.numel() * 4 * iters / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
+def attention_large_batch(dev, B=1024, iters=20):
+    """The fused region-attention kernel at an evaluation-sized batch (B images x 36 regions, one caption row each), where
+    a launch moves enough unique bytes (229 MB) to be bandwidth-bound: the north_star's HBM-roofline target applies here;
+    at the bs10 SCST shape a launch moves 2-5 MB and is latency-bound.  HIP events around `iters` launches."""
+    from imagecaptioning.pytorch_amd import ops
+    K, A, R = 36, 512, 1000
+    att_h = torch.randn(B, A, device=dev)
+    p_att = torch.randn(B, K, A, device=dev)
+    att = torch.randn(B, K, R, device=dev)
+    w = torch.randn(A, device=dev) * 0.1
+    bb = torch.zeros(1, device=dev)
+    for _ in range(3):
+        ops.attention_fwd(att_h, p_att, att, None, w, bb, 1)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        ops.attention_fwd(att_h, p_att, att, None, w, bb, 1)
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) / iters * 1e3
+    byts = 4.0 * (B * K * (A + R) + B * (A + R + K))
+    return {'B': B, 'n': 1, 'avg_launch_us': round(us, 1), 'unique_bytes_per_launch': round(byts),
+            'achieved_gbs': round(byts / us / 1e3, 1), 'frac_of_8tbs': round(byts / us / 1e3 / HBM_PEAK_GBS, 4)}
+
+
 def pmc_traffic():
     """HBM bytes per decode-GEMM launch from the PMC passes of this same command (FETCH_SIZE and WRITE_SIZE need
     separate rocprofv3 --pmc runs, so they cannot be sampled inside this process): profiles/r01_pmc_traffic.json,
@@ -202,8 +227,11 @@ def main():
                      'achieved': round(a_ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(a_ach / HBM_PEAK_GBS, 4), 'avg_launch_us': round(a_ms / max(a_n, 1) * 1e3, 2),
                      'algorithmic_bytes_per_launch': round(a_bytes / max(a_n, 1)),
-                     'note': 'bs10 x n5: 2.4 MB unique bytes per launch is below the HBM bandwidth-delay product; '
-                             'see DESIGN.md for the large-batch figure'}
+                     'note': 'bs10 x n5: 2.4-4.7 MB unique bytes per launch is below the HBM bandwidth-delay product '
+                             '(latency-bound); large_batch is the same kernel at an evaluation-sized batch',
+                     'large_batch': None if args.no_prof else attention_large_batch(dev)}
+        if attention['large_batch'] and copy_gbs:
+            attention['large_batch']['frac_of_measured_copy'] = round(attention['large_batch']['achieved_gbs'] / copy_gbs, 4)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(opt, model, B, n, L, args.cpu_iters)
