@@ -157,3 +157,55 @@ def synthetic_corpus(num_images: int, vocab: int, refs_per_image: int = 5, width
             arr[j, :ln] = rng.choice(vocab, size=ln, p=p) + 1
         out.append(arr)
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# second, independent restatement in plain C (oracle/ciderd_c/ciderd.c): sorted key arrays + binary search
+# --------------------------------------------------------------------------------------------------
+class CiderDRefC:
+    """ctypes wrapper of libciderd_ref.so (make -C oracle/ciderd_c).  Same contract as :class:`CiderD`; used to
+    cross-check the two restatements (tests/test_oracle_ciderd.py) and as a fast CPU scorer."""
+
+    def __init__(self, document_frequency, ref_len, lib_path=None):
+        import ctypes as C
+        import os
+        path = lib_path or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ciderd_c', 'libciderd_ref.so')
+        self._lib = C.CDLL(path)
+        self._lib.ciderd_ref_score.restype = C.c_int
+        keys = np.fromiter((self._pack(g) for g in document_frequency.keys()), dtype=np.uint64, count=len(document_frequency))
+        vals = np.fromiter((float(v) for v in document_frequency.values()), dtype=np.float64, count=len(document_frequency))
+        order = np.argsort(keys, kind='stable')
+        self.keys, self.vals = np.ascontiguousarray(keys[order]), np.ascontiguousarray(vals[order])
+        self.log_ref_len = math.log(float(ref_len))
+
+    @staticmethod
+    def _pack(tokens):
+        k = 0
+        for q, t in enumerate(tokens):
+            k |= (int(t) + 1) << (16 * q)
+        return k
+
+    def score(self, hyp: np.ndarray, hyp_img: np.ndarray, gts: Sequence[np.ndarray]) -> np.ndarray:
+        """hyp [H,L] int64 rows, hyp_img [H] image of each row, gts list of [n_ref, w] arrays -> scores [H]."""
+        import ctypes as C
+        B = len(gts)
+        max_refs = max(len(g) for g in gts)
+        w = max(np.asarray(g).shape[1] for g in gts)
+        refs = np.zeros((B, max_refs, w), dtype=np.int32)
+        n_refs = np.zeros(B, dtype=np.int32)
+        for i, g in enumerate(gts):
+            g = np.asarray(g).astype(np.int32)
+            refs[i, :g.shape[0], :g.shape[1]] = g
+            if g.shape[1] < w:
+                refs[i, :g.shape[0], g.shape[1]][(g != 0).all(1)] = -1      # full rows of a narrower array keep no EOS
+            n_refs[i] = g.shape[0]
+        hyp = np.ascontiguousarray(hyp, dtype=np.int64)
+        hyp_img = np.ascontiguousarray(hyp_img, dtype=np.int32)
+        out = np.zeros(hyp.shape[0], dtype=np.float64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)                            # noqa: E731
+        rc = self._lib.ciderd_ref_score(p(hyp), C.c_int(hyp.shape[0]), C.c_int(hyp.shape[1]), p(hyp_img), p(refs), p(n_refs),
+                                        C.c_int(max_refs), C.c_int(w), p(self.keys), p(self.vals), C.c_int64(len(self.keys)),
+                                        C.c_double(self.log_ref_len), p(out))
+        if rc:
+            raise RuntimeError('ciderd_ref_score failed: %d' % rc)
+        return out

@@ -50,6 +50,14 @@ def test_ciderd_kernel_matches_oracle(vocab, L, B, n):
     np.testing.assert_allclose(scores.cpu().numpy(), scores_ref, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(reward.cpu().numpy(), rewards_ref[:, 0], rtol=1e-5, atol=1e-6)
     assert abs(scores_ref[0] - 10.0) < 1e-9 or n_refs[0] > 1
+    # the independent plain-C restatement (oracle/ciderd_c) as a second checker of the kernel
+    import os
+    import subprocess
+    subprocess.check_call(['make', '-s', '-C', os.path.join(os.path.dirname(os.path.abspath(C.__file__)), 'ciderd_c')])
+    hyp_all = np.concatenate([sampled, greedy], 0)
+    img_all = np.concatenate([np.arange(N) // n, np.arange(B)])
+    scores_c = C.CiderDRefC(df, ref_len).score(hyp_all, img_all, gts)
+    np.testing.assert_allclose(scores.cpu().numpy(), scores_c, rtol=1e-10, atol=1e-12)
 
 
 def test_ciderd_edge_cases_empty_ragged_and_full_length():

@@ -107,3 +107,46 @@ def test_document_frequency_counts_images_not_occurrences():
     df, ref_len = C.build_document_frequency([[[1, 2, 1], [1, 2]], [[1, 3]]])
     assert ref_len == 2
     assert df[(1,)] == 2 and df[(2,)] == 1 and df[(1, 2)] == 1 and df[(2, 1)] == 1 and df[(3,)] == 1
+
+
+def test_c_restatement_agrees_with_python_restatement():
+    """oracle/ciderd_c/ciderd.c (sorted arrays + binary search) vs oracle/ciderd.py (dictionaries): two independent
+    restatements of the same published algorithm must agree to float64 rounding -- on random hypotheses, exact copies,
+    EOS-at-0 rows, rows without EOS, ragged reference counts and widths, and n-grams absent from the DF table."""
+    import os
+    import subprocess
+    import numpy as np
+    from oracle import ciderd as C
+    cdir = os.path.join(os.path.dirname(os.path.abspath(C.__file__)), 'ciderd_c')
+    subprocess.check_call(['make', '-s', '-C', cdir])
+    rng = np.random.default_rng(11)
+    vocab, L, B, n = 60, 14, 6, 3
+    corpus = C.synthetic_corpus(200, vocab, 5, L, seed=2)
+    df, ref_len = C.build_document_frequency([[C.tokens_of(r) for r in g] for g in corpus])
+    gts = []
+    for i in range(B):
+        k, w = 1 + i % 5, L - (i % 3)
+        g = np.zeros((k, w), dtype=np.uint32)
+        for j in range(k):
+            ln = int(rng.integers(1, w + 1))
+            g[j, :ln] = rng.integers(1, vocab + 1, size=ln)
+        gts.append(g)
+    gts[1] = corpus[0][:, :L]                                     # an image whose refs are in the DF corpus
+    N = B * n
+    hyp = np.zeros((N, L), dtype=np.int64)
+    for i in range(3, N):
+        ln = int(rng.integers(1, L + 1))
+        hyp[i, :ln] = rng.integers(1, vocab + 1, size=ln)
+    hyp[1] = rng.integers(1, vocab + 1, size=L)                   # no EOS
+    hyp[2, :gts[0].shape[1]] = gts[0][0]                          # copy of image 0's only reference
+    hyp[4, :L] = corpus[0][1][:L].astype(np.int64)              # a reference of image 1 (rows 3..5 score against it)
+    hyp[7, :4] = [vocab + 5, vocab + 6, 1, 2]                     # unseen tokens
+    hyp_img = np.arange(N) // n
+    py = C.CiderD(df, ref_len)
+    ref_tok = [[C.tokens_of(r) for r in g] for g in gts]
+    _, want = py.compute_score([C.tokens_of(r) for r in hyp], [ref_tok[i] for i in hyp_img])
+    got = C.CiderDRefC(df, ref_len).score(hyp, hyp_img, gts)
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-13)
+    # an exact copy of the only reference scores 10 on every n-gram order it is long enough to have
+    assert got[2] >= 2.5 - 1e-9 and abs(got[2] / 2.5 - round(got[2] / 2.5)) < 1e-9
+    assert got[4] > 2.0 and got[0] >= 0.0 and got.max() <= 10.0 + 1e-9
