@@ -425,12 +425,21 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
         int ts_cap = ares_ts_cap(d->M, use_x3);
         int ts_max = ares_plan(d->N, tiles, want, ts_cap, &splits);
         if (use_x3 && ((d->N + 127) / 128) * splits > want) {
-            // the bf16 planes of 64 rows cap a slice at 12 chunks; if that pushes the grid past one workgroup per CU
-            // (a second, mostly empty round) the exact-fp32 image with its longer slices wins (30.2 vs 26.8 us)
-            int splits32 = 0;
-            const int ts32 = ares_plan(d->N, tiles, want, ares_ts_cap(d->M, 0), &splits32);
-            if (((d->N + 127) / 128) * splits32 <= want) {
-                use_x3 = 0; ts_cap = ares_ts_cap(d->M, 0); ts_max = ts32; splits = splits32;
+            // the bf16 planes of 64 rows cap a slice at 12 chunks; when that pushes the grid past one workgroup per CU
+            // (a second, mostly empty round), first try HALF-size slices with two workgroups resident per CU (<= 6
+            // chunks = 77 KB of LDS each, everything in one round: 21.0 vs 27.8 us for dX = dG [W_ih | W_hh] with
+            // N = 3000), else the exact-fp32 image with its longer slices (26.3 us)
+            const int nblk = (d->N + 127) / 128;
+            int splits2 = 0;
+            const int ts2 = ares_plan(d->N, tiles, 2 * want, 3, &splits2);
+            if (nblk * splits2 <= 2 * want && (int64_t)splits2 * d->M * d->N <= slab_cap) {
+                ts_cap = 3; ts_max = ts2; splits = splits2;
+            } else {
+                int splits32 = 0;
+                const int ts32 = ares_plan(d->N, tiles, want, ares_ts_cap(d->M, 0), &splits32);
+                if (nblk * splits32 <= want) {
+                    use_x3 = 0; ts_cap = ares_ts_cap(d->M, 0); ts_max = ts32; splits = splits32;
+                }
             }
         }
         if ((splits > 1 || d->defer_reduce) && (int64_t)splits * d->M * d->N > slab_cap) ts_max = 99;   // slabs do not fit

@@ -36,11 +36,14 @@ dx = torch.empty(M, 2 * R, device=dev)
 segs = [(h, R, W_ih, 2 * R + E, R, 1), (x, E, (W_ih, 2 * R), 2 * R + E, E, 1), (h, R, W_hh, R, R, 1)]
 Wlang = torch.randn(4 * R, 2 * R, device=dev) * 0.03
 Wh = torch.randn(512, R, device=dev) * 0.03
+Wcat3 = torch.randn(4 * R, 3 * R, device=dev) * 0.03
+dx3 = torch.empty(M, 3 * R, device=dev)
 outh = torch.empty(M, 512, device=dev)
 for splits in [int(s) for s in (sys.argv[2].split(',') if len(sys.argv) > 2 else ['0'])]:
     t1 = timeit(lambda: ops.gemm(segs, M, 4 * R, out, ws=ws, splits=splits, defer_reduce=True))
     t2 = timeit(lambda: ops.gemm([(h, R, Wl, R, R, 1)], M, 9488, outl, ws=ws, splits=max(1, splits // 3) if splits else 0))
     t3 = timeit(lambda: ops.gemm([(dg, 4 * R, Wlang, 2 * R, 4 * R, 1)], M, 2 * R, dx, a_layout=0, b_layout=1, ws=ws, splits=splits * 2))
     t4 = timeit(lambda: ops.gemm([(h, R, Wh, R, R, 1)], M, 512, outh, ws=ws, splits=0))
-    print('M=%d splits=%d: gates(deferred) %.1f us (%.2f TB/s)  logit %.1f us  dX_nn %.1f us  h2att %.1f us' %
-          (M, splits, t1, 48e6 / t1 / 1e6, t2, t3, t4), flush=True)
+    t5 = timeit(lambda: ops.gemm([(dg, 4 * R, Wcat3, 3 * R, 4 * R, 1)], M, 3 * R, dx3, a_layout=0, b_layout=1, ws=ws, defer_reduce=True))
+    print('M=%d splits=%d: gates(deferred) %.1f us (%.2f TB/s)  logit %.1f us  dX_nn %.1f us  h2att %.1f us  dX2_nn(deferred) %.1f us' %
+          (M, splits, t1, 48e6 / t1 / 1e6, t2, t3, t4, t5), flush=True)
