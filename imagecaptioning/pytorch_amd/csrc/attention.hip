@@ -305,13 +305,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
             const int j = i / q4, c = (i - j * q4) * 4;
             const float *p = x_slabs + (size_t)(row0 + j) * x_cols + c;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            for (int s0 = 0; s0 < x_splits; s0 += 4) {      // 4 independent 16-byte slab loads in flight
-                f32x4 part[4];
+            for (int s0 = 0; s0 < x_splits; s0 += 8) {      // 8 independent 16-byte slab loads in flight
+                f32x4 part[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 8; ++u)
                     part[u] = (s0 + u < x_splits) ? *reinterpret_cast<const f32x4 *>(p + (size_t)(s0 + u) * x_stride)
                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
-                v += (part[0] + part[1]) + (part[2] + part[3]);
+                v += ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
             }
             *reinterpret_cast<f32x4 *>(x_out + (size_t)(row0 + j) * x_cols + c) = v;
             if (c < R) {
