@@ -54,6 +54,31 @@ int gemm(void *stream, int a_layout, int b_layout, int M, int N, float *C, int l
     return rc;
 }
 
+// teacher forcing: [T,N,R] (time-major, as the steps wrote it) -> [N,T,R] so that ONE fat GEMM over all T*N rows lands in
+// the [N,L,V1] layout of seqLogprobs
+__global__ void tn_to_nt_kernel(const float *__restrict__ src, float *__restrict__ dst, int T, int N, int R) {
+    const size_t total = (size_t)T * N * R;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % R);
+        const size_t row = i / R;                     // = n * T + t
+        const int n = (int)(row / T), t = (int)(row % T);
+        dst[i] = src[((size_t)t * N + n) * R + c];
+    }
+}
+
+// bookkeeping of the teacher-forced pass (what the per-step select kernel writes in mode 2 with no finish mask)
+__global__ void teacher_bookkeep_kernel(const float *__restrict__ seq_logp, const int64_t *__restrict__ forced, int forced_ld,
+                                        int64_t *__restrict__ seq, float *__restrict__ sel_logp, uint8_t *__restrict__ live,
+                                        int N, int L, int V1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * L) return;
+    const int r = i / L, t = i % L;
+    const int64_t tok = forced[(size_t)r * forced_ld + t];
+    seq[i] = tok;
+    if (sel_logp) sel_logp[i] = seq_logp[(size_t)i * V1 + tok];
+    if (live) live[i] = 1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -72,6 +97,10 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
     hipStream_t st = (hipStream_t)stream;
     const size_t NR = (size_t)N * R;
     const int ld_att_ih = 2 * R + E;
+    // teacher forcing knows every input token up front: the vocabulary projection + log-softmax of all T steps run as ONE
+    // fat GEMM over T*N rows after the loop (20 launches of a 320-row GEMM + 20 select launches otherwise)
+    const bool batched_logit = r->teacher && T == L && r->seq_logp &&
+                               (int64_t)N * T * R <= r->partial_capacity - CAPMI_WS_COUNTER_FLOATS;
 
     // initial state (slot 0) and flags
     hipError_t e;
@@ -137,6 +166,7 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
                                    r->gates_lang + (size_t)t * N * 4 * R,
                                    r->drop_out ? r->drop_out + (size_t)t * NR : nullptr, h_drop, N, R, stream));
         }
+        if (batched_logit) continue;
         // 8-9. vocabulary projection left as K-slice slabs; log-softmax + choice + bookkeeping assemble the row
         //      (slabs + bias) in registers: no split-K reduce launch, no logits round trip
         {
@@ -156,6 +186,20 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
                                            r->gumbel ? r->gumbel + (size_t)t * N * V1 : nullptr, r->seed, r->forced,
                                            r->forced_ld, r->teacher ? 1 : 0, r->seq, L, r->it, r->unfinished, r->seq_logp,
                                            r->sel_logp, r->live, &ne, (r->top_k > 0 || r->top_p > 0.f) ? &flt : nullptr, stream));
+    }
+    if (batched_logit) {
+        float *hd_nt = r->partial + CAPMI_WS_COUNTER_FLOATS;          // the split-K workspace is idle here
+        const size_t total = (size_t)N * T * R;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(tn_to_nt_kernel, dim3(blocks), dim3(256), 0, st, r->h_drop, hd_nt, T, N, R);
+        CAPMI_CHECK_LAUNCH();
+        SegSpec s{hd_nt, R, w->logit_w, R, R, 1};
+        RC(gemm(stream, 0, 0, N * T, V1, r->seq_logp, V1, &s, 1, nullptr, 0, 0, nullptr, w->logit_b));
+        RC(capmi_log_softmax_rows(r->seq_logp, r->seq_logp, N * T, V1, stream));
+        hipLaunchKernelGGL(teacher_bookkeep_kernel, dim3((N * L + 255) / 256), dim3(256), 0, st, r->seq_logp, r->forced,
+                           r->forced_ld, r->seq, r->sel_logp, r->live, N, L, V1);
+        CAPMI_CHECK_LAUNCH();
     }
     return 0;
 }
