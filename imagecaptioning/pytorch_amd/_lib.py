@@ -96,6 +96,7 @@ class NewFCBwdScratch(C.Structure):
 
 
 _I, _F, _P, _U64, _I64 = C.c_int, C.c_float, C.c_void_p, C.c_uint64, C.c_int64
+DECODE_NO_REPEAT, DECODE_NO_BAD_ENDING, DECODE_BLOCK_TRIGRAMS = 1, 2, 4      # capmi.h CAPMI_DECODE_*
 
 # name -> argtypes (restype is always int unless noted).  Must list EVERY symbol of include/capmi.h:
 # tests/test_abi.py cross-checks this table against the header and the built library.
@@ -132,6 +133,11 @@ SIGNATURES = {
     'capmi_beam_reorder': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     'capmi_beam_logsoftmax': [_P, _P, _I, _I, _F, _I, _P],
     'capmi_updown_beam_search': [C.POINTER(UpDownWeights), C.POINTER(UpDownBeam), _P],
+    'capmi_updown_decode_step': [C.POINTER(UpDownWeights), C.POINTER(UpDownBeam), _I, _I, _P, _P, _I, _P],
+    'capmi_decode_constrain': [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P],
+    'capmi_beam_diversity': [_P, _P, _I, _I, _I, _P, _I, _I, _F, _P],
+    'capmi_column_penalty': [_P, _I, _I, _P, _I, _I, _F, _P],
+    'capmi_select_logp': [_P, _I, _I, _I, _I, _I, _F, _P, _U64, _P, _I, _P, _P, _P, _P, _I, _P, _P],
     'capmi_layernorm_fwd': [_P] * 6 + [_I, _I, _F, _P],
     'capmi_layernorm_bwd': [_P] * 6 + [_I, _P, _I, _I, _F, _P],
     'capmi_mha_fwd': [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -341,6 +341,6 @@ class BeamDecoder:
 def sample_beam(model, P, att_feats, att_masks, h, L, opt):
     from . import beam
     g = AoAGraph(P, {}, h, 0.0, 0.0, False, 0)
-    g.prepare(att_feats, att_masks)
-    dec = BeamDecoder(g, opt.get('beam_size', 10))
-    return beam.beam_search_steps(model, dec.step, dec.reorder, g.B, dec.V1, L, opt, att_feats.device)
+    g.prepare(att_feats, att_masks)               # refined features are shared by every decoder (diverse groups)
+    return beam.beam_search_steps(model, lambda rows: BeamDecoder(g, rows), g.B, P['embed.0.weight'].shape[0], L, opt,
+                                  att_feats.device)

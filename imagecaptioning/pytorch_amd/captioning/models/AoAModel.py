@@ -146,6 +146,20 @@ class AoAModel(CaptionModel):
                 P = dict(zip(self._param_names, [p.detach() for _, p in self.named_parameters()]))
                 return engine.sample_beam(self, P, att_feats.float().contiguous(), att_masks, self.num_heads, self.seq_length, opt)
         from .utils import parse_sample_method
+        from imagecaptioning.pytorch_amd import decode
+        if decode.wants_options(opt):
+            if not att_feats.is_cuda:
+                raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
+            if att_masks is not None:
+                ml = int(att_masks.long().sum(1).max())
+                att_feats, att_masks = att_feats[:, :ml], att_masks[:, :ml].float().contiguous()
+            P = dict(zip(self._param_names, [p.detach() for _, p in self.named_parameters()]))
+
+            def make(rows):
+                g = engine.AoAGraph(P, {}, self.num_heads, 0.0, 0.0, False, 0)
+                g.prepare(att_feats.float().contiguous(), att_masks)
+                return engine.BeamDecoder(g, rows)
+            return self._sample_with_options(make, att_feats.size(0), opt)
         mode, temperature, top_k, top_p = parse_sample_method(method, opt.get('temperature', 1.0))
         L = self.seq_length
         cfg = dict(n=int(opt.get('sample_n', 1)), T=L, L=L, mode=mode, temperature=temperature,

@@ -22,10 +22,6 @@ from imagecaptioning.pytorch_amd import updown_engine as engine
 from imagecaptioning.pytorch_amd import ops
 from imagecaptioning.pytorch_amd._lib import CapmiError
 
-bad_endings = ['a', 'an', 'the', 'in', 'for', 'at', 'of', 'with', 'before', 'after', 'on', 'upon', 'near', 'to', 'is',
-               'are', 'am', 'the']
-
-
 from .utils import parse_sample_method      # noqa: E402
 
 
@@ -123,7 +119,6 @@ class AttModel(CaptionModel):
         self.logit = nn.Linear(self.rnn_size, self.vocab_size + 1)
         self.ctx2att = nn.Linear(self.rnn_size, self.att_hid_size)
         self.vocab = opt.vocab
-        self.bad_endings_ix = [int(k) for k, v in self.vocab.items() if v in bad_endings]
         self._flat = None
         self._rng_calls = 0
         self._last_rollout = None
@@ -219,11 +214,16 @@ class AttModel(CaptionModel):
         group_size = opt.get('group_size', 1)
         if beam_size > 1 and sample_method in ('greedy', 'beam_search'):
             return self._sample_beam(fc_feats, att_feats, att_masks, opt)
-        if group_size > 1:
-            raise NotImplementedError('diverse sampling (group_size > 1) is outside the hot-path scope')
-        for k in ('decoding_constraint', 'block_trigrams', 'remove_bad_endings'):
-            if opt.get(k, 0):
-                raise NotImplementedError('%s is not part of the accelerated rollout yet' % k)
+        from imagecaptioning.pytorch_amd import decode
+        if decode.wants_options(opt):
+            # _diverse_sample (AttModel.py:270-271) / decoding constraints (:293-330): host-stepped, same kernels
+            def make(rows):
+                from imagecaptioning.pytorch_amd.step import UpDownStepper
+                P = {k: v.detach() for k, v in self.named_parameters()}
+                pr = engine.prepare(P, fc_feats.float().contiguous(), att_feats.float().contiguous(),
+                                    None if att_masks is None else att_masks.float())
+                return UpDownStepper(P, pr, rows)
+            return self._sample_with_options(make, fc_feats.size(0), opt)
         if not opt.get('output_logsoftmax', 1):
             raise NotImplementedError('output_logsoftmax=0 is only used by margin structure losses')
         mode, temperature, top_k, top_p = parse_sample_method(sample_method, temperature)

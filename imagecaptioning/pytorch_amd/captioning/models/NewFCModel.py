@@ -97,12 +97,21 @@ class NewFCModel(CaptionModel):
 
     def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
         method = opt.get('sample_method', 'greedy')
-        if opt.get('beam_size', 1) > 1:
-            raise NotImplementedError('beam search for newfc is not accelerated')
         from .utils import parse_sample_method
+        from imagecaptioning.pytorch_amd import decode, beam
+        from imagecaptioning.pytorch_amd.step import NewFCStepper
+        if not fc_feats.is_cuda:
+            raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
+        P = dict(zip(self._param_names, [p.detach() for _, p in self.named_parameters()]))
+        if opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search'):
+            # AttModel._sample_beam on the single-step decoder (the image step is taken once per image, AttModel.py:925-927)
+            with torch.no_grad():
+                return beam.beam_search_steps(self, lambda rows: NewFCStepper(P, fc_feats, rows), fc_feats.size(0),
+                                              P['embed.weight'].shape[0], self.seq_length, opt, fc_feats.device)
         mode, temperature, top_k, top_p = parse_sample_method(method, opt.get('temperature', 1.0))
-        if top_k or top_p:
-            raise NotImplementedError('top-k / nucleus sampling is not wired into the newfc rollout (plumbing config)')
+        if decode.wants_options(opt) or top_k or top_p:
+            # options the one-call rollout has no hooks for: host-stepped (eval numerics, no gradient)
+            return self._sample_with_options(lambda rows: NewFCStepper(P, fc_feats, rows), fc_feats.size(0), opt)
         cfg = dict(n=int(opt.get('sample_n', 1)), T=self.seq_length, L=self.seq_length, mode=mode,
                    temperature=temperature, seed=self._next_seed())
         return self._run(cfg, fc_feats)

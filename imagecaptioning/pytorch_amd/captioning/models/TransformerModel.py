@@ -208,6 +208,13 @@ class TransformerModel(CaptionModel):
                 P = self._pdict([p for _, p in self.named_parameters()])
                 return engine.sample_beam(self, P, att_feats, att_masks, self.h, self.N_enc, self.N_dec, self.seq_length, opt)
         from .utils import parse_sample_method
+        from imagecaptioning.pytorch_amd import decode
+        if decode.wants_options(opt):
+            att_feats, att_masks = self._clip(att_feats, att_masks)
+            P = self._pdict([p for _, p in self.named_parameters()])
+            return self._sample_with_options(
+                lambda rows: engine.Decoder(P, att_feats, att_masks, self.h, self.N_enc, self.N_dec, self.seq_length, rows),
+                att_feats.size(0), opt)
         mode, temperature, top_k, top_p = parse_sample_method(method, opt.get('temperature', 1.0))
         n = int(opt.get('sample_n', 1))
         att_feats, att_masks = self._clip(att_feats, att_masks)

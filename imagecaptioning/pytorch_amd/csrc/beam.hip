@@ -139,7 +139,7 @@ int gemm(void *stream, int M, int N, float *C, int ldc, const SegSpec *segs, int
 
 // one decoder step on `rows` rows, `n` rows per image (get_logprobs_state, AttModel.py:166-176)
 int decode_step(const capmi_updown_weights *w, capmi_updown_beam *b, int rows, int n, const float *st_in, float *st_out,
-                float *logp_out, void *stream) {
+                float *logp_out, float temperature, void *stream) {
     const int B = b->B, K = b->K, A = b->A, R = b->R, E = b->E, V1 = b->V1;
     const size_t per = (size_t)B * b->bd * R;
     const float *h_att_p = st_in, *c_att_p = st_in + per, *h_lang_p = st_in + 2 * per, *c_lang_p = st_in + 3 * per;
@@ -172,7 +172,8 @@ int decode_step(const capmi_updown_weights *w, capmi_updown_beam *b, int rows, i
         SegSpec s{h_lang, R, w->logit_w, R, R, 1};     // eval mode: no dropout on the output
         RC(gemm(stream, rows, V1, b->logits, V1, &s, 1, b->partial, b->partial_capacity, 0, nullptr, w->logit_b));
     }
-    return capmi_beam_logsoftmax(b->logits, logp_out, rows, V1, b->temperature, b->unk_col, stream);
+    if (!logp_out) return 0;      // raw logits wanted (capmi_updown_decode_step)
+    return capmi_beam_logsoftmax(b->logits, logp_out, rows, V1, temperature, b->unk_col, stream);
 }
 
 }  // namespace
@@ -209,6 +210,18 @@ int capmi_beam_logsoftmax(const float *logits, float *out, int N, int V1, float 
     return 0;
 }
 
+int capmi_updown_decode_step(const capmi_updown_weights *w, capmi_updown_beam *b, int rows, int rows_per_image,
+                             const float *state_in, float *state_out, int first, void *stream) {
+    if (!w || !b || b->B <= 0 || b->bd <= 0 || rows_per_image <= 0 || rows_per_image > b->bd || rows != b->B * rows_per_image ||
+        !state_in || !state_out || state_in == state_out || !b->partial || !b->logits || !b->it)
+        return CAPMI_EINVAL;
+    if (first) {   // fc term of the attention LSTM, once per set of images
+        SegSpec s{b->fc, b->R, w->att_w_ih + b->R, 2 * b->R + b->E, b->R, 1};
+        RC(gemm(stream, b->B, 4 * b->R, b->fc_gates, 4 * b->R, &s, 1, b->partial, b->partial_capacity, 0, nullptr));
+    }
+    return decode_step(w, b, rows, rows_per_image, state_in, state_out, nullptr, 1.f, stream);
+}
+
 int capmi_updown_beam_search(const capmi_updown_weights *w, capmi_updown_beam *b, void *stream) {
     if (!w || !b || b->B <= 0 || b->bd <= 0 || b->bd > BD_MAX || b->L <= 0 || !b->partial) return CAPMI_EINVAL;
     const int B = b->B, bd = b->bd, R = b->R, E = b->E, V1 = b->V1, L = b->L;
@@ -225,7 +238,8 @@ int capmi_updown_beam_search(const capmi_updown_weights *w, capmi_updown_beam *b
     }
     // first step from BOS on B rows (AttModel.py:235-239): rows b of the [B*bd]-row arrays, one row per image
     float *st_a = b->state, *st_b = b->state + st_sz;
-    RC(decode_step(w, b, B, 1, st_a, st_b, b->logp_rows, stream));
+    // the first distribution is the model's own log_softmax: the temperature only enters at CaptionModel.py:203-204
+    RC(decode_step(w, b, B, 1, st_a, st_b, b->logp_rows, 1.f, stream));
     // NOTE: after this call the B live rows of st_b / logp_rows[0] are rows 0..B-1 (cur = 1 per image)
     float *cur_state = st_b, *nxt_state = st_a;
     int cur = 1;
@@ -239,7 +253,7 @@ int capmi_updown_beam_search(const capmi_updown_weights *w, capmi_updown_beam *b
         if ((e = hipMemcpyAsync(b->it, b->token + o, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToDevice, st)) != hipSuccess)
             return (int)e;
         // step on B*bd rows, bd rows per image; writes the next state in place of the consumed one
-        RC(decode_step(w, b, N, bd, nxt_state, cur_state, b->logp_rows + (size_t)(t + 1) * N * V1, stream));
+        RC(decode_step(w, b, N, bd, nxt_state, cur_state, b->logp_rows + (size_t)(t + 1) * N * V1, b->temperature, stream));
         cur = bd;
         // cur_state now holds the new state; nxt_state is free
     }

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
     float temperature, const float *__restrict__ gumbel, uint64_t seed, const int64_t *__restrict__ forced,
     int forced_ld, int no_finish_mask, int64_t *__restrict__ seq, int seq_ld, int64_t *__restrict__ it_next,
     uint8_t *__restrict__ unfinished, float *__restrict__ seq_logp, float *__restrict__ sel_logp,
-    uint8_t *__restrict__ live, const NextEmbed ne, int top_k, float top_p) {
+    uint8_t *__restrict__ live, const NextEmbed ne, int top_k, float top_p, int prenorm) {
     __shared__ float s_f[32];
     __shared__ int s_i[32];
     const int r = blockIdx.x;
@@ -94,7 +94,10 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
     float s = 0.f;
     for (int v = threadIdx.x; v < V1; v += blockDim.x) s += __expf(x[v] - m);
     s = block_sum(s, s_f);
-    const float lse = m + __logf(s);
+    // prenorm: the row already holds (possibly constrained: -inf / penalised entries) log-probabilities that must be
+    // stored and gathered as they are (AttModel.py:293-330 edits them AFTER log_softmax); Categorical / arg-max only
+    // need them up to a constant, so nothing is renormalised
+    const float lse = prenorm ? 0.f : m + __logf(s);
 
     // choose
     int token;
@@ -171,12 +174,15 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
 
     // bookkeeping (AttModel.py:340-347)
     const bool was_unf = (step == 0 || no_finish_mask) ? true : (unfinished[r] != 0);
+    const int chosen = token;
     if (!was_unf) token = 0;
     const float keep = was_unf ? 1.f : 0.f;
     float *out = seq_logp ? seq_logp + ((size_t)r * L + step) * V1 : nullptr;
     if (out) {
         if (was_unf)
             for (int v = threadIdx.x; v < V1; v += blockDim.x) out[v] = x[v] - lse;
+        else if (prenorm)   // logprobs * unfinished (AttModel.py:345): -inf * 0 = NaN is kept as the reference produces it
+            for (int v = threadIdx.x; v < V1; v += blockDim.x) out[v] = x[v] * keep;
         else
             for (int v = threadIdx.x; v < V1; v += blockDim.x) out[v] = 0.f;
     }
@@ -185,7 +191,9 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
     if (threadIdx.x == 0) {
         seq[(size_t)r * seq_ld + step] = token;
         it_next[r] = token;
-        if (sel_logp) sel_logp[(size_t)r * L + step] = keep * (x[token] - lse);
+        // prenorm 2 (AttModel._diverse_sample, AttModel.py:436-447): the log-prob of the token the sampler picked, also
+        // for rows that had already finished (their token is overwritten by the pad, the stored value is not)
+        if (sel_logp) sel_logp[(size_t)r * L + step] = prenorm == 2 ? x[chosen] : keep * (x[token] - lse);
         if (live) live[(size_t)r * L + step] = was_unf ? 1 : 0;
         if (!no_finish_mask) unfinished[r] = (was_unf && token != 0) ? 1 : 0;
     }
@@ -433,7 +441,24 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
     hipLaunchKernelGGL(logsoftmax_select_kernel, dim3(N), dim3(SEL_THREADS), 0, st, partial, splits, (size_t)slab_stride, bias,
                        V1, step, L, mode, row_mode,
                        temperature, gumbel, seed, forced, forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished,
-                       seq_logp, sel_logp, live, ne, top_k, top_p);
+                       seq_logp, sel_logp, live, ne, top_k, top_p, 0);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_select_logp(const float *logp, int N, int V1, int step, int L, int mode, float temperature, const float *gumbel,
+                      uint64_t seed, int64_t *seq, int seq_ld, int64_t *it_next, uint8_t *unfinished, float *seq_logp,
+                      float *sel_logp, int sel_unmasked, const capmi_sample_filter *filter, void *stream) {
+    if (!logp || N <= 0 || V1 <= 0 || step < 0 || step >= L || !seq || !it_next || !unfinished) return CAPMI_EINVAL;
+    if (mode != 0 && mode != 1) return CAPMI_EINVAL;
+    if (mode == 1 && !(temperature > 0.f)) return CAPMI_EINVAL;
+    const int top_k = filter ? filter->top_k : 0;
+    const float top_p = filter ? filter->top_p : 0.f;
+    if (top_k < 0 || top_p < 0.f || top_p >= 1.f || (top_k > 0 && top_p > 0.f)) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(logsoftmax_select_kernel, dim3(N), dim3(SEL_THREADS), 0, (hipStream_t)stream, logp, 1, (size_t)0,
+                       (const float *)nullptr, V1, step, L, mode, (const uint8_t *)nullptr, temperature, gumbel, seed,
+                       (const int64_t *)nullptr, 0, 0, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp,
+                       (uint8_t *)nullptr, NextEmbed{}, top_k, top_p, sel_unmasked ? 2 : 1);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

@@ -396,5 +396,6 @@ def sample_beam(model, P, att_feats, att_masks, h, n_enc, n_dec, L, opt):
     """AttModel._sample_beam (AttModel.py:218-256) for the Transformer: beam_size hypotheses per image share the image's
     encoder memory (no repeat_tensors copy), the KV caches follow the beams by parent pointer."""
     from . import beam
-    dec = Decoder(P, att_feats, att_masks, h, n_enc, n_dec, L, opt.get('beam_size', 10))
-    return beam.beam_search_steps(model, dec.step, dec.reorder, dec.B, dec.V1, L, opt, att_feats.device)
+    B, V1 = att_feats.shape[0], P['model.generator.proj.weight'].shape[0]
+    return beam.beam_search_steps(model, lambda rows: Decoder(P, att_feats, att_masks, h, n_enc, n_dec, L, rows), B, V1, L, opt,
+                                  att_feats.device)

@@ -469,6 +469,46 @@ typedef struct capmi_updown_beam {
 
 int capmi_updown_beam_search(const capmi_updown_weights *w, capmi_updown_beam *b, void *stream);
 
+/* ONE UpDown decoder step on already prepared features: AttModel.get_logprobs_state (AttModel.py:166-176) up to the raw
+ * logits (b->logits [rows,V1]); the caller normalises.  Tokens are read from b->it [rows]; `rows` = b->B *
+ * rows_per_image hypotheses, image-major.  state_in / state_out are distinct [4][b->B*b->bd, R] arrays
+ * (h_att, c_att, h_lang, c_lang).  first != 0 also (re)computes b->fc_gates.  Uses of b: B, bd (row capacity per image),
+ * K, A, R, E, V1, fc, att, p_att, att_mask, xt, gates, att_h, alpha, ctx, fc_gates, logits, it, partial. */
+int capmi_updown_decode_step(const capmi_updown_weights *w, capmi_updown_beam *b, int rows, int rows_per_image,
+                             const float *state_in, float *state_out, int first, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Decode-time options (eval): the reference edits the [rows,V1] log-probabilities of a step on the host side
+ * (AttModel.py:293-330, 391-432; CaptionModel.py:38-57, 152-157).  Here they are in-place device edits.
+ * ------------------------------------------------------------------------------------------- */
+#define CAPMI_DECODE_NO_REPEAT 1       /* decoding_constraint: the previous token gets -inf              */
+#define CAPMI_DECODE_NO_BAD_ENDING 2   /* remove_bad_endings: column 0 gets -inf after a bad-ending word  */
+#define CAPMI_DECODE_BLOCK_TRIGRAMS 4  /* block_trigrams: -0.693*2 per earlier occurrence of the trigram  */
+/* logp [N,V1] in place.  prev[r*prev_stride] = token row r emitted at step t-1 (flags 1, 2; call only for t > 0).
+ * bad_endings [n_bad] token ids.  seq [N,seq_ld] tokens emitted so far (columns 0..t-1; flag 4, rows < trigram_rows
+ * only -- the reference loops over the image batch, AttModel.py:310, 322). */
+int capmi_decode_constrain(float *logp, int N, int V1, const int64_t *prev, int prev_stride, int flags,
+                           const int64_t *bad_endings, int n_bad, const int64_t *seq, int seq_ld, int t, int trigram_rows,
+                           void *stream);
+/* diverse beam search, CaptionModel.add_diversity (CaptionModel.py:38-57): out [B*cur,V1] = logp - change*lambda where
+ * change[b,v] counts v among prev_tokens[b*prev_stride + 0..n_prev-1] (choices of the earlier groups at this local
+ * time).  logp != out. */
+int capmi_beam_diversity(const float *logp, float *out, int B, int cur, int V1, const int64_t *prev_tokens, int prev_stride,
+                         int n_prev, float diversity_lambda, void *stream);
+/* AttModel._diverse_sample (AttModel.py:395-397): logp[:, tokens] -= lambda for EVERY row, once per distinct token;
+ * tokens[i*token_stride], i < n_tokens.  One call per earlier group. */
+int capmi_column_penalty(float *logp, int N, int V1, const int64_t *tokens, int n_tokens, int token_stride,
+                         float diversity_lambda, void *stream);
+/* Token choice from rows that ALREADY hold (constrained) log-probabilities: nothing is renormalised, the rows are
+ * stored as they are times the unfinished flag (AttModel.py:333-347; -inf * 0 = NaN like there).  mode 0 arg-max,
+ * 1 Categorical(logits = logp / temperature) with the optional top-k / nucleus filter.  sel_logp [N,L] (optional):
+ * the picked token's log-prob times the unfinished flag, or -- sel_unmasked != 0, AttModel._diverse_sample
+ * (AttModel.py:436-447) -- the log-prob of the token the sampler picked even for rows that had finished.  Other
+ * arguments as in capmi_logsoftmax_select_partial. */
+int capmi_select_logp(const float *logp, int N, int V1, int step, int L, int mode, float temperature, const float *gumbel,
+                      uint64_t seed, int64_t *seq, int seq_ld, int64_t *it_next, uint8_t *unfinished, float *seq_logp,
+                      float *sel_logp, int sel_unmasked, const capmi_sample_filter *filter, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Transformer captioner building blocks (BASELINE configs[3]; TransformerModel.py).  The contractions
  * (QKV / output projections, FFN, generator) run on capmi_gemm_f32 with fused bias / ReLU / dropout /

@@ -299,8 +299,118 @@ def main_beam2():
         print(name + '_tiny_beam.npz:', len(out), 'arrays')
 
 
+OPT_CASES = (
+    # tag, kind, opt
+    ('dc', 'sample', {'decoding_constraint': 1}),
+    ('rbe', 'sample', {'remove_bad_endings': 1}),
+    ('tri', 'sample', {'block_trigrams': 1}),
+    ('all', 'sample', {'decoding_constraint': 1, 'remove_bad_endings': 1, 'block_trigrams': 1}),
+    ('tri_n2', 'sample', {'block_trigrams': 1, 'decoding_constraint': 1, 'sample_n': 2}),
+    ('div3', 'sample', {'group_size': 3, 'diversity_lambda': 0.5}),
+    ('div2c', 'sample', {'group_size': 2, 'diversity_lambda': 0.8, 'decoding_constraint': 1, 'remove_bad_endings': 1,
+                         'temperature': 1.5}),
+    ('bT', 'beam', {'beam_size': 3, 'temperature': 2.0}),
+    ('bdc', 'beam', {'beam_size': 3, 'decoding_constraint': 1, 'remove_bad_endings': 1}),
+    ('bg2', 'beam', {'beam_size': 4, 'group_size': 2, 'diversity_lambda': 0.5}),
+    ('bg3', 'beam', {'beam_size': 3, 'group_size': 3, 'diversity_lambda': 1.0, 'temperature': 1.3}),
+    ('bg2c', 'beam', {'beam_size': 4, 'group_size': 2, 'diversity_lambda': 0.5, 'decoding_constraint': 1,
+                      'remove_bad_endings': 1, 'sample_n': 2, 'length_penalty': 'wu_0.5'}),
+)
+
+
+def family_model(models, name):
+    """the reference model of tests/golden/<name>_tiny.npz"""
+    z = np.load(os.path.join(HERE, name + '_tiny.npz'))
+    opt = tiny_opt(name, drop=0.0)
+    if name == 'transformer':
+        opt.N_enc, opt.N_dec, opt.d_model, opt.d_ff, opt.num_att_heads, opt.dropout = 2, 2, 16, 32, 2, 0.0
+    elif name == 'aoa':
+        opt.refine, opt.refine_aoa, opt.use_ff, opt.decoder_type, opt.use_multi_head = 1, 1, 0, 'AoA', 2
+        opt.num_heads, opt.multi_head_scale, opt.mean_feats, opt.ctx_drop, opt.dropout_aoa = 2, 1, 1, 1, 0.3
+        opt.num_layers = 2
+    model = models.setup(opt)
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('P.')})
+    return model.eval()
+
+
+def main_opts():
+    """Decode-time options (AttModel._sample constraints, _diverse_sample, diverse / constrained beam search) of the real
+    reference on the weights of the four tiny fixtures.  Everything is greedy / beam (deterministic).  `bad_endings_ix`
+    is set by hand (the tiny vocabulary has no English words): the words that precede the end token in the plain, the
+    decoding_constraint and the decoding_constraint + block_trigrams greedy decodes, so that remove_bad_endings really changes the output."""
+    sys.path.insert(0, REF)
+    import captioning.models as models
+    ref_attmodel = sys.modules['captioning.models.AttModel']     # (the package attribute of that name is the class)
+
+    class _TorchCompat:
+        """The reference indexes with a uint8 mask (AttModel.py:303, 414), which torch 1.x treated as a boolean mask and
+        torch >= 2 rejects.  Inside the reference module only, from_numpy() turns uint8 arrays into bool -- the torch 1.x
+        meaning -- so that the unmodified reference code runs; nothing else is altered."""
+
+        def __getattr__(self, k):
+            return getattr(torch, k)
+
+        @staticmethod
+        def from_numpy(a):
+            x = torch.from_numpy(a)
+            return x.bool() if x.dtype == torch.uint8 else x
+    ref_attmodel.torch = _TorchCompat()
+    # CaptionModel.add_diversity calls self.repeat_tensor (CaptionModel.py:53), a method that no longer exists in the
+    # reference (the helper lives on as models/utils.py:repeat_tensors), so diverse beam search raises AttributeError from the
+    # second step on.  Bind the missing name to that helper -- the evident intent -- so the reference code can run.
+    ref_utils = sys.modules['captioning.models.utils']
+    sys.modules['captioning.models.CaptionModel'].CaptionModel.repeat_tensor = lambda self, n, x: ref_utils.repeat_tensors(n, x)
+    u = np.load(os.path.join(HERE, 'updown_tiny.npz'))
+    fc, att, am = (torch.from_numpy(u[k]) for k in ('fc', 'att', 'att_masks'))
+    eos_bias = {'updown': 0.15, 'newfc': 1.0, 'transformer': -0.3, 'aoa': 0.5}
+    if len(sys.argv) > 2:
+        eos_bias = dict(zip(('updown', 'newfc', 'transformer', 'aoa'), map(float, sys.argv[2:6])))
+    for name in ('updown', 'newfc', 'transformer', 'aoa'):
+        model = family_model(models, name)
+        # the weights of <name>_tiny.npz never emit the end token and repeat one word; for these fixtures perturb them
+        # harder (seeded) and lift the end-token bias so that captions have varied lengths, then store the weights used
+        torch.manual_seed(2024)
+        with torch.no_grad():
+            for k, p_ in model.named_parameters():
+                p_.add_(0.3 * torch.randn_like(p_))
+            bias = dict(model.named_parameters())['model.generator.proj.bias' if name == 'transformer' else 'logit.bias']
+            bias[0] += eos_bias[name]
+        out = {('P.' + k): v.detach().numpy().copy() for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            seq0, _ = model(fc, att, am, opt={'sample_method': 'greedy'}, mode='sample')
+            seq_dc, _ = model(fc, att, am, opt={'sample_method': 'greedy', 'decoding_constraint': 1}, mode='sample')
+            seq_tri, _ = model(fc, att, am, opt={'sample_method': 'greedy', 'decoding_constraint': 1, 'block_trigrams': 1},
+                               mode='sample')
+            bad = set()
+            for row in seq0.tolist() + seq_dc.tolist() + seq_tri.tolist():
+                toks = [w for w in row if w > 0]
+                if toks and len(toks) < len(row):      # the caption really ended: its last word is declared a bad ending
+                    bad.add(toks[-1])
+            bad = sorted(bad)
+            model.bad_endings_ix = bad
+            out['bad_endings_ix'] = np.array(bad, dtype=np.int64)
+            out['plain_seq'] = seq0.numpy()
+            changed = []
+            for tag, kind, kw in OPT_CASES:
+                o = {'sample_method': 'greedy' if kind == 'sample' else 'beam_search', 'beam_size': 1, 'sample_n': 1}
+                o.update(kw)
+                seq, slp = model(fc, att, am, opt=o, mode='sample')
+                if kind == 'beam':
+                    _dump_beams(model, out, tag, seq, slp)
+                else:
+                    out[tag + '_seq'] = seq.numpy()
+                    out[tag + '_logp'] = slp.numpy()
+                    if seq.shape == seq0.shape:
+                        changed.append((tag, int((seq != seq0).sum())))
+        np.savez_compressed(os.path.join(HERE, name + '_tiny_opts.npz'), **out)
+        print(name + '_tiny_opts.npz:', len(out), 'arrays; bad endings', bad, '; tokens changed vs plain greedy', changed)
+        print(seq0.numpy(), out['all_seq'], out['div3_seq'], sep='\n')
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'beam2':
+    if len(sys.argv) > 1 and sys.argv[1] == 'opts':
+        main_opts()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'beam2':
         main_beam2()
     elif len(sys.argv) > 1 and sys.argv[1] == 'aoa':
         main_aoa()
