@@ -46,7 +46,7 @@ class UpDownRollout(C.Structure):
                 [(k, c_f) for k in ('h_att', 'c_att', 'h_lang', 'c_lang', 'xt', 'it_all', 'gates_att', 'gates_lang',
                                     'att_h', 'alpha', 'ctx', 'h_drop', 'seq', 'seq_logp', 'sel_logp', 'live',
                                     'fc_gates', 'logits', 'it', 'unfinished', 'partial')] +
-                [('partial_capacity', C.c_int64), ('top_k', C.c_int), ('top_p', C.c_float)])
+                [('partial_capacity', C.c_int64), ('top_k', C.c_int), ('top_p', C.c_float), ('ss_mode', c_f)])
 
 
 class SampleFilter(C.Structure):

@@ -124,6 +124,8 @@ class AoAModel(CaptionModel):
         return _Fn.apply(self, cfg, att_feats.float().contiguous(), att_masks, *params)
 
     def _forward(self, fc_feats, att_feats, seq, att_masks=None):
+        if self.training and self.ss_prob > 0:
+            raise NotImplementedError('scheduled sampling (ss_prob > 0) is only wired into the UpDown rollout')
         B = att_feats.size(0)
         if seq.ndim == 3:
             seq = seq.reshape(-1, seq.shape[2])

@@ -48,7 +48,7 @@ class _RolloutFn(torch.autograd.Function):
                             temperature=cfg.get('temperature', 1.0), drop_xt=cfg.get('drop_xt'),
                             drop_out=cfg.get('drop_out'), gumbel=cfg.get('gumbel'), seed=cfg.get('seed', 0),
                             forced=cfg.get('forced'), teacher=cfg.get('teacher', False), row_mode=cfg.get('row_mode'),
-                            top_k=cfg.get('top_k', 0), top_p=cfg.get('top_p', 0.0), **extra)
+                            top_k=cfg.get('top_k', 0), top_p=cfg.get('top_p', 0.0), ss_mode=cfg.get('ss_mode'), **extra)
         seq, seq_logp = ro.run()
         ctx.model, ctx.ro, ctx.pr, ctx.P = model, ro, pr, P
         ctx.mark_non_differentiable(seq)
@@ -184,8 +184,6 @@ class AttModel(CaptionModel):
 
     def _forward(self, fc_feats, att_feats, seq, att_masks=None):
         """Teacher-forced log-probs [N,T,V1] (AttModel.py:126-164)."""
-        if self.training and self.ss_prob > 0:
-            raise NotImplementedError('scheduled sampling (ss_prob > 0) is inactive in the BASELINE configs')
         self._device_check(fc_feats)
         B = fc_feats.size(0)
         if seq.ndim == 3:
@@ -201,6 +199,16 @@ class AttModel(CaptionModel):
         K = att_feats.shape[1] if att_masks is None else int(att_masks.long().sum(1).max())
         cfg = dict(n=n, T=T_eff, L=T, mode='forced', forced=seq, teacher=True)
         cfg.update(self._dropout_masks(B, K, N, T_eff, fc_feats.device))
+        if self.training and self.ss_prob > 0.0:
+            # scheduled sampling (AttModel.py:145-154): from step 1 on each row feeds, with probability ss_prob, a draw from
+            # the model's previous distribution instead of the ground-truth word.  The coin flips are made here for all
+            # steps at once (they do not depend on the model), the draws happen inside the rollout.
+            coin = self._ss_coin if getattr(self, '_ss_coin', None) is not None else \
+                torch.rand(T_eff, N, device=fc_feats.device) < self.ss_prob            # _ss_coin / _ss_gumbel: test hooks
+            cfg['ss_mode'] = torch.where(coin, 1, 2).to(torch.uint8).contiguous()
+            cfg['seed'] = self._next_seed()
+            if getattr(self, '_ss_gumbel', None) is not None:
+                cfg['gumbel'] = self._ss_gumbel
         _, logp = self._run(cfg, fc_feats, att_feats, att_masks)
         return logp
 

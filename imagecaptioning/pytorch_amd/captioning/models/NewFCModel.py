@@ -85,6 +85,8 @@ class NewFCModel(CaptionModel):
         return _RolloutFn.apply(self, cfg, fc_feats.float().contiguous(), *params)
 
     def _forward(self, fc_feats, att_feats, seq, att_masks=None):
+        if self.training and self.ss_prob > 0:
+            raise NotImplementedError('scheduled sampling (ss_prob > 0) is only wired into the UpDown rollout')
         B = fc_feats.size(0)
         if seq.ndim == 3:
             seq = seq.reshape(-1, seq.shape[2])

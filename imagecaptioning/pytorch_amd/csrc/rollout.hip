@@ -99,7 +99,9 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
     const int ld_att_ih = 2 * R + E;
     // teacher forcing knows every input token up front: the vocabulary projection + log-softmax of all T steps run as ONE
     // fat GEMM over T*N rows after the loop (20 launches of a 320-row GEMM + 20 select launches otherwise)
-    const bool batched_logit = r->teacher && T == L && r->seq_logp &&
+    // scheduled sampling: the next input may be a draw from this step's distribution, so the steps stay sequential
+    const bool sched = r->teacher && r->ss_mode;
+    const bool batched_logit = r->teacher && !sched && T == L && r->seq_logp &&
                                (int64_t)N * T * R <= r->partial_capacity - CAPMI_WS_COUNTER_FLOATS;
 
     // initial state (slot 0) and flags
@@ -131,7 +133,7 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
 
         // 1. token embedding (+ReLU +dropout).  Free-running rollouts: only step 0 launches it (BOS); afterwards the
         //    select kernel of step t-1 has already written xt (the workgroup that chose the token embeds it).
-        if (r->teacher)
+        if (r->teacher && (!sched || t == 0))
             RC(capmi_embed_fwd(r->forced + t, r->forced_ld, r->it_all ? r->it_all + (size_t)t * N : nullptr, w->embed,
                                r->drop_xt ? r->drop_xt + (size_t)t * N * E : nullptr, xt, N, E, 1, stream));
         else if (t == 0)
@@ -175,11 +177,21 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
         }
         capmi_sample_filter flt{r->top_k, r->top_p};
         capmi_next_embed ne{};
-        if (!r->teacher && t + 1 < T) {
+        if ((!r->teacher || sched) && t + 1 < T) {
             ne.E = w->embed; ne.Edim = E; ne.relu = 1;
             ne.mask = r->drop_xt ? r->drop_xt + (size_t)(t + 1) * N * E : nullptr;
             ne.x = r->xt + (size_t)(t + 1) * N * E;
             ne.it_save = r->it_all ? r->it_all + (size_t)(t + 1) * N : nullptr;
+        }
+        if (sched && t + 1 < T) {
+            // AttModel.py:145-154: the token chosen here is the INPUT of step t+1 -- forced[:, t+1] (mode 2 rows) or a
+            // categorical draw from this step's log-probs (mode 1 rows, temperature 1); it is embedded by the same launch
+            RC(capmi_logsoftmax_select_partial(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, (int64_t)N * V1, w->logit_b, N, V1,
+                                               t, L, 2, r->ss_mode + (size_t)(t + 1) * N, 1.f,
+                                               r->gumbel ? r->gumbel + (size_t)t * N * V1 : nullptr, r->seed, r->forced + 1,
+                                               r->forced_ld, 1, r->seq, L, r->it, r->unfinished, r->seq_logp, r->sel_logp,
+                                               r->live, &ne, nullptr, stream));
+            continue;
         }
         RC(capmi_logsoftmax_select_partial(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, (int64_t)N * V1, w->logit_b, N, V1, t,
                                            L, r->teacher ? 2 : r->mode, r->teacher ? nullptr : r->row_mode, r->temperature,

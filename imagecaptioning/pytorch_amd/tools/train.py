@@ -66,14 +66,14 @@ def train(opt):
     lw_model = LossWrapper(model, opt)
     model.train()
     sched = misc.LRSchedule(opt, model_size=getattr(model, 'd_model', None))
-    if misc.scheduled_sampling_prob(opt, 10 ** 6) > 0:
-        raise NotImplementedError('scheduled sampling (scheduled_sampling_start >= 0) is off in every BASELINE config')
     sc_ready = False
     it, epoch = 0, 0
     epoch_done = True
     while it < opt.max_iters:
         if epoch_done:
             sched.epoch_start(epoch)
+            if misc.scheduled_sampling_prob(opt, epoch) > 0:                 # tools/train.py:142-146
+                opt.ss_prob = model.ss_prob = misc.scheduled_sampling_prob(opt, epoch)
             epoch_done = False
         sc_flag = opt.self_critical_after != -1 and epoch >= opt.self_critical_after
         struc_flag = opt.structure_after != -1 and epoch >= opt.structure_after

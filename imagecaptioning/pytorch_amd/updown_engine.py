@@ -111,8 +111,10 @@ class Rollout:
 
     def __init__(self, P, pr, n, T, L=None, mode='greedy', temperature=1.0, drop_xt=None, drop_out=None,
                  gumbel=None, seed=0, forced=None, teacher=False, row_mode=None, ws=None, keep_for_backward=True,
-                 row_img=None, B_grad=None, top_k=0, top_p=0.0):
-        """row_img (int32 [N]) + B_grad: ragged grouping for the fused SCST rollout -- the first B_grad
+                 row_img=None, B_grad=None, top_k=0, top_p=0.0, ss_mode=None):
+        """ss_mode (uint8 [T,N], teacher only): scheduled sampling, 1 = the input of (step, row) is drawn from the previous
+        step's distribution, 2 = teacher-forced (capmi.h capmi_updown_rollout.ss_mode).
+        row_img (int32 [N]) + B_grad: ragged grouping for the fused SCST rollout -- the first B_grad
         feature images own rows b*n..b*n+n-1 (sampled, with gradient), the remaining rows (greedy baseline)
         point at further feature images through row_img."""
         dev = pr.fc.device
@@ -158,6 +160,10 @@ class Rollout:
             assert forced.dtype == torch.long and forced.is_contiguous()
             r.forced, r.forced_ld = ptr(forced), forced.shape[1]
         r.teacher = int(teacher)
+        if ss_mode is not None:
+            assert teacher and ss_mode.dtype == torch.uint8 and ss_mode.shape == (T, N) and ss_mode.is_contiguous()
+        self.ss_mode = ss_mode
+        r.ss_mode = ptr(ss_mode)
         for k in ('h_att', 'c_att', 'h_lang', 'c_lang', 'xt', 'it_all', 'gates_att', 'gates_lang', 'att_h', 'alpha',
                   'ctx', 'h_drop', 'seq', 'seq_logp', 'sel_logp', 'live', 'fc_gates', 'logits', 'it', 'unfinished'):
             setattr(r, k, getattr(self, k).data_ptr())

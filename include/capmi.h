@@ -366,6 +366,10 @@ typedef struct capmi_updown_rollout {
     /* sampling filter (mode 1 rows only): see capmi_sample_filter */
     int top_k;
     float top_p;
+    /* scheduled sampling (teacher == 1 only; AttModel.py:145-154): [T,N] or NULL.  ss_mode[t*N + r] says where the INPUT
+     * token of row r at step t comes from: 2 = forced[r, t] (teacher forcing), 1 = a draw from the model's own distribution
+     * of step t-1 (torch.multinomial(exp(outputs[:, t-1])), here Gumbel-max at temperature 1).  Row t = 0 is ignored (BOS). */
+    const uint8_t *ss_mode;
 } capmi_updown_rollout;
 
 int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout *r, void *stream);

@@ -407,8 +407,42 @@ def main_opts():
         print(seq0.numpy(), out['all_seq'], out['div3_seq'], sep='\n')
 
 
+def main_ss():
+    """Scheduled sampling (AttModel._forward with ss_prob > 0, AttModel.py:145-154) of the real reference: train mode (the
+    branch is training-only; drop_prob 0 keeps dropout the identity), torch.manual_seed fixed right before the call so that
+    the oracle can replay the same uniform_/multinomial draws.  Stores log-probs, XE loss and every gradient."""
+    sys.path.insert(0, REF)
+    import captioning.models as models
+    from captioning.modules import losses
+    z = np.load(os.path.join(HERE, 'updown_tiny.npz'))
+    model = models.setup(tiny_opt('updown', drop=0.0))
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('P.')})
+    fc, att, am = (torch.from_numpy(z[k]) for k in ('fc', 'att', 'att_masks'))
+    labels, masks = torch.from_numpy(z['labels']), torch.from_numpy(z['masks'])
+    out = {}
+    model.train()
+    for tag, prob, seed in (('p50', 0.5, 11), ('p100', 1.0, 12)):
+        model.ss_prob = prob
+        model.zero_grad()
+        torch.manual_seed(seed)
+        logp = model(fc, att, labels[..., :-1], am)
+        loss = losses.LanguageModelCriterion()(logp, labels[..., 1:], masks[..., 1:])
+        loss.backward()
+        out[tag + '_seed'] = np.array(seed)
+        out[tag + '_prob'] = np.array(prob)
+        out[tag + '_logp'] = logp.detach().numpy()
+        out[tag + '_loss'] = loss.detach().numpy()
+        for k, p in model.named_parameters():
+            out['%s_grad.%s' % (tag, k)] = p.grad.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, 'updown_tiny_ss.npz'), **out)
+    print('updown_tiny_ss.npz:', len(out), 'arrays; differs from plain teacher forcing by',
+          float(np.abs(out['p50_logp'] - z['xe_logp_mask']).max()))
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'opts':
+    if len(sys.argv) > 1 and sys.argv[1] == 'ss':
+        main_ss()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'opts':
         main_opts()
     elif len(sys.argv) > 1 and sys.argv[1] == 'beam2':
         main_beam2()

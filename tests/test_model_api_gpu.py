@@ -410,3 +410,48 @@ def test_sample_methods_gumbel_topk_nucleus():
                     before = torch.cumsum(sp, 1) - sp                          # mass strictly above each sorted entry
                     ok = before.gather(1, rank[:, None]).squeeze(1) < num + 1e-6
                 assert bool((ok | ~live).all()), (method, t)
+
+
+@pytest.mark.parametrize('flatten', [False, True])
+def test_scheduled_sampling_matches_oracle(flatten):
+    """AttModel._forward with ss_prob > 0 (AttModel.py:145-154): coins and Gumbel noise injected into both sides (the
+    oracle's own draw order is pinned to the reference by tests/golden/updown_tiny_ss.npz); log-probs, XE loss and all
+    gradients must agree, and differ from plain teacher forcing."""
+    from oracle import att_lstm as O
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import LanguageModelCriterion
+    z, model = golden_model(flatten)
+    fc, att, am = (torch.from_numpy(z[k]) for k in ('fc', 'att', 'att_masks'))
+    labels, masks = torch.from_numpy(z['labels']), torch.from_numpy(z['masks'])
+    seq = labels[..., :-1].reshape(-1, labels.shape[-1] - 1)
+    N, T = seq.shape
+    zero_cols = (seq[:, 1:].sum(0) == 0).nonzero()
+    T_eff = int(zero_cols[0]) + 1 if zero_cols.numel() else T
+    g = torch.Generator().manual_seed(21)
+    coin = torch.rand(T, N, generator=g) < 0.5          # the oracle (like the reference) flips the coin before the early break
+    gumbel = -torch.log(-torch.log(torch.rand(T, N, model.vocab_size + 1, generator=g).clamp_min(1e-20)))
+    P = {k: torch.from_numpy(z['P.' + k]).requires_grad_(True) for k in model.state_dict()}
+    want = O.forward_teacher(P, fc, att, labels[..., :-1], am, ss_coin=coin, ss_gumbel=gumbel)
+    loss_w = O.lm_criterion(want, labels[..., 1:], masks[..., 1:])
+    loss_w.backward()
+    assert (want.detach() - torch.from_numpy(z['xe_logp_mask'])).abs().max() > 1e-2
+
+    model.train()
+    model.ss_prob = 0.5
+    model._ss_coin, model._ss_gumbel = coin[:T_eff].to(DEV), gumbel[:T_eff].to(DEV).contiguous()
+    model.zero_grad()
+    logp = model(fc.to(DEV), att.to(DEV), labels[..., :-1].to(DEV), am.to(DEV))
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-5, atol=2e-6)
+    loss = LanguageModelCriterion()(logp, labels[..., 1:].to(DEV), masks[..., 1:].to(DEV))
+    np.testing.assert_allclose(loss.item(), loss_w.item(), rtol=1e-5)
+    loss.backward()
+    grads = model._flat.grad_views if flatten else {k: p.grad for k, p in model.named_parameters()}
+    for k, p in P.items():
+        np.testing.assert_allclose(grads[k].cpu().numpy(), p.grad.numpy(), rtol=3e-4, atol=3e-7, err_msg=k)
+    # without the hooks the coins come from torch.rand: with ss_prob 1 every input after BOS is a model draw
+    model._ss_coin = model._ss_gumbel = None
+    model.ss_prob = 1.0
+    with torch.no_grad():
+        a = model(fc.to(DEV), att.to(DEV), labels[..., :-1].to(DEV), am.to(DEV))
+        b = model(fc.to(DEV), att.to(DEV), labels[..., :-1].to(DEV), am.to(DEV))
+    assert torch.isfinite(a).all() and not torch.equal(a, b)            # fresh draws per call
+    assert torch.equal(a[:, 0], b[:, 0])                                # step 0 only sees BOS

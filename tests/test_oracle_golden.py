@@ -153,3 +153,24 @@ def test_aoa_teacher_forced_loss_grads_and_greedy(tag):
         seq, slp = A.greedy(P, att, am, h=2, max_len=8)
     assert np.array_equal(seq.numpy(), z['greedy_seq_' + tag])
     np.testing.assert_allclose(slp.numpy(), z['greedy_logp_' + tag], rtol=1e-5, atol=3e-6)
+
+
+@pytest.mark.parametrize('tag', ['p50', 'p100'])
+def test_updown_scheduled_sampling_replays_the_reference(tag):
+    """AttModel._forward with ss_prob > 0 (AttModel.py:145-154): after the same torch.manual_seed the oracle makes the same
+    uniform_/multinomial calls as the reference, so log-probs, loss and every gradient must coincide."""
+    z, P = load('updown_tiny.npz')
+    g = np.load(os.path.join(GOLDEN, 'updown_tiny_ss.npz'))
+    for v in P.values():
+        v.requires_grad_(True)
+    fc, att, am = (torch.from_numpy(z[k]) for k in ('fc', 'att', 'att_masks'))
+    labels, masks = torch.from_numpy(z['labels']), torch.from_numpy(z['masks'])
+    torch.manual_seed(int(g[tag + '_seed']))
+    logp = O.forward_teacher(P, fc, att, labels[..., :-1], am, ss_prob=float(g[tag + '_prob']))
+    np.testing.assert_allclose(logp.detach().numpy(), g[tag + '_logp'], **TOL)
+    assert np.abs(g[tag + '_logp'] - z['xe_logp_mask']).max() > 1e-2          # the sampled inputs really changed the outputs
+    loss = O.lm_criterion(logp, labels[..., 1:], masks[..., 1:])
+    np.testing.assert_allclose(loss.item(), g[tag + '_loss'], rtol=1e-6)
+    loss.backward()
+    for k, p in P.items():
+        np.testing.assert_allclose(p.grad.numpy(), g['%s_grad.%s' % (tag, k)], rtol=2e-4, atol=2e-7, err_msg=k)
