@@ -171,7 +171,10 @@ def main():
 
     def sync():
         if dist is not None:
-            dist.barrier()
+            if dist.get_backend() == 'nccl':
+                dist.barrier(device_ids=[local])     # bind the barrier's collective to this rank's GPU explicitly
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):

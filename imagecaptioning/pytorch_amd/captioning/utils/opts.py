@@ -23,6 +23,8 @@ DEFAULTS = dict(
     use_multi_head=2, num_heads=8, multi_head_scale=1, mean_feats=1, ctx_drop=1, dropout_aoa=0.3,
     # eval
     beam_size=1, sample_method='greedy', temperature=1.0, suppress_UNK=1, length_penalty='', num_images=20, device='cuda',
+    group_size=1, diversity_lambda=0.5, decoding_constraint=0, block_trigrams=0, remove_bad_endings=0, sample_n=1,
+    sample_n_method='sample', verbose_beam=0,                                # opts.py:288-330 add_eval_sample_opts
     # data (synthetic only: the reference's h5/lmdb loaders are outside the hot path)
     input_synthetic=1, vocab_size=9487, synthetic_regions=36, synthetic_images=200,
 )

@@ -79,3 +79,55 @@ def test_yaml_base_inheritance(tmp_path):
     (tmp_path / 'sc.yml').write_text('_BASE_: base.yml\nself_critical_after: 0\nbatch_size: 5\n')
     cfg = config.load(str(tmp_path / 'sc.yml'))
     assert cfg == {'caption_model': 'updown', 'rnn_size': 1000, 'batch_size': 5, 'self_critical_after': 0}
+
+
+@pytest.mark.parametrize('model_args', [
+    ['--caption_model', 'updown'],
+    ['--caption_model', 'aoa', '--num_heads', '4', '--num_layers', '2'],
+])
+def test_eval_sample_n_methods_and_decode_flags(model_args):
+    """eval_utils.eval_split_n (eval_utils.py:228-290): bs / sample / top-k / dbs / diverse sampling, plus the decode flags of
+    the command line (decoding_constraint, block_trigrams, remove_bad_endings) reaching the sampler."""
+    sys.path.insert(0, PKG)
+    from imagecaptioning.pytorch_amd.tools import eval as E
+    small = model_args + ['--rnn_size', '64', '--input_encoding_size', '64', '--att_hid_size', '32', '--fc_feat_size', '48',
+                          '--att_feat_size', '48', '--vocab_size', '60', '--synthetic_regions', '7', '--seq_length', '8', '--max_length', '8',
+                          '--batch_size', '4', '--seq_per_img', '3', '--synthetic_images', '16', '--num_images', '4']
+    for method, extra in (('bs', []), ('sample', ['--temperature', '1.2']), ('top3', []), ('dbs', ['--beam_size', '2']),
+                          ('dgreedy', ['--diversity_lambda', '2.0'])):
+        import imagecaptioning.pytorch_amd.captioning.models  # noqa: F401
+        opt = _opts(small + ['--sample_n', '3', '--sample_n_method', method, '--decoding_constraint', '1', '--block_trigrams', '1',
+                             '--remove_bad_endings', '1'] + extra)
+        captured = {}
+        orig = E.eval_split
+
+        def spy(model, crit, loader, o):
+            r = orig(model, crit, loader, o)
+            captured['n'] = model.n_predictions
+            return r
+        E.eval_split = spy
+        try:
+            loss, preds = E.main(opt)
+        finally:
+            E.eval_split = orig
+        assert loss == loss and len(preds) >= 4
+        n_preds = captured['n']
+        assert len(n_preds) == 4 * 3, (method, len(n_preds))
+        for p in preds + n_preds:
+            words = p['caption'].split()
+            assert all(a != b for a, b in zip(words, words[1:])), (method, p['caption'])      # decoding_constraint held
+
+
+def test_train_with_scheduled_sampling(tmp_path):
+    """tools/train.py:142-146: ss_prob rises with the epoch and reaches the model; the XE step runs with sampled inputs."""
+    sys.path.insert(0, PKG)
+    from imagecaptioning.pytorch_amd.tools import train as T
+    small = ['--caption_model', 'updown', '--rnn_size', '32', '--input_encoding_size', '32', '--att_hid_size', '16', '--fc_feat_size', '24',
+             '--att_feat_size', '24', '--vocab_size', '40', '--synthetic_regions', '5', '--seq_length', '6', '--max_length', '6',
+             '--batch_size', '4', '--seq_per_img', '2', '--synthetic_images', '8', '--checkpoint_path', str(tmp_path),
+             '--scheduled_sampling_start', '0', '--scheduled_sampling_increase_every', '1', '--scheduled_sampling_increase_prob', '0.2',
+             '--scheduled_sampling_max_prob', '0.5']
+    opt = _opts(small + ['--max_iters', '10'])          # 2 iterations per epoch -> epochs 0..4
+    loss = T.train(opt)
+    assert loss == loss
+    assert opt.ss_prob == pytest.approx(0.5)             # min(0.2 * 4, 0.5) at epoch 4
