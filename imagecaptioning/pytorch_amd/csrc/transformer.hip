@@ -68,58 +68,65 @@ __global__ void layernorm_bwd_kernel(const float *__restrict__ dy, const float *
 // ---------------------------------------------------------------- short-sequence MHA
 constexpr int MHA_T = 256;
 
-// workgroup = (kv row, head).  LDS: K [Tk][dk+1], V [Tk][dk+1], then per query row: Q [Tq][dk+1], S [Tq][Tk+1]
+// workgroup = (kv row, head): the K/V tile of one image (or caption) and head is staged in LDS once and serves ALL
+// q_per_kv * Tq query rows that attend to it.  The query rows are flattened (caption-major) and processed CH at a time --
+// as many as fit in LDS next to K/V, normally all of them -- so a decode step (Tq = 1, 5 captions per image) or a
+// cross-attention (5 x 21 rows per image) is ONE pass of four block-wide phases instead of q_per_kv sequential passes.
+// LDS: K [Tk][dk+1], V [Tk][dk+1], Q [CH][dk+1], S [CH][Tk+1]  (+1: conflict-free column walks)
 __global__ __launch_bounds__(MHA_T) void mha_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                        const float *__restrict__ v, int ldkv, int kstride,
                                                        const uint8_t *__restrict__ mask, int mask_tq, int mask_per_q,
                                                        int causal, int q_pos0, const float *__restrict__ drop,
                                                        float *__restrict__ o, float *__restrict__ p, int q_per_kv, int Tq,
-                                                       int Tk, int h, int dk) {
+                                                       int Tk, int h, int dk, int CH) {
     extern __shared__ float lds[];
-    const int D = h * dk, P1 = dk + 1;
-    float *sK = lds, *sV = sK + Tk * P1, *sQ = sV + Tk * P1, *sS = sQ + Tq * P1;
+    const int D = h * dk, P1 = dk + 1, S1 = Tk + 1;
+    float *sK = lds, *sV = sK + Tk * P1, *sQ = sV + Tk * P1, *sS = sQ + CH * P1;
     const int kvr = blockIdx.x, hd = blockIdx.y;
     const float scale = rsqrtf((float)dk);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {
         const int j = i / dk, c = i % dk;
         sK[j * P1 + c] = k[(size_t)kvr * ldkv + (size_t)j * kstride + hd * dk + c];
         sV[j * P1 + c] = v[(size_t)kvr * ldkv + (size_t)j * kstride + hd * dk + c];
     }
-    for (int rq = 0; rq < q_per_kv; ++rq) {
-        const int r = kvr * q_per_kv + rq;
-        __syncthreads();
-        for (int i = threadIdx.x; i < Tq * dk; i += blockDim.x) {
-            const int t = i / dk, c = i % dk;
-            sQ[t * P1 + c] = q[((size_t)r * Tq + t) * D + hd * dk + c];
+    const int R_all = q_per_kv * Tq;
+    for (int row0 = 0; row0 < R_all; row0 += CH) {
+        const int rows = min(CH, R_all - row0);
+        __syncthreads();                    // K/V staged (first trip); the previous chunk's readers are done
+        for (int i = threadIdx.x; i < rows * dk; i += blockDim.x) {
+            const int lr = i / dk, c = i % dk, gr = row0 + lr;
+            const int r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
+            sQ[lr * P1 + c] = q[((size_t)r * Tq + t) * D + hd * dk + c];
         }
         __syncthreads();
-        const uint8_t *mrow = mask ? mask + (size_t)(mask_per_q ? r : kvr) * mask_tq * Tk : nullptr;
-        for (int i = threadIdx.x; i < Tq * Tk; i += blockDim.x) {
-            const int t = i / Tk, j = i % Tk;
+        for (int i = threadIdx.x; i < rows * Tk; i += blockDim.x) {
+            const int lr = i / Tk, j = i % Tk, gr = row0 + lr;
+            const int r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
             float s = 0.f;
-            for (int c = 0; c < dk; ++c) s += sQ[t * P1 + c] * sK[j * P1 + c];
+            for (int c = 0; c < dk; ++c) s += sQ[lr * P1 + c] * sK[j * P1 + c];
             s *= scale;
             bool ok = true;
-            if (mrow) ok = mrow[(size_t)(mask_tq > 1 ? t : 0) * Tk + j] != 0;
+            if (mask) ok = mask[((size_t)(mask_per_q ? r : kvr) * mask_tq + (mask_tq > 1 ? t : 0)) * Tk + j] != 0;
             if (causal && j > q_pos0 + t) ok = false;
-            sS[t * (Tk + 1) + j] = ok ? s : -INFINITY;
+            sS[lr * S1 + j] = ok ? s : -INFINITY;
         }
         __syncthreads();
-        // softmax per query row: one wave per row
-        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        for (int t = wid; t < Tq; t += nw) {
-            float *row = sS + t * (Tk + 1);
+        for (int lr = wid; lr < rows; lr += nw) {          // softmax: one wave per query row
+            const int gr = row0 + lr;
+            const int r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
+            float *row = sS + lr * S1;
             float m = -INFINITY;
             for (int j = lane; j < Tk; j += 64) m = fmaxf(m, row[j]);
             m = wave_max(m);
-            float s = 0.f;
+            float sum = 0.f;
             for (int j = lane; j < Tk; j += 64) {
                 const float e = __expf(row[j] - m);
                 row[j] = e;
-                s += e;
+                sum += e;
             }
-            s = wave_sum(s);
-            const float is = 1.f / s;
+            sum = wave_sum(sum);
+            const float is = 1.f / sum;
             for (int j = lane; j < Tk; j += 64) {
                 float pr = row[j] * is;
                 const size_t pi = (((size_t)r * h + hd) * Tq + t) * Tk + j;
@@ -129,27 +136,29 @@ __global__ __launch_bounds__(MHA_T) void mha_fwd_kernel(const float *__restrict_
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < Tq * dk; i += blockDim.x) {
-            const int t = i / dk, c = i % dk;
+        for (int i = threadIdx.x; i < rows * dk; i += blockDim.x) {
+            const int lr = i / dk, c = i % dk, gr = row0 + lr;
+            const int r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
             float acc = 0.f;
-            for (int j = 0; j < Tk; ++j) acc += sS[t * (Tk + 1) + j] * sV[j * P1 + c];
+            for (int j = 0; j < Tk; ++j) acc += sS[lr * S1 + j] * sV[j * P1 + c];
             o[((size_t)r * Tq + t) * D + hd * dk + c] = acc;
         }
     }
 }
 
-// backward, same decomposition; dK/dV accumulated over the q_per_kv rows in LDS and written once
+// backward, same decomposition; dK/dV accumulate over the chunks in LDS and are written once.
+// LDS: K, V, dK, dV [Tk][dk+1]; Q, dO [CH][dk+1]; P, P*drop, dS [CH][Tk+1]
 __global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict__ d_o, const float *__restrict__ q,
                                                        const float *__restrict__ k, const float *__restrict__ v, int ldkv,
                                                        int kstride, const float *__restrict__ p,
                                                        const float *__restrict__ drop, float *__restrict__ dq,
                                                        float *__restrict__ dk_out, float *__restrict__ dv_out, int dkv_ld,
                                                        int dkv_stride, int accumulate, int q_per_kv, int Tq, int Tk, int h,
-                                                       int dk) {
+                                                       int dk, int CH) {
     extern __shared__ float lds[];
     const int D = h * dk, P1 = dk + 1, S1 = Tk + 1;
     float *sK = lds, *sV = sK + Tk * P1, *sdK = sV + Tk * P1, *sdV = sdK + Tk * P1;
-    float *sQ = sdV + Tk * P1, *sdO = sQ + Tq * P1, *sP = sdO + Tq * P1, *sdS = sP + Tq * S1;
+    float *sQ = sdV + Tk * P1, *sdO = sQ + CH * P1, *sP = sdO + CH * P1, *sPd = sP + CH * S1, *sdS = sPd + CH * S1;
     const int kvr = blockIdx.x, hd = blockIdx.y;
     const float scale = rsqrtf((float)dk);
     for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {
@@ -160,56 +169,57 @@ __global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict_
         sdV[j * P1 + c] = 0.f;
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int rq = 0; rq < q_per_kv; ++rq) {
-        const int r = kvr * q_per_kv + rq;
+    const int R_all = q_per_kv * Tq;
+    for (int row0 = 0; row0 < R_all; row0 += CH) {
+        const int rows = min(CH, R_all - row0);
         __syncthreads();
-        for (int i = threadIdx.x; i < Tq * dk; i += blockDim.x) {
-            const int t = i / dk, c = i % dk;
-            sQ[t * P1 + c] = q[((size_t)r * Tq + t) * D + hd * dk + c];
-            sdO[t * P1 + c] = d_o[((size_t)r * Tq + t) * D + hd * dk + c];
+        for (int i = threadIdx.x; i < rows * dk; i += blockDim.x) {
+            const int lr = i / dk, c = i % dk, gr = row0 + lr;
+            const size_t gi = ((size_t)(kvr * q_per_kv + gr / Tq) * Tq + gr % Tq) * D + hd * dk + c;
+            sQ[lr * P1 + c] = q[gi];
+            sdO[lr * P1 + c] = d_o[gi];
         }
-        for (int i = threadIdx.x; i < Tq * Tk; i += blockDim.x) {
-            const int t = i / Tk, j = i % Tk;
-            sP[t * S1 + j] = p[(((size_t)r * h + hd) * Tq + t) * Tk + j];
+        for (int i = threadIdx.x; i < rows * Tk; i += blockDim.x) {
+            const int lr = i / Tk, j = i % Tk, gr = row0 + lr;
+            const size_t pi = (((size_t)(kvr * q_per_kv + gr / Tq) * h + hd) * Tq + gr % Tq) * Tk + j;
+            const float pr = p[pi];
+            sP[lr * S1 + j] = pr;
+            sPd[lr * S1 + j] = drop ? pr * drop[pi] : pr;
         }
         __syncthreads();
-        // dP_drop = dO V^T ; dP = dP_drop * drop ; dV += (P*drop)^T dO
-        for (int i = threadIdx.x; i < Tq * Tk; i += blockDim.x) {
-            const int t = i / Tk, j = i % Tk;
+        // dP_drop = dO V^T ; dP = dP_drop * drop
+        for (int i = threadIdx.x; i < rows * Tk; i += blockDim.x) {
+            const int lr = i / Tk, j = i % Tk, gr = row0 + lr;
             float acc = 0.f;
-            for (int c = 0; c < dk; ++c) acc += sdO[t * P1 + c] * sV[j * P1 + c];
-            const float dm = drop ? drop[(((size_t)r * h + hd) * Tq + t) * Tk + j] : 1.f;
-            sdS[t * S1 + j] = acc * dm;          // dP (w.r.t. the pre-dropout probabilities)
+            for (int c = 0; c < dk; ++c) acc += sdO[lr * P1 + c] * sV[j * P1 + c];
+            float dm = 1.f;
+            if (drop) dm = drop[(((size_t)(kvr * q_per_kv + gr / Tq) * h + hd) * Tq + gr % Tq) * Tk + j];
+            sdS[lr * S1 + j] = acc * dm;          // dP (w.r.t. the pre-dropout probabilities)
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {
-            const int j = i / dk, c = i % dk;
-            float acc = 0.f;
-            for (int t = 0; t < Tq; ++t) {
-                const float dm = drop ? drop[(((size_t)r * h + hd) * Tq + t) * Tk + j] : 1.f;
-                acc += sP[t * S1 + j] * dm * sdO[t * P1 + c];
-            }
-            sdV[j * P1 + c] += acc;
-        }
         // softmax backward per row: dS = P * (dP - sum_j P dP) * scale
-        for (int t = wid; t < Tq; t += nw) {
+        for (int lr = wid; lr < rows; lr += nw) {
             float s = 0.f;
-            for (int j = lane; j < Tk; j += 64) s += sP[t * S1 + j] * sdS[t * S1 + j];
+            for (int j = lane; j < Tk; j += 64) s += sP[lr * S1 + j] * sdS[lr * S1 + j];
             s = wave_sum(s);
-            for (int j = lane; j < Tk; j += 64) sdS[t * S1 + j] = sP[t * S1 + j] * (sdS[t * S1 + j] - s) * scale;
+            for (int j = lane; j < Tk; j += 64) sdS[lr * S1 + j] = sP[lr * S1 + j] * (sdS[lr * S1 + j] - s) * scale;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < Tq * dk; i += blockDim.x) {     // dQ = dS K
-            const int t = i / dk, c = i % dk;
+        for (int i = threadIdx.x; i < rows * dk; i += blockDim.x) {     // dQ = dS K
+            const int lr = i / dk, c = i % dk, gr = row0 + lr;
             float acc = 0.f;
-            for (int j = 0; j < Tk; ++j) acc += sdS[t * S1 + j] * sK[j * P1 + c];
-            dq[((size_t)r * Tq + t) * D + hd * dk + c] = acc;
+            for (int j = 0; j < Tk; ++j) acc += sdS[lr * S1 + j] * sK[j * P1 + c];
+            dq[((size_t)(kvr * q_per_kv + gr / Tq) * Tq + gr % Tq) * D + hd * dk + c] = acc;
         }
-        for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {     // dK += dS^T Q
+        for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {       // dK += dS^T Q ; dV += (P*drop)^T dO
             const int j = i / dk, c = i % dk;
-            float acc = 0.f;
-            for (int t = 0; t < Tq; ++t) acc += sdS[t * S1 + j] * sQ[t * P1 + c];
-            sdK[j * P1 + c] += acc;
+            float ak = 0.f, av = 0.f;
+            for (int lr = 0; lr < rows; ++lr) {
+                ak += sdS[lr * S1 + j] * sQ[lr * P1 + c];
+                av += sPd[lr * S1 + j] * sdO[lr * P1 + c];
+            }
+            sdK[j * P1 + c] += ak;
+            sdV[j * P1 + c] += av;
         }
     }
     __syncthreads();
@@ -358,7 +368,15 @@ int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, int 
     if (!q || !k || !v || !o || Nq <= 0 || q_per_kv <= 0 || Nq % q_per_kv || Tq <= 0 || Tk <= 0 || h <= 0 || dk <= 0)
         return CAPMI_EINVAL;
     if (mask && mask_tq != 1 && mask_tq != Tq) return CAPMI_EINVAL;
-    const size_t lds = ((size_t)2 * Tk * (dk + 1) + (size_t)Tq * (dk + 1) + (size_t)Tq * (Tk + 1)) * sizeof(float);
+    // query rows per pass: all q_per_kv * Tq of them when they fit in ~64 KB next to K/V (two workgroups per CU), else as many
+    // as do; K/V alone may take up to the full 160 KB
+    const int64_t fixed_f = (int64_t)2 * Tk * (dk + 1), per_f = (int64_t)(dk + 1) + (Tk + 1);
+    int CH = q_per_kv * Tq;
+    {
+        const int64_t budget = 64 * 1024 / 4, room = budget > fixed_f ? (budget - fixed_f) / per_f : 0;
+        if (CH > room) CH = (int)(room > 0 ? room : 1);
+    }
+    const size_t lds = (size_t)(fixed_f + (int64_t)CH * per_f) * sizeof(float);
     if (lds > 160 * 1024) return CAPMI_EINVAL;
     static bool attr_f = false;      // more than 64 KB of dynamic LDS needs the opt-in (36 regions x 64 dims already do in bwd)
     if (!attr_f) {
@@ -366,7 +384,7 @@ int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, int 
         attr_f = true;
     }
     hipLaunchKernelGGL(mha_fwd_kernel, dim3(Nq / q_per_kv, h), dim3(MHA_T), lds, (hipStream_t)stream, q, k, v, ldkv, kstride,
-                       mask, mask_tq, mask_per_q, causal, q_pos0, drop, o, p, q_per_kv, Tq, Tk, h, dk);
+                       mask, mask_tq, mask_per_q, causal, q_pos0, drop, o, p, q_per_kv, Tq, Tk, h, dk, CH);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -379,7 +397,13 @@ int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float 
     if (dkv_ld <= 0) dkv_ld = Tk * dkv_stride;
     if (!d_o || !q || !k || !v || !p || !dq || !dk_out || !dv_out || Nq <= 0 || q_per_kv <= 0 || Nq % q_per_kv)
         return CAPMI_EINVAL;
-    const size_t lds = ((size_t)4 * Tk * (dk + 1) + (size_t)2 * Tq * (dk + 1) + (size_t)2 * Tq * (Tk + 1)) * sizeof(float);
+    const int64_t fixed_b = (int64_t)4 * Tk * (dk + 1), per_b = (int64_t)2 * (dk + 1) + 3 * (Tk + 1);
+    int CH = q_per_kv * Tq;
+    {
+        const int64_t budget = 96 * 1024 / 4, room = budget > fixed_b ? (budget - fixed_b) / per_b : 0;
+        if (CH > room) CH = (int)(room > 0 ? room : 1);
+    }
+    const size_t lds = (size_t)(fixed_b + (int64_t)CH * per_b) * sizeof(float);
     if (lds > 160 * 1024) return CAPMI_EINVAL;
     static bool attr_b = false;
     if (!attr_b) {
@@ -387,7 +411,7 @@ int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float 
         attr_b = true;
     }
     hipLaunchKernelGGL(mha_bwd_kernel, dim3(Nq / q_per_kv, h), dim3(MHA_T), lds, (hipStream_t)stream, d_o, q, k, v, ldkv, kstride,
-                       p, drop, dq, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, q_per_kv, Tq, Tk, h, dk);
+                       p, drop, dq, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, q_per_kv, Tq, Tk, h, dk, CH);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

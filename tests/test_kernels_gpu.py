@@ -283,3 +283,55 @@ def test_colsum_bias_gradients(dev, rows, cols, accumulate):
     ref = x.double().sum(0) + (out.double() if accumulate else 0)
     ops.colsum(x, out, accumulate=accumulate)
     assert rel_err(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize('Nkv,q_per_kv,Tq,Tk,h,dk,mask_mode,causal,use_drop', [
+    (3, 1, 21, 21, 2, 64, 'per_q', 0, True),       # decoder self-attention (pad & causal mask per caption)
+    (3, 5, 21, 36, 8, 64, 'per_kv', 0, True),      # cross-attention, 5 captions share an image's K/V
+    (4, 5, 1, 36, 8, 128, 'per_kv', 0, False),     # AoA decode step: one query per caption
+    (2, 6, 21, 36, 2, 64, None, 0, True),          # 126 query rows per workgroup: more than one LDS pass (chunking)
+    (2, 1, 7, 7, 4, 16, None, 1, False),           # causal flag instead of a mask tensor
+])
+def test_mha_fwd_bwd_matches_torch(dev, Nkv, q_per_kv, Tq, Tk, h, dk, mask_mode, causal, use_drop):
+    """capmi_mha_fwd/bwd (MultiHeadedAttention, TransformerModel.py:152-195) vs a float64 torch restatement, all layouts the
+    engines use: K/V shared by q_per_kv query rows, per-query and per-kv masks, causal flag, attention dropout masks."""
+    from imagecaptioning.pytorch_amd.transformer_engine import mha_fwd, mha_bwd
+    g = torch.Generator().manual_seed(Nkv * 100 + Tq)
+    D, Nq = h * dk, Nkv * q_per_kv
+    q = torch.randn(Nq, Tq, D, generator=g)
+    k = torch.randn(Nkv, Tk, D, generator=g)
+    v = torch.randn(Nkv, Tk, D, generator=g)
+    d_o = torch.randn(Nq, Tq, D, generator=g)
+    mask = None
+    if mask_mode == 'per_q':
+        mask = (torch.rand(Nq, Tq, Tk, generator=g) > 0.3)
+        mask[..., 0] = True
+    elif mask_mode == 'per_kv':
+        mask = (torch.rand(Nkv, 1, Tk, generator=g) > 0.3)
+        mask[..., 0] = True
+    drop = ((torch.rand(Nq, h, Tq, Tk, generator=g) > 0.2).float() / 0.8) if use_drop else None
+
+    qd, kd, vd = (x.double().requires_grad_(True) for x in (q, k, v))
+    qh = qd.view(Nq, Tq, h, dk).transpose(1, 2)
+    kh = kd.view(Nkv, Tk, h, dk).transpose(1, 2).repeat_interleave(q_per_kv, 0)
+    vh = vd.view(Nkv, Tk, h, dk).transpose(1, 2).repeat_interleave(q_per_kv, 0)
+    sc = qh @ kh.transpose(-1, -2) / dk ** 0.5
+    if mask is not None:
+        m = mask if mask_mode == 'per_q' else mask.repeat_interleave(q_per_kv, 0)
+        sc = sc.masked_fill(~m.unsqueeze(1), float('-inf'))
+    if causal:
+        sc = sc.masked_fill(~torch.tril(torch.ones(Tq, Tk, dtype=torch.bool)), float('-inf'))
+    pw = torch.softmax(sc, -1)
+    out = ((pw * drop.double() if drop is not None else pw) @ vh).transpose(1, 2).reshape(Nq, Tq, D)
+    out.backward(d_o.double())
+
+    dv_ = lambda x: None if x is None else x.to(dev).contiguous()      # noqa: E731
+    m_d = None if mask is None else mask.to(torch.uint8).to(dev).contiguous()
+    o, p = mha_fwd(dv_(q), dv_(k), dv_(v), Tk * D, Nq, q_per_kv, Tq, Tk, h, mask=m_d, mask_tq=Tq if mask_mode == 'per_q' else 1,
+                   mask_per_q=1 if mask_mode == 'per_q' else 0, causal=causal, drop=dv_(drop))
+    assert rel_err(o.cpu().double(), out.detach()) < 2e-6
+    assert rel_err(p.cpu().double(), pw.detach()) < 2e-6
+    dq, dk_, dv2 = mha_bwd(dv_(d_o), dv_(q), dv_(k), dv_(v), Tk * D, p, dv_(drop), Nq, q_per_kv, Tq, Tk, h)
+    assert rel_err(dq.cpu().double(), qd.grad) < 5e-6
+    assert rel_err(dk_.cpu().double(), kd.grad) < 5e-6
+    assert rel_err(dv2.cpu().double(), vd.grad) < 5e-6
