@@ -24,7 +24,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # the host driver only supports dmabuf IPC (RCCL needs it)
+
+import torch                                                # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -124,6 +126,10 @@ def main():
         # nccl == RCCL on ROCm (xGMI).  CAPMI_DIST_BACKEND=gloo only exists to exercise the multi-process path on a
         # single-GPU box (two ranks sharing cuda:0), never for measurements.
         dist.init_process_group(os.environ.get('CAPMI_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
+        if dist.get_backend() == 'nccl':
+            # create the RCCL communicator here, on the main thread: the first gradient bucket is otherwise reduced from
+            # inside autograd's backward thread
+            dist.barrier(device_ids=[local])
 
     from imagecaptioning.pytorch_amd import synthetic, _lib
     from imagecaptioning.pytorch_amd.captioning import models

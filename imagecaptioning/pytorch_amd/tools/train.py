@@ -50,6 +50,7 @@ def train(opt):
     dev = torch.device('cuda', local)
     if world > 1:
         dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.barrier(device_ids=[local])              # RCCL communicator created on the main thread, before any backward
     if not opt.input_synthetic:
         raise SystemExit('only --input_synthetic 1 is available: the h5/lmdb loaders of the reference are outside the hot path')
     opt.seed = opt.seed + rank                        # each rank draws its own images
