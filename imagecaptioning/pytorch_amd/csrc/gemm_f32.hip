@@ -519,8 +519,6 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     dim3 grid(gn, gm, splits);
     const ProfInfo pi{pcls, bytes, flops};
     int rc;
-    static const int env_pf = [] { const char *e = getenv("CAPMI_GEMM_PF"); return e ? atoi(e) : 3; }();
-    (void)env_pf;
     if (x3_ok) rc = launch_x3(a, d->a_layout, d->b_layout, grid, st, pcls, bytes, flops);
     else if (BM == 32 && BN == 128) rc = launch_cfg<32, 128, 1, 4, 3>(a, d->a_layout, d->b_layout, grid, st, pi);
     else if (BM == 64 && BN == 64) rc = launch_cfg<64, 64, 2, 2, 3>(a, d->a_layout, d->b_layout, grid, st, pi);
