@@ -191,3 +191,80 @@ def test_sampling_with_constraints_never_repeats_a_token():
     rep = (s[:, 1:] == s[:, :-1]) & (s[:, 1:] != 0)
     assert not rep.any()
     assert len(torch.unique(s, dim=0)) > 8                       # genuinely sampled
+
+
+def _full_size_model_and_oracle(B):
+    """UpDown at the BASELINE sizes (R=E=1000, A=512, V1=9488, K=36, L=20) with random weights, on both sides."""
+    import argparse
+    from imagecaptioning.pytorch_amd.captioning import models
+    from oracle import att_lstm as O
+    from test_updown_gpu import full_size_params
+    P = full_size_params(seed=5)
+    V = 9487
+    vocab = {str(i): 'w%d' % i for i in range(1, V + 1)}
+    opt = argparse.Namespace(caption_model='updown', vocab_size=V, input_encoding_size=1000, rnn_size=1000, num_layers=1,
+                             drop_prob_lm=0.5, seq_length=20, max_length=20, fc_feat_size=2048, att_feat_size=2048, att_hid_size=512,
+                             use_bn=0, logit_layers=1, vocab=vocab)
+    model = models.setup(opt)
+    model.load_state_dict(P)
+    model = model.to(DEV).eval()
+    g = torch.Generator().manual_seed(8)
+    fc = (torch.randn(B, 2048, generator=g) * 0.5).clamp_min(0)
+    att = (torch.randn(B, 36, 2048, generator=g) * 0.5).clamp_min(0)
+    feats = O.prepare_feature(P, fc, att, None)
+
+    def stepper(n):
+        f = O.repeat_rows(n, *feats) if n > 1 else feats
+        return lambda it, state: O.updown_step(P, it, f[0], f[1], f[2], f[3], state)
+    return model, P, fc, att, stepper, O
+
+
+def test_full_size_constrained_greedy_and_diverse_sample_vs_oracle():
+    """decoding_constraint + block_trigrams + remove_bad_endings in AttModel._sample and a 3-group _diverse_sample at the
+    BASELINE sizes: tokens exact, log-probs to 1e-4 against oracle/decode_opts.py (itself pinned to the reference)."""
+    from oracle import decode_opts as D
+    B, L, V1 = 4, 20, 9488
+    model, P, fc, att, stepper, O = _full_size_model_and_oracle(B)
+    with torch.no_grad():
+        plain, _ = model(fc.to(DEV), att.to(DEV), None, opt={'sample_method': 'greedy'}, mode='sample')
+    bad = sorted({int(w) for row in plain.cpu().tolist() for w in row[:3] if w > 0})       # words the decode really uses
+    model.bad_endings_ix = bad
+    kw = dict(decoding_constraint=1, remove_bad_endings=1, block_trigrams=1)
+    with torch.no_grad():
+        want_seq, want_lp = D.constrained_sample(stepper(1), O.zero_state(P, B), B, B, V1, L, bad_endings=bad, **kw)
+        seq, lp = model(fc.to(DEV), att.to(DEV), None, opt=dict(sample_method='greedy', **kw), mode='sample')
+    assert torch.equal(seq.cpu(), want_seq)
+    got, want = lp.cpu(), want_lp
+    assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.isneginf(got), torch.isneginf(want))
+    fin = torch.isfinite(want)
+    assert float((got[fin] - want[fin]).abs().max()) < 1e-4
+    with torch.no_grad():
+        want_seq, want_lp = D.diverse_sample(stepper(1), lambda: O.zero_state(P, B), B, V1, L, 3, diversity_lambda=0.7,
+                                             decoding_constraint=1)
+        seq, lp = model(fc.to(DEV), att.to(DEV), None, opt=dict(sample_method='greedy', group_size=3, diversity_lambda=0.7,
+                                                              decoding_constraint=1), mode='sample')
+    assert torch.equal(seq.cpu(), want_seq)
+    assert float((lp.cpu() - want_lp).abs().max()) < 1e-4
+    assert len({tuple(r) for r in seq.cpu().tolist()}) > B           # the groups really differ
+
+
+def test_full_size_diverse_beam_search_vs_oracle():
+    """Diverse beam search (beam 6 = 3 groups x 2, lambda 0.5, decoding_constraint) at the BASELINE sizes vs the oracle:
+    every finished beam's tokens, score and un-augmented score."""
+    from oracle import decode_opts as D
+    B, L, V1 = 2, 20, 9488
+    model, P, fc, att, stepper, O = _full_size_model_and_oracle(B)
+    kw = dict(beam_size=6, group_size=3, diversity_lambda=0.5, decoding_constraint=1)
+    with torch.no_grad():
+        logp0, state = stepper(1)(torch.zeros(B, dtype=torch.long), O.zero_state(P, B))
+        want_seq, want_lp, want_done = D.beam_search(stepper(2), state, logp0, V1, L, unk_col=None, **kw)
+        seq, lp = model(fc.to(DEV), att.to(DEV), None, opt=dict(sample_method='beam_search', sample_n=1, suppress_UNK=0, **kw),
+                        mode='sample')
+    assert torch.equal(seq.cpu(), want_seq)
+    fin = torch.isfinite(want_lp)
+    assert torch.equal(torch.isfinite(lp.cpu()), fin) and float((lp.cpu()[fin] - want_lp[fin]).abs().max()) < 1e-4
+    for k in range(B):
+        assert len(model.done_beams[k]) == len(want_done[k]) == 6
+        for a, b in zip(model.done_beams[k], want_done[k]):
+            assert torch.equal(a['seq'].cpu(), b['seq'])
+            assert abs(a['p'] - b['p']) < 1e-3
