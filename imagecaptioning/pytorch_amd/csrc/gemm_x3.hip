@@ -81,45 +81,41 @@ struct Stager {
             kq0 = 4 * kg;
         }
     }
-    __device__ __forceinline__ void fetch(float (&r)[16], int k0) const {
-        const bool interior = !edge_rows && k0 + BK <= K;      // workgroup-uniform
+    // ONE straight-line path with a fixed number of loads (4 per operand): tiles in the interior of the operand take the
+    // same clamps (all zero) and keep-factors (all one) as edge tiles.  Any branch around a load -- even a workgroup-uniform
+    // interior/edge one -- makes the number of YOUNGER loads in flight unknown to the compiler at the point where an
+    // older register set is consumed, and it then waits with s_waitcnt vmcnt(0): the 2-tile prefetch distance of the
+    // staging pipeline collapsed to "wait for everything", i.e. one exposed HBM latency per K tile.
+    // r: the raw 16 floats; f: the factor (1 = keep, 0 = out of range) of quad p (KC) / of k row j (k-major).  The factors
+    // are applied when the registers are SPLIT (x3_r2s), not here: touching a loaded value at fetch time would park the
+    // wave on that load and there would be no prefetch at all.
+    // Returns (workgroup-uniform) whether any factor can be 0, so that interior tiles skip the multiplies.
+    __device__ __forceinline__ bool fetch(float (&r)[16], float (&f)[4], int k0) const {
         if (KC) {
-            if (interior) {
-                gcb b = src + (size_t)k0 * 4;
+            const int over = max(k0 + kq0 - (K - 4), 0);              // clamp this thread's quads to K-4
+            const float kk = (k0 + kq0 < K) ? 1.f : 0.f;
+            gcb b = src + (size_t)(k0 - over) * 4;
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const f32x4 v = *(gcf4)(b + voff[p]);
-                    r[4 * p] = v[0]; r[4 * p + 1] = v[1]; r[4 * p + 2] = v[2]; r[4 * p + 3] = v[3];
-                }
-            } else {
-                const int over = max(k0 + kq0 - (K - 4), 0);              // clamp this thread's quads to K-4
-                const float kk = (k0 + kq0 < K) ? 1.f : 0.f;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const f32x4 v = *(gcf4)(src + (size_t)(k0 - over) * 4 + voff[p]);
-                    const float kp = kk * keep[p];
-                    r[4 * p] = v[0] * kp; r[4 * p + 1] = v[1] * kp; r[4 * p + 2] = v[2] * kp; r[4 * p + 3] = v[3] * kp;
-                }
+            for (int p = 0; p < 4; ++p) {
+                const f32x4 v = *(gcf4)(b + voff[p]);
+                f[p] = kk * keep[p];
+                r[4 * p] = v[0]; r[4 * p + 1] = v[1]; r[4 * p + 2] = v[2]; r[4 * p + 3] = v[3];
             }
         } else {
             f32x4 v[4];
-            if (interior) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = *(gcf4)(src + (size_t)(k0 + j) * ld * 4 + voff[0]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = k0 + kq0 + j;
-                    const int back = max(k - (K - 1), 0);                 // clamp the k row to K-1
-                    v[j] = *(gcf4)(src + ((size_t)(k0 + j) - back) * ld * 4 + voff[0]);
-                    v[j] *= (k < K ? keep[0] : 0.f);
-                }
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + kq0 + j;
+                const int back = max(k - (K - 1), 0);                 // clamp the k row to K-1
+                v[j] = *(gcf4)(src + ((size_t)(k0 + j) - back) * ld * 4 + voff[0]);
+                f[j] = k < K ? keep[0] : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) r[4 * i + j] = v[j][i];       // quad i = row 4mq+i, k = 4kg..4kg+3
         }
+        return edge_rows || k0 + BK > K;
     }
 };
 
@@ -128,8 +124,8 @@ __device__ __forceinline__ float bfloat(uint32_t b) { return __builtin_bit_cast(
 __device__ __forceinline__ uint32_t pack2(uint32_t lo, uint32_t hi) { return (lo >> 16) | (hi & 0xffff0000u); }
 
 // registers -> three bf16 planes in LDS
-template <bool KC>
-__device__ __forceinline__ void x3_r2s(const float (&r)[16], unsigned short *dst, int tid) {
+template <bool KC, bool EDGE>
+__device__ __forceinline__ void x3_r2s(const float (&r)[16], const float (&f)[4], unsigned short *dst, int tid) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         int row, kq;
@@ -145,7 +141,7 @@ __device__ __forceinline__ void x3_r2s(const float (&r)[16], unsigned short *dst
         uint32_t h[4], m[4], l[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float x = r[4 * p + j];
+            const float x = EDGE ? r[4 * p + j] * (KC ? f[p] : f[j]) : r[4 * p + j];   // out-of-range rows / k -> 0
             h[j] = fbits(x) & 0xffff0000u;
             const float r1 = x - bfloat(h[j]);            // exact
             m[j] = fbits(r1) & 0xffff0000u;
@@ -189,7 +185,9 @@ __device__ __forceinline__ Unit unit_of(const KArgs &a, int u, int gm, int gn) {
     return r;
 }
 
-template <bool AKC, bool BKC>
+// ABL: compile-time ablations for profiling (CAPMI_GEMM_ABLATE, [K][rows] x [K][rows] shapes only): 1 no MFMAs, 2 no global
+// fetch, 4 no split/store.  Compile-time because a run-time test around the loads costs the exact vmcnt waits.
+template <bool AKC, bool BKC, int ABL = 0>
 __global__ __launch_bounds__(XNT) void gemm_x3_kernel(const KArgs a, int gm, int gn) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];      // 2 stages = 120 KB
     const int units = gm * gn * a.splits;
@@ -199,6 +197,8 @@ __global__ __launch_bounds__(XNT) void gemm_x3_kernel(const KArgs a, int gm, int
         // ---------------- staging waves ----------------
         const int tid = threadIdx.x - NT;
         float ra0[16], rb0[16], ra1[16], rb1[16];          // pipeline step g lives in register set g & 1
+        float fa0[4], fb0[4], fa1[4], fb1[4];              // ... with its keep-factors
+        bool e0 = false, e1 = false;                       // ... and whether any of them can be zero (workgroup-uniform)
         // K segments ([h | x | ...] x [W slices]) are walked in place.  The segment of a K tile is workgroup-uniform; its
         // fields are picked with STATIC indices behind a uniform switch (a dynamically indexed kernel-argument table
         // would be copied to scratch), and the per-lane offsets are rebuilt only when the segment or the unit changes.
@@ -225,17 +225,24 @@ __global__ __launch_bounds__(XNT) void gemm_x3_kernel(const KArgs a, int gm, int
             const Unit un = unit_of(a, fu, gm, gn);
             f_t0 = un.t_begin; f_nt = un.nt; f_m0 = un.m0; f_n0 = un.n0;
         }
-        auto fetch = [&](float (&xa)[16], float (&xb)[16]) {
-            if (fu >= units) return;
-            int sidx, k0;
-            locate(a, f_t0 + ft, sidx, k0);
-            sidx = __builtin_amdgcn_readfirstlane(sidx);
-            if (sidx != cur_seg || f_m0 != cur_m0 || f_n0 != cur_n0) bind(sidx, f_m0, f_n0);
-            if (!(a.ablate & 2)) {
-                sa.fetch(xa, k0);
-                sb.fetch(xb, k0);
+        // Every call issues exactly the same loads (see Stager::fetch); past the last unit the cursor stays on the last
+        // tile and the (few) extra fetches are thrown away.
+        int last_k0 = 0;
+        auto fetch = [&](float (&xa)[16], float (&xb)[16], float (&ya)[4], float (&yb)[4], bool &edge) {
+            const bool live = fu < units;                  // workgroup-uniform
+            if (live) {
+                int sidx, k0;
+                locate(a, f_t0 + ft, sidx, k0);
+                sidx = __builtin_amdgcn_readfirstlane(sidx);
+                if (sidx != cur_seg || f_m0 != cur_m0 || f_n0 != cur_n0) bind(sidx, f_m0, f_n0);
+                last_k0 = k0;
             }
-            if (++ft == f_nt) {
+            if (!(ABL & 2)) {
+                const bool ea = sa.fetch(xa, ya, last_k0);
+                const bool eb = sb.fetch(xb, yb, last_k0);
+                edge = ea || eb;
+            }
+            if (live && ++ft == f_nt) {
                 fu += gridDim.x;
                 ft = 0;
                 if (fu < units) {
@@ -246,27 +253,37 @@ __global__ __launch_bounds__(XNT) void gemm_x3_kernel(const KArgs a, int gm, int
         };
         int steps = 0;
         for (int u = blockIdx.x; u < units; u += gridDim.x) steps += unit_of(a, u, gm, gn).nt;
-        auto store = [&](const float (&xa)[16], const float (&xb)[16], int g) {
-            if (a.ablate & 4) return;
+        // the interior/edge branch sits HERE, around VALU + LDS work only (a branch around the loads would cost the exact waits)
+        auto store = [&](const float (&xa)[16], const float (&xb)[16], const float (&ya)[4], const float (&yb)[4], bool edge, int g) {
+            if (ABL & 4) return;
             unsigned short *st = smem + (g & 1) * XSTAGE;
-            x3_r2s<AKC>(xa, st, tid);
-            x3_r2s<BKC>(xb, st + 3 * XPLANE, tid);
-        };
-        fetch(ra0, rb0);                                   // step 0
-        fetch(ra1, rb1);                                   // step 1
-        if (steps > 0) store(ra0, rb0, 0);
-        fetch(ra0, rb0);                                   // step 2
-        __syncthreads();                                   // stage 0 ready
-        // while the MFMA waves consume step g (stage g&1) we publish step g+1 and fetch step g+3 into its registers
-        for (int g = 0; g < steps; g += 2) {
-            if (g + 1 < steps) store(ra1, rb1, g + 1);
-            fetch(ra1, rb1);
-            __syncthreads();
-            if (g + 1 < steps) {
-                if (g + 2 < steps) store(ra0, rb0, g + 2);
-                fetch(ra0, rb0);
-                __syncthreads();
+            if (edge) {
+                x3_r2s<AKC, true>(xa, ya, st, tid);
+                x3_r2s<BKC, true>(xb, yb, st + 3 * XPLANE, tid);
+            } else {
+                x3_r2s<AKC, false>(xa, ya, st, tid);
+                x3_r2s<BKC, false>(xb, yb, st + 3 * XPLANE, tid);
             }
+        };
+        // Two register sets alternate: while the MFMA waves consume step g (stage g&1) the staging waves publish step g+1 and
+        // fetch step g+3 into the registers step g+1 just left.  The fetches are unconditional (fixed load count per
+        // half-iteration, see Stager::fetch), only stores and barriers are guarded, so the compiler waits with exact
+        // s_waitcnt vmcnt(8..15) for the OLDER set while the younger set's loads stay in flight.  (A third set in flight
+        // changed nothing: with the MFMAs ablated the staging side runs at the operand delivery rate, 5.4 TB/s of
+        // mostly-L2 traffic for the dW GEMM, whatever the depth.)
+        fetch(ra0, rb0, fa0, fb0, e0);                     // step 0
+        fetch(ra1, rb1, fa1, fb1, e1);                     // step 1
+        if (steps > 0) store(ra0, rb0, fa0, fb0, e0, 0);
+        fetch(ra0, rb0, fa0, fb0, e0);                     // step 2
+        __syncthreads();                                   // stage 0 ready
+        for (int g = 0; g < steps; g += 2) {
+            if (g + 1 < steps) store(ra1, rb1, fa1, fb1, e1, g + 1);
+            fetch(ra1, rb1, fa1, fb1, e1);
+            __syncthreads();
+            const bool second = g + 1 < steps;
+            if (second && g + 2 < steps) store(ra0, rb0, fa0, fb0, e0, g + 2);
+            fetch(ra0, rb0, fa0, fb0, e0);
+            if (second) __syncthreads();
         }
         return;
     }
@@ -287,7 +304,7 @@ __global__ __launch_bounds__(XNT) void gemm_x3_kernel(const KArgs a, int gm, int
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int i = 0; i < un.nt; ++i, ++g) {
             const unsigned short *As = smem + (g & 1) * XSTAGE, *Bs = As + 3 * XPLANE;
-            if (!(a.ablate & 1))
+            if (!(ABL & 1))
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 av[2][3], bv[2][3];
@@ -383,6 +400,24 @@ int launch_x3(const KArgs &a, int a_layout, int b_layout, dim3 tiles, hipStream_
         if (prof) hipExtLaunchKernelGGL((gemm_x3_kernel<AK, BK_>), grid, dim3(XNT), lds, st, e0, e1, 0, a, gm, gn);     \
         else hipLaunchKernelGGL((gemm_x3_kernel<AK, BK_>), grid, dim3(XNT), lds, st, a, gm, gn);                        \
     } while (0)
+#define CAPMI_X3A(ABL_)                                                                                         \
+    do {                                                                                                        \
+        static bool attr_set = false;                                                                           \
+        if (!attr_set) {                                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_x3_kernel<false, false, ABL_>),      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+            attr_set = true;                                                                                    \
+        }                                                                                                       \
+        hipLaunchKernelGGL((gemm_x3_kernel<false, false, ABL_>), grid, dim3(XNT), lds, st, a, gm, gn);          \
+    } while (0)
+    if (a.ablate && a_layout == 1 && b_layout == 1) {
+        if (a.ablate == 1) CAPMI_X3A(1);
+        else if (a.ablate == 2) CAPMI_X3A(2);
+        else if (a.ablate == 4) CAPMI_X3A(4);
+        else CAPMI_X3A(6);
+        CAPMI_CHECK_LAUNCH();
+        return 0;
+    }
     if (a_layout == 0 && b_layout == 0) CAPMI_X3(true, true);
     else if (a_layout == 0 && b_layout == 1) CAPMI_X3(true, false);
     else if (a_layout == 1 && b_layout == 1) CAPMI_X3(false, false);
