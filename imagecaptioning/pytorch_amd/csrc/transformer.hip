@@ -72,39 +72,47 @@ constexpr int MHA_T = 256;
 // q_per_kv * Tq query rows that attend to it.  The query rows are flattened (caption-major) and processed CH at a time --
 // as many as fit in LDS next to K/V, normally all of them -- so a decode step (Tq = 1, 5 captions per image) or a
 // cross-attention (5 x 21 rows per image) is ONE pass of four block-wide phases instead of q_per_kv sequential passes.
-// LDS: K [Tk][dk+1], V [Tk][dk+1], Q [CH][dk+1], S [CH][Tk+1]  (+1: conflict-free column walks)
+// Every inner product runs on 16-byte LDS reads along the head dimension (dk % 4 == 0, row pitch dk + 4 floats: the
+// 16 lanes of a ds_read_b128 phase hit 64 distinct banks), i.e. 2 LDS instructions per 4 FMAs instead of 8; the
+// phases of these short-sequence kernels are LDS-instruction bound.
+// LDS: K [Tk][dk+4], V [Tk][dk+4], Q [CH][dk+4], S [CH][Tk+1]
+__device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+#define LDS4(p) (*reinterpret_cast<const f32x4 *>(p))
+
 __global__ __launch_bounds__(MHA_T) void mha_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                        const float *__restrict__ v, int ldkv, int kstride,
                                                        const uint8_t *__restrict__ mask, int mask_tq, int mask_per_q,
                                                        int causal, int q_pos0, const float *__restrict__ drop,
                                                        float *__restrict__ o, float *__restrict__ p, int q_per_kv, int Tq,
                                                        int Tk, int h, int dk, int CH) {
-    extern __shared__ float lds[];
-    const int D = h * dk, P1 = dk + 1, S1 = Tk + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int D = h * dk, P1 = dk + 4, S1 = Tk + 1, d4 = dk >> 2;
     float *sK = lds, *sV = sK + Tk * P1, *sQ = sV + Tk * P1, *sS = sQ + CH * P1;
     const int kvr = blockIdx.x, hd = blockIdx.y;
     const float scale = rsqrtf((float)dk);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {
-        const int j = i / dk, c = i % dk;
-        sK[j * P1 + c] = k[(size_t)kvr * ldkv + (size_t)j * kstride + hd * dk + c];
-        sV[j * P1 + c] = v[(size_t)kvr * ldkv + (size_t)j * kstride + hd * dk + c];
+    for (int i = threadIdx.x; i < Tk * d4; i += blockDim.x) {
+        const int j = i / d4, c = (i - j * d4) * 4;
+        const size_t gi = (size_t)kvr * ldkv + (size_t)j * kstride + hd * dk + c;
+        *reinterpret_cast<f32x4 *>(sK + j * P1 + c) = *reinterpret_cast<const f32x4 *>(k + gi);
+        *reinterpret_cast<f32x4 *>(sV + j * P1 + c) = *reinterpret_cast<const f32x4 *>(v + gi);
     }
     const int R_all = q_per_kv * Tq;
     for (int row0 = 0; row0 < R_all; row0 += CH) {
         const int rows = min(CH, R_all - row0);
         __syncthreads();                    // K/V staged (first trip); the previous chunk's readers are done
-        for (int i = threadIdx.x; i < rows * dk; i += blockDim.x) {
-            const int lr = i / dk, c = i % dk, gr = row0 + lr;
+        for (int i = threadIdx.x; i < rows * d4; i += blockDim.x) {
+            const int lr = i / d4, c = (i - lr * d4) * 4, gr = row0 + lr;
             const int r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
-            sQ[lr * P1 + c] = q[((size_t)r * Tq + t) * D + hd * dk + c];
+            *reinterpret_cast<f32x4 *>(sQ + lr * P1 + c) = *reinterpret_cast<const f32x4 *>(q + ((size_t)r * Tq + t) * D + hd * dk + c);
         }
         __syncthreads();
         for (int i = threadIdx.x; i < rows * Tk; i += blockDim.x) {
-            const int lr = i / Tk, j = i % Tk, gr = row0 + lr;
+            const int lr = i / Tk, j = i - lr * Tk, gr = row0 + lr;
             const int r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
+            const float *qa = sQ + lr * P1, *ka = sK + j * P1;
             float s = 0.f;
-            for (int c = 0; c < dk; ++c) s += sQ[lr * P1 + c] * sK[j * P1 + c];
+            for (int c = 0; c < dk; c += 4) s += dot4(LDS4(qa + c), LDS4(ka + c));
             s *= scale;
             bool ok = true;
             if (mask) ok = mask[((size_t)(mask_per_q ? r : kvr) * mask_tq + (mask_tq > 1 ? t : 0)) * Tk + j] != 0;
@@ -136,18 +144,19 @@ __global__ __launch_bounds__(MHA_T) void mha_fwd_kernel(const float *__restrict_
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < rows * dk; i += blockDim.x) {
-            const int lr = i / dk, c = i % dk, gr = row0 + lr;
+        for (int i = threadIdx.x; i < rows * d4; i += blockDim.x) {      // o = P V: 4 head columns per thread
+            const int lr = i / d4, c = (i - lr * d4) * 4, gr = row0 + lr;
             const int r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
-            float acc = 0.f;
-            for (int j = 0; j < Tk; ++j) acc += sS[lr * S1 + j] * sV[j * P1 + c];
-            o[((size_t)r * Tq + t) * D + hd * dk + c] = acc;
+            const float *pr = sS + lr * S1;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < Tk; ++j) acc += pr[j] * LDS4(sV + j * P1 + c);
+            *reinterpret_cast<f32x4 *>(o + ((size_t)r * Tq + t) * D + hd * dk + c) = acc;
         }
     }
 }
 
 // backward, same decomposition; dK/dV accumulate over the chunks in LDS and are written once.
-// LDS: K, V, dK, dV [Tk][dk+1]; Q, dO [CH][dk+1]; P, P*drop, dS [CH][Tk+1]
+// LDS: K, V, dK, dV [Tk][dk+4]; Q, dO [CH][dk+4]; P, P*drop, dS [CH][Tk+1]
 __global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict__ d_o, const float *__restrict__ q,
                                                        const float *__restrict__ k, const float *__restrict__ v, int ldkv,
                                                        int kstride, const float *__restrict__ p,
@@ -155,46 +164,49 @@ __global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict_
                                                        float *__restrict__ dk_out, float *__restrict__ dv_out, int dkv_ld,
                                                        int dkv_stride, int accumulate, int q_per_kv, int Tq, int Tk, int h,
                                                        int dk, int CH) {
-    extern __shared__ float lds[];
-    const int D = h * dk, P1 = dk + 1, S1 = Tk + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int D = h * dk, P1 = dk + 4, S1 = Tk + 1, d4 = dk >> 2;
     float *sK = lds, *sV = sK + Tk * P1, *sdK = sV + Tk * P1, *sdV = sdK + Tk * P1;
     float *sQ = sdV + Tk * P1, *sdO = sQ + CH * P1, *sP = sdO + CH * P1, *sPd = sP + CH * S1, *sdS = sPd + CH * S1;
     const int kvr = blockIdx.x, hd = blockIdx.y;
     const float scale = rsqrtf((float)dk);
-    for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {
-        const int j = i / dk, c = i % dk;
-        sK[j * P1 + c] = k[(size_t)kvr * ldkv + (size_t)j * kstride + hd * dk + c];
-        sV[j * P1 + c] = v[(size_t)kvr * ldkv + (size_t)j * kstride + hd * dk + c];
-        sdK[j * P1 + c] = 0.f;
-        sdV[j * P1 + c] = 0.f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < Tk * d4; i += blockDim.x) {
+        const int j = i / d4, c = (i - j * d4) * 4;
+        const size_t gi = (size_t)kvr * ldkv + (size_t)j * kstride + hd * dk + c;
+        *reinterpret_cast<f32x4 *>(sK + j * P1 + c) = *reinterpret_cast<const f32x4 *>(k + gi);
+        *reinterpret_cast<f32x4 *>(sV + j * P1 + c) = *reinterpret_cast<const f32x4 *>(v + gi);
+        *reinterpret_cast<f32x4 *>(sdK + j * P1 + c) = zero4;
+        *reinterpret_cast<f32x4 *>(sdV + j * P1 + c) = zero4;
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int R_all = q_per_kv * Tq;
     for (int row0 = 0; row0 < R_all; row0 += CH) {
         const int rows = min(CH, R_all - row0);
         __syncthreads();
-        for (int i = threadIdx.x; i < rows * dk; i += blockDim.x) {
-            const int lr = i / dk, c = i % dk, gr = row0 + lr;
+        for (int i = threadIdx.x; i < rows * d4; i += blockDim.x) {
+            const int lr = i / d4, c = (i - lr * d4) * 4, gr = row0 + lr;
             const size_t gi = ((size_t)(kvr * q_per_kv + gr / Tq) * Tq + gr % Tq) * D + hd * dk + c;
-            sQ[lr * P1 + c] = q[gi];
-            sdO[lr * P1 + c] = d_o[gi];
+            *reinterpret_cast<f32x4 *>(sQ + lr * P1 + c) = *reinterpret_cast<const f32x4 *>(q + gi);
+            *reinterpret_cast<f32x4 *>(sdO + lr * P1 + c) = *reinterpret_cast<const f32x4 *>(d_o + gi);
         }
         for (int i = threadIdx.x; i < rows * Tk; i += blockDim.x) {
-            const int lr = i / Tk, j = i % Tk, gr = row0 + lr;
+            const int lr = i / Tk, j = i - lr * Tk, gr = row0 + lr;
             const size_t pi = (((size_t)(kvr * q_per_kv + gr / Tq) * h + hd) * Tq + gr % Tq) * Tk + j;
             const float pr = p[pi];
+            const float dm = drop ? drop[pi] : 1.f;
             sP[lr * S1 + j] = pr;
-            sPd[lr * S1 + j] = drop ? pr * drop[pi] : pr;
+            sPd[lr * S1 + j] = pr * dm;
+            sdS[lr * S1 + j] = dm;               // parked here until dP is formed below
         }
         __syncthreads();
         // dP_drop = dO V^T ; dP = dP_drop * drop
         for (int i = threadIdx.x; i < rows * Tk; i += blockDim.x) {
-            const int lr = i / Tk, j = i % Tk, gr = row0 + lr;
+            const int lr = i / Tk, j = i - lr * Tk;
+            const float *da = sdO + lr * P1, *va = sV + j * P1;
             float acc = 0.f;
-            for (int c = 0; c < dk; ++c) acc += sdO[lr * P1 + c] * sV[j * P1 + c];
-            float dm = 1.f;
-            if (drop) dm = drop[(((size_t)(kvr * q_per_kv + gr / Tq) * h + hd) * Tq + gr % Tq) * Tk + j];
-            sdS[lr * S1 + j] = acc * dm;          // dP (w.r.t. the pre-dropout probabilities)
+            for (int c = 0; c < dk; c += 4) acc += dot4(LDS4(da + c), LDS4(va + c));
+            sdS[lr * S1 + j] *= acc;             // dP (w.r.t. the pre-dropout probabilities)
         }
         __syncthreads();
         // softmax backward per row: dS = P * (dP - sum_j P dP) * scale
@@ -205,36 +217,38 @@ __global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict_
             for (int j = lane; j < Tk; j += 64) sdS[lr * S1 + j] = sP[lr * S1 + j] * (sdS[lr * S1 + j] - s) * scale;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < rows * dk; i += blockDim.x) {     // dQ = dS K
-            const int lr = i / dk, c = i % dk, gr = row0 + lr;
-            float acc = 0.f;
-            for (int j = 0; j < Tk; ++j) acc += sdS[lr * S1 + j] * sK[j * P1 + c];
-            dq[((size_t)(kvr * q_per_kv + gr / Tq) * Tq + gr % Tq) * D + hd * dk + c] = acc;
+        for (int i = threadIdx.x; i < rows * d4; i += blockDim.x) {     // dQ = dS K: 4 head columns per thread
+            const int lr = i / d4, c = (i - lr * d4) * 4, gr = row0 + lr;
+            const float *ds = sdS + lr * S1;
+            f32x4 acc = zero4;
+            for (int j = 0; j < Tk; ++j) acc += ds[j] * LDS4(sK + j * P1 + c);
+            *reinterpret_cast<f32x4 *>(dq + ((size_t)(kvr * q_per_kv + gr / Tq) * Tq + gr % Tq) * D + hd * dk + c) = acc;
         }
-        for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {       // dK += dS^T Q ; dV += (P*drop)^T dO
-            const int j = i / dk, c = i % dk;
-            float ak = 0.f, av = 0.f;
+        for (int i = threadIdx.x; i < Tk * d4; i += blockDim.x) {       // dK += dS^T Q ; dV += (P*drop)^T dO
+            const int j = i / d4, c = (i - j * d4) * 4;
+            f32x4 ak = zero4, av = zero4;
             for (int lr = 0; lr < rows; ++lr) {
-                ak += sdS[lr * S1 + j] * sQ[lr * P1 + c];
-                av += sPd[lr * S1 + j] * sdO[lr * P1 + c];
+                ak += sdS[lr * S1 + j] * LDS4(sQ + lr * P1 + c);
+                av += sPd[lr * S1 + j] * LDS4(sdO + lr * P1 + c);
             }
-            sdK[j * P1 + c] += ak;
-            sdV[j * P1 + c] += av;
+            *reinterpret_cast<f32x4 *>(sdK + j * P1 + c) += ak;
+            *reinterpret_cast<f32x4 *>(sdV + j * P1 + c) += av;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < Tk * dk; i += blockDim.x) {
-        const int j = i / dk, c = i % dk;
+    for (int i = threadIdx.x; i < Tk * d4; i += blockDim.x) {
+        const int j = i / d4, c = (i - j * d4) * 4;
         const size_t oi = (size_t)kvr * dkv_ld + (size_t)j * dkv_stride + hd * dk + c;
+        f32x4 gk = LDS4(sdK + j * P1 + c), gv = LDS4(sdV + j * P1 + c);
         if (accumulate) {
-            dk_out[oi] += sdK[j * P1 + c];
-            dv_out[oi] += sdV[j * P1 + c];
-        } else {
-            dk_out[oi] = sdK[j * P1 + c];
-            dv_out[oi] = sdV[j * P1 + c];
+            gk += *reinterpret_cast<const f32x4 *>(dk_out + oi);
+            gv += *reinterpret_cast<const f32x4 *>(dv_out + oi);
         }
+        *reinterpret_cast<f32x4 *>(dk_out + oi) = gk;
+        *reinterpret_cast<f32x4 *>(dv_out + oi) = gv;
     }
 }
+#undef LDS4
 
 __global__ void embed_pe_fwd_kernel(const int64_t *__restrict__ tok, int tok_ld, const float *__restrict__ E,
                                     const float *__restrict__ pe, const float *__restrict__ drop, float *__restrict__ x,
@@ -368,9 +382,13 @@ int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, int 
     if (!q || !k || !v || !o || Nq <= 0 || q_per_kv <= 0 || Nq % q_per_kv || Tq <= 0 || Tk <= 0 || h <= 0 || dk <= 0)
         return CAPMI_EINVAL;
     if (mask && mask_tq != 1 && mask_tq != Tq) return CAPMI_EINVAL;
+    // 16-byte accesses along the head dimension
+    if (dk % 4 || ldkv % 4 || kstride % 4 || ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
+                                                reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(o)) & 15))
+        return CAPMI_EINVAL;
     // query rows per pass: all q_per_kv * Tq of them when they fit in ~64 KB next to K/V (two workgroups per CU), else as many
     // as do; K/V alone may take up to the full 160 KB
-    const int64_t fixed_f = (int64_t)2 * Tk * (dk + 1), per_f = (int64_t)(dk + 1) + (Tk + 1);
+    const int64_t fixed_f = (int64_t)2 * Tk * (dk + 4), per_f = (int64_t)(dk + 4) + (Tk + 1);
     int CH = q_per_kv * Tq;
     {
         const int64_t budget = 64 * 1024 / 4, room = budget > fixed_f ? (budget - fixed_f) / per_f : 0;
@@ -397,7 +415,12 @@ int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float 
     if (dkv_ld <= 0) dkv_ld = Tk * dkv_stride;
     if (!d_o || !q || !k || !v || !p || !dq || !dk_out || !dv_out || Nq <= 0 || q_per_kv <= 0 || Nq % q_per_kv)
         return CAPMI_EINVAL;
-    const int64_t fixed_b = (int64_t)4 * Tk * (dk + 1), per_b = (int64_t)2 * (dk + 1) + 3 * (Tk + 1);
+    if (dk % 4 || ldkv % 4 || kstride % 4 || dkv_ld % 4 || dkv_stride % 4 ||
+        ((reinterpret_cast<uintptr_t>(d_o) | reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
+          reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dk_out) |
+          reinterpret_cast<uintptr_t>(dv_out)) & 15))
+        return CAPMI_EINVAL;
+    const int64_t fixed_b = (int64_t)4 * Tk * (dk + 4), per_b = (int64_t)2 * (dk + 4) + 3 * (Tk + 1);
     int CH = q_per_kv * Tq;
     {
         const int64_t budget = 96 * 1024 / 4, room = budget > fixed_b ? (budget - fixed_b) / per_b : 0;

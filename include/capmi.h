@@ -533,7 +533,8 @@ int capmi_layernorm_bwd(const float *dy, const float *x, const float *a, const f
  * kstride: floats between consecutive keys of one kv row (D for packed [Tk,D]; 2R when K and V are the two halves of
  * AoA's p_att rows, AoAModel.py:168).  mask: uint8 [Nq or Nkv-broadcast, mask_tq (1 or Tq), Tk] (0 = -inf), or NULL; causal != 0 additionally
  * masks key j > query position (q_pos0 + i).  drop: optional pre-scaled keep mask [Nq,h,Tq,Tk] applied to the
- * probabilities.  Outputs o [Nq,Tq,D] and p [Nq,h,Tq,Tk] (softmax probabilities BEFORE dropout, saved). */
+ * probabilities.  Outputs o [Nq,Tq,D] and p [Nq,h,Tq,Tk] (softmax probabilities BEFORE dropout, saved).
+ * dk % 4 == 0 and 16-byte aligned q / k / v / o rows (ldkv, kstride multiples of 4): the head dimension moves in 16-byte pieces. */
 int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, int kstride, const uint8_t *mask, int mask_tq,
                   int mask_per_q, int causal, int q_pos0, const float *drop, float *o, float *p, int Nq, int q_per_kv,
                   int Tq, int Tk, int h, int dk, void *stream);
