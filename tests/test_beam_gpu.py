@@ -97,3 +97,47 @@ def test_beam_search_transformer_aoa_match_reference(name, tag, bs, masked, kw):
             assert np.array_equal(bm['seq'].cpu().numpy(), g['%s_%d_%d_seq' % (tag, k, j)]), (k, j)
             np.testing.assert_allclose(bm['p'], g['%s_%d_%d_p' % (tag, k, j)], rtol=2e-5, atol=2e-5)
             np.testing.assert_allclose(bm['unaug_p'], g['%s_%d_%d_unaug' % (tag, k, j)], rtol=1e-4)
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_beam_select_invariants_random_shapes(seed):
+    """The reference's per-step asserts (CaptionModel.py:89,97,100) as properties over random shapes: vocabulary sizes that
+    are not multiples of 4 or of the workgroup size, first step (cur = 1) and later steps (cur = bd), ties, -inf entries
+    (decoding constraints) and beams already pushed down by -1000."""
+    from imagecaptioning.pytorch_amd import _lib
+    from imagecaptioning.pytorch_amd._lib import lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(100 + seed)
+    B = int(torch.randint(1, 7, (1,), generator=g))
+    bd = int(torch.randint(1, 9, (1,), generator=g))
+    cur = 1 if seed % 3 == 0 else bd
+    V1 = int(torch.randint(max(bd, 5), 3000, (1,), generator=g)) if seed % 2 else 9488
+    logp = torch.log_softmax(torch.randn(B * cur, V1, generator=g) * 3, 1)
+    logp[torch.rand(B * cur, V1, generator=g) < 0.01] = float('-inf')          # constrained entries
+    if seed % 4 == 1:
+        logp = (logp * 4).round() / 4                                           # exact ties: lowest flat index wins, like torch.sort(stable)
+    sums = torch.randn(B, bd, generator=g) * 2
+    sums[torch.rand(B, bd, generator=g) < 0.3] -= 1000.0                        # beams that already ended
+    last = int(seed % 5 == 4)
+    d = lambda t: t.to(DEV).contiguous()                                        # noqa: E731
+    logp_d, sums_d = d(logp), d(sums)
+    parent = torch.empty(B, bd, dtype=torch.int32, device=DEV)
+    token = torch.empty(B, bd, dtype=torch.long, device=DEV)
+    score, nxt = torch.empty(B, bd, device=DEV), torch.empty(B, bd, device=DEV)
+    ended = torch.empty(B, bd, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.capmi_beam_select(ptr(logp_d), ptr(sums_d), B, cur, bd, V1, last, ptr(parent), ptr(token), ptr(score), ptr(nxt),
+                                     ptr(ended), stream_ptr()), 'select')
+    cand = (sums[:, :cur].unsqueeze(-1) + logp.view(B, cur, V1)).reshape(B, -1)
+    ys, ix = torch.sort(cand, dim=-1, descending=True, stable=True)
+    ys, ix = ys[:, :bd], ix[:, :bd]
+    assert torch.equal(score.cpu(), ys)                                         # CaptionModel.py:100: beam_logprobs_sum == ys
+    finite = torch.isfinite(ys)
+    got_ix = parent.cpu().long() * V1 + token.cpu()
+    if seed % 4 != 1:                                                           # without ties the choice itself is unique
+        assert torch.equal(got_ix[finite], ix[finite])
+    else:                                                                       # with ties: the chosen candidates carry the sorted scores
+        assert torch.equal(cand.gather(1, got_ix)[finite], ys[finite])
+        assert all(len(set(r.tolist())) == bd for r in got_ix)                  # and no candidate is taken twice
+    tok = token.cpu()
+    want_end = (tok == 0) | bool(last)
+    assert torch.equal(ended.cpu().bool(), want_end)
+    assert torch.equal(nxt.cpu()[finite], (ys - 1000.0 * want_end.float())[finite])
