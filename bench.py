@@ -141,7 +141,10 @@ def main():
     torch.manual_seed(1234)                       # identical initial weights on every rank
     model = models.setup(opt).to(dev)
     flat = model.flatten_parameters_()
-    if world > 1:
+    # CAPMI_DDP_OVERLAP=0: one all-reduce of the whole flat gradient after the backward instead of buckets launched from
+    # inside it (the simple path; also what the N>1 runs fall back to if the overlapped path fails on its first step)
+    overlap = world > 1 and os.environ.get('CAPMI_DDP_OVERLAP', '1') != '0'
+    if overlap:
         flat.begin_overlap()
     lw = LossWrapper(model, opt)
     if args.global_batch:
@@ -164,15 +167,17 @@ def main():
         flat.zero_grad()
         loss.backward()
         flat.collect_grads()
-        if world > 1:
+        adam = dict(lr=opt.learning_rate, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon,
+                    weight_decay=opt.weight_decay, clip_value=opt.grad_clip_value)
+        if overlap:
             # the backward has already launched the all-reduce of every gradient bucket it finished (logit layer before
             # the BPTT loop, LSTM weights before the attention/prefill gradients); reduce the rest and run clip+Adam
             # bucket by bucket as the collectives land
-            flat.finish_overlap_and_step(opt.learning_rate, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon,
-                                         opt.weight_decay, clip_value=opt.grad_clip_value)
+            flat.finish_overlap_and_step(**adam)
+        elif world > 1:
+            flat.adam_step(grad_scale=flat.all_reduce(), **adam)
         else:
-            flat.adam_step(opt.learning_rate, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
-                           clip_value=opt.grad_clip_value, grad_scale=1.0)
+            flat.adam_step(grad_scale=1.0, **adam)
         return loss
 
     def sync():
@@ -183,6 +188,20 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
+    if overlap:
+        # first step of the overlapped path under a guard: RCCL only exists on the driver's multi-GPU box, so if anything
+        # about launching collectives from inside the backward fails there, every rank (same code, same failure) drops to
+        # the single all-reduce instead of losing the measurement
+        try:
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:                                     # noqa: BLE001
+            print('rank %d: overlapped all-reduce failed (%s: %s); falling back to one all-reduce per step'
+                  % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
+            overlap = False
+            flat.on_grads_ready = None
+            flat._ov = None
+            flat.grad.zero_()
     for _ in range(args.warmup):
         step()
     lib.capmi_prof_reset()
@@ -256,7 +275,7 @@ def main():
                                    'bottom-up feats, R=E=1000 A=512, vocab 9487, seq_len 20, greedy baseline + CIDEr-D + '
                                    'RewardCriterion + BPTT + clip 0.1 + Adam',
                        'global_batch': B * world, 'captions_per_step': B * n * world, 'seq_len': L,
-                       'parallelism': 'dp%d (flat fp32 gradient, %s)' % (world, 'bucketed RCCL all-reduce overlapped with the backward' if world > 1 else 'no collective')},
+                       'parallelism': 'dp%d (flat fp32 gradient, %s)' % (world, ('bucketed RCCL all-reduce overlapped with the backward' if overlap else 'one RCCL all-reduce per step') if world > 1 else 'no collective')},
             'loss': float(loss.detach()), 'roofline': roofline, 'attention': attention, 'kernel_ms_per_step': per_class,
             'cpu_baseline': cpu}
         print(json.dumps(line), flush=True)
