@@ -103,3 +103,47 @@ def test_df_image_roundtrip(tmp_path):
             assert keys[s] != 0
             s = (s + 1) & (cap - 1)
         assert vals[s] == c
+
+
+def test_decode_option_flags_and_eval_kwargs():
+    """Host-side plumbing of the decode options: which requests leave the one-call rollouts (decode.wants_options), which
+    constraint bits apply at which step (AttModel.py:293, 298, 307: t > 0, t > 0, t >= 3), how finished beams are padded for
+    decode_sequence, and that tools/eval.py hands every sampler flag of the command line to the model (eval_utils.py:169-171)."""
+    from imagecaptioning.pytorch_amd import decode, _lib
+    from imagecaptioning.pytorch_amd.tools import eval as E
+    assert not decode.wants_options({'sample_method': 'greedy', 'beam_size': 5})
+    for k in ('decoding_constraint', 'block_trigrams', 'remove_bad_endings'):
+        assert decode.wants_options({k: 1})
+    assert decode.wants_options({'group_size': 2}) and not decode.wants_options({'group_size': 1})
+    o = {'decoding_constraint': 1, 'remove_bad_endings': 1, 'block_trigrams': 1}
+    assert decode._flags(o, 0) == 0
+    assert decode._flags(o, 1) == decode._flags(o, 2) == _lib.DECODE_NO_REPEAT | _lib.DECODE_NO_BAD_ENDING
+    assert decode._flags(o, 3) == _lib.DECODE_NO_REPEAT | _lib.DECODE_NO_BAD_ENDING | _lib.DECODE_BLOCK_TRIGRAMS
+    assert decode._flags({'block_trigrams': 1}, 2) == 0
+    st = E._pad_stack([torch.tensor([4, 5, 0]), torch.tensor([7, 0]), torch.tensor([1, 2, 3, 9])])
+    assert st.tolist() == [[4, 5, 0, 0], [7, 0, 0, 0], [1, 2, 3, 9]]
+    opt = argparse.Namespace(sample_method='top5', beam_size=1, temperature=0.7, suppress_UNK=1, length_penalty='wu_0.5', group_size=2,
+                             diversity_lambda=0.3, decoding_constraint=1, block_trigrams=1, remove_bad_endings=0, max_length=16,
+                             unrelated=123)
+    kw = E.eval_kwargs_of(opt)
+    assert kw == {'sample_method': 'top5', 'beam_size': 1, 'temperature': 0.7, 'suppress_UNK': 1, 'length_penalty': 'wu_0.5',
+                  'group_size': 2, 'diversity_lambda': 0.3, 'decoding_constraint': 1, 'block_trigrams': 1, 'remove_bad_endings': 0,
+                  'max_length': 16}
+
+
+def test_parse_sample_method_and_bad_endings():
+    """CaptionModel.sample_next_word's method strings (CaptionModel.py:370-407) and the bad-ending vocabulary (AttModel.py:27,96)."""
+    from imagecaptioning.pytorch_amd.captioning.models.utils import parse_sample_method
+    from imagecaptioning.pytorch_amd.captioning.models.CaptionModel import CaptionModel
+    assert parse_sample_method('greedy', 0.5) == ('greedy', 0.5, 0, 0.0)
+    assert parse_sample_method('sample', 1.3) == ('sample', 1.3, 0, 0.0)
+    assert parse_sample_method('gumbel', 1.3) == ('sample', 1.0, 0, 0.0)          # the temperature cancels in the arg-max
+    assert parse_sample_method('top5', 2.0) == ('sample', 2.0, 5, 0.0)
+    assert parse_sample_method('top0.9', 1.0) == ('sample', 1.0, 0, 0.9)
+    with pytest.raises(NotImplementedError):
+        parse_sample_method('beam_search_xyz', 1.0)
+    m = CaptionModel()
+    m.vocab = {'1': 'a', '2': 'dog', '3': 'with', '4': 'the', '5': 'UNK'}
+    assert sorted(m.bad_endings_ix) == [1, 3, 4]
+    m.bad_endings_ix = [2]
+    assert m.bad_endings_ix == [2]
