@@ -39,6 +39,11 @@ class DevicePrefetcher:
                 t = data.get(k)
                 if torch.is_tensor(t):
                     out[k] = self._pin(split, slot, k, t).to(self.device, non_blocking=True)
+            # reference captions travel with the batch as a device image (rewards.GtsBatch): packed here, once per batch, on the
+            # copy stream -- the SCST step then never re-packs them and never has to recognise a batch by object identity
+            from ..utils import rewards
+            if rewards.CiderD_scorer is not None and data.get('gts') is not None:
+                out['gts'] = rewards.pack_gts(data['gts'])
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self._queue.setdefault(split, []).append((out, ev))

@@ -4,7 +4,7 @@ device side: the SCST reward never leaves HBM (no .cpu().numpy() round trip, rew
 import torch
 
 from . import losses
-from ..utils.rewards import self_critical_reward_device
+from ..utils.rewards import self_critical_reward_device, select_gts
 
 
 class LossWrapper(torch.nn.Module):
@@ -38,7 +38,7 @@ class LossWrapper(torch.nn.Module):
                     fc_feats, att_feats, att_masks,
                     opt={'sample_method': opt.train_sample_method, 'beam_size': opt.train_beam_size,
                          'output_logsoftmax': 1, 'sample_n': opt.train_sample_n}, mode='sample')
-                gts = [gts[_] for _ in gt_indices.tolist()]
+                gts = select_gts(gts, gt_indices)
                 struc_loss = self.struc_crit(sample_logprobs, gen_result, gts, reduction=reduction)
             else:
                 struc_loss = {'loss': torch.tensor(0).type_as(fc_feats), 'reward': torch.tensor(0).type_as(fc_feats)}
@@ -68,7 +68,7 @@ class LossWrapper(torch.nn.Module):
                     fc_feats, att_feats, att_masks,
                     opt={'sample_method': opt.train_sample_method, 'beam_size': opt.train_beam_size,
                          'sample_n': opt.train_sample_n}, mode='sample')
-            gts = [gts[_] for _ in gt_indices.tolist()]
+            gts = select_gts(gts, gt_indices)
             adv, _scores = self_critical_reward_device(greedy_res, gts, gen_result, opt)      # [N] on device
             reward = adv.unsqueeze(1).expand(-1, gen_result.shape[1])
             loss = self.rl_crit(sample_logprobs, gen_result.data, reward, reduction=reduction)

@@ -14,7 +14,23 @@ import torch
 from imagecaptioning.pytorch_amd.ciderd import DeviceCiderD
 
 CiderD_scorer = None
-_ref_cache = {}
+
+
+class GtsBatch(list):
+    """The reference's ``data['gts']`` (list, per image, of [n_ref, L] integer arrays; dataloader.py:213-214, 256) carrying
+    the device image of itself: ``packed = (refs int32 [B,max_refs,w], n_refs int32 [B])``.  The loader / prefetcher builds it
+    once per batch (``pack_gts``), so the reward path neither re-packs nor guesses identity from object addresses; a plain
+    list is packed on the spot every time (no cache)."""
+    packed = None
+
+
+def pack_gts(data_gts):
+    """list of reference arrays -> GtsBatch with its device image (needs init_scorer first)."""
+    if isinstance(data_gts, GtsBatch) and data_gts.packed is not None:
+        return data_gts
+    out = GtsBatch(data_gts)
+    out.packed = CiderD_scorer.pack_refs(list(data_gts))
+    return out
 
 
 def init_scorer(cached_tokens, device=None):
@@ -39,17 +55,20 @@ def init_scorer(cached_tokens, device=None):
 def reset_scorer():
     global CiderD_scorer
     CiderD_scorer = None
-    _ref_cache.clear()
+
+
+def select_gts(gts, gt_indices):
+    """loss_wrapper.py:69 ``gts = [gts[_] for _ in gt_indices.tolist()]``; the packed device image survives when the
+    selection is the whole batch in order (always, outside nn.DataParallel scatter)."""
+    idx = gt_indices.tolist() if hasattr(gt_indices, 'tolist') else list(gt_indices)
+    if isinstance(gts, GtsBatch) and gts.packed is not None and idx == list(range(len(gts))):
+        return gts
+    return [gts[i] for i in idx]
 
 
 def _pack(data_gts):
-    key = tuple(id(g) for g in data_gts)
-    hit = _ref_cache.get(key)
-    if hit is None:
-        _ref_cache.clear()
-        hit = CiderD_scorer.pack_refs(data_gts)
-        _ref_cache[key] = hit
-    return hit
+    packed = getattr(data_gts, 'packed', None)
+    return packed if packed is not None else CiderD_scorer.pack_refs(list(data_gts))
 
 
 def self_critical_reward_device(greedy_res, data_gts, gen_result, opt):

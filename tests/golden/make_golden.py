@@ -439,8 +439,89 @@ def main_ss():
           float(np.abs(out['p50_logp'] - z['xe_logp_mask']).max()))
 
 
+def main_rewards():
+    """Call-site fixture for the reward plumbing: the REAL reference ``captioning/utils/rewards.py``
+    (array_to_str :33-39, get_self_critical_reward :41-81, get_scores :83-114) is imported and run unmodified.  Only the
+    external scorer object is supplied (the ``cider`` submodule is empty in the checkout): a stub with the upstream
+    ``compute_score(gts: {id -> [str]}, res: [{'image_id', 'caption': [str]}]) -> (mean, np.ndarray)`` interface that parses
+    the strings the reference built and scores them with oracle/ciderd.py.  What this pins: the strings the reference
+    feeds the scorer (0 kept, cut after the first 0, rows without 0 at full length), the res/gts layout (N sampled then
+    B greedy, refs of image i // n resp. i - N), cider_reward_weight, the advantage and its repeat along L.  The CIDEr-D
+    arithmetic itself stays unpinned (upstream absent).  Ragged inputs: EOS at step 0, no EOS, 1..5 references."""
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import captioning.utils.rewards as R            # the reference (prints 'cider or coco-caption missing')
+    from oracle import ciderd as C
+
+    vocab, L, B, n = 40, 10, 5, 3
+    N = B * n
+    corpus = C.synthetic_corpus(120, vocab, 5, L, seed=21)
+    df, ref_len = C.build_document_frequency([[C.tokens_of(r) for r in g] for g in corpus])
+    oracle = C.CiderD(df, ref_len)
+    seen = {'gts': [], 'res': []}
+
+    class Stub:
+        def compute_score(self, gts, res):
+            hyps, refs = [], []
+            for r in res:                                     # upstream iterates `res` in list order (SURVEY A.7)
+                assert len(r['caption']) == 1
+                hyps.append([int(t) for t in r['caption'][0].split()])
+                refs.append([[int(t) for t in s.split()] for s in gts[r['image_id']]])
+            seen['res'].append([r['caption'][0] for r in res])
+            seen['gts'].append([list(gts[r['image_id']]) for r in res])
+            return oracle.compute_score(hyps, refs)
+
+    R.CiderD_scorer = Stub()
+    rng = np.random.default_rng(8)
+    gts = []
+    for i in range(B):
+        k = 1 + (i * 2) % 5                                   # 1, 3, 5, 2, 4 references
+        g = np.zeros((k, L), dtype=np.uint32)
+        for j in range(k):
+            ln = int(rng.integers(1, L + 1))                  # ln == L: a reference without terminating 0
+            g[j, :ln] = rng.integers(1, vocab + 1, size=ln)
+        gts.append(g)
+    gts[1][0, :] = rng.integers(1, vocab + 1, size=L)         # full-length reference, no 0
+    gen = np.zeros((N, L), dtype=np.int64)
+    for i in range(N):
+        src = gts[i // n][rng.integers(0, len(gts[i // n]))].astype(np.int64).copy()
+        flip = rng.random(L) < 0.35
+        src[flip] = rng.integers(0, vocab + 1, size=int(flip.sum()))
+        gen[i] = src
+    gen[0] = 0                                                # EOS at step 0 -> the caption "0"
+    gen[1] = rng.integers(1, vocab + 1, size=L)               # no EOS at all
+    gen[2] = gts[0][0]                                        # identical to image 0's only reference
+    gen[5, :4] = [vocab + 3, vocab + 4, 1, 2]                 # n-grams absent from the DF table
+    gen[5, 4:] = 0
+    greedy = np.stack([gts[i][0].astype(np.int64) for i in range(B)])
+    greedy[0, 2:] = 0
+    greedy[3] = 0
+    greedy[4] = rng.integers(1, vocab + 1, size=L)
+    out = dict(vocab=np.array(vocab), L=np.array(L), B=np.array(B), n=np.array(n), corpus_seed=np.array(21),
+               corpus_images=np.array(120), gen=gen, greedy=greedy)
+    for i, g in enumerate(gts):
+        out['gts_%d' % i] = g
+    import contextlib
+    import io
+    for w in (1.0, 0.5):
+        opt = argparse.Namespace(cider_reward_weight=w, bleu_reward_weight=0)
+        with contextlib.redirect_stdout(io.StringIO()):       # the reference prints the mean score
+            rew = R.get_self_critical_reward(torch.from_numpy(greedy), gts, torch.from_numpy(gen), opt)
+            sc = R.get_scores(gts, torch.from_numpy(gen), opt)
+        assert rew.dtype == np.float64 and rew.shape == (N, L)
+        out['reward_w%g' % w] = rew
+        out['scores_w%g' % w] = np.asarray(sc, dtype=np.float64)
+    # the strings of the first get_self_critical_reward call, as the reference built them
+    out['res_strings'] = np.array(seen['res'][0])
+    out['gts_strings'] = np.array(['|'.join(g) for g in seen['gts'][0]])
+    np.savez_compressed(os.path.join(HERE, 'rewards_callsite.npz'), **out)
+    print('rewards_callsite.npz:', len(out), 'arrays; reward range', float(out['reward_w1'].min()), float(out['reward_w1'].max()))
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'ss':
+    if len(sys.argv) > 1 and sys.argv[1] == 'rewards':
+        main_rewards()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'ss':
         main_ss()
     elif len(sys.argv) > 1 and sys.argv[1] == 'opts':
         main_opts()
