@@ -518,8 +518,72 @@ def main_rewards():
     print('rewards_callsite.npz:', len(out), 'arrays; reward range', float(out['reward_w1'].min()), float(out['reward_w1'].max()))
 
 
+def main_full():
+    """BASELINE-size gradient fixtures: too slow for the GPU test run (minutes of CPU backward), so
+    they are computed here once and stored compactly -- per parameter the gradient's L2 norm and a fixed 256-element probe
+    (tests/shapes.py:grad_probe), plus tokens / selected log-probs / losses.  Inputs are regenerated from seeds on the GPU box.
+
+    * ``c3_*``: BASELINE configs[2] shape (bs10 x sample_n 5, L=20, dropout 0.5): sampled rollout + RewardCriterion +
+      backward of oracle/att_lstm.py (pinned to the reference by updown_tiny.npz) with injected masks / Gumbel noise --
+      the reference's own RNG stream cannot be reproduced by a kernel.
+    * ``c2_*``: the REAL reference (captioning.models.setup('updown') with the same weights loaded, drop_prob_lm 0) on
+      the teacher-forced XE path at bs10 x 5 captions, T=21: loss, target log-probs, gradient norms and probes."""
+    sys.path.insert(0, REF)
+    root = os.path.dirname(os.path.dirname(HERE))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    import time
+    import shapes
+    from oracle import att_lstm as O
+    out = {}
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+
+    t0 = time.time()
+    P = shapes.full_size_params(seed=99)
+    c = shapes.c3_case(seed=2)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    seq, slp = O.rollout(Pg, c['fc'], c['att'], None, method='sample', sample_n=c['n'], temperature=1.0, max_len=c['L'],
+                         drops=c['drops'], gumbel=c['gumbel'])
+    loss = O.reward_criterion(slp, seq, c['reward'])
+    loss.backward()
+    out['c3_seq'] = seq.numpy()
+    out['c3_sel_logp'] = slp.detach().gather(2, seq.unsqueeze(2)).squeeze(2).numpy()
+    out['c3_loss'] = loss.detach().numpy()
+    for k, p in Pg.items():
+        out['c3_gnorm.' + k] = np.array(float(p.grad.double().norm()))
+        out['c3_gprobe.' + k] = shapes.grad_probe(p.grad).numpy().copy()
+    print('c3 (oracle, N=50, L=20): %.0f s, loss %.6f' % (time.time() - t0, float(loss)))
+
+    t0 = time.time()
+    import captioning.models as models          # the reference
+    from captioning.modules import losses
+    from imagecaptioning.pytorch_amd import synthetic
+    opt = synthetic.updown_opt(drop_prob_lm=0.0)
+    model = models.setup(opt)
+    P2 = shapes.full_size_params(seed=7)
+    model.load_state_dict(P2)
+    model.train()
+    fc, att = shapes.feats(10, seed=3)
+    labels, masks = shapes.c2_labels()
+    logp = model(fc, att, labels[..., :-1], None)
+    loss = losses.LanguageModelCriterion()(logp, labels[..., 1:], masks[..., 1:])
+    loss.backward()
+    tgt = labels[..., 1:].reshape(-1, labels.shape[-1] - 1)
+    out['c2_loss'] = loss.detach().numpy()
+    out['c2_tgt_logp'] = logp.detach().gather(2, tgt[:, :logp.shape[1]].unsqueeze(2)).squeeze(2).numpy()
+    out['c2_logp_row0'] = logp.detach()[0, :3].numpy()                  # three full distributions
+    for k, p in model.named_parameters():
+        out['c2_gnorm.' + k] = np.array(float(p.grad.double().norm()))
+        out['c2_gprobe.' + k] = shapes.grad_probe(p.grad).numpy().copy()
+    print('c2 (reference, N=50, T=21): %.0f s, loss %.6f' % (time.time() - t0, float(loss)))
+    np.savez_compressed(os.path.join(HERE, 'updown_full_grads.npz'), **out)
+    print('updown_full_grads.npz:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'rewards':
+    if len(sys.argv) > 1 and sys.argv[1] == 'full':
+        main_full()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'rewards':
         main_rewards()
     elif len(sys.argv) > 1 and sys.argv[1] == 'ss':
         main_ss()

@@ -1,0 +1,62 @@
+"""Deterministic BASELINE-size inputs shared by the fixture generator (tests/golden/make_golden.py) and the GPU parity
+tests: everything is drawn from seeded torch CPU generators, so the build container and the GPU box see the same bits."""
+import torch
+
+
+def full_size_params(seed=1234, V1=9488, R=1000, E=1000, A=512, F=2048):
+    """UpDown parameters at configs/updown/updown.yml sizes under the reference's state_dict keys."""
+    g = torch.Generator().manual_seed(seed)
+    u = lambda *s, a: (torch.rand(*s, generator=g) * 2 - 1) * a       # noqa: E731
+    P = {'embed.0.weight': torch.randn(V1, E, generator=g),
+         'fc_embed.0.weight': u(R, F, a=F ** -0.5), 'fc_embed.0.bias': u(R, a=F ** -0.5),
+         'att_embed.0.weight': u(R, F, a=F ** -0.5), 'att_embed.0.bias': u(R, a=F ** -0.5),
+         'ctx2att.weight': u(A, R, a=R ** -0.5), 'ctx2att.bias': u(A, a=R ** -0.5),
+         'core.att_lstm.weight_ih': u(4 * R, 2 * R + E, a=R ** -0.5), 'core.att_lstm.weight_hh': u(4 * R, R, a=R ** -0.5),
+         'core.att_lstm.bias_ih': u(4 * R, a=R ** -0.5), 'core.att_lstm.bias_hh': u(4 * R, a=R ** -0.5),
+         'core.lang_lstm.weight_ih': u(4 * R, 2 * R, a=R ** -0.5), 'core.lang_lstm.weight_hh': u(4 * R, R, a=R ** -0.5),
+         'core.lang_lstm.bias_ih': u(4 * R, a=R ** -0.5), 'core.lang_lstm.bias_hh': u(4 * R, a=R ** -0.5),
+         'core.attention.h2att.weight': u(A, R, a=R ** -0.5), 'core.attention.h2att.bias': u(A, a=R ** -0.5),
+         'core.attention.alpha_net.weight': u(1, A, a=A ** -0.5), 'core.attention.alpha_net.bias': u(1, a=A ** -0.5),
+         'logit.weight': u(V1, R, a=R ** -0.5), 'logit.bias': u(V1, a=R ** -0.5)}
+    return P
+
+
+def feats(B, K=36, F=2048, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    fc = (torch.randn(B, F, generator=g) * 0.5).clamp_min(0)
+    att = (torch.randn(B, K, F, generator=g) * 0.5).clamp_min(0)
+    return fc, att
+
+
+def c3_case(seed=2):
+    """BASELINE configs[2] shape: bs10 x train_sample_n 5, L=20, dropout 0.5 masks + Gumbel noise + a reward, all seeded."""
+    from oracle import att_lstm as O
+    B, n, K, L, R, E, V1 = 10, 5, 36, 20, 1000, 1000, 9488
+    N = B * n
+    g = torch.Generator().manual_seed(seed)
+    fc = (torch.randn(B, 2048, generator=g) * 0.5).clamp_min(0)
+    att = (torch.randn(B, K, 2048, generator=g) * 0.5).clamp_min(0)
+    drops = O.make_drops(0.5, B, K, N, L, E, R, g)
+    gum = -torch.log(-torch.log(torch.rand(L, N, V1, generator=g).clamp_min(1e-20)))
+    reward = torch.randn(N, 1, generator=g).repeat(1, L)
+    return dict(B=B, n=n, K=K, L=L, N=N, fc=fc, att=att, drops=drops, gumbel=gum, reward=reward)
+
+
+def c2_labels(B=10, n=5, L=20, V1=9488, seed=5):
+    """labels [B,n,L+2] / masks as dataloader.py:245-249 builds them (BOS/EOS columns 0, nonzeros + 2 ones)."""
+    g = torch.Generator().manual_seed(seed)
+    labels = torch.zeros(B, n, L + 2, dtype=torch.long)
+    masks = torch.zeros(B, n, L + 2)
+    for b in range(B):
+        for j in range(n):
+            ln = L if (b == 0 and j == 0) else int(torch.randint(6, L + 1, (1,), generator=g))
+            labels[b, j, 1:ln + 1] = torch.randint(1, V1, (ln,), generator=g)
+            masks[b, j, :ln + 2] = 1
+    return labels, masks
+
+
+def grad_probe(t, k=256):
+    """a fixed, spread-out sample of a tensor's elements (what the compact fixtures store of each gradient)."""
+    flat = t.reshape(-1)
+    step = max(1, flat.numel() // k)
+    return flat[::step][:k]

@@ -115,21 +115,7 @@ def test_golden_sampled_forced_reward_grads():
         np.testing.assert_allclose(grads[k].cpu().numpy(), ref, rtol=5e-4, atol=1e-6 + 2e-5 * np.abs(ref).max(), err_msg=k)
 
 
-def full_size_params(seed=1234, V1=9488, R=1000, E=1000, A=512, F=2048):
-    g = torch.Generator().manual_seed(seed)
-    u = lambda *s, a: (torch.rand(*s, generator=g) * 2 - 1) * a       # noqa: E731
-    P = {'embed.0.weight': torch.randn(V1, E, generator=g),
-         'fc_embed.0.weight': u(R, F, a=F ** -0.5), 'fc_embed.0.bias': u(R, a=F ** -0.5),
-         'att_embed.0.weight': u(R, F, a=F ** -0.5), 'att_embed.0.bias': u(R, a=F ** -0.5),
-         'ctx2att.weight': u(A, R, a=R ** -0.5), 'ctx2att.bias': u(A, a=R ** -0.5),
-         'core.att_lstm.weight_ih': u(4 * R, 2 * R + E, a=R ** -0.5), 'core.att_lstm.weight_hh': u(4 * R, R, a=R ** -0.5),
-         'core.att_lstm.bias_ih': u(4 * R, a=R ** -0.5), 'core.att_lstm.bias_hh': u(4 * R, a=R ** -0.5),
-         'core.lang_lstm.weight_ih': u(4 * R, 2 * R, a=R ** -0.5), 'core.lang_lstm.weight_hh': u(4 * R, R, a=R ** -0.5),
-         'core.lang_lstm.bias_ih': u(4 * R, a=R ** -0.5), 'core.lang_lstm.bias_hh': u(4 * R, a=R ** -0.5),
-         'core.attention.h2att.weight': u(A, R, a=R ** -0.5), 'core.attention.h2att.bias': u(A, a=R ** -0.5),
-         'core.attention.alpha_net.weight': u(1, A, a=A ** -0.5), 'core.attention.alpha_net.bias': u(1, a=A ** -0.5),
-         'logit.weight': u(V1, R, a=R ** -0.5), 'logit.bias': u(V1, a=R ** -0.5)}
-    return P
+from shapes import full_size_params  # noqa: E402
 
 
 def test_full_size_greedy_vs_oracle():
