@@ -61,7 +61,7 @@ class _RolloutFn(torch.autograd.Function):
         flat = model._flat
         stash = flat.begin_backward() if flat is not None else None
         grads = model._grad_targets(P)
-        d_fc, d_att, d_p_att = ro.backward(g_logp, grads, on_ready=flat.on_grads_ready if (flat is not None and stash is None) else None)
+        d_fc, d_att, d_p_att = ro.backward(g_logp, grads, on_ready=flat.on_grads_ready if (flat is not None and flat.overlap_allowed(stash)) else None)
         engine.prepare_backward(P, pr, d_fc, d_att, d_p_att, grads)
         if flat is not None:
             flat.end_backward(stash)

@@ -31,6 +31,21 @@ def save_checkpoint(opt, model, infos, optimizer_state=None, append=''):
     return path
 
 
+def load_infos(start_from, id_):
+    """tools/train.py:50-66: infos_<id>.pkl of the run being resumed ({} when absent)."""
+    path = os.path.join(start_from, 'infos_%s.pkl' % id_)
+    if not os.path.isfile(path):
+        return {}
+    with open(path, 'rb') as f:
+        return pickle.load(f)
+
+
+def load_optimizer_state(start_from):
+    """tools/train.py:112-119: optimizer.pth next to model.pth (None when absent)."""
+    path = os.path.join(start_from, 'optimizer.pth')
+    return torch.load(path, map_location='cpu', weights_only=False) if os.path.isfile(path) else None
+
+
 class LRSchedule:
     """Host-side learning-rate policy of the reference's training loop, for the fused clip+Adam step on the flat buffer
     (which takes the rate as a launch argument, so no torch optimizer object is involved):

@@ -39,11 +39,43 @@ class FlatParams:
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_count = 0
         self.on_grads_ready = None      # set by begin_overlap(); native backwards call it per finished bucket
+        self._bw_expected, self._bw_seen = 1, 0
+
+    # ---- optimizer state (the reference's optimizer.pth, misc.py:87-102 / tools/train.py:112-119) --------------------
+    def state_dict(self):
+        return {'exp_avg': self.exp_avg.detach().cpu().clone(), 'exp_avg_sq': self.exp_avg_sq.detach().cpu().clone(),
+                'step_count': int(self.step_count), 'total': int(self.total)}
+
+    def load_state_dict(self, sd):
+        if int(sd['total']) != self.total:
+            raise ValueError('optimizer state is for %d flat elements, the model has %d' % (int(sd['total']), self.total))
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        self.step_count = int(sd['step_count'])
+
+    def expect_backwards(self, k):
+        """How many native backward passes this optimisation step will run (2 when LossWrapper mixes an XE and a structure
+        loss, loss_wrapper.py:25-48).  Gradient buckets may only be handed to the collective by the LAST of them: an earlier
+        pass would put buffers in flight that the next pass clones, overwrites and accumulates into."""
+        self._bw_expected = max(1, int(k))
+
+    def overlap_allowed(self, stash):
+        """True when this backward pass (begin_backward() already called) may announce finished buckets."""
+        if self.on_grads_ready is None:
+            return False
+        if self._bw_seen > self._bw_expected:
+            raise RuntimeError('a %d. native backward ran in one step while the bucketed all-reduce is on and only %d were '
+                               'declared: gradients already in flight would be overwritten -- call '
+                               'flat.expect_backwards(k) before the step (or train without CAPMI_DDP_OVERLAP)'
+                               % (self._bw_seen, self._bw_expected))
+        # accumulating passes add their stash AFTER the phases ran (end_backward): nothing is final before that
+        return self._bw_seen == self._bw_expected and stash is None
 
     def begin_backward(self):
         """Called by a native backward BEFORE it overwrites the flat gradient views.  Returns a stash of gradients
         that already exist (a second backward pass within one step accumulates, like autograd would)."""
         stash = None
+        self._bw_seen += 1
         for n, p in zip(self.names, self.params):
             if p.grad is not None:
                 stash = stash or {}
@@ -146,5 +178,6 @@ class FlatParams:
                       clip_value, grad_scale, self.step_count)
 
     def zero_grad(self):
+        self._bw_seen = 0
         for p in self.params:
             p.grad = None

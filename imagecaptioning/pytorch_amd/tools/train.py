@@ -53,24 +53,54 @@ def train(opt):
         dist.barrier(device_ids=[local])              # RCCL communicator created on the main thread, before any backward
     if not opt.input_synthetic:
         raise SystemExit('only --input_synthetic 1 is available: the h5/lmdb loaders of the reference are outside the hot path')
+    if opt.optim != 'adam':
+        raise NotImplementedError("optim %r: the fused flat-buffer step implements Adam (misc.py:125-126, every BASELINE "
+                                  "config); other optimizers of misc.build_optimizer are out of scope" % opt.optim)
+    if opt.grad_clip_mode not in ('value',) and opt.grad_clip_value > 0:
+        raise NotImplementedError("grad_clip_mode %r: only clip_grad_value_ (train.py:194-195, the default) is fused into the "
+                                  "Adam kernel" % opt.grad_clip_mode)
     opt.seed = opt.seed + rank                        # each rank draws its own images
     loader = SyntheticLoader(opt)
     opt.vocab = loader.get_vocab()
     loader = DevicePrefetcher(loader, dev)             # batches arrive already resident in HBM (pinned, side stream)
     torch.manual_seed(1234)                           # identical weights on every rank
     model = models.setup(opt).to(dev)
+    infos = {}
     if opt.start_from:
         model.load_state_dict(torch.load(os.path.join(opt.start_from, 'model.pth'), map_location=dev))
+        infos = misc.load_infos(opt.start_from, opt.id)                          # tools/train.py:50-66
     flat = model.flatten_parameters_()
-    if world > 1:
+    overlap = world > 1 and os.environ.get('CAPMI_DDP_OVERLAP', '0') == '1'      # default: ONE all-reduce per step
+    if overlap:
         flat.begin_overlap()
     lw_model = LossWrapper(model, opt)
     model.train()
     sched = misc.LRSchedule(opt, model_size=getattr(model, 'd_model', None))
+    it, epoch = int(infos.get('iter', 0)), int(infos.get('epoch', 0))
+    if opt.start_from:
+        # tools/train.py:112-119: the optimizer resumes too -- Adam moments + step count (bias correction), the rate
+        # schedule's state, the iteration / epoch counters (they drive warm-up, decay, ss_prob and the XE->SCST switch)
+        # and the loader position
+        osd = misc.load_optimizer_state(opt.start_from)
+        if osd is not None:
+            flat.load_state_dict(osd['flat'])
+            sched.load_state_dict(osd['sched'])
+        for split, pos in infos.get('loader_pos', {}).items():
+            loader.loader.pos[split] = pos                                       # nothing is prefetched yet
+        model._rng_calls = int(infos.get('rng_calls', 0))                        # dropout / sampling Philox stream position
     sc_ready = False
-    it, epoch = 0, 0
     epoch_done = True
-    while it < opt.max_iters:
+    train_loss = float('nan')
+
+    last_pos = {}
+
+    def checkpoint():
+        # the prefetcher runs ahead of the loop: the position to resume from is the one of the last CONSUMED batch
+        misc.save_checkpoint(opt, model, {'iter': it, 'epoch': epoch, 'opt': opt, 'vocab': opt.vocab,
+                                          'loader_pos': dict(last_pos), 'rng_calls': int(getattr(model, '_rng_calls', 0))},
+                             optimizer_state={'flat': flat.state_dict(), 'sched': sched.state_dict()})
+
+    while it < opt.max_iters and (opt.max_epochs == -1 or epoch < opt.max_epochs):     # tools/train.py:279-280
         if epoch_done:
             sched.epoch_start(epoch)
             if misc.scheduled_sampling_prob(opt, epoch) > 0:                 # tools/train.py:142-146
@@ -88,16 +118,19 @@ def train(opt):
         out = lw_model(fc, att, labels, masks, att_masks, data['gts'], torch.arange(len(data['gts'])), sc_flag, struc_flag, False)
         loss = out['loss'].mean()
         flat.zero_grad()
+        two = struc_flag and 0 < opt.structure_loss_weight < 1                # XE + structure rollouts: two native backwards
+        flat.expect_backwards(2 if two else 1)
         loss.backward()
         flat.collect_grads()
         opt.current_lr = sched.rate(it)
         clip = opt.grad_clip_value if opt.grad_clip_mode == 'value' else 0.0
-        if world > 1:      # buckets finished by the backward are already in flight; clip+Adam follows each as it lands
+        if overlap:        # buckets finished by the backward are already in flight; clip+Adam follows each as it lands
             flat.finish_overlap_and_step(opt.current_lr, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
                                          clip_value=clip)
-        else:
+        else:              # one flat fp32 all-reduce per step; 1/world and the value clip inside the Adam kernel
+            scale = flat.all_reduce() if world > 1 else 1.0
             flat.adam_step(opt.current_lr, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
-                           clip_value=clip, grad_scale=1.0)
+                           clip_value=clip, grad_scale=scale)
         train_loss = loss.item()
         torch.cuda.synchronize()
         t2 = time.time()
@@ -111,18 +144,25 @@ def train(opt):
                 print('iter %d (epoch %d), avg_reward = %.3f, time/batch = %.3f' % (it, epoch, out['reward'].mean().item(), t2 - t1))
             print('Read data:', t1 - t0)
         it += 1
+        last_pos['train'] = data['bounds']['it_pos_now']
         if data['bounds']['wrapped']:
             epoch += 1
             epoch_done = True
         if opt.val_every and it % opt.val_every == 0:
             val_loss = validation_loss(lw_model, loader, opt, dev)          # eval_utils.eval_split's loss half (:228-256)
+            if world > 1:
+                # every rank evaluates its own images: the plateau decision must see ONE number, or the ranks pick
+                # different learning rates and the replicas drift apart
+                v = torch.tensor([val_loss], dtype=torch.float64, device=dev)
+                dist.all_reduce(v)
+                val_loss = float(v) / world
             sched.plateau_step(val_loss)
             if rank == 0:
                 print('validation loss: %.3f (lr %.2e)' % (val_loss, sched.current_lr))
         if rank == 0 and opt.save_checkpoint_every and it % opt.save_checkpoint_every == 0:
-            misc.save_checkpoint(opt, model, {'iter': it, 'epoch': epoch, 'opt': opt, 'vocab': opt.vocab})
+            checkpoint()
     if rank == 0 and opt.save_checkpoint_every:
-        misc.save_checkpoint(opt, model, {'iter': it, 'epoch': epoch, 'opt': opt, 'vocab': opt.vocab})
+        checkpoint()
     if world > 1:
         dist.destroy_process_group()
     return train_loss

@@ -31,12 +31,57 @@ def test_train_xe_then_scst_then_eval_beam(tmp_path):
                                 '--val_images', '8', '--reduce_on_plateau', '0']))
     assert l1 < l0, 'XE loss should fall on a 16-image synthetic set (%.3f -> %.3f)' % (l0, l1)
     rewards.reset_scorer()
-    T.train(_opts(small + ['--max_iters', '3', '--self_critical_after', '0', '--train_sample_n', '3', '--start_from', str(tmp_path)]))
+    # resumes at iteration 25 of the checkpoint (tools/train.py:50-66): three more, self-critical
+    T.train(_opts(small + ['--max_iters', '28', '--self_critical_after', '0', '--train_sample_n', '3', '--start_from', str(tmp_path)]))
     rewards.reset_scorer()
     loss, preds = E.main(_opts(small + ['--beam_size', '3', '--sample_method', 'beam_search', '--num_images', '8',
                                          '--start_from', str(tmp_path)]))
     assert len(preds) == 8 and all(isinstance(p['caption'], str) for p in preds)
     assert loss == loss
+
+
+def test_resume_restores_optimizer_schedule_counters_and_loader(tmp_path):
+    """tools/train.py:50-119 + misc.save_checkpoint: model.pth, optimizer.pth (Adam moments, step count, schedule state) and
+    infos (iter, epoch, loader position) -- a run stopped at iteration 4 and resumed to 8 ends with the SAME parameters as an
+    uninterrupted run of 8 (warm-up schedule on, so a restart at iteration 0 would show)."""
+    sys.path.insert(0, PKG)
+    from imagecaptioning.pytorch_amd.tools import train as T
+    small = ['--caption_model', 'updown', '--rnn_size', '32', '--input_encoding_size', '32', '--att_hid_size', '16', '--fc_feat_size', '24',
+             '--att_feat_size', '24', '--vocab_size', '40', '--synthetic_regions', '5', '--seq_length', '6', '--max_length', '6',
+             '--batch_size', '4', '--seq_per_img', '2', '--synthetic_images', '12', '--use_warmup', '1', '--noamopt_warmup', '6',
+             '--learning_rate', '0.01', '--drop_prob_lm', '0.5']
+    a, b = tmp_path / 'a', tmp_path / 'b'
+    T.train(_opts(small + ['--max_iters', '8', '--save_checkpoint_every', '8', '--checkpoint_path', str(a)]))
+    T.train(_opts(small + ['--max_iters', '4', '--save_checkpoint_every', '4', '--checkpoint_path', str(b)]))
+    import pickle
+    infos = pickle.load(open(b / 'infos_capmi.pkl', 'rb'))
+    assert infos['iter'] == 4 and infos['epoch'] == 1 and infos['loader_pos']['train'] == 4       # 12 images / 4 per batch
+    osd = torch.load(b / 'optimizer.pth', weights_only=False)
+    assert osd['flat']['step_count'] == 4 and float(osd['flat']['exp_avg_sq'].abs().max()) > 0
+    T.train(_opts(small + ['--max_iters', '8', '--save_checkpoint_every', '8', '--checkpoint_path', str(b), '--start_from', str(b)]))
+    pa, pb = torch.load(a / 'model.pth'), torch.load(b / 'model.pth')
+    # (not bitwise: the embedding gradient is scattered with float atomics; a restart of the warm-up / of Adam's moments
+    # would move the parameters by ~1e-2 with this learning rate)
+    for k in pa:
+        assert float((pa[k] - pb[k]).abs().max()) < 2e-5, (k, float((pa[k] - pb[k]).abs().max()))
+    assert torch.load(b / 'optimizer.pth', weights_only=False)['flat']['step_count'] == 8
+
+
+def test_unsupported_training_options_fail_loudly(tmp_path):
+    sys.path.insert(0, PKG)
+    from imagecaptioning.pytorch_amd.tools import train as T
+    small = ['--rnn_size', '32', '--input_encoding_size', '32', '--att_hid_size', '16', '--fc_feat_size', '24', '--att_feat_size', '24',
+             '--vocab_size', '40', '--synthetic_regions', '5', '--seq_length', '6', '--max_length', '6', '--batch_size', '4',
+             '--seq_per_img', '2', '--synthetic_images', '8', '--max_iters', '1', '--checkpoint_path', str(tmp_path)]
+    with pytest.raises(NotImplementedError):
+        T.train(_opts(small + ['--grad_clip_mode', 'norm']))
+    with pytest.raises(NotImplementedError):
+        T.train(_opts(small + ['--optim', 'sgd']))
+    # max_epochs of the reference configs is honoured (tools/train.py:279-280): 8 images / 4 per batch = 2 iterations per epoch
+    opt = _opts(small[:-4] + ['--max_iters', '100', '--max_epochs', '2', '--checkpoint_path', str(tmp_path), '--save_checkpoint_every', '1000'])
+    T.train(opt)
+    import pickle
+    assert pickle.load(open(tmp_path / 'infos_capmi.pkl', 'rb'))['iter'] == 4
 
 
 def test_transformer_noam_schedule_runs(tmp_path):

@@ -130,8 +130,10 @@ def _compare_model_with_oracle(model, forward_ref, greedy_ref, att, am, labels, 
     worst = {}
     for k, p in model.named_parameters():
         ref = P[k].grad
-        if float(ref.abs().max()) < 1e-12:
-            assert float(p.grad.abs().max()) < 1e-6, k
+        if float(ref.abs().max()) < 1e-12 or k.endswith('linears.1.bias'):
+            # attention KEY bias: adds the same q.b to every score of a query, which the softmax cancels -- its gradient is
+            # mathematically zero and pure rounding noise on both sides
+            assert float(p.grad.abs().max()) < 1e-5 and float(ref.abs().max()) < 1e-5, k
             continue
         worst[k] = rel(p.grad, ref)
     bad = {k: v for k, v in worst.items() if v >= 1e-3}
