@@ -82,8 +82,21 @@ __device__ __forceinline__ void load_b(float (&b)[16], const TileRef *tp, int co
     }
 }
 
+// ABL = 16: phase trace (s_memtime) of waves 0 and 4 of every workgroup into the ticket words of the workspace
+#define CAPMI_STAMP(slot)                                                                                          \
+    do {                                                                                                           \
+        if ((ABL & 16) && lane == 0 && (wid & 3) == 0) {                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+            reinterpret_cast<unsigned long long *>(a.counters)[((blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wid >> 2)) * 9 + (slot)] = \
+                __builtin_readcyclecounter();                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+        }                                                                                                          \
+    } while (0)
+
 // TM = 1: M <= 32 (one accumulator chain, 32 staged rows); TM = 2: M <= 64
-template <bool BKC, int TS, int TM, bool X3>
+// ABL (profiling builds of the <true,6,2,x3> shape only, CAPMI_ARES_ABLATE): 1 = no activation loads, 2 = no split / MFMA,
+// 4 = no weight loads, 8 = no K-half reduction / stores.  Never for results.
+template <bool BKC, int TS, int TM, bool X3, int ABL = 0>
 __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
     constexpr int ROWS = 32 * TM;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -94,13 +107,26 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
     float *As = lds;                                            // [ROWS][pitch]            (exact fp32 path)
     unsigned short *Ah = reinterpret_cast<unsigned short *>(lds);   // [3][ROWS][pitchH]    (bf16x3 path)
     TileRef *tiles = X3 ? reinterpret_cast<TileRef *>(Ah + 3 * planeH) : reinterpret_cast<TileRef *>(lds + ROWS * pitch);   // [SL]
-    const int n0 = blockIdx.x * AR_BN, z = blockIdx.y;
+    // XCD-aware workgroup -> (column block, K slice) map: workgroups are dispatched round-robin over the 8 XCDs (id % 8),
+    // each with a private L2.  All column blocks of one K slice read the SAME activation slice, so slices are dealt to
+    // XCDs (slice-major rank p, contiguous p per XCD): an XCD's L2 then fetches 1/8 of the activations once instead of all of
+    // them, and 31 of 32 workgroups find their slice in L2.  Pure speed: any placement computes the same result.
+    int bx = blockIdx.x, z = blockIdx.y;
+    if (a.ablate & 1) {
+        const int L = blockIdx.y * gridDim.x + blockIdx.x, total = gridDim.x * gridDim.y;
+        const int q = total >> 3, r = total & 7, xcd = L & 7;
+        const int p = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        z = p / (int)gridDim.x;
+        bx = p - z * (int)gridDim.x;
+    }
+    const int n0 = bx * AR_BN;
     const int t0 = z * SL;          // every slice runs exactly SL chunks; slots past the last K tile are zero padded
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int cg = wid & 3, kh = wid >> 2;
     const int l31 = lane & 31, half = lane >> 5;
     const int col = n0 + 32 * cg + l31;
     const int colc = min(col, a.N - 1);
+    CAPMI_STAMP(0);
 
     if (threadIdx.x < SL) {
         int s = 0, k0 = 0;
@@ -122,6 +148,7 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
         tiles[threadIdx.x] = t;
     }
     __syncthreads();
+    CAPMI_STAMP(1);
     const TileRef *mine = tiles + kh * TS;
 
     // Loads return IN ORDER (vmcnt counts them so): the activation loads (L2 hits, all workgroups of a K slice read the
@@ -144,11 +171,15 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
             const int k = (c4 & 7) * 4;
             const bool ok = row < a.M && k < tp->arem;
             gcf p = as_global(tp->A) + (ok ? (size_t)((row * tp->rdiv) >> 16) * tp->lda + k : 0);
+            if (ABL & 1) v[j] = f32x4{1.f, 2.f, 3.f, (float)j}; else
             v[j] = *(gcf4)p;
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < PF; ++u) load_b<BKC>(b[u], &mine[u], colc, half);
+        for (int u = 0; u < PF; ++u) {
+            if (ABL & 4) { for (int q = 0; q < 16; ++q) b[u][q] = (float)(q + u + lane); }
+            else load_b<BKC>(b[u], &mine[u], colc, half);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -181,7 +212,9 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
             }
         }
     }
+    CAPMI_STAMP(2);
     __syncthreads();
+    CAPMI_STAMP(3);
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -264,8 +297,17 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
         wsplit(b[0], w0);
 #pragma unroll
         for (int c = 0; c < TS; ++c) {
-            if (c + PF < TS) load_b<BKC>(b[(c + PF) % (PF + 1)], &mine[c + PF], colc, half);
+            if (c + PF < TS) {
+                if (ABL & 4) { for (int q = 0; q < 16; ++q) b[(c + PF) % (PF + 1)][q] = (float)(q + c + lane); }
+                else load_b<BKC>(b[(c + PF) % (PF + 1)], &mine[c + PF], colc, half);
+            }
             __builtin_amdgcn_sched_barrier(0);
+            if (ABL & 2) {
+                // keep the loads live without the split / MFMA work
+#pragma unroll
+                for (int q = 0; q < 16; ++q) asm volatile("" ::"v"(b[c % (PF + 1)][q]));
+                continue;
+            }
             // the scheduler may interleave these two: MFMAs of chunk c, VALU split of chunk c + 1
             if (c & 1) {
                 if (c + 1 < TS) wsplit(b[(c + 1) % (PF + 1)], w0);
@@ -275,12 +317,22 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
                 mma3(w0, c);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (ABL & 16) {
+                if (c == 0) { asm volatile("" ::"v"(acc0[0]), "v"(acc1[0])); CAPMI_STAMP(4); }
+                if (c == 2 % TS && TS > 1) { asm volatile("" ::"v"(acc0[0]), "v"(acc1[0])); CAPMI_STAMP(5); }
+                if (c == TS - 1) { asm volatile("" ::"v"(acc0[15]), "v"(acc1[15])); CAPMI_STAMP(6); }
+            }
         }
     }
 
     // K halves meet in LDS (the activation slice is dead): waves 4-7 park their 64x32 sums, waves 0-3 add and store.
     // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     constexpr int RP = AR_BN + 4;
+    if (ABL & 8) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { asm volatile("" ::"v"(acc0[r])); asm volatile("" ::"v"(acc1[r])); }
+        return;
+    }
     __syncthreads();
     float *red = lds;                                           // [64][RP]
     if (kh == 1) {
@@ -292,6 +344,7 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
         }
     }
     __syncthreads();
+    CAPMI_STAMP(7);
     if (kh == 1 || col >= a.N) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -307,6 +360,7 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
             if (row < a.M) out[(size_t)row * a.N] = acc0[r];
             if (TM == 2 && row + 32 < a.M) out[(size_t)(row + 32) * a.N] = acc1[r];
         }
+        if (ABL & 16) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CAPMI_STAMP(8); }
         return;
     }
     float cb = 0.f;
@@ -327,6 +381,7 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
         }
     }
 }
+
 
 }  // namespace
 
@@ -362,6 +417,15 @@ static int launch_ts(const KArgs &a, hipStream_t st, int pcls, double bytes, dou
     dim3 grid((a.N + AR_BN - 1) / AR_BN, a.splits);
     hipEvent_t e0, e1;
     const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
+    if constexpr (BKC && TS == 6 && TM == 2 && X3) {
+        static const int abl = [] { const char *e = getenv("CAPMI_ARES_ABLATE"); return e ? atoi(e) : 0; }();
+        if (abl) {
+#define CAPMI_ABL(V) case V: { static bool set = false; if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_ares_kernel<BKC, TS, TM, X3, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+            hipLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM, X3, V>), grid, dim3(AR_NT), lds, st, a); return 0; }
+            switch (abl) { CAPMI_ABL(1) CAPMI_ABL(2) CAPMI_ABL(3) CAPMI_ABL(4) CAPMI_ABL(6) CAPMI_ABL(7) CAPMI_ABL(8) CAPMI_ABL(10) CAPMI_ABL(15) CAPMI_ABL(16) default: break; }
+#undef CAPMI_ABL
+        }
+    }
     if (prof) hipExtLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM, X3>), grid, dim3(AR_NT), lds, st, e0, e1, 0, a);
     else hipLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM, X3>), grid, dim3(AR_NT), lds, st, a);
     CAPMI_CHECK_LAUNCH();

@@ -447,6 +447,8 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
             a.splits = splits;
             a.to_partial = (splits > 1 || d->defer_reduce) ? 1 : 0;
             a.self_reduce = 0;
+            static const int env_aopt = [] { const char *e = getenv("CAPMI_ARES_OPT"); return e ? atoi(e) : 0; }();
+            a.ablate = env_aopt;             // speed-only switches of the A-resident kernel (see gemm_ares.hip)
             if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > slab_cap)) return CAPMI_EINVAL;
             d->splits_used = splits;
             int rc = launch_ares(a, d->b_layout, ts_max, use_x3, st, pcls, bytes, flops);
