@@ -59,11 +59,15 @@ class UpDownGrads(C.Structure):
         'h2att_w', 'h2att_b', 'alpha_w', 'alpha_b', 'logit_w', 'logit_b', 'd_fc', 'd_att', 'd_p_att')]
 
 
+class SparseLogpGrad(C.Structure):
+    _fields_ = [('g_sel', c_f), ('g_sum', c_f), ('tok', c_f), ('tok_ld', C.c_int)]
+
+
 class UpDownBwdScratch(C.Structure):
     _fields_ = ([(k, c_f) for k in ('dlogits', 'd_hdrop', 'dg_att', 'dg_lang', 'd_x2', 'd_e_all', 'd_att_h_all',
                                     'dh_att_attn', 'd_x1', 'dc_att', 'dc_lang', 'd_xt_all', 'sum_dg_att', 'w_lang_cat',
                                     'w_att_cat', 'partial')] +
-                [('partial_capacity', C.c_int64)])
+                [('partial_capacity', C.c_int64), ('sparse', C.POINTER(SparseLogpGrad))])
 
 
 class UpDownBeam(C.Structure):
@@ -92,7 +96,7 @@ class NewFCGrads(C.Structure):
 
 class NewFCBwdScratch(C.Structure):
     _fields_ = ([(k, c_f) for k in ('dlogits', 'd_hdrop', 'd_sums', 'dh_prev', 'dc', 'd_x_all', 'd_ximg', 'partial')] +
-                [('partial_capacity', C.c_int64)])
+                [('partial_capacity', C.c_int64), ('sparse', C.POINTER(SparseLogpGrad))])
 
 
 _I, _F, _P, _U64, _I64 = C.c_int, C.c_float, C.c_void_p, C.c_uint64, C.c_int64
@@ -118,6 +122,7 @@ SIGNATURES = {
     'capmi_logsoftmax_select_partial': [_P, _I, _I64, _P, _I, _I, _I, _I, _I, _P, _F, _P, _U64, _P, _I, _I, _P, _I, _P, _P, _P,
                                         _P, _P, _P, _P, _P],
     'capmi_logsoftmax_bwd': [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'capmi_logsoftmax_bwd_sparse': [C.POINTER(SparseLogpGrad), _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'capmi_splitk_reduce': [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P],
     'capmi_dropout_mask': [_P, _I64, _F, _U64, _U64, _P],
     'capmi_colsum': [_P, _I, _I, _I, _P, _I, _P],

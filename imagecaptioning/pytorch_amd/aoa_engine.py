@@ -166,15 +166,15 @@ class AoAGraph:
         return self.seq, self.seq_logp
 
     # ------------------------------------------------------------------ backward
-    def backward(self, g_logp):
+    def backward(self, g_logp, sparse=None):
         P, g, h, B, K, R, n, N, T, L = self.P, self.g, self.h, self.B, self.K, self.R, self.n, self.N, self.T, self.L
         V1, E = P['embed.0.weight'].shape
         dev = self.dev
         st = stream_ptr()
         z = lambda *s: torch.empty(*s, dtype=_f32, device=dev)       # noqa: E731
-        g_logp = g_logp.contiguous()
+        g_logp = None if g_logp is None else g_logp.contiguous()
         dlogits = z(T, N, V1)
-        check(lib.capmi_logsoftmax_bwd(ptr(g_logp), ptr(self.seq_logp), ptr(self.live), ptr(dlogits), N, L, T, V1, st), 'logsoftmax_bwd')
+        ops.logsoftmax_bwd(g_logp, sparse, self.seq_logp, self.live, dlogits, N, L, T, V1)
         TN = T * N
         d_outdrop = ops.matmul_nn(dlogits.view(TN, V1), P['logit.weight'])            # [TN,R]
         ops.matmul_tn(dlogits.view(TN, V1), self.out_drop.view(TN, R), out=g['logit.weight'])

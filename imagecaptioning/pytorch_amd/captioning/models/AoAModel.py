@@ -51,6 +51,8 @@ class _Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, cfg, att_feats, att_masks, *params):
         P = dict(zip(model._param_names, [p.detach() for p in params]))
+        ctx.sink = cfg.pop('_sink', None)
+        ctx.set_materialize_grads(False)        # the dense log-prob gradient may be undefined (sparse route)
         grads = model._flat.grad_views if model._flat is not None else {k: torch.empty_like(v) for k, v in P.items()}
         g = engine.AoAGraph(P, grads, model.num_heads, model.drop_prob_lm, model.dropout_aoa, model.training, model._next_seed())
         g.prepare(att_feats, att_masks)
@@ -63,7 +65,10 @@ class _Fn(torch.autograd.Function):
     def backward(ctx, _gs, g_logp):
         flat = ctx.model._flat
         stash = flat.begin_backward() if flat is not None else None
-        ctx.g.backward(g_logp)
+        from imagecaptioning.pytorch_amd import sparse_logp
+        g_logp, sparse, keep = sparse_logp.split_grad(g_logp, ctx.sink, ctx.g.seq_logp)
+        ctx.g._sparse_keep = keep
+        ctx.g.backward(g_logp, sparse=sparse)
         if flat is not None:
             flat.end_backward(stash)
             return (None,) * (4 + len(ctx.model._param_names))
@@ -121,7 +126,11 @@ class AoAModel(CaptionModel):
             ml = int(att_masks.long().sum(1).max())
             att_feats, att_masks = att_feats[:, :ml], att_masks[:, :ml].float().contiguous()
         params = [p for _, p in self.named_parameters()]
-        return _Fn.apply(self, cfg, att_feats.float().contiguous(), att_masks, *params)
+        from imagecaptioning.pytorch_amd import sparse_logp
+        cfg = dict(cfg)
+        cfg['_sink'] = sink = sparse_logp.LogpSink()
+        seq, logp = _Fn.apply(self, cfg, att_feats.float().contiguous(), att_masks, *params)
+        return seq, sparse_logp.attach(logp, sink)
 
     def _forward(self, fc_feats, att_feats, seq, att_masks=None):
         if self.training and self.ss_prob > 0:

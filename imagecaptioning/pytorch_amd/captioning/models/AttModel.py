@@ -20,6 +20,7 @@ import torch.nn as nn
 from .CaptionModel import CaptionModel
 from imagecaptioning.pytorch_amd import updown_engine as engine
 from imagecaptioning.pytorch_amd import ops
+from imagecaptioning.pytorch_amd import sparse_logp
 from imagecaptioning.pytorch_amd._lib import CapmiError
 
 from .utils import parse_sample_method      # noqa: E402
@@ -51,6 +52,8 @@ class _RolloutFn(torch.autograd.Function):
                             top_k=cfg.get('top_k', 0), top_p=cfg.get('top_p', 0.0), ss_mode=cfg.get('ss_mode'), **extra)
         seq, seq_logp = ro.run()
         ctx.model, ctx.ro, ctx.pr, ctx.P = model, ro, pr, P
+        ctx.sink = cfg.get('_sink')
+        ctx.set_materialize_grads(False)        # the dense log-prob gradient may be undefined (sparse route)
         ctx.mark_non_differentiable(seq)
         model._last_rollout = ro
         return seq, seq_logp
@@ -61,7 +64,9 @@ class _RolloutFn(torch.autograd.Function):
         flat = model._flat
         stash = flat.begin_backward() if flat is not None else None
         grads = model._grad_targets(P)
-        d_fc, d_att, d_p_att = ro.backward(g_logp, grads, on_ready=flat.on_grads_ready if (flat is not None and flat.overlap_allowed(stash)) else None)
+        g_logp, sparse, keep = sparse_logp.split_grad(g_logp, ctx.sink, ro.seq_logp)       # the criteria hand their gradient over sparse
+        ro._sparse_keep = keep
+        d_fc, d_att, d_p_att = ro.backward(g_logp, grads, sparse=sparse, on_ready=flat.on_grads_ready if (flat is not None and flat.overlap_allowed(stash)) else None)
         engine.prepare_backward(P, pr, d_fc, d_att, d_p_att, grads)
         if flat is not None:
             flat.end_backward(stash)
@@ -172,7 +177,9 @@ class AttModel(CaptionModel):
         att_feats = att_feats.float().contiguous()
         if att_masks is not None:
             att_masks = att_masks.float().contiguous()
-        return _RolloutFn.apply(self, cfg, fc_feats, att_feats, att_masks, *params)
+        cfg['_sink'] = sink = sparse_logp.LogpSink()
+        seq, logp = _RolloutFn.apply(self, cfg, fc_feats, att_feats, att_masks, *params)
+        return seq, sparse_logp.attach(logp, sink)
 
     # ------------------------------------------------------------------ reference API
     def _prepare_feature(self, fc_feats, att_feats, att_masks):

@@ -7,6 +7,7 @@ import torch.nn as nn
 from .CaptionModel import CaptionModel
 from imagecaptioning.pytorch_amd import newfc_engine as engine
 from imagecaptioning.pytorch_amd import ops
+from imagecaptioning.pytorch_amd import sparse_logp
 from imagecaptioning.pytorch_amd._lib import CapmiError
 
 
@@ -23,6 +24,8 @@ class _RolloutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, cfg, fc_feats, *params):
         P = dict(zip(model._param_names, [p.detach() for p in params]))
+        ctx.sink = cfg.pop('_sink', None)
+        ctx.set_materialize_grads(False)        # the dense log-prob gradient may be undefined (sparse route)
         ro = engine.Rollout(P, fc_feats, **cfg)
         seq, logp = ro.run()
         ctx.model, ctx.ro, ctx.P = model, ro, P
@@ -35,7 +38,9 @@ class _RolloutFn(torch.autograd.Function):
         flat = model._flat
         stash = flat.begin_backward() if flat is not None else None
         grads = flat.grad_views if flat is not None else {k: torch.empty_like(v) for k, v in P.items()}
-        ro.backward(g_logp, grads)
+        g_logp, sparse, keep = sparse_logp.split_grad(g_logp, ctx.sink, ro.seq_logp)
+        ro._sparse_keep = keep
+        ro.backward(g_logp, grads, sparse=sparse)
         if flat is not None:
             flat.end_backward(stash)
             return (None,) * (3 + len(model._param_names))
@@ -82,7 +87,9 @@ class NewFCModel(CaptionModel):
             cfg['drop_out'] = ops.dropout_mask((T, N, self.rnn_size), self.drop_prob_lm, self._next_seed(), 0,
                                                fc_feats.device)
         params = [p for _, p in self.named_parameters()]
-        return _RolloutFn.apply(self, cfg, fc_feats.float().contiguous(), *params)
+        cfg['_sink'] = sink = sparse_logp.LogpSink()
+        seq, logp = _RolloutFn.apply(self, cfg, fc_feats.float().contiguous(), *params)
+        return seq, sparse_logp.attach(logp, sink)
 
     def _forward(self, fc_feats, att_feats, seq, att_masks=None):
         if self.training and self.ss_prob > 0:

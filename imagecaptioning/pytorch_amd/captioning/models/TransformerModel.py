@@ -100,8 +100,10 @@ class _EncDec(nn.Module):
 
 class _Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, att_feats, att_masks, seq, n, *params):
+    def forward(ctx, model, att_feats, att_masks, seq, n, sink, *params):
         P = model._pdict(params)
+        ctx.sink = sink
+        ctx.set_materialize_grads(False)        # the dense log-prob gradient may be undefined (sparse route)
         grads = model._grad_targets(P)
         g = engine.TransformerGraph(P, grads, model.h, model.N_enc, model.N_dec, model.drop_prob_lm, model.dropout,
                                     model.training, model._next_seed())
@@ -114,11 +116,14 @@ class _Fn(torch.autograd.Function):
     def backward(ctx, g_logp):
         flat = ctx.model._flat
         stash = flat.begin_backward() if flat is not None else None
-        ctx.g.backward(g_logp)
+        from imagecaptioning.pytorch_amd import sparse_logp
+        g_logp, sparse, keep = sparse_logp.split_grad(g_logp, ctx.sink, ctx.g.logp)
+        ctx.g._sparse_keep = keep
+        ctx.g.backward(g_logp, sparse=sparse)
         if flat is not None:
             flat.end_backward(stash)
-            return (None,) * (5 + len(ctx.model._param_names))
-        return (None, None, None, None, None) + tuple(ctx.grads[k] for k in ctx.model._param_names)
+            return (None,) * (6 + len(ctx.model._param_names))
+        return (None, None, None, None, None, None) + tuple(ctx.grads[k] for k in ctx.model._param_names)
 
 
 class TransformerModel(CaptionModel):
@@ -193,7 +198,9 @@ class TransformerModel(CaptionModel):
         att_feats, att_masks = self._clip(att_feats, att_masks)
         n = seq.shape[0] // att_feats.shape[0]
         params = [p for _, p in self.named_parameters()]
-        return _Fn.apply(self, att_feats, att_masks, seq, n, *params)
+        from imagecaptioning.pytorch_amd import sparse_logp
+        sink = sparse_logp.LogpSink()
+        return sparse_logp.attach(_Fn.apply(self, att_feats, att_masks, seq, n, sink, *params), sink)
 
     def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
         """AttModel._sample for the Transformer.  Tokens are drawn with the KV-cached decoder under no_grad; when a
@@ -239,4 +246,5 @@ class TransformerModel(CaptionModel):
         inp = torch.cat([seq.new_zeros(seq.shape[0], 1), seq[:, :-1]], 1)
         logp_g = self._forward(None, att_feats, inp, att_masks)
         live = torch.cat([seq.new_ones(seq.shape[0], 1), (seq[:, :-1] > 0).long()], 1).cumprod(1)     # unfinished-before-step
-        return seq, logp_g * live.unsqueeze(-1).to(logp_g)
+        from imagecaptioning.pytorch_amd import sparse_logp
+        return seq, sparse_logp.attach_masked(logp_g * live.unsqueeze(-1).to(logp_g), logp_g, live)

@@ -1,10 +1,13 @@
 """Criteria of the hot path (reference captioning/modules/losses.py).  They consume the dense
 log-prob tensor the model API returns; the arithmetic is a gather + masked mean over [N,L] values
-(K14/K15 of SURVEY.md 2.3) -- device tensor ops on the same HIP stream, no host sync."""
+(K14/K15 of SURVEY.md 2.3) -- device tensor ops on the same HIP stream, no host sync.  The gather goes
+through ``sparse_logp.select_logp``: when the tensor comes from a capmi rollout its gradient travels back
+as [N,L] values + token ids (``capmi_logsoftmax_bwd_sparse``), never as a dense [N,L,V1] tensor."""
 import torch
 import torch.nn as nn
 
 from ..utils.rewards import get_scores
+from imagecaptioning.pytorch_amd.sparse_logp import select_logp, sum_logp
 
 
 def _shifted_mask(seq, like):
@@ -17,7 +20,7 @@ class RewardCriterion(nn.Module):
     """losses.py:18-37."""
 
     def forward(self, input, seq, reward, reduction='mean'):
-        sel = input.gather(2, seq.unsqueeze(2)).squeeze(2)
+        sel = select_logp(input, seq)
         mask = _shifted_mask(seq, sel)
         out = -sel * reward.to(sel) * mask
         if reduction == 'none':
@@ -35,7 +38,7 @@ class LanguageModelCriterion(nn.Module):
         T = input.size(1)
         target = target[:, :T]
         mask = mask[:, :T].to(input)
-        out = -input.gather(2, target.unsqueeze(2)).squeeze(2) * mask
+        out = -select_logp(input, target) * mask
         if reduction == 'none':
             return out.sum(1) / mask.sum(1)
         return out.sum() / mask.sum()
@@ -54,14 +57,14 @@ class LabelSmoothing(nn.Module):
             target = target.reshape(-1, target.shape[2])
             mask = mask.reshape(-1, mask.shape[2])
         N, T, V1 = input.shape
-        target = target[:, :T].reshape(-1)
+        tgt2 = target[:, :T]
+        target = tgt2.reshape(-1)
         mask = mask[:, :T].reshape(-1).to(input)
-        lp = input.reshape(-1, V1)
         off = self.smoothing / (V1 - 1)
         # sum_v q log q is a constant of (smoothing, V1); -sum_v q logp = -off*sum(lp) - (conf-off)*lp[target]
         ent = (V1 - 1) * (off * torch.log(torch.tensor(off)) if off > 0 else 0.0) + \
               (self.confidence * torch.log(torch.tensor(self.confidence)) if self.confidence > 0 else 0.0)
-        cross = off * lp.sum(1) + (self.confidence - off) * lp.gather(1, target.unsqueeze(1)).squeeze(1)
+        cross = off * sum_logp(input).reshape(-1) + (self.confidence - off) * select_logp(input, tgt2.contiguous()).reshape(-1)
         out = (ent - cross) * mask
         if reduction == 'none':
             return out.view(N, T).sum(1) / mask.view(N, T).sum(1)
@@ -85,7 +88,7 @@ class StructureLosses(nn.Module):
         N = input.size(0)
         n = N // len(data_gts)
         assert n == self.opt.train_sample_n, n
-        sel = input.gather(2, seq.unsqueeze(2)).squeeze(2)
+        sel = select_logp(input, seq)
         mask = _shifted_mask(seq, sel)
         scores = get_scores(data_gts, seq, self.opt, as_tensor=True).to(sel).view(-1, n)
         out['reward'] = scores

@@ -172,14 +172,15 @@ int capmi_newfc_rollout_fwd(const capmi_newfc_weights *w, capmi_newfc_rollout *r
 
 int capmi_newfc_rollout_bwd(const capmi_newfc_weights *w, const capmi_newfc_rollout *r, const float *g_seq_logp,
                             capmi_newfc_bwd_scratch *s, capmi_newfc_grads *g, void *stream) {
-    if (!w || !r || !g_seq_logp || !s || !g) return CAPMI_EINVAL;
+    if (!w || !r || (!g_seq_logp && !(s && s->sparse)) || !s || !g) return CAPMI_EINVAL;
     const int B = r->B, n = r->n, N = r->N, R = r->R, E = r->E, V1 = r->V1, T = r->T, L = r->L;
     hipStream_t st = (hipStream_t)stream;
     const size_t NR = (size_t)N * R;
     const int TN = T * N;
     float *P = s->partial;
     const int64_t cap = s->partial_capacity;
-    RC(capmi_logsoftmax_bwd(g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
+    if (s->sparse) RC(capmi_logsoftmax_bwd_sparse(s->sparse, g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
+    else RC(capmi_logsoftmax_bwd(g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
     {
         SegSpec a{s->dlogits, V1, w->logit_w, R, V1, 1};
         RC(gemm(stream, 0, 1, TN, R, s->d_hdrop, R, &a, 1, P, cap, 0, nullptr));

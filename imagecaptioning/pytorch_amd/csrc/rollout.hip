@@ -223,7 +223,7 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
 
 int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_updown_rollout *r, const float *g_seq_logp,
                                     capmi_updown_bwd_scratch *s, capmi_updown_grads *g, int phases, void *stream) {
-    if (!w || !r || !g_seq_logp || !s || !g || !(phases & CAPMI_BWD_ALL)) return CAPMI_EINVAL;
+    if (!w || !r || (!g_seq_logp && !(s && s->sparse)) || !s || !g || !(phases & CAPMI_BWD_ALL)) return CAPMI_EINVAL;
     const int B = r->B, n = r->n, N = r->N, K = r->K, A = r->A, R = r->R, E = r->E, V1 = r->V1, T = r->T, L = r->L;
     hipStream_t st = (hipStream_t)stream;
     const size_t NR = (size_t)N * R;
@@ -234,7 +234,8 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
 
     // ---- logit layer, batched over all T*N rows ----------------------------------------------
     if (phases & CAPMI_BWD_LOGIT) {
-        RC(capmi_logsoftmax_bwd(g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
+        if (s->sparse) RC(capmi_logsoftmax_bwd_sparse(s->sparse, g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
+        else RC(capmi_logsoftmax_bwd(g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
         SegSpec a{s->dlogits, V1, w->logit_w, R, V1, 1};   // d_hdrop = dlogits W_logit          [TN,R]
         RC(gemm(stream, 0, 1, TN, R, s->d_hdrop, R, &a, 1, P, cap, 0, nullptr));
         SegSpec b{s->dlogits, V1, r->h_drop, R, TN, 1};     // dW_logit = dlogits^T h_drop         [V1,R]

@@ -400,6 +400,44 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_bwd_kernel(const float
     for (int v = threadIdx.x; v < V1; v += blockDim.x) o[v] = gr[v] - __expf(lp[v]) * s;
 }
 
+// The same gradient when the loss touches the log-probs only through (i) the entry of ONE token per (row, step) and (ii)
+// the row sum -- every criterion of the hot path (losses.py:18-37 RewardCriterion, :168-187 new_self_critical, :204-224
+// LanguageModelCriterion: only (i); :227-265 LabelSmoothing: (i) and (ii)).  With a = dL/d logp[r,t,tok] and b = dL/d sum_v logp[r,t,v]
+//     dlogits[v] = a (1[v == tok] - p_v) + b (1 - V1 p_v)            p = exp(logp)
+// plus the dense form above when a dense gradient exists too.  Reads the saved log-probs once and writes dlogits once: the
+// dense [N,L,V1] gradient the reference's autograd materialises (gather backward: zero fill + scatter, 2 x 45 MB at bs10 x 5,
+// 2 x 255 MB at bs64) never exists.
+__global__ __launch_bounds__(SEL_THREADS) void logsoftmax_bwd_sparse_kernel(
+    const float *__restrict__ g_sel, const float *__restrict__ g_sum, const int64_t *__restrict__ tok, int tok_ld,
+    const float *__restrict__ g, const float *__restrict__ seq_logp, const uint8_t *__restrict__ live,
+    float *__restrict__ dlogits, int N, int L, int V1) {
+    __shared__ float s_f[32];
+    const int t = blockIdx.x / N, n = blockIdx.x % N;
+    const size_t r = (size_t)n * L + t;
+    const float *lp = seq_logp + r * V1;
+    float *o = dlogits + (size_t)blockIdx.x * V1;
+    if (live && !live[r]) {
+        for (int v = threadIdx.x; v < V1; v += blockDim.x) o[v] = 0.f;
+        return;
+    }
+    const float a = g_sel ? g_sel[r] : 0.f;
+    const float b = g_sum ? g_sum[r] : 0.f;
+    const int token = g_sel ? (int)tok[(size_t)n * tok_ld + t] : -1;
+    float s = a + b * (float)V1;                      // sum over v of the implied dense gradient
+    const float *gr = g ? g + r * V1 : nullptr;
+    if (gr) {
+        float sd = 0.f;
+        for (int v = threadIdx.x; v < V1; v += blockDim.x) sd += gr[v];
+        s += block_sum(sd, s_f);
+    }
+    for (int v = threadIdx.x; v < V1; v += blockDim.x) {
+        float d = b - __expf(lp[v]) * s;
+        if (v == token) d += a;
+        if (gr) d += gr[v];
+        o[v] = d;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -470,6 +508,17 @@ int capmi_logsoftmax_select(const float *logits, int N, int V1, int step, int L,
     return capmi_logsoftmax_select_partial(logits, 1, 0, nullptr, N, V1, step, L, mode, row_mode, temperature, gumbel,
                                            seed, forced, forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished,
                                            seq_logp, sel_logp, live, nullptr, nullptr, stream);
+}
+
+int capmi_logsoftmax_bwd_sparse(const capmi_sparse_logp_grad *sp, const float *g, const float *seq_logp, const uint8_t *live,
+                                float *dlogits, int N, int L, int T, int V1, void *stream) {
+    if (!sp || !seq_logp || !dlogits || N <= 0 || T <= 0 || T > L || V1 <= 0) return CAPMI_EINVAL;
+    if (!sp->g_sel && !sp->g_sum && !g) return CAPMI_EINVAL;
+    if (sp->g_sel && (!sp->tok || sp->tok_ld < T)) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(logsoftmax_bwd_sparse_kernel, dim3(N * T), dim3(SEL_THREADS), 0, (hipStream_t)stream, sp->g_sel,
+                       sp->g_sum, sp->tok, sp->tok_ld, g, seq_logp, live, dlogits, N, L, V1);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
 }
 
 int capmi_logsoftmax_bwd(const float *g, const float *seq_logp, const uint8_t *live, float *dlogits, int N, int L,

@@ -58,7 +58,7 @@ class Rollout:
         check(lib.capmi_newfc_rollout_fwd(C.byref(self.w), C.byref(self.r), stream_ptr()), 'capmi_newfc_rollout_fwd')
         return self.seq, self.seq_logp
 
-    def backward(self, g_seq_logp, grads):
+    def backward(self, g_seq_logp, grads, sparse=None):
         B, n, N, R, E, V1, T, L = self.dims
         dev = self.seq.device
         z = lambda *s: torch.empty(*s, dtype=_f32, device=dev)          # noqa: E731
@@ -73,7 +73,9 @@ class Rollout:
             setattr(g, f, grads[k].data_ptr())
         d_fc_emb = z(B, E)
         g.d_fc_emb = d_fc_emb.data_ptr()
-        g_seq_logp = g_seq_logp.contiguous()
+        g_seq_logp = None if g_seq_logp is None else g_seq_logp.contiguous()
+        if sparse is not None:
+            s.sparse = C.pointer(sparse)
         check(lib.capmi_newfc_rollout_bwd(C.byref(self.w), C.byref(self.r), ptr(g_seq_logp), C.byref(s), C.byref(g),
                                           stream_ptr()), 'capmi_newfc_rollout_bwd')
         # fc_embed (plain Linear) backward

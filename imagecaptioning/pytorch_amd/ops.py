@@ -215,6 +215,17 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, clip, grad_scale,
                               grad_scale, step, stream_ptr()), 'capmi_adam_step')
 
 
+def logsoftmax_bwd(g_dense, sparse, seq_logp, live, dlogits, N, L, T, V1):
+    """d(logits) [T,N,V1] from the loss gradient w.r.t. the dense log-probs: dense (`g_dense` [N,L,V1]), sparse
+    (`sparse`, a _lib.SparseLogpGrad from sparse_logp.split_grad) or both."""
+    if sparse is not None:
+        check(lib.capmi_logsoftmax_bwd_sparse(C.byref(sparse), ptr(g_dense), ptr(seq_logp), ptr(live), ptr(dlogits), N, L, T, V1,
+                                              stream_ptr()), 'capmi_logsoftmax_bwd_sparse')
+    else:
+        check(lib.capmi_logsoftmax_bwd(ptr(g_dense), ptr(seq_logp), ptr(live), ptr(dlogits), N, L, T, V1, stream_ptr()),
+              'capmi_logsoftmax_bwd')
+
+
 def logsoftmax_select(logits, step, L, mode, temperature, gumbel, seed, forced, no_finish_mask, seq, it_next, unfinished,
                       seq_logp, sel_logp, live, top_k=0, top_p=0.0):
     """capmi_logsoftmax_select_partial on finished logits [N,V1] (one slab, no bias) with the optional top-k / nucleus

@@ -253,18 +253,20 @@ class TransformerGraph:
         return self.logp
 
     # ---------------- backward of both
-    def backward(self, g_logp):
+    def backward(self, g_logp, sparse=None):
         P, g = self.P, self.grads
         N, T, B, K, D = self.N, self.T, self.B, self.K, self.D
-        V1 = g_logp.shape[-1]
-        dlogits = torch.empty(N * T, V1, dtype=_f32, device=g_logp.device)
-        g_logp = g_logp.contiguous()
-        check(lib.capmi_logsoftmax_bwd(ptr(g_logp), ptr(self.logp), None, ptr(dlogits), N * T, 1, 1, V1, stream_ptr()),
-              'logsoftmax_bwd')
+        V1 = self.logp.shape[-1]
+        dev = self.logp.device
+        dlogits = torch.empty(N * T, V1, dtype=_f32, device=dev)
+        g_logp = None if g_logp is None else g_logp.contiguous()
+        if sparse is not None:
+            sparse.tok_ld = 1                    # [N,T] tokens / gradients seen as N*T rows of one step
+        ops.logsoftmax_bwd(g_logp, sparse, self.logp, None, dlogits, N * T, 1, 1, V1)
         d_out = self.gen.bwd(dlogits)
-        dx = torch.zeros(N * T, D, dtype=_f32, device=g_logp.device)
+        dx = torch.zeros(N * T, D, dtype=_f32, device=dev)
         self.dec_norm.bwd(d_out, dx)
-        d_mem = torch.zeros(B * K, D, dtype=_f32, device=g_logp.device)
+        d_mem = torch.zeros(B * K, D, dtype=_f32, device=dev)
         for (n0, sa, n1, ca, n2, ff) in reversed(self.dec):
             # x3 = x2 + m*ff(n2(x2)) ; dx currently = d x3
             n2.bwd(ff.bwd(dx), dx)
@@ -277,7 +279,7 @@ class TransformerGraph:
         check(lib.capmi_embed_pe_bwd(ptr(self.seq), T, ptr(dx), ptr(self.drop_tgt), ptr(g['model.tgt_embed.0.lut.weight']), N, T,
                                      D, stream_ptr()), 'embed_pe_bwd')
         # encoder
-        dxe = torch.zeros(B * K, D, dtype=_f32, device=g_logp.device)
+        dxe = torch.zeros(B * K, D, dtype=_f32, device=dev)
         self.enc_norm.bwd(d_mem, dxe)
         for (n0, at, n1, ff) in reversed(self.enc):
             n1.bwd(ff.bwd(dxe), dxe)

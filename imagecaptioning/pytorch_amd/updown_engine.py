@@ -185,8 +185,8 @@ class Rollout:
                   (16, ('core.attention.h2att.weight', 'core.attention.h2att.bias', 'core.attention.alpha_net.weight',
                         'core.attention.alpha_net.bias')))
 
-    def backward(self, g_seq_logp, grads, on_ready=None):
-        """g_seq_logp [N,L,V1].  grads: dict name -> preallocated fp32 tensor (overwritten) for every
+    def backward(self, g_seq_logp, grads, on_ready=None, sparse=None):
+        """g_seq_logp [N,L,V1] (None when `sparse`, a _lib.SparseLogpGrad, carries the loss gradient).  grads: dict name -> preallocated fp32 tensor (overwritten) for every
         PARAM_KEYS entry.  Also returns (d_fc, d_att, d_p_att) consumed by prepare_backward.
         on_ready(names): called after the launches that complete the gradients `names` have been enqueued, so a
         data-parallel trainer can start reducing that bucket while the later phases still run."""
@@ -206,7 +206,9 @@ class Rollout:
             setattr(g, f, grads[k].data_ptr())
         d_fc, d_att, d_p_att = z(B, R), z(B, K, R), z(B, K, A)
         g.d_fc, g.d_att, g.d_p_att = d_fc.data_ptr(), d_att.data_ptr(), d_p_att.data_ptr()
-        g_seq_logp = g_seq_logp.contiguous()
+        g_seq_logp = None if g_seq_logp is None else g_seq_logp.contiguous()
+        if sparse is not None:                    # the loss gradient in sparse form (sparse_logp.split_grad)
+            s.sparse = C.pointer(sparse)
         if on_ready is None:
             check(lib.capmi_updown_rollout_bwd(C.byref(self.w), C.byref(self.r), ptr(g_seq_logp), C.byref(s), C.byref(g),
                                                stream_ptr()), 'capmi_updown_rollout_bwd')

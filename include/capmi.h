@@ -243,6 +243,23 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
 int capmi_logsoftmax_bwd(const float *g, const float *seq_logp, const uint8_t *live, float *dlogits,
                          int N, int L, int T, int V1, void *stream);
 
+/* Sparse form of the same gradient: every criterion of the hot path reads the dense
+ * log-probs only through ONE entry per (row, step) -- `input.gather(2, target)` at losses.py:24 (RewardCriterion), :81
+ * (StructureLosses), :213 (LanguageModelCriterion) -- and, for LabelSmoothing (:258-262), through the row sum.  With
+ *   g_sel [N,L] = dL / d logp[r,t,tok[r,t]]   (NULL: none)      tok [N,tok_ld] int64, tok_ld >= T
+ *   g_sum [N,L] = dL / d sum_v logp[r,t,v]    (NULL: none)
+ * the gradient w.r.t. the logits is  g_sel (onehot(tok) - p) + g_sum (1 - V1 p),  p = exp(logp); an additional dense
+ * gradient `g` [N,L,V1] (NULL: none) is added in its dense form.  The [N,L,V1] gradient tensor of the reference's autograd
+ * (zero fill + scatter) is never materialised. */
+typedef struct capmi_sparse_logp_grad {
+    const float *g_sel;
+    const float *g_sum;
+    const int64_t *tok;
+    int tok_ld;
+} capmi_sparse_logp_grad;
+int capmi_logsoftmax_bwd_sparse(const capmi_sparse_logp_grad *sp, const float *g, const float *seq_logp,
+                                const uint8_t *live, float *dlogits, int N, int L, int T, int V1, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Elementwise helpers
  * ------------------------------------------------------------------------------------------- */
@@ -403,9 +420,10 @@ typedef struct capmi_updown_bwd_scratch {
     float *w_att_cat;   /* [4R,2R]  = [att W_ih(:, 0:R) | att W_hh] */
     float *partial;
     int64_t partial_capacity;
+    const capmi_sparse_logp_grad *sparse;   /* NULL, or the loss gradient in sparse form (then g_seq_logp may be NULL) */
 } capmi_updown_bwd_scratch;
 
-/* g_seq_logp [N,T,V1]: gradient w.r.t. the dense log-probs returned by the forward. */
+/* g_seq_logp [N,T,V1]: gradient w.r.t. the dense log-probs returned by the forward (NULL when s->sparse carries it). */
 int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_rollout *r,
                              const float *g_seq_logp, capmi_updown_bwd_scratch *s,
                              capmi_updown_grads *g, void *stream);
@@ -614,6 +632,7 @@ typedef struct capmi_newfc_bwd_scratch {
     float *d_x_all;   /* [T,N,E]  */
     float *d_ximg;    /* [N,E]    */
     float *partial; int64_t partial_capacity;
+    const capmi_sparse_logp_grad *sparse;   /* as in capmi_updown_bwd_scratch */
 } capmi_newfc_bwd_scratch;
 
 int capmi_newfc_rollout_fwd(const capmi_newfc_weights *w, capmi_newfc_rollout *r, void *stream);

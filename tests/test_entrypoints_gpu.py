@@ -63,6 +63,8 @@ def test_resume_restores_optimizer_schedule_counters_and_loader(tmp_path):
     # (not bitwise: the embedding gradient is scattered with float atomics; a restart of the warm-up / of Adam's moments
     # would move the parameters by ~1e-2 with this learning rate)
     for k in pa:
+        if k == 'core.attention.alpha_net.bias':
+            continue      # its gradient is mathematically zero (softmax shift invariance): Adam normalises rounding noise to +-lr
         assert float((pa[k] - pb[k]).abs().max()) < 2e-5, (k, float((pa[k] - pb[k]).abs().max()))
     assert torch.load(b / 'optimizer.pth', weights_only=False)['flat']['step_count'] == 8
 

@@ -1,0 +1,180 @@
+"""The loss gradient travels from the criteria to the rollout backward in SPARSE form (selected-token gradient [N,L] + token ids
+[+ row-sum gradient for label smoothing]) instead of a dense [N,L,V1] tensor (reference
+losses.py:24, :81, :213, :258-262).  The results must equal the dense route exactly up to summation order."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def test_kernel_sparse_equals_dense_formula():
+    import ctypes as C
+    from imagecaptioning.pytorch_amd import _lib, ops
+    from imagecaptioning.pytorch_amd._lib import ptr
+    g = torch.Generator(device='cpu').manual_seed(0)
+    N, L, T, V1 = 7, 6, 5, 9488
+    logp = torch.log_softmax(torch.randn(N, L, V1, generator=g), 2).to(DEV)
+    live = (torch.rand(N, L, generator=g) > 0.2).to(torch.uint8).to(DEV)
+    tok = torch.randint(0, V1, (N, L), generator=g).to(DEV)
+    a = torch.randn(N, L, generator=g).to(DEV)
+    b = (torch.randn(N, L, generator=g) * 1e-3).to(DEV)
+    dense_extra = (torch.randn(N, L, V1, generator=g) * 1e-3).to(DEV)
+    for use_b, use_dense in ((False, False), (True, False), (True, True)):
+        gd = torch.zeros(N, L, V1, device=DEV)
+        gd.scatter_(2, tok.unsqueeze(2), a.unsqueeze(2))
+        if use_b:
+            gd += b.unsqueeze(2)
+        if use_dense:
+            gd += dense_extra
+        want = torch.empty(T, N, V1, device=DEV)
+        ops.logsoftmax_bwd(gd, None, logp, live, want, N, L, T, V1)
+        sp = _lib.SparseLogpGrad()
+        sp.g_sel, sp.tok, sp.tok_ld = ptr(a), ptr(tok), L
+        sp.g_sum = ptr(b) if use_b else None
+        got = torch.full((T, N, V1), float('nan'), device=DEV)
+        ops.logsoftmax_bwd(dense_extra if use_dense else None, sp, logp, live, got, N, L, T, V1)
+        assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-9
+        # against the definition, in float64
+        p = logp.double().exp()
+        ref = gd.double() - p * gd.double().sum(2, keepdim=True)
+        ref = ref * live.unsqueeze(2).double()
+        assert float((got.double() - ref[:, :T].transpose(0, 1)).abs().max()) < 1e-6
+
+
+def _grads(model):
+    return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+
+def _check_same(ga, gb):
+    floor = 1e-7 * max(float(v.abs().max()) for v in gb.values())      # gradients that are mathematically zero hold rounding noise
+    for k in ga:
+        scale = float(gb[k].abs().max())
+        assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * scale + floor, k
+
+
+@pytest.mark.parametrize('family', ['updown', 'newfc', 'transformer', 'aoa'])
+@pytest.mark.parametrize('crit_name', ['xe', 'ls'])
+def test_xe_and_label_smoothing_sparse_route_equals_dense_route(family, crit_name):
+    from test_model_api_gpu import tiny_opt
+    from imagecaptioning.pytorch_amd import sparse_logp
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import LanguageModelCriterion, LabelSmoothing
+    u = np.load(os.path.join(GOLDEN, 'updown_tiny.npz'))
+    z = np.load(os.path.join(GOLDEN, family + '_tiny.npz'))
+    kw = {'updown': {}, 'newfc': dict(caption_model='newfc'),
+          'transformer': dict(caption_model='transformer', N_enc=2, N_dec=2, d_model=16, d_ff=32, num_att_heads=2, dropout=0.0),
+          'aoa': dict(caption_model='aoa', refine=1, refine_aoa=1, use_ff=0, decoder_type='AoA', use_multi_head=2, num_heads=2,
+                      multi_head_scale=1, mean_feats=1, ctx_drop=1, dropout_aoa=0.3, num_layers=2)}[family]
+    model = models.setup(tiny_opt(**kw))
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('P.')})
+    model = model.to(DEV)
+    model.eval() if family == 'aoa' else model.train()
+    fc, att, am = (torch.from_numpy(u[k]).to(DEV) for k in ('fc', 'att', 'att_masks'))
+    labels, masks = torch.from_numpy(u['labels']).to(DEV), torch.from_numpy(u['masks']).to(DEV)
+    crit = LanguageModelCriterion() if crit_name == 'xe' else LabelSmoothing(smoothing=0.2)
+    taken = []
+    orig = sparse_logp.split_grad
+
+    def spy(g_logp, sink, like=None):
+        out = orig(g_logp, sink, like)
+        taken.append((out[0] is None, out[1] is not None))
+        return out
+    sparse_logp.split_grad = spy
+    try:
+        model.zero_grad()
+        logp = model(fc, att, labels[..., :-1], am)
+        assert getattr(logp, '_capmi_sink', None) is not None
+        loss_s = crit(logp, labels[..., 1:], masks[..., 1:])
+        loss_s.backward()
+        g_sparse = _grads(model)
+        assert taken == [(True, True)], taken            # no dense gradient reached the rollout, a sparse one did
+        model.zero_grad()
+        logp = model(fc, att, labels[..., :-1], am) * 1.0       # a plain tensor: the dense route (gather + autograd scatter)
+        loss_d = crit(logp, labels[..., 1:], masks[..., 1:])
+        loss_d.backward()
+        assert taken[-1] == (False, False)
+    finally:
+        sparse_logp.split_grad = orig
+    assert abs(loss_s.item() - loss_d.item()) < 1e-6
+    _check_same(g_sparse, _grads(model))
+
+
+def test_scst_reward_criterion_sparse_route_and_mixed_dense_use():
+    """RewardCriterion on a sampled rollout (the SCST step) + an entropy-like term that reads the dense tensor: the sparse and
+    the dense gradient parts are added in the rollout backward."""
+    from test_model_api_gpu import golden_model
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import RewardCriterion
+    z, model = golden_model(True)
+    model.train()
+    fc, att, am = (torch.from_numpy(z[k]).to(DEV) for k in ('fc', 'att', 'att_masks'))
+    forced = torch.from_numpy(z['sample_seq']).to(DEV)
+    reward = torch.from_numpy(z['sample_reward']).to(DEV)
+
+    def run(dense_route, with_entropy):
+        model.zero_grad()
+        seq, logp = model(fc, att, am, opt={'sample_method': 'sample', 'sample_n': 2, 'temperature': 1.3, '_forced_seq': forced},
+                          mode='sample')
+        lp = logp * 1.0 if dense_route else logp
+        loss = RewardCriterion()(lp, seq, reward)
+        if with_entropy:
+            loss = loss + 1e-3 * (logp.exp() * logp).sum(2).mean()
+        loss.backward()
+        return loss.item(), _grads(model)
+    l0, g0 = run(False, False)
+    np.testing.assert_allclose(l0, z['rl_loss'], rtol=1e-5)
+    for k, p in g0.items():
+        ref = z['rl_grad.' + k]
+        np.testing.assert_allclose(p.cpu().numpy(), ref, rtol=5e-4, atol=1e-6 + 2e-5 * np.abs(ref).max(), err_msg=k)
+    l1, g1 = run(True, False)
+    _check_same(g0, g1)
+    l2, g2 = run(False, True)
+    l3, g3 = run(True, True)
+    assert abs(l2 - l3) < 1e-6
+    _check_same(g2, g3)
+
+
+def test_transformer_scst_masked_logprobs_keep_the_sparse_route():
+    from test_model_api_gpu import tiny_opt
+    from imagecaptioning.pytorch_amd import sparse_logp
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import RewardCriterion
+    u = np.load(os.path.join(GOLDEN, 'updown_tiny.npz'))
+    z = np.load(os.path.join(GOLDEN, 'transformer_tiny.npz'))
+    model = models.setup(tiny_opt(caption_model='transformer', N_enc=2, N_dec=2, d_model=16, d_ff=32, num_att_heads=2, dropout=0.0))
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('P.')})
+    model = model.to(DEV)
+    model.train()
+    att = torch.from_numpy(u['att']).to(DEV)
+    torch.manual_seed(3)
+    model._rng_calls = 5
+    seq, logp = model(None, att, None, opt={'sample_method': 'sample', 'sample_n': 2}, mode='sample')
+    assert getattr(logp, '_capmi_masked', None) is not None
+    reward = torch.randn(seq.shape[0], 1, device=DEV).expand(-1, seq.shape[1])
+    taken = []
+    orig = sparse_logp.split_grad
+
+    def spy(g_logp, sink, like=None):
+        out = orig(g_logp, sink, like)
+        taken.append((out[0] is None, out[1] is not None))
+        return out
+    sparse_logp.split_grad = spy
+    try:
+        model.zero_grad()
+        loss = RewardCriterion()(logp, seq, reward)
+        loss.backward()
+        gs = _grads(model)
+        assert taken == [(True, True)]
+        model.zero_grad()
+        model._rng_calls = 5
+        seq2, logp2 = model(None, att, None, opt={'sample_method': 'sample', 'sample_n': 2}, mode='sample')
+        assert torch.equal(seq, seq2)
+        RewardCriterion()(logp2 * 1.0, seq2, reward).backward()
+    finally:
+        sparse_logp.split_grad = orig
+    _check_same(gs, _grads(model))
