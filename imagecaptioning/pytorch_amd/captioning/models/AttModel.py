@@ -283,7 +283,7 @@ class AttModel(CaptionModel):
         if _gumbel is not None:
             cfg['gumbel'] = _gumbel
         seq, logp = self._run(cfg, fc_feats, att_feats, att_masks)
-        return seq[N:], seq[:N], logp[:N]
+        return seq[N:], seq[:N], sparse_logp.attach_rows(logp[:N], logp)
 
     def _sample_beam(self, fc_feats, att_feats, att_masks=None, opt={}):
         from imagecaptioning.pytorch_amd.beam import sample_beam

@@ -269,6 +269,199 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
     }
 }
 
+
+// ---- forward, round 2: every global load of the launch is issued before the first one is consumed ------------------------
+// The kernel above is a chain of dependent round trips (h2att slabs -> barrier -> 5 regions of p_att -> barrier -> softmax ->
+// three trips over att): 14 us for 4.7 MB at the SCST shape, every trip paying 1-2 us of L2 / Infinity-Cache latency.  None of
+// those loads depends on a computed value: the addresses of the slabs, of the p_att tile and of the att tile are known at
+// entry.  Here a thread issues, in the order it will need them,
+//     <= 4 x 16 B of h2att K-slice slabs | 5 regions x 2 x 16 B of p_att | 18 regions x 16 B of att      (K <= 36 ... 40)
+// branch-free (clamped addresses, invalid lanes zeroed afterwards, so the compiler's s_waitcnt vmcnt(n) stays exact) and only
+// then reduces the slabs, scores, normalises and accumulates the context out of registers: ONE memory round trip per launch.
+// Shapes outside the fast path (A > 512, R > 1024, K > 40, unaligned) keep the kernel above.
+constexpr int V2_KMAX = 40;          // regions held in registers: 5 score regions per wave x 8 waves, 20 att rows per half
+constexpr int V2_SREG = 5, V2_CREG = 20;
+template <int NR>      // rows per workgroup held in registers (1 or 2; larger groups use the kernel above)
+__global__ __launch_bounds__(ATT_THREADS) void attention_fwd_v2_kernel(
+    const float *__restrict__ att_h, const float *__restrict__ p_att, const float *__restrict__ att,
+    const float *__restrict__ mask, const float *__restrict__ w, const float *__restrict__ bptr,
+    float *__restrict__ ctx, float *__restrict__ alpha, int B, int n_img, int rpb, int chunks, int K, int A, int R,
+    const int *__restrict__ row_img, int h_splits, size_t h_stride, const float *__restrict__ h_bias,
+    float *__restrict__ att_h_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *s_h = lds;                         // [NR][512]; later the context combine buffer [NR][1024]
+    float *s_e = lds + (size_t)NR * 1024;     // [NR][V2_KMAX]
+    float *s_p = s_e + NR * V2_KMAX;          // [4][NR * 512] slab partial sums of the four slab groups
+    int b, chunk, row0, n;
+    if (row_img) {
+        row0 = blockIdx.x;
+        n = 1;
+        b = row_img[row0];
+    } else {
+        if (!decode_block(B, chunks, b, chunk)) return;
+        row0 = b * n_img + chunk * rpb;
+        n = min(rpb, n_img - chunk * rpb);
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nA4 = (n * A) >> 2;                                   // 16-byte pieces of this workgroup's att_h rows
+
+    // ---- issue everything -------------------------------------------------------------------------------------------
+    // (a) att_h: thread t owns piece t % 128 (+128 i) of the rows and slab group t / 128 (4 groups): <= 4 loads per piece
+    const int sgrp = threadIdx.x >> 7, pc0 = threadIdx.x & 127;
+    const int per_grp = h_splits > 0 ? (h_splits + 3) >> 2 : 1;     // slabs per group (<= 4 handled in registers)
+    f32x4 hv[NR][4];
+    const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int pc = pc0 + 128 * i;
+        const int pcc = min(pc, max(nA4 - 1, 0));
+        const float *p = att_h + (size_t)row0 * A + (size_t)pcc * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            hv[i][u] = zz;
+            if (i < n) {      // n is workgroup-uniform: no divergence, and unused rows cost no loads
+                const int sl = h_splits > 0 ? min(sgrp * per_grp + u, h_splits - 1) : 0;
+                hv[i][u] = *reinterpret_cast<const f32x4 *>(p + (size_t)sl * h_stride);
+            }
+        }
+    }
+    // (b) p_att: wave w scores regions w, w + 8, ...; lane covers a = 4 lane and 4 lane + 256
+    const float *pb = p_att + (size_t)b * K * A;
+    const int a0 = lane * 4, a1c = min(a0 + 256, A - 4);
+    const int a0c = min(a0, A - 4);
+    f32x4 p0[V2_SREG], p1[V2_SREG];
+#pragma unroll
+    for (int g = 0; g < V2_SREG; ++g) {
+        const int k = min(wid + 8 * g, K - 1);
+        p0[g] = *reinterpret_cast<const f32x4 *>(pb + (size_t)k * A + a0c);
+        p1[g] = *reinterpret_cast<const f32x4 *>(pb + (size_t)k * A + a1c);
+    }
+    // (c) att: thread (cg, half) owns columns 4 cg .. 4 cg + 3 and regions half, half + 2, ...
+    const float *ab = att + (size_t)b * K * R;
+    const int cg = threadIdx.x & 255, half = threadIdx.x >> 8;
+    const int r = cg * 4, rc = min(r, R - 4);
+    f32x4 av[V2_CREG];
+#pragma unroll
+    for (int g = 0; g < V2_CREG; ++g) {
+        const int k = min(half + 2 * g, K - 1);
+        av[g] = *reinterpret_cast<const f32x4 *>(ab + (size_t)k * R + rc);
+    }
+    const f32x4 w0 = *reinterpret_cast<const f32x4 *>(w + a0c), w1 = *reinterpret_cast<const f32x4 *>(w + a1c);
+    const float bias = bptr ? bptr[0] : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- att_h: finish the split-K reduction (+ bias), keep the rows for the backward pass ------------------------------
+    if (h_splits > 0) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int pc = pc0 + 128 * i;
+            if (i < n && pc < nA4) {
+                f32x4 v = zz;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u < per_grp && sgrp * per_grp + u < h_splits) v += hv[i][u];
+                *reinterpret_cast<f32x4 *>(s_p + (size_t)sgrp * NR * 512 + pc * 4) = v;
+            }
+        }
+        __syncthreads();
+        for (int pc = threadIdx.x; pc < nA4; pc += ATT_THREADS) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(s_p + pc * 4);
+#pragma unroll
+            for (int q = 1; q < 4; ++q) v += *reinterpret_cast<const f32x4 *>(s_p + (size_t)q * NR * 512 + pc * 4);
+            if (h_bias) v += *reinterpret_cast<const f32x4 *>(h_bias + (pc * 4) % A);
+            *reinterpret_cast<f32x4 *>(s_h + pc * 4) = v;
+            if (att_h_out) *reinterpret_cast<f32x4 *>(att_h_out + (size_t)row0 * A + pc * 4) = v;
+        }
+    } else {
+        if (sgrp == 0) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int pc = pc0 + 128 * i;
+                if (i < n && pc < nA4) *reinterpret_cast<f32x4 *>(s_h + pc * 4) = hv[i][0];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- scores -------------------------------------------------------------------------------------------------------
+    const bool v0 = a0 < A, v1 = a0 + 256 < A;
+#pragma unroll
+    for (int g = 0; g < V2_SREG; ++g) {
+        const int k = wid + 8 * g;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            if (j < n) {
+                float acc = 0.f;
+                const f32x4 h0 = *reinterpret_cast<const f32x4 *>(s_h + j * A + a0c);
+                const f32x4 h1 = *reinterpret_cast<const f32x4 *>(s_h + j * A + a1c);
+                const float t0 = w0[0] * tanh_f(p0[g][0] + h0[0]) + w0[1] * tanh_f(p0[g][1] + h0[1]) +
+                                 w0[2] * tanh_f(p0[g][2] + h0[2]) + w0[3] * tanh_f(p0[g][3] + h0[3]);
+                const float t1 = w1[0] * tanh_f(p1[g][0] + h1[0]) + w1[1] * tanh_f(p1[g][1] + h1[1]) +
+                                 w1[2] * tanh_f(p1[g][2] + h1[2]) + w1[3] * tanh_f(p1[g][3] + h1[3]);
+                acc = (v0 ? t0 : 0.f) + (v1 ? t1 : 0.f);
+                const float e = wave_sum(acc) + bias;
+                if (lane == 0 && k < K) s_e[j * V2_KMAX + k] = e;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- softmax over regions (+ mask renormalisation), one wave per row ---------------------------------------------------
+    for (int j = wid; j < n; j += 8) {
+        float *e = s_e + j * V2_KMAX;
+        const float x = lane < K ? e[lane] : -INFINITY;            // K <= 40 < 64: one element per lane
+        const float m = wave_max(x);
+        float ex = lane < K ? __expf(x - m) : 0.f;
+        const float inv = 1.f / wave_sum(ex);
+        ex *= inv;
+        if (mask) {
+            ex *= lane < K ? mask[(size_t)b * K + lane] : 0.f;
+            ex = ex / wave_sum(ex);
+        }
+        if (lane < K) {
+            e[lane] = ex;
+            alpha[(size_t)(row0 + j) * K + lane] = ex;
+        }
+    }
+    __syncthreads();
+
+    // ---- context out of registers ------------------------------------------------------------------------------------------
+    float c0[NR], c1[NR], c2[NR], c3[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) c0[j] = c1[j] = c2[j] = c3[j] = 0.f;
+#pragma unroll
+    for (int g = 0; g < V2_CREG; ++g) {
+        const int k = half + 2 * g;
+        if (k < K) {              // workgroup-half-uniform
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                if (j < n) {
+                    const float al = s_e[j * V2_KMAX + k];
+                    c0[j] += al * av[g][0]; c1[j] += al * av[g][1]; c2[j] += al * av[g][2]; c3[j] += al * av[g][3];
+                }
+            }
+        }
+    }
+    __syncthreads();                          // s_h is dead: reuse it as the combine buffer [NMAX][1024]
+    float *s_c = s_h;
+    if (half == 1 && r < R) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+            if (j < n) *reinterpret_cast<f32x4 *>(s_c + j * 1024 + r) = f32x4{c0[j], c1[j], c2[j], c3[j]};
+    }
+    __syncthreads();
+    if (half == 0 && r < R) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            if (j < n) {
+                const f32x4 o = *reinterpret_cast<const f32x4 *>(s_c + j * 1024 + r);
+                *reinterpret_cast<f32x4 *>(ctx + (size_t)(row0 + j) * R + r) =
+                    f32x4{c0[j] + o[0], c1[j] + o[1], c2[j] + o[2], c3[j] + o[3]};
+            }
+        }
+    }
+}
+
 // ---- backward, one step: d_ctx -> d_e, d_att_h ------------------------------------------------
 // With or without the mask renormalisation the softmax-input gradient is
 //   d_e[k] = alpha[k] * (dalpha[k] - sum_k' alpha[k'] dalpha[k'])   (alpha = the FINAL weights),
@@ -521,6 +714,30 @@ static int attention_fwd_launch(const float *att_h, int h_splits, int64_t h_stri
     const double abytes = 4.0 * ((double)B * K * (A + R) + (double)N * (A + R + K));
     const int rpb = row_img ? 1 : pick_rpb(B, n), chunks = row_img ? 1 : (n + rpb - 1) / rpb;
     hipEvent_t e0, e1;
+    // round-2 kernel: all loads up front, one memory round trip (BASELINE shapes: K = 36, A = 512, R = 1000)
+    static const int env_v2 = [] { const char *e = getenv("CAPMI_ATT_V2"); return e ? atoi(e) : 1; }();
+    const bool al16 = ((reinterpret_cast<uintptr_t>(att_h) | reinterpret_cast<uintptr_t>(p_att) | reinterpret_cast<uintptr_t>(att) |
+                        reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(h_bias) |
+                        reinterpret_cast<uintptr_t>(att_h_out)) & 15) == 0;
+    // (latency regime only: with more workgroups than CUs the 188-VGPR kernel's single resident workgroup per CU loses to
+    //  the occupancy of the kernel above -- measured 27.8 vs 21.7 us at B = 512, 51 vs 37 us at B = 1024)
+    if (env_v2 && al16 && rpb <= 2 && (row_img ? N : grid_blocks(B, chunks)) <= 256 && K <= V2_KMAX && A % 4 == 0 && A >= 4 && A <= 512 && R % 4 == 0 && R >= 4 && R <= 1024 &&
+        h_splits <= 16 && (h_stride & 3) == 0) {
+        const size_t lds2 = ((size_t)rpb * 1024 + (size_t)rpb * V2_KMAX + (size_t)4 * rpb * 512) * sizeof(float);
+        const bool prof = capmi_prof::take_events(CAPMI_PROF_ATTENTION_FWD, &e0, &e1, abytes, (double)N * K * (2.0 * A + 2.0 * R));
+        const dim3 grid(row_img ? N : grid_blocks(B, chunks));
+#define CAPMI_ATT_V2(NR_)                                                                                                   \
+        if (prof) hipExtLaunchKernelGGL(attention_fwd_v2_kernel<NR_>, grid, dim3(ATT_THREADS), lds2, (hipStream_t)stream, e0,   \
+                                        e1, 0, att_h, p_att, att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K, A, R, row_img,  \
+                                        h_splits, (size_t)h_stride, h_bias, att_h_out);                                        \
+        else hipLaunchKernelGGL(attention_fwd_v2_kernel<NR_>, grid, dim3(ATT_THREADS), lds2, (hipStream_t)stream, att_h, p_att, \
+                                att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K, A, R, row_img, h_splits, (size_t)h_stride,   \
+                                h_bias, att_h_out)
+        if (rpb == 1) { CAPMI_ATT_V2(1); } else { CAPMI_ATT_V2(2); }
+#undef CAPMI_ATT_V2
+        CAPMI_CHECK_LAUNCH();
+        return 0;
+    }
     if (capmi_prof::take_events(CAPMI_PROF_ATTENTION_FWD, &e0, &e1, abytes, (double)N * K * (2.0 * A + 2.0 * R)))
         hipExtLaunchKernelGGL(attention_fwd_kernel, dim3(row_img ? N : grid_blocks(B, chunks)), dim3(ATT_THREADS), lds,
                               (hipStream_t)stream, e0, e1, 0, att_h, p_att, att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K,

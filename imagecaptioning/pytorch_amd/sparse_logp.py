@@ -75,8 +75,19 @@ def attach_masked(out, parent, row_mask):
     return out
 
 
+def attach_rows(out, parent):
+    """`out` = parent[:out.shape[0]] (the sampled rows of the fused SCST rollout, whose greedy-baseline rows ride in the same
+    tensor): gathers on `out` are served from `parent` with the remaining rows padded (token 0, zero gradient)."""
+    out._capmi_rows = parent
+    return out
+
+
 def select_logp(logp, idx):
     """logp[r, t, idx[r, t]] for idx [N, T] int64 (T == logp.shape[1]); sparse gradient when the tensor carries a sink."""
+    parent = getattr(logp, '_capmi_rows', None)
+    if parent is not None and idx.shape == logp.shape[:2]:
+        pad = idx.new_zeros(parent.shape[0] - idx.shape[0], idx.shape[1])
+        return select_logp(parent, torch.cat([idx, pad], 0))[:idx.shape[0]]
     masked = getattr(logp, '_capmi_masked', None)
     if masked is not None and idx.shape == logp.shape[:2]:
         parent, row_mask = masked
