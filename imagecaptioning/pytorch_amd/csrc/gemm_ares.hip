@@ -87,7 +87,7 @@ __device__ __forceinline__ void load_b(float (&b)[16], const TileRef *tp, int co
     do {                                                                                                           \
         if ((ABL & 16) && lane == 0 && (wid & 3) == 0) {                                                           \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
-            reinterpret_cast<unsigned long long *>(a.counters)[((blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wid >> 2)) * 9 + (slot)] = \
+            reinterpret_cast<unsigned long long *>(a.counters)[((blockIdx.y * gridDim.x + blockIdx.x) * 2 + (wid >> 2)) * 10 + (slot)] = \
                 __builtin_readcyclecounter();                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
         }                                                                                                          \
@@ -96,7 +96,13 @@ __device__ __forceinline__ void load_b(float (&b)[16], const TileRef *tp, int co
 // TM = 1: M <= 32 (one accumulator chain, 32 staged rows); TM = 2: M <= 64
 // ABL (profiling builds of the <true,6,2,x3> shape only, CAPMI_ARES_ABLATE): 1 = no activation loads, 2 = no split / MFMA,
 // 4 = no weight loads, 8 = no K-half reduction / stores.  Never for results.
-template <bool BKC, int TS, int TM, bool X3, int ABL = 0>
+// DIRECT (round 2, bf16x3 path).  The phase trace showed the tile table costing 2.4k cycles before the activation loads -- which
+// then need another 5-10k cycles to arrive -- could even be issued: per-lane indexing of the kernel-argument segment array had
+// become a chain of dependent GLOBAL loads plus an integer division.  Here the segment fields are pinned in SGPRs (s_load), the
+// table entries are resolved by value selects against host-computed tile starts / reciprocals, and only ONE weight chunk per
+// wave is requested ahead of the activations; the rest of the ring follows once they have landed (the full ring ahead of them
+// delayed their arrival from 5k to 10-13k cycles).
+template <bool BKC, int TS, int TM, bool X3, int ABL = 0, bool DIRECT = false>
 __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
     constexpr int ROWS = 32 * TM;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -128,7 +134,36 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
     const int colc = min(col, a.N - 1);
     CAPMI_STAMP(0);
 
-    if (threadIdx.x < SL) {
+    // segment fields as wave-uniform values (s_load from the kernel arguments, pinned in SGPRs)
+    const float *sgA[CAPMI_MAX_SEG], *sgB[CAPMI_MAX_SEG];
+    int sgLda[CAPMI_MAX_SEG], sgLdb[CAPMI_MAX_SEG], sgK[CAPMI_MAX_SEG], sgRdiv[CAPMI_MAX_SEG], sgT[CAPMI_MAX_SEG];
+    if (DIRECT) {
+#pragma unroll
+        for (int i = 0; i < CAPMI_MAX_SEG; ++i) {
+            sgA[i] = a.seg[i].A; sgB[i] = a.seg[i].B; sgLda[i] = a.seg[i].lda; sgLdb[i] = a.seg[i].ldb; sgK[i] = a.seg[i].K;
+            sgRdiv[i] = a.seg[i].rdiv; sgT[i] = a.seg[i].tstart;
+            asm volatile("" : "+s"(sgA[i]), "+s"(sgB[i]), "+s"(sgLda[i]), "+s"(sgLdb[i]), "+s"(sgK[i]), "+s"(sgRdiv[i]), "+s"(sgT[i]));
+        }
+    }
+    // tile (flat index) -> TileRef, by value selects (works per lane and, on uniform input, on the scalar unit)
+    auto resolve = [&](int tile) {
+        TileRef t;
+        const bool real = tile < a.tiles_total;
+        const int tl = real ? tile : 0;
+        const int s = (tl >= sgT[1] ? 1 : 0) + (tl >= sgT[2] ? 1 : 0) + (tl >= sgT[3] ? 1 : 0);
+#define CAPMI_SEL(F) (s == 3 ? F[3] : s == 2 ? F[2] : s == 1 ? F[1] : F[0])
+        const int k0 = (tl - CAPMI_SEL(sgT)) * 32;
+        const int K = CAPMI_SEL(sgK);
+        t.lda = CAPMI_SEL(sgLda); t.ldb = CAPMI_SEL(sgLdb); t.rdiv = CAPMI_SEL(sgRdiv);
+        t.A = CAPMI_SEL(sgA) + k0;
+        t.B = BKC ? CAPMI_SEL(sgB) + k0 : CAPMI_SEL(sgB) + (size_t)k0 * t.ldb;
+#undef CAPMI_SEL
+        t.arem = real ? K - k0 : 0;
+        t.brem = K - k0;
+        return t;
+    };
+    if (DIRECT && threadIdx.x < SL) tiles[threadIdx.x] = resolve(t0 + (int)threadIdx.x);
+    if (!DIRECT && threadIdx.x < SL) {
         int s = 0, k0 = 0;
         const bool real = t0 + (int)threadIdx.x < a.tiles_total;
         if (real) locate(a, t0 + threadIdx.x, s, k0);
@@ -150,6 +185,12 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
     __syncthreads();
     CAPMI_STAMP(1);
     const TileRef *mine = tiles + kh * TS;
+    // this wave's weight chunk u: from the LDS table, or resolved on the scalar unit (kh is wave-uniform)
+    const int khu = __builtin_amdgcn_readfirstlane(kh);
+    auto load_w = [&](float (&bb)[16], int u) {
+        load_b<BKC>(bb, &mine[u], colc, half);
+    };
+    (void)khu;
 
     // Loads return IN ORDER (vmcnt counts them so): the activation loads (L2 hits, all workgroups of a K slice read the
     // same rows) are issued FIRST and the weight prefetch ring right behind them, so the staging below waits for the
@@ -163,30 +204,54 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
     constexpr int NP = TS * TM;
     {
         f32x4 v[NP];
+        float okf[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int idx = j * AR_NT + (int)threadIdx.x;
             const int row = idx / quads, c4 = idx - row * quads;
-            const TileRef *tp = &tiles[c4 >> 3];
             const int k = (c4 & 7) * 4;
+            if (DIRECT) {
+                const TileRef t = tiles[c4 >> 3];
+                okf[j] = (row < a.M && k < t.arem) ? 1.f : 0.f;
+                const int off = (int)okf[j] * (((row * t.rdiv) >> 16) * t.lda + k);
+                v[j] = *(gcf4)(as_global(t.A) + off);
+                continue;
+            }
+            const TileRef *tp = &tiles[c4 >> 3];
             const bool ok = row < a.M && k < tp->arem;
             gcf p = as_global(tp->A) + (ok ? (size_t)((row * tp->rdiv) >> 16) * tp->lda + k : 0);
             if (ABL & 1) v[j] = f32x4{1.f, 2.f, 3.f, (float)j}; else
             v[j] = *(gcf4)p;
         }
         __builtin_amdgcn_sched_barrier(0);
+        constexpr int PF0 = DIRECT ? 1 : PF;       // weight chunks requested ahead of the activations' arrival
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
+        for (int u = 0; u < PF0; ++u) {
             if (ABL & 4) { for (int q = 0; q < 16; ++q) b[u][q] = (float)(q + u + lane); }
-            else load_b<BKC>(b[u], &mine[u], colc, half);
+            else load_w(b[u], u);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
+            if (DIRECT) { v[j] *= okf[j]; continue; }
             const int idx = j * AR_NT + (int)threadIdx.x;
             const int row = idx / quads, c4 = idx - row * quads;
             const bool ok = row < a.M && (c4 & 7) * 4 < tiles[c4 >> 3].arem;
             v[j] *= ok ? 1.f : 0.f;                // multiply (not select) so the load stays unconditional
+        }
+        if (DIRECT) {                               // the activations are here: now fill the rest of the weight ring
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = PF0; u < PF; ++u) {
+                if (ABL & 4) { for (int q = 0; q < 16; ++q) b[u][q] = (float)(q + u + lane); }
+                else load_w(b[u], u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ABL & 16) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) asm volatile("" ::"v"(v[j][0]));
+            CAPMI_STAMP(9);
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -287,7 +352,7 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
     if (!X3) {
 #pragma unroll
         for (int c = 0; c < TS; ++c) {
-            if (c + PF < TS) load_b<BKC>(b[(c + PF) % (PF + 1)], &mine[c + PF], colc, half);
+            if (c + PF < TS) load_w(b[(c + PF) % (PF + 1)], c + PF);
             __builtin_amdgcn_sched_barrier(0);
             mma(b[c % (PF + 1)], c);
             __builtin_amdgcn_sched_barrier(0);
@@ -299,7 +364,7 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
         for (int c = 0; c < TS; ++c) {
             if (c + PF < TS) {
                 if (ABL & 4) { for (int q = 0; q < 16; ++q) b[(c + PF) % (PF + 1)][q] = (float)(q + c + lane); }
-                else load_b<BKC>(b[(c + PF) % (PF + 1)], &mine[c + PF], colc, half);
+                else load_w(b[(c + PF) % (PF + 1)], c + PF);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (ABL & 2) {
@@ -417,12 +482,39 @@ static int launch_ts(const KArgs &a, hipStream_t st, int pcls, double bytes, dou
     dim3 grid((a.N + AR_BN - 1) / AR_BN, a.splits);
     hipEvent_t e0, e1;
     const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
+    if constexpr (X3) {
+        if (a.ablate & 2) {                 // table-free direct addressing (CAPMI_ARES_OPT bit 1)
+            static bool dset = false;
+            if (!dset) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_ares_kernel<BKC, TS, TM, X3, 0, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                dset = true;
+            }
+            if constexpr (BKC && TS == 6 && TM == 2) {
+                static const int abl = [] { const char *e = getenv("CAPMI_ARES_ABLATE"); return e ? atoi(e) : 0; }();
+                if (abl == 16) {
+                    static bool tset = false;
+                    if (!tset) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_ares_kernel<BKC, TS, TM, X3, 16, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        tset = true;
+                    }
+                    hipLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM, X3, 16, true>), grid, dim3(AR_NT), lds, st, a);
+                    return 0;
+                }
+            }
+            if (prof) hipExtLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM, X3, 0, true>), grid, dim3(AR_NT), lds, st, e0, e1, 0, a);
+            else hipLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM, X3, 0, true>), grid, dim3(AR_NT), lds, st, a);
+            CAPMI_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if constexpr (BKC && TS == 6 && TM == 2 && X3) {
         static const int abl = [] { const char *e = getenv("CAPMI_ARES_ABLATE"); return e ? atoi(e) : 0; }();
         if (abl) {
 #define CAPMI_ABL(V) case V: { static bool set = false; if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_ares_kernel<BKC, TS, TM, X3, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
             hipLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM, X3, V>), grid, dim3(AR_NT), lds, st, a); return 0; }
-            switch (abl) { CAPMI_ABL(1) CAPMI_ABL(2) CAPMI_ABL(3) CAPMI_ABL(4) CAPMI_ABL(6) CAPMI_ABL(7) CAPMI_ABL(8) CAPMI_ABL(10) CAPMI_ABL(15) CAPMI_ABL(16) default: break; }
+            switch (abl) { CAPMI_ABL(1) CAPMI_ABL(2) CAPMI_ABL(3) CAPMI_ABL(4) CAPMI_ABL(6) CAPMI_ABL(7) CAPMI_ABL(8) CAPMI_ABL(10) CAPMI_ABL(15) CAPMI_ABL(16) CAPMI_ABL(20) default: break; }
 #undef CAPMI_ABL
         }
     }

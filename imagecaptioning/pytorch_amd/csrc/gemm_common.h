@@ -16,6 +16,8 @@ struct Seg {
     const float *A, *B;
     int lda, ldb, K, a_row_div;
     int vecA, vecB;   // 16-byte vector loads legal for this segment
+    int rdiv;         // ceil(65536 / a_row_div): row / a_row_div == (row * rdiv) >> 16 for row < 64
+    int tstart;       // index of this segment's first K tile in the flat tile list (INT_MAX for unused slots)
 };
 
 struct KArgs {

@@ -359,7 +359,13 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
         if (d->a_layout == 1 && o.a_row_div != 1) return CAPMI_EINVAL;
         o.vecA = aligned16(g.A) && (g.lda % 4 == 0);
         o.vecB = aligned16(g.B) && (g.ldb % 4 == 0);
+        o.rdiv = (65536 + o.a_row_div - 1) / o.a_row_div;
+        o.tstart = tiles;
         tiles += (g.K + BK - 1) / BK;
+    }
+    for (int s = d->nseg; s < CAPMI_MAX_SEG; ++s) {      // unused slots: never selected, but always valid to read
+        a.seg[s] = a.seg[0];
+        a.seg[s].tstart = 0x7fffffff;
     }
     a.tiles_total = tiles;
     static const int env_ablate = [] { const char *e = getenv("CAPMI_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
@@ -447,7 +453,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
             a.splits = splits;
             a.to_partial = (splits > 1 || d->defer_reduce) ? 1 : 0;
             a.self_reduce = 0;
-            static const int env_aopt = [] { const char *e = getenv("CAPMI_ARES_OPT"); return e ? atoi(e) : 0; }();
+            static const int env_aopt = [] { const char *e = getenv("CAPMI_ARES_OPT"); return e ? atoi(e) : 2; }();
             a.ablate = env_aopt;             // speed-only switches of the A-resident kernel (see gemm_ares.hip)
             if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > slab_cap)) return CAPMI_EINVAL;
             d->splits_used = splits;

@@ -156,7 +156,8 @@ __global__ void lstm_cell_bwd_kernel(const float *__restrict__ dh_a, int ld_a, c
 // 16-byte variant of the backward cell (R % 4 == 0, aligned operands: every BASELINE size): one thread per 4 outputs, one
 // wave per workgroup, slab loads BRANCH-FREE (index clamped, contribution multiplied by 0/1) so that a trip is a fixed run
 // of loads with exact vmcnt waits; same pairwise summation order as the scalar kernel (bit-identical).  5.5 -> 5.1 us; the
-// same treatment of the forward cell measured no gain (7.2 vs 7.5 us: launch + one memory round trip is the floor there).
+// same treatment of the forward cell measured no gain in round 1 (7.2 vs 7.5 us) and again in round 2 with all 32 slab
+// loads of a thread issued up front (7.1 vs 7.4 us): launch + one first-touch round trip is the floor there.
 __device__ __forceinline__ f32x4 slab_sum8(const float *p, int s0, int splits, size_t stride) {
     f32x4 part[8];
 #pragma unroll

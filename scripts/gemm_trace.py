@@ -27,16 +27,16 @@ def run(i):
 for i in range(12):
     run(i)
 torch.cuda.synchronize()
-t = ws.buf[:9216].view(torch.int32).cpu().numpy().view(np.uint64).reshape(256, 2, 9).astype(np.float64)
+t = ws.buf[:10240].view(torch.int32).cpu().numpy().view(np.uint64).reshape(256, 2, 10).astype(np.float64)
 ws.buf[:16384].zero_()
 t0 = t[:, :, 0].min()
 rel = (t - t0) / 100.0      # s_memtime ticks: 100 MHz constant clock on gfx9 -> 10 ns per tick?  printed raw below too
-names = ['entry', 'table+barrier', 'A staged (LDS written)', 'barrier', 'chunk 0 done', 'chunk 2 done', 'loop done', 'K-half reduce', 'slab stored']
-print('raw tick span of the launch: %.0f ticks' % (t.max() - t0))
+names = ['entry', 'table+barrier', 'A staged (LDS written)', 'barrier', 'chunk 0 done', 'chunk 2 done', 'loop done', 'K-half reduce', 'slab stored', 'A landed']
+# the cycle counters of different XCDs are not synchronised: report every stamp relative to ITS OWN wave's entry stamp
 for k in (0, 1):
-    print('wave kh=%d: phase end (ticks since first workgroup entry): median / min / max over 256 workgroups' % k)
-    for s_, nm in enumerate(names):
-        col = t[:, k, s_] - t0
-        if col.max() <= 0 or (k == 1 and s_ == 8):
+    print('wave kh=%d: cycles since the wave entered the kernel: median / min / max over 256 workgroups' % k)
+    for s_ in (1, 9, 2, 3, 4, 5, 6, 7, 8):
+        if k == 1 and s_ == 8:
             continue
-        print('  %-26s %8.0f %8.0f %8.0f' % (nm, np.median(col), col.min(), col.max()))
+        col = t[:, k, s_] - t[:, k, 0]
+        print('  %-26s %8.0f %8.0f %8.0f' % (names[s_], np.median(col), col.min(), col.max()))
