@@ -60,7 +60,12 @@ class UpDownGrads(C.Structure):
 
 
 class SparseLogpGrad(C.Structure):
-    _fields_ = [('g_sel', c_f), ('g_sum', c_f), ('tok', c_f), ('tok_ld', C.c_int)]
+    _fields_ = [('g_sel', c_f), ('g_sum', c_f), ('tok', c_f), ('tok_ld', C.c_int), ('scale', c_f)]
+
+
+class MaskDesc(C.Structure):
+    _fields_ = [('mask', c_f), ('count', C.c_int64), ('offset', C.c_uint64), ('row_len', C.c_int), ('rows', C.c_int),
+                ('keep_from', C.c_int)]
 
 
 class UpDownBwdScratch(C.Structure):
@@ -125,6 +130,9 @@ SIGNATURES = {
     'capmi_logsoftmax_bwd_sparse': [C.POINTER(SparseLogpGrad), _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'capmi_splitk_reduce': [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P],
     'capmi_dropout_mask': [_P, _I64, _F, _U64, _U64, _P],
+    'capmi_dropout_masks': [C.POINTER(MaskDesc), _I, _F, _U64, _P],
+    'capmi_rollout_init': [_P, _P, _P, _P, _I64, _P, _P, _I, _P],
+    'capmi_reward_criterion': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     'capmi_colsum': [_P, _I, _I, _I, _P, _I, _P],
     'capmi_group_rowsum': [_P, _I, _I64, _I, _I, _I, _P, _P],
     'capmi_relu_mask_bwd': [_P, _P, _P, _P, _I64, _P],

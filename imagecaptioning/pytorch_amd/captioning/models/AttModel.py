@@ -33,18 +33,26 @@ class _RolloutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, cfg, fc_feats, att_feats, att_masks, *params):
         P = dict(zip(model._param_names, [p.detach() for p in params]))
-        pr = engine.prepare(P, fc_feats, att_feats, att_masks, cfg.get('drop_fc'), cfg.get('drop_att'))
-        pr_run, extra = pr, {}
         if cfg.get('fused_greedy'):
             # fused SCST rollout: sampled rows read the train-mode (dropout) features, the greedy-baseline rows the
-            # eval-mode features of the same images -> 2B feature images, explicit row -> image map
-            pr_eval = engine.prepare(P, fc_feats, att_feats, att_masks)
+            # eval-mode features of the same images -> 2B feature images written side by side (no torch.cat), explicit
+            # row -> image map
+            B = fc_feats.shape[0]
+            K = att_feats.shape[1] if att_masks is None else int(att_masks.long().sum(1).max())
+            R, A = P['fc_embed.0.weight'].shape[0], P['ctx2att.weight'].shape[0]
+            dev = fc_feats.device
             pr_run = engine.Prepared()
-            pr_run.fc = torch.cat([pr.fc, pr_eval.fc], 0)
-            pr_run.att = torch.cat([pr.att, pr_eval.att], 0)
-            pr_run.p_att = torch.cat([pr.p_att, pr_eval.p_att], 0)
+            pr_run.fc = torch.empty(2 * B, R, dtype=torch.float32, device=dev)
+            pr_run.att = torch.empty(2 * B, K, R, dtype=torch.float32, device=dev)
+            pr_run.p_att = torch.empty(2 * B, K, A, dtype=torch.float32, device=dev)
+            pr = engine.prepare(P, fc_feats, att_feats, att_masks, cfg.get('drop_fc'), cfg.get('drop_att'),
+                                out=(pr_run.fc[:B], pr_run.att[:B], pr_run.p_att[:B]))
+            engine.prepare(P, fc_feats, att_feats, att_masks, out=(pr_run.fc[B:], pr_run.att[B:], pr_run.p_att[B:]))
             pr_run.att_masks = None if pr.att_masks is None else torch.cat([pr.att_masks, pr.att_masks], 0)
-            extra = dict(row_img=cfg['row_img'], B_grad=fc_feats.shape[0])
+            extra = dict(row_img=cfg['row_img'], B_grad=B)
+        else:
+            pr = engine.prepare(P, fc_feats, att_feats, att_masks, cfg.get('drop_fc'), cfg.get('drop_att'))
+            pr_run, extra = pr, {}
         ro = engine.Rollout(P, pr_run, n=cfg['n'], T=cfg['T'], L=cfg['L'], mode=cfg['mode'],
                             temperature=cfg.get('temperature', 1.0), drop_xt=cfg.get('drop_xt'),
                             drop_out=cfg.get('drop_out'), gumbel=cfg.get('gumbel'), seed=cfg.get('seed', 0),
@@ -52,7 +60,9 @@ class _RolloutFn(torch.autograd.Function):
                             top_k=cfg.get('top_k', 0), top_p=cfg.get('top_p', 0.0), ss_mode=cfg.get('ss_mode'), **extra)
         seq, seq_logp = ro.run()
         ctx.model, ctx.ro, ctx.pr, ctx.P = model, ro, pr, P
-        ctx.sink = cfg.get('_sink')
+        ctx.sink = sink = cfg.get('_sink')
+        if sink is not None:
+            sink.sel, sink.seq = ro.sel_logp, ro.seq        # what a fused criterion needs: selected log-probs + tokens
         ctx.set_materialize_grads(False)        # the dense log-prob gradient may be undefined (sparse route)
         ctx.mark_non_differentiable(seq)
         model._last_rollout = ro
@@ -157,18 +167,19 @@ class AttModel(CaptionModel):
         self._rng_calls += 1
         return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._rng_calls * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
-    def _dropout_masks(self, B, K, N, T, dev):
+    def _dropout_masks(self, B, K, N, T, dev, eval_rows_from=None):
         """Philox keep-masks for one rollout (dropout is ON in train mode, also while sampling:
-        loss_wrapper.py:63).  Returns dict of pre-scaled masks or {} in eval mode / p == 0."""
+        loss_wrapper.py:63), all four in ONE launch.  Returns dict of pre-scaled masks or {} in eval mode / p == 0.
+        eval_rows_from: caption rows >= this index run in eval mode (mask 1.0): the greedy rows of the fused SCST rollout."""
         p = self.drop_prob_lm
         if not self.training or p <= 0:
             return {}
         seed = self._next_seed()
         R, E = self.rnn_size, self.input_encoding_size
-        return dict(drop_fc=ops.dropout_mask((B, R), p, seed, 0, dev),
-                    drop_att=ops.dropout_mask((B, K, R), p, seed, 1 << 40, dev),
-                    drop_xt=ops.dropout_mask((T, N, E), p, seed, 2 << 40, dev),
-                    drop_out=ops.dropout_mask((T, N, R), p, seed, 3 << 40, dev))
+        fc, att, xt, out = ops.dropout_masks([((B, R), 0, None, dev), ((B, K, R), 1 << 40, None, dev),
+                                              ((T, N, E), 2 << 40, eval_rows_from, dev),
+                                              ((T, N, R), 3 << 40, eval_rows_from, dev)], p, seed)
+        return dict(drop_fc=fc, drop_att=att, drop_xt=xt, drop_out=out)
 
     def _run(self, cfg, fc_feats, att_feats, att_masks):
         self._device_check(fc_feats)
@@ -272,18 +283,27 @@ class AttModel(CaptionModel):
         was_training = self.training
         self.train()                               # dropout masks for the sampled rows
         cfg = dict(n=n, T=L, L=L, mode='sample', temperature=temperature, seed=self._next_seed(), fused_greedy=True)
-        cfg.update(self._dropout_masks(B, K, N + B, L, dev))
+        cfg.update(self._dropout_masks(B, K, N + B, L, dev, eval_rows_from=N))     # greedy rows: eval mode
         self.train(was_training)
-        for k in ('drop_xt', 'drop_out'):
-            if k in cfg:
-                cfg[k][:, N:] = 1.0                 # greedy rows: eval mode
-        cfg['row_img'] = torch.cat([torch.arange(N, device=dev) // n, B + torch.arange(B, device=dev)]).to(torch.int32)
-        cfg['row_mode'] = torch.cat([torch.ones(N, dtype=torch.uint8, device=dev),
-                                     torch.zeros(B, dtype=torch.uint8, device=dev)])
+        cfg['row_img'], cfg['row_mode'] = self._fused_maps(B, n, dev)
         if _gumbel is not None:
             cfg['gumbel'] = _gumbel
         seq, logp = self._run(cfg, fc_feats, att_feats, att_masks)
-        return seq[N:], seq[:N], sparse_logp.attach_rows(logp[:N], logp)
+        gen = seq[:N]
+        gen._capmi_all = seq             # sampled rows first, greedy rows behind them: the reward kernel scores them in place
+        return seq[N:], gen, sparse_logp.attach_rows(logp[:N], logp)
+
+    def _fused_maps(self, B, n, dev):
+        """row -> feature image and row -> mode of the fused SCST rollout (cached per shape: built once, not per step)"""
+        cache = self.__dict__.setdefault('_fused_map_cache', {})
+        key = (B, n, str(dev))
+        if key not in cache:
+            N = B * n
+            row_img = torch.cat([torch.arange(N, device=dev) // n, B + torch.arange(B, device=dev)]).to(torch.int32)
+            row_mode = torch.cat([torch.ones(N, dtype=torch.uint8, device=dev), torch.zeros(B, dtype=torch.uint8, device=dev)])
+            hyp_img = torch.cat([torch.arange(N, device=dev) // n, torch.arange(B, device=dev)]).to(torch.int32)
+            cache[key] = (row_img, row_mode, hyp_img)
+        return cache[key][:2]
 
     def _sample_beam(self, fc_feats, att_feats, att_masks=None, opt={}):
         from imagecaptioning.pytorch_amd.beam import sample_beam

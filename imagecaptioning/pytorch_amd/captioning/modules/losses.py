@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from ..utils.rewards import get_scores
-from imagecaptioning.pytorch_amd.sparse_logp import select_logp, sum_logp
+from imagecaptioning.pytorch_amd.sparse_logp import select_logp, sum_logp, fused_reward_criterion
 
 
 def _shifted_mask(seq, like):
@@ -20,6 +20,10 @@ class RewardCriterion(nn.Module):
     """losses.py:18-37."""
 
     def forward(self, input, seq, reward, reduction='mean'):
+        # straight from the rollout's saved selected log-probs when `input` / `seq` are its untouched outputs: one launch
+        fused = fused_reward_criterion(input, seq, reward, per_row=(reduction == 'none'))
+        if fused is not None:
+            return fused
         sel = select_logp(input, seq)
         mask = _shifted_mask(seq, sel)
         out = -sel * reward.to(sel) * mask

@@ -78,8 +78,12 @@ def self_critical_reward_device(greedy_res, data_gts, gen_result, opt):
     B = len(data_gts)
     n = gen_result.shape[0] // B
     refs, n_refs = _pack(data_gts)
+    hyp_all = getattr(gen_result, '_capmi_all', None)        # fused SCST rollout: sampled + greedy rows already side by side
+    if hyp_all is not None and not (hyp_all.dtype == torch.long and hyp_all.is_contiguous() and
+                                    hyp_all.shape[0] == gen_result.shape[0] + greedy_res.shape[0]):
+        hyp_all = None
     reward, scores = CiderD_scorer.self_critical_reward(greedy_res.long().contiguous(), gen_result.long().contiguous(),
-                                                         refs, n_refs, n)
+                                                         refs, n_refs, n, hyp_all=hyp_all)
     w = getattr(opt, 'cider_reward_weight', 1)
     if w != 1:
         reward = reward * w

@@ -135,12 +135,20 @@ class DeviceCiderD:
                                      stream_ptr()), 'capmi_ciderd_score')
         return scores
 
-    def self_critical_reward(self, greedy, sampled, refs, n_refs, n):
-        """rewards.py:41-81 on device: scores of N sampled + B greedy rows, advantage [N] float32."""
+    def self_critical_reward(self, greedy, sampled, refs, n_refs, n, hyp_all=None):
+        """rewards.py:41-81 on device: scores of N sampled + B greedy rows, advantage [N] float32.
+        hyp_all: the [N+B, L] tensor holding `sampled` then `greedy` already side by side (the fused SCST rollout writes them
+        that way): scored in place, no concatenation."""
         N = sampled.shape[0]
         B = greedy.shape[0]
-        hyp = torch.cat([sampled, greedy], 0).contiguous()
-        img = torch.cat([torch.arange(N, device=hyp.device) // n, torch.arange(B, device=hyp.device)]).to(torch.int32)
+        hyp = hyp_all if hyp_all is not None else torch.cat([sampled, greedy], 0).contiguous()
+        key = (N, B, n, str(hyp.device))
+        img = self._img_cache.get(key) if hasattr(self, '_img_cache') else None
+        if img is None:
+            if not hasattr(self, '_img_cache'):
+                self._img_cache = {}
+            img = torch.cat([torch.arange(N, device=hyp.device) // n, torch.arange(B, device=hyp.device)]).to(torch.int32)
+            self._img_cache[key] = img
         scores = self.score(hyp, img, refs, n_refs)
         reward = torch.empty(N, dtype=torch.float32, device=hyp.device)
         check(lib.capmi_scst_advantage(ptr(scores), N, n, ptr(reward), stream_ptr()), 'capmi_scst_advantage')

@@ -230,6 +230,49 @@ __global__ void dropout_mask_kernel(float *__restrict__ mask, size_t count, floa
     }
 }
 
+// All dropout masks of one rollout in ONE launch (round 2: four launches of the kernel above, 5 us + a kernel boundary each,
+// sat in front of every training rollout).  Segment i covers mask_i[count_i] with Philox offset off_i; elements whose
+// row index within a slab (`row_len` floats per row, `rows` rows per slab) is >= keep_from are written as 1.0 -- the
+// greedy-baseline rows of the fused SCST rollout run in eval mode (loss_wrapper.py:57-60).
+struct MaskSegs {
+    float *mask[CAPMI_MAX_MASKS];
+    unsigned long long count[CAPMI_MAX_MASKS], offset[CAPMI_MAX_MASKS];
+    int row_len[CAPMI_MAX_MASKS], rows[CAPMI_MAX_MASKS], keep_from[CAPMI_MAX_MASKS];
+    int n;
+};
+__global__ void dropout_masks_kernel(const MaskSegs sg, float p, uint64_t seed) {
+    const Philox rng(seed);
+    const float scale = 1.f / (1.f - p);
+    for (int i = 0; i < sg.n; ++i) {
+        const size_t count = sg.count[i], quads = (count + 3) / 4;
+        float *mask = sg.mask[i];
+        const int row_len = sg.row_len[i], rows = sg.rows[i], keep_from = sg.keep_from[i];
+        for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (size_t)gridDim.x * blockDim.x) {
+            uint32_t o[4];
+            rng.gen(sg.offset[i] + q, 0x6d61736bULL, o);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t e = q * 4 + k;
+                if (e < count) {
+                    const bool eval_row = keep_from < rows && (int)((e / row_len) % rows) >= keep_from;
+                    mask[e] = eval_row ? 1.f : ((u01(o[k]) < p) ? 0.f : scale);
+                }
+            }
+        }
+    }
+}
+
+// initial state of a rollout (slot 0 of h / c, BOS tokens, unfinished flags) in one launch instead of six memsets
+__global__ void rollout_init_kernel(float *__restrict__ a, float *__restrict__ b, float *__restrict__ c, float *__restrict__ d,
+                                    size_t count, int64_t *__restrict__ it, uint8_t *__restrict__ unfinished, int N) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        a[i] = 0.f; b[i] = 0.f;
+        if (c) c[i] = 0.f;
+        if (d) d[i] = 0.f;
+        if (i < (size_t)N) { it[i] = 0; unfinished[i] = 1; }
+    }
+}
+
 // Column sums of a [rows, cols] matrix (bias gradients over all T*N rows).  1024 threads = 16 column quads x 64 row
 // slices: a wave reads four 256-byte row segments per instruction, every thread keeps <= rows/64 INDEPENDENT 16-byte
 // loads in flight (the old one-column-per-thread loop was a serial chain of 150 scalar loads: 45 us for 19 MB), and
@@ -416,6 +459,34 @@ int capmi_dropout_mask(float *mask, int64_t count, float p, uint64_t seed, uint6
     if (!mask || count <= 0 || p < 0.f || p >= 1.f) return CAPMI_EINVAL;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((size_t)(count + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        mask, (size_t)count, p, seed, offset);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_dropout_masks(const capmi_mask_desc *descs, int n, float p, uint64_t seed, void *stream) {
+    if (!descs || n < 1 || n > CAPMI_MAX_MASKS || p < 0.f || p >= 1.f) return CAPMI_EINVAL;
+    MaskSegs sg{};
+    sg.n = n;
+    size_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        const capmi_mask_desc &d = descs[i];
+        if (!d.mask || d.count <= 0) return CAPMI_EINVAL;
+        sg.mask[i] = d.mask; sg.count[i] = (unsigned long long)d.count; sg.offset[i] = d.offset;
+        sg.row_len[i] = d.row_len > 0 ? d.row_len : 1;
+        sg.rows[i] = d.rows > 0 ? d.rows : 1;
+        sg.keep_from[i] = (d.keep_from >= 0 && d.rows > 0) ? d.keep_from : sg.rows[i];
+        if ((size_t)d.count > most) most = (size_t)d.count;
+    }
+    hipLaunchKernelGGL(dropout_masks_kernel, dim3(grid_for((most + 3) / 4)), dim3(256), 0, (hipStream_t)stream, sg, p, seed);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_rollout_init(float *h0, float *c0, float *h1, float *c1, int64_t count, int64_t *it, uint8_t *unfinished, int N,
+                       void *stream) {
+    if (!h0 || !c0 || !it || !unfinished || count < N || N <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(rollout_init_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, (hipStream_t)stream, h0, c0, h1, c1,
+                       (size_t)count, it, unfinished, N);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

@@ -66,6 +66,30 @@ __global__ void tn_to_nt_kernel(const float *__restrict__ src, float *__restrict
     }
 }
 
+// [lang W_ih | lang W_hh] -> w_lang_cat [4R,3R] and [att W_ih(:, 0:R) | att W_hh] -> w_att_cat [4R,2R] in one launch (were four
+// hipMemcpy2DAsync: 42 us + 4 kernel boundaries per BPTT).  R % 4 == 0 and 16-byte aligned operands (checked by the caller).
+__global__ void pack_recurrent_kernel(const float *__restrict__ lang_ih, const float *__restrict__ lang_hh,
+                                      const float *__restrict__ att_ih, const float *__restrict__ att_hh,
+                                      float *__restrict__ w_lang_cat, float *__restrict__ w_att_cat, int R, int ld_att_ih) {
+    const int R4 = R >> 2;
+    const int per_row = 5 * R4;                  // 3R + 2R floats of packed output per weight row, in 16-byte pieces
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * R * per_row) return;
+    const int row = i / per_row, q = i - row * per_row;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    if (q < 3 * R4) {
+        const int c = q * 4;
+        const f4 v = c < 2 * R ? *reinterpret_cast<const f4 *>(lang_ih + (size_t)row * 2 * R + c)
+                               : *reinterpret_cast<const f4 *>(lang_hh + (size_t)row * R + (c - 2 * R));
+        *reinterpret_cast<f4 *>(w_lang_cat + (size_t)row * 3 * R + c) = v;
+    } else {
+        const int c = (q - 3 * R4) * 4;
+        const f4 v = c < R ? *reinterpret_cast<const f4 *>(att_ih + (size_t)row * ld_att_ih + c)
+                           : *reinterpret_cast<const f4 *>(att_hh + (size_t)row * R + (c - R));
+        *reinterpret_cast<f4 *>(w_att_cat + (size_t)row * 2 * R + c) = v;
+    }
+}
+
 // bookkeeping of the teacher-forced pass (what the per-step select kernel writes in mode 2 with no finish mask)
 __global__ void teacher_bookkeep_kernel(const float *__restrict__ seq_logp, const int64_t *__restrict__ forced, int forced_ld,
                                         int64_t *__restrict__ seq, float *__restrict__ sel_logp, uint8_t *__restrict__ live,
@@ -105,13 +129,7 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
                                (int64_t)N * T * R <= r->partial_capacity - CAPMI_WS_COUNTER_FLOATS;
 
     // initial state (slot 0) and flags
-    hipError_t e;
-    if ((e = hipMemsetAsync(r->h_att, 0, NR * sizeof(float), st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(r->c_att, 0, NR * sizeof(float), st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(r->h_lang, 0, NR * sizeof(float), st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(r->c_lang, 0, NR * sizeof(float), st)) != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(r->it, 0, (size_t)N * sizeof(int64_t), st)) != hipSuccess) return (int)e;   // bos = 0
-    if ((e = hipMemsetAsync(r->unfinished, 1, (size_t)N, st)) != hipSuccess) return (int)e;
+    RC(capmi_rollout_init(r->h_att, r->c_att, r->h_lang, r->c_lang, (int64_t)NR, r->it, r->unfinished, N, stream));   // bos = 0
 
     // fc term of the attention LSTM, once: fc_gates[B,4R] = fc W_ih[:, R:2R]^T
     {
@@ -247,16 +265,27 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
     //      dX GEMM per LSTM instead of two (+ their split-K reductions): 80 MB of copies per BPTT buys back
     //      ~80 launches.
     if (phases & CAPMI_BWD_RECURRENT) {
-        hipError_t e;
-        const size_t fb = sizeof(float);
-        if ((e = hipMemcpy2DAsync(s->w_lang_cat, 3 * R * fb, w->lang_w_ih, 2 * R * fb, 2 * R * fb, 4 * R,
-                                  hipMemcpyDeviceToDevice, st)) != hipSuccess) return (int)e;
-        if ((e = hipMemcpy2DAsync(s->w_lang_cat + 2 * R, 3 * R * fb, w->lang_w_hh, R * fb, R * fb, 4 * R,
-                                  hipMemcpyDeviceToDevice, st)) != hipSuccess) return (int)e;
-        if ((e = hipMemcpy2DAsync(s->w_att_cat, 2 * R * fb, w->att_w_ih, (size_t)ld_att_ih * fb, R * fb, 4 * R,
-                                  hipMemcpyDeviceToDevice, st)) != hipSuccess) return (int)e;
-        if ((e = hipMemcpy2DAsync(s->w_att_cat + R, 2 * R * fb, w->att_w_hh, R * fb, R * fb, 4 * R,
-                                  hipMemcpyDeviceToDevice, st)) != hipSuccess) return (int)e;
+        const bool al = R % 4 == 0 && ld_att_ih % 4 == 0 &&
+                        ((reinterpret_cast<uintptr_t>(w->lang_w_ih) | reinterpret_cast<uintptr_t>(w->lang_w_hh) |
+                          reinterpret_cast<uintptr_t>(w->att_w_ih) | reinterpret_cast<uintptr_t>(w->att_w_hh) |
+                          reinterpret_cast<uintptr_t>(s->w_lang_cat) | reinterpret_cast<uintptr_t>(s->w_att_cat)) & 15) == 0;
+        if (al) {
+            const int total = 4 * R * 5 * R;
+            hipLaunchKernelGGL(pack_recurrent_kernel, dim3((total / 4 + 255) / 256), dim3(256), 0, st, w->lang_w_ih, w->lang_w_hh,
+                               w->att_w_ih, w->att_w_hh, s->w_lang_cat, s->w_att_cat, R, ld_att_ih);
+            CAPMI_CHECK_LAUNCH();
+        } else {
+            hipError_t e;
+            const size_t fb = sizeof(float);
+            if ((e = hipMemcpy2DAsync(s->w_lang_cat, 3 * R * fb, w->lang_w_ih, 2 * R * fb, 2 * R * fb, 4 * R,
+                                      hipMemcpyDeviceToDevice, st)) != hipSuccess) return (int)e;
+            if ((e = hipMemcpy2DAsync(s->w_lang_cat + 2 * R, 3 * R * fb, w->lang_w_hh, R * fb, R * fb, 4 * R,
+                                      hipMemcpyDeviceToDevice, st)) != hipSuccess) return (int)e;
+            if ((e = hipMemcpy2DAsync(s->w_att_cat, 2 * R * fb, w->att_w_ih, (size_t)ld_att_ih * fb, R * fb, 4 * R,
+                                      hipMemcpyDeviceToDevice, st)) != hipSuccess) return (int)e;
+            if ((e = hipMemcpy2DAsync(s->w_att_cat + R, 2 * R * fb, w->att_w_hh, R * fb, R * fb, 4 * R,
+                                      hipMemcpyDeviceToDevice, st)) != hipSuccess) return (int)e;
+        }
     }
 
     // ---- BPTT over the recurrent part ----------------------------------------------------------

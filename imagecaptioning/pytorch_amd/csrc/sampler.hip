@@ -410,7 +410,7 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_bwd_kernel(const float
 __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_bwd_sparse_kernel(
     const float *__restrict__ g_sel, const float *__restrict__ g_sum, const int64_t *__restrict__ tok, int tok_ld,
     const float *__restrict__ g, const float *__restrict__ seq_logp, const uint8_t *__restrict__ live,
-    float *__restrict__ dlogits, int N, int L, int V1) {
+    float *__restrict__ dlogits, int N, int L, int V1, const float *__restrict__ scale) {
     __shared__ float s_f[32];
     const int t = blockIdx.x / N, n = blockIdx.x % N;
     const size_t r = (size_t)n * L + t;
@@ -420,8 +420,9 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_bwd_sparse_kernel(
         for (int v = threadIdx.x; v < V1; v += blockDim.x) o[v] = 0.f;
         return;
     }
-    const float a = g_sel ? g_sel[r] : 0.f;
-    const float b = g_sum ? g_sum[r] : 0.f;
+    const float sc = scale ? scale[0] : 1.f;          // upstream gradient of the scalar loss (sparse parts only)
+    const float a = g_sel ? sc * g_sel[r] : 0.f;
+    const float b = g_sum ? sc * g_sum[r] : 0.f;
     const int token = g_sel ? (int)tok[(size_t)n * tok_ld + t] : -1;
     float s = a + b * (float)V1;                      // sum over v of the implied dense gradient
     const float *gr = g ? g + r * V1 : nullptr;
@@ -438,9 +439,66 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_bwd_sparse_kernel(
     }
 }
 
+// RewardCriterion (losses.py:18-37) on the selected log-probs a rollout already wrote: mask = (seq > 0) shifted right with a
+// leading 1, loss = -sum(sel * reward * mask) / sum(mask) (or per row), and the coefficient d loss / d sel for the backward --
+// one launch instead of the reference's gather + ~12 elementwise / reduction launches over [N,L] values.
+__global__ __launch_bounds__(1024) void reward_criterion_kernel(const float *__restrict__ sel, int sel_ld,
+                                                               const int64_t *__restrict__ seq, int seq_ld,
+                                                               const float *__restrict__ reward, int rw_rs, int rw_cs,
+                                                               int N_used, int N_all, int L, int per_row,
+                                                               float *__restrict__ loss, float *__restrict__ gcoef) {
+    __shared__ float s_f[32];
+    __shared__ float s_rows[2048];             // per-row mask counts (N_used <= 2048 checked by the host)
+    float num = 0.f, den = 0.f;
+    for (int i = threadIdx.x; i < N_used * L; i += blockDim.x) {
+        const int n = i / L, t = i - n * L;
+        const float m = (t == 0 || seq[(size_t)n * seq_ld + t - 1] > 0) ? 1.f : 0.f;
+        num -= sel[(size_t)n * sel_ld + t] * reward[(size_t)n * rw_rs + (size_t)t * rw_cs] * m;
+        den += m;
+    }
+    if (per_row) {
+        for (int n = threadIdx.x; n < N_used; n += blockDim.x) {
+            float rn = 0.f, rd = 0.f;
+            for (int t = 0; t < L; ++t) {
+                const float m = (t == 0 || seq[(size_t)n * seq_ld + t - 1] > 0) ? 1.f : 0.f;
+                rn -= sel[(size_t)n * sel_ld + t] * reward[(size_t)n * rw_rs + (size_t)t * rw_cs] * m;
+                rd += m;
+            }
+            loss[n] = rn / rd;
+            s_rows[n] = rd;
+        }
+        __syncthreads();
+    } else {
+        num = block_sum(num, s_f);
+        den = block_sum(den, s_f);
+        if (threadIdx.x == 0) loss[0] = num / den;
+    }
+    for (int i = threadIdx.x; i < N_all * L; i += blockDim.x) {
+        const int n = i / L, t = i - n * L;
+        float gc = 0.f;
+        if (n < N_used) {
+            const float m = (t == 0 || seq[(size_t)n * seq_ld + t - 1] > 0) ? 1.f : 0.f;
+            gc = -reward[(size_t)n * rw_rs + (size_t)t * rw_cs] * m / (per_row ? s_rows[n] : den);
+        }
+        gcoef[i] = gc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int capmi_reward_criterion(const float *sel, int sel_ld, const int64_t *seq, int seq_ld, const float *reward, int reward_row_stride,
+                           int reward_col_stride, int N_used, int N_all, int L, int per_row, float *loss, float *gcoef,
+                           void *stream) {
+    if (!sel || !seq || !reward || !loss || !gcoef || N_used <= 0 || N_all < N_used || L <= 0 || sel_ld < L || seq_ld < L)
+        return CAPMI_EINVAL;
+    if (per_row && N_used > 2048) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(reward_criterion_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sel, sel_ld, seq, seq_ld, reward,
+                       reward_row_stride, reward_col_stride, N_used, N_all, L, per_row, loss, gcoef);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
 
 int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t slab_stride, const float *bias, int N,
                                     int V1, int step, int L, int mode, const uint8_t *row_mode, float temperature,
@@ -516,7 +574,7 @@ int capmi_logsoftmax_bwd_sparse(const capmi_sparse_logp_grad *sp, const float *g
     if (!sp->g_sel && !sp->g_sum && !g) return CAPMI_EINVAL;
     if (sp->g_sel && (!sp->tok || sp->tok_ld < T)) return CAPMI_EINVAL;
     hipLaunchKernelGGL(logsoftmax_bwd_sparse_kernel, dim3(N * T), dim3(SEL_THREADS), 0, (hipStream_t)stream, sp->g_sel,
-                       sp->g_sum, sp->tok, sp->tok_ld, g, seq_logp, live, dlogits, N, L, V1);
+                       sp->g_sum, sp->tok, sp->tok_ld, g, seq_logp, live, dlogits, N, L, V1, sp->scale);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

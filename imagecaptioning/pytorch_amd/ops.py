@@ -85,12 +85,13 @@ def _dev(x):
     return (x[0] if isinstance(x, tuple) else x).device
 
 
-def linear(x, weight, bias=None, relu=False, mul_mask=None, row_div=1, rows=None, ws=None):
-    """y = act(x @ weight.T + bias) (* mask); x [M0,K] read as row r -> r // row_div."""
-    _chk(x, weight, bias, mul_mask)
+def linear(x, weight, bias=None, relu=False, mul_mask=None, row_div=1, rows=None, ws=None, out=None):
+    """y = act(x @ weight.T + bias) (* mask); x [M0,K] read as row r -> r // row_div.  out: optional [M,N] contiguous target."""
+    _chk(x, weight, bias, mul_mask, out)
     M = x.shape[0] * row_div if rows is None else rows
     N, K = weight.shape
-    out = torch.empty(M, N, dtype=_f32, device=x.device)
+    if out is None:
+        out = torch.empty(M, N, dtype=_f32, device=x.device)
     gemm([(x, x.shape[1], weight, K, K, row_div)], M, N, out, bias=bias, relu=relu, mul_mask=mul_mask, ws=ws)
     return out
 
@@ -194,6 +195,39 @@ def dropout_mask(shape, p, seed, offset, device):
     m = torch.empty(shape, dtype=_f32, device=device)
     check(lib.capmi_dropout_mask(ptr(m), m.numel(), float(p), int(seed), int(offset), stream_ptr()), 'capmi_dropout_mask')
     return m
+
+
+def dropout_masks(specs, p, seed):
+    """All dropout masks of a rollout in one launch.  specs: list of (shape, philox_offset, keep_from) with keep_from = None or
+    the first row index (of the second-to-last dimension) that stays in eval mode (mask 1.0).  Returns the mask tensors."""
+    dev = specs[0][3] if len(specs[0]) > 3 else None
+    descs = (_lib.MaskDesc * len(specs))()
+    outs = []
+    for i, sp in enumerate(specs):
+        shape, offset, keep_from = sp[0], sp[1], sp[2]
+        m = torch.empty(shape, dtype=_f32, device=sp[3])
+        outs.append(m)
+        descs[i].mask, descs[i].count, descs[i].offset = m.data_ptr(), m.numel(), int(offset)
+        descs[i].row_len = int(shape[-1])
+        descs[i].rows = int(shape[-2]) if len(shape) >= 2 else 1
+        descs[i].keep_from = -1 if keep_from is None else int(keep_from)
+    check(lib.capmi_dropout_masks(descs, len(specs), float(p), int(seed), stream_ptr()), 'capmi_dropout_masks')
+    return outs
+
+
+def reward_criterion(sel, seq, reward, n_used, per_row=False):
+    """capmi_reward_criterion: sel [N_all, L] f32, seq [N_all, L] int64 (rows 0..n_used-1 are scored), reward [n_used] or
+    [n_used, L] f32.  Returns (loss [1] or [n_used], gcoef [N_all, L])."""
+    _chk(sel, seq)
+    if not (reward.is_cuda and reward.dtype == _f32):
+        raise _lib.CapmiError('reward must be a float32 device tensor')
+    N_all, L = sel.shape
+    loss = torch.empty(n_used if per_row else 1, dtype=_f32, device=sel.device)
+    gcoef = torch.empty(N_all, L, dtype=_f32, device=sel.device)
+    rs, cs = (reward.stride(0), reward.stride(1)) if reward.ndim == 2 else (reward.stride(0), 0)
+    check(lib.capmi_reward_criterion(ptr(sel), sel.stride(0), ptr(seq), seq.stride(0), ptr(reward), rs, cs, int(n_used), N_all, L,
+                                     int(per_row), ptr(loss), ptr(gcoef), stream_ptr()), 'capmi_reward_criterion')
+    return loss, gcoef
 
 
 def colsum(x, out=None, accumulate=False):

@@ -21,12 +21,13 @@ class LogpSink:
     """collects the sparse loss gradient of ONE rollout between the criterion's backward and the rollout's backward"""
 
     def __init__(self):
-        self.tok = self.g_sel = self.g_sum = None
+        self.tok = self.g_sel = self.g_sum = self.scale = None
         self.sel_taken = self.sum_taken = False
+        self.sel = self.seq = None        # set by rollouts that save the selected log-probs / tokens (fused criteria)
 
     def take(self):
-        out = (self.tok, self.g_sel, self.g_sum)
-        self.tok = self.g_sel = self.g_sum = None
+        out = (self.tok, self.g_sel, self.g_sum, self.scale)
+        self.tok = self.g_sel = self.g_sum = self.scale = None
         return None if out[1] is None and out[2] is None else out
 
 
@@ -108,6 +109,50 @@ def sum_logp(logp):
     return _SumLogp.apply(logp, sink)
 
 
+class _FusedReward(torch.autograd.Function):
+    """RewardCriterion on the selected log-probs the rollout saved (capmi_reward_criterion): forward = ONE launch, backward
+    = nothing but handing (coefficients, tokens, upstream scalar) to the sink."""
+
+    @staticmethod
+    def forward(ctx, logp, sink, reward, n_used, per_row):
+        from . import ops
+        loss, gcoef = ops.reward_criterion(sink.sel, sink.seq, reward, n_used, per_row)
+        ctx.sink, ctx.gcoef, ctx.per_row, ctx.n_used = sink, gcoef, per_row, n_used
+        return loss if per_row else loss.squeeze(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        sink = ctx.sink
+        sink.tok = sink.seq
+        if ctx.per_row:                               # one upstream value per row
+            gc = ctx.gcoef.clone()
+            gc[:ctx.n_used] *= g.reshape(-1, 1).to(gc)
+            sink.g_sel = gc
+        else:                                         # scalar loss: the upstream gradient stays a device scalar
+            sink.g_sel = ctx.gcoef
+            sink.scale = g.reshape(1).float().contiguous()
+        return None, None, None, None, None
+
+
+def fused_reward_criterion(logp, seq, reward, per_row=False):
+    """RewardCriterion(logp, seq, reward) through the rollout's saved selected log-probs, or None when `logp` / `seq` are not
+    the untouched outputs of one capmi rollout (then the caller takes the generic route)."""
+    if _DENSE or not logp.requires_grad:
+        return None
+    parent = getattr(logp, '_capmi_rows', None)
+    full = parent if parent is not None else logp
+    sink = getattr(full, '_capmi_sink', None)
+    if sink is None or sink.sel is None or sink.sel_taken or sink.seq is None:
+        return None
+    n_used = logp.shape[0]
+    if seq.data_ptr() != sink.seq.data_ptr() or seq.shape != (n_used, sink.seq.shape[1]) or not seq.is_contiguous():
+        return None                                   # not the rollout's own tokens
+    if reward.shape[0] != n_used or reward.ndim not in (1, 2) or not reward.is_cuda:
+        return None
+    sink.sel_taken = True
+    return _FusedReward.apply(full, sink, reward.float(), n_used, per_row)
+
+
 def split_grad(g_logp, sink, like=None):
     """What a rollout backward receives -> (dense gradient or None, SparseLogpGrad struct or None, keep-alive tuple).
     `like`: the saved dense log-probs, for the (rare) case that no gradient at all arrived."""
@@ -117,13 +162,13 @@ def split_grad(g_logp, sink, like=None):
         if dense is None and like is not None:
             dense = torch.zeros_like(like)
         return dense, None, ()
-    tok, g_sel, g_sum = sp
+    tok, g_sel, g_sum, scale = sp
     s = _lib.SparseLogpGrad()
-    s.g_sel, s.g_sum = ptr(g_sel), ptr(g_sum)
+    s.g_sel, s.g_sum, s.scale = ptr(g_sel), ptr(g_sum), ptr(scale)
     if g_sel is not None:
         assert tok.dtype == torch.long and tok.is_contiguous() and tok.shape == g_sel.shape
         s.tok, s.tok_ld = ptr(tok), tok.shape[1]
-    return dense, s, (tok, g_sel, g_sum, s)
+    return dense, s, (tok, g_sel, g_sum, scale, s)
 
 
 def byref_or_none(s):

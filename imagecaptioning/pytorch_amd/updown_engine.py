@@ -49,9 +49,10 @@ class Prepared:
     __slots__ = ('fc', 'att', 'p_att', 'att_masks', 'fc_in', 'att_in', 'drop_fc', 'drop_att', 'K')
 
 
-def prepare(P, fc_feats, att_feats, att_masks=None, drop_fc=None, drop_att=None, ws=None):
+def prepare(P, fc_feats, att_feats, att_masks=None, drop_fc=None, drop_att=None, ws=None, out=None):
     """AttModel._prepare_feature (AttModel.py:114-124): three MFMA GEMMs with fused bias/ReLU/dropout
-    epilogues.  Padded regions (att_masks == 0) are zeroed like pad_packed_sequence does (44-49)."""
+    epilogues.  Padded regions (att_masks == 0) are zeroed like pad_packed_sequence does (44-49).
+    out: optional (fc [B,R], att [B,K,R], p_att [B,K,A]) contiguous targets (slices of a caller's larger buffers)."""
     B = fc_feats.shape[0]
     if att_masks is not None:
         max_len = int(att_masks.long().sum(1).max())          # clip_att, AttModel.py:106-112
@@ -63,7 +64,8 @@ def prepare(P, fc_feats, att_feats, att_masks=None, drop_fc=None, drop_att=None,
     pr = Prepared()
     pr.K = K
     pr.fc_in, pr.att_in, pr.drop_fc = fc_feats.contiguous(), att_feats.contiguous(), drop_fc
-    pr.fc = ops.linear(pr.fc_in, P['fc_embed.0.weight'], P['fc_embed.0.bias'], relu=True, mul_mask=drop_fc, ws=ws)
+    o_fc, o_att, o_patt = out if out is not None else (None, None, None)
+    pr.fc = ops.linear(pr.fc_in, P['fc_embed.0.weight'], P['fc_embed.0.bias'], relu=True, mul_mask=drop_fc, ws=ws, out=o_fc)
     R = pr.fc.shape[1]
     att_mask_full = drop_att
     if att_masks is not None:
@@ -71,9 +73,11 @@ def prepare(P, fc_feats, att_feats, att_masks=None, drop_fc=None, drop_att=None,
         att_mask_full = (m if drop_att is None else m * drop_att).contiguous()
     pr.drop_att = att_mask_full
     att2d = ops.linear(pr.att_in.view(B * K, -1), P['att_embed.0.weight'], P['att_embed.0.bias'], relu=True,
-                       mul_mask=None if att_mask_full is None else att_mask_full.view(B * K, R), ws=ws)
+                       mul_mask=None if att_mask_full is None else att_mask_full.view(B * K, R), ws=ws,
+                       out=None if o_att is None else o_att.view(B * K, R))
     pr.att = att2d.view(B, K, R)
-    pr.p_att = ops.linear(att2d, P['ctx2att.weight'], P['ctx2att.bias'], ws=ws).view(B, K, -1)
+    pr.p_att = ops.linear(att2d, P['ctx2att.weight'], P['ctx2att.bias'], ws=ws,
+                          out=None if o_patt is None else o_patt.view(B * K, -1)).view(B, K, -1)
     pr.att_masks = att_masks
     return pr
 

@@ -256,9 +256,19 @@ typedef struct capmi_sparse_logp_grad {
     const float *g_sum;
     const int64_t *tok;
     int tok_ld;
+    const float *scale;   /* NULL, or a DEVICE scalar multiplying g_sel / g_sum (the upstream gradient of a scalar loss) */
 } capmi_sparse_logp_grad;
 int capmi_logsoftmax_bwd_sparse(const capmi_sparse_logp_grad *sp, const float *g, const float *seq_logp,
                                 const uint8_t *live, float *dlogits, int N, int L, int T, int V1, void *stream);
+
+/* RewardCriterion.forward (losses.py:18-37) on the selected log-probs a rollout wrote (capmi_updown_rollout.sel_logp):
+ *   mask[r,t] = 1 for t == 0, else (seq[r,t-1] > 0)            (the EOS step still counts, losses.py:28-29)
+ *   loss = -sum(sel * reward * mask) / sum(mask)                 (per_row: one value per row, reduction='none')
+ *   gcoef[r,t] = d loss / d sel[r,t]  (rows N_used .. N_all-1, e.g. the greedy rows of a fused SCST rollout: 0)
+ * reward[r,t] is read at reward[r * reward_row_stride + t * reward_col_stride] ([N] advantage: strides 1, 0). */
+int capmi_reward_criterion(const float *sel, int sel_ld, const int64_t *seq, int seq_ld, const float *reward,
+                           int reward_row_stride, int reward_col_stride, int N_used, int N_all, int L, int per_row,
+                           float *loss, float *gcoef, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Elementwise helpers
@@ -269,6 +279,21 @@ int capmi_splitk_reduce(const float *partial, int splits, float *C, int ldc, int
                         const float *mul_mask, int relu, int accumulate, void *stream);
 /* Bernoulli keep-masks scaled by 1/(1-p): mask[i] in {0, 1/(1-p)}; Philox4x32-10(seed, offset+i) */
 int capmi_dropout_mask(float *mask, int64_t count, float p, uint64_t seed, uint64_t offset, void *stream);
+/* up to CAPMI_MAX_MASKS masks in one launch (the fc / att / xt / output dropouts of one rollout, AttModel.py:83-90, 122,
+ * 640).  Viewing mask i as slabs of `rows` rows of `row_len` floats, rows >= keep_from are written as 1.0 (eval-mode rows of
+ * the fused SCST rollout); rows == 0 or keep_from < 0: none. */
+#define CAPMI_MAX_MASKS 4
+typedef struct capmi_mask_desc {
+    float *mask;
+    int64_t count;
+    uint64_t offset;
+    int row_len, rows, keep_from;
+} capmi_mask_desc;
+int capmi_dropout_masks(const capmi_mask_desc *descs, int n, float p, uint64_t seed, void *stream);
+/* zero `count` floats of up to four state buffers (h1 / c1 may be NULL), it[0..N) = 0 (BOS), unfinished[0..N) = 1:
+ * the initial state of AttModel._sample / _forward (init_hidden AttModel.py:99-102, :281-285) in one launch */
+int capmi_rollout_init(float *h0, float *c0, float *h1, float *c1, int64_t count, int64_t *it, uint8_t *unfinished, int N,
+                       void *stream);
 /* out[c] = sum_r in[r*ld + c]  (bias gradients) ; accumulate optional */
 int capmi_colsum(const float *in, int rows, int cols, int ld, float *out, int accumulate, void *stream);
 /* out[g, c] = sum_{j<group} in[(g*group + j)*cols + c], summed over T slabs of stride slab */

@@ -179,11 +179,14 @@ def test_fused_scst_rollouts_equal_separate_rollouts():
     m_fc, m_att, m_xt, m_out = keep(B, R), keep(B, K, R), keep(L, N + B, E), keep(L, N + B, R)
 
     def masks_for(rows):
-        def f(B_, K_, N_, T_, dev):
+        def f(B_, K_, N_, T_, dev, eval_rows_from=None):
             if not model.training:
                 return {}
-            return dict(drop_fc=m_fc, drop_att=m_att, drop_xt=m_xt[:, :N_].contiguous().clone(),
-                        drop_out=m_out[:, :N_].contiguous().clone())
+            xt, out = m_xt[:, :N_].contiguous().clone(), m_out[:, :N_].contiguous().clone()
+            if eval_rows_from is not None:               # greedy-baseline rows of the fused rollout run in eval mode
+                xt[:, eval_rows_from:] = 1.0
+                out[:, eval_rows_from:] = 1.0
+            return dict(drop_fc=m_fc, drop_att=m_att, drop_xt=xt, drop_out=out)
         return f
 
     model._dropout_masks = masks_for(None)

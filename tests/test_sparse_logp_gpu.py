@@ -215,3 +215,65 @@ def test_fused_scst_rollout_keeps_the_sparse_route():
     assert taken == [(True, True), (False, False)], taken
     assert torch.equal(res[0][0], res[1][0])
     _check_same(res[0][1], res[1][1])
+
+
+def test_fused_reward_criterion_equals_generic_route_and_launch_count_drops():
+    """The SCST branch of LossWrapper end to end: RewardCriterion served by capmi_reward_criterion from the rollout's saved
+    selected log-probs (loss and every gradient equal to the generic gather route), hypotheses scored in place, masks in
+    one launch."""
+    from test_model_api_gpu import golden_model
+    from imagecaptioning.pytorch_amd import sparse_logp
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import RewardCriterion
+    z, model = golden_model(True)
+    model.train()
+    fc, att, am = (torch.from_numpy(z[k]).to(DEV) for k in ('fc', 'att', 'att_masks'))
+    B, n, L, V1 = fc.shape[0], 2, model.seq_length, model.vocab_size + 1
+    g = torch.Generator().manual_seed(6)
+    gum = -torch.log(-torch.log(torch.rand(L, B * n + B, V1, generator=g).clamp_min(1e-20))).to(DEV)
+    adv = torch.randn(B * n, generator=g).to(DEV)
+    res = []
+    for mode in ('fused', 'generic', 'fused_rows'):
+        model.zero_grad()
+        model._rng_calls = 11
+        greedy, gen, logp = model.scst_rollouts(fc, att, am, sample_n=n, _gumbel=gum)
+        assert gen._capmi_all.shape[0] == B * n + B and gen.data_ptr() == gen._capmi_all.data_ptr()
+        reward = adv.unsqueeze(1).expand(-1, L)
+        if mode == 'generic':
+            saved, sparse_logp._DENSE = sparse_logp._DENSE, False
+            fr = sparse_logp.fused_reward_criterion
+            sparse_logp.fused_reward_criterion = lambda *a, **k: None
+            import imagecaptioning.pytorch_amd.captioning.modules.losses as Lm
+            keep = Lm.fused_reward_criterion
+            Lm.fused_reward_criterion = lambda *a, **k: None
+            try:
+                loss = RewardCriterion()(logp, gen.data, reward)
+            finally:
+                Lm.fused_reward_criterion = keep
+                sparse_logp.fused_reward_criterion = fr
+                sparse_logp._DENSE = saved
+        elif mode == 'fused':
+            loss = RewardCriterion()(logp, gen.data, reward)
+            assert loss.grad_fn is not None and 'FusedReward' in type(loss.grad_fn).__name__
+        else:
+            rows = RewardCriterion()(logp, gen.data, reward, reduction='none')
+            assert rows.shape == (B * n,)
+            m = torch.cat([gen.new_ones(B * n, 1), (gen[:, :-1] > 0).long()], 1).float()
+            loss = (rows * m.sum(1)).sum() / m.sum()              # the mean form rebuilt from the per-row losses
+        loss.backward()
+        res.append((loss.item(), _grads(model), gen.clone()))
+    assert torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][2], res[2][2])
+    assert abs(res[0][0] - res[1][0]) < 1e-6 and abs(res[0][0] - res[2][0]) < 1e-5
+    _check_same(res[0][1], res[1][1])
+    _check_same(res[2][1], res[1][1])
+
+
+def test_dropout_masks_one_launch_equals_four_and_eval_rows():
+    from imagecaptioning.pytorch_amd import ops
+    seed, p = 1234567, 0.5
+    shapes = [((3, 16), 0), ((3, 5, 16), 1 << 40), ((4, 9, 12), 2 << 40), ((4, 9, 16), 3 << 40)]
+    one = ops.dropout_masks([(s, off, None, DEV) for s, off in shapes], p, seed)
+    for m, (s, off) in zip(one, shapes):
+        assert torch.equal(m, ops.dropout_mask(s, p, seed, off, DEV))
+        assert set(m.unique().tolist()) <= {0.0, 2.0}
+    ev = ops.dropout_masks([(shapes[2][0], shapes[2][1], 6, DEV)], p, seed)[0]
+    assert torch.equal(ev[:, :6], one[2][:, :6]) and bool((ev[:, 6:] == 1).all())
