@@ -31,6 +31,7 @@ import torch                                                # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+DF_IMAGES = 10000
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32-input MFMA (v_mfma_f32_32x32x2_f32), 155 TF measured
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (32x32x16), 2495 TF measured
@@ -51,41 +52,55 @@ def measured_copy_gbs(dev, mb=1024, iters=8):
     return 2.0 * src.numel() * 4 * iters / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
-def attention_large_batch(dev, B=1024, iters=20):
+def attention_large_batch(dev, B=1024, sets=6, iters=30):
     """The fused region-attention kernel at an evaluation-sized batch (B images x 36 regions, one caption row each), where
     a launch moves enough unique bytes (229 MB) to be bandwidth-bound: the north_star's HBM-roofline target applies here;
-    at the bs10 SCST shape a launch moves 2-5 MB and is latency-bound.  HIP events around `iters` launches."""
-    from imagecaptioning.pytorch_amd import ops
+    at the bs10 SCST shape a launch moves 2-5 MB and is latency-bound.  The launches ROTATE over `sets` independent input
+    sets (6 x 229 MB = 1.4 GB > 5 x the 256 MiB Infinity Cache), so every launch streams from HBM; the same-buffer figure
+    (inputs resident in the Infinity Cache) is reported beside it as `cached_gbs`.  Kernel time from the in-dispatch HIP
+    events of libcapmi (class 3), i.e. without host launch overhead."""
+    import ctypes as C
+    from imagecaptioning.pytorch_amd import ops, _lib
+    lib = _lib.lib
     K, A, R = 36, 512, 1000
-    att_h = torch.randn(B, A, device=dev)
-    p_att = torch.randn(B, K, A, device=dev)
-    att = torch.randn(B, K, R, device=dev)
     w = torch.randn(A, device=dev) * 0.1
     bb = torch.zeros(1, device=dev)
-    for _ in range(3):
-        ops.attention_fwd(att_h, p_att, att, None, w, bb, 1)
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(iters):
-        ops.attention_fwd(att_h, p_att, att, None, w, bb, 1)
-    b.record()
-    torch.cuda.synchronize()
-    us = a.elapsed_time(b) / iters * 1e3
+    data = [(torch.randn(B, A, device=dev), torch.randn(B, K, A, device=dev), torch.randn(B, K, R, device=dev)) for _ in range(sets)]
+
+    def run(rotate):
+        for i in range(sets):
+            ops.attention_fwd(*data[i if rotate else 0], None, w, bb, 1)
+        torch.cuda.synchronize()
+        lib.capmi_prof_reset()
+        lib.capmi_prof_enable(1 << 3)
+        for i in range(iters):
+            ops.attention_fwd(*data[i % sets if rotate else 0], None, w, bb, 1)
+        torch.cuda.synchronize()
+        lib.capmi_prof_enable(0)
+        ms, n, b_, f_ = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        assert lib.capmi_prof_read(3, C.byref(ms), C.byref(n), C.byref(b_), C.byref(f_)) == 0 and n.value == iters
+        lib.capmi_prof_reset()
+        return ms.value / iters * 1e3
+    us_hbm, us_cached = run(True), run(False)
     byts = 4.0 * (B * K * (A + R) + B * (A + R + K))
-    return {'B': B, 'n': 1, 'avg_launch_us': round(us, 1), 'unique_bytes_per_launch': round(byts),
-            'achieved_gbs': round(byts / us / 1e3, 1), 'frac_of_8tbs': round(byts / us / 1e3 / HBM_PEAK_GBS, 4)}
+    return {'B': B, 'n': 1, 'rotating_sets': sets, 'working_set_mb': round(sets * byts / 1e6), 'avg_launch_us': round(us_hbm, 1),
+            'unique_bytes_per_launch': round(byts), 'achieved_gbs': round(byts / us_hbm / 1e3, 1),
+            'frac_of_8tbs': round(byts / us_hbm / 1e3 / HBM_PEAK_GBS, 4),
+            'cached_avg_launch_us': round(us_cached, 1), 'cached_gbs': round(byts / us_cached / 1e3, 1)}
 
 
 def pmc_traffic():
     """HBM bytes per decode-GEMM launch from the PMC passes of this same command (FETCH_SIZE and WRITE_SIZE need
-    separate rocprofv3 --pmc runs, so they cannot be sampled inside this process): profiles/r01_pmc_traffic.json,
-    written by tools_pmc_traffic.py with the gfx950 corrections of MI355X_MICROARCH.md.  None if absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
-    try:
-        with open(path) as f:
-            return round(json.load(f)['decode_gemm']['traffic_bytes'])
-    except (OSError, KeyError, ValueError):
-        return None
+    separate rocprofv3 --pmc runs, so they cannot be sampled inside this process): profiles/r0N_pmc_traffic.json,
+    written by scripts/tools_pmc_traffic.py with the gfx950 corrections of MI355X_MICROARCH.md.  None if absent."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        try:
+            with open(os.path.join(here, 'profiles', name)) as f:
+                return round(json.load(f)['decode_gemm']['traffic_bytes'])
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 F32_MFMA_PEAK_TF = 157.3
 
 
@@ -141,11 +156,25 @@ def main():
     torch.manual_seed(1234)                       # identical initial weights on every rank
     model = models.setup(opt).to(dev)
     flat = model.flatten_parameters_()
-    # CAPMI_DDP_OVERLAP=0: one all-reduce of the whole flat gradient after the backward instead of buckets launched from
-    # inside it (the simple path; also what the N>1 runs fall back to if the overlapped path fails on its first step)
-    overlap = world > 1 and os.environ.get('CAPMI_DDP_OVERLAP', '1') != '0'
+    # Default for N > 1: ONE all-reduce of the whole flat fp32 gradient per step (north_star / SURVEY 8e).
+    # CAPMI_DDP_OVERLAP=1 opts into the bucketed variant (6 collectives launched from inside the backward as the phases finish
+    # their gradients, clip+Adam pipelined behind them).
+    overlap = world > 1 and os.environ.get('CAPMI_DDP_OVERLAP', '0') == '1'
     if overlap:
         flat.begin_overlap()
+    if world > 1:
+        # a hung collective cannot be caught by try/except: a watchdog thread ends the process group with a diagnostic instead
+        # of letting the driver's timeout kill an unexplained run
+        import threading
+        limit = float(os.environ.get('CAPMI_BENCH_WATCHDOG_S', '600'))
+
+        def _bark():
+            print('rank %d: bench.py exceeded its %.0f s watchdog (a hung RCCL collective?); aborting' % (rank, limit),
+                  file=sys.stderr, flush=True)
+            os._exit(3)
+        watchdog = threading.Timer(limit, _bark)
+        watchdog.daemon = True
+        watchdog.start()
     lw = LossWrapper(model, opt)
     if args.global_batch:
         if args.global_batch % world:
@@ -153,15 +182,20 @@ def main():
         args.batch = args.global_batch // world
     B, n, L = args.batch, opt.train_sample_n, opt.max_length
     fc, att = synthetic.batch(B, seed=1234 + rank, device=dev)
-    corpus = synthetic.corpus(2000, seed=7)       # DF table: 2000 synthetic "images" x 5 refs
+    corpus = synthetic.corpus(DF_IMAGES, seed=7)  # DF table: 10000 synthetic "images" x 5 refs
     df, ref_len = synthetic.document_frequency(corpus)
     rewards.reset_scorer()
     rewards.init_scorer((df, ref_len), device=dev)
-    gts = synthetic.corpus(B, seed=100 + rank)
+    # the references travel with the batch as a device image, packed by the loader side (captioning/data/prefetch.py does the
+    # same for real batches): inputs are resident in HBM before the timed region
+    gts = rewards.pack_gts(synthetic.corpus(B, seed=100 + rank))
     gt_indices = torch.arange(B)
     labels = masks = None
 
+    ar_events = None          # (start, end) events around the all-reduce of the steps that measure it
+
     def step():
+        nonlocal_ar = ar_events
         out = lw(fc, att, labels, masks, None, gts, gt_indices, True, False, False)
         loss = out['loss'].mean()
         flat.zero_grad()
@@ -175,7 +209,12 @@ def main():
             # bucket by bucket as the collectives land
             flat.finish_overlap_and_step(**adam)
         elif world > 1:
-            flat.adam_step(grad_scale=flat.all_reduce(), **adam)
+            if nonlocal_ar is not None:
+                nonlocal_ar[0].record()
+            scale = flat.all_reduce()
+            if nonlocal_ar is not None:
+                nonlocal_ar[1].record()
+            flat.adam_step(grad_scale=scale, **adam)
         else:
             flat.adam_step(grad_scale=1.0, **adam)
         return loss
@@ -188,20 +227,6 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
-    if overlap:
-        # first step of the overlapped path under a guard: RCCL only exists on the driver's multi-GPU box, so if anything
-        # about launching collectives from inside the backward fails there, every rank (same code, same failure) drops to
-        # the single all-reduce instead of losing the measurement
-        try:
-            step()
-            torch.cuda.synchronize()
-        except Exception as e:                                     # noqa: BLE001
-            print('rank %d: overlapped all-reduce failed (%s: %s); falling back to one all-reduce per step'
-                  % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
-            overlap = False
-            flat.on_grads_ready = None
-            flat._ov = None
-            flat.grad.zero_()
     # device initialisation, outside the W / K protocol and reported as `init_steps`: the first process on a fresh box pays
     # one-off costs (code-object load, allocator growth to the step's working set, clock ramp) that took up to 15 % off a
     # short measurement when only W = 1-2 warm-up steps preceded it
@@ -220,6 +245,17 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     lib.capmi_prof_enable(0)
+    allreduce_ms = None
+    if dist is not None and not overlap:
+        # collective time of the single flat all-reduce: HIP events around it on 5 extra (untimed) steps
+        ms = []
+        for _ in range(5):
+            ar_events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            step()
+            torch.cuda.synchronize()
+            ms.append(ar_events[0].elapsed_time(ar_events[1]))
+        ar_events = None
+        allreduce_ms = sorted(ms)[len(ms) // 2]
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -233,7 +269,7 @@ def main():
         a_ms, a_n, a_bytes, _ = prof_read(lib, 3)
         per_class = {'gemm_decode': {'ms_per_step': round(g_ms / args.steps, 4), 'launches_per_step': g_n / args.steps},
                      'attention_fwd': {'ms_per_step': round(a_ms / args.steps, 4), 'launches_per_step': a_n / args.steps},
-                     'note': 'full per-kernel table: profiles/r01*_scst_kernel_stats.md (rocprofv3 --kernel-trace --stats)'}
+                     'note': 'full per-kernel table: profiles/r02*_scst_kernel_stats.md (rocprofv3 --kernel-trace --stats)'}
         ach = (g_bytes / g_n) / (g_ms / g_n * 1e-3) / 1e9 if g_n else 0.0
         tfl = g_flops / (g_ms * 1e-3) / 1e12 if g_ms else 0.0
         # which roof bounds this launch mix.  The decode GEMMs compute fp32 through the bf16 pipe by the exact 3-way
@@ -283,6 +319,9 @@ def main():
                                    'RewardCriterion + BPTT + clip 0.1 + Adam',
                        'global_batch': B * world, 'captions_per_step': B * n * world, 'seq_len': L,
                        'parallelism': 'dp%d (flat fp32 gradient, %s)' % (world, ('bucketed RCCL all-reduce overlapped with the backward' if overlap else 'one RCCL all-reduce per step') if world > 1 else 'no collective')},
+            'collective': None if world == 1 else {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
+                                                   'mode': 'bucketed overlap' if overlap else 'one flat all-reduce per step',
+                                                   'bytes': int(flat.grad.numel() * 4), 'allreduce_ms': None if allreduce_ms is None else round(allreduce_ms, 3)},
             'loss': float(loss.detach()), 'roofline': roofline, 'attention': attention, 'kernel_ms_per_step': per_class,
             'cpu_baseline': cpu}
         print(json.dumps(line), flush=True)
@@ -301,17 +340,25 @@ def cpu_baseline(opt, model, B, n, L, iters):
     cores = min(os.cpu_count() or 1, int(os.environ.get('CAPMI_CPU_THREADS', '16')))
     torch.set_num_threads(cores)
     P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    corpus = synthetic.corpus(2000, seed=7)
+    corpus = synthetic.corpus(DF_IMAGES, seed=7)
     df, ref_len = synthetic.document_frequency(corpus)
     oracle = scst_step.ScstOracle(P, OC.CiderD(df, ref_len), drop_prob=opt.drop_prob_lm, lr=opt.learning_rate,
                                   clip=opt.grad_clip_value, sample_n=n, max_len=L)
     fc, att = synthetic.batch(B, seed=1234)
     gts = synthetic.corpus(B, seed=100)
     sec = scst_step.time_iterations(oracle, fc, att, gts, iters=iters, warmup=1)
-    return {'value': round(B * n / sec, 2), 'unit': 'captions/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d timed SCST iterations (bs%d x n%d, L=%d) of oracle/scst_step.py after 1 warm-up, median; '
-                      'torch fp32 on %d threads (host has %d cores; more threads are slower for these shapes)'
-                      % (iters, B, n, L, cores, os.cpu_count() or 1), 'sec_per_iteration': round(sec, 3)}
+    out = {'value': round(B * n / sec, 2), 'unit': 'captions/s', 'cores': cores, 'kind': 'port',
+           'sample': '%d timed SCST iterations (bs%d x n%d, L=%d) of oracle/scst_step.py after 1 warm-up, median; '
+                     'torch fp32 on %d threads (host has %d cores; more threads are slower for these shapes)'
+                     % (iters, B, n, L, cores, os.cpu_count() or 1), 'sec_per_iteration': round(sec, 3)}
+    # /root/reference does not exist on the GPU box, so the IMPORTED reference modules were timed in the build container on the
+    # same workload (scripts/time_reference_cpu.py -> profiles/r02_cpu_reference.json); reported beside the on-box port
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r02_cpu_reference.json')) as f:
+            out['reference_in_build_container'] = json.load(f)
+    except (OSError, ValueError):
+        out['reference_in_build_container'] = None
+    return out
 
 
 if __name__ == '__main__':
