@@ -1,0 +1,172 @@
+"""Real feature / label loader with the reference's batch-dict contract (captioning/data/dataloader.py:182-299), host side of
+SURVEY 8f-1/2: what feeds ``DevicePrefetcher`` when training on precomputed bottom-up features instead of synthetic data.
+
+Inputs (same options as the reference, ``opts.py:23-37``):
+  input_json      the dataset json of scripts/prepro_labels.py: ``images`` [{id, split, file_path}], ``ix_to_word``
+  input_label_h5  the label file.  h5py is not installable here, so the native format is an ``.npz`` with the SAME four arrays the
+                  reference's h5 holds (prepro_labels.py:158-163): ``labels`` uint32 [M, L], ``label_start_ix`` / ``label_end_ix``
+                  (1-based, inclusive), ``label_length``; an ``.h5`` path is read through h5py when that module exists
+                  (``tools/convert_labels.py`` turns one into the other once)
+  input_fc_dir    ``<id>.npy`` pooled features [F] (optional: mean of the regions when missing, dataloader.py:295-298)
+  input_att_dir   ``<id>.npz`` with key ``feat`` (or ``z``, dataloader.py:40) [K_i, F], K_i variable (10..100 for adaptive
+                  bottom-up features) -- or ``<id>.npy``
+
+``get_batch(split)`` returns CPU tensors: ``fc_feats [B,F]``, ``att_feats [B,Kmax,F]`` zero padded, ``att_masks [B,Kmax]`` or
+None when every image of the batch has Kmax regions (:240-241), ``labels [B,n,L+2]`` int64 with BOS/EOS columns 0, ``masks``
+(nonzeros + 2 ones, :245-249), ``gts`` (all reference rows of each image, uint32), ``bounds``, ``infos``.  Decompression of the
+next images runs on a small thread pool while the device computes (the reference uses DataLoader worker processes,
+:350-372)."""
+import json
+import os
+import random
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+
+def load_labels(path):
+    """-> dict(labels uint32 [M,L], label_start_ix, label_end_ix) from .npz (native) or .h5 (when h5py is importable)"""
+    if str(path).endswith('.npz'):
+        z = np.load(path)
+        return {k: z[k] for k in ('labels', 'label_start_ix', 'label_end_ix')}
+    try:
+        import h5py
+    except ImportError as e:
+        raise RuntimeError('%s is HDF5 and h5py is not available here: convert it once with tools/convert_labels.py '
+                           '(on a machine that has h5py) and pass the .npz' % path) from e
+    with h5py.File(path, 'r') as f:
+        return {k: f[k][:] for k in ('labels', 'label_start_ix', 'label_end_ix')}
+
+
+class FeatureLoader:
+    def __init__(self, opt, workers=4):
+        self.opt = opt
+        self.batch_size = opt.batch_size
+        self.seq_per_img = opt.seq_per_img
+        self.info = json.load(open(opt.input_json))
+        self.ix_to_word = self.info['ix_to_word']
+        self.vocab_size = len(self.ix_to_word)
+        lab = load_labels(opt.input_label_h5)
+        self.label = lab['labels']
+        self.label_start_ix, self.label_end_ix = lab['label_start_ix'], lab['label_end_ix']
+        self.seq_length = int(self.label.shape[1])
+        self.fc_dir, self.att_dir = getattr(opt, 'input_fc_dir', None), opt.input_att_dir
+        self.use_fc = bool(getattr(opt, 'use_fc', True))
+        self.norm_att_feat = bool(getattr(opt, 'norm_att_feat', 0))
+        self.split_ix = {'train': [], 'val': [], 'test': []}
+        for ix, img in enumerate(self.info['images']):        # dataloader.py:143-156
+            sp = img.get('split')
+            if sp is None:
+                for k in self.split_ix:
+                    self.split_ix[k].append(ix)
+            elif sp in self.split_ix:
+                self.split_ix[sp].append(ix)
+            elif getattr(opt, 'train_only', 0) == 0:            # restval
+                self.split_ix['train'].append(ix)
+        self.rng = random.Random(getattr(opt, 'seed', 1234))
+        self.order = {k: list(v) for k, v in self.split_ix.items()}
+        self.rng.shuffle(self.order['train'])                  # MySampler shuffles the train split (dataloader.py:394-397)
+        self.pos = {'train': 0, 'val': 0, 'test': 0}
+        self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        self._pending = {}
+
+    # ---- reference accessors
+    def get_vocab(self):
+        return self.ix_to_word
+
+    def get_vocab_size(self):
+        return self.vocab_size
+
+    def get_seq_length(self):
+        return self.seq_length
+
+    def document_frequency(self):
+        """{n-gram tuple -> #train images containing it}, #images -- what scripts/prepro_ngrams.py:17-80 stores in
+        data/<cached_tokens>.p (used when that pickle is not at hand)."""
+        from imagecaptioning.pytorch_amd import synthetic
+        refs = [self.label[self.label_start_ix[ix] - 1: self.label_end_ix[ix]] for ix in self.split_ix['train']]
+        return synthetic.document_frequency(refs)
+
+    # ---- one image
+    def _att(self, img_id):
+        p = os.path.join(self.att_dir, str(img_id) + '.npz')
+        if os.path.exists(p):
+            z = np.load(p)
+            a = z['feat'] if 'feat' in z else z['z']
+        else:
+            a = np.load(os.path.join(self.att_dir, str(img_id) + '.npy'))
+        a = np.asarray(a, dtype=np.float32).reshape(-1, a.shape[-1])
+        if self.norm_att_feat:
+            a = a / np.linalg.norm(a, 2, 1, keepdims=True)
+        return a
+
+    def _image(self, ix):
+        img_id = self.info['images'][ix]['id']
+        att = self._att(img_id)
+        fc = None
+        if self.use_fc:
+            p = os.path.join(self.fc_dir, str(img_id) + '.npy') if self.fc_dir else None
+            fc = np.load(p).astype(np.float32) if p and os.path.exists(p) else att.mean(0)      # dataloader.py:295-298
+        else:
+            fc = np.zeros((0,), dtype=np.float32)
+        return fc, att
+
+    def _captions(self, ix, rng):
+        """dataloader.py:165-184: seq_per_img consecutive captions from a random start, or sampling with replacement"""
+        ix1, ix2 = int(self.label_start_ix[ix]) - 1, int(self.label_end_ix[ix]) - 1
+        ncap = ix2 - ix1 + 1
+        assert ncap > 0, 'an image does not have any label'
+        n = self.seq_per_img
+        if ncap < n:
+            return np.stack([self.label[rng.randint(ix1, ix2)] for _ in range(n)]).astype(np.int64)
+        s = rng.randint(ix1, ix2 - n + 1)
+        return self.label[s:s + n].astype(np.int64)
+
+    # ---- batches
+    def _next_indices(self, split, B):
+        order, out, wrapped = self.order[split], [], False
+        for _ in range(B):
+            out.append(order[self.pos[split]])
+            self.pos[split] += 1
+            if self.pos[split] >= len(order):
+                self.pos[split] = 0
+                wrapped = True
+                if split == 'train':
+                    self.rng.shuffle(order)
+        return out, wrapped
+
+    def _schedule(self, split, B):
+        idx, wrapped = self._next_indices(split, B)
+        return idx, wrapped, self.pos[split], [self.pool.submit(self._image, ix) for ix in idx]
+
+    def get_batch(self, split, batch_size=None):
+        B = batch_size or self.batch_size
+        key = (split, B)
+        job = self._pending.pop(key, None) or self._schedule(split, B)
+        self._pending[key] = self._schedule(split, B)          # decode the NEXT batch's features in the background
+        idx, wrapped, pos_now, futs = job
+        feats = [f.result() for f in futs]
+        n, L = self.seq_per_img, self.seq_length
+        F = feats[0][1].shape[1]
+        kmax = max(a.shape[0] for _, a in feats)
+        fc = np.stack([f for f, _ in feats]).astype(np.float32)
+        att = np.zeros((B, kmax, F), dtype=np.float32)
+        att_masks = np.zeros((B, kmax), dtype=np.float32)
+        labels = np.zeros((B, n, L + 2), dtype=np.int64)
+        masks = np.zeros((B, n, L + 2), dtype=np.float32)
+        gts, infos = [], []
+        for b, (ix, (_, a)) in enumerate(zip(idx, feats)):
+            att[b, :a.shape[0]] = a
+            att_masks[b, :a.shape[0]] = 1
+            seq = self._captions(ix, self.rng)
+            labels[b, :, 1:L + 1] = seq
+            for j in range(n):
+                masks[b, j, :int((seq[j] != 0).sum()) + 2] = 1
+            gts.append(self.label[self.label_start_ix[ix] - 1: self.label_end_ix[ix]])
+            im = self.info['images'][ix]
+            infos.append({'ix': ix, 'id': im['id'], 'file_path': im.get('file_path', '')})
+        return {'fc_feats': torch.from_numpy(fc), 'att_feats': torch.from_numpy(att),
+                'att_masks': None if att_masks.sum() == att_masks.size else torch.from_numpy(att_masks),     # :240-241
+                'labels': torch.from_numpy(labels), 'masks': torch.from_numpy(masks), 'gts': gts,
+                'bounds': {'it_pos_now': pos_now, 'it_max': len(self.order[split]), 'wrapped': wrapped}, 'infos': infos}

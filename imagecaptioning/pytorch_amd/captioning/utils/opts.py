@@ -27,6 +27,8 @@ DEFAULTS = dict(
     sample_n_method='sample', verbose_beam=0,                                # opts.py:288-330 add_eval_sample_opts
     # data (synthetic only: the reference's h5/lmdb loaders are outside the hot path)
     input_synthetic=1, vocab_size=9487, synthetic_regions=36, synthetic_images=200,
+    # real precomputed features (captioning/data/feature_loader.py; opts.py:23-37 of the reference)
+    input_json='', input_label_h5='', input_fc_dir='', input_att_dir='', use_fc=1, norm_att_feat=0, train_only=0,
 )
 
 

@@ -51,8 +51,6 @@ def train(opt):
     if world > 1:
         dist.init_process_group('nccl', rank=rank, world_size=world)
         dist.barrier(device_ids=[local])              # RCCL communicator created on the main thread, before any backward
-    if not opt.input_synthetic:
-        raise SystemExit('only --input_synthetic 1 is available: the h5/lmdb loaders of the reference are outside the hot path')
     if opt.optim != 'adam':
         raise NotImplementedError("optim %r: the fused flat-buffer step implements Adam (misc.py:125-126, every BASELINE "
                                   "config); other optimizers of misc.build_optimizer are out of scope" % opt.optim)
@@ -60,7 +58,14 @@ def train(opt):
         raise NotImplementedError("grad_clip_mode %r: only clip_grad_value_ (train.py:194-195, the default) is fused into the "
                                   "Adam kernel" % opt.grad_clip_mode)
     opt.seed = opt.seed + rank                        # each rank draws its own images
-    loader = SyntheticLoader(opt)
+    if opt.input_json:                                # precomputed bottom-up features + labels (variable region counts)
+        from captioning.data.feature_loader import FeatureLoader
+        loader = FeatureLoader(opt)
+        opt.vocab_size, opt.seq_length = loader.vocab_size, loader.seq_length
+        if not getattr(opt, 'max_length', None) or opt.max_length > opt.seq_length:
+            opt.max_length = opt.seq_length
+    else:
+        loader = SyntheticLoader(opt)
     opt.vocab = loader.get_vocab()
     loader = DevicePrefetcher(loader, dev)             # batches arrive already resident in HBM (pinned, side stream)
     torch.manual_seed(1234)                           # identical weights on every rank
@@ -109,7 +114,11 @@ def train(opt):
         sc_flag = opt.self_critical_after != -1 and epoch >= opt.self_critical_after
         struc_flag = opt.structure_after != -1 and epoch >= opt.structure_after
         if (sc_flag or struc_flag) and not sc_ready:
-            rewards.init_scorer(loader.document_frequency(), device=dev)     # train.py:152,159 init_scorer(cached_tokens)
+            # train.py:152,159 init_scorer(opt.cached_tokens): the prepro_ngrams pickle (or its converted image) when it exists,
+            # else the same table rebuilt from the training references
+            ct = str(opt.cached_tokens)
+            have = any(os.path.exists(p_) for p_ in (ct, os.path.join('data', ct + '.p'), os.path.join('data', ct + '.capmi.npz')))
+            rewards.init_scorer(ct if (opt.input_json and have) else loader.document_frequency(), device=dev)
             sc_ready = True
         t0 = time.time()
         data = loader.get_batch('train')

@@ -1,0 +1,135 @@
+"""The real feature / label loader (captioning/data/feature_loader.py) against the reference's batch contract
+(captioning/data/dataloader.py:182-299): built on a tiny on-disk dataset with a VARIABLE number of regions per image."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+PKG = os.path.join(ROOT, 'imagecaptioning', 'pytorch_amd')
+
+
+def make_dataset(tmp, n_img=9, F=24, L=7, vocab=30, fixed_regions=None, seed=0):
+    rng = np.random.default_rng(seed)
+    att_dir, fc_dir = tmp / 'att', tmp / 'fc'
+    att_dir.mkdir(), fc_dir.mkdir()
+    images, labels, start, end = [], [], [], []
+    for i in range(n_img):
+        img_id = 1000 + i
+        K = fixed_regions or int(rng.integers(3, 9))
+        feat = np.clip(rng.standard_normal((K, F)), 0, None).astype(np.float32)
+        np.savez_compressed(att_dir / ('%d.npz' % img_id), feat=feat)
+        if i % 2 == 0:                                           # odd images have no fc file: mean of the regions (dataloader.py:295-298)
+            np.save(fc_dir / ('%d.npy' % img_id), feat.mean(0) + 1.0)
+        ncap = int(rng.integers(2, 7))                           # some images have fewer captions than seq_per_img
+        start.append(len(labels) + 1)
+        for _ in range(ncap):
+            ln = int(rng.integers(2, L + 1))
+            row = np.zeros(L, dtype=np.uint32)
+            row[:ln] = rng.integers(1, vocab + 1, size=ln)
+            labels.append(row)
+        end.append(len(labels))
+        images.append({'id': img_id, 'split': 'train' if i < n_img - 3 else ('val' if i < n_img - 1 else 'restval'),
+                       'file_path': 'img/%d.jpg' % img_id})
+    info = {'images': images, 'ix_to_word': {str(i): 'w%d' % i for i in range(1, vocab + 1)}}
+    (tmp / 'data.json').write_text(json.dumps(info))
+    np.savez(tmp / 'labels.npz', labels=np.stack(labels), label_start_ix=np.array(start, dtype=np.uint32),
+             label_end_ix=np.array(end, dtype=np.uint32), label_length=np.array([(r > 0).sum() for r in labels], dtype=np.uint32))
+    return ['--input_json', str(tmp / 'data.json'), '--input_label_h5', str(tmp / 'labels.npz'), '--input_att_dir', str(att_dir),
+            '--input_fc_dir', str(fc_dir), '--fc_feat_size', str(F), '--att_feat_size', str(F)]
+
+
+def _opts(argv):
+    sys.path.insert(0, PKG)
+    from captioning.utils import opts
+    return opts.parse_opt(argv)
+
+
+def test_batch_contract_variable_regions(tmp_path):
+    sys.path.insert(0, PKG)
+    from captioning.data.feature_loader import FeatureLoader
+    args = make_dataset(tmp_path)
+    ld = FeatureLoader(_opts(args + ['--batch_size', '4', '--seq_per_img', '3']))
+    assert ld.vocab_size == 30 and ld.seq_length == 7
+    assert len(ld.split_ix['train']) == 7 and len(ld.split_ix['val']) == 2      # restval joins train (train_only 0)
+    seen, wraps = [], 0
+    for _ in range(5):
+        d = ld.get_batch('train')
+        B, n, L = 4, 3, 7
+        K = d['att_feats'].shape[1]
+        assert d['fc_feats'].shape == (B, 24) and d['att_feats'].shape == (B, K, 24) and d['att_feats'].dtype == torch.float32
+        assert d['labels'].shape == (B, n, L + 2) and d['labels'].dtype == torch.int64 and d['masks'].shape == (B, n, L + 2)
+        assert bool((d['labels'][..., 0] == 0).all()) and bool((d['labels'][..., -1] == 0).all())
+        for b in range(B):
+            ix = d['infos'][b]['ix']
+            feat = np.load(tmp_path / 'att' / ('%d.npz' % d['infos'][b]['id']))['feat']
+            k = feat.shape[0]
+            np.testing.assert_array_equal(d['att_feats'][b, :k].numpy(), feat)
+            assert float(d['att_feats'][b, k:].abs().sum()) == 0
+            if d['att_masks'] is not None:
+                assert d['att_masks'][b].tolist() == [1.0] * k + [0.0] * (K - k)
+            else:
+                assert k == K
+            want_fc = feat.mean(0) + (1.0 if (d['infos'][b]['id'] - 1000) % 2 == 0 else 0.0)
+            np.testing.assert_allclose(d['fc_feats'][b].numpy(), want_fc, rtol=1e-6)
+            refs = ld.label[ld.label_start_ix[ix] - 1: ld.label_end_ix[ix]]
+            np.testing.assert_array_equal(d['gts'][b], refs)
+            for j in range(n):
+                row = d['labels'][b, j, 1:L + 1].numpy()
+                assert any((row == r).all() for r in refs)                          # every label row is one of the image's captions
+                nz = int((row != 0).sum())
+                assert d['masks'][b, j].tolist() == [1.0] * (nz + 2) + [0.0] * (L - nz)   # dataloader.py:245-249
+        seen += [i['ix'] for i in d['infos']]
+        wraps += int(d['bounds']['wrapped'])
+        assert d['bounds']['it_max'] == 7
+    assert wraps == 2 and set(seen) == set(ld.split_ix['train'])                  # 20 draws over 7 images: two epoch wraps
+    v = ld.get_batch('val', batch_size=2)
+    assert [i['ix'] for i in v['infos']] == ld.split_ix['val'] and v['bounds']['wrapped']
+
+
+def test_fixed_region_count_gives_no_att_masks_and_df_table(tmp_path):
+    sys.path.insert(0, PKG)
+    from captioning.data.feature_loader import FeatureLoader
+    args = make_dataset(tmp_path, fixed_regions=5)
+    ld = FeatureLoader(_opts(args + ['--batch_size', '3', '--seq_per_img', '2']))
+    d = ld.get_batch('train')
+    assert d['att_masks'] is None and d['att_feats'].shape[1] == 5               # dataloader.py:240-241
+    df, ref_len = ld.document_frequency()
+    assert ref_len == len(ld.split_ix['train']) and all(1 <= c <= ref_len for c in df.values())
+    assert (0,) in df                                                           # the terminating 0 counts as a token (rewards.py:33-39)
+
+
+def test_h5_labels_need_h5py_or_the_converter(tmp_path):
+    sys.path.insert(0, PKG)
+    from captioning.data import feature_loader as FL
+    (tmp_path / 'x.h5').write_bytes(b'not really hdf5')
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError, match='convert_labels'):
+            FL.load_labels(str(tmp_path / 'x.h5'))
+
+
+@pytest.mark.gpu
+def test_train_on_real_feature_files_xe_then_scst(tmp_path):
+    """tools/train.py end to end on on-disk features with 3..8 regions per image (att_masks path), through the prefetcher"""
+    sys.path.insert(0, PKG)
+    from imagecaptioning.pytorch_amd.tools import train as T
+    from captioning.utils import rewards
+    data = tmp_path / 'data'
+    data.mkdir()
+    args = make_dataset(data, n_img=12)
+    small = args + ['--caption_model', 'updown', '--rnn_size', '32', '--input_encoding_size', '32', '--att_hid_size', '16',
+                    '--batch_size', '4', '--seq_per_img', '3', '--losses_log_every', '5', '--checkpoint_path', str(tmp_path / 'ck'),
+                    '--learning_rate', '0.01']
+    l0 = T.train(_opts(small + ['--max_iters', '1']))
+    l1 = T.train(_opts(small + ['--max_iters', '30', '--save_checkpoint_every', '30']))
+    assert l1 < l0
+    rewards.reset_scorer()
+    T.train(_opts(small + ['--max_iters', '33', '--self_critical_after', '0', '--train_sample_n', '3', '--start_from', str(tmp_path / 'ck'),
+                           '--cached_tokens', 'no-such-table']))
+    rewards.reset_scorer()
