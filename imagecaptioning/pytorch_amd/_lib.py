@@ -138,6 +138,8 @@ SIGNATURES = {
     'capmi_relu_mask_bwd': [_P, _P, _P, _P, _I64, _P],
     'capmi_adam_step': [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _I, _P],
     'capmi_ciderd_score': [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, C.c_uint32, C.c_double, _P, _P],
+    'capmi_ciderd_cook_refs': [_P, _P, _I, _I, _I, _P, _P, C.c_uint32, C.c_double, _P, _P],
+    'capmi_ciderd_score_cooked': [_P, _I, _I, _P, _P, _P, _I, _P, _P, C.c_uint32, C.c_double, _P, _P],
     'capmi_scst_advantage': [_P, _I, _I, _P, _P],
     'capmi_prof_enable': [_I],
     'capmi_prof_reset': [],

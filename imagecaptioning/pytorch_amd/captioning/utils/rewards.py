@@ -77,13 +77,15 @@ def self_critical_reward_device(greedy_res, data_gts, gen_result, opt):
         raise NotImplementedError('BLEU reward (default weight 0, opts.py:185) is out of scope')
     B = len(data_gts)
     n = gen_result.shape[0] // B
-    refs, n_refs = _pack(data_gts)
+    packed = _pack(data_gts)
+    refs, n_refs = packed
     hyp_all = getattr(gen_result, '_capmi_all', None)        # fused SCST rollout: sampled + greedy rows already side by side
     if hyp_all is not None and not (hyp_all.dtype == torch.long and hyp_all.is_contiguous() and
                                     hyp_all.shape[0] == gen_result.shape[0] + greedy_res.shape[0]):
         hyp_all = None
     reward, scores = CiderD_scorer.self_critical_reward(greedy_res.long().contiguous(), gen_result.long().contiguous(),
-                                                         refs, n_refs, n, hyp_all=hyp_all)
+                                                         refs, n_refs, n, hyp_all=hyp_all,
+                                                         cooked=getattr(packed, 'cooked', None))
     w = getattr(opt, 'cider_reward_weight', 1)
     if w != 1:
         reward = reward * w
@@ -105,7 +107,9 @@ def get_scores(data_gts, gen_result, opt, as_tensor=False):
     B = len(data_gts)
     N = gen_result.shape[0]
     n = N // B
-    refs, n_refs = _pack(data_gts)
+    packed = _pack(data_gts)
+    refs, n_refs = packed
     img = (torch.arange(N, device=gen_result.device) // n).to(torch.int32)
-    scores = CiderD_scorer.score(gen_result.long().contiguous(), img, refs, n_refs) * getattr(opt, 'cider_reward_weight', 1)
+    scores = CiderD_scorer.score(gen_result.long().contiguous(), img, refs, n_refs, getattr(packed, 'cooked', None)) * \
+        getattr(opt, 'cider_reward_weight', 1)
     return scores if as_tensor else scores.cpu().numpy()

@@ -86,6 +86,15 @@ def load_df_image(path):
     return keys, vals, float(z['ref_len'])
 
 
+class PackedRefs(tuple):
+    """(refs int32 [B,max_refs,w], n_refs int32 [B]) -- unpacks like the pair it used to be -- plus `.cooked`"""
+
+    def __new__(cls, refs, n_refs, cooked=None):
+        self = super().__new__(cls, (refs, n_refs))
+        self.cooked = cooked
+        return self
+
+
 class DeviceCiderD:
     def __init__(self, document_frequency, ref_len, device, _table=None):
         keys, vals = _table if _table is not None else build_table(document_frequency)
@@ -123,19 +132,35 @@ class DeviceCiderD:
                 full = (g != 0).all(1)
                 refs[i, :g.shape[0], g.shape[1]][full] = -1
             n_refs[i] = g.shape[0]
-        return torch.from_numpy(refs).to(self.device), torch.from_numpy(n_refs).to(self.device)
+        refs_d, n_refs_d = torch.from_numpy(refs).to(self.device), torch.from_numpy(n_refs).to(self.device)
+        return PackedRefs(refs_d, n_refs_d, self.cook(refs_d, n_refs_d))
 
-    def score(self, hyp, hyp_img, refs, n_refs):
+    COOKED_BYTES = 4392            # capmi.h CAPMI_CIDERD_COOKED_BYTES
+
+    def cook(self, refs, n_refs):
+        """references cooked once per batch (capmi_ciderd_cook_refs): uint8 [B*max_refs, COOKED_BYTES] on the device"""
+        B, max_refs, w = refs.shape
+        cooked = torch.zeros(B * max_refs, self.COOKED_BYTES, dtype=torch.uint8, device=refs.device)
+        check(lib.capmi_ciderd_cook_refs(ptr(refs), ptr(n_refs), B, max_refs, w, ptr(self.keys), ptr(self.vals), self.cap,
+                                         self.log_ref_len, ptr(cooked), stream_ptr()), 'capmi_ciderd_cook_refs')
+        return cooked
+
+    def score(self, hyp, hyp_img, refs, n_refs, cooked=None):
         """hyp int64 [H,L] (device), hyp_img int32 [H] -> float64 [H] CIDEr-D, no host sync."""
         assert hyp.dtype == torch.long and hyp.is_contiguous() and hyp.is_cuda
         H, L = hyp.shape
         scores = torch.empty(H, dtype=torch.float64, device=hyp.device)
+        if cooked is not None:
+            check(lib.capmi_ciderd_score_cooked(ptr(hyp), H, L, ptr(hyp_img), ptr(cooked), ptr(n_refs), refs.shape[1],
+                                                ptr(self.keys), ptr(self.vals), self.cap, self.log_ref_len, ptr(scores),
+                                                stream_ptr()), 'capmi_ciderd_score_cooked')
+            return scores
         check(lib.capmi_ciderd_score(ptr(hyp), H, L, ptr(hyp_img), ptr(refs), ptr(n_refs), refs.shape[1], refs.shape[2],
                                      ptr(self.keys), ptr(self.vals), self.cap, self.log_ref_len, ptr(scores),
                                      stream_ptr()), 'capmi_ciderd_score')
         return scores
 
-    def self_critical_reward(self, greedy, sampled, refs, n_refs, n, hyp_all=None):
+    def self_critical_reward(self, greedy, sampled, refs, n_refs, n, hyp_all=None, cooked=None):
         """rewards.py:41-81 on device: scores of N sampled + B greedy rows, advantage [N] float32.
         hyp_all: the [N+B, L] tensor holding `sampled` then `greedy` already side by side (the fused SCST rollout writes them
         that way): scored in place, no concatenation."""
@@ -149,7 +174,7 @@ class DeviceCiderD:
                 self._img_cache = {}
             img = torch.cat([torch.arange(N, device=hyp.device) // n, torch.arange(B, device=hyp.device)]).to(torch.int32)
             self._img_cache[key] = img
-        scores = self.score(hyp, img, refs, n_refs)
+        scores = self.score(hyp, img, refs, n_refs, cooked)
         reward = torch.empty(N, dtype=torch.float32, device=hyp.device)
         check(lib.capmi_scst_advantage(ptr(scores), N, n, ptr(reward), stream_ptr()), 'capmi_scst_advantage')
         return reward, scores

@@ -96,12 +96,36 @@ __device__ void cook(const int *tok, int w, Cooked &c, const uint64_t *keys, con
     __syncthreads();
 }
 
+static_assert(sizeof(Cooked) == CAPMI_CIDERD_COOKED_BYTES, "capmi.h CAPMI_CIDERD_COOKED_BYTES must equal sizeof(Cooked)");
+
+// References are cooked ONCE per batch (SURVEY Appendix A "refs pre-cooked per image once"): the scoring kernel below cooked
+// each of an image's references again for every one of its hypotheses (300 cooks instead of 50 at bs10 x (5+1), with their
+// hash probes and O(len^2) de-duplication loops).  One workgroup per (image, reference slot).
+__global__ __launch_bounds__(CT) void ciderd_cook_refs_kernel(const int32_t *__restrict__ refs, const int32_t *__restrict__ n_refs,
+                                                             int max_refs, int ref_w, const uint64_t *__restrict__ keys,
+                                                             const double *__restrict__ vals, uint32_t cap, double log_ref_len,
+                                                             Cooked *__restrict__ out) {
+    __shared__ Cooked Rf;
+    __shared__ int tok_r[LMAX];
+    const int img = blockIdx.x / max_refs, r = blockIdx.x % max_refs;
+    if (r >= n_refs[img]) return;
+    if (threadIdx.x < ref_w) tok_r[threadIdx.x] = refs[((size_t)img * max_refs + r) * ref_w + threadIdx.x];
+    __syncthreads();
+    cook(tok_r, ref_w, Rf, keys, vals, cap, log_ref_len);
+    const uint64_t *src = reinterpret_cast<const uint64_t *>(&Rf);
+    uint64_t *dst = reinterpret_cast<uint64_t *>(out + blockIdx.x);
+    for (int i = threadIdx.x; i < (int)(sizeof(Cooked) / 8); i += CT) dst[i] = src[i];
+}
+
+// COOKED: the references come pre-cooked from ciderd_cook_refs_kernel (refs / ref_w unused)
+template <bool COOKED>
 __global__ __launch_bounds__(CT) void ciderd_kernel(const int64_t *__restrict__ hyp, int L,
                                                    const int32_t *__restrict__ hyp_img,
                                                    const int32_t *__restrict__ refs,
                                                    const int32_t *__restrict__ n_refs, int max_refs, int ref_w,
                                                    const uint64_t *__restrict__ keys, const double *__restrict__ vals,
-                                                   uint32_t cap, double log_ref_len, double *__restrict__ scores) {
+                                                   uint32_t cap, double log_ref_len, double *__restrict__ scores,
+                                                   const Cooked *__restrict__ cooked) {
     __shared__ Cooked H, Rf;
     __shared__ int tok_h[LMAX], tok_r[LMAX];
     __shared__ double contrib[CT];
@@ -116,9 +140,16 @@ __global__ __launch_bounds__(CT) void ciderd_kernel(const int64_t *__restrict__ 
     const int nr = n_refs[img];
     const int len_h_bi = H.len > 0 ? H.len - 1 : 0;      // upstream "length" = number of bigrams
     for (int r = 0; r < nr; ++r) {
-        if (tid < ref_w) tok_r[tid] = refs[((size_t)img * max_refs + r) * ref_w + tid];
-        __syncthreads();
-        cook(tok_r, ref_w, Rf, keys, vals, cap, log_ref_len);
+        if (COOKED) {
+            const uint64_t *src = reinterpret_cast<const uint64_t *>(cooked + (size_t)img * max_refs + r);
+            uint64_t *dst = reinterpret_cast<uint64_t *>(&Rf);
+            for (int i = tid; i < (int)(sizeof(Cooked) / 8); i += CT) dst[i] = src[i];
+            __syncthreads();
+        } else {
+            if (tid < ref_w) tok_r[tid] = refs[((size_t)img * max_refs + r) * ref_w + tid];
+            __syncthreads();
+            cook(tok_r, ref_w, Rf, keys, vals, cap, log_ref_len);
+        }
         double cv = 0.0;
         if (H.first[tid]) {
             const uint64_t key = H.key[tid];
@@ -159,8 +190,34 @@ extern "C" int capmi_ciderd_score(const int64_t *hyp, int H, int L, const int32_
     if (!hyp || !hyp_img || !refs || !n_refs || !table_keys || !table_vals || !scores) return CAPMI_EINVAL;
     if (H <= 0 || L <= 0 || L > LMAX || ref_w <= 0 || ref_w > LMAX || max_refs <= 0) return CAPMI_EINVAL;
     if (table_cap == 0 || (table_cap & (table_cap - 1))) return CAPMI_EINVAL;
-    hipLaunchKernelGGL(ciderd_kernel, dim3(H), dim3(CT), 0, (hipStream_t)stream, hyp, L, hyp_img, refs, n_refs, max_refs,
-                       ref_w, table_keys, table_vals, table_cap, log_ref_len, scores);
+    hipLaunchKernelGGL(ciderd_kernel<false>, dim3(H), dim3(CT), 0, (hipStream_t)stream, hyp, L, hyp_img, refs, n_refs, max_refs,
+                       ref_w, table_keys, table_vals, table_cap, log_ref_len, scores, (const Cooked *)nullptr);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int capmi_ciderd_cook_refs(const int32_t *refs, const int32_t *n_refs, int B, int max_refs, int ref_w,
+                                      const uint64_t *table_keys, const double *table_vals, uint32_t table_cap,
+                                      double log_ref_len, void *cooked, void *stream) {
+    if (!refs || !n_refs || !table_keys || !table_vals || !cooked || B <= 0 || max_refs <= 0 || ref_w <= 0 || ref_w > LMAX)
+        return CAPMI_EINVAL;
+    if (table_cap == 0 || (table_cap & (table_cap - 1)) || (reinterpret_cast<uintptr_t>(cooked) & 7)) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(ciderd_cook_refs_kernel, dim3(B * max_refs), dim3(CT), 0, (hipStream_t)stream, refs, n_refs, max_refs, ref_w,
+                       table_keys, table_vals, table_cap, log_ref_len, reinterpret_cast<Cooked *>(cooked));
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int capmi_ciderd_score_cooked(const int64_t *hyp, int H, int L, const int32_t *hyp_img, const void *cooked,
+                                         const int32_t *n_refs, int max_refs, const uint64_t *table_keys,
+                                         const double *table_vals, uint32_t table_cap, double log_ref_len, double *scores,
+                                         void *stream) {
+    if (!hyp || !hyp_img || !cooked || !n_refs || !table_keys || !table_vals || !scores) return CAPMI_EINVAL;
+    if (H <= 0 || L <= 0 || L > LMAX || max_refs <= 0) return CAPMI_EINVAL;
+    if (table_cap == 0 || (table_cap & (table_cap - 1))) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(ciderd_kernel<true>, dim3(H), dim3(CT), 0, (hipStream_t)stream, hyp, L, hyp_img, (const int32_t *)nullptr,
+                       n_refs, max_refs, 0, table_keys, table_vals, table_cap, log_ref_len, scores,
+                       reinterpret_cast<const Cooked *>(cooked));
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

@@ -328,6 +328,17 @@ int capmi_ciderd_score(const int64_t *hyp, int H, int L, const int32_t *hyp_img,
                        const int32_t *refs, const int32_t *n_refs, int max_refs, int ref_w,
                        const uint64_t *table_keys, const double *table_vals, uint32_t table_cap,
                        double log_ref_len, double *scores, void *stream);
+/* References cooked once per batch: n-gram keys, tf-idf vectors, norms and length of every reference of
+ * every image, CAPMI_CIDERD_COOKED_BYTES per (image, reference slot) in `cooked` [B * max_refs]; capmi_ciderd_score_cooked
+ * then scores hypotheses against them without re-cooking a reference per hypothesis (same arithmetic, same results). */
+#define CAPMI_CIDERD_COOKED_BYTES 4392
+int capmi_ciderd_cook_refs(const int32_t *refs, const int32_t *n_refs, int B, int max_refs, int ref_w,
+                           const uint64_t *table_keys, const double *table_vals, uint32_t table_cap,
+                           double log_ref_len, void *cooked, void *stream);
+int capmi_ciderd_score_cooked(const int64_t *hyp, int H, int L, const int32_t *hyp_img, const void *cooked,
+                              const int32_t *n_refs, int max_refs, const uint64_t *table_keys,
+                              const double *table_vals, uint32_t table_cap, double log_ref_len, double *scores,
+                              void *stream);
 /* advantage + broadcast (rewards.py:76-79): reward[r] = scores[r] - scores[N + r/n]  (float32 [N]) */
 int capmi_scst_advantage(const double *scores, int N, int n, float *reward, void *stream);
 

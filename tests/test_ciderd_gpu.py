@@ -58,6 +58,15 @@ def test_ciderd_kernel_matches_oracle(vocab, L, B, n):
     img_all = np.concatenate([np.arange(N) // n, np.arange(B)])
     scores_c = C.CiderDRefC(df, ref_len).score(hyp_all, img_all, gts)
     np.testing.assert_allclose(scores.cpu().numpy(), scores_c, rtol=1e-10, atol=1e-12)
+    # references cooked once per batch (capmi_ciderd_cook_refs) must give bit-identical scores
+    packed = dev.pack_refs(gts)
+    assert packed.cooked is not None and packed.cooked.shape == (B * refs.shape[1], dev.COOKED_BYTES)
+    hyp_t = torch.from_numpy(hyp_all).to(DEV)
+    img_t = torch.from_numpy(img_all.astype(np.int32)).to(DEV)
+    plain = dev.score(hyp_t, img_t, refs, n_refs)
+    cooked = dev.score(hyp_t, img_t, refs, n_refs, packed.cooked)
+    assert torch.equal(plain, cooked)
+    assert torch.equal(plain, scores)
 
 
 def test_ciderd_edge_cases_empty_ragged_and_full_length():
@@ -100,3 +109,7 @@ def test_ciderd_edge_cases_empty_ragged_and_full_length():
     np.testing.assert_allclose(scores.cpu().numpy(), scores_ref, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(reward.cpu().numpy(), rewards_ref[:, 0], rtol=1e-5, atol=1e-6)
     assert np.isfinite(scores_ref).all()
+    packed = dev.pack_refs(gts)                       # ragged reference counts / widths through the pre-cooked path
+    reward2, scores2 = dev.self_critical_reward(torch.from_numpy(greedy).to(DEV), torch.from_numpy(sampled).to(DEV), refs,
+                                                n_refs, n, cooked=packed.cooked)
+    assert torch.equal(scores, scores2) and torch.equal(reward, reward2)
