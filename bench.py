@@ -160,6 +160,8 @@ def main():
     # CAPMI_DDP_OVERLAP=1 opts into the bucketed variant (6 collectives launched from inside the backward as the phases finish
     # their gradients, clip+Adam pipelined behind them).
     overlap = world > 1 and os.environ.get('CAPMI_DDP_OVERLAP', '0') == '1'
+    # CAPMI_DDP_MODE=rsag: reduce-scatter -> clip+Adam on the rank's 1/N shard -> all-gather of the parameters
+    sharded = world > 1 and not overlap and os.environ.get('CAPMI_DDP_MODE', 'allreduce') == 'rsag'
     if overlap:
         flat.begin_overlap()
     if world > 1:
@@ -208,6 +210,8 @@ def main():
             # the BPTT loop, LSTM weights before the attention/prefill gradients); reduce the rest and run clip+Adam
             # bucket by bucket as the collectives land
             flat.finish_overlap_and_step(**adam)
+        elif sharded:
+            flat.sharded_step(**adam)
         elif world > 1:
             if nonlocal_ar is not None:
                 nonlocal_ar[0].record()
@@ -246,7 +250,7 @@ def main():
     dt = time.perf_counter() - t0
     lib.capmi_prof_enable(0)
     allreduce_ms = None
-    if dist is not None and not overlap:
+    if dist is not None and not overlap and not sharded:
         # collective time of the single flat all-reduce: HIP events around it on 5 extra (untimed) steps
         ms = []
         for _ in range(5):
@@ -320,7 +324,7 @@ def main():
                        'global_batch': B * world, 'captions_per_step': B * n * world, 'seq_len': L,
                        'parallelism': 'dp%d (flat fp32 gradient, %s)' % (world, ('bucketed RCCL all-reduce overlapped with the backward' if overlap else 'one RCCL all-reduce per step') if world > 1 else 'no collective')},
             'collective': None if world == 1 else {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
-                                                   'mode': 'bucketed overlap' if overlap else 'one flat all-reduce per step',
+                                                   'mode': 'bucketed overlap' if overlap else ('reduce-scatter + sharded Adam + all-gather' if sharded else 'one flat all-reduce per step'),
                                                    'bytes': int(flat.grad.numel() * 4), 'allreduce_ms': None if allreduce_ms is None else round(allreduce_ms, 3)},
             'loss': float(loss.detach()), 'roofline': roofline, 'attention': attention, 'kernel_ms_per_step': per_class,
             'cpu_baseline': cpu}

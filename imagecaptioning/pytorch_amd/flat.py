@@ -26,7 +26,8 @@ class FlatParams:
         for s in sizes:
             self.offsets.append(off)
             off += (s + 3) // 4 * 4
-        self.total = off
+        self.used = off
+        self.total = (off + 63) // 64 * 64          # equal 16-byte-aligned shards for up to 16 ranks (sharded_step)
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.grad_views = {}
@@ -131,7 +132,7 @@ class FlatParams:
         import torch.distributed as dist
         ov = self._ov
         pos = 0
-        for lo, hi in sorted(ov['done']) + [(self.total, self.total)]:
+        for lo, hi in sorted(ov['done']) + [(self.used, self.used)]:      # the padding behind `used` carries no gradient
             if lo > pos:
                 ov['works'].append(dist.all_reduce(self.grad[pos:lo], op=dist.ReduceOp.SUM, group=ov['group'], async_op=True))
                 ov['done'].append((pos, lo))
@@ -169,6 +170,32 @@ class FlatParams:
         import torch.distributed as dist
         ws = world_size or dist.get_world_size(group)
         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+        return 1.0 / ws
+
+    def sharded_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=0.0, group=None, adam=None):
+        """Reduce-scatter + all-gather instead of all-reduce (the two halves of the collective, with the
+        optimizer between them): every rank receives the SUM of ONE 1/G shard of the flat gradient, runs the fused clip+Adam
+        on that shard only (1/G of the 28 B/parameter the optimizer streams), and the updated parameter shards are all-gathered.
+        Same wire bytes as a ring all-reduce, but the 0.27 ms Adam pass shrinks by G and no rank ever holds -- or clips --
+        anything but averaged gradients.  Elementwise update => identical to all_reduce() + adam_step().
+        `adam`: test hook replacing ops.adam_step (CPU tests have no HIP device)."""
+        import torch.distributed as dist
+        ws, rank = dist.get_world_size(group), dist.get_rank(group)
+        if self.total % (4 * ws):
+            raise ValueError('flat buffer of %d floats does not split into %d aligned shards' % (self.total, ws))
+        shard = self.total // ws
+        lo, hi = rank * shard, (rank + 1) * shard
+        try:
+            dist.reduce_scatter_tensor(self.grad[lo:hi], self.grad, op=dist.ReduceOp.SUM, group=group)
+        except (RuntimeError, NotImplementedError):        # gloo has no reduce-scatter: same result through an all-reduce
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+        self.step_count += 1
+        (adam or ops.adam_step)(self.flat[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], lr, betas[0],
+                                betas[1], eps, weight_decay, clip_value, 1.0 / ws, self.step_count)
+        try:
+            dist.all_gather_into_tensor(self.flat, self.flat[lo:hi], group=group)
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather([self.flat[r * shard:(r + 1) * shard] for r in range(ws)], self.flat[lo:hi].clone(), group=group)
         return 1.0 / ws
 
     def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=0.0, grad_scale=1.0):

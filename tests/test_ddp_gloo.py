@@ -121,3 +121,65 @@ def test_single_flat_allreduce_averages_gradients():
         clipped_after = want.clamp(-0.1, 0.1)
         clipped_before = (got[0][0][i].clamp(-0.1, 0.1) + got[1][0][i].clamp(-0.1, 0.1)) / 2
         assert clipped_after.shape == clipped_before.shape
+
+
+def _cpu_adam(p, g, m, v, lr, b1, b2, eps, wd, clip, scale, step):
+    """reference arithmetic of capmi_adam_step (clip after scaling, bias-corrected Adam) for the CPU-only test"""
+    g = g * scale
+    if clip > 0:
+        g = g.clamp(-clip, clip)
+    if wd:
+        g = g + wd * p
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.addcdiv_(m / (1 - b1 ** step), (v / (1 - b2 ** step)).sqrt() + eps, value=-lr)
+
+
+def _worker_sharded(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from imagecaptioning.pytorch_amd.flat import FlatParams
+    out = []
+    for mode in ('allreduce', 'sharded'):
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+        flat = FlatParams(net)
+        assert flat.total % 64 == 0 and flat.total >= flat.used
+        for step in range(3):
+            g = torch.Generator().manual_seed(100 * step + rank)
+            for n, p in zip(flat.names, flat.params):
+                flat.grad_views[n].copy_(torch.randn(p.shape, generator=g) * (rank + 1))
+            flat.end_backward()
+            if mode == 'allreduce':
+                scale = flat.all_reduce()
+                flat.step_count += 1
+                _cpu_adam(flat.flat, flat.grad, flat.exp_avg, flat.exp_avg_sq, 1e-2, 0.9, 0.999, 1e-8, 0.0, 0.1, scale, flat.step_count)
+            else:
+                flat.sharded_step(1e-2, clip_value=0.1, adam=_cpu_adam)
+        out.append(flat.flat.clone())
+        assert all(torch.equal(p.data, flat.flat[o:o + p.numel()].view_as(p)) for p, o in zip(flat.params, flat.offsets))
+    q.put((rank, out[0], out[1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_step_reduce_scatter_adam_all_gather_equals_all_reduce():
+    """reduce-scatter -> clip+Adam on the own shard -> all-gather of the parameters == all-reduce + full Adam, and every rank
+    ends with the same, complete parameters"""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        rank, a, b = q.get(timeout=120)
+        got[rank] = (a, b)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.equal(got[0][1], got[1][1])                     # replicas identical after the all-gather
+    assert torch.allclose(got[0][0], got[0][1], atol=1e-7)       # same update as the all-reduce route
