@@ -94,13 +94,44 @@ class Attention(nn.Module):
 
 
 class UpDownCore(nn.Module):
-    """Parameter holder for UpDownCore (AttModel.py:615-622): att_lstm, lang_lstm, attention."""
+    """UpDownCore (AttModel.py:615-640): att_lstm, lang_lstm, attention.  The rollouts never call this module (they run in
+    libcapmi from its parameters); ``forward`` is the reference's step contract for callers that drive the core themselves
+    (AttEnsemble.py:52-53 ``m.core(xt, fc, att, p_att, state, masks)``), served by the same kernels: two 4-/3-segment gate
+    GEMMs read the concatenated inputs in place, the LSTM cells finish their split-K slabs, fused region attention.  No
+    autograd through it (inference API)."""
 
     def __init__(self, opt):
         super().__init__()
         self.att_lstm = nn.LSTMCell(opt.input_encoding_size + opt.rnn_size * 2, opt.rnn_size)
         self.lang_lstm = nn.LSTMCell(opt.rnn_size * 2, opt.rnn_size)
         self.attention = Attention(opt)
+        self.drop_prob_lm = opt.drop_prob_lm
+
+    @torch.no_grad()
+    def forward(self, xt, fc_feats, att_feats, p_att_feats, state, att_masks=None):
+        h, c = state
+        N, R = h[0].shape
+        E = xt.shape[1]
+        ws = ops.default_workspace(xt.device)
+        f = lambda t: t.detach().float().contiguous()              # noqa: E731
+        xt, fc_feats, att_feats, p_att_feats = f(xt), f(fc_feats), f(att_feats), f(p_att_feats)
+        h_lang_prev, h_att_prev, c_att_prev, c_lang_prev = f(h[1]), f(h[0]), f(c[0]), f(c[1])
+        a, l, at = self.att_lstm, self.lang_lstm, self.attention
+        ld = 2 * R + E
+        W = a.weight_ih.detach()
+        # att_lstm input = cat([prev_h, fc_feats, xt]) (AttModel.py:626): three K segments of W_ih + W_hh, read in place
+        splits = ops.gemm([(h_lang_prev, R, W, ld, R, 1), (fc_feats, R, (W, R), ld, R, 1), (xt, E, (W, 2 * R), ld, E, 1),
+                           (h_att_prev, R, a.weight_hh.detach(), R, R, 1)], N, 4 * R, ws.buf, ws=ws, defer_reduce=True)
+        h_att, c_att, _, _ = ops.lstm_cell_fwd(ws.slabs, splits, a.bias_ih.detach(), a.bias_hh.detach(), c_att_prev)
+        att_h = ops.linear(h_att, at.h2att.weight.detach(), at.h2att.bias.detach(), ws=ws)
+        ctx, _ = ops.attention_fwd(att_h, p_att_feats, att_feats, None if att_masks is None else f(att_masks),
+                                   at.alpha_net.weight.detach().reshape(-1).contiguous(), at.alpha_net.bias.detach(), 1)
+        Wl = l.weight_ih.detach()
+        splits = ops.gemm([(ctx, R, Wl, 2 * R, R, 1), (h_att, R, (Wl, R), 2 * R, R, 1),
+                           (h_lang_prev, R, l.weight_hh.detach(), R, R, 1)], N, 4 * R, ws.buf, ws=ws, defer_reduce=True)
+        h_lang, c_lang, _, _ = ops.lstm_cell_fwd(ws.slabs, splits, l.bias_ih.detach(), l.bias_hh.detach(), c_lang_prev)
+        out = nn.functional.dropout(h_lang, self.drop_prob_lm, self.training)
+        return out, (torch.stack([h_att, h_lang]), torch.stack([c_att, c_lang]))
 
 
 class AttModel(CaptionModel):

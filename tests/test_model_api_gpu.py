@@ -458,3 +458,34 @@ def test_scheduled_sampling_matches_oracle(flatten):
         b = model(fc.to(DEV), att.to(DEV), labels[..., :-1].to(DEV), am.to(DEV))
     assert torch.isfinite(a).all() and not torch.equal(a, b)            # fresh draws per call
     assert torch.equal(a[:, 0], b[:, 0])                                # step 0 only sees BOS
+
+
+def test_step_api_embed_core_logit_are_callable_like_the_reference():
+    """AttEnsemble.py:29-61 drives a model through m.embed(it) -> m.core(xt, fc, att, p_att, state, masks) -> m.logit(out):
+    the three attributes must be callable and reproduce get_logprobs_state / the reference's greedy fixture."""
+    z, model = golden_model(False)
+    model.eval()
+    fc, att, am = (torch.from_numpy(z[k]).to(DEV) for k in ('fc', 'att', 'att_masks'))
+    with torch.no_grad():
+        p_fc, p_att_feats, pp_att, p_masks = model._prepare_feature(fc, att, am)
+        B = fc.shape[0]
+        state = model.init_hidden(B)
+        state2 = model.init_hidden(B)
+        it = torch.zeros(B, dtype=torch.long, device=DEV)
+        seq = []
+        for t in range(model.seq_length):
+            xt = model.embed(it)
+            out, state = model.core(xt, p_fc, p_att_feats, pp_att, state, p_masks)
+            logp = torch.log_softmax(model.logit(out), 1)
+            want, state2 = model.get_logprobs_state(it, p_fc, p_att_feats, pp_att, p_masks, state2)
+            assert float((logp - want).abs().max()) < 2e-5
+            for a_, b_ in zip(state, state2):
+                assert float((a_ - b_).abs().max()) < 2e-5
+            it = logp.argmax(1)
+            seq.append(it)
+        seq = torch.stack(seq, 1)
+    ref = z['greedy_seq_mask']
+    got = seq.cpu().numpy()
+    for r in range(B):                                # rows agree with the reference's greedy decode up to the first EOS
+        n_ = int((ref[r] > 0).sum())
+        assert (got[r, :n_] == ref[r, :n_]).all()
