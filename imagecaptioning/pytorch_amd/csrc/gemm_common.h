@@ -1,5 +1,5 @@
-// Shared argument block of the GEMM kernels (LDS-tiled fat kernel in gemm_f32.hip, direct-to-register
-// skinny kernel in gemm_skinny.hip).
+// Shared argument block of the GEMM kernels (LDS-tiled kernel in gemm_f32.hip, A-resident decode kernel in gemm_ares.hip,
+// bf16x3 fat kernel in gemm_x3.hip).
 #pragma once
 #include "capmi_common.h"
 #include "../../../include/capmi.h"
@@ -56,9 +56,6 @@ __device__ __forceinline__ void locate(const KArgs &a, int tile, int &s, int &k0
     k0 = t * BK;
 }
 
-
-// skinny (M <= 64, A stored [M][K]) direct-to-register path; defined in gemm_skinny.hip
-int launch_skinny(const KArgs &a, int b_layout, int tm, dim3 grid, hipStream_t st);
 
 // A-resident skinny path (M <= 64, A stored [M][K]); defined in gemm_ares.hip
 int ares_plan(int N, int tiles, int want_blocks, int ts_cap, int *splits);

@@ -391,34 +391,10 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
 
     static const int env_path = [] { const char *e = getenv("CAPMI_GEMM_PATH"); return e ? atoi(e) : 0; }();
     static const int env_blocks = [] { const char *e = getenv("CAPMI_GEMM_BLOCKS"); return e ? atoi(e) : 512; }();
-    if (env_path == 1 && d->a_layout == 0 && d->M <= 64) {
-        // ---- skinny direct-to-register path (gemm_skinny.hip) ----
-        const int tm = d->M <= 32 ? 1 : 2;
-        const int gn = (d->N + 31) / 32, gm = (d->M + 32 * tm - 1) / (32 * tm);
-        int splits = d->splits;
-        if (splits == 0) {
-            const int blocks = gn * gm;
-            splits = (512 + blocks - 1) / blocks;
-            if (splits > tiles / 8) splits = tiles / 8;
-            if (splits > 16) splits = 16;
-            if (splits < 1) splits = 1;
-            while (splits > 1 && (int64_t)splits * d->M * d->N > slab_cap) --splits;
-        }
-        if (splits > tiles) splits = tiles;
-        a.splits = splits;
-        a.to_partial = (splits > 1 || d->defer_reduce) ? 1 : 0;
-        a.self_reduce = (splits > 1 && !d->defer_reduce) ? 1 : 0;
-        if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > slab_cap)) return CAPMI_EINVAL;
-        if (a.self_reduce && gn * gm > CAPMI_WS_COUNTER_FLOATS) return CAPMI_EINVAL;
-        d->splits_used = splits;
-        capmi_prof::Scope prof(pcls, st, bytes, flops);
-        return launch_skinny(a, d->b_layout, tm, dim3(gn, gm, splits), st);
-    }
-
     bool ares_ok = d->a_layout == 0 && d->M <= 64 && BK == 32;
     for (int s = 0; s < d->nseg && ares_ok; ++s)     // branch-free 16-byte operand fetch: aligned, K % 4 == 0
         ares_ok = a.seg[s].vecA && (a.seg[s].K % 4 == 0) && (d->b_layout == 1 || a.seg[s].vecB);
-    if ((env_path == 2 || env_path == 0) && ares_ok) {     // CAPMI_GEMM_PATH=3 forces the LDS-tiled kernel
+    if (env_path != 3 && ares_ok) {     // CAPMI_GEMM_PATH=3 forces the LDS-tiled kernel
         // ---- A-resident path (gemm_ares.hip): activations stay in LDS, weights stream straight to VGPRs ----
         static const int env_ab = [] { const char *e = getenv("CAPMI_ARES_BLOCKS"); return e ? atoi(e) : 256; }();
         // bf16x3 split (see gemm_x3.hip) for the decode GEMMs too: activations split once when staged, weights split in
