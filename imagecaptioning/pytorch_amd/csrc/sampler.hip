@@ -209,7 +209,7 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
     int mode, const uint8_t *__restrict__ row_mode, float temperature, const float *__restrict__ gumbel, uint64_t seed,
     const int64_t *__restrict__ forced, int forced_ld, int no_finish_mask, int64_t *__restrict__ seq, int seq_ld,
     int64_t *__restrict__ it_next, uint8_t *__restrict__ unfinished, float *__restrict__ seq_logp,
-    float *__restrict__ sel_logp, uint8_t *__restrict__ live, const NextEmbed ne, int top_k, float top_p) {
+    float *__restrict__ sel_logp, uint8_t *__restrict__ live, const NextEmbed ne, int top_k, float top_p, int abl) {
     __shared__ float s_f[32];
     __shared__ int s_i[32];
     __shared__ float s_tok;
@@ -220,29 +220,41 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
 
     f32x4 x[NQ];
     {
+        // every load of the row assembly -- the first four K-slice slabs and the bias -- is issued before the first add,
+        // branch-free (quad index clamped, surplus slabs re-read slab 0 and are multiplied away): ONE memory round trip
+        // (round 1 waited for slab 0 + bias, then for the other slabs; 14.2 us per launch at 60 rows x 9488)
+        f32x4 p4[4][NQ], bq[NQ];
+        const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
-            const int q = threadIdx.x + j * SEL_THREADS;
-            x[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            if (q < nq) {
-                x[j] = *reinterpret_cast<const f32x4 *>(src + (size_t)r * V1 + 4 * q);
-                if (bias) x[j] += *reinterpret_cast<const f32x4 *>(bias + 4 * q);
-            }
+            const int qc = min((int)threadIdx.x + j * SEL_THREADS, nq - 1);
+            const float *base = src + (size_t)r * V1 + 4 * qc;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p4[u][j] = *reinterpret_cast<const f32x4 *>(base + (size_t)(u < splits ? u : 0) * slab_stride);
+            bq[j] = bias ? *reinterpret_cast<const f32x4 *>(bias + 4 * qc) : zz;
         }
-        for (int s0 = 1; s0 < splits; s0 += 3) {          // 3 slabs x NQ quads of independent loads in flight
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            x[j] = p4[0][j] + bq[j];
+#pragma unroll
+            for (int u = 1; u < 4; ++u) x[j] += p4[u][j] * (u < splits ? 1.f : 0.f);
+        }
+        for (int s0 = 4; s0 < splits; s0 += 3) {          // further slabs: 3 x NQ quads of independent loads in flight
             f32x4 p3[3][NQ];
 #pragma unroll
             for (int u = 0; u < 3; ++u)
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) {
-                    const int q = threadIdx.x + j * SEL_THREADS;
-                    p3[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (q < nq && s0 + u < splits)
-                        p3[u][j] = *reinterpret_cast<const f32x4 *>(src + (s0 + u) * slab_stride + (size_t)r * V1 + 4 * q);
+                    const int qc = min((int)threadIdx.x + j * SEL_THREADS, nq - 1);
+                    p3[u][j] = *reinterpret_cast<const f32x4 *>(src + (size_t)min(s0 + u, splits - 1) * slab_stride + (size_t)r * V1 + 4 * qc);
+                    p3[u][j] *= (s0 + u < splits) ? 1.f : 0.f;
                 }
 #pragma unroll
             for (int j = 0; j < NQ; ++j) x[j] += (p3[0][j] + p3[1][j]) + p3[2][j];
         }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+            if ((int)threadIdx.x + j * SEL_THREADS >= nq) x[j] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     }
 
     float m = -INFINITY;
@@ -322,7 +334,9 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
                 const int q = threadIdx.x + j * SEL_THREADS;
                 if (q < nq) {
                     float gn[4];
-                    if (gumbel) {
+                    if (abl & 4) {
+                        gn[0] = gn[1] = gn[2] = gn[3] = 0.f;
+                    } else if (gumbel) {
                         const f32x4 g = *reinterpret_cast<const f32x4 *>(gumbel + (size_t)r * V1 + 4 * q);
                         gn[0] = g[0]; gn[1] = g[1]; gn[2] = g[2]; gn[3] = g[3];
                     } else {
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
     const bool was_unf = (step == 0 || no_finish_mask) ? true : (unfinished[r] != 0);
     if (!was_unf) token = 0;
     const float keep = was_unf ? 1.f : 0.f;
-    float *out = seq_logp ? seq_logp + ((size_t)r * L + step) * V1 : nullptr;
+    float *out = (seq_logp && !(abl & 1)) ? seq_logp + ((size_t)r * L + step) * V1 : nullptr;
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const int q = threadIdx.x + j * SEL_THREADS;
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
             if (q == (token >> 2)) s_tok = x[j][token & 3];     // the owner of the chosen logit publishes it
         }
     }
-    emit_next_embed(ne, r, token);
+    if (!(abl & 2)) emit_next_embed(ne, r, token);
     __syncthreads();   // s_tok visible; all reads of unfinished[r] done before thread 0 rewrites it
     if (threadIdx.x == 0) {
         seq[(size_t)r * seq_ld + step] = token;
@@ -522,11 +536,12 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
     const bool al = ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(bias) |
                       reinterpret_cast<uintptr_t>(gumbel) | reinterpret_cast<uintptr_t>(seq_logp)) & 15) == 0 &&
                     (slab_stride % 4 == 0);
+    static const int env_abl = [] { const char *e = getenv("CAPMI_SEL_ABLATE"); return e ? atoi(e) : 0; }();   // profiling only
     if (al && V1 % 4 == 0 && V1 <= 3 * 4 * SEL_THREADS) {
 #define CAPMI_SEL(NQ)                                                                                                   \
     hipLaunchKernelGGL(logsoftmax_select_reg_kernel<NQ>, dim3(N), dim3(SEL_THREADS), 0, st, partial, splits,           \
                        (size_t)slab_stride, bias, V1, step, L, mode, row_mode, temperature, gumbel, seed, forced,       \
-                       forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live, ne, top_k, top_p)
+                       forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live, ne, top_k, top_p, env_abl)
         if (V1 <= 4 * SEL_THREADS) CAPMI_SEL(1);
         else if (V1 <= 8 * SEL_THREADS) CAPMI_SEL(2);
         else CAPMI_SEL(3);

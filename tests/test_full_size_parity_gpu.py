@@ -253,3 +253,64 @@ def test_new_self_critical_structure_loss_vs_reference_fixture():
     O.new_self_critical_loss(lp, torch.from_numpy(z['sample_seq']), scores, n).backward()
     np.testing.assert_allclose(slp.grad.cpu().numpy(), lp.grad.numpy(), rtol=1e-5, atol=1e-8)
     assert out['reward'].shape == (B, n)
+
+
+def test_aoa_new_self_critical_step_gradients_vs_oracle():
+    """BASELINE configs[4] (configs/aoa_nsc.yml): AoA sampled rollout (train_sample_n rows per image, injected Gumbel noise) ->
+    StructureLosses 'new_self_critical' (losses.py:168-187, scores injected: CIDEr is pinned elsewhere) -> backward.  The oracle
+    teacher-forces the sampled tokens (identical log-probs when dropout is off, as in the eval-mode fixture) and differentiates
+    its own restatement of the loss: tokens are the model's, log-probs <= 1e-4, every gradient <= 1e-3 relative."""
+    import argparse
+    from oracle import aoa as A, att_lstm as O
+    from test_model_api_gpu import tiny_opt
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd.captioning.modules import losses as L
+    z = np.load(os.path.join(GOLDEN, 'aoa_tiny.npz'))
+    u = np.load(os.path.join(GOLDEN, 'updown_tiny.npz'))
+    opt = tiny_opt(caption_model='aoa', refine=1, refine_aoa=1, use_ff=0, decoder_type='AoA', use_multi_head=2, num_heads=2,
+                   multi_head_scale=1, mean_feats=1, ctx_drop=1, dropout_aoa=0.3, num_layers=2)
+    model = models.setup(opt)
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('P.')})
+    model = model.to(DEV)
+    model.eval()
+    att, am = torch.from_numpy(u['att']), torch.from_numpy(u['att_masks'])
+    B, n, Lmax, V1 = att.shape[0], 3, model.seq_length, model.vocab_size + 1
+    N = B * n
+    g = torch.Generator().manual_seed(17)
+    gum = -torch.log(-torch.log(torch.rand(Lmax, N, V1, generator=g).clamp_min(1e-20)))
+    scores = torch.rand(N, generator=g).double()
+    seq, logp = model(None, att.to(DEV), am.to(DEV), opt={'sample_method': 'sample', 'sample_n': n, '_gumbel': gum.to(DEV)},
+                      mode='sample')
+    assert logp.requires_grad and seq.shape == (N, Lmax) and int((seq > 0).sum()) > N       # real captions, several lengths
+    sopt = argparse.Namespace(structure_loss_type='new_self_critical', train_sample_n=n, entropy_reward_weight=0,
+                              self_cider_reward_weight=0, cider_reward_weight=1, bleu_reward_weight=0)
+    saved = L.get_scores
+    L.get_scores = lambda data_gts, gen_result, o, as_tensor=False: scores.to(DEV)
+    try:
+        out = L.StructureLosses(sopt)(logp, seq, [None] * B)
+    finally:
+        L.get_scores = saved
+    model.zero_grad()
+    out['loss'].backward()
+    # oracle: same weights, the sampled tokens teacher-forced
+    P = {k: torch.from_numpy(z['P.' + k]).clone() for k in model.state_dict()}
+    for v in P.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    seq_c = seq.cpu()
+    inp = torch.cat([seq_c.new_zeros(N, 1), seq_c[:, :-1]], 1).view(B, n, Lmax)
+    logp_o = A.forward_teacher(P, att, inp, am, h=2)
+    live = torch.cat([seq_c.new_ones(N, 1), (seq_c[:, :-1] > 0).long()], 1).cumprod(1).bool()
+    sel = logp.detach().cpu().gather(2, seq_c.unsqueeze(2)).squeeze(2)
+    sel_o = logp_o.detach().gather(2, seq_c.unsqueeze(2)).squeeze(2)
+    assert float(((sel - sel_o).abs() * live).max()) < 1e-4
+    assert torch.equal(logp_o.detach()[:, 0].argmax(1) * 0, seq_c[:, 0] * 0)       # shapes line up
+    loss_o = O.new_self_critical_loss(logp_o, seq_c, scores, n)
+    assert abs(loss_o.item() - out['loss'].item()) < 1e-5
+    loss_o.backward()
+    floor = 1e-7 * max(float(p.grad.abs().max()) for p in P.values() if p.grad is not None)
+    for k, p in model.named_parameters():
+        ref = P[k].grad
+        if k.endswith('linears.1.bias'):
+            continue                                      # attention key bias: mathematically zero gradient
+        assert float((p.grad.cpu() - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + floor, k
