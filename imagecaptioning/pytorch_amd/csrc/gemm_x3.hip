@@ -51,7 +51,8 @@ typedef const char __attribute__((address_space(1))) *gcb;
 template <bool KC>
 struct Stager {
     gcb src;
-    unsigned voff[4];     // KC: byte offset of (clamped row, in-tile k) per quad; k-major: voff[0] = clamped column * 4
+    unsigned voff[4];     // KC: byte offset of (clamped row, in-tile k) per quad; k-major: voff[0] = (4kg * ld + clamped column) * 4
+    unsigned voff0;       // k-major: the kg = 0 variant of voff[0] (always a valid k row of the tile)
     float keep[4];        // row validity (1 / 0) per quad (k-major: keep[0])
     int ld, K, kq0;
     bool edge_rows;       // workgroup-uniform: some rows of this operand tile are out of range
@@ -76,7 +77,8 @@ struct Stager {
             // into four (row, 4 k) quads.  rows % 4 == 0 (host checks): a quad of rows is entirely valid or invalid.
             const int lane = tid & 63, kg = lane >> 3, mq = (tid >> 6) * 8 + (lane & 7);
             const int row = row0 + 4 * mq;
-            voff[0] = ((unsigned)(4 * kg) * (unsigned)ld + (unsigned)min(row, nrows - 4)) * 4u;
+            voff0 = (unsigned)min(row, nrows - 4) * 4u;
+            voff[0] = (unsigned)(4 * kg) * (unsigned)ld * 4u + voff0;
             keep[0] = row < nrows ? 1.f : 0.f;
             kq0 = 4 * kg;
         }
@@ -86,29 +88,34 @@ struct Stager {
     // interior/edge one -- makes the number of YOUNGER loads in flight unknown to the compiler at the point where an
     // older register set is consumed, and it then waits with s_waitcnt vmcnt(0): the 2-tile prefetch distance of the
     // staging pipeline collapsed to "wait for everything", i.e. one exposed HBM latency per K tile.
-    // r: the raw 16 floats; f: the factor (1 = keep, 0 = out of range) of quad p (KC) / of k row j (k-major).  The factors
-    // are applied when the registers are SPLIT (x3_r2s), not here: touching a loaded value at fetch time would park the
-    // wave on that load and there would be no prefetch at all.
+    // Every address is (workgroup-uniform 64-bit base of the tile) + (32-bit per-lane byte offset): SGPR-base loads, no
+    // per-load 64-bit VALU arithmetic.  K % 4 == 0 (host checks), so a thread's quad of k is entirely inside or outside K:
+    // an outside quad is redirected to an inside one of the same tile and zeroed by its factor.
+    // r: the raw 16 floats; f: the factor (1 = keep, 0 = out of range) of quad p (KC) / of the thread's k quad (k-major, all
+    // four f equal).  The factors are applied when the registers are SPLIT (x3_r2s), not here: touching a loaded value at
+    // fetch time would park the wave on that load and there would be no prefetch at all.
     // Returns (workgroup-uniform) whether any factor can be 0, so that interior tiles skip the multiplies.
     __device__ __forceinline__ bool fetch(float (&r)[16], float (&f)[4], int k0) const {
+        const bool inside = k0 + kq0 < K;                      // per lane; false only in the last tile of a segment
         if (KC) {
-            const int over = max(k0 + kq0 - (K - 4), 0);              // clamp this thread's quads to K-4
-            const float kk = (k0 + kq0 < K) ? 1.f : 0.f;
-            gcb b = src + (size_t)(k0 - over) * 4;
+            const unsigned back = inside ? 0u : (unsigned)kq0 * 4u;      // -> the tile's first quad of the same row
+            gcb b = src + (size_t)k0 * 4;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const f32x4 v = *(gcf4)(b + voff[p]);
-                f[p] = kk * keep[p];
+                const f32x4 v = *(gcf4)(b + (voff[p] - back));
+                f[p] = inside ? keep[p] : 0.f;
                 r[4 * p] = v[0]; r[4 * p + 1] = v[1]; r[4 * p + 2] = v[2]; r[4 * p + 3] = v[3];
             }
         } else {
+            const unsigned off = inside ? voff[0] : voff0;
+            const size_t ld4 = (size_t)ld * 4;
+            gcb b = src + (size_t)k0 * ld4;
             f32x4 v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int k = k0 + kq0 + j;
-                const int back = max(k - (K - 1), 0);                 // clamp the k row to K-1
-                v[j] = *(gcf4)(src + ((size_t)(k0 + j) - back) * ld * 4 + voff[0]);
-                f[j] = k < K ? keep[0] : 0.f;
+                v[j] = *(gcf4)(b + off);
+                b += ld4;
+                f[j] = inside ? keep[0] : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -121,7 +128,8 @@ struct Stager {
 
 __device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ float bfloat(uint32_t b) { return __builtin_bit_cast(float, b); }
-__device__ __forceinline__ uint32_t pack2(uint32_t lo, uint32_t hi) { return (lo >> 16) | (hi & 0xffff0000u); }
+// upper halves of two fp32 bit patterns -> one dword of two bf16 (v_perm_b32: bytes 2,3 of lo, bytes 2,3 of hi)
+__device__ __forceinline__ uint32_t pack2(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
 // registers -> three bf16 planes in LDS
 template <bool KC, bool EDGE>
@@ -138,14 +146,16 @@ __device__ __forceinline__ void x3_r2s(const float (&r)[16], const float (&f)[4]
             row = 4 * ((tid >> 6) * 8 + (lane & 7)) + p;
             kq = 4 * (lane >> 3);
         }
+        // 5.5 VALU ops per element: and, sub, and, sub + three packs per pair.  The packs take the UPPER halves of x, x - h
+        // and x - h - m directly (the upper half of x is h's, of x - h is m's; l has <= 8 significant bits).
         uint32_t h[4], m[4], l[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float x = EDGE ? r[4 * p + j] * (KC ? f[p] : f[j]) : r[4 * p + j];   // out-of-range rows / k -> 0
-            h[j] = fbits(x) & 0xffff0000u;
-            const float r1 = x - bfloat(h[j]);            // exact
-            m[j] = fbits(r1) & 0xffff0000u;
-            l[j] = fbits(r1 - bfloat(m[j]));               // exact, <= 8 significant bits: truncation is lossless
+            h[j] = fbits(x);
+            const float r1 = x - bfloat(h[j] & 0xffff0000u);            // exact
+            m[j] = fbits(r1);
+            l[j] = fbits(r1 - bfloat(m[j] & 0xffff0000u));              // exact, <= 8 significant bits: truncation is lossless
         }
         unsigned short *o = dst + row * XP + kq;
         *reinterpret_cast<u32x2 *>(o) = u32x2{pack2(h[0], h[1]), pack2(h[2], h[3])};
@@ -185,114 +195,141 @@ __device__ __forceinline__ Unit unit_of(const KArgs &a, int u, int gm, int gn) {
     return r;
 }
 
-// ABL: compile-time ablations for profiling (CAPMI_GEMM_ABLATE, [K][rows] x [K][rows] shapes only): 1 no MFMAs, 2 no global
-// fetch, 4 no split/store.  Compile-time because a run-time test around the loads costs the exact vmcnt waits.
-template <bool AKC, bool BKC, int ABL = 0>
-__global__ __launch_bounds__(XNT) void gemm_x3_kernel(const KArgs a, int gm, int gn) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];      // 2 stages = 120 KB
-    const int units = gm * gn * a.splits;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-
-    if (wid >= 4) {
-        // ---------------- staging waves ----------------
-        const int tid = threadIdx.x - NT;
-        float ra0[16], rb0[16], ra1[16], rb1[16];          // pipeline step g lives in register set g & 1
-        float fa0[4], fb0[4], fa1[4], fb1[4];              // ... with its keep-factors
-        bool e0 = false, e1 = false;                       // ... and whether any of them can be zero (workgroup-uniform)
-        // K segments ([h | x | ...] x [W slices]) are walked in place.  The segment of a K tile is workgroup-uniform; its
-        // fields are picked with STATIC indices behind a uniform switch (a dynamically indexed kernel-argument table
-        // would be copied to scratch), and the per-lane offsets are rebuilt only when the segment or the unit changes.
-        Stager<AKC> sa;
-        Stager<BKC> sb;
-        int cur_seg = -1, cur_m0 = 0, cur_n0 = 0;
-        auto bind = [&](int sidx, int m0_, int n0_) {
+// ---------------- staging waves: HBM -> registers -> split -> LDS planes ----------------
+// DOA / DOB: this wave stages operand A / B (one wave per SIMD stages both; with two staging waves per SIMD one takes each).
+template <bool AKC, bool BKC, int ABL, bool DOA, bool DOB>
+__device__ __forceinline__ void x3_staging(const KArgs &a, int gm, int gn, int units, int tid, unsigned short *smem) {
+    float ra0[16], rb0[16], ra1[16], rb1[16];          // pipeline step g lives in register set g & 1
+    float fa0[4], fb0[4], fa1[4], fb1[4];              // ... with its keep-factors
+    bool e0 = false, e1 = false;                       // ... and whether any of them can be zero (workgroup-uniform)
+    // K segments ([h | x | ...] x [W slices]) are walked in place.  The segment of a K tile is workgroup-uniform; its
+    // fields are picked with STATIC indices behind a uniform switch (a dynamically indexed kernel-argument table
+    // would be copied to scratch), and the per-lane offsets are rebuilt only when the segment or the unit changes.
+    Stager<AKC> sa;
+    Stager<BKC> sb;
+    auto bind = [&](int sidx, int m0_, int n0_) {
 #define CAPMI_X3_SEG(I)                                                   \
     case I:                                                               \
         sa.init(a.seg[I].A, a.seg[I].lda, a.seg[I].K);                    \
         sb.init(a.seg[I].B, a.seg[I].ldb, a.seg[I].K);                    \
         break;
-            switch (sidx) {
-                CAPMI_X3_SEG(0) CAPMI_X3_SEG(1) CAPMI_X3_SEG(2) CAPMI_X3_SEG(3)
-            }
+        switch (sidx) {
+            CAPMI_X3_SEG(0) CAPMI_X3_SEG(1) CAPMI_X3_SEG(2) CAPMI_X3_SEG(3)
+        }
 #undef CAPMI_X3_SEG
-            sa.set_tile(m0_, a.M, tid);
-            sb.set_tile(n0_, a.N, tid);
-            cur_seg = sidx; cur_m0 = m0_; cur_n0 = n0_;
-        };
-        // fetch cursor: runs up to 3 steps ahead of the step being consumed, across unit boundaries
-        int fu = blockIdx.x, ft = 0, f_t0 = 0, f_nt = 0, f_m0 = 0, f_n0 = 0;
-        if (fu < units) {
-            const Unit un = unit_of(a, fu, gm, gn);
-            f_t0 = un.t_begin; f_nt = un.nt; f_m0 = un.m0; f_n0 = un.n0;
+        if (DOA) sa.set_tile(m0_, a.M, tid);
+        if (DOB) sb.set_tile(n0_, a.N, tid);
+    };
+    // fetch cursor: runs up to 3 steps ahead of the step being consumed, across unit boundaries.  It is advanced
+    // incrementally (k0 += BK; next segment / next unit are rare uniform branches): a flat tile index decoded per step
+    // cost ~150 scalar instructions per K tile, a third of the staging wave's issue slots.
+    int fu = blockIdx.x, f_left = 0, f_sleft = 0, f_k0 = 0, f_s = 0, f_m0 = 0, f_n0 = 0;
+    auto open_unit = [&]() {
+        const Unit un = unit_of(a, fu, gm, gn);
+        int sidx, k0;
+        locate(a, un.t_begin, sidx, k0);
+        f_s = __builtin_amdgcn_readfirstlane(sidx);
+        f_k0 = k0; f_left = un.nt; f_m0 = un.m0; f_n0 = un.n0;
+        bind(f_s, f_m0, f_n0);
+        f_sleft = (sa.K - k0 + BK - 1) / BK;
+    };
+    if (fu < units) open_unit();
+    // Every call issues exactly the same loads (see Stager::fetch); past the last unit the cursor stays on the last
+    // tile and the (few) extra fetches are thrown away.
+    auto fetch = [&](float (&xa)[16], float (&xb)[16], float (&ya)[4], float (&yb)[4], bool &edge) {
+        if (!(ABL & 2)) {
+            bool ea = false, eb = false;
+            if (DOA) ea = sa.fetch(xa, ya, f_k0);
+            if (DOB) eb = sb.fetch(xb, yb, f_k0);
+            edge = ea || eb;
         }
-        // Every call issues exactly the same loads (see Stager::fetch); past the last unit the cursor stays on the last
-        // tile and the (few) extra fetches are thrown away.
-        int last_k0 = 0;
-        auto fetch = [&](float (&xa)[16], float (&xb)[16], float (&ya)[4], float (&yb)[4], bool &edge) {
-            const bool live = fu < units;                  // workgroup-uniform
-            if (live) {
-                int sidx, k0;
-                locate(a, f_t0 + ft, sidx, k0);
-                sidx = __builtin_amdgcn_readfirstlane(sidx);
-                if (sidx != cur_seg || f_m0 != cur_m0 || f_n0 != cur_n0) bind(sidx, f_m0, f_n0);
-                last_k0 = k0;
-            }
-            if (!(ABL & 2)) {
-                const bool ea = sa.fetch(xa, ya, last_k0);
-                const bool eb = sb.fetch(xb, yb, last_k0);
-                edge = ea || eb;
-            }
-            if (live && ++ft == f_nt) {
+        if (f_left > 0) {                              // workgroup-uniform
+            if (--f_left == 0) {
                 fu += gridDim.x;
-                ft = 0;
-                if (fu < units) {
-                    const Unit un = unit_of(a, fu, gm, gn);
-                    f_t0 = un.t_begin; f_nt = un.nt; f_m0 = un.m0; f_n0 = un.n0;
-                }
-            }
-        };
-        int steps = 0;
-        for (int u = blockIdx.x; u < units; u += gridDim.x) steps += unit_of(a, u, gm, gn).nt;
-        // the interior/edge branch sits HERE, around VALU + LDS work only (a branch around the loads would cost the exact waits)
-        auto store = [&](const float (&xa)[16], const float (&xb)[16], const float (&ya)[4], const float (&yb)[4], bool edge, int g) {
-            if (ABL & 4) return;
-            unsigned short *st = smem + (g & 1) * XSTAGE;
-            if (edge) {
-                x3_r2s<AKC, true>(xa, ya, st, tid);
-                x3_r2s<BKC, true>(xb, yb, st + 3 * XPLANE, tid);
+                if (fu < units) open_unit();
+            } else if (--f_sleft == 0) {
+                bind(++f_s, f_m0, f_n0);
+                f_k0 = 0;
+                f_sleft = (sa.K + BK - 1) / BK;
             } else {
-                x3_r2s<AKC, false>(xa, ya, st, tid);
-                x3_r2s<BKC, false>(xb, yb, st + 3 * XPLANE, tid);
+                f_k0 += BK;
             }
-        };
-        // Two register sets alternate: while the MFMA waves consume step g (stage g&1) the staging waves publish step g+1 and
-        // fetch step g+3 into the registers step g+1 just left.  The fetches are unconditional (fixed load count per
-        // half-iteration, see Stager::fetch), only stores and barriers are guarded, so the compiler waits with exact
-        // s_waitcnt vmcnt(8..15) for the OLDER set while the younger set's loads stay in flight.  (A third set in flight
-        // changed nothing: with the MFMAs ablated the staging side runs at the operand delivery rate, 5.4 TB/s of
-        // mostly-L2 traffic for the dW GEMM, whatever the depth.)
-        fetch(ra0, rb0, fa0, fb0, e0);                     // step 0
-        fetch(ra1, rb1, fa1, fb1, e1);                     // step 1
-        if (steps > 0) store(ra0, rb0, fa0, fb0, e0, 0);
-        fetch(ra0, rb0, fa0, fb0, e0);                     // step 2
-        __syncthreads();                                   // stage 0 ready
-        for (int g = 0; g < steps; g += 2) {
-            if (g + 1 < steps) store(ra1, rb1, fa1, fb1, e1, g + 1);
-            fetch(ra1, rb1, fa1, fb1, e1);
-            __syncthreads();
-            const bool second = g + 1 < steps;
-            if (second && g + 2 < steps) store(ra0, rb0, fa0, fb0, e0, g + 2);
-            fetch(ra0, rb0, fa0, fb0, e0);
-            if (second) __syncthreads();
         }
+    };
+    int steps = 0;
+    for (int u = blockIdx.x; u < units; u += gridDim.x) steps += unit_of(a, u, gm, gn).nt;
+    // the interior/edge branch sits HERE, around VALU + LDS work only (a branch around the loads would cost the exact waits)
+    auto store = [&](const float (&xa)[16], const float (&xb)[16], const float (&ya)[4], const float (&yb)[4], bool edge, int g) {
+        if (ABL & 4) return;
+        unsigned short *st = smem + (g & 1) * XSTAGE;
+        if (edge) {
+            if (DOA) x3_r2s<AKC, true>(xa, ya, st, tid);
+            if (DOB) x3_r2s<BKC, true>(xb, yb, st + 3 * XPLANE, tid);
+        } else {
+            if (DOA) x3_r2s<AKC, false>(xa, ya, st, tid);
+            if (DOB) x3_r2s<BKC, false>(xb, yb, st + 3 * XPLANE, tid);
+        }
+    };
+    // Two register sets alternate: while the MFMA waves consume step g (stage g&1) the staging waves publish step g+1 and
+    // fetch step g+3 into the registers step g+1 just left.  The fetches are unconditional (fixed load count per
+    // half-iteration, see Stager::fetch), only stores and barriers are guarded, so the compiler waits with exact
+    // s_waitcnt vmcnt(8..15) for the OLDER set while the younger set's loads stay in flight.
+    fetch(ra0, rb0, fa0, fb0, e0);                     // step 0
+    fetch(ra1, rb1, fa1, fb1, e1);                     // step 1
+    if (steps > 0) store(ra0, rb0, fa0, fb0, e0, 0);
+    fetch(ra0, rb0, fa0, fb0, e0);                     // step 2
+    __syncthreads();                                   // stage 0 ready
+    for (int g = 0; g < steps; g += 2) {
+        if (g + 1 < steps) store(ra1, rb1, fa1, fb1, e1, g + 1);
+        fetch(ra1, rb1, fa1, fb1, e1);
+        __syncthreads();
+        const bool second = g + 1 < steps;
+        if (second && g + 2 < steps) store(ra0, rb0, fa0, fb0, e0, g + 2);
+        fetch(ra0, rb0, fa0, fb0, e0);
+        if (second) __syncthreads();
+    }
+}
+
+// ABL: compile-time ablations for profiling (CAPMI_GEMM_ABLATE, same-layout shapes only): 1 no MFMAs, 2 no global
+// fetch, 4 no split/store.  Compile-time because a run-time test around the loads costs the exact vmcnt waits.
+// NSW: staging waves.  4: one per SIMD stages both operands (512 threads, 256 registers: the MFMA waves software-pipeline
+// their LDS reads).  8: two per SIMD, one per operand (768 threads, 168 registers: plain read-then-multiply MFMA loop).
+template <bool AKC, bool BKC, int ABL = 0, int NSW = 4>
+__global__ __launch_bounds__(256 + 64 * NSW) void gemm_x3_kernel(const KArgs a, int gm, int gn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];      // 2 stages = 120 KB
+    const int units = gm * gn * a.splits;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+
+    if (wid >= 4) {
+        if (a.ablate & 8) __builtin_amdgcn_s_setprio(1);
+        if (NSW == 4) x3_staging<AKC, BKC, ABL, true, true>(a, gm, gn, units, threadIdx.x - NT, smem);
+        else if (wid < 8) x3_staging<AKC, BKC, ABL, true, false>(a, gm, gn, units, threadIdx.x - NT, smem);
+        else x3_staging<AKC, BKC, ABL, false, true>(a, gm, gn, units, threadIdx.x - 2 * NT, smem);
         return;
     }
 
     // ---------------- MFMA waves ----------------
     const int wm0 = ((wid >> 1) & 1) * 64, wn0 = (wid & 1) * 64;
     const int l31 = lane & 31, half = lane >> 5;
+    // LDS reads are software-pipelined against the MFMAs: the fragments of K half 1 are requested before the 24 MFMAs of half 0
+    // are issued, and the fragments of the NEXT tile's half 0 (other stage, possibly the next unit's) before the MFMAs of
+    // half 1, so the matrix pipe never waits for ds_read latency (measured 0.90 -> ... us per K tile with staging ablated; the
+    // pipe needs 0.64).  The one barrier per K tile sits between the two halves: by then every read of this stage has
+    // completed (the barrier's lgkmcnt(0)) and the staging waves have published the next one.
+    auto read_frag = [&](bf16x8 (&av)[2][3], bf16x8 (&bv)[2][3], int g_, int ks) {
+        const unsigned short *As = smem + (g_ & 1) * XSTAGE, *Bs = As + 3 * XPLANE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                av[q][pl] = *reinterpret_cast<const bf16x8 *>(As + pl * XPLANE + (wm0 + 32 * q + l31) * XP + 16 * ks + 8 * half);
+                bv[q][pl] = *reinterpret_cast<const bf16x8 *>(Bs + pl * XPLANE + (wn0 + 32 * q + l31) * XP + 16 * ks + 8 * half);
+            }
+    };
     __syncthreads();                                       // stage 0 ready
     int g = 0;
+    bf16x8 av0[2][3], bv0[2][3], av1[2][3], bv1[2][3];
+    if (NSW == 4) read_frag(av0, bv0, 0, 0);
     for (int u = blockIdx.x; u < units; u += gridDim.x) {
         const Unit un = unit_of(a, u, gm, gn);
         f32x16 acc[2][2];
@@ -302,43 +339,52 @@ __global__ __launch_bounds__(XNT) void gemm_x3_kernel(const KArgs a, int gm, int
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int i = 0; i < un.nt; ++i, ++g) {
-            const unsigned short *As = smem + (g & 1) * XSTAGE, *Bs = As + 3 * XPLANE;
-            if (!(ABL & 1))
+        // six of the nine cross terms, small ones first (planes: 0 = h, 1 = m, 2 = l)
+        auto mfma24 = [&](const bf16x8 (&av)[2][3], const bf16x8 (&bv)[2][3]) {
+            if (ABL & 1) return;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 av[2][3], bv[2][3];
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
+                for (int j = 0; j < 2; ++j) {
+                    acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][2], bv[j][0], acc[q][j], 0, 0, 0);
+                    acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][2], acc[q][j], 0, 0, 0);
+                }
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        av[q][pl] = *reinterpret_cast<const bf16x8 *>(As + pl * XPLANE + (wm0 + 32 * q + l31) * XP + 16 * ks + 8 * half);
-                        bv[q][pl] = *reinterpret_cast<const bf16x8 *>(Bs + pl * XPLANE + (wn0 + 32 * q + l31) * XP + 16 * ks + 8 * half);
-                    }
-                // six of the nine cross terms, small ones first (planes: 0 = h, 1 = m, 2 = l)
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
+                for (int j = 0; j < 2; ++j) {
+                    acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][1], acc[q][j], 0, 0, 0);
+                    acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][0], acc[q][j], 0, 0, 0);
+                }
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][2], bv[j][0], acc[q][j], 0, 0, 0);
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][2], acc[q][j], 0, 0, 0);
-                    }
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][1], acc[q][j], 0, 0, 0);
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][0], acc[q][j], 0, 0, 0);
-                    }
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][1], acc[q][j], 0, 0, 0);
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][0], acc[q][j], 0, 0, 0);
-                    }
+                for (int j = 0; j < 2; ++j) {
+                    acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][1], acc[q][j], 0, 0, 0);
+                    acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][0], acc[q][j], 0, 0, 0);
+                }
+        };
+        if (NSW == 4) {
+            for (int i = 0; i < un.nt; ++i, ++g) {
+                // (sched_barrier: the scheduler otherwise sinks the reads behind most of the MFMAs to shorten live ranges)
+                read_frag(av1, bv1, g, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma24(av0, bv0);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();                               // stage g&1 released, stage (g+1)&1 ready
+                read_frag(av0, bv0, g + 1, 0);                 // (past the last step: harmless read of a stale stage)
+                __builtin_amdgcn_sched_barrier(0);
+                mfma24(av1, bv1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();                               // stage g&1 released, stage (g+1)&1 ready
+        } else {
+            for (int i = 0; i < un.nt; ++i, ++g) {
+                read_frag(av0, bv0, g, 0);
+                mfma24(av0, bv0);
+                read_frag(av0, bv0, g, 1);
+                mfma24(av0, bv0);
+                __syncthreads();                               // stage g&1 released, stage (g+1)&1 ready
+            }
         }
 
         // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -386,35 +432,49 @@ int launch_x3(const KArgs &a, int a_layout, int b_layout, dim3 tiles, hipStream_
     const int units = gn * gm * a.splits;
     static const int env_wg = [] { const char *e = getenv("CAPMI_X3_WGS"); return e ? atoi(e) : 256; }();
     const dim3 grid(units < env_wg ? units : env_wg);
+    static const int env_nsw = [] { const char *e = getenv("CAPMI_X3_NSW"); return e ? atoi(e) : 8; }();
     hipEvent_t e0, e1;
     const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
     constexpr size_t lds = 2 * (size_t)XSTAGE * sizeof(unsigned short);
+#define CAPMI_X3N(AK, BK_, NSW_)                                                                                \
+    do {                                                                                                        \
+        static bool attr_set = false;                                                                           \
+        if (!attr_set) {                                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_x3_kernel<AK, BK_, 0, NSW_>),        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+            attr_set = true;                                                                                    \
+        }                                                                                                       \
+        const dim3 blk(256 + 64 * NSW_);                                                                        \
+        if (prof) hipExtLaunchKernelGGL((gemm_x3_kernel<AK, BK_, 0, NSW_>), grid, blk, lds, st, e0, e1, 0, a, gm, gn);  \
+        else hipLaunchKernelGGL((gemm_x3_kernel<AK, BK_, 0, NSW_>), grid, blk, lds, st, a, gm, gn);                     \
+    } while (0)
 #define CAPMI_X3(AK, BK_)                                                                                       \
     do {                                                                                                        \
-        static bool attr_set = false;                                                                           \
-        if (!attr_set) {                                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_x3_kernel<AK, BK_>),                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
-            attr_set = true;                                                                                    \
-        }                                                                                                       \
-        if (prof) hipExtLaunchKernelGGL((gemm_x3_kernel<AK, BK_>), grid, dim3(XNT), lds, st, e0, e1, 0, a, gm, gn);     \
-        else hipLaunchKernelGGL((gemm_x3_kernel<AK, BK_>), grid, dim3(XNT), lds, st, a, gm, gn);                        \
+        if (env_nsw == 8) CAPMI_X3N(AK, BK_, 8);                                                                \
+        else CAPMI_X3N(AK, BK_, 4);                                                                             \
     } while (0)
-#define CAPMI_X3A(ABL_)                                                                                         \
+#define CAPMI_X3A(AK, BK_, ABL_)                                                                                \
     do {                                                                                                        \
         static bool attr_set = false;                                                                           \
         if (!attr_set) {                                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_x3_kernel<false, false, ABL_>),      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_x3_kernel<AK, BK_, ABL_>),           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
             attr_set = true;                                                                                    \
         }                                                                                                       \
-        hipLaunchKernelGGL((gemm_x3_kernel<false, false, ABL_>), grid, dim3(XNT), lds, st, a, gm, gn);          \
+        hipLaunchKernelGGL((gemm_x3_kernel<AK, BK_, ABL_>), grid, dim3(XNT), lds, st, a, gm, gn);               \
     } while (0)
-    if (a.ablate && a_layout == 1 && b_layout == 1) {
-        if (a.ablate == 1) CAPMI_X3A(1);
-        else if (a.ablate == 2) CAPMI_X3A(2);
-        else if (a.ablate == 4) CAPMI_X3A(4);
-        else CAPMI_X3A(6);
+    if ((a.ablate & 7) && a_layout == b_layout) {            // profiling builds: [K][rows] x [K][rows] and [rows][K] x [rows][K]
+        if (a_layout == 1) {
+            if ((a.ablate & 7) == 1) CAPMI_X3A(false, false, 1);
+            else if ((a.ablate & 7) == 2) CAPMI_X3A(false, false, 2);
+            else if ((a.ablate & 7) == 4) CAPMI_X3A(false, false, 4);
+            else CAPMI_X3A(false, false, 6);
+        } else {
+            if ((a.ablate & 7) == 1) CAPMI_X3A(true, true, 1);
+            else if ((a.ablate & 7) == 2) CAPMI_X3A(true, true, 2);
+            else if ((a.ablate & 7) == 4) CAPMI_X3A(true, true, 4);
+            else CAPMI_X3A(true, true, 6);
+        }
         CAPMI_CHECK_LAUNCH();
         return 0;
     }

@@ -28,7 +28,14 @@ shapes = [('dW_lstm  dG^T X   [4000x1000] K=1200', 4 * R, R, TN, 1, 1),
           ('dW_logit dL^T h   [9488x1000] K=1200', V1, R, TN, 1, 1),
           ('d_hdrop  dL W     [1200x1000] K=9488', TN, R, V1, 0, 1),
           ('d_xt     dG W     [1200x1000] K=4000', TN, R, 4 * R, 0, 1),
-          ('square   A B^T    [4096x4096] K=1024', 4096, 4096, 1024, 0, 0)]
+          ('square   A B^T    [4096x4096] K=1024', 4096, 4096, 1024, 0, 0),
+          ('square   A B^T    [4096x4096] K=1056', 4096, 4096, 1056, 0, 0),
+          ('ffn1     x W^T    [5440x2048] K=512 ', 5440, 2048, 512, 0, 0),
+          ('ffn1     x W^T    [5440x2048] K=528 ', 5440, 2048, 528, 0, 0),
+          ('ffn2     h W^T    [5440x512 ] K=2048', 5440, 512, 2048, 0, 0),
+          ('ffn2     h W^T    [5440x512 ] K=2080', 5440, 512, 2080, 0, 0),
+          ('dW_ffn1  dH^T x   [2048x512 ] K=5440', 2048, 512, 5440, 1, 1),
+          ('dx_ffn1  dH W     [5440x512 ] K=2048', 5440, 512, 2048, 0, 1)]
 for name, M, N, K, al, bl in shapes:
     A = torch.randn((K, M) if al else (M, K), device=dev)
     B = torch.randn((K, N) if bl else (N, K), device=dev)
