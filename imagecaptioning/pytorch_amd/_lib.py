@@ -68,6 +68,15 @@ class MaskDesc(C.Structure):
                 ('keep_from', C.c_int)]
 
 
+class ReduceItem(C.Structure):
+    _fields_ = [('partial', c_f), ('C', c_f), ('bias', c_f), ('splits', C.c_int32), ('M', C.c_int32), ('N', C.c_int32),
+                ('ldc', C.c_int32), ('accumulate', C.c_int32), ('reserved', C.c_int32)]
+
+
+class ColsumItem(C.Structure):
+    _fields_ = [('in', c_f), ('out', c_f), ('rows', C.c_int32), ('cols', C.c_int32), ('ld', C.c_int32), ('accumulate', C.c_int32)]
+
+
 class UpDownBwdScratch(C.Structure):
     _fields_ = ([(k, c_f) for k in ('dlogits', 'd_hdrop', 'dg_att', 'dg_lang', 'd_x2', 'd_e_all', 'd_att_h_all',
                                     'dh_att_attn', 'd_x1', 'dc_att', 'dc_lang', 'd_xt_all', 'sum_dg_att', 'w_lang_cat',
@@ -134,6 +143,8 @@ SIGNATURES = {
     'capmi_rollout_init': [_P, _P, _P, _P, _I64, _P, _P, _I, _P],
     'capmi_reward_criterion': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     'capmi_colsum': [_P, _I, _I, _I, _P, _I, _P],
+    'capmi_colsum_batch': [_P, _I, _P],
+    'capmi_splitk_reduce_batch': [_P, _I, _P],
     'capmi_group_rowsum': [_P, _I, _I64, _I, _I, _I, _P, _P],
     'capmi_relu_mask_bwd': [_P, _P, _P, _P, _I64, _P],
     'capmi_adam_step': [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _I, _P],

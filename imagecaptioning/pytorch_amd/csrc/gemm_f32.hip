@@ -23,6 +23,7 @@
 #include "profile.h"
 #include "../../../include/capmi.h"
 #include "gemm_common.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <hip/hip_ext.h>
 
@@ -305,6 +306,44 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ partial, int spli
     }
 }
 
+// blockIdx.y = item; its M x N outputs are walked by the item's blockIdx.x workgroups, 16 bytes per thread when the shapes allow
+__global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const capmi_reduce_item *__restrict__ items) {
+    const capmi_reduce_item it = items[blockIdx.y];
+    const size_t total = (size_t)it.M * it.N;
+    const bool vec = it.N % 4 == 0 && it.ldc % 4 == 0 && ((reinterpret_cast<uintptr_t>(it.partial) | reinterpret_cast<uintptr_t>(it.C)) & 15) == 0 &&
+                     (!it.bias || (reinterpret_cast<uintptr_t>(it.bias) & 15) == 0);
+    if (vec) {
+        const size_t quads = total / 4;
+        for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (size_t)gridDim.x * blockDim.x) {
+            const size_t i = q * 4;
+            const int row = (int)(i / it.N), col = (int)(i % it.N);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int s0 = 0; s0 < it.splits; s0 += 4) {        // 4 independent 16-byte loads in flight
+                f32x4 tv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    tv[u] = (s0 + u < it.splits) ? *reinterpret_cast<const f32x4 *>(it.partial + (size_t)(s0 + u) * total + i)
+                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+                v += (tv[0] + tv[1]) + (tv[2] + tv[3]);
+            }
+            if (it.bias) v += *reinterpret_cast<const f32x4 *>(it.bias + col);
+            f32x4 *o = reinterpret_cast<f32x4 *>(it.C + (size_t)row * it.ldc + col);
+            if (it.accumulate) v += *o;
+            *o = v;
+        }
+        return;
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / it.N), col = (int)(i % it.N);
+        float v = 0.f;
+        for (int s0 = 0; s0 < it.splits; ++s0) v += it.partial[(size_t)s0 * total + i];
+        if (it.bias) v += it.bias[col];
+        float *o = it.C + (size_t)row * it.ldc + col;
+        if (it.accumulate) v += *o;
+        *o = v;
+    }
+}
+
 struct ProfInfo {
     int cls;
     double bytes, flops;
@@ -340,6 +379,13 @@ extern "C" int capmi_splitk_reduce(const float *partial, int splits, float *C, i
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, splits, C, ldc, M,
                        N, bias, bias2, row_bias, row_bias_div > 0 ? row_bias_div : 1, mul_mask, relu, accumulate);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int capmi_splitk_reduce_batch(const capmi_reduce_item *items, int n_items, void *stream) {
+    if (!items || n_items <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(64, n_items), dim3(256), 0, (hipStream_t)stream, items);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -500,6 +546,10 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     if (x3_ok) a.self_reduce = 0;      // the persistent kernel always leaves plain slabs
     if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > slab_cap)) return CAPMI_EINVAL;
     d->splits_used = splits;
+    static const int env_log = [] { const char *e = getenv("CAPMI_GEMM_LOG"); return e ? atoi(e) : 0; }();   // shape census (profiling)
+    if (env_log)
+        fprintf(stderr, "capmi_gemm M=%d N=%d tiles=%d al=%d bl=%d x3=%d splits=%d defer=%d acc=%d\n", d->M, d->N, tiles, d->a_layout,
+                d->b_layout, (int)x3_ok, splits, d->defer_reduce, d->accumulate);
     dim3 grid(gn, gm, splits);
     const ProfInfo pi{pcls, bytes, flops};
     int rc;

@@ -328,6 +328,55 @@ __global__ __launch_bounds__(CS_Q * CS_R) void colsum_kernel(const float *__rest
     }
 }
 
+// Many column sums in one launch (all bias gradients of a layer-by-layer backward): blockIdx.y = item, blockIdx.x walks the
+// item's 64-column blocks; every block sums ALL rows of its columns (deterministic, no atomics, no zero-fill launch).
+__global__ __launch_bounds__(CS_Q * CS_R) void colsum_batch_kernel(const capmi_colsum_item *__restrict__ items) {
+    __shared__ f32x4 red[CS_R][CS_Q];
+    const capmi_colsum_item it = items[blockIdx.y];
+    const int cq = threadIdx.x % CS_Q, ry = threadIdx.x / CS_Q;
+    const int cblocks = (it.cols + 4 * CS_Q - 1) / (4 * CS_Q);
+    const bool vec = (reinterpret_cast<uintptr_t>(it.in) & 15) == 0 && it.ld % 4 == 0 && it.cols % 4 == 0;
+    for (int cb = blockIdx.x; cb < cblocks; cb += gridDim.x) {
+        const int col = (cb * CS_Q + cq) * 4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (col < it.cols) {
+            if (vec) {
+                const float *p = it.in + col;
+                int r = ry;
+                for (; r + 3 * CS_R < it.rows; r += 4 * CS_R) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (size_t)r * it.ld);
+                    const f32x4 b = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + CS_R) * it.ld);
+                    const f32x4 c = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + 2 * CS_R) * it.ld);
+                    const f32x4 d = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + 3 * CS_R) * it.ld);
+                    s += (a + b) + (c + d);
+                }
+                for (; r < it.rows; r += CS_R) s += *reinterpret_cast<const f32x4 *>(p + (size_t)r * it.ld);
+            } else {
+                for (int r = ry; r < it.rows; r += CS_R)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (col + k < it.cols) s[k] += it.in[(size_t)r * it.ld + col + k];
+            }
+        }
+        red[ry][cq] = s;
+        __syncthreads();
+        if (ry < 4) {
+            f32x4 t = red[ry * 16][cq];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) t += red[ry * 16 + k][cq];
+            red[ry * 16][cq] = t;
+        }
+        __syncthreads();
+        if (ry == 0 && col < it.cols) {
+            const f32x4 t = (red[0][cq] + red[16][cq]) + (red[32][cq] + red[48][cq]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (col + k < it.cols) it.out[col + k] = it.accumulate ? it.out[col + k] + t[k] : t[k];
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void group_rowsum_kernel(const float *__restrict__ in, int T, size_t slab, int groups, int group, int cols,
                                     float *__restrict__ out) {
     const size_t total = (size_t)groups * cols;
@@ -508,6 +557,13 @@ int capmi_colsum(const float *in, int rows, int cols, int ld, float *out, int ac
     }
     hipLaunchKernelGGL(colsum_kernel, dim3(cblocks, rsplit), dim3(CS_Q * CS_R), 0, (hipStream_t)stream, in, rows, cols, ld, out,
                        accumulate, vec, rsplit);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_colsum_batch(const capmi_colsum_item *items, int n_items, void *stream) {
+    if (!items || n_items <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(colsum_batch_kernel, dim3(32, n_items), dim3(CS_Q * CS_R), 0, (hipStream_t)stream, items);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

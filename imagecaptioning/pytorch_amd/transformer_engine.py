@@ -15,6 +15,8 @@ MI355X-first differences from the reference's dataflow (same numbers):
 import ctypes as C
 import math
 
+import os
+
 import torch
 
 from . import _lib, ops
@@ -34,13 +36,19 @@ def layernorm_fwd(x, a, b):
     return y, mean, inv
 
 
-def layernorm_bwd(dy, x, a, mean, inv, dx_accum):
-    """dx_accum += d(LN)/dx ; returns (d_a, d_b)."""
+def layernorm_bwd(dy, x, a, mean, inv, dx_accum, d_a=None, d_b=None):
+    """dx_accum += d(LN)/dx ; d_a, d_b (given or new) receive the gain / bias gradients.  `dy` must not be modified by the
+    caller afterwards (inside deferred_grads its column sum is taken at the end of the backward)."""
     M, D = x.shape
     g = torch.empty_like(x)
     check(lib.capmi_layernorm_bwd(ptr(dy), ptr(x), ptr(a), ptr(mean), ptr(inv), ptr(dx_accum), 1, ptr(g), M, D, EPS,
                                   stream_ptr()), 'layernorm_bwd')
-    return ops.colsum(g), ops.colsum(dy)
+    d = Lin.deferred
+    if d is not None and d_a is not None:
+        d.colsum(g, d_a)
+        d.colsum(dy, d_b)
+        return d_a, d_b
+    return ops.colsum(g, out=d_a), ops.colsum(dy, out=d_b)
 
 
 def mha_fwd(q, k, v, ldkv, Nq, q_per_kv, Tq, Tk, h, mask=None, mask_tq=1, mask_per_q=0, causal=0, q_pos0=0, drop=None,
@@ -76,6 +84,8 @@ def mha_bwd(d_o, q, k, v, ldkv, p, drop, Nq, q_per_kv, Tq, Tk, h, kstride=0, dk_
 class Lin:
     """y = [residual +] mask * act(x W^T + b); backward writes dW, db into `grads` and returns dx."""
 
+    deferred = None      # an ops.DeferredGrads while a whole-model backward runs (see deferred_grads)
+
     def __init__(self, P, grads, wname, bname):
         self.P, self.grads, self.wn, self.bn = P, grads, wname, bname
 
@@ -94,12 +104,58 @@ class Lin:
             self.y_act = y if relu else None
         return y
 
-    def bwd(self, dy, need_dx=True):
+    def bwd_params(self, dy, fresh=False):
+        """dW, db; returns the gradient at the GEMM output (after the activation / mask Jacobian).  fresh: the caller will
+        not modify `dy` afterwards (a running gradient accumulator must not be read at the end of the backward)."""
         if self.relu or self.mask is not None:
             dy = ops.relu_mask_bwd(dy.contiguous(), self.y_act if self.relu else None, self.mask)
-        ops.matmul_tn(dy, self.x, out=self.grads[self.wn])
-        ops.colsum(dy, out=self.grads[self.bn])
+            fresh = True
+        d = Lin.deferred
+        if d is not None:
+            d.dw(dy, self.x, self.grads[self.wn])
+            if fresh:
+                d.colsum(dy, self.grads[self.bn])
+            else:
+                ops.colsum(dy, out=self.grads[self.bn])
+        else:
+            ops.matmul_tn(dy, self.x, out=self.grads[self.wn])
+            ops.colsum(dy, out=self.grads[self.bn])
+        return dy
+
+    def bwd(self, dy, need_dx=True, fresh=False):
+        dy = self.bwd_params(dy, fresh)
         return ops.matmul_nn(dy, self.P[self.wn]) if need_dx else None
+
+
+class deferred_grads:
+    """with deferred_grads(device): every Lin.bwd inside leaves its dW split-K slabs / records its bias column sum; leaving
+    the block finishes them all in two launches (ops.DeferredGrads)."""
+
+    def __init__(self, device):
+        self.dev = device
+
+    def __enter__(self):
+        self.prev = Lin.deferred
+        Lin.deferred = ops.DeferredGrads(self.dev) if os.environ.get('CAPMI_DEFER_GRADS', '1') != '0' else None
+        return self
+
+    def __exit__(self, et, ev, tb):
+        d, Lin.deferred = Lin.deferred, self.prev
+        if d is not None and et is None:
+            d.flush()
+        return False
+
+
+def bwd_sum(lins, dys):
+    """sum_i dy_i W_i for projections of the SAME input (Q/K/V of self-attention, K/V of cross-attention) as ONE GEMM whose
+    K dimension walks the (dy_i, W_i) pairs as segments: no per-projection dX launches and no elementwise adds."""
+    dys = [l.bwd_params(dy, fresh=True) for l, dy in zip(lins, dys)]       # mha_bwd outputs: written once
+    M = dys[0].shape[0]
+    Ws = [l.P[l.wn] for l in lins]
+    N = Ws[0].shape[1]
+    out = torch.empty(M, N, dtype=_f32, device=dys[0].device)
+    ops.gemm([(dy, dy.shape[1], W, N, dy.shape[1], 1) for dy, W in zip(dys, Ws)], M, N, out, a_layout=0, b_layout=1)
+    return out
 
 
 class Norm:
@@ -112,9 +168,8 @@ class Norm:
         return y
 
     def bwd(self, dy, dx_accum):
-        da, db = layernorm_bwd(dy, self.x, self.P[self.pre + '.a_2'], self.mean, self.inv, dx_accum)
-        self.grads[self.pre + '.a_2'].copy_(da)
-        self.grads[self.pre + '.b_2'].copy_(db)
+        layernorm_bwd(dy, self.x, self.P[self.pre + '.a_2'], self.mean, self.inv, dx_accum, self.grads[self.pre + '.a_2'],
+                      self.grads[self.pre + '.b_2'])
 
 
 class Attn:
@@ -146,13 +201,10 @@ class Attn:
         d_o = self.lo.bwd(dy)
         dq, dk, dv = mha_bwd(d_o.view(Nq, Tq, D), self.q, self.k, self.v, Tk * D, self.p, self.drop_p, Nq, q_per_kv, Tq, Tk,
                              self.h)
-        dx = self.lq.bwd(dq.view(Nq * Tq, D))
-        dkv = self.lk.bwd(dk.view(Nkv * Tk, D))
-        dkv += self.lv.bwd(dv.view(Nkv * Tk, D))
         if self.self_attn:
-            dx += dkv
-            return dx, None
-        return dx, dkv
+            return bwd_sum((self.lq, self.lk, self.lv), (dq.view(Nq * Tq, D), dk.view(Nkv * Tk, D), dv.view(Nkv * Tk, D))), None
+        dx = self.lq.bwd(dq.view(Nq * Tq, D), fresh=True)
+        return dx, bwd_sum((self.lk, self.lv), (dk.view(Nkv * Tk, D), dv.view(Nkv * Tk, D)))
 
 
 class FFN:
@@ -164,7 +216,7 @@ class FFN:
         return self.l2.fwd(self.l1.fwd(x, relu=True, mask=drop_ff), mask=res_mask, residual=residual)
 
     def bwd(self, dy):
-        return self.l1.bwd(self.l2.bwd(dy))
+        return self.l1.bwd(self.l2.bwd(dy), fresh=True)
 
 
 class Dropper:
@@ -263,7 +315,13 @@ class TransformerGraph:
         if sparse is not None:
             sparse.tok_ld = 1                    # [N,T] tokens / gradients seen as N*T rows of one step
         ops.logsoftmax_bwd(g_logp, sparse, self.logp, None, dlogits, N * T, 1, 1, V1)
-        d_out = self.gen.bwd(dlogits)
+        with deferred_grads(dev):
+            self._backward_layers(dlogits, dev)
+
+    def _backward_layers(self, dlogits, dev):
+        P, g = self.P, self.grads
+        N, T, B, K, D = self.N, self.T, self.B, self.K, self.D
+        d_out = self.gen.bwd(dlogits, fresh=True)
         dx = torch.zeros(N * T, D, dtype=_f32, device=dev)
         self.dec_norm.bwd(d_out, dx)
         d_mem = torch.zeros(B * K, D, dtype=_f32, device=dev)

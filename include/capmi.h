@@ -277,6 +277,17 @@ int capmi_reward_criterion(const float *sel, int sel_ld, const int64_t *seq, int
 int capmi_splitk_reduce(const float *partial, int splits, float *C, int ldc, int M, int N,
                         const float *bias, const float *bias2, const float *row_bias, int row_bias_div,
                         const float *mul_mask, int relu, int accumulate, void *stream);
+/* The same for MANY independent GEMMs in one launch: the weight-gradient GEMMs of a layer-by-layer backward (dW = dY^T X of
+ * every nn.Linear, TransformerModel.py / AoAModel.py) leave their K-slice slabs (capmi_gemm_desc.defer_reduce = 1, one
+ * workspace region each) and nothing reads dW before the optimizer, so ONE launch at the end of the backward finishes them
+ * all.  `items` is DEVICE memory (the kernel reads the table); slabs of item i: partial + s * M * N, s < splits. */
+typedef struct capmi_reduce_item {
+    const float *partial;
+    float *C;
+    const float *bias;
+    int32_t splits, M, N, ldc, accumulate, reserved;
+} capmi_reduce_item;
+int capmi_splitk_reduce_batch(const capmi_reduce_item *items, int n_items, void *stream);
 /* Bernoulli keep-masks scaled by 1/(1-p): mask[i] in {0, 1/(1-p)}; Philox4x32-10(seed, offset+i) */
 int capmi_dropout_mask(float *mask, int64_t count, float p, uint64_t seed, uint64_t offset, void *stream);
 /* up to CAPMI_MAX_MASKS masks in one launch (the fc / att / xt / output dropouts of one rollout, AttModel.py:83-90, 122,
@@ -296,6 +307,13 @@ int capmi_rollout_init(float *h0, float *c0, float *h1, float *c1, int64_t count
                        void *stream);
 /* out[c] = sum_r in[r*ld + c]  (bias gradients) ; accumulate optional */
 int capmi_colsum(const float *in, int rows, int cols, int ld, float *out, int accumulate, void *stream);
+/* all bias gradients of a backward in one launch (no atomics, no zero-fill): `items` is DEVICE memory */
+typedef struct capmi_colsum_item {
+    const float *in;
+    float *out;
+    int32_t rows, cols, ld, accumulate;
+} capmi_colsum_item;
+int capmi_colsum_batch(const capmi_colsum_item *items, int n_items, void *stream);
 /* out[g, c] = sum_{j<group} in[(g*group + j)*cols + c], summed over T slabs of stride slab */
 int capmi_group_rowsum(const float *in, int T, int64_t slab, int groups, int group, int cols,
                        float *out, void *stream);

@@ -79,6 +79,7 @@ def test_struct_layouts_match_header():
     pairs = {'capmi_gemm_seg': _lib.GemmSeg, 'capmi_gemm_desc': _lib.GemmDesc, 'capmi_updown_weights': _lib.UpDownWeights,
              'capmi_updown_rollout': _lib.UpDownRollout, 'capmi_updown_grads': _lib.UpDownGrads,
              'capmi_updown_bwd_scratch': _lib.UpDownBwdScratch, 'capmi_sparse_logp_grad': _lib.SparseLogpGrad, 'capmi_mask_desc': _lib.MaskDesc,
+             'capmi_reduce_item': _lib.ReduceItem, 'capmi_colsum_item': _lib.ColsumItem,
              'capmi_newfc_bwd_scratch': _lib.NewFCBwdScratch}
     for cname, cls in pairs.items():
         assert fields(cname) == [f[0] for f in cls._fields_], cname
