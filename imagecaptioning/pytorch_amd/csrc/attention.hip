@@ -621,6 +621,135 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_bwd_kernel(
     }
 }
 
+// ---- backward, one step, ONE ROW per workgroup (the fused SCST rollout's row_img mode, or rpb == 1) ----------------
+// Same math as attention_bwd_kernel, restructured around its memory round trips (the old kernel walked slabs -> att ->
+// p_att as three dependent phases, 408 KB through one CU per row):
+//  * every global operand of the later phases (the image's att tile for the wave's regions, the thread's p_att column,
+//    att_h, w) is requested BEFORE the slab reduction starts and sits in registers when its phase begins;
+//  * the dX slab reduction is spread over gridDim.y workgroups per row: role 0 finishes only the d_ctx columns it needs,
+//    roles 1.. finish the remaining columns (dh_att | dh_lang of d_x2) on other CUs and exit.
+constexpr int BW2_KMAX = 40, BW2_KPW = 5;     // regions, regions per wave (8 waves)
+__global__ __launch_bounds__(ATT_THREADS) void attention_bwd_v2_kernel(
+    const float *__restrict__ d_ctx, int ld_dctx, const float *__restrict__ att_h, const float *__restrict__ alpha,
+    const float *__restrict__ p_att, const float *__restrict__ att, const float *__restrict__ w,
+    float *__restrict__ d_att_h, float *__restrict__ d_e, int B, int n_img, int chunks, int K, int A, int R,
+    const int *__restrict__ row_img, const float *__restrict__ x_slabs, int x_splits, size_t x_stride, int x_cols,
+    float *__restrict__ x_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *s_dc = lds;                        // [R]
+    float *s_de = lds + R;                    // [K]
+    int b, chunk, row0;
+    if (row_img) {
+        row0 = blockIdx.x;
+        b = row_img[row0];
+    } else {
+        if (!decode_block(B, chunks, b, chunk)) return;
+        row0 = b * n_img + chunk;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int role = blockIdx.y;
+    if (role > 0) {
+        // columns [R, x_cols) in (gridDim.y - 1) equal shares of whole quads
+        const int q_all = (x_cols - R) >> 2, per = (q_all + gridDim.y - 2) / (gridDim.y - 1);
+        const int q_lo = (role - 1) * per, q_hi = min(q_lo + per, q_all);
+        for (int q = q_lo + tid; q < q_hi; q += blockDim.x) {
+            const int c = R + 4 * q;
+            const float *p = x_slabs + (size_t)row0 * x_cols + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int s0 = 0; s0 < x_splits; s0 += 8) {
+                f32x4 part[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    part[u] = (s0 + u < x_splits) ? *reinterpret_cast<const f32x4 *>(p + (size_t)(s0 + u) * x_stride)
+                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+                v += ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+            }
+            *reinterpret_cast<f32x4 *>(x_out + (size_t)row0 * x_cols + c) = v;
+        }
+        return;
+    }
+    // ---- (1) request everything the later phases read
+    const float *ab = att + (size_t)b * K * R;
+    f32x4 av[BW2_KPW][4];
+#pragma unroll
+    for (int g = 0; g < BW2_KPW; ++g) {
+        const int k = wid + 8 * g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = lane * 4 + 256 * q;
+            av[g][q] = (k < K && r < R) ? *reinterpret_cast<const f32x4 *>(ab + (size_t)k * R + r) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float *pb = p_att + (size_t)b * K * A;
+    float pv[BW2_KMAX];
+#pragma unroll
+    for (int k = 0; k < BW2_KMAX; ++k) pv[k] = (k < K && tid < A) ? pb[(size_t)k * A + tid] : 0.f;
+    const float hh = tid < A ? att_h[(size_t)row0 * A + tid] : 0.f;
+    const float wa = tid < A ? w[tid] : 0.f;
+    const float al = tid < K ? alpha[(size_t)row0 * K + tid] : 0.f;
+    // ---- (2) d_ctx of this row: finish the slab reduction of its columns (or read it)
+    if (x_slabs) {
+        for (int q = tid; q < (R >> 2); q += blockDim.x) {
+            const int c = 4 * q;
+            const float *p = x_slabs + (size_t)row0 * x_cols + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int s0 = 0; s0 < x_splits; s0 += 8) {
+                f32x4 part[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    part[u] = (s0 + u < x_splits) ? *reinterpret_cast<const f32x4 *>(p + (size_t)(s0 + u) * x_stride)
+                                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+                v += ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+            }
+            *reinterpret_cast<f32x4 *>(x_out + (size_t)row0 * x_cols + c) = v;
+            *reinterpret_cast<f32x4 *>(s_dc + c) = v;
+        }
+    } else {
+        for (int r = tid; r < R; r += blockDim.x) s_dc[r] = d_ctx[(size_t)row0 * ld_dctx + r];
+    }
+    __syncthreads();
+    // ---- (3) dalpha[k] = att[b,k,:] . d_ctx from the registers
+#pragma unroll
+    for (int g = 0; g < BW2_KPW; ++g) {
+        const int k = wid + 8 * g;
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = lane * 4 + 256 * q;
+            if (r < R) {
+                const f32x4 dcv = *reinterpret_cast<const f32x4 *>(s_dc + r);
+                acc += av[g][q][0] * dcv[0] + av[g][q][1] * dcv[1] + av[g][q][2] * dcv[2] + av[g][q][3] * dcv[3];
+            }
+        }
+        const float sum = wave_sum(acc);
+        if (lane == 0 && k < K) s_de[k] = sum;
+    }
+    __syncthreads();
+    // ---- (4) softmax Jacobian (K <= 40 <= 64: one wave)
+    if (wid == 0) {
+        const float da = lane < K ? s_de[lane] : 0.f;
+        const float c = wave_sum(al * da);
+        if (lane < K) {
+            const float de = al * (da - c);
+            s_de[lane] = de;
+            d_e[(size_t)row0 * K + lane] = de;
+        }
+    }
+    __syncthreads();
+    // ---- (5) d_att_h[a] = w[a] sum_k d_e[k] (1 - tanh^2(p_att[k,a] + att_h[a])) from the registers
+    if (tid < A) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < BW2_KMAX; ++k) {
+            if (k < K) {
+                const float t = tanh_f(pv[k] + hh);
+                acc += s_de[k] * (1.f - t * t);
+            }
+        }
+        d_att_h[(size_t)row0 * A + tid] = wa * acc;
+    }
+}
+
 // ---- backward, time-batched feature / parameter gradients --------------------------------------
 // d_att[b, k, :] = sum over time and over the image's n caption rows of alpha[row, k] * d_ctx[row, :].
 // grid (B, ceil(K/KCH), ceil(R/128)): every workgroup owns KCH regions x 128 columns of one image and streams its
@@ -776,6 +905,20 @@ static int attention_bwd_launch(const float *d_ctx, int ld_dctx, const float *x_
     const size_t lds = ((size_t)NMAX * ((R + 3) & ~3) + (size_t)NMAX * K) * sizeof(float);
     if (lds > 64 * 1024) return CAPMI_EINVAL;
     const int rpb = row_img ? 1 : pick_rpb(B, n), chunks = row_img ? 1 : (n + rpb - 1) / rpb;
+    static const int env_v2 = [] { const char *e = getenv("CAPMI_ATT_BWD_V2"); return e ? atoi(e) : 1; }();
+    if (env_v2 && rpb == 1 && K <= BW2_KMAX && A <= ATT_THREADS && R % 4 == 0 && R <= 1024 &&
+        (reinterpret_cast<uintptr_t>(att) & 15) == 0 && (!x_slabs || (x_cols - R) % 4 == 0)) {
+        int roles = 1;
+        if (x_slabs && x_cols > R) {
+            roles = 1 + (x_cols - R + 1023) / 1024;
+            if (roles > 4) roles = 4;
+        }
+        hipLaunchKernelGGL(attention_bwd_v2_kernel, dim3(row_img ? N : grid_blocks(B, chunks), roles), dim3(ATT_THREADS),
+                           (size_t)(R + K) * sizeof(float), (hipStream_t)stream, d_ctx, ld_dctx, att_h, alpha, p_att, att, w,
+                           d_att_h, d_e, B, n, chunks, K, A, R, row_img, x_slabs, x_splits, (size_t)x_stride, x_cols, x_out);
+        CAPMI_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(attention_bwd_kernel, dim3(row_img ? N : grid_blocks(B, chunks)), dim3(ATT_THREADS), lds,
                        (hipStream_t)stream, d_ctx, ld_dctx, att_h, alpha, p_att, att, w, d_att_h, d_e, B, n, rpb, chunks, K,
                        A, R, row_img, x_slabs, x_splits, (size_t)x_stride, x_cols, x_out);
