@@ -285,6 +285,36 @@ def test_colsum_bias_gradients(dev, rows, cols, accumulate):
     assert rel_err(out, ref) < 2e-6
 
 
+def test_deferred_grads_batched_reduce_and_colsum(dev):
+    """ops.DeferredGrads: weight-gradient GEMMs leave their K-slice slabs, bias column sums are only recorded, flush() finishes
+    everything with one capmi_splitk_reduce_batch + one capmi_colsum_batch launch.  Shapes of the Transformer backward (fat
+    bf16x3 GEMMs with 4..15 K slices), a vocabulary-wide bias, an unaligned pair (scalar paths), and a second round with other
+    shapes on the same arena (regions landing on former slab data)."""
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(5)
+
+    def one_round(shapes):
+        d = ops.DeferredGrads(dev)
+        want = []
+        for K, M, N in shapes:
+            dy = torch.randn(K, M, generator=g).to(dev)
+            x = torch.randn(K, N, generator=g).to(dev)
+            dW = torch.full((M, N), float('nan'), device=dev)
+            db = torch.full((M,), float('nan'), device=dev)
+            d.dw(dy, x, dW)
+            d.colsum(dy, db)
+            want.append((dW, dy.double().t() @ x.double(), db, dy.double().sum(0)))
+            del dy, x                                   # the collector keeps what it still has to read
+        assert len(d.red) == len(shapes) and len(d.col) == len(shapes)
+        d.flush()
+        for dW, rW, db, rb in want:
+            assert rel_err(dW, rW) < 4e-6
+            assert rel_err(db, rb) < 4e-6
+
+    one_round([(6720, 512, 512), (2304, 512, 512), (6720, 512, 2048), (1200, 9488, 512), (333, 130, 70)])
+    one_round([(2304, 2048, 512), (640, 9488, 64), (6720, 512, 512)])
+
+
 @pytest.mark.parametrize('Nkv,q_per_kv,Tq,Tk,h,dk,mask_mode,causal,use_drop', [
     (3, 1, 21, 21, 2, 64, 'per_q', 0, True),       # decoder self-attention (pad & causal mask per caption)
     (3, 5, 21, 36, 8, 64, 'per_kv', 0, True),      # cross-attention, 5 captions share an image's K/V
