@@ -17,9 +17,10 @@ None when every image of the batch has Kmax regions (:240-241), ``labels [B,n,L+
 next images runs on a small thread pool while the device computes (the reference uses DataLoader worker processes,
 :350-372)."""
 import json
+import multiprocessing
 import os
 import random
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -39,8 +40,29 @@ def load_labels(path):
         return {k: f[k][:] for k in ('labels', 'label_start_ix', 'label_end_ix')}
 
 
+def decode_image(att_dir, fc_dir, img_id, use_fc, norm_att_feat):
+    """(fc [F] or [0], att [K_i, F]) of one image from its files (dataloader.py:186-229, 295-298)"""
+    p = os.path.join(att_dir, str(img_id) + '.npz')
+    if os.path.exists(p):
+        z = np.load(p)
+        a = z['feat'] if 'feat' in z else z['z']
+    else:
+        a = np.load(os.path.join(att_dir, str(img_id) + '.npy'))
+    a = np.asarray(a, dtype=np.float32).reshape(-1, a.shape[-1])
+    if norm_att_feat:
+        a = a / np.linalg.norm(a, 2, 1, keepdims=True)
+    if not use_fc:
+        return np.zeros((0,), dtype=np.float32), a
+    p = os.path.join(fc_dir, str(img_id) + '.npy') if fc_dir else None
+    fc = np.load(p).astype(np.float32) if p and os.path.exists(p) else a.mean(0)          # dataloader.py:295-298
+    return fc, a
+
+
 class FeatureLoader:
-    def __init__(self, opt, workers=4):
+    def __init__(self, opt, workers=4, processes=None):
+        """workers: size of the decode pool; processes: worker PROCESSES instead of threads (default: CAPMI_LOADER_PROCS=1).
+        np.load of a compressed .npz holds the GIL for most of its time: threads top out at ~400 images/s of 36 x 2048
+        features whatever their number, N processes scale to ~N x 400 (scripts/loader_bench.py)."""
         self.opt = opt
         self.batch_size = opt.batch_size
         self.seq_per_img = opt.seq_per_img
@@ -68,7 +90,13 @@ class FeatureLoader:
         self.order = {k: list(v) for k, v in self.split_ix.items()}
         self.rng.shuffle(self.order['train'])                  # MySampler shuffles the train split (dataloader.py:394-397)
         self.pos = {'train': 0, 'val': 0, 'test': 0}
-        self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        if processes is None:
+            processes = os.environ.get('CAPMI_LOADER_PROCS', '0') == '1'
+        self.processes = bool(processes)
+        if self.processes:        # spawn: the parent may already hold a HIP context, which a forked child must not inherit
+            self.pool = ProcessPoolExecutor(max_workers=max(1, workers), mp_context=multiprocessing.get_context('spawn'))
+        else:
+            self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
         self._pending = {}
 
     # ---- reference accessors
@@ -89,28 +117,15 @@ class FeatureLoader:
         return synthetic.document_frequency(refs)
 
     # ---- one image
-    def _att(self, img_id):
-        p = os.path.join(self.att_dir, str(img_id) + '.npz')
-        if os.path.exists(p):
-            z = np.load(p)
-            a = z['feat'] if 'feat' in z else z['z']
-        else:
-            a = np.load(os.path.join(self.att_dir, str(img_id) + '.npy'))
-        a = np.asarray(a, dtype=np.float32).reshape(-1, a.shape[-1])
-        if self.norm_att_feat:
-            a = a / np.linalg.norm(a, 2, 1, keepdims=True)
-        return a
-
     def _image(self, ix):
-        img_id = self.info['images'][ix]['id']
-        att = self._att(img_id)
-        fc = None
-        if self.use_fc:
-            p = os.path.join(self.fc_dir, str(img_id) + '.npy') if self.fc_dir else None
-            fc = np.load(p).astype(np.float32) if p and os.path.exists(p) else att.mean(0)      # dataloader.py:295-298
-        else:
-            fc = np.zeros((0,), dtype=np.float32)
-        return fc, att
+        return decode_image(self.att_dir, self.fc_dir, self.info['images'][ix]['id'], self.use_fc, self.norm_att_feat)
+
+    def submit_image(self, ix):
+        """future of (fc, att) of image `ix` on the decode pool (threads, or worker processes: a pure function of paths)"""
+        if self.processes:
+            return self.pool.submit(decode_image, self.att_dir, self.fc_dir, self.info['images'][ix]['id'], self.use_fc,
+                                    self.norm_att_feat)
+        return self.pool.submit(self._image, ix)
 
     def _captions(self, ix, rng):
         """dataloader.py:165-184: seq_per_img consecutive captions from a random start, or sampling with replacement"""
@@ -138,7 +153,23 @@ class FeatureLoader:
 
     def _schedule(self, split, B):
         idx, wrapped = self._next_indices(split, B)
-        return idx, wrapped, self.pos[split], [self.pool.submit(self._image, ix) for ix in idx]
+        return idx, wrapped, self.pos[split], [self.submit_image(ix) for ix in idx]
+
+    def label_part(self, idx):
+        """labels [B,n,L+2] int64, masks, gts, infos of the images `idx` (dataloader.py:165-184, 243-259)"""
+        B, n, L = len(idx), self.seq_per_img, self.seq_length
+        labels = np.zeros((B, n, L + 2), dtype=np.int64)
+        masks = np.zeros((B, n, L + 2), dtype=np.float32)
+        gts, infos = [], []
+        for b, ix in enumerate(idx):
+            seq = self._captions(ix, self.rng)
+            labels[b, :, 1:L + 1] = seq
+            for j in range(n):
+                masks[b, j, :int((seq[j] != 0).sum()) + 2] = 1
+            gts.append(self.label[self.label_start_ix[ix] - 1: self.label_end_ix[ix]])
+            im = self.info['images'][ix]
+            infos.append({'ix': ix, 'id': im['id'], 'file_path': im.get('file_path', '')})
+        return labels, masks, gts, infos
 
     def get_batch(self, split, batch_size=None):
         B = batch_size or self.batch_size
@@ -147,25 +178,15 @@ class FeatureLoader:
         self._pending[key] = self._schedule(split, B)          # decode the NEXT batch's features in the background
         idx, wrapped, pos_now, futs = job
         feats = [f.result() for f in futs]
-        n, L = self.seq_per_img, self.seq_length
         F = feats[0][1].shape[1]
         kmax = max(a.shape[0] for _, a in feats)
         fc = np.stack([f for f, _ in feats]).astype(np.float32)
         att = np.zeros((B, kmax, F), dtype=np.float32)
         att_masks = np.zeros((B, kmax), dtype=np.float32)
-        labels = np.zeros((B, n, L + 2), dtype=np.int64)
-        masks = np.zeros((B, n, L + 2), dtype=np.float32)
-        gts, infos = [], []
-        for b, (ix, (_, a)) in enumerate(zip(idx, feats)):
+        for b, (_, a) in enumerate(feats):
             att[b, :a.shape[0]] = a
             att_masks[b, :a.shape[0]] = 1
-            seq = self._captions(ix, self.rng)
-            labels[b, :, 1:L + 1] = seq
-            for j in range(n):
-                masks[b, j, :int((seq[j] != 0).sum()) + 2] = 1
-            gts.append(self.label[self.label_start_ix[ix] - 1: self.label_end_ix[ix]])
-            im = self.info['images'][ix]
-            infos.append({'ix': ix, 'id': im['id'], 'file_path': im.get('file_path', '')})
+        labels, masks, gts, infos = self.label_part(idx)
         return {'fc_feats': torch.from_numpy(fc), 'att_feats': torch.from_numpy(att),
                 'att_masks': None if att_masks.sum() == att_masks.size else torch.from_numpy(att_masks),     # :240-241
                 'labels': torch.from_numpy(labels), 'masks': torch.from_numpy(masks), 'gts': gts,

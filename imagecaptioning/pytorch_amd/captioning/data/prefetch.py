@@ -30,15 +30,16 @@ class DevicePrefetcher:
         return buf
 
     def _issue(self, split):
-        data = self.loader.get_batch(split)
         slot = self._slot.get(split, 0)
         self._slot[split] = (slot + 1) % (self.depth + 1)
-        out = dict(data)
         with torch.cuda.stream(self.stream):
+            data = self.loader.get_batch(split)        # (inside the stream context: a ResidentFeatures store works on this stream)
+            out = dict(data)
             for k in TENSOR_KEYS:
                 t = data.get(k)
                 if torch.is_tensor(t):
-                    out[k] = self._pin(split, slot, k, t).to(self.device, non_blocking=True)
+                    # (a ResidentFeatures loader hands over features that already live in HBM, gathered on this stream)
+                    out[k] = t if t.device.type == 'cuda' else self._pin(split, slot, k, t).to(self.device, non_blocking=True)
             # reference captions travel with the batch as a device image (rewards.GtsBatch): packed here, once per batch, on the
             # copy stream -- the SCST step then never re-packs them and never has to recognise a batch by object identity
             from ..utils import rewards

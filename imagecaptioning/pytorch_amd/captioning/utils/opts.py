@@ -28,7 +28,7 @@ DEFAULTS = dict(
     # data (synthetic only: the reference's h5/lmdb loaders are outside the hot path)
     input_synthetic=1, vocab_size=9487, synthetic_regions=36, synthetic_images=200,
     # real precomputed features (captioning/data/feature_loader.py; opts.py:23-37 of the reference)
-    input_json='', input_label_h5='', input_fc_dir='', input_att_dir='', use_fc=1, norm_att_feat=0, train_only=0,
+    input_json='', input_label_h5='', input_fc_dir='', input_att_dir='', use_fc=1, norm_att_feat=0, train_only=0, resident_features=1, resident_budget_gb=0.0,
 )
 
 

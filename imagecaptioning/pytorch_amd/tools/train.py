@@ -67,6 +67,10 @@ def train(opt):
     else:
         loader = SyntheticLoader(opt)
     opt.vocab = loader.get_vocab()
+    if opt.input_json and getattr(opt, 'resident_features', 1):
+        # the whole feature set lives in HBM after its first epoch (36 GB for COCO at 36 regions; budget: half the device memory)
+        from captioning.data.resident import ResidentFeatures
+        loader = ResidentFeatures(loader, dev, budget_bytes=int(opt.resident_budget_gb * (1 << 30)) if opt.resident_budget_gb > 0 else None)
     loader = DevicePrefetcher(loader, dev)             # batches arrive already resident in HBM (pinned, side stream)
     torch.manual_seed(1234)                           # identical weights on every rank
     model = models.setup(opt).to(dev)

@@ -133,3 +133,54 @@ def test_train_on_real_feature_files_xe_then_scst(tmp_path):
     T.train(_opts(small + ['--max_iters', '33', '--self_critical_after', '0', '--train_sample_n', '3', '--start_from', str(tmp_path / 'ck'),
                            '--cached_tokens', 'no-such-table']))
     rewards.reset_scorer()
+
+
+@pytest.mark.parametrize('fixed,budget_rows', [(None, None), (6, None), (None, 14)])
+def test_resident_feature_store_returns_the_streaming_loaders_batches(tmp_path, fixed, budget_rows):
+    """captioning/data/resident.py: after an image's first draw its features live in the device store and later batches are a
+    row gather -- three epochs of batches (variable and fixed region counts, partial batches over the wrap, and a budget that
+    only holds some of the images) equal the streaming FeatureLoader's, tensor for tensor.  Runs on the CPU device here; the GPU
+    suite runs the same store under DevicePrefetcher."""
+    args = make_dataset(tmp_path, fixed_regions=fixed)
+    from captioning.data.feature_loader import FeatureLoader
+    from captioning.data.resident import ResidentFeatures
+    a = FeatureLoader(_opts(args + ['--batch_size', '4', '--seq_per_img', '3']))
+    b = ResidentFeatures(FeatureLoader(_opts(args + ['--batch_size', '4', '--seq_per_img', '3'])), 'cpu',
+                         budget_bytes=None if budget_rows is None else budget_rows * 24 * 4, first_rows=8)
+    n_train = len(a.split_ix['train'])
+    for it in range(3 * ((n_train + 3) // 4) + 1):
+        x, y = a.get_batch('train'), b.get_batch('train')
+        for k in ('fc_feats', 'att_feats', 'labels', 'masks'):
+            assert torch.equal(x[k], y[k].cpu()), (it, k)
+        assert (x['att_masks'] is None) == (y['att_masks'] is None)
+        if x['att_masks'] is not None:
+            assert torch.equal(x['att_masks'], y['att_masks'])
+        assert all(np.array_equal(g, h) for g, h in zip(x['gts'], y['gts']))
+        assert x['bounds'] == y['bounds'] and x['infos'] == y['infos']
+    if budget_rows is None:
+        assert b.misses == n_train and b.streamed == 0 and b.hits > 2 * n_train - 4      # every image decoded exactly once
+    else:
+        assert b.streamed > 0 and b.used <= budget_rows                                  # the rest is streamed every time
+    assert b.get_vocab() == a.get_vocab() and b.pos is b.loader.pos                      # the wrapped loader's interface
+
+
+@pytest.mark.gpu
+def test_resident_store_under_the_device_prefetcher_gpu(tmp_path):
+    """The HBM-resident store behind DevicePrefetcher (its gathers and inserts run on the prefetcher's copy stream) delivers the
+    same device batches as the streaming loader behind DevicePrefetcher, over three epochs with variable region counts."""
+    args = make_dataset(tmp_path, n_img=23, F=40)
+    from captioning.data.feature_loader import FeatureLoader
+    from captioning.data.resident import ResidentFeatures
+    from captioning.data.prefetch import DevicePrefetcher
+    dev = torch.device('cuda:0')
+    a = DevicePrefetcher(FeatureLoader(_opts(args + ['--batch_size', '5', '--seq_per_img', '3'])), dev)
+    res = ResidentFeatures(FeatureLoader(_opts(args + ['--batch_size', '5', '--seq_per_img', '3'])), dev, first_rows=16)
+    b = DevicePrefetcher(res, dev)
+    for it in range(14):
+        x, y = a.get_batch('train'), b.get_batch('train')
+        for k in ('fc_feats', 'att_feats', 'labels', 'masks', 'att_masks'):
+            assert (x[k] is None) == (y[k] is None), (it, k)
+            if x[k] is not None:
+                assert y[k].is_cuda and torch.equal(x[k], y[k]), (it, k)
+        assert x['bounds'] == y['bounds']
+    assert res.streamed == 0 and res.misses == len(res.split_ix['train']) and res.hits > 0
