@@ -47,6 +47,10 @@ def train(opt):
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
+    if 'OMP_NUM_THREADS' not in os.environ:
+        # the host only assembles batches and issues launches: torch's default of 128 OpenMP threads on this 256-core host
+        # spin after every incidental CPU op and starve the decode threads (36 vs 8 ms per iteration, scripts/train_e2e.sh)
+        torch.set_num_threads(4)
     dev = torch.device('cuda', local)
     if world > 1:
         dist.init_process_group('nccl', rank=rank, world_size=world)
@@ -109,6 +113,7 @@ def train(opt):
                                           'loader_pos': dict(last_pos), 'rng_calls': int(getattr(model, '_rng_calls', 0))},
                              optimizer_state={'flat': flat.state_dict(), 'sched': sched.state_dict()})
 
+    iter_times = []
     while it < opt.max_iters and (opt.max_epochs == -1 or epoch < opt.max_epochs):     # tools/train.py:279-280
         if epoch_done:
             sched.epoch_start(epoch)
@@ -147,6 +152,7 @@ def train(opt):
         train_loss = loss.item()
         torch.cuda.synchronize()
         t2 = time.time()
+        iter_times.append(t2 - t0)
         if rank == 0 and it % opt.losses_log_every == 0:
             if struc_flag:
                 print('iter %d (epoch %d), train_loss = %.3f, lm_loss = %.3f, struc_loss = %.3f, time/batch = %.3f'
@@ -176,6 +182,11 @@ def train(opt):
             checkpoint()
     if rank == 0 and opt.save_checkpoint_every:
         checkpoint()
+    if rank == 0 and len(iter_times) >= 20:        # loader + step + per-iteration host sync, second half of the run
+        tail = iter_times[len(iter_times) // 2:]
+        ms = 1e3 * sum(tail) / len(tail)
+        print('mean time/iteration over the last %d iterations: %.2f ms = %.0f captions/s per GPU'
+              % (len(tail), ms, opt.batch_size * opt.seq_per_img / ms * 1e3))
     if world > 1:
         dist.destroy_process_group()
     return train_loss

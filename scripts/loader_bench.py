@@ -53,7 +53,7 @@ def main():
 
 
     per_epoch = n_img // 10
-    for workers, procs in ((1, False), (4, False), (4, True), (8, True), (16, True)):
+    for workers, procs in ((1, False), (4, False), (8, False), (16, False), (4, True), (8, True)):
         ld = FeatureLoader(opts.parse_opt(argv), workers=workers, processes=procs)
         rate(ld, 2, False)                                   # worker start-up
         r, _ = rate(ld, per_epoch, False)
