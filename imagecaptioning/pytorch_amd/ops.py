@@ -154,7 +154,10 @@ class DeferredGrads:
         K, M = dy.shape
         N = x.shape[1]
         cf = Workspace.COUNTER_FLOATS
-        region = self.arena.take(cf + 16 * M * N)
+        if cf + 2 * M * N > SlabArena.CHUNK:            # a gradient this large needs no K split to fill the chip
+            gemm([(dy, M, x, N, K, 1)], M, N, out, a_layout=1, b_layout=1)
+            return
+        region = self.arena.take(min(cf + 16 * M * N, SlabArena.CHUNK))      # (the GEMM limits its K split to the region)
         splits = gemm([(dy, M, x, N, K, 1)], M, N, out, a_layout=1, b_layout=1, ws=_WsView(region), defer_reduce=True)
         self.arena.commit(cf + splits * M * N)
         self.red.append((region.data_ptr() + 4 * cf, out.data_ptr(), 0, splits, M, N, N, 0, 0))
