@@ -115,22 +115,24 @@ class AoAGraph:
         self.q, self.att_o, self.pre2, self.out_drop = z(T, N, R), z(T, N, R), z(T, N, 2 * R), z(T, N, R)
         self.p_dec = z(T, N, h, 1, K)
         self.it_all = torch.empty(T, N, dtype=torch.long, device=dev)
-        self.m_xt, self.m_ctx, self.m_out, self.m_patt = [], [], [], []
+        # the dropout masks of ALL T steps in two launches ([T, ...] arrays; step t uses slice t)
+        self.m_xt_all, self.m_ctx_all, self.m_out_all = self.d_lm.many([(T, N, E), (T, N, R), (T, N, R)])
+        self.m_patt_all = self.d_att(T, N, h, 1, K)
+        unb = lambda a: [None] * T if a is None else list(a.unbind(0))       # noqa: E731
+        self.m_xt, self.m_ctx, self.m_out, self.m_patt = unb(self.m_xt_all), unb(self.m_ctx_all), unb(self.m_out_all), unb(self.m_patt_all)
         self.seq = torch.zeros(N, L, dtype=torch.long, device=dev)
         self.seq_logp = torch.zeros(N, L, V1, dtype=_f32, device=dev)
         self.sel = torch.zeros(N, L, dtype=_f32, device=dev)
         self.live = torch.zeros(N, L, dtype=torch.uint8, device=dev)
         it = torch.zeros(N, dtype=torch.long, device=dev)
         unf = torch.ones(N, dtype=torch.uint8, device=dev)
-        logits = z(N, V1)
         mode_i = 2 if teacher else {'greedy': 0, 'sample': 1, 'forced': 2}[mode]
         st = stream_ptr()
         a_n, b_n = P['core.attention.norm.a_2'], P['core.attention.norm.b_2']
         Wq, bq = P['core.attention.linears.0.weight'], P['core.attention.linears.0.bias']
         Wc, bc = P['core.att2ctx.0.weight'], P['core.att2ctx.0.bias']
         for t in range(T):
-            m_xt, m_ctx, m_out, m_p = self.d_lm(N, E), self.d_lm(N, R), self.d_lm(N, R), self.d_att(N, h, 1, K)
-            self.m_xt.append(m_xt); self.m_ctx.append(m_ctx); self.m_out.append(m_out); self.m_patt.append(m_p)
+            m_xt, m_ctx, m_out, m_p = self.m_xt[t], self.m_ctx[t], self.m_out[t], self.m_patt[t]
             if teacher:
                 check(lib.capmi_embed_fwd(forced.data_ptr() + 8 * t, forced.shape[1], ptr(self.it_all[t]), ptr(P['embed.0.weight']),
                                           ptr(m_xt), ptr(self.xt[t]), N, E, 1, st), 'embed_fwd')
@@ -160,9 +162,11 @@ class AoAGraph:
                 self.out_drop[t].copy_(self.out[t + 1])
             else:
                 check(lib.capmi_relu_mask_bwd(ptr(self.out[t + 1]), None, ptr(m_out), ptr(self.out_drop[t]), N * R, st), 'out_drop')
-            ops.gemm([(self.out_drop[t], R, P['logit.weight'], R, R, 1)], N, V1, logits, bias=P['logit.bias'])
-            ops.logsoftmax_select(logits, t, L, mode_i, temperature, None if gumbel is None else gumbel[t], seed, forced,
-                                  1 if teacher else 0, self.seq, it, unf, self.seq_logp, self.sel, self.live, top_k, top_p)
+            # the logit GEMM leaves its K-slice slabs; log-softmax + select finishes them with the bias (no reduce launch)
+            sp = ops.gemm([(self.out_drop[t], R, P['logit.weight'], R, R, 1)], N, V1, ws.buf, ws=ws, defer_reduce=True)
+            ops.logsoftmax_select(ws.slabs, t, L, mode_i, temperature, None if gumbel is None else gumbel[t], seed, forced,
+                                  1 if teacher else 0, self.seq, it, unf, self.seq_logp, self.sel, self.live, top_k, top_p,
+                                  splits=sp, stride=N * V1, bias=P['logit.bias'], shape=(N, V1))
         return self.seq, self.seq_logp
 
     # ------------------------------------------------------------------ backward
@@ -188,9 +192,10 @@ class AoAGraph:
         d_sum_all = z(T, N, R)                  # gradient reaching (mean + Drop(ctx_prev)) at each step
         d_p_att = torch.zeros(B * K, 2 * R, dtype=_f32, device=dev)
         dh_next, dc_next, d_ctx_next = None, None, None
+        d_out_all = mul_mask(d_outdrop, self.m_out_all)              # the out_drop Jacobian of all steps in one launch
         for t in range(T - 1, -1, -1):
             # out_{t+1}: from the logit (through out_drop) and from step t+1's ctx input
-            d_out = mul_mask(d_outdrop[t], self.m_out[t])
+            d_out = d_out_all[t]
             if d_ctx_next is not None:
                 d_out = d_out + d_ctx_next
             check(lib.capmi_glu_bwd(ptr(d_out), None, ptr(self.pre2[t]), ptr(d_pre2_all[t]), N, R, st), 'glu_bwd')
@@ -198,13 +203,11 @@ class AoAGraph:
             d_att = d_cat[:, :R].contiguous()
             dh = d_cat[:, R:].contiguous()
             # attention: dq, dK/dV accumulated into the two halves of d_p_att across rows of an image and across time
-            dq = torch.empty(N, 1, R, dtype=_f32, device=dev)
+            dq = dq_all[t]                                               # [N,R] = [N,1,R], written in place
             check(lib.capmi_mha_bwd(ptr(d_att), ptr(self.q[t]), self.p_att.data_ptr() + 4 * R, ptr(self.p_att), K * 2 * R, 2 * R,
                                     ptr(self.p_dec[t]), ptr(self.m_patt[t]), ptr(dq), d_p_att.data_ptr() + 4 * R, ptr(d_p_att),
                                     K * 2 * R, 2 * R, 1, N, n, 1, K, h, R // h, st), 'mha_bwd')
-            dq_all[t].copy_(dq.view(N, R))
-            d_qn = ops.matmul_nn(dq_all[t], Wq)
-            ln_dy[t].copy_(d_qn)
+            d_qn = ops.matmul_nn(dq_all[t], Wq, out=ln_dy[t])
             check(lib.capmi_layernorm_bwd(ptr(d_qn), ptr(self.h_att[t + 1]), ptr(a_n), ptr(self.q_ln_mean[t]), ptr(self.q_ln_inv[t]),
                                           ptr(dh), 1, ptr(ln_g[t]), N, R, EPS, st), 'layernorm_bwd')
             # LSTM cell
@@ -235,7 +238,7 @@ class AoAGraph:
         # embedding
         d_xt = ops.matmul_nn(dg2, W_ih[:, :E].contiguous())
         g['embed.0.weight'].zero_()
-        masks_xt = None if self.m_xt[0] is None else torch.stack(self.m_xt).contiguous()
+        masks_xt = self.m_xt_all
         check(lib.capmi_embed_bwd(ptr(self.it_all), ptr(d_xt), ptr(self.xt), ptr(masks_xt), ptr(g['embed.0.weight']), TN, E, 1, st),
               'embed_bwd')
         # attention query path

@@ -365,12 +365,14 @@ def logsoftmax_bwd(g_dense, sparse, seq_logp, live, dlogits, N, L, T, V1):
 
 
 def logsoftmax_select(logits, step, L, mode, temperature, gumbel, seed, forced, no_finish_mask, seq, it_next, unfinished,
-                      seq_logp, sel_logp, live, top_k=0, top_p=0.0):
-    """capmi_logsoftmax_select_partial on finished logits [N,V1] (one slab, no bias) with the optional top-k / nucleus
-    filter; used by the host-stepped decoders (Transformer, AoA)."""
-    N, V1 = logits.shape
+                      seq_logp, sel_logp, live, top_k=0, top_p=0.0, splits=1, stride=0, bias=None, shape=None):
+    """capmi_logsoftmax_select_partial with the optional top-k / nucleus filter; used by the host-stepped decoders
+    (Transformer, AoA).  logits: finished [N,V1] (one slab, no bias), or -- with shape=(N,V1) -- the `splits` K-slice slabs a
+    deferred logit GEMM left `stride` floats apart, finished here together with `bias`."""
+    N, V1 = logits.shape if shape is None else shape
     flt = _lib.SampleFilter(int(top_k), float(top_p))
-    check(lib.capmi_logsoftmax_select_partial(ptr(logits), 1, 0, None, N, V1, step, L, mode, None, float(temperature),
+    check(lib.capmi_logsoftmax_select_partial(ptr(logits), int(splits), int(stride), ptr(bias), N, V1, step, L, mode, None,
+                                              float(temperature),
                                               ptr(gumbel), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(forced),
                                               0 if forced is None else forced.shape[1], int(no_finish_mask), ptr(seq), L,
                                               ptr(it_next), ptr(unfinished), ptr(seq_logp), ptr(sel_logp), ptr(live), None,

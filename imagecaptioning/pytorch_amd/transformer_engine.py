@@ -229,6 +229,16 @@ class Dropper:
         self.k += 1
         return ops.dropout_mask(shape, self.p, self.seed, self.k << 36, self.dev)
 
+    def many(self, shapes):
+        """several masks (<= CAPMI_MAX_MASKS) in ONE launch, e.g. the per-step masks of all T steps of a rollout as [T, ...]"""
+        if not self.on:
+            return [None] * len(shapes)
+        specs = []
+        for sh in shapes:
+            self.k += 1
+            specs.append((tuple(sh), self.k << 36, None, self.dev))
+        return ops.dropout_masks(specs, self.p, self.seed)
+
 
 class TransformerGraph:
     """One teacher-forced forward (and its backward) of TransformerModel._forward (TransformerModel.py:340-348)."""
