@@ -74,7 +74,8 @@ class ReduceItem(C.Structure):
 
 
 class ColsumItem(C.Structure):
-    _fields_ = [('in', c_f), ('out', c_f), ('rows', C.c_int32), ('cols', C.c_int32), ('ld', C.c_int32), ('accumulate', C.c_int32)]
+    _fields_ = [('in', c_f), ('out', c_f), ('out2', c_f), ('rows', C.c_int32), ('cols', C.c_int32), ('ld', C.c_int32),
+                ('accumulate', C.c_int32)]
 
 
 class UpDownBwdScratch(C.Structure):
@@ -144,6 +145,7 @@ SIGNATURES = {
     'capmi_reward_criterion': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     'capmi_colsum': [_P, _I, _I, _I, _P, _I, _P],
     'capmi_colsum_batch': [_P, _I, _P],
+    'capmi_colsum_batch_args': [C.POINTER(ColsumItem), _I, _P],
     'capmi_splitk_reduce_batch': [_P, _I, _P],
     'capmi_group_rowsum': [_P, _I, _I64, _I, _I, _I, _P, _P],
     'capmi_relu_mask_bwd': [_P, _P, _P, _P, _I64, _P],

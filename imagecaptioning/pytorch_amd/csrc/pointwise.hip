@@ -328,11 +328,10 @@ __global__ __launch_bounds__(CS_Q * CS_R) void colsum_kernel(const float *__rest
     }
 }
 
-// Many column sums in one launch (all bias gradients of a layer-by-layer backward): blockIdx.y = item, blockIdx.x walks the
-// item's 64-column blocks; every block sums ALL rows of its columns (deterministic, no atomics, no zero-fill launch).
-__global__ __launch_bounds__(CS_Q * CS_R) void colsum_batch_kernel(const capmi_colsum_item *__restrict__ items) {
+// Many column sums in one launch (all bias gradients of a backward): blockIdx.y = item, blockIdx.x walks the item's
+// 64-column blocks; every block sums ALL rows of its columns (deterministic, no atomics, no zero-fill launch).
+__device__ __forceinline__ void colsum_item_body(const capmi_colsum_item &it) {
     __shared__ f32x4 red[CS_R][CS_Q];
-    const capmi_colsum_item it = items[blockIdx.y];
     const int cq = threadIdx.x % CS_Q, ry = threadIdx.x / CS_Q;
     const int cblocks = (it.cols + 4 * CS_Q - 1) / (4 * CS_Q);
     const bool vec = (reinterpret_cast<uintptr_t>(it.in) & 15) == 0 && it.ld % 4 == 0 && it.cols % 4 == 0;
@@ -371,10 +370,28 @@ __global__ __launch_bounds__(CS_Q * CS_R) void colsum_batch_kernel(const capmi_c
             const f32x4 t = (red[0][cq] + red[16][cq]) + (red[32][cq] + red[48][cq]);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (col + k < it.cols) it.out[col + k] = it.accumulate ? it.out[col + k] + t[k] : t[k];
+                if (col + k < it.cols) {
+                    const float v = it.accumulate ? it.out[col + k] + t[k] : t[k];
+                    it.out[col + k] = v;
+                    if (it.out2) it.out2[col + k] = v;
+                }
         }
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(CS_Q * CS_R) void colsum_batch_kernel(const capmi_colsum_item *__restrict__ items) {
+    colsum_item_body(items[blockIdx.y]);
+}
+struct ColsumArgs {
+    capmi_colsum_item items[CAPMI_COLSUM_ARGS_MAX];
+};
+__global__ __launch_bounds__(CS_Q * CS_R) void colsum_batch_args_kernel(const ColsumArgs a) {
+    // (static indices: a dynamically indexed kernel-argument array would be copied to scratch)
+    capmi_colsum_item it = a.items[0];
+#pragma unroll
+    for (int i = 1; i < CAPMI_COLSUM_ARGS_MAX; ++i)
+        if (blockIdx.y == i) it = a.items[i];
+    colsum_item_body(it);
 }
 
 __global__ void group_rowsum_kernel(const float *__restrict__ in, int T, size_t slab, int groups, int group, int cols,
@@ -564,6 +581,21 @@ int capmi_colsum(const float *in, int rows, int cols, int ld, float *out, int ac
 int capmi_colsum_batch(const capmi_colsum_item *items, int n_items, void *stream) {
     if (!items || n_items <= 0) return CAPMI_EINVAL;
     hipLaunchKernelGGL(colsum_batch_kernel, dim3(32, n_items), dim3(CS_Q * CS_R), 0, (hipStream_t)stream, items);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_colsum_batch_args(const capmi_colsum_item *host_items, int n_items, void *stream) {
+    if (!host_items || n_items <= 0 || n_items > CAPMI_COLSUM_ARGS_MAX) return CAPMI_EINVAL;
+    ColsumArgs a{};
+    int max_cb = 1;
+    for (int i = 0; i < n_items; ++i) {
+        a.items[i] = host_items[i];
+        if (!a.items[i].in || !a.items[i].out || a.items[i].rows <= 0 || a.items[i].cols <= 0) return CAPMI_EINVAL;
+        const int cb = (a.items[i].cols + 4 * CS_Q - 1) / (4 * CS_Q);
+        if (cb > max_cb) max_cb = cb;
+    }
+    hipLaunchKernelGGL(colsum_batch_args_kernel, dim3(max_cb < 64 ? max_cb : 64, n_items), dim3(CS_Q * CS_R), 0, (hipStream_t)stream, a);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

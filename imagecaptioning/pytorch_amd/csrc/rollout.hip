@@ -249,6 +249,25 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
     const int ld_att_ih = 2 * R + E;
     float *P = s->partial;
     const int64_t cap = s->partial_capacity;
+    // bias gradients (column sums over all T*N rows): with every phase in this one call they are recorded and finished by ONE
+    // launch at the end (4 launches + 3 zero-fills + 2 copies otherwise); a phased call (DDP bucket overlap) keeps each phase
+    // complete when it returns
+    const bool batch_cols = (phases & CAPMI_BWD_ALL) == CAPMI_BWD_ALL;
+    capmi_colsum_item cols[CAPMI_COLSUM_ARGS_MAX];
+    int n_cols = 0;
+    auto colsum = [&](const float *in, int rows, int ncol, float *out, float *out2) -> int {
+        if (batch_cols) {
+            cols[n_cols++] = capmi_colsum_item{in, out, out2, rows, ncol, ncol, 0};
+            return 0;
+        }
+        int rc = capmi_colsum(in, rows, ncol, ncol, out, 0, stream);
+        if (rc) return rc;
+        if (out2) {
+            hipError_t e = hipMemcpyAsync(out2, out, (size_t)ncol * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
+        return 0;
+    };
 
     // ---- logit layer, batched over all T*N rows ----------------------------------------------
     if (phases & CAPMI_BWD_LOGIT) {
@@ -258,7 +277,7 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         RC(gemm(stream, 0, 1, TN, R, s->d_hdrop, R, &a, 1, P, cap, 0, nullptr));
         SegSpec b{s->dlogits, V1, r->h_drop, R, TN, 1};     // dW_logit = dlogits^T h_drop         [V1,R]
         RC(gemm(stream, 1, 1, V1, R, g->logit_w, R, &b, 1, P, cap, 0, nullptr));
-        RC(capmi_colsum(s->dlogits, TN, V1, V1, g->logit_b, 0, stream));
+        RC(colsum(s->dlogits, TN, V1, g->logit_b, nullptr));
     }
 
     // ---- pack the recurrent weight slices once: [W_ih | W_hh] side by side, so that each step needs ONE
@@ -361,9 +380,8 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         RC(gemm(stream, 1, 1, 4 * R, E, g->att_w_ih + 2 * R, ld_att_ih, &b, 1, P, cap, 0, nullptr));
         SegSpec c{s->dg_att, 4 * R, r->h_att, R, TN, 1};           // x h_att_prev
         RC(gemm(stream, 1, 1, 4 * R, R, g->att_w_hh, R, &c, 1, P, cap, 0, nullptr));
-        RC(capmi_colsum(s->dg_att, TN, 4 * R, 4 * R, g->att_b_ih, 0, stream));
-        hipError_t e = hipMemcpyAsync(g->att_b_hh, g->att_b_ih, (size_t)4 * R * sizeof(float), hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return (int)e;
+        RC(colsum(s->dg_att, TN, 4 * R, g->att_b_ih, g->att_b_hh));
+        hipError_t e;
         // fc columns: sum over time and over the n rows of an image first
         RC(capmi_group_rowsum(s->dg_att, T, (int64_t)N * 4 * R, B, n, 4 * R, s->sum_dg_att, stream));
         SegSpec d{s->sum_dg_att, 4 * R, r->fc, R, B, 1};
@@ -387,18 +405,17 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         RC(gemm(stream, 1, 1, 4 * R, R, g->lang_w_ih + R, 2 * R, &b, 1, P, cap, 0, nullptr));
         SegSpec c{s->dg_lang, 4 * R, r->h_lang, R, TN, 1};
         RC(gemm(stream, 1, 1, 4 * R, R, g->lang_w_hh, R, &c, 1, P, cap, 0, nullptr));
-        RC(capmi_colsum(s->dg_lang, TN, 4 * R, 4 * R, g->lang_b_ih, 0, stream));
-        hipError_t e = hipMemcpyAsync(g->lang_b_hh, g->lang_b_ih, (size_t)4 * R * sizeof(float), hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return (int)e;
+        RC(colsum(s->dg_lang, TN, 4 * R, g->lang_b_ih, g->lang_b_hh));
     }
     // attention parameters / features
     if (phases & CAPMI_BWD_ATTENTION) {
         SegSpec a{s->d_att_h_all, A, r->h_att + NR, R, TN, 1};
         RC(gemm(stream, 1, 1, A, R, g->h2att_w, R, &a, 1, P, cap, 0, nullptr));
-        RC(capmi_colsum(s->d_att_h_all, TN, A, A, g->h2att_b, 0, stream));
+        RC(colsum(s->d_att_h_all, TN, A, g->h2att_b, nullptr));
         RC(capmi_attention_bwd_batched(s->d_x2, 3 * R, r->att_h, r->alpha, s->d_e_all, r->p_att, w->alpha_w, g->d_att,
                                        g->d_p_att, g->alpha_w, g->alpha_b, T, B, n, N, K, A, R, stream));
     }
+    if (n_cols) RC(capmi_colsum_batch_args(cols, n_cols, stream));
     return 0;
 }
 

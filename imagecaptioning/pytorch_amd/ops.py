@@ -165,7 +165,7 @@ class DeferredGrads:
     def colsum(self, dy, out):
         _chk(dy, out)
         assert dy.is_contiguous()
-        self.col.append((dy.data_ptr(), out.data_ptr(), dy.shape[0], dy.shape[1], dy.shape[1], 0))
+        self.col.append((dy.data_ptr(), out.data_ptr(), 0, dy.shape[0], dy.shape[1], dy.shape[1], 0))
         self.keep.append(dy)               # read at flush()
 
     def _table(self, name, rows, fmt):
@@ -184,7 +184,7 @@ class DeferredGrads:
             t = self._table('red', self.red, '<QQQiiiiii')
             check(lib.capmi_splitk_reduce_batch(t.data_ptr(), len(self.red), stream_ptr()), 'capmi_splitk_reduce_batch')
         if self.col:
-            t = self._table('col', self.col, '<QQiiii')
+            t = self._table('col', self.col, '<QQQiiii')
             check(lib.capmi_colsum_batch(t.data_ptr(), len(self.col), stream_ptr()), 'capmi_colsum_batch')
         self.red, self.col, self.keep = [], [], []
 

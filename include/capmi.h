@@ -311,9 +311,13 @@ int capmi_colsum(const float *in, int rows, int cols, int ld, float *out, int ac
 typedef struct capmi_colsum_item {
     const float *in;
     float *out;
+    float *out2;                 /* optional second copy of the result (nn.LSTMCell's bias_hh gradient = bias_ih's) */
     int32_t rows, cols, ld, accumulate;
 } capmi_colsum_item;
 int capmi_colsum_batch(const capmi_colsum_item *items, int n_items, void *stream);
+/* the same with the items in HOST memory (<= CAPMI_COLSUM_ARGS_MAX of them, passed to the kernel by value) */
+#define CAPMI_COLSUM_ARGS_MAX 8
+int capmi_colsum_batch_args(const capmi_colsum_item *host_items, int n_items, void *stream);
 /* out[g, c] = sum_{j<group} in[(g*group + j)*cols + c], summed over T slabs of stride slab */
 int capmi_group_rowsum(const float *in, int T, int64_t slab, int groups, int group, int cols,
                        float *out, void *stream);
