@@ -59,7 +59,7 @@ def decode_image(att_dir, fc_dir, img_id, use_fc, norm_att_feat):
 
 
 class FeatureLoader:
-    def __init__(self, opt, workers=4, processes=None):
+    def __init__(self, opt, workers=4, processes=None, lookahead=3):
         """workers: size of the decode pool; processes: worker PROCESSES instead of threads (default: CAPMI_LOADER_PROCS=1).
         np.load of a compressed .npz holds the GIL for most of its time: threads top out at ~400 images/s of 36 x 2048
         features whatever their number, N processes scale to ~N x 400 (scripts/loader_bench.py)."""
@@ -86,7 +86,10 @@ class FeatureLoader:
                 self.split_ix[sp].append(ix)
             elif getattr(opt, 'train_only', 0) == 0:            # restval
                 self.split_ix['train'].append(ix)
-        self.rng = random.Random(getattr(opt, 'seed', 1234))
+        self.rng = random.Random(getattr(opt, 'seed', 1234))                  # epoch order
+        self.cap_rng = random.Random(getattr(opt, 'seed', 1234) + 7919)       # which captions of an image (own stream: the
+        #                                                                       order RNG is drawn `lookahead` batches ahead)
+        self.lookahead = max(1, int(lookahead))
         self.order = {k: list(v) for k, v in self.split_ix.items()}
         self.rng.shuffle(self.order['train'])                  # MySampler shuffles the train split (dataloader.py:394-397)
         self.pos = {'train': 0, 'val': 0, 'test': 0}
@@ -162,7 +165,7 @@ class FeatureLoader:
         masks = np.zeros((B, n, L + 2), dtype=np.float32)
         gts, infos = [], []
         for b, ix in enumerate(idx):
-            seq = self._captions(ix, self.rng)
+            seq = self._captions(ix, self.cap_rng)
             labels[b, :, 1:L + 1] = seq
             for j in range(n):
                 masks[b, j, :int((seq[j] != 0).sum()) + 2] = 1
@@ -174,9 +177,10 @@ class FeatureLoader:
     def get_batch(self, split, batch_size=None):
         B = batch_size or self.batch_size
         key = (split, B)
-        job = self._pending.pop(key, None) or self._schedule(split, B)
-        self._pending[key] = self._schedule(split, B)          # decode the NEXT batch's features in the background
-        idx, wrapped, pos_now, futs = job
+        q = self._pending.setdefault(key, [])
+        while len(q) < self.lookahead + 1:                     # decode the NEXT batches' features in the background
+            q.append(self._schedule(split, B))
+        idx, wrapped, pos_now, futs = q.pop(0)
         feats = [f.result() for f in futs]
         F = feats[0][1].shape[1]
         kmax = max(a.shape[0] for _, a in feats)

@@ -90,9 +90,10 @@ class ResidentFeatures:
         ld = self.loader
         B = batch_size or ld.batch_size
         key = (split, B)
-        job = self._pending.pop(key, None) or self._schedule(split, B)
-        self._pending[key] = self._schedule(split, B)          # decode the NEXT batch's new images in the background
-        idx, wrapped, pos_now, futs = job
+        q = self._pending.setdefault(key, [])
+        while len(q) < ld.lookahead + 1:                       # decode the NEXT batches' new images in the background
+            q.append(self._schedule(split, B))
+        idx, wrapped, pos_now, futs = q.pop(0)
         new, seen = [], set()
         for ix in idx:
             if ix in self.slot:
