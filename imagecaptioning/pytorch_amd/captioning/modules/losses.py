@@ -76,7 +76,14 @@ class LabelSmoothing(nn.Module):
 
 
 class StructureLosses(nn.Module):
-    """losses.py:40-202, 'new_self_critical' branch (168-187) only -- the one the *_nsc configs use."""
+    """losses.py:40-202.  Every ``structure_loss_type`` whose input is log-probabilities: 'new_self_critical' (168-187, the one
+    the *_nsc BASELINE configs use), 'seqnll' (81-88), 'risk' (89-103), 'softmax_margin' (147-155), 'best_of_n' (189-199), with
+    the optional ``entropy_reward_weight`` (66-69).  All of them only read the log-probabilities of the sampled tokens, so the
+    gradient stays sparse (``select_logp``).  The margin types that take RAW LOGITS ('max_margin', 'multi_margin',
+    'real_softmax_margin': sampled with output_logsoftmax=0, loss_wrapper.py:31-37) and the self-CIDEr reward are not
+    implemented: the rollouts always emit log-softmax."""
+
+    LOGPROB_TYPES = ('new_self_critical', 'seqnll', 'risk', 'softmax_margin', 'best_of_n')
 
     def __init__(self, opt):
         super().__init__()
@@ -84,24 +91,49 @@ class StructureLosses(nn.Module):
         self.loss_type = opt.structure_loss_type
 
     def forward(self, input, seq, data_gts, reduction='mean'):
-        if self.loss_type != 'new_self_critical':
-            raise NotImplementedError('structure_loss_type %r is outside the BASELINE configs' % self.loss_type)
-        if getattr(self.opt, 'entropy_reward_weight', 0) > 0 or getattr(self.opt, 'self_cider_reward_weight', 0) > 0:
-            raise NotImplementedError('entropy / self-cider rewards default to 0 and are out of scope')
+        if self.loss_type not in self.LOGPROB_TYPES:
+            raise NotImplementedError('structure_loss_type %r takes raw logits (output_logsoftmax=0 rollouts): only %s are '
+                                      'implemented' % (self.loss_type, ', '.join(self.LOGPROB_TYPES)))
+        if getattr(self.opt, 'self_cider_reward_weight', 0) > 0:
+            raise NotImplementedError('self_cider_reward_weight (get_self_cider_scores, rewards.py:116-137) is out of scope')
         out = {}
         N = input.size(0)
         n = N // len(data_gts)
         assert n == self.opt.train_sample_n, n
+        ew = getattr(self.opt, 'entropy_reward_weight', 0)
+        ent = None
+        if ew > 0:                      # mean per-token entropy of each sampled sequence, no gradient (:66-69); needs the dense rows
+            with torch.no_grad():
+                lp = torch.log_softmax(input.detach(), 2)
+                ent = -(lp.exp() * lp).sum(2)
         sel = select_logp(input, seq)
         mask = _shifted_mask(seq, sel)
-        scores = get_scores(data_gts, seq, self.opt, as_tensor=True).to(sel).view(-1, n)
+        scores = get_scores(data_gts, seq, self.opt, as_tensor=True)
+        scores = (scores if torch.is_tensor(scores) else torch.as_tensor(scores)).to(sel).view(-1, n)
         out['reward'] = scores
-        baseline = (scores.sum(1, keepdim=True) - scores) / (scores.shape[1] - 1)
-        adv = scores - baseline
-        output = -sel * mask * adv.reshape(-1, 1)
-        if reduction == 'none':
-            output = output.sum(1) / mask.sum(1)
+        if ent is not None:
+            scores = scores + ew * ((ent * mask).sum(1) / mask.sum(1)).view(-1, n)
+        lt = self.loss_type
+        if lt in ('new_self_critical', 'best_of_n'):
+            if lt == 'new_self_critical':           # leave-one-out baseline: the mean score of the image's other samples
+                w = scores - (scores.sum(1, keepdim=True) - scores) / (scores.shape[1] - 1)
+            else:                                   # supervise only the best-scoring sample(s) of each image
+                w = (scores == scores.max(1, keepdim=True)[0]).to(sel)
+            output = -sel * mask * w.reshape(-1, 1)
+            output = output.sum(1) / mask.sum(1) if reduction == 'none' else output.sum() / mask.sum()
         else:
-            output = output.sum() / mask.sum()
+            costs = -scores
+            if lt in ('risk', 'softmax_margin'):     # rescale the costs of each image to [0, 1]
+                costs = costs - costs.min(1, keepdim=True)[0]
+                costs = costs / costs.max(1, keepdim=True)[0]
+            tot = (sel * mask).sum(1)
+            if lt == 'risk':                         # expected cost under softmax(exp(sequence log-prob)) over the n samples
+                assert reduction == 'mean'
+                output = (torch.softmax(tot.view(-1, n).exp(), 1) * costs).sum(1).mean()
+            else:                                    # cross-entropy towards the cheapest sample of each image
+                avg = (tot / mask.sum(1)).view(-1, n)
+                if lt == 'softmax_margin':
+                    avg = avg + costs
+                output = nn.functional.cross_entropy(avg, costs.min(1)[1], reduction=reduction)
         out['loss'] = output
         return out

@@ -518,6 +518,68 @@ def main_rewards():
     print('rewards_callsite.npz:', len(out), 'arrays; reward range', float(out['reward_w1'].min()), float(out['reward_w1'].max()))
 
 
+def main_struct():
+    """StructureLosses fixture (losses.py:40-202): the REAL reference ``captioning/modules/losses.StructureLosses`` run on
+    a small log-softmax tensor for every ``structure_loss_type`` whose input is log-probabilities (seqnll, risk, softmax_margin,
+    new_self_critical, best_of_n; the *margin types that take raw logits need output_logsoftmax=0 rollouts and stay out of
+    scope), with and without ``entropy_reward_weight``, reductions 'mean' and 'none' where the reference supports them.  The
+    scores come from an injected ``get_scores`` (CIDEr-D is pinned elsewhere).  Stored: loss and d loss / d input."""
+    sys.path.insert(0, REF)
+    import argparse
+    import torch
+    import captioning.modules.losses as RL
+    B, n, L, V1 = 4, 3, 6, 11
+    N = B * n
+    g = torch.Generator().manual_seed(314)
+    logits = torch.randn(N, L, V1, generator=g, dtype=torch.float64)
+    seq = torch.randint(1, V1, (N, L), generator=g)
+    for r, ln in enumerate([6, 3, 1, 0, 5, 2, 6, 4, 1, 3, 2, 5]):       # ragged: EOS at step 0, no EOS at all, ...
+        seq[r, ln:] = 0
+    scores = torch.rand(N, generator=g, dtype=torch.float64).numpy()
+    scores[3:6] = scores[3]                                                # an image whose samples all score the same
+    out = {'logits': logits.numpy(), 'seq': seq.numpy(), 'scores': scores, 'B': B, 'n': n}
+    RL.get_scores = lambda data_gts, gen_result, opt: scores.copy()
+    for lt in ('seqnll', 'risk', 'softmax_margin', 'new_self_critical', 'best_of_n'):
+        for ew in (0.0, 0.3):
+            for red in ('mean', 'none'):
+                if red == 'none' and lt == 'risk':
+                    continue                                               # the reference asserts reduction == 'mean'
+                if lt == 'risk' and ew == 0.0:
+                    continue                                               # 0/0: an image with equal scores makes costs nan
+                opt = argparse.Namespace(structure_loss_type=lt, train_sample_n=n, entropy_reward_weight=ew,
+                                         self_cider_reward_weight=0)
+                x = torch.log_softmax(logits.clone(), 2).requires_grad_(True)
+                import contextlib
+                import io
+                with contextlib.redirect_stdout(io.StringIO()), warnings_off():
+                    o = RL.StructureLosses(opt)(x, seq, [None] * B, reduction=red)
+                loss = o['loss']
+                w = torch.linspace(0.5, 1.5, loss.numel(), dtype=torch.float64).view_as(loss) if red == 'none' else None
+                (loss if w is None else (loss * w).sum()).backward()
+                key = '%s_e%d_%s' % (lt, int(ew * 10), red)
+                out[key + '_loss'] = loss.detach().numpy()
+                out[key + '_grad'] = x.grad.numpy()
+                out[key + '_reward'] = o['reward'].numpy()
+    np.savez_compressed(os.path.join(HERE, 'structure_losses.npz'), **out)
+    print('wrote structure_losses.npz with', len(out), 'arrays')
+
+
+def warnings_off():
+    import warnings
+    c = warnings.catch_warnings()
+    c.__enter__()
+    warnings.simplefilter('ignore')
+
+    class _X:
+        def __enter__(self_):
+            return None
+
+        def __exit__(self_, *a):
+            c.__exit__(*a)
+            return False
+    return _X()
+
+
 def main_full():
     """BASELINE-size gradient fixtures: too slow for the GPU test run (minutes of CPU backward), so
     they are computed here once and stored compactly -- per parameter the gradient's L2 norm and a fixed 256-element probe
@@ -581,7 +643,9 @@ def main_full():
 
 
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'full':
+    if len(sys.argv) > 1 and sys.argv[1] == 'struct':
+        main_struct()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'full':
         main_full()
     elif len(sys.argv) > 1 and sys.argv[1] == 'rewards':
         main_rewards()

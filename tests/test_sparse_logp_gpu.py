@@ -277,3 +277,38 @@ def test_dropout_masks_one_launch_equals_four_and_eval_rows():
         assert set(m.unique().tolist()) <= {0.0, 2.0}
     ev = ops.dropout_masks([(shapes[2][0], shapes[2][1], 6, DEV)], p, seed)[0]
     assert torch.equal(ev[:, :6], one[2][:, :6]) and bool((ev[:, 6:] == 1).all())
+
+
+@pytest.mark.parametrize('loss_type,ew', [('seqnll', 0.0), ('softmax_margin', 0.0), ('risk', 0.2), ('best_of_n', 0.0),
+                                          ('new_self_critical', 0.2)])
+def test_structure_loss_types_sparse_route_equals_dense_route(loss_type, ew):
+    """Every log-probability StructureLosses type (losses.py:40-202; values pinned to the reference class on CPU by
+    tests/test_structure_losses.py) on a sampled UpDown rollout: the loss only reads the sampled tokens' log-probabilities, so
+    its gradient reaches the rollout backward in sparse form -- same loss and parameter gradients as the dense autograd route
+    (the entropy reward reads the dense rows without gradient)."""
+    import argparse
+    from test_model_api_gpu import golden_model
+    from imagecaptioning.pytorch_amd.captioning.modules import losses as L
+    z, model = golden_model(True)
+    model.train()
+    fc, att, am = (torch.from_numpy(z[k]).to(DEV) for k in ('fc', 'att', 'att_masks'))
+    forced = torch.from_numpy(z['sample_seq']).to(DEV)
+    N = forced.shape[0]
+    scores = torch.linspace(0.1, 0.9, N, dtype=torch.float64).flip(0).to(DEV) ** 2
+    opt = argparse.Namespace(structure_loss_type=loss_type, train_sample_n=2, entropy_reward_weight=ew, self_cider_reward_weight=0)
+    saved = L.get_scores
+    L.get_scores = lambda data_gts, gen_result, o, as_tensor=False: scores.clone()
+
+    def run(dense_route):
+        model.zero_grad()
+        seq, logp = model(fc, att, am, opt={'sample_method': 'sample', 'sample_n': 2, '_forced_seq': forced}, mode='sample')
+        out = L.StructureLosses(opt)(logp * 1.0 if dense_route else logp, seq, [None] * (N // 2))
+        out['loss'].backward()
+        return out['loss'].item(), _grads(model)
+    try:
+        l0, g0 = run(False)
+        l1, g1 = run(True)
+    finally:
+        L.get_scores = saved
+    assert np.isfinite(l0) and abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0))
+    _check_same(g0, g1)
