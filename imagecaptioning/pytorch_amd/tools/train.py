@@ -133,8 +133,15 @@ def train(opt):
         data = loader.get_batch('train')
         fc, att, labels, masks, att_masks = (data[k] for k in ('fc_feats', 'att_feats', 'labels', 'masks', 'att_masks'))
         t1 = time.time()
-        out = lw_model(fc, att, labels, masks, att_masks, data['gts'], torch.arange(len(data['gts'])), sc_flag, struc_flag, False)
-        loss = out['loss'].mean()
+        # tools/train.py:160-165, 187-191: after drop_worst_after the rows with the highest loss are left out of the mean
+        drop_worst_flag = opt.drop_worst_after != -1 and epoch >= opt.drop_worst_after
+        out = lw_model(fc, att, labels, masks, att_masks, data['gts'], torch.arange(len(data['gts'])), sc_flag, struc_flag,
+                       drop_worst_flag)
+        if not drop_worst_flag:
+            loss = out['loss'].mean()
+        else:
+            rows = out['loss']
+            loss = torch.topk(rows, k=int(rows.shape[0] * (1 - opt.drop_worst_rate)), largest=False)[0].mean()
         flat.zero_grad()
         two = struc_flag and 0 < opt.structure_loss_weight < 1                # XE + structure rollouts: two native backwards
         flat.expect_backwards(2 if two else 1)

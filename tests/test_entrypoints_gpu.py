@@ -178,3 +178,30 @@ def test_train_with_scheduled_sampling(tmp_path):
     loss = T.train(opt)
     assert loss == loss
     assert opt.ss_prob == pytest.approx(0.5)             # min(0.2 * 4, 0.5) at epoch 4
+
+
+def test_train_drop_worst_xe_and_scst(tmp_path):
+    """tools/train.py:160-165, 187-191: from drop_worst_after on, LossWrapper returns one loss per caption row (reduction 'none')
+    and the rows with the highest loss are left out of the mean -- XE epochs first, then self-critical ones."""
+    sys.path.insert(0, PKG)
+    from imagecaptioning.pytorch_amd.tools import train as T
+    from captioning.modules import loss_wrapper as LW
+    small = ['--caption_model', 'updown', '--rnn_size', '32', '--input_encoding_size', '32', '--att_hid_size', '16', '--fc_feat_size', '24',
+             '--att_feat_size', '24', '--vocab_size', '40', '--synthetic_regions', '5', '--seq_length', '6', '--max_length', '6',
+             '--batch_size', '4', '--seq_per_img', '2', '--synthetic_images', '8', '--checkpoint_path', str(tmp_path),
+             '--drop_worst_after', '1', '--drop_worst_rate', '0.25', '--self_critical_after', '2', '--train_sample_n', '2']
+    seen = []
+    orig = LW.LossWrapper.forward
+
+    def spy(self, *a):
+        out = orig(self, *a)
+        seen.append((a[-1], tuple(out['loss'].shape)))      # (drop_worst_flag, loss shape)
+        return out
+    LW.LossWrapper.forward = spy
+    try:
+        loss = T.train(_opts(small + ['--max_iters', '8']))          # 2 iterations per epoch -> epochs 0..3
+    finally:
+        LW.LossWrapper.forward = orig
+    assert loss == loss
+    assert [f for f, _ in seen] == [False, False] + [True] * 6
+    assert all(sh == () for f, sh in seen if not f) and all(sh == (8,) for f, sh in seen if f)       # 4 images x 2 rows
