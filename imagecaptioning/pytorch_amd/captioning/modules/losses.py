@@ -3,6 +3,8 @@ log-prob tensor the model API returns; the arithmetic is a gather + masked mean 
 (K14/K15 of SURVEY.md 2.3) -- device tensor ops on the same HIP stream, no host sync.  The gather goes
 through ``sparse_logp.select_logp``: when the tensor comes from a capmi rollout its gradient travels back
 as [N,L] values + token ids (``capmi_logsoftmax_bwd_sparse``), never as a dense [N,L,V1] tensor."""
+import math
+
 import torch
 import torch.nn as nn
 
@@ -66,8 +68,8 @@ class LabelSmoothing(nn.Module):
         mask = mask[:, :T].reshape(-1).to(input)
         off = self.smoothing / (V1 - 1)
         # sum_v q log q is a constant of (smoothing, V1); -sum_v q logp = -off*sum(lp) - (conf-off)*lp[target]
-        ent = (V1 - 1) * (off * torch.log(torch.tensor(off)) if off > 0 else 0.0) + \
-              (self.confidence * torch.log(torch.tensor(self.confidence)) if self.confidence > 0 else 0.0)
+        ent = (V1 - 1) * (off * math.log(off) if off > 0 else 0.0) + \
+              (self.confidence * math.log(self.confidence) if self.confidence > 0 else 0.0)
         cross = off * sum_logp(input).reshape(-1) + (self.confidence - off) * select_logp(input, tgt2.contiguous()).reshape(-1)
         out = (ent - cross) * mask
         if reduction == 'none':

@@ -564,6 +564,44 @@ def main_struct():
     print('wrote structure_losses.npz with', len(out), 'arrays')
 
 
+def main_crit():
+    """Criterion fixture (losses.py:18-37, 204-265): the REAL reference RewardCriterion, LanguageModelCriterion and
+    LabelSmoothing(0.2) on one small log-softmax tensor, reductions 'mean' and 'none' (the drop_worst path, train.py:187-191),
+    3-D [B, n, T] targets for the language criteria, targets / masks longer than the input (truncated by the reference),
+    all-padding rows excluded.  Stored: loss and d loss / d input."""
+    sys.path.insert(0, REF)
+    import torch
+    import captioning.modules.losses as RL
+    B, n, T, V1 = 3, 2, 7, 13
+    N = B * n
+    g = torch.Generator().manual_seed(2718)
+    logits = torch.randn(N, T, V1, generator=g, dtype=torch.float64)
+    tgt = torch.randint(1, V1, (B, n, T + 2), generator=g)
+    mask = torch.zeros(B, n, T + 2, dtype=torch.float64)
+    for r, ln in enumerate([7, 4, 2, 6, 1, 5]):
+        tgt.view(N, -1)[r, ln:] = 0
+        mask.view(N, -1)[r, :ln + 1] = 1
+    seq = torch.randint(1, V1, (N, T), generator=g)
+    for r, ln in enumerate([7, 0, 3, 5, 1, 6]):
+        seq[r, ln:] = 0
+    reward = torch.randn(N, 1, generator=g, dtype=torch.float64).expand(N, T).contiguous()
+    out = {'logits': logits.numpy(), 'target': tgt.numpy(), 'mask': mask.numpy(), 'seq': seq.numpy(), 'reward': reward.numpy()}
+    crits = {'lm': (RL.LanguageModelCriterion(), lambda c, x, red: c(x, tgt, mask, reduction=red)),
+             'ls': (RL.LabelSmoothing(smoothing=0.2), lambda c, x, red: c(x, tgt.view(N, -1), mask.view(N, -1), reduction=red)),
+             'rl': (RL.RewardCriterion(), lambda c, x, red: c(x, seq, reward, reduction=red))}
+    with warnings_off():
+        for name, (c, call) in crits.items():
+            for red in ('mean', 'none'):
+                x = torch.log_softmax(logits.clone(), 2).requires_grad_(True)
+                loss = call(c, x, red)
+                w = torch.linspace(0.5, 1.5, loss.numel(), dtype=torch.float64).view_as(loss) if red == 'none' else None
+                (loss if w is None else (loss * w).sum()).backward()
+                out['%s_%s_loss' % (name, red)] = loss.detach().numpy()
+                out['%s_%s_grad' % (name, red)] = x.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, 'criteria.npz'), **out)
+    print('wrote criteria.npz with', len(out), 'arrays')
+
+
 def warnings_off():
     import warnings
     c = warnings.catch_warnings()
@@ -645,6 +683,8 @@ def main_full():
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'struct':
         main_struct()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'crit':
+        main_crit()
     elif len(sys.argv) > 1 and sys.argv[1] == 'full':
         main_full()
     elif len(sys.argv) > 1 and sys.argv[1] == 'rewards':

@@ -52,3 +52,29 @@ def test_cases_cover_every_logprob_type_and_logit_types_are_refused():
         crit = L.StructureLosses(argparse.Namespace(structure_loss_type=lt, train_sample_n=2))
         with pytest.raises(NotImplementedError, match='raw logits'):
             crit(torch.zeros(2, 3, 4), torch.ones(2, 3, dtype=torch.long), [None])
+
+
+CRIT = np.load(os.path.join(ROOT, 'tests', 'golden', 'criteria.npz'))
+
+
+@pytest.mark.parametrize('name', ['lm', 'ls', 'rl'])
+@pytest.mark.parametrize('red', ['mean', 'none'])
+def test_criteria_match_the_reference_classes(name, red):
+    """RewardCriterion / LanguageModelCriterion / LabelSmoothing(0.2) (losses.py:18-37, 204-265) against the reference classes'
+    own outputs (tests/golden/criteria.npz, ``make_golden.py crit``): both reductions (``'none'`` feeds drop_worst,
+    train.py:187-191), [B, n, T] targets, targets and masks longer than the input, loss and dense gradient."""
+    from captioning.modules import losses as L
+    x = torch.log_softmax(torch.from_numpy(CRIT['logits']), 2).requires_grad_(True)
+    tgt, mask = torch.from_numpy(CRIT['target']), torch.from_numpy(CRIT['mask'])
+    N = x.shape[0]
+    if name == 'lm':
+        loss = L.LanguageModelCriterion()(x, tgt, mask, reduction=red)
+    elif name == 'ls':
+        loss = L.LabelSmoothing(smoothing=0.2)(x, tgt.view(N, -1), mask.view(N, -1), reduction=red)
+    else:
+        loss = L.RewardCriterion()(x, torch.from_numpy(CRIT['seq']), torch.from_numpy(CRIT['reward']), reduction=red)
+    ref = torch.from_numpy(CRIT['%s_%s_loss' % (name, red)])
+    assert loss.shape == ref.shape and torch.allclose(loss, ref, rtol=1e-10, atol=1e-12), (loss, ref)
+    w = torch.linspace(0.5, 1.5, loss.numel(), dtype=torch.float64).view_as(loss) if red == 'none' else None
+    (loss if w is None else (loss * w).sum()).backward()
+    assert torch.allclose(x.grad, torch.from_numpy(CRIT['%s_%s_grad' % (name, red)]), rtol=1e-9, atol=1e-12)
