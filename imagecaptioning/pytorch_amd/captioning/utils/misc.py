@@ -5,8 +5,14 @@ import pickle
 import torch
 
 
+# misc.py:17-18 (the post-processing list of decode_sequence; the decode-time constraint uses AttModel's own list)
+DECODE_BAD_ENDINGS = frozenset(['with', 'in', 'on', 'of', 'a', 'at', 'to', 'for', 'an', 'this', 'his', 'her', 'that', 'the'])
+
+
 def decode_sequence(ix_to_word, seq):
-    """misc.py:62-84: token rows -> strings, stop at the first 0."""
+    """misc.py:62-84: token rows -> strings, stop at the first 0; with REMOVE_BAD_ENDINGS=1 in the environment the trailing
+    run of function words is cut (unless the caption consists of nothing else); BPE continuation marks '@@ ' are joined."""
+    strip = bool(int(os.getenv('REMOVE_BAD_ENDINGS', '0')))
     out = []
     for row in seq.tolist():
         words = []
@@ -14,7 +20,13 @@ def decode_sequence(ix_to_word, seq):
             if ix <= 0:
                 break
             words.append(ix_to_word[str(ix)])
-        out.append(' '.join(words))
+        if strip:
+            tail = 0
+            while tail < len(words) and words[-1 - tail] in DECODE_BAD_ENDINGS:
+                tail += 1
+            if tail < len(words):
+                words = words[:len(words) - tail]
+        out.append(' '.join(words).replace('@@ ', ''))
     return out
 
 

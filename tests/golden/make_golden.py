@@ -602,6 +602,42 @@ def main_crit():
     print('wrote criteria.npz with', len(out), 'arrays')
 
 
+def main_misc():
+    """Host helpers of captioning/utils/misc.py that the hot path's callers use, run from the REAL reference module:
+    decode_sequence (:62-84, with and without REMOVE_BAD_ENDINGS, BPE '@@ ' joins), penalty_builder (:133-157: '', wu_a, avg_a),
+    NoamOpt.rate (:160-199)."""
+    sys.path.insert(0, REF)
+    import torch
+    import captioning.utils.misc as M
+    words = ['a', 'dog', 'sits', 'on', 'the', 'mat', 'with', 'un@@', 'happy', 'of', 'an', 'cat', 'his', 'that', 'red']
+    ix_to_word = {str(i + 1): w for i, w in enumerate(words)}
+    seq = torch.tensor([[2, 3, 4, 5, 6, 0, 0, 0],          # plain
+                        [1, 2, 3, 4, 5, 0, 9, 9],          # ends on 'on the': two bad endings to strip; junk after the 0
+                        [8, 9, 12, 7, 10, 11, 0, 0],       # BPE join + 'with of an' tail
+                        [4, 5, 7, 0, 0, 0, 0, 0],          # ONLY bad endings
+                        [0, 1, 2, 3, 0, 0, 0, 0],          # empty
+                        [12, 15, 14, 13, 1, 5, 10, 11]])   # no terminator, 5 bad endings at the end
+    out = {'seq': seq.numpy(), 'words': np.array(words)}
+    for env in ('0', '1'):
+        os.environ['REMOVE_BAD_ENDINGS'] = env
+        out['decoded_%s' % env] = np.array(M.decode_sequence(ix_to_word, seq))
+    os.environ.pop('REMOVE_BAD_ENDINGS')
+    lengths = np.array([1, 2, 5, 9, 16, 20], dtype=np.float64)
+    logps = np.array([-0.3, -1.7, -4.2, -9.9, -13.0, -21.5])
+    for cfg in ('', 'wu_0.7', 'wu_0.0', 'avg_0.0'):
+        f = M.penalty_builder(cfg)
+        out['penalty_%s' % cfg] = np.array([f(float(l), float(y)) for l, y in zip(lengths, logps)])
+    out['pen_lengths'], out['pen_logps'] = lengths, logps
+    lin = torch.nn.Linear(2, 2)
+    for d_model, factor, warmup in ((512, 1.0, 2000), (1024, 2.0, 10000)):
+        no = M.NoamOpt(d_model, factor, warmup, torch.optim.Adam(lin.parameters(), lr=0))
+        steps = [1, 2, 100, warmup - 1, warmup, warmup + 1, 10 * warmup]
+        out['noam_%d_%g_%d' % (d_model, factor, warmup)] = np.array([no.rate(st) for st in steps])
+        out['noam_steps_%d' % warmup] = np.array(steps)
+    np.savez_compressed(os.path.join(HERE, 'misc_helpers.npz'), **out)
+    print('wrote misc_helpers.npz:', list(out['decoded_1']))
+
+
 def warnings_off():
     import warnings
     c = warnings.catch_warnings()
@@ -685,6 +721,8 @@ if __name__ == '__main__':
         main_struct()
     elif len(sys.argv) > 1 and sys.argv[1] == 'crit':
         main_crit()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'misc':
+        main_misc()
     elif len(sys.argv) > 1 and sys.argv[1] == 'full':
         main_full()
     elif len(sys.argv) > 1 and sys.argv[1] == 'rewards':

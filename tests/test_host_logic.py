@@ -147,3 +147,28 @@ def test_parse_sample_method_and_bad_endings():
     assert sorted(m.bad_endings_ix) == [1, 3, 4]
     m.bad_endings_ix = [2]
     assert m.bad_endings_ix == [2]
+
+
+def test_misc_helpers_match_the_reference_module(monkeypatch):
+    """decode_sequence (incl. REMOVE_BAD_ENDINGS and BPE joins), the beam-search length penalties and the Noam rate against
+    outputs of the reference's captioning/utils/misc.py (tests/golden/misc_helpers.npz, ``make_golden.py misc``)."""
+    import numpy as np
+    from imagecaptioning.pytorch_amd import beam
+    misc = _misc()
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'misc_helpers.npz'))
+    ix_to_word = {str(i + 1): str(w) for i, w in enumerate(z['words'])}
+    seq = torch.from_numpy(z['seq'])
+    for env in ('0', '1'):
+        monkeypatch.setenv('REMOVE_BAD_ENDINGS', env)
+        assert misc.decode_sequence(ix_to_word, seq) == [str(s) for s in z['decoded_' + env]]
+    monkeypatch.delenv('REMOVE_BAD_ENDINGS')
+    assert misc.decode_sequence(ix_to_word, seq) == [str(s) for s in z['decoded_0']]
+    for cfg in ('', 'wu_0.7', 'wu_0.0', 'avg_0.0'):
+        f = beam._penalty(cfg)
+        got = [f(float(l), float(y)) for l, y in zip(z['pen_lengths'], z['pen_logps'])]
+        assert np.allclose(got, z['penalty_' + cfg], rtol=1e-12)
+    for d_model, factor, warmup in ((512, 1.0, 2000), (1024, 2.0, 10000)):
+        sched = misc.LRSchedule(argparse.Namespace(noamopt=1, noamopt_factor=factor, noamopt_warmup=warmup, learning_rate=0.0),
+                                model_size=d_model)
+        got = [sched.noam_rate(int(st)) for st in z['noam_steps_%d' % warmup]]
+        assert np.allclose(got, z['noam_%d_%g_%d' % (d_model, factor, warmup)], rtol=1e-12)
