@@ -81,11 +81,11 @@ def eval_split(model, crit, loader, opt):
         loss_sum += loss
         loss_n += 1
         if seq_logp.dim() == 3:
-            mask = (seq > 0).to(seq_logp)
-            mask = torch.cat([mask.new_ones(mask.shape[0], 1), mask[:, :-1]], 1)
-            entropy = -(torch.softmax(seq_logp, 2) * seq_logp).nan_to_num(0.0).sum(2)                          # :173
-            entropy = (entropy * mask).sum(1) / mask.sum(1)
-            perplexity = -(seq_logp.gather(2, seq.unsqueeze(2)).squeeze(2) * mask).sum(1) / mask.sum(1)       # :174
+            # eval_utils.py:173-174: sums over ALL L steps (rows after the end are zero) over (#tokens + 1); the only deviation:
+            # 0 * -inf of a constrained token counts as 0 instead of making the whole caption's entropy NaN
+            steps = (seq > 0).to(seq_logp).sum(1) + 1
+            entropy = -(torch.softmax(seq_logp, 2) * seq_logp).nan_to_num(0.0).sum(2).sum(1) / steps
+            perplexity = -seq_logp.gather(2, seq.unsqueeze(2)).squeeze(2).sum(1) / steps
         else:                                  # _diverse_sample returns the chosen tokens' log-probs only (AttModel.py:449)
             entropy = perplexity = torch.full((seq.shape[0],), float('nan'))
         if opt.beam_size > 1 and getattr(opt, 'verbose_beam', 0):                                              # :177-181
