@@ -89,7 +89,7 @@ def attention_large_batch(dev, B=1024, sets=6, iters=30):
             'cached_avg_launch_us': round(us_cached, 1), 'cached_gbs': round(byts / us_cached / 1e3, 1)}
 
 
-def pmc_traffic():
+def pmc_traffic(instance=False):
     """HBM bytes per decode-GEMM launch from the PMC passes of this same command (FETCH_SIZE and WRITE_SIZE need
     separate rocprofv3 --pmc runs, so they cannot be sampled inside this process): profiles/r0N_pmc_traffic.json,
     written by scripts/tools_pmc_traffic.py with the gfx950 corrections of MI355X_MICROARCH.md.  None if absent."""
@@ -97,7 +97,12 @@ def pmc_traffic():
     for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         try:
             with open(os.path.join(here, 'profiles', name)) as f:
-                return round(json.load(f)['decode_gemm']['traffic_bytes'])
+                d = json.load(f)
+            if instance:       # the dominant kernel instance alone (LSTM-gate / logit GEMMs)
+                for k, v in d['kernels'].items():
+                    if 'gemm_ares_kernel<true, 6, 2, true' in k:
+                        return round(v['fetch_bytes_corrected'] + v['write_bytes'])
+            return round(d['decode_gemm']['traffic_bytes'])
         except (OSError, KeyError, ValueError):
             continue
     return None
@@ -241,7 +246,7 @@ def main():
     for _ in range(args.warmup):
         step()
     lib.capmi_prof_reset()
-    lib.capmi_prof_enable(0 if args.no_prof else ((1 << 0) | (1 << 3)))   # decode GEMM + fused attention, in-dispatch events
+    lib.capmi_prof_enable(0 if args.no_prof else ((1 << 0) | (1 << 3) | (1 << 9)))   # decode GEMMs + fused attention, in-dispatch events
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -269,9 +274,15 @@ def main():
 
     if rank == 0:
         copy_gbs = 0.0 if args.no_prof else measured_copy_gbs(dev)     # kept out of rocprofv3 kernel tables
-        g_ms, g_n, g_bytes, g_flops = prof_read(lib, 0)
+        # the dominant kernel = ONE instance, gemm_ares_kernel<true,6,2,x3>: the decode-step GEMMs that stream >= 16 MB of weights
+        # (2 LSTM gate GEMMs + the logit GEMM per step; class 9).  The small decode GEMMs (h2att, prepare: class 0) are latency-
+        # bound launches of the same template family and are reported together with it under `all_decode_gemms`.
+        s_ms, s_n, s_bytes, s_flops = prof_read(lib, 0)
+        g_ms, g_n, g_bytes, g_flops = prof_read(lib, 9)
+        all_ms, all_n, all_bytes = s_ms + g_ms, s_n + g_n, s_bytes + g_bytes
         a_ms, a_n, a_bytes, _ = prof_read(lib, 3)
-        per_class = {'gemm_decode': {'ms_per_step': round(g_ms / args.steps, 4), 'launches_per_step': g_n / args.steps},
+        per_class = {'gemm_decode_stream': {'ms_per_step': round(g_ms / args.steps, 4), 'launches_per_step': g_n / args.steps},
+                     'gemm_decode_small': {'ms_per_step': round(s_ms / args.steps, 4), 'launches_per_step': s_n / args.steps},
                      'attention_fwd': {'ms_per_step': round(a_ms / args.steps, 4), 'launches_per_step': a_n / args.steps},
                      'note': 'full per-kernel table: profiles/r02*_scst_kernel_stats.md (rocprofv3 --kernel-trace --stats)'}
         ach = (g_bytes / g_n) / (g_ms / g_n * 1e-3) / 1e9 if g_n else 0.0
@@ -284,19 +295,28 @@ def main():
         mfma_peak = MFMA_BF16_PEAK_TFLOPS / 6.0 if x3 else MFMA_F32_PEAK_TFLOPS
         ai = g_flops / g_bytes if g_bytes else 0.0
         mfma_bound = ai > mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
-        roofline = {'kernel': 'gemm_ares (decode-step weight streaming, M<=64, activations resident in LDS, %s)'
+        all_ach = (all_bytes / all_n) / (all_ms / all_n * 1e-3) / 1e9 if all_n else 0.0
+        roofline = {'kernel': 'gemm_ares_kernel<true,6,2,x3> (LSTM-gate / logit GEMMs of the decode step: weight streaming, M<=64, '
+                              'activations resident in LDS, %s)'
                               % ('fp32 via exact bf16x3 split, v_mfma_f32_32x32x16_bf16' if x3 else 'v_mfma_f32_32x32x2_f32'),
+                    'launches_per_step': g_n / args.steps,
                     'bound': 'mfma' if mfma_bound else 'hbm',
                     'achieved': round(tfl if mfma_bound else ach, 2),
                     'peak': round(mfma_peak, 1) if mfma_bound else HBM_PEAK_GBS,
                     'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
                     'frac': round(tfl / mfma_peak if mfma_bound else ach / HBM_PEAK_GBS, 4),
-                    'traffic': pmc_traffic(), 'hbm_copy_measured_gbs': round(copy_gbs, 1),
+                    'traffic': pmc_traffic(instance=True), 'hbm_copy_measured_gbs': round(copy_gbs, 1),
                     'hbm_frac_of_measured_copy': round(ach / copy_gbs, 4) if copy_gbs else None, 'avg_launch_us': round(g_ms / max(g_n, 1) * 1e3, 2),
                     'algorithmic_bytes_per_launch': round(g_bytes / max(g_n, 1)),
                     'algorithmic_flops_per_launch': round(g_flops / max(g_n, 1)),
                     'flop_per_byte': round(ai, 2), 'hbm_gbs': round(ach, 1), 'hbm_frac': round(ach / HBM_PEAK_GBS, 4),
-                    'mfma_tflops': round(tfl, 2), 'mfma_frac': round(tfl / mfma_peak, 4), 'mfma_peak_tflops': round(mfma_peak, 1)}
+                    'mfma_tflops': round(tfl, 2), 'mfma_frac': round(tfl / mfma_peak, 4), 'mfma_peak_tflops': round(mfma_peak, 1),
+                    'all_decode_gemms': {'launches_per_step': all_n / args.steps, 'avg_launch_us': round(all_ms / max(all_n, 1) * 1e3, 2),
+                                         'algorithmic_bytes_per_launch': round(all_bytes / max(all_n, 1)),
+                                         'achieved': round(all_ach, 1), 'frac': round(all_ach / HBM_PEAK_GBS, 4),
+                                         'traffic': pmc_traffic(),
+                                         'note': 'round-1 definition of this object: the streaming launches above + the '
+                                                 '~22 latency-bound small decode GEMMs (h2att, prepare) per step'}}
         a_ach = (a_bytes / a_n) / (a_ms / a_n * 1e-3) / 1e9 if a_n else 0.0
         attention = {'kernel': 'attention_fwd (fused score+softmax+context, one workgroup per image)', 'bound': 'hbm',
                      'achieved': round(a_ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

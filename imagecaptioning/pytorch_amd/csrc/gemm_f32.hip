@@ -432,8 +432,9 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     }
     const double bytes = 4.0 * (abytes + ksum * d->N + (double)d->M * d->N);
     const double flops = 2.0 * d->M * (double)d->N * ksum;
-    const int pcls = (d->M <= 64 && d->a_layout == 0) ? (d->b_layout == 0 ? CAPMI_PROF_GEMM_DECODE : CAPMI_PROF_GEMM_BPTT)
-                                                       : CAPMI_PROF_GEMM_FAT;
+    int pcls = (d->M <= 64 && d->a_layout == 0) ? (d->b_layout == 0 ? CAPMI_PROF_GEMM_DECODE : CAPMI_PROF_GEMM_BPTT)
+                                                 : CAPMI_PROF_GEMM_FAT;
+    if (pcls == CAPMI_PROF_GEMM_DECODE && bytes >= 16e6) pcls = CAPMI_PROF_GEMM_DECODE_STREAM;
 
     static const int env_path = [] { const char *e = getenv("CAPMI_GEMM_PATH"); return e ? atoi(e) : 0; }();
     static const int env_blocks = [] { const char *e = getenv("CAPMI_GEMM_BLOCKS"); return e ? atoi(e) : 512; }();

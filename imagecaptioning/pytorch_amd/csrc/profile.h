@@ -17,7 +17,9 @@ enum CapmiProfClass {
     CAPMI_PROF_LSTM_CELL = 6,
     CAPMI_PROF_CIDERD = 7,
     CAPMI_PROF_ADAM = 8,
-    CAPMI_PROF_NCLASS = 9
+    CAPMI_PROF_GEMM_DECODE_STREAM = 9,   // the decode-step GEMMs that stream >= 16 MB of weights (LSTM gates, logit): ONE kernel
+                                         // instance, gemm_ares_kernel<true,6,2,x3>, the dominant row of the rocprofv3 table
+    CAPMI_PROF_NCLASS = 10
 };
 
 namespace capmi_prof {
