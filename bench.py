@@ -94,7 +94,7 @@ def pmc_traffic(instance=False):
     separate rocprofv3 --pmc runs, so they cannot be sampled inside this process): profiles/r0N_pmc_traffic.json,
     written by scripts/tools_pmc_traffic.py with the gfx950 corrections of MI355X_MICROARCH.md.  None if absent."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r02k_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         try:
             with open(os.path.join(here, 'profiles', name)) as f:
                 d = json.load(f)
