@@ -140,8 +140,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
-    if world > 1:
+    # CAPMI_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL communicator, flat all-reduce, collective timing) with ONE
+    # rank -- how the N > 1 path is exercised on a 1-GPU box (tests/test_entrypoints_gpu.py); never a measurement
+    multi = world > 1 or os.environ.get('CAPMI_BENCH_FORCE_DIST') == '1'
+    if multi:
         import torch.distributed as dist
+        os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # nccl == RCCL on ROCm (xGMI).  CAPMI_DIST_BACKEND=gloo only exists to exercise the multi-process path on a
         # single-GPU box (two ranks sharing cuda:0), never for measurements.
@@ -164,12 +168,12 @@ def main():
     # Default for N > 1: ONE all-reduce of the whole flat fp32 gradient per step (north_star / SURVEY 8e).
     # CAPMI_DDP_OVERLAP=1 opts into the bucketed variant (6 collectives launched from inside the backward as the phases finish
     # their gradients, clip+Adam pipelined behind them).
-    overlap = world > 1 and os.environ.get('CAPMI_DDP_OVERLAP', '0') == '1'
+    overlap = multi and os.environ.get('CAPMI_DDP_OVERLAP', '0') == '1'
     # CAPMI_DDP_MODE=rsag: reduce-scatter -> clip+Adam on the rank's 1/N shard -> all-gather of the parameters
-    sharded = world > 1 and not overlap and os.environ.get('CAPMI_DDP_MODE', 'allreduce') == 'rsag'
+    sharded = multi and not overlap and os.environ.get('CAPMI_DDP_MODE', 'allreduce') == 'rsag'
     if overlap:
         flat.begin_overlap()
-    if world > 1:
+    if multi:
         # a hung collective cannot be caught by try/except: a watchdog thread ends the process group with a diagnostic instead
         # of letting the driver's timeout kill an unexplained run
         import threading
@@ -217,7 +221,7 @@ def main():
             flat.finish_overlap_and_step(**adam)
         elif sharded:
             flat.sharded_step(**adam)
-        elif world > 1:
+        elif multi:
             if nonlocal_ar is not None:
                 nonlocal_ar[0].record()
             scale = flat.all_reduce()
@@ -342,8 +346,8 @@ def main():
                                    'bottom-up feats, R=E=1000 A=512, vocab 9487, seq_len 20, greedy baseline + CIDEr-D + '
                                    'RewardCriterion + BPTT + clip 0.1 + Adam',
                        'global_batch': B * world, 'captions_per_step': B * n * world, 'seq_len': L,
-                       'parallelism': 'dp%d (flat fp32 gradient, %s)' % (world, ('bucketed RCCL all-reduce overlapped with the backward' if overlap else 'one RCCL all-reduce per step') if world > 1 else 'no collective')},
-            'collective': None if world == 1 else {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
+                       'parallelism': 'dp%d (flat fp32 gradient, %s)' % (world, ('bucketed RCCL all-reduce overlapped with the backward' if overlap else 'one RCCL all-reduce per step') if multi else 'no collective')},
+            'collective': None if not multi else {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
                                                    'mode': 'bucketed overlap' if overlap else ('reduce-scatter + sharded Adam + all-gather' if sharded else 'one flat all-reduce per step'),
                                                    'bytes': int(flat.grad.numel() * 4), 'allreduce_ms': None if allreduce_ms is None else round(allreduce_ms, 3)},
             'loss': float(loss.detach()), 'roofline': roofline, 'attention': attention, 'kernel_ms_per_step': per_class,

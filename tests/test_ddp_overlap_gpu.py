@@ -88,3 +88,33 @@ def test_bucketed_overlap_through_native_backward_keeps_ranks_identical():
     # same update as the single flat all-reduce.  The embedding scatter uses fp32 atomics, so gradients agree only up to
     # summation order and Adam (lr 1e-2, 3 steps) magnifies that on near-zero gradients: a loose bound on the parameters
     np.testing.assert_allclose(a[0][0], b[0][0], rtol=1e-3, atol=5e-4)
+
+
+@pytest.mark.parametrize('mode', ['allreduce', 'rsag', 'overlap'])
+def test_bench_multi_gpu_code_path_on_rccl_with_one_rank(mode):
+    """bench.py exactly as the driver launches it for N > 1 (python -m torch.distributed.run ... bench.py --gpus N), with N = 1
+    and CAPMI_BENCH_FORCE_DIST=1: RCCL communicator on this GPU, the flat all-reduce (or reduce-scatter / sharded Adam /
+    all-gather, or the bucketed overlap) on the real 210 MB gradient buffer, barrier-bracketed timing, the `collective` object
+    of the JSON line.  A single rank cannot prove scaling; it proves that the N > 1 path runs on RCCL."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, CAPMI_BENCH_FORCE_DIST='1', CAPMI_BENCH_WATCHDOG_S='150', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('CAPMI_DDP_OVERLAP', None)
+    env.pop('CAPMI_DDP_MODE', None)
+    if mode == 'rsag':
+        env['CAPMI_DDP_MODE'] = 'rsag'
+    if mode == 'overlap':
+        env['CAPMI_DDP_OVERLAP'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '1',
+           '--no-cpu-baseline', '--no-prof']
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=170)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
+    col = line['collective']
+    assert col['backend'] == 'nccl' and col['ranks'] == 1 and col['bytes'] > 200e6
+    assert line['n_gpus'] == 1 and line['value'] > 1000 and np.isfinite(line['loss'])
+    if mode == 'allreduce':
+        assert col['mode'] == 'one flat all-reduce per step' and col['allreduce_ms'] is not None and col['allreduce_ms'] >= 0
