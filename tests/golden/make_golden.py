@@ -638,6 +638,26 @@ def main_misc():
     print('wrote misc_helpers.npz:', list(out['decoded_1']))
 
 
+def main_opts_defaults():
+    """The defaults of every command-line flag of the reference (captioning/utils/opts.py:18-277, parse_opt with an empty
+    command line; ``yacs`` -- only needed for --cfg files -- is stubbed).  tests/test_host_logic.py holds the mirror's DEFAULTS
+    against it."""
+    import json
+    import types
+    m, mc = types.ModuleType('yacs'), types.ModuleType('yacs.config')
+    mc.CfgNode = type('CfgNode', (dict,), {})
+    m.config = mc
+    sys.modules['yacs'], sys.modules['yacs.config'] = m, mc
+    sys.path.insert(0, REF)
+    argv, sys.argv = sys.argv, ['train.py']
+    import captioning.utils.opts as RO
+    ref = vars(RO.parse_opt())
+    sys.argv = argv
+    json.dump({k: v for k, v in sorted(ref.items()) if isinstance(v, (int, float, str, type(None)))},
+              open(os.path.join(HERE, 'opts_defaults.json'), 'w'), indent=0)
+    print('wrote opts_defaults.json with', len(ref), 'flags')
+
+
 def warnings_off():
     import warnings
     c = warnings.catch_warnings()
@@ -723,6 +743,8 @@ if __name__ == '__main__':
         main_crit()
     elif len(sys.argv) > 1 and sys.argv[1] == 'misc':
         main_misc()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'opts_defaults':
+        main_opts_defaults()
     elif len(sys.argv) > 1 and sys.argv[1] == 'full':
         main_full()
     elif len(sys.argv) > 1 and sys.argv[1] == 'rewards':

@@ -172,3 +172,17 @@ def test_misc_helpers_match_the_reference_module(monkeypatch):
                                 model_size=d_model)
         got = [sched.noam_rate(int(st)) for st in z['noam_steps_%d' % warmup]]
         assert np.allclose(got, z['noam_%d_%g_%d' % (d_model, factor, warmup)], rtol=1e-12)
+
+
+def test_option_defaults_are_the_references():
+    """Every flag the mirror's opts.py shares with the reference has the reference's default (tests/golden/opts_defaults.json,
+    ``make_golden.py opts_defaults``), except the deliberate ones: the default model family, paths, logging cadence."""
+    import json
+    from imagecaptioning.pytorch_amd.captioning.utils import opts
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'opts_defaults.json')))
+    deliberate = {'caption_model', 'batch_size', 'checkpoint_path', 'id', 'save_checkpoint_every', 'losses_log_every', 'start_from',
+                  'input_json', 'input_label_h5', 'input_fc_dir', 'input_att_dir'}
+    shared = [k for k in opts.DEFAULTS if k in ref]
+    assert len(shared) > 60
+    wrong = {k: (opts.DEFAULTS[k], ref[k]) for k in shared if k not in deliberate and opts.DEFAULTS[k] != ref[k]}
+    assert not wrong, wrong
