@@ -645,7 +645,8 @@ def main_opts_defaults():
     import json
     import types
     m, mc = types.ModuleType('yacs'), types.ModuleType('yacs.config')
-    mc.CfgNode = type('CfgNode', (dict,), {})
+    mc.CfgNode = type('CfgNode', (dict,), {'__init__': lambda self, *a, **k: dict.__init__(self),
+                                           'merge_from_file': lambda self, *a: None, 'merge_from_list': lambda self, *a: None})
     m.config = mc
     sys.modules['yacs'], sys.modules['yacs.config'] = m, mc
     sys.path.insert(0, REF)
