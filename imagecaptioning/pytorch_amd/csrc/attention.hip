@@ -939,9 +939,18 @@ int capmi_attention_bwd_partial(const float *x_slabs, int x_splits, int64_t x_st
                                 const float *att_h, const float *alpha, const float *p_att, const float *att,
                                 const float *w, float *d_att_h, float *d_e, int B, int n, int K, int A, int R,
                                 const int32_t *row_img, int N, void *stream) {
-    if (!x_slabs || !x_out || x_splits < 1 || x_cols < R || (x_cols & 3) || (x_stride & 3) ||
-        ((reinterpret_cast<uintptr_t>(x_slabs) | reinterpret_cast<uintptr_t>(x_out)) & 15))
-        return CAPMI_EINVAL;
+    if (!x_slabs || !x_out || x_splits < 1 || x_cols < R) return CAPMI_EINVAL;
+    if ((x_cols & 3) || (x_stride & 3) || ((reinterpret_cast<uintptr_t>(x_slabs) | reinterpret_cast<uintptr_t>(x_out)) & 15)) {
+        // sizes the 16-byte slab loads cannot take (hidden size not a multiple of 4, odd row counts): finish the K-slice
+        // reduction with the generic reduce launch, then run the Jacobian on the finished rows
+        const int rows = row_img ? N : B * n;
+        if (x_stride != (int64_t)rows * x_cols) return CAPMI_EINVAL;
+        const int rc = capmi_splitk_reduce(x_slabs, x_splits, x_out, x_cols, rows, x_cols, nullptr, nullptr, nullptr, 1, nullptr, 0,
+                                           0, stream);
+        if (rc) return rc;
+        return attention_bwd_launch(x_out, x_cols, nullptr, 0, 0, 0, nullptr, att_h, alpha, p_att, att, w, d_att_h, d_e, B, n, K, A,
+                                    R, row_img, N, stream);
+    }
     return attention_bwd_launch(x_out, x_cols, x_slabs, x_splits, x_stride, x_cols, x_out, att_h, alpha, p_att, att, w, d_att_h,
                                 d_e, B, n, K, A, R, row_img, N, stream);
 }

@@ -314,3 +314,74 @@ def test_aoa_new_self_critical_step_gradients_vs_oracle():
         if k.endswith('linears.1.bias'):
             continue                                      # attention key bias: mathematically zero gradient
         assert float((p.grad.cpu() - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + floor, k
+
+
+@pytest.mark.parametrize('R,E,A,F,K,V1,B,n,L,masked', [
+    (52, 52, 20, 36, 7, 101, 3, 2, 6, False),        # multiples of 4 but of nothing larger; odd vocabulary and region count
+    (50, 30, 18, 22, 5, 57, 2, 3, 5, True),          # nothing aligned: every vector path falls back to its scalar form
+    (128, 64, 64, 100, 40, 1000, 9, 5, 8, True),     # K = 40: the upper limit of the register-resident attention kernels
+    (64, 48, 32, 40, 41, 333, 4, 4, 7, False),       # K = 41: one region beyond it (the general kernels), 16 caption rows
+    (256, 256, 512, 64, 36, 2048, 13, 5, 4, True),   # 65 caption rows: one more than a 64-row decode tile
+])
+def test_updown_odd_shapes_xe_gradients_and_greedy_tokens_vs_oracle(R, E, A, F, K, V1, B, n, L, masked):
+    """Shape sweep of the UpDown hot path against the oracle run live: sizes that are not multiples of the vector widths / tile
+    sizes, region counts on both sides of the fused attention kernels' register limits, and a row count one past the 64-row
+    decode tile -- teacher-forced log-probs <= 1e-4, every XE gradient <= 1e-3 relative, greedy tokens exact (with and without
+    att_masks)."""
+    from oracle import att_lstm as O
+    from test_model_api_gpu import tiny_opt
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import LanguageModelCriterion
+    P = shapes.full_size_params(seed=R + K, V1=V1, R=R, E=E, A=A, F=F)
+    g = torch.Generator().manual_seed(1000 + R)
+    fc = (torch.randn(B, F, generator=g) * 0.5).clamp_min(0)
+    att = (torch.randn(B, K, F, generator=g) * 0.5).clamp_min(0)
+    am = None
+    if masked:
+        am = (torch.rand(B, K, generator=g) > 0.3).float()
+        am[:, 0] = 1
+        am[0] = 1                                                       # one image with every region valid
+    labels, masks = _labels(B, n, L, V1, seed=R)
+    opt = tiny_opt(vocab_size=V1 - 1, input_encoding_size=E, rnn_size=R, att_hid_size=A, fc_feat_size=F, att_feat_size=F,
+                   seq_length=L, max_length=L, vocab={str(i): 'w%d' % i for i in range(1, V1)})
+    model = models.setup(opt)
+    model.load_state_dict(P)
+    model = model.to(DEV)
+    model.train()                                                       # drop_prob_lm = 0: deterministic
+    d = lambda t: None if t is None else t.to(DEV)                      # noqa: E731
+    logp = model(d(fc), d(att), d(labels[..., :-1]), d(am))
+    Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = O.forward_teacher(Po, fc, att, labels[..., :-1], am)
+    assert float((logp.detach().cpu() - ref.detach()).abs().max()) < 1e-4
+    LanguageModelCriterion()(logp, d(labels[..., 1:]), d(masks[..., 1:])).backward()
+    O.lm_criterion(ref, labels[..., 1:].reshape(B * n, -1), masks[..., 1:].reshape(B * n, -1)).backward()
+    floor = 1e-7 * max(float(p.grad.abs().max()) for p in Po.values())
+    for k, p in model.named_parameters():
+        want = Po[k].grad
+        if k == 'core.attention.alpha_net.bias':
+            continue                                                    # mathematically zero (softmax shift invariance)
+        assert float((p.grad.cpu() - want).abs().max()) <= 1e-3 * float(want.abs().max()) + floor, k
+    model.eval()
+    with torch.no_grad():
+        seq, _ = model(d(fc), d(att), d(am), opt={'sample_method': 'greedy'}, mode='sample')
+        want_seq, _ = O.rollout({k: v.detach() for k, v in Po.items()}, fc, att, am, method='greedy', max_len=L)
+    assert torch.equal(seq.cpu(), want_seq)
+    # sampled rollout (the SCST path: n rows per image, injected Gumbel noise) + RewardCriterion gradients
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import RewardCriterion
+    N = B * n
+    gum = -torch.log(-torch.log(torch.rand(L, N, V1, generator=g).clamp_min(1e-20)))
+    reward = torch.randn(N, 1, generator=g).repeat(1, L)
+    model.train()
+    model.zero_grad()
+    seq, slp = model(d(fc), d(att), d(am), opt={'sample_method': 'sample', 'sample_n': n, '_gumbel': d(gum)}, mode='sample')
+    Ps = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    want_seq, want_lp = O.rollout(Ps, fc, att, am, method='sample', sample_n=n, gumbel=gum, max_len=L)
+    assert torch.equal(seq.cpu(), want_seq)
+    RewardCriterion()(slp, seq, d(reward)).backward()
+    O.reward_criterion(want_lp, want_seq, reward).backward()
+    floor = 1e-7 * max(float(p.grad.abs().max()) for p in Ps.values())
+    for k, p in model.named_parameters():
+        if k == 'core.attention.alpha_net.bias':
+            continue
+        want = Ps[k].grad
+        assert float((p.grad.cpu() - want).abs().max()) <= 1e-3 * float(want.abs().max()) + floor, ('scst', k)
