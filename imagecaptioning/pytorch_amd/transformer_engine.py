@@ -54,6 +54,9 @@ def layernorm_bwd(dy, x, a, mean, inv, dx_accum, d_a=None, d_b=None):
 def mha_fwd(q, k, v, ldkv, Nq, q_per_kv, Tq, Tk, h, mask=None, mask_tq=1, mask_per_q=0, causal=0, q_pos0=0, drop=None,
             want_p=True, kstride=0):
     D = q.shape[-1]
+    if (D // h) % 4:
+        raise NotImplementedError('multi-head attention with head size %d: the kernels move the head dimension in 16-byte pieces '
+                                  '(head size %% 4 == 0; every BASELINE config uses 64 or 128)' % (D // h))
     o = torch.empty(Nq, Tq, D, dtype=_f32, device=q.device)
     p = torch.empty(Nq, h, Tq, Tk, dtype=_f32, device=q.device) if want_p else None
     check(lib.capmi_mha_fwd(_a(q), _a(k), _a(v), ldkv, kstride, ptr(mask), mask_tq, mask_per_q, causal, q_pos0, ptr(drop), ptr(o),

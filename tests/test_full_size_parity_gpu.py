@@ -385,3 +385,95 @@ def test_updown_odd_shapes_xe_gradients_and_greedy_tokens_vs_oracle(R, E, A, F, 
             continue
         want = Ps[k].grad
         assert float((p.grad.cpu() - want).abs().max()) <= 1e-3 * float(want.abs().max()) + floor, ('scst', k)
+
+
+@pytest.mark.parametrize('d,h,dff,nl,K,V1,B,n,L,masked', [
+    (48, 4, 100, 2, 7, 101, 3, 2, 5, False),         # head size 12, odd vocabulary / regions
+    (40, 5, 52, 1, 41, 57, 2, 3, 6, True),           # head size 8, 41 regions, att_masks
+    (96, 2, 36, 3, 36, 777, 4, 1, 9, True),          # head size 48, d_ff < d_model, one caption per image
+])
+def test_transformer_odd_shapes_vs_oracle(d, h, dff, nl, K, V1, B, n, L, masked):
+    """Shape sweep of the Transformer path against oracle/transformer.py run live (sizes away from 512 / 2048 / 8 heads)."""
+    from oracle import transformer as T
+    from imagecaptioning.pytorch_amd import synthetic
+    from imagecaptioning.pytorch_amd.captioning import models
+    F = 44
+    opt = synthetic.updown_opt(caption_model='transformer', input_encoding_size=d, rnn_size=dff, d_model=d, d_ff=dff, N_enc=nl,
+                               N_dec=nl, num_att_heads=h, dropout=0.0, drop_prob_lm=0.0, seq_length=L, max_length=L,
+                               vocab_size=V1 - 1, fc_feat_size=F, att_feat_size=F,
+                               vocab={str(i): 'w%d' % i for i in range(1, V1)})
+    torch.manual_seed(100 + d)
+    model = models.setup(opt).to(DEV)
+    model.train()
+    _, att = shapes.feats(B, K=K, F=F, seed=d)
+    am = None
+    if masked:
+        am = torch.ones(B, K)
+        am[0, K // 2:] = 0
+        am[-1, 1:] = 0                                 # an image with a single valid region
+    labels, masks = _labels(B, n, L, V1, seed=d + 1)
+    _compare_model_with_oracle(
+        model, lambda P: T.forward_teacher(P, att, labels[..., :-1], am, h=h, n_enc=nl, n_dec=nl),
+        lambda P: T.greedy(P, att, am, h=h, n_enc=nl, n_dec=nl, max_len=L), att, am, labels, masks)
+
+
+@pytest.mark.parametrize('R,h,K,V1,B,n,L,masked', [
+    (48, 4, 7, 101, 3, 2, 5, False),
+    (64, 2, 41, 333, 2, 3, 6, True),
+])
+def test_aoa_odd_shapes_vs_oracle(R, h, K, V1, B, n, L, masked):
+    """Shape sweep of the AoA path against oracle/aoa.py run live (eval mode, see test_aoa_baseline_size_vs_oracle)."""
+    from oracle import aoa as A
+    from imagecaptioning.pytorch_amd import synthetic
+    from imagecaptioning.pytorch_amd.captioning import models
+    F = 36
+    opt = synthetic.updown_opt(caption_model='aoa', input_encoding_size=R, rnn_size=R, att_hid_size=R // 2, num_heads=h,
+                               multi_head_scale=1, use_multi_head=2, refine=1, refine_aoa=1, use_ff=0, decoder_type='AoA',
+                               mean_feats=1, ctx_drop=1, dropout_aoa=0.3, num_layers=2, drop_prob_lm=0.0, seq_length=L,
+                               max_length=L, vocab_size=V1 - 1, fc_feat_size=F, att_feat_size=F,
+                               vocab={str(i): 'w%d' % i for i in range(1, V1)})
+    torch.manual_seed(200 + R)
+    model = models.setup(opt).to(DEV)
+    model.eval()
+    _, att = shapes.feats(B, K=K, F=F, seed=R)
+    am = None
+    if masked:
+        am = torch.ones(B, K)
+        am[1, K // 3:] = 0
+    labels, masks = _labels(B, n, L, V1, seed=R + 1)
+    _compare_model_with_oracle(
+        model, lambda P: A.forward_teacher(P, att, labels[..., :-1], am, h=h),
+        lambda P: A.greedy(P, att, am, h=h, max_len=L), att, am, labels, masks)
+
+
+@pytest.mark.parametrize('R,F,V1,B,n,L', [(50, 30, 57, 3, 2, 5), (132, 100, 1001, 13, 5, 7)])
+def test_newfc_odd_shapes_vs_oracle(R, F, V1, B, n, L):
+    """Shape sweep of the NewFC path against oracle/att_lstm.py run live (unaligned hidden size; 65 caption rows)."""
+    from oracle import att_lstm as O
+    from imagecaptioning.pytorch_amd import synthetic
+    from imagecaptioning.pytorch_amd.captioning import models
+    opt = synthetic.updown_opt(caption_model='newfc', input_encoding_size=R, rnn_size=R, drop_prob_lm=0.0, seq_length=L,
+                               max_length=L, vocab_size=V1 - 1, fc_feat_size=F, att_feat_size=F,
+                               vocab={str(i): 'w%d' % i for i in range(1, V1)})
+    torch.manual_seed(300 + R)
+    model = models.setup(opt).to(DEV)
+    model.train()
+    fc, _ = shapes.feats(B, K=1, F=F, seed=R)
+    labels, masks = _labels(B, n, L, V1, seed=R + 2)
+    _compare_model_with_oracle(
+        model, lambda P: O.newfc_forward_teacher(P, fc, labels[..., :-1]),
+        lambda P: O.newfc_rollout_greedy(P, fc, max_len=L), None, None, labels, masks, fc=fc)
+
+
+def test_head_size_not_a_multiple_of_4_is_refused_loudly():
+    """The one size restriction of the Transformer / AoA kernels (16-byte moves along the head dimension): a clear error, never a
+    wrong result."""
+    from imagecaptioning.pytorch_amd import synthetic
+    from imagecaptioning.pytorch_amd.captioning import models
+    opt = synthetic.updown_opt(caption_model='transformer', input_encoding_size=24, rnn_size=40, d_model=24, d_ff=40, N_enc=1,
+                               N_dec=1, num_att_heads=4, dropout=0.0, drop_prob_lm=0.0, seq_length=5, max_length=5, vocab_size=56,
+                               fc_feat_size=44, att_feat_size=44, vocab={str(i): 'w%d' % i for i in range(1, 57)})
+    model = models.setup(opt).to(DEV)
+    _, att = shapes.feats(2, K=7, F=44, seed=1)
+    with pytest.raises(NotImplementedError, match='head size 6'):
+        model(None, att.to(DEV), torch.randint(1, 57, (2, 1, 6), device=DEV), None)
