@@ -152,20 +152,27 @@ def test_scst_step_end_to_end_matches_oracle_reward_and_updates():
     rewards.reset_scorer()
 
 
-def test_fused_scst_rollouts_equal_separate_rollouts():
+@pytest.mark.parametrize('R,E,A,F,K,V,B,n,L', [
+    (16, 16, 12, 20, 6, 30, 5, 3, 8),          # the tiny fixture sizes
+    (50, 30, 18, 22, 5, 56, 2, 3, 5),          # nothing aligned
+    (64, 48, 32, 40, 41, 332, 4, 4, 7),        # 41 regions: beyond the register-resident attention kernels
+    (128, 128, 64, 64, 36, 999, 13, 5, 6),     # 65 sampled + 13 greedy rows: more than one 64-row decode tile
+])
+def test_fused_scst_rollouts_equal_separate_rollouts(R, E, A, F, K, V, B, n, L):
     """The fused (greedy rows riding in the sampled rollout's MFMA tile) pass must reproduce, row for row,
     what the reference's two separate calls produce: greedy tokens of an eval-mode decode and, with the same
-    dropout masks and Gumbel noise, the sampled tokens / log-probs / gradients of a train-mode decode."""
+    dropout masks and Gumbel noise, the sampled tokens / log-probs / gradients of a train-mode decode -- at the fixture's sizes
+    and at unaligned / larger ones."""
     from imagecaptioning.pytorch_amd.captioning import models
     from imagecaptioning.pytorch_amd.captioning.modules.losses import RewardCriterion
-    opt = tiny_opt(drop_prob_lm=0.5)
+    opt = tiny_opt(drop_prob_lm=0.5, vocab_size=V, input_encoding_size=E, rnn_size=R, att_hid_size=A, fc_feat_size=F,
+                   att_feat_size=F, seq_length=L, max_length=L, vocab={str(i): 'w%d' % i for i in range(1, V + 1)})
     torch.manual_seed(11)
     model = models.setup(opt).to(DEV)
-    B, n, L, K = 5, 3, 8, 6
     V1 = opt.vocab_size + 1
     g = torch.Generator().manual_seed(5)
-    fc = torch.randn(B, 20, generator=g).clamp_min(0).to(DEV)
-    att = torch.randn(B, K, 20, generator=g).clamp_min(0).to(DEV)
+    fc = torch.randn(B, F, generator=g).clamp_min(0).to(DEV)
+    att = torch.randn(B, K, F, generator=g).clamp_min(0).to(DEV)
     am = torch.ones(B, K)
     am[1, 4:] = 0
     am = am.to(DEV)
