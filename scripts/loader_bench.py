@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Feature-loader throughput on files of the BASELINE shape (36 x 2048 fp32 regions per image, np.savez_compressed
 like scripts/prepro_feats.py writes them): the streaming FeatureLoader (decompress + pad every epoch, what the reference does)
-against the HBM-resident store from its second epoch on.  The SCST step consumes 10 images per 5.2 ms = 1 900 images/s per GPU.
+against the HBM-resident store from its second epoch on.  The SCST step consumes 10 images per 4.7 ms = 2 100 images/s per GPU.
     python scripts/loader_bench.py [n_images] [device]"""
 import json
 import os
