@@ -114,6 +114,8 @@ def train(opt):
                              optimizer_state={'flat': flat.state_dict(), 'sched': sched.state_dict()})
 
     iter_times = []
+    loss_slots = [(torch.empty(1, dtype=torch.float32, pin_memory=True), torch.cuda.Event()) for _ in range(2)]
+    prev_slot = None
     while it < opt.max_iters and (opt.max_epochs == -1 or epoch < opt.max_epochs):     # tools/train.py:279-280
         if epoch_done:
             sched.epoch_start(epoch)
@@ -156,8 +158,24 @@ def train(opt):
             scale = flat.all_reduce() if world > 1 else 1.0
             flat.adam_step(opt.current_lr, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
                            clip_value=clip, grad_scale=scale)
-        train_loss = loss.item()
-        torch.cuda.synchronize()
+        # The reference reads the loss back right here (train.py:197), leaving the GPU idle while the host prepares the next
+        # iteration.  Same values, one iteration later: the loss goes to a pinned buffer asynchronously and the host waits for the
+        # PREVIOUS iteration's copy, so one iteration is always queued behind the running one (never more: the host stays at most
+        # one iteration ahead).  Iterations that print, validate or checkpoint wait for their own loss.
+        slot = loss_slots[it & 1]
+        slot[0].copy_(loss.detach().reshape(1), non_blocking=True)
+        slot[1].record()
+        if prev_slot is not None:
+            prev_slot[1].synchronize()
+            train_loss = float(prev_slot[0][0])
+        wait_now = (it % opt.losses_log_every == 0 or it + 1 >= opt.max_iters or os.environ.get('CAPMI_TRAIN_LAG', '1') == '0'
+                    or (opt.val_every and (it + 1) % opt.val_every == 0)
+                    or (opt.save_checkpoint_every and (it + 1) % opt.save_checkpoint_every == 0))
+        if wait_now:
+            slot[1].synchronize()
+            train_loss = float(slot[0][0])
+            torch.cuda.synchronize()
+        prev_slot = None if wait_now else slot
         t2 = time.time()
         iter_times.append(t2 - t0)
         if rank == 0 and it % opt.losses_log_every == 0:
@@ -187,6 +205,9 @@ def train(opt):
                 print('validation loss: %.3f (lr %.2e)' % (val_loss, sched.current_lr))
         if rank == 0 and opt.save_checkpoint_every and it % opt.save_checkpoint_every == 0:
             checkpoint()
+    if prev_slot is not None:            # the loop ended on max_epochs: the last iteration's loss is still in flight
+        prev_slot[1].synchronize()
+        train_loss = float(prev_slot[0][0])
     if rank == 0 and opt.save_checkpoint_every:
         checkpoint()
     if rank == 0 and len(iter_times) >= 20:        # loader + step + per-iteration host sync, second half of the run
