@@ -82,7 +82,8 @@ class UpDownBwdScratch(C.Structure):
     _fields_ = ([(k, c_f) for k in ('dlogits', 'd_hdrop', 'dg_att', 'dg_lang', 'd_x2', 'd_e_all', 'd_att_h_all',
                                     'dh_att_attn', 'd_x1', 'dc_att', 'dc_lang', 'd_xt_all', 'sum_dg_att', 'w_lang_cat',
                                     'w_att_cat', 'partial')] +
-                [('partial_capacity', C.c_int64), ('sparse', C.POINTER(SparseLogpGrad))])
+                [('partial_capacity', C.c_int64), ('sparse', C.POINTER(SparseLogpGrad)), ('n_grad_rows', C.c_int), ('pack', c_f),
+                 ('pack_capacity', C.c_int64)])
 
 
 class UpDownBeam(C.Structure):

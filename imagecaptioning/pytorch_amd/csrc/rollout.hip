@@ -90,6 +90,40 @@ __global__ void pack_recurrent_kernel(const float *__restrict__ lang_ih, const f
     }
 }
 
+// Rows [0, Nb) of every time slab of up to 9 saved forward tensors ([slots][Nf][C] -> [slots][Nb][C]) in one launch: the fused
+// SCST rollout carries its greedy-baseline rows (no gradient) behind the sampled ones, and the backward runs on the sampled
+// rows only -- its time-batched GEMMs then need the activations without the gaps.  C in floats (int64 tokens: C = 2).
+struct PackItem {
+    const float *src;
+    float *dst;
+    int C, slots;
+};
+struct PackArgs {
+    PackItem it[9];
+    int n, Nf, Nb;
+};
+__global__ void pack_rows_kernel(const PackArgs a) {
+    PackItem it = a.it[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i)
+        if (blockIdx.y == i) it = a.it[i];          // static indices: no scratch copy of the argument table
+    if ((int)blockIdx.y >= a.n) return;
+    const size_t per_slot = (size_t)a.Nb * it.C, total = per_slot * it.slots;
+    const bool vec = it.C % 4 == 0 && ((reinterpret_cast<uintptr_t>(it.src) | reinterpret_cast<uintptr_t>(it.dst)) & 15) == 0;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    if (vec) {
+        for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total / 4; q += (size_t)gridDim.x * blockDim.x) {
+            const size_t i = q * 4, slot = i / per_slot, rem = i - slot * per_slot;
+            *reinterpret_cast<f4 *>(it.dst + i) = *reinterpret_cast<const f4 *>(it.src + slot * (size_t)a.Nf * it.C + rem);
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+            const size_t slot = i / per_slot, rem = i - slot * per_slot;
+            it.dst[i] = it.src[slot * (size_t)a.Nf * it.C + rem];
+        }
+    }
+}
+
 // bookkeeping of the teacher-forced pass (what the per-step select kernel writes in mode 2 with no finish mask)
 __global__ void teacher_bookkeep_kernel(const float *__restrict__ seq_logp, const int64_t *__restrict__ forced, int forced_ld,
                                         int64_t *__restrict__ seq, float *__restrict__ sel_logp, uint8_t *__restrict__ live,
@@ -242,10 +276,43 @@ int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_r
 int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_updown_rollout *r, const float *g_seq_logp,
                                     capmi_updown_bwd_scratch *s, capmi_updown_grads *g, int phases, void *stream) {
     if (!w || !r || (!g_seq_logp && !(s && s->sparse)) || !s || !g || !(phases & CAPMI_BWD_ALL)) return CAPMI_EINVAL;
-    const int B = r->B, n = r->n, N = r->N, K = r->K, A = r->A, R = r->R, E = r->E, V1 = r->V1, T = r->T, L = r->L;
+    const int B = r->B, n = r->n, Nf = r->N, K = r->K, A = r->A, R = r->R, E = r->E, V1 = r->V1, T = r->T, L = r->L;
     hipStream_t st = (hipStream_t)stream;
-    const size_t NR = (size_t)N * R;
+    // Rows [0, N) of the rollout carry gradient.  N = all Nf rows, or -- fused SCST rollout, s->n_grad_rows -- the sampled rows
+    // only: the greedy-baseline rows behind them would ride through every time-batched GEMM as zeros (K or M = T*60 instead of
+    // T*50).  The saved forward tensors keep their Nf-row time slabs (NRf); everything the backward produces is [T][N][..].
+    const int N = (s->n_grad_rows > 0 && s->n_grad_rows < Nf) ? s->n_grad_rows : Nf;
+    const bool compact = N < Nf;
+    const size_t NR = (size_t)N * R, NRf = (size_t)Nf * R;
     const int TN = T * N;
+    // saved activations the time-batched GEMMs read as [T*N, C] matrices: the tensors themselves, or their packed copies
+    const float *a_hdrop = r->h_drop, *a_hlang = r->h_lang, *a_xt = r->xt, *a_hatt = r->h_att, *a_ctx = r->ctx,
+                *a_dropxt = r->drop_xt, *a_atth = r->att_h, *a_alpha = r->alpha;
+    const int64_t *a_it = r->it_all;
+    if (compact) {
+        float *q = s->pack;
+        const int64_t need = (int64_t)N * ((int64_t)T * (4 * (int64_t)R + 2 * (int64_t)E + 2 + A + K) + R) + 64;
+        if (!q || s->pack_capacity < need) return CAPMI_EINVAL;
+        auto take = [&](size_t floats) { float *o = q; q += (floats + 3) & ~(size_t)3; return o; };
+        float *p_hdrop = take((size_t)TN * R), *p_hlang = take((size_t)TN * R), *p_xt = take((size_t)TN * E),
+              *p_hatt = take((size_t)(T + 1) * N * R), *p_ctx = take((size_t)TN * R),
+              *p_dropxt = r->drop_xt ? take((size_t)TN * E) : nullptr, *p_it = take((size_t)TN * 2),
+              *p_atth = take((size_t)TN * A), *p_alpha = take((size_t)TN * K);
+        if (phases & CAPMI_BWD_LOGIT) {             // the first phase of a (possibly phased) backward packs for all of them
+            PackArgs pa{};
+            pa.Nf = Nf; pa.Nb = N;
+            auto add = [&](const void *src, float *dst, int C_, int slots) {
+                if (src) pa.it[pa.n++] = PackItem{static_cast<const float *>(src), dst, C_, slots};
+            };
+            add(r->h_drop, p_hdrop, R, T); add(r->h_lang, p_hlang, R, T); add(r->xt, p_xt, E, T);
+            add(r->h_att, p_hatt, R, T + 1); add(r->ctx, p_ctx, R, T); add(r->drop_xt, p_dropxt, E, T);
+            add(r->it_all, p_it, 2, T); add(r->att_h, p_atth, A, T); add(r->alpha, p_alpha, K, T);
+            hipLaunchKernelGGL(pack_rows_kernel, dim3(64, pa.n), dim3(256), 0, st, pa);
+            CAPMI_CHECK_LAUNCH();
+        }
+        a_hdrop = p_hdrop; a_hlang = p_hlang; a_xt = p_xt; a_hatt = p_hatt; a_ctx = p_ctx; a_dropxt = p_dropxt;
+        a_it = r->it_all ? reinterpret_cast<const int64_t *>(p_it) : nullptr; a_atth = p_atth; a_alpha = p_alpha;
+    }
     const int ld_att_ih = 2 * R + E;
     float *P = s->partial;
     const int64_t cap = s->partial_capacity;
@@ -275,7 +342,7 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         else RC(capmi_logsoftmax_bwd(g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
         SegSpec a{s->dlogits, V1, w->logit_w, R, V1, 1};   // d_hdrop = dlogits W_logit          [TN,R]
         RC(gemm(stream, 0, 1, TN, R, s->d_hdrop, R, &a, 1, P, cap, 0, nullptr));
-        SegSpec b{s->dlogits, V1, r->h_drop, R, TN, 1};     // dW_logit = dlogits^T h_drop         [V1,R]
+        SegSpec b{s->dlogits, V1, a_hdrop, R, TN, 1};       // dW_logit = dlogits^T h_drop         [V1,R]
         RC(gemm(stream, 1, 1, V1, R, g->logit_w, R, &b, 1, P, cap, 0, nullptr));
         RC(colsum(s->dlogits, TN, V1, g->logit_b, nullptr));
     }
@@ -335,11 +402,11 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
 
         // language LSTM cell: dh = d_hdrop*mask + dh_lang(att-LSTM input of step t+1: d_x1 slabs, columns 0..R)
         //                          + dh_lang(own W_hh, t+1)
-        RC(capmi_lstm_cell_bwd_partial(s->d_hdrop + (size_t)t * NR, R, r->drop_out ? r->drop_out + (size_t)t * NR : nullptr,
+        RC(capmi_lstm_cell_bwd_partial(s->d_hdrop + (size_t)t * NR, R, r->drop_out ? r->drop_out + (size_t)t * NRf : nullptr,
                                        last ? nullptr : x1_slabs, 2 * R, x1_splits, x1_stride,
                                        d_x2_next ? d_x2_next + 2 * R : nullptr, 3 * R, 1, 0, last ? nullptr : dc_lang_in,
-                                       r->gates_lang + (size_t)t * N * 4 * R, r->c_lang + (size_t)t * NR,
-                                       r->c_lang + (size_t)(t + 1) * NR, dg_lang, dc_lang_out, N, R, stream));
+                                       r->gates_lang + (size_t)t * Nf * 4 * R, r->c_lang + (size_t)t * NRf,
+                                       r->c_lang + (size_t)(t + 1) * NRf, dg_lang, dc_lang_out, N, R, stream));
         // d_x2 = dg_lang [W_ih | W_hh]  -> (d_ctx | dh_att | dh_lang_prev), left as slabs; the attention Jacobian
         // (d_ctx -> d_att_h, and d_e kept for the batched pass) finishes the reduction of its rows and publishes d_x2
         int x2_splits = 1;
@@ -348,7 +415,7 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
             RC(gemm(stream, 0, 1, N, 3 * R, P, 3 * R, &a, 1, P, capm, 1, &x2_splits));
         }
         RC(capmi_attention_bwd_partial(P + CAPMI_WS_COUNTER_FLOATS, x2_splits, (int64_t)N * 3 * R, 3 * R, d_x2,
-                                       r->att_h + (size_t)t * N * A, r->alpha + (size_t)t * N * K, r->p_att, r->att,
+                                       r->att_h + (size_t)t * Nf * A, r->alpha + (size_t)t * Nf * K, r->p_att, r->att,
                                        w->alpha_w, s->d_att_h_all + (size_t)t * N * A, s->d_e_all + (size_t)t * N * K,
                                        r->B_feat > 0 ? r->B_feat : B, n, K, A, R, r->row_img, N, stream));
         {
@@ -359,8 +426,8 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         // columns R..2R)
         RC(capmi_lstm_cell_bwd_partial(d_x2 + R, 3 * R, nullptr, h_slabs, R, h_splits, h_stride,
                                        last ? nullptr : x1_slabs + R, 2 * R, x1_splits, x1_stride,
-                                       last ? nullptr : dc_att_in, r->gates_att + (size_t)t * N * 4 * R,
-                                       r->c_att + (size_t)t * NR, r->c_att + (size_t)(t + 1) * NR, dg_att, dc_att_out, N, R,
+                                       last ? nullptr : dc_att_in, r->gates_att + (size_t)t * Nf * 4 * R,
+                                       r->c_att + (size_t)t * NRf, r->c_att + (size_t)(t + 1) * NRf, dg_att, dc_att_out, N, R,
                                        stream));
         // d_x1 = dg_att [W_ih(:, 0:R) | W_hh] -> (dh_lang_prev | dh_att_prev) as slabs for step t-1; not needed at t = 0
         if (t > 0) {
@@ -374,11 +441,11 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
     // ---- time-batched parameter / feature gradients --------------------------------------------
     // attention LSTM
     if (phases & CAPMI_BWD_ATT_LSTM) {
-        SegSpec a{s->dg_att, 4 * R, r->h_lang, R, TN, 1};          // x h_lang_prev  (slots 0..T-1)
+        SegSpec a{s->dg_att, 4 * R, a_hlang, R, TN, 1};            // x h_lang_prev  (slots 0..T-1)
         RC(gemm(stream, 1, 1, 4 * R, R, g->att_w_ih, ld_att_ih, &a, 1, P, cap, 0, nullptr));
-        SegSpec b{s->dg_att, 4 * R, r->xt, E, TN, 1};              // x xt
+        SegSpec b{s->dg_att, 4 * R, a_xt, E, TN, 1};               // x xt
         RC(gemm(stream, 1, 1, 4 * R, E, g->att_w_ih + 2 * R, ld_att_ih, &b, 1, P, cap, 0, nullptr));
-        SegSpec c{s->dg_att, 4 * R, r->h_att, R, TN, 1};           // x h_att_prev
+        SegSpec c{s->dg_att, 4 * R, a_hatt, R, TN, 1};             // x h_att_prev
         RC(gemm(stream, 1, 1, 4 * R, R, g->att_w_hh, R, &c, 1, P, cap, 0, nullptr));
         RC(colsum(s->dg_att, TN, 4 * R, g->att_b_ih, g->att_b_hh));
         hipError_t e;
@@ -395,24 +462,24 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         RC(gemm(stream, 0, 1, TN, E, s->d_xt_all, E, &x, 1, P, cap, 0, nullptr));
         e = hipMemsetAsync(g->embed, 0, (size_t)V1 * E * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
-        RC(capmi_embed_bwd(r->it_all, s->d_xt_all, r->xt, r->drop_xt, g->embed, TN, E, 1, stream));
+        RC(capmi_embed_bwd(a_it, s->d_xt_all, a_xt, a_dropxt, g->embed, TN, E, 1, stream));
     }
     // language LSTM
     if (phases & CAPMI_BWD_LANG_LSTM) {
-        SegSpec a{s->dg_lang, 4 * R, r->ctx, R, TN, 1};
+        SegSpec a{s->dg_lang, 4 * R, a_ctx, R, TN, 1};
         RC(gemm(stream, 1, 1, 4 * R, R, g->lang_w_ih, 2 * R, &a, 1, P, cap, 0, nullptr));
-        SegSpec b{s->dg_lang, 4 * R, r->h_att + NR, R, TN, 1};      // h_att of the same step (slots 1..T)
+        SegSpec b{s->dg_lang, 4 * R, a_hatt + (compact ? NR : NRf), R, TN, 1};      // h_att of the same step (slots 1..T)
         RC(gemm(stream, 1, 1, 4 * R, R, g->lang_w_ih + R, 2 * R, &b, 1, P, cap, 0, nullptr));
-        SegSpec c{s->dg_lang, 4 * R, r->h_lang, R, TN, 1};
+        SegSpec c{s->dg_lang, 4 * R, a_hlang, R, TN, 1};
         RC(gemm(stream, 1, 1, 4 * R, R, g->lang_w_hh, R, &c, 1, P, cap, 0, nullptr));
         RC(colsum(s->dg_lang, TN, 4 * R, g->lang_b_ih, g->lang_b_hh));
     }
     // attention parameters / features
     if (phases & CAPMI_BWD_ATTENTION) {
-        SegSpec a{s->d_att_h_all, A, r->h_att + NR, R, TN, 1};
+        SegSpec a{s->d_att_h_all, A, a_hatt + (compact ? NR : NRf), R, TN, 1};
         RC(gemm(stream, 1, 1, A, R, g->h2att_w, R, &a, 1, P, cap, 0, nullptr));
         RC(colsum(s->d_att_h_all, TN, A, g->h2att_b, nullptr));
-        RC(capmi_attention_bwd_batched(s->d_x2, 3 * R, r->att_h, r->alpha, s->d_e_all, r->p_att, w->alpha_w, g->d_att,
+        RC(capmi_attention_bwd_batched(s->d_x2, 3 * R, a_atth, a_alpha, s->d_e_all, r->p_att, w->alpha_w, g->d_att,
                                        g->d_p_att, g->alpha_w, g->alpha_b, T, B, n, N, K, A, R, stream));
     }
     if (n_cols) RC(capmi_colsum_batch_args(cols, n_cols, stream));

@@ -9,6 +9,7 @@ Mirrors, for the UpDown model (AttModel.py:875-879 + UpDownCore 615-640):
   Rollout.backward()  the autograd graph torch would have recorded for them
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -205,6 +206,12 @@ class Rollout:
         for k, t in keep.items():
             setattr(s, k, t.data_ptr())
         s.partial, s.partial_capacity = self.ws.buf.data_ptr(), self.ws.capacity
+        if self.row_img is not None and B * n < N and os.environ.get('CAPMI_BWD_ALL_ROWS') != '1':
+            # fused SCST rollout: rows [B*n, N) are the greedy baseline (eval mode, no gradient) -- the backward runs on the
+            # sampled rows only and packs the saved activations once for its time-batched GEMMs
+            nb = B * n
+            keep['pack'] = z(nb * (T * (4 * R + 2 * E + 2 + A + K) + R) + 64)
+            s.n_grad_rows, s.pack, s.pack_capacity = nb, keep['pack'].data_ptr(), keep['pack'].numel()
         g = _lib.UpDownGrads()
         for f, k in _W_FIELDS:
             setattr(g, f, grads[k].data_ptr())

@@ -479,6 +479,13 @@ typedef struct capmi_updown_bwd_scratch {
     float *partial;
     int64_t partial_capacity;
     const capmi_sparse_logp_grad *sparse;   /* NULL, or the loss gradient in sparse form (then g_seq_logp may be NULL) */
+    /* Rows [0, n_grad_rows) of the rollout carry gradient (0: all N).  The fused SCST rollout (row_img) keeps its greedy-baseline
+     * rows behind the sampled ones; with n_grad_rows = B * n the backward runs on the sampled rows only and every [T,N,..]
+     * array above is [T,n_grad_rows,..].  It then needs `pack`: >= n_grad_rows * (T * (4R + 2E + 2 + A + K) + R) + 64 floats
+     * for gap-free copies of the saved activations. */
+    int n_grad_rows;
+    float *pack;
+    int64_t pack_capacity;
 } capmi_updown_bwd_scratch;
 
 /* g_seq_logp [N,T,V1]: gradient w.r.t. the dense log-probs returned by the forward (NULL when s->sparse carries it). */
