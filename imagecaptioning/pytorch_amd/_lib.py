@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ('M', C.c_int), ('N', C.c_int), ('C', c_f), ('ldc', C.c_int), ('bias', c_f), ('bias2', c_f),
                 ('row_bias', c_f), ('row_bias_div', C.c_int), ('mul_mask', c_f), ('relu', C.c_int),
                 ('accumulate', C.c_int), ('partial', c_f), ('partial_capacity', C.c_int64), ('splits', C.c_int),
-                ('defer_reduce', C.c_int), ('splits_used', C.c_int)]
+                ('defer_reduce', C.c_int), ('splits_used', C.c_int), ('a_planes', c_f * MAX_SEG), ('zero_planes', c_f)]
 
 
 class UpDownWeights(C.Structure):
@@ -46,7 +46,8 @@ class UpDownRollout(C.Structure):
                 [(k, c_f) for k in ('h_att', 'c_att', 'h_lang', 'c_lang', 'xt', 'it_all', 'gates_att', 'gates_lang',
                                     'att_h', 'alpha', 'ctx', 'h_drop', 'seq', 'seq_logp', 'sel_logp', 'live',
                                     'fc_gates', 'logits', 'it', 'unfinished', 'partial')] +
-                [('partial_capacity', C.c_int64), ('top_k', C.c_int), ('top_p', C.c_float), ('ss_mode', c_f)])
+                [('partial_capacity', C.c_int64), ('top_k', C.c_int), ('top_p', C.c_float), ('ss_mode', c_f),
+                 ('planes', c_f), ('planes_bytes', C.c_int64)])
 
 
 class SampleFilter(C.Structure):
@@ -83,7 +84,7 @@ class UpDownBwdScratch(C.Structure):
                                     'dh_att_attn', 'd_x1', 'dc_att', 'dc_lang', 'd_xt_all', 'sum_dg_att', 'w_lang_cat',
                                     'w_att_cat', 'partial')] +
                 [('partial_capacity', C.c_int64), ('sparse', C.POINTER(SparseLogpGrad)), ('n_grad_rows', C.c_int), ('pack', c_f),
-                 ('pack_capacity', C.c_int64)])
+                 ('pack_capacity', C.c_int64), ('planes', c_f), ('planes_bytes', C.c_int64)])
 
 
 class UpDownBeam(C.Structure):
@@ -124,13 +125,21 @@ SIGNATURES = {
     'capmi_version': [],
     'capmi_arch': [],
     'capmi_gemm_f32': [C.POINTER(GemmDesc), _P],
+    'capmi_planes_bytes': [_I],
+    'capmi_planes_from_f32': [_P, _I, _I, _I, _P, _P],
+    'capmi_updown_planes_bytes': [_I, _I],
+    'capmi_updown_bwd_planes_bytes': [_I],
     'capmi_attention_fwd': [_P] * 8 + [_I] * 5 + [_P, _I, _P],
     'capmi_attention_fwd_partial': [_P, _I, _I64, _P, _P] + [_P] * 7 + [_I] * 5 + [_P, _I, _P],
+    'capmi_attention_fwd_partial_pl': [_P, _I, _I64, _P, _P] + [_P] * 7 + [_I] * 5 + [_P, _I, _P, _P],
     'capmi_attention_bwd': [_P, _I] + [_P] * 8 + [_I] * 5 + [_P, _I, _P],
     'capmi_attention_bwd_partial': [_P, _I, _I64, _I, _P] + [_P] * 7 + [_I] * 5 + [_P, _I, _P],
     'capmi_attention_bwd_batched': [_P, _I] + [_P] * 9 + [_I] * 7 + [_P],
     'capmi_lstm_cell_fwd': [_P, _I, _P, _P, _P, _I, _P] + [_P] * 6 + [_I, _I, _P],
+    'capmi_lstm_cell_fwd_pl': [_P, _I, _P, _P, _P, _I, _P] + [_P] * 6 + [_I, _I, _P, _P, _P],
     'capmi_lstm_cell_bwd': [_P, _I, _P, _P, _I, _P, _I] + [_P] * 6 + [_I, _I, _P],
+    'capmi_lstm_cell_bwd_partial_pl': [_P, _I, _P, _P, _I, _I, _I64, _P, _I, _I, _I64] + [_P] * 6 + [_I, _I, _P, _P],
+    'capmi_embed_fwd_pl': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     'capmi_lstm_cell_bwd_partial': [_P, _I, _P, _P, _I, _I, _I64, _P, _I, _I, _I64] + [_P] * 6 + [_I, _I, _P],
     'capmi_embed_fwd': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P],
     'capmi_embed_bwd': [_P] * 5 + [_I, _I, _I, _P],
@@ -207,7 +216,9 @@ def _load():
         except AttributeError as e:  # pragma: no cover
             raise ImportError('libcapmi.so does not export %s (stale build?)' % name) from e
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == 'capmi_arch' else C.c_int
+        fn.restype = (C.c_char_p if name == 'capmi_arch' else
+                      C.c_int64 if name in ('capmi_planes_bytes', 'capmi_updown_planes_bytes', 'capmi_updown_bwd_planes_bytes')
+                      else C.c_int)
     return lib
 
 

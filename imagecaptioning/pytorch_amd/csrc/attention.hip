@@ -56,7 +56,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
     const float *__restrict__ mask, const float *__restrict__ w, const float *__restrict__ bptr,
     float *__restrict__ ctx, float *__restrict__ alpha, int B, int n_img, int rpb, int chunks, int K, int A, int R,
     const int *__restrict__ row_img, int h_splits, size_t h_stride, const float *__restrict__ h_bias,
-    float *__restrict__ att_h_out) {
+    float *__restrict__ att_h_out, unsigned char *__restrict__ pl_ctx) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int AH = A > 1024 ? A : 1024;  // s_h doubles as the [NMAX][1024] combine buffer of the context phase
     float *s_h = lds;                    // [NMAX][AH]
@@ -246,8 +246,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
             for (int j = 0; j < NMAX; ++j) {
                 if (j < n) {
                     const f32x4 o = *reinterpret_cast<const f32x4 *>(s_c + j * 1024 + r);
-                    *reinterpret_cast<f32x4 *>(ctx + (size_t)(row0 + j) * R + r) =
-                        f32x4{c0[j] + o[0], c1[j] + o[1], c2[j] + o[2], c3[j] + o[3]};
+                    const f32x4 cv = f32x4{c0[j] + o[0], c1[j] + o[1], c2[j] + o[2], c3[j] + o[3]};
+                    *reinterpret_cast<f32x4 *>(ctx + (size_t)(row0 + j) * R + r) = cv;
+                    if (pl_ctx) pl_store4(pl_ctx, row0 + j, r, cv);     // A planes of ctx for the language-LSTM gate GEMM
                 }
             }
         }
@@ -264,7 +265,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
             }
 #pragma unroll
             for (int j = 0; j < NMAX; ++j)
-                if (j < n) ctx[(size_t)(row0 + j) * R + r] = a0[j];
+                if (j < n) {
+                    ctx[(size_t)(row0 + j) * R + r] = a0[j];
+                    if (pl_ctx) pl_store1(pl_ctx, row0 + j, r, a0[j]);
+                }
         }
     }
 }
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_v2_kernel(
     const float *__restrict__ mask, const float *__restrict__ w, const float *__restrict__ bptr,
     float *__restrict__ ctx, float *__restrict__ alpha, int B, int n_img, int rpb, int chunks, int K, int A, int R,
     const int *__restrict__ row_img, int h_splits, size_t h_stride, const float *__restrict__ h_bias,
-    float *__restrict__ att_h_out) {
+    float *__restrict__ att_h_out, unsigned char *__restrict__ pl_ctx) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *s_h = lds;                         // [NR][512]; later the context combine buffer [NR][1024]
     float *s_e = lds + (size_t)NR * 1024;     // [NR][V2_KMAX]
@@ -455,8 +459,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_v2_kernel(
         for (int j = 0; j < NR; ++j) {
             if (j < n) {
                 const f32x4 o = *reinterpret_cast<const f32x4 *>(s_c + j * 1024 + r);
-                *reinterpret_cast<f32x4 *>(ctx + (size_t)(row0 + j) * R + r) =
-                    f32x4{c0[j] + o[0], c1[j] + o[1], c2[j] + o[2], c3[j] + o[3]};
+                const f32x4 cv = f32x4{c0[j] + o[0], c1[j] + o[1], c2[j] + o[2], c3[j] + o[3]};
+                *reinterpret_cast<f32x4 *>(ctx + (size_t)(row0 + j) * R + r) = cv;
+                if (pl_ctx) pl_store4(pl_ctx, row0 + j, r, cv);         // A planes of ctx for the language-LSTM gate GEMM
             }
         }
     }
@@ -833,10 +838,11 @@ extern "C" {
 static int attention_fwd_launch(const float *att_h, int h_splits, int64_t h_stride, const float *h_bias, float *att_h_out,
                                 const float *p_att, const float *att, const float *mask, const float *w, const float *b,
                                 float *ctx, float *alpha, int B, int n, int K, int A, int R, const int32_t *row_img, int N,
-                                void *stream) {
+                                void *stream, unsigned char *pl_ctx = nullptr) {
     if (!att_h || !p_att || !att || !w || !ctx || !alpha || B <= 0 || K <= 0 || A <= 0 || R <= 0) return CAPMI_EINVAL;
     if (row_img ? N <= 0 : n <= 0) return CAPMI_EINVAL;
     if (!row_img) N = B * n;
+    if (pl_ctx && N > 64) return CAPMI_EINVAL;
     const size_t lds = ((size_t)NMAX * (A > 1024 ? A : 1024) + (size_t)NMAX * K) * sizeof(float);
     if (lds > 64 * 1024) return CAPMI_EINVAL;
     // unique (algorithmic) bytes: image tiles once + per-row att_h in, ctx and alpha out
@@ -858,10 +864,10 @@ static int attention_fwd_launch(const float *att_h, int h_splits, int64_t h_stri
 #define CAPMI_ATT_V2(NR_)                                                                                                   \
         if (prof) hipExtLaunchKernelGGL(attention_fwd_v2_kernel<NR_>, grid, dim3(ATT_THREADS), lds2, (hipStream_t)stream, e0,   \
                                         e1, 0, att_h, p_att, att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K, A, R, row_img,  \
-                                        h_splits, (size_t)h_stride, h_bias, att_h_out);                                        \
+                                        h_splits, (size_t)h_stride, h_bias, att_h_out, pl_ctx);                                \
         else hipLaunchKernelGGL(attention_fwd_v2_kernel<NR_>, grid, dim3(ATT_THREADS), lds2, (hipStream_t)stream, att_h, p_att, \
                                 att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K, A, R, row_img, h_splits, (size_t)h_stride,   \
-                                h_bias, att_h_out)
+                                h_bias, att_h_out, pl_ctx)
         if (rpb == 1) { CAPMI_ATT_V2(1); } else { CAPMI_ATT_V2(2); }
 #undef CAPMI_ATT_V2
         CAPMI_CHECK_LAUNCH();
@@ -870,11 +876,11 @@ static int attention_fwd_launch(const float *att_h, int h_splits, int64_t h_stri
     if (capmi_prof::take_events(CAPMI_PROF_ATTENTION_FWD, &e0, &e1, abytes, (double)N * K * (2.0 * A + 2.0 * R)))
         hipExtLaunchKernelGGL(attention_fwd_kernel, dim3(row_img ? N : grid_blocks(B, chunks)), dim3(ATT_THREADS), lds,
                               (hipStream_t)stream, e0, e1, 0, att_h, p_att, att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K,
-                              A, R, row_img, h_splits, (size_t)h_stride, h_bias, att_h_out);
+                              A, R, row_img, h_splits, (size_t)h_stride, h_bias, att_h_out, pl_ctx);
     else
         hipLaunchKernelGGL(attention_fwd_kernel, dim3(row_img ? N : grid_blocks(B, chunks)), dim3(ATT_THREADS), lds,
                            (hipStream_t)stream, att_h, p_att, att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K, A, R, row_img,
-                           h_splits, (size_t)h_stride, h_bias, att_h_out);
+                           h_splits, (size_t)h_stride, h_bias, att_h_out, pl_ctx);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -893,6 +899,15 @@ int capmi_attention_fwd_partial(const float *h_partial, int h_splits, int64_t h_
     if (h_splits < 1) return CAPMI_EINVAL;
     return attention_fwd_launch(h_partial, h_splits, h_stride, h_bias, att_h_out, p_att, att, mask, w, b, ctx, alpha, B, n, K,
                                 A, R, row_img, N, stream);
+}
+
+int capmi_attention_fwd_partial_pl(const float *h_partial, int h_splits, int64_t h_stride, const float *h_bias,
+                                   float *att_h_out, const float *p_att, const float *att, const float *mask, const float *w,
+                                   const float *b, float *ctx, float *alpha, int B, int n, int K, int A, int R,
+                                   const int32_t *row_img, int N, void *ctx_planes, void *stream) {
+    if (h_splits < 1) return CAPMI_EINVAL;
+    return attention_fwd_launch(h_partial, h_splits, h_stride, h_bias, att_h_out, p_att, att, mask, w, b, ctx, alpha, B, n, K,
+                                A, R, row_img, N, stream, static_cast<unsigned char *>(ctx_planes));
 }
 
 static int attention_bwd_launch(const float *d_ctx, int ld_dctx, const float *x_slabs, int x_splits, int64_t x_stride, int x_cols,

@@ -100,3 +100,52 @@ struct Philox {
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
 }  // namespace capmi
+
+// ---- "A planes": an activation matrix X[M <= 64, K] pre-split for the decode GEMMs (gemm_ares.hip, round 3) -------------
+// The decode GEMMs run fp32 through the bf16 matrix pipe by an exact 3-way split x = h + m + l (three truncated bf16
+// values).  Round 2 split the activation slice inside every one of the 32 column-block workgroups that share it (VGPR round
+// trip + ~5.5 VALU ops per element + LDS writes before the first MFMA could start).  Now the PRODUCER of an activation (LSTM
+// cell, attention, select/embed, cell backward) writes the three planes once, already in the LDS image the GEMM wants, and
+// the GEMM copies its K slice with LDS-DMA (global_load_lds_dwordx4: no VGPRs, no VALU, no ds_write).
+// Layout: K is cut in chunks of 32; chunk c = [plane 3][row 64][32 bf16 = 64 B] = CAPMI_PL_CHUNK_BYTES.  Inside a row the four
+// 16-byte pieces (8 k each) are XOR-swizzled by (row >> 2) & 3 so that the MFMA fragment reads (ds_read_b128: 16-lane groups
+// over 16 rows, same piece) touch all 64 banks exactly once.  Rows >= M and k >= K are never written and stay zero (the
+// buffers are zero-filled once when they are allocated).
+#define CAPMI_PL_CHUNK_BYTES 12288
+#define CAPMI_PL_PLANE_BYTES 4096
+
+namespace capmi {
+__device__ __forceinline__ uint32_t f2u(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float u2f(uint32_t x) { return __builtin_bit_cast(float, x); }
+// byte offset of element (row, k) inside plane 0
+__device__ __forceinline__ size_t pl_offset(int row, int k) {
+    const int kk = k & 31;
+    return (size_t)(k >> 5) * CAPMI_PL_CHUNK_BYTES + row * 64 + ((((kk >> 3) ^ (row >> 2)) & 3) << 4) + ((kk & 7) << 1);
+}
+__device__ __forceinline__ void pl_store1(unsigned char *pl, int row, int k, float x) {
+    const uint32_t h = f2u(x) & 0xffff0000u;
+    const float r1 = x - u2f(h);
+    const uint32_t m = f2u(r1) & 0xffff0000u;
+    const uint32_t l = f2u(r1 - u2f(m));
+    unsigned char *o = pl + pl_offset(row, k);
+    *reinterpret_cast<unsigned short *>(o) = (unsigned short)(h >> 16);
+    *reinterpret_cast<unsigned short *>(o + CAPMI_PL_PLANE_BYTES) = (unsigned short)(m >> 16);
+    *reinterpret_cast<unsigned short *>(o + 2 * CAPMI_PL_PLANE_BYTES) = (unsigned short)(l >> 16);
+}
+// four consecutive k (k % 4 == 0): one 8-byte store per plane
+__device__ __forceinline__ void pl_store4(unsigned char *pl, int row, int k, f32x4 v) {
+    typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+    uint32_t h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = f2u(v[e]) & 0xffff0000u;
+        const float r1 = v[e] - u2f(h[e]);
+        m[e] = f2u(r1) & 0xffff0000u;
+        l[e] = f2u(r1 - u2f(m[e]));
+    }
+    unsigned char *o = pl + pl_offset(row, k);
+    *reinterpret_cast<u32x2_ *>(o) = u32x2_{(h[0] >> 16) | (h[1] & 0xffff0000u), (h[2] >> 16) | (h[3] & 0xffff0000u)};
+    *reinterpret_cast<u32x2_ *>(o + CAPMI_PL_PLANE_BYTES) = u32x2_{(m[0] >> 16) | (m[1] & 0xffff0000u), (m[2] >> 16) | (m[3] & 0xffff0000u)};
+    *reinterpret_cast<u32x2_ *>(o + 2 * CAPMI_PL_PLANE_BYTES) = u32x2_{(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
+}
+}  // namespace capmi

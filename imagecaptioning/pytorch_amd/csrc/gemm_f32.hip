@@ -407,8 +407,10 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
         o.vecB = aligned16(g.B) && (g.ldb % 4 == 0);
         o.rdiv = (65536 + o.a_row_div - 1) / o.a_row_div;
         o.tstart = tiles;
+        o.Apl = static_cast<const unsigned char *>(d->a_planes[s]);
         tiles += (g.K + BK - 1) / BK;
     }
+    a.zero_planes = static_cast<const unsigned char *>(d->zero_planes);
     for (int s = d->nseg; s < CAPMI_MAX_SEG; ++s) {      // unused slots: never selected, but always valid to read
         a.seg[s] = a.seg[0];
         a.seg[s].tstart = 0x7fffffff;
@@ -480,7 +482,18 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
             a.ablate = env_aopt;             // speed-only switches of the A-resident kernel (see gemm_ares.hip)
             if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > slab_cap)) return CAPMI_EINVAL;
             d->splits_used = splits;
-            int rc = launch_ares(a, d->b_layout, ts_max, use_x3, st, pcls, bytes, flops);
+            // round 3: every segment also delivered as A planes -> LDS-DMA staged kernel (CAPMI_APL=0 keeps the kernel above)
+            static const int env_apl = [] { const char *e = getenv("CAPMI_APL"); return e ? atoi(e) : 1; }();
+            static const int env_apl_opt = [] { const char *e = getenv("CAPMI_APL_OPT"); return e ? atoi(e) : 1; }();
+            bool apl_ok = env_apl && use_x3 && d->zero_planes && ts_max <= apl_ts_cap(d->b_layout);
+            for (int s = 0; s < d->nseg && apl_ok; ++s) apl_ok = d->a_planes[s] != nullptr && a.seg[s].a_row_div == 1;
+            int rc;
+            if (apl_ok) {
+                a.ablate = env_apl_opt;          // bit 0: XCD-aware workgroup map
+                rc = launch_apl(a, d->b_layout, ts_max, st, pcls, bytes, flops);
+            } else {
+                rc = launch_ares(a, d->b_layout, ts_max, use_x3, st, pcls, bytes, flops);
+            }
             if (rc) return rc;
             if (splits > 1 && !d->defer_reduce)
                 return capmi_splitk_reduce(a.partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,

@@ -26,7 +26,7 @@ inline bool aligned16(P... p) {
 // ---------------------------------------------------------------- embedding
 __global__ void embed_fwd_kernel(const int64_t *__restrict__ it, int it_stride, int64_t *__restrict__ it_save,
                                  const float *__restrict__ E, const float *__restrict__ mask, float *__restrict__ x,
-                                 int N, int Ed, int relu) {
+                                 int N, int Ed, int relu, unsigned char *__restrict__ pl) {
     const size_t total = (size_t)N * Ed;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / Ed), c = (int)(i % Ed);
@@ -36,6 +36,7 @@ __global__ void embed_fwd_kernel(const int64_t *__restrict__ it, int it_stride, 
         if (relu) v = fmaxf(v, 0.f);
         if (mask) v *= mask[i];
         x[i] = v;
+        if (pl) pl_store1(pl, r, c, v);          // A planes of x for the attention-LSTM gate GEMM (N <= 64)
     }
 }
 
@@ -62,7 +63,8 @@ __global__ void lstm_cell_fwd_kernel(const float *__restrict__ partial, int spli
                                      int row_bias_div, const int *__restrict__ row_bias_idx,
                                      const float *__restrict__ c_prev, float *__restrict__ h,
                                      float *__restrict__ c, float *__restrict__ gates_act,
-                                     const float *__restrict__ out_mask, float *__restrict__ h_drop, int N, int R) {
+                                     const float *__restrict__ out_mask, float *__restrict__ h_drop, int N, int R,
+                                     unsigned char *__restrict__ pl_h, unsigned char *__restrict__ pl_hd) {
     const size_t total = (size_t)N * R;
     const size_t slab = (size_t)N * 4 * R;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -101,8 +103,73 @@ __global__ void lstm_cell_fwd_kernel(const float *__restrict__ partial, int spli
             float *ga = gates_act + (size_t)r * 4 * R + j;
             ga[0] = ig; ga[R] = fg; ga[2 * R] = gg; ga[3 * (size_t)R] = og;
         }
-        if (h_drop) h_drop[i] = out_mask ? hn * out_mask[i] : hn;
+        const float hd = out_mask ? hn * out_mask[i] : hn;
+        if (h_drop) h_drop[i] = hd;
+        if (pl_h) pl_store1(pl_h, r, j, hn);
+        if (pl_hd) pl_store1(pl_hd, r, j, hd);
     }
+}
+
+// The same cell, 16 bytes at a time, for the rollouts that also want the A PLANES of h / h_drop (round 3; R % 4 == 0, aligned
+// operands, N <= 64): one thread per 4 hidden units, every slab load of a trip issued before the first is consumed
+// (branch-free, clamped + multiplied by 0/1 like slab_sum8), and the planes leave as one 8-byte store per plane instead of
+// three 2-byte stores per element.  Same summation order per element as the scalar kernel: slabs in order, 8 per trip.
+__device__ __forceinline__ f32x4 slab_seq8(const float *p, int s0, int splits, size_t stride, f32x4 acc) {
+    f32x4 part[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) part[u] = *reinterpret_cast<const f32x4 *>(p + (size_t)min(s0 + u, splits - 1) * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += part[u] * ((s0 + u < splits) ? 1.f : 0.f);
+    return acc;
+}
+
+__global__ __launch_bounds__(64) void lstm_cell_fwd_vec_kernel(
+    const float *__restrict__ partial, int splits, const float *__restrict__ b_ih, const float *__restrict__ b_hh,
+    const float *__restrict__ row_bias, int row_bias_div, const int *__restrict__ row_bias_idx,
+    const float *__restrict__ c_prev, float *__restrict__ h, float *__restrict__ c, float *__restrict__ gates_act,
+    const float *__restrict__ out_mask, float *__restrict__ h_drop, int N, int R, unsigned char *__restrict__ pl_h,
+    unsigned char *__restrict__ pl_hd) {
+    const int R4 = R >> 2;
+    const int i4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 >= N * R4) return;
+    const int r = i4 / R4, j = (i4 - r * R4) * 4;
+    const size_t i = (size_t)r * R + j;
+    const size_t slab = (size_t)N * 4 * R;
+    const f32x4 cp = *reinterpret_cast<const f32x4 *>(c_prev + i);
+    f32x4 om = {1.f, 1.f, 1.f, 1.f};
+    if (out_mask) om = *reinterpret_cast<const f32x4 *>(out_mask + i);
+    f32x4 g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const size_t col = (size_t)q * R + j;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < splits; s0 += 8) acc = slab_seq8(partial + (size_t)r * 4 * R + col, s0, splits, slab, acc);
+        if (b_ih) acc += *reinterpret_cast<const f32x4 *>(b_ih + col);
+        if (b_hh) acc += *reinterpret_cast<const f32x4 *>(b_hh + col);
+        if (row_bias)
+            acc += *reinterpret_cast<const f32x4 *>(row_bias + (size_t)(row_bias_idx ? row_bias_idx[r] : r / row_bias_div) * 4 * R + col);
+        g[q] = acc;
+    }
+    f32x4 ig, fg, gg, og, cn, hn, hd;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        ig[e] = sigmoid_f(g[0][e]); fg[e] = sigmoid_f(g[1][e]); gg[e] = tanh_f(g[2][e]); og[e] = sigmoid_f(g[3][e]);
+        cn[e] = fg[e] * cp[e] + ig[e] * gg[e];
+        hn[e] = og[e] * tanh_f(cn[e]);
+        hd[e] = out_mask ? hn[e] * om[e] : hn[e];
+    }
+    *reinterpret_cast<f32x4 *>(c + i) = cn;
+    *reinterpret_cast<f32x4 *>(h + i) = hn;
+    if (gates_act) {
+        float *ga = gates_act + (size_t)r * 4 * R + j;
+        *reinterpret_cast<f32x4 *>(ga) = ig;
+        *reinterpret_cast<f32x4 *>(ga + R) = fg;
+        *reinterpret_cast<f32x4 *>(ga + 2 * (size_t)R) = gg;
+        *reinterpret_cast<f32x4 *>(ga + 3 * (size_t)R) = og;
+    }
+    if (h_drop) *reinterpret_cast<f32x4 *>(h_drop + i) = hd;
+    if (pl_h) pl_store4(pl_h, r, j, hn);
+    if (pl_hd) pl_store4(pl_hd, r, j, hd);
 }
 
 // dh_b / dh_c may arrive as split-K slabs of the dX GEMMs of the previous BPTT step (b_splits / c_splits > 1,
@@ -112,7 +179,8 @@ __global__ void lstm_cell_bwd_kernel(const float *__restrict__ dh_a, int ld_a, c
                                      const float *__restrict__ dh_c, int ld_c, int c_splits, size_t c_stride,
                                      const float *__restrict__ dc_next, const float *__restrict__ gates_act,
                                      const float *__restrict__ c_prev, const float *__restrict__ c_new,
-                                     float *__restrict__ d_gates, float *__restrict__ dc_prev, int N, int R) {
+                                     float *__restrict__ d_gates, float *__restrict__ dc_prev, int N, int R,
+                                     unsigned char *__restrict__ pl_dg) {
     const size_t total = (size_t)N * R;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / R), j = (int)(i % R);
@@ -145,10 +213,13 @@ __global__ void lstm_cell_bwd_kernel(const float *__restrict__ dh_a, int ld_a, c
         float dc = dh * og * (1.f - tc * tc);
         if (dc_next) dc += dc_next[i];
         float *dg = d_gates + (size_t)r * 4 * R + j;
-        dg[0] = dc * gg * ig * (1.f - ig);
-        dg[R] = dc * c_prev[i] * fg * (1.f - fg);
-        dg[2 * R] = dc * ig * (1.f - gg * gg);
-        dg[3 * (size_t)R] = dh * tc * og * (1.f - og);
+        const float d0 = dc * gg * ig * (1.f - ig), d1 = dc * c_prev[i] * fg * (1.f - fg);
+        const float d2 = dc * ig * (1.f - gg * gg), d3 = dh * tc * og * (1.f - og);
+        dg[0] = d0; dg[R] = d1; dg[2 * R] = d2; dg[3 * (size_t)R] = d3;
+        if (pl_dg) {                             // A planes of d_gates [N, 4R] for the dX GEMM of this BPTT step
+            pl_store1(pl_dg, r, j, d0); pl_store1(pl_dg, r, R + j, d1);
+            pl_store1(pl_dg, r, 2 * R + j, d2); pl_store1(pl_dg, r, 3 * R + j, d3);
+        }
         dc_prev[i] = dc * fg;
     }
 }
@@ -171,7 +242,8 @@ __global__ __launch_bounds__(64) void lstm_cell_bwd_vec_kernel(
     const float *__restrict__ dh_a, int ld_a, const float *__restrict__ dh_a_mask, const float *__restrict__ dh_b, int ld_b,
     int b_splits, size_t b_stride, const float *__restrict__ dh_c, int ld_c, int c_splits, size_t c_stride,
     const float *__restrict__ dc_next, const float *__restrict__ gates_act, const float *__restrict__ c_prev,
-    const float *__restrict__ c_new, float *__restrict__ d_gates, float *__restrict__ dc_prev, int N, int R) {
+    const float *__restrict__ c_new, float *__restrict__ d_gates, float *__restrict__ dc_prev, int N, int R,
+    unsigned char *__restrict__ pl_dg) {
     const int R4 = R >> 2;
     const int i4 = blockIdx.x * blockDim.x + threadIdx.x;
     if (i4 >= N * R4) return;
@@ -212,6 +284,10 @@ __global__ __launch_bounds__(64) void lstm_cell_bwd_vec_kernel(
     *reinterpret_cast<f32x4 *>(dg + 2 * (size_t)R) = d2;
     *reinterpret_cast<f32x4 *>(dg + 3 * (size_t)R) = d3;
     *reinterpret_cast<f32x4 *>(dc_prev + i) = dcp;
+    if (pl_dg) {                                 // A planes of d_gates [N, 4R] for the dX GEMM of this BPTT step
+        pl_store4(pl_dg, r, j, d0); pl_store4(pl_dg, r, R + j, d1);
+        pl_store4(pl_dg, r, 2 * R + j, d2); pl_store4(pl_dg, r, 3 * R + j, d3);
+    }
 }
 
 // ---------------------------------------------------------------- misc
@@ -462,13 +538,18 @@ __global__ void scst_advantage_kernel(const double *__restrict__ scores, int N, 
 
 extern "C" {
 
-int capmi_embed_fwd(const int64_t *it, int it_stride, int64_t *it_save, const float *E, const float *mask, float *x,
-                    int N, int Edim, int relu, void *stream) {
-    if (!it || !E || !x || N <= 0 || Edim <= 0 || it_stride < 1) return CAPMI_EINVAL;
+int capmi_embed_fwd_pl(const int64_t *it, int it_stride, int64_t *it_save, const float *E, const float *mask, float *x,
+                       int N, int Edim, int relu, void *x_planes, void *stream) {
+    if (!it || !E || !x || N <= 0 || Edim <= 0 || it_stride < 1 || (x_planes && N > 64)) return CAPMI_EINVAL;
     hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((size_t)N * Edim)), dim3(256), 0, (hipStream_t)stream, it,
-                       it_stride, it_save, E, mask, x, N, Edim, relu);
+                       it_stride, it_save, E, mask, x, N, Edim, relu, static_cast<unsigned char *>(x_planes));
     CAPMI_CHECK_LAUNCH();
     return 0;
+}
+
+int capmi_embed_fwd(const int64_t *it, int it_stride, int64_t *it_save, const float *E, const float *mask, float *x,
+                    int N, int Edim, int relu, void *stream) {
+    return capmi_embed_fwd_pl(it, it_stride, it_save, E, mask, x, N, Edim, relu, nullptr, stream);
 }
 
 int capmi_embed_bwd(const int64_t *it, const float *dx, const float *x_saved, const float *mask, float *dE, int rows,
@@ -480,35 +561,64 @@ int capmi_embed_bwd(const int64_t *it, const float *dx, const float *x_saved, co
     return 0;
 }
 
+int capmi_lstm_cell_fwd_pl(const float *partial, int splits, const float *b_ih, const float *b_hh, const float *row_bias,
+                           int row_bias_div, const int32_t *row_bias_idx, const float *c_prev, float *h, float *c,
+                           float *gates_act, const float *out_mask, float *h_drop, int N, int R, void *h_planes,
+                           void *h_drop_planes, void *stream) {
+    if (!partial || splits < 1 || !c_prev || !h || !c || N <= 0 || R <= 0) return CAPMI_EINVAL;
+    if ((h_planes || h_drop_planes) && N > 64) return CAPMI_EINVAL;
+    unsigned char *pl_h = static_cast<unsigned char *>(h_planes), *pl_hd = static_cast<unsigned char *>(h_drop_planes);
+    const int rbd = row_bias_div > 0 ? row_bias_div : 1;
+    if ((pl_h || pl_hd) && R % 4 == 0 &&
+        aligned16(partial, b_ih, b_hh, row_bias, c_prev, h, c, gates_act, out_mask, h_drop)) {
+        const int quads = N * (R / 4);
+        hipLaunchKernelGGL(lstm_cell_fwd_vec_kernel, dim3((quads + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, splits,
+                           b_ih, b_hh, row_bias, rbd, row_bias_idx, c_prev, h, c, gates_act, out_mask, h_drop, N, R, pl_h, pl_hd);
+        CAPMI_CHECK_LAUNCH();
+        return 0;
+    }
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid_for((size_t)N * R)), dim3(256), 0, (hipStream_t)stream, partial,
+                       splits, b_ih, b_hh, row_bias, rbd, row_bias_idx, c_prev, h, c, gates_act, out_mask, h_drop, N, R, pl_h,
+                       pl_hd);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
 int capmi_lstm_cell_fwd(const float *partial, int splits, const float *b_ih, const float *b_hh, const float *row_bias,
                         int row_bias_div, const int32_t *row_bias_idx, const float *c_prev, float *h, float *c, float *gates_act,
                         const float *out_mask, float *h_drop, int N, int R, void *stream) {
-    if (!partial || splits < 1 || !c_prev || !h || !c || N <= 0 || R <= 0) return CAPMI_EINVAL;
-    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid_for((size_t)N * R)), dim3(256), 0, (hipStream_t)stream, partial,
-                       splits, b_ih, b_hh, row_bias, row_bias_div > 0 ? row_bias_div : 1, row_bias_idx, c_prev, h, c, gates_act,
-                       out_mask, h_drop, N, R);
-    CAPMI_CHECK_LAUNCH();
-    return 0;
+    return capmi_lstm_cell_fwd_pl(partial, splits, b_ih, b_hh, row_bias, row_bias_div, row_bias_idx, c_prev, h, c, gates_act,
+                                  out_mask, h_drop, N, R, nullptr, nullptr, stream);
 }
 
 int capmi_lstm_cell_bwd_partial(const float *dh_a, int ld_a, const float *dh_a_mask, const float *dh_b, int ld_b,
                                 int b_splits, int64_t b_stride, const float *dh_c, int ld_c, int c_splits,
                                 int64_t c_stride, const float *dc_next, const float *gates_act, const float *c_prev,
                                 const float *c_new, float *d_gates, float *dc_prev, int N, int R, void *stream) {
+    return capmi_lstm_cell_bwd_partial_pl(dh_a, ld_a, dh_a_mask, dh_b, ld_b, b_splits, b_stride, dh_c, ld_c, c_splits, c_stride,
+                                          dc_next, gates_act, c_prev, c_new, d_gates, dc_prev, N, R, nullptr, stream);
+}
+
+int capmi_lstm_cell_bwd_partial_pl(const float *dh_a, int ld_a, const float *dh_a_mask, const float *dh_b, int ld_b,
+                                   int b_splits, int64_t b_stride, const float *dh_c, int ld_c, int c_splits,
+                                   int64_t c_stride, const float *dc_next, const float *gates_act, const float *c_prev,
+                                   const float *c_new, float *d_gates, float *dc_prev, int N, int R, void *d_gates_planes,
+                                   void *stream) {
     if (!gates_act || !c_prev || !c_new || !d_gates || !dc_prev || N <= 0 || R <= 0) return CAPMI_EINVAL;
-    if ((dh_b && b_splits < 1) || (dh_c && c_splits < 1)) return CAPMI_EINVAL;
+    if ((dh_b && b_splits < 1) || (dh_c && c_splits < 1) || (d_gates_planes && N > 64)) return CAPMI_EINVAL;
+    unsigned char *pl_dg = static_cast<unsigned char *>(d_gates_planes);
     if (R % 4 == 0 && ld_a % 4 == 0 && ld_b % 4 == 0 && ld_c % 4 == 0 && b_stride % 4 == 0 && c_stride % 4 == 0 &&
         aligned16(dh_a, dh_a_mask, dh_b, dh_c, dc_next, gates_act, c_prev, c_new, d_gates, dc_prev)) {
         const int quads = N * (R / 4);
         hipLaunchKernelGGL(lstm_cell_bwd_vec_kernel, dim3((quads + 63) / 64), dim3(64), 0, (hipStream_t)stream, dh_a, ld_a,
                            dh_a_mask, dh_b, ld_b, b_splits, (size_t)b_stride, dh_c, ld_c, c_splits, (size_t)c_stride, dc_next,
-                           gates_act, c_prev, c_new, d_gates, dc_prev, N, R);
+                           gates_act, c_prev, c_new, d_gates, dc_prev, N, R, pl_dg);
         CAPMI_CHECK_LAUNCH();
         return 0;
     }
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for((size_t)N * R)), dim3(256), 0, (hipStream_t)stream, dh_a,
                        ld_a, dh_a_mask, dh_b, ld_b, b_splits, (size_t)b_stride, dh_c, ld_c, c_splits, (size_t)c_stride,
-                       dc_next, gates_act, c_prev, c_new, d_gates, dc_prev, N, R);
+                       dc_next, gates_act, c_prev, c_new, d_gates, dc_prev, N, R, pl_dg);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

@@ -30,19 +30,26 @@ struct SegSpec {
     int ldb;
     int K;
     int a_row_div;
+    const void *Apl;        // the same activations as A planes (capmi.h capmi_planes_from_f32), or null
 };
+
+// chunk images of a K-wide planes buffer
+inline int64_t pl_chunks(int K) { return (K + 31) / 32; }
+constexpr int64_t PL_CHUNK = 12288;
 
 // C[M,N] = sum_s A_s op B_s ; thin wrapper filling capmi_gemm_desc
 int gemm(void *stream, int a_layout, int b_layout, int M, int N, float *C, int ldc, const SegSpec *segs, int nseg,
          float *partial, int64_t cap, int defer, int *splits_used, const float *bias = nullptr,
-         const float *bias2 = nullptr, int accumulate = 0) {
+         const float *bias2 = nullptr, int accumulate = 0, const void *zero_planes = nullptr) {
     capmi_gemm_desc d{};
     d.nseg = nseg;
     for (int i = 0; i < nseg; ++i) {
         d.seg[i].A = segs[i].A; d.seg[i].lda = segs[i].lda;
         d.seg[i].B = segs[i].B; d.seg[i].ldb = segs[i].ldb;
         d.seg[i].K = segs[i].K; d.seg[i].a_row_div = segs[i].a_row_div > 0 ? segs[i].a_row_div : 1;
+        d.a_planes[i] = zero_planes ? segs[i].Apl : nullptr;
     }
+    d.zero_planes = zero_planes;
     d.a_layout = a_layout; d.b_layout = b_layout;
     d.M = M; d.N = N; d.C = C; d.ldc = ldc;
     d.bias = bias; d.bias2 = bias2;
@@ -142,6 +149,12 @@ __global__ void teacher_bookkeep_kernel(const float *__restrict__ seq_logp, cons
 extern "C" {
 
 int capmi_version(void) { return 1; }
+
+int64_t capmi_updown_planes_bytes(int R, int E) {
+    const int64_t nR = pl_chunks(R), nE = pl_chunks(E);
+    return (4 * nR + nE + (nR > nE ? nR : nE)) * PL_CHUNK;
+}
+int64_t capmi_updown_bwd_planes_bytes(int R) { return (2 * pl_chunks(4 * R) + 1) * PL_CHUNK; }
 const char *capmi_arch(void) { return "gfx950"; }
 
 int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout *r, void *stream) {
@@ -161,6 +174,18 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
     const bool sched = r->teacher && r->ss_mode;
     const bool batched_logit = r->teacher && !sched && T == L && r->seq_logp &&
                                (int64_t)N * T * R <= r->partial_capacity - CAPMI_WS_COUNTER_FLOATS;
+
+    // A planes of the step's activations (round 3, N <= 64): [h_att | h_lang | ctx | h_drop | xt | zero]; the zero image also
+    // stands in for the all-zero state of step 0
+    unsigned char *pl_h_att = nullptr, *pl_h_lang = nullptr, *pl_ctx = nullptr, *pl_h_drop = nullptr, *pl_xt = nullptr,
+                  *pl_zero = nullptr;
+    if (r->planes && N <= 64 && r->planes_bytes >= capmi_updown_planes_bytes(R, E) &&
+        (reinterpret_cast<uintptr_t>(r->planes) & 15) == 0) {
+        unsigned char *q = static_cast<unsigned char *>(r->planes);
+        const int64_t nR = pl_chunks(R) * PL_CHUNK, nE = pl_chunks(E) * PL_CHUNK;
+        pl_h_att = q; pl_h_lang = q + nR; pl_ctx = q + 2 * nR; pl_h_drop = q + 3 * nR; pl_xt = q + 4 * nR;
+        pl_zero = q + 4 * nR + nE;
+    }
 
     // initial state (slot 0) and flags
     RC(capmi_rollout_init(r->h_att, r->c_att, r->h_lang, r->c_lang, (int64_t)NR, r->it, r->unfinished, N, stream));   // bos = 0
@@ -186,46 +211,52 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
         // 1. token embedding (+ReLU +dropout).  Free-running rollouts: only step 0 launches it (BOS); afterwards the
         //    select kernel of step t-1 has already written xt (the workgroup that chose the token embeds it).
         if (r->teacher && (!sched || t == 0))
-            RC(capmi_embed_fwd(r->forced + t, r->forced_ld, r->it_all ? r->it_all + (size_t)t * N : nullptr, w->embed,
-                               r->drop_xt ? r->drop_xt + (size_t)t * N * E : nullptr, xt, N, E, 1, stream));
+            RC(capmi_embed_fwd_pl(r->forced + t, r->forced_ld, r->it_all ? r->it_all + (size_t)t * N : nullptr, w->embed,
+                                  r->drop_xt ? r->drop_xt + (size_t)t * N * E : nullptr, xt, N, E, 1, pl_xt, stream));
         else if (t == 0)
-            RC(capmi_embed_fwd(r->it, 1, r->it_all ? r->it_all + (size_t)t * N : nullptr, w->embed,
-                               r->drop_xt ? r->drop_xt + (size_t)t * N * E : nullptr, xt, N, E, 1, stream));
+            RC(capmi_embed_fwd_pl(r->it, 1, r->it_all ? r->it_all + (size_t)t * N : nullptr, w->embed,
+                                  r->drop_xt ? r->drop_xt + (size_t)t * N * E : nullptr, xt, N, E, 1, pl_xt, stream));
 
         // 2-3. attention LSTM: gates = [h_lang_prev | xt | h_att_prev] . [W_ih(:, 0:R) | W_ih(:, 2R:) | W_hh]
         {
-            SegSpec s[3] = {{h_lang_prev, R, w->att_w_ih, ld_att_ih, R, 1},
-                            {xt, E, w->att_w_ih + 2 * R, ld_att_ih, E, 1},
-                            {h_att_prev, R, w->att_w_hh, R, R, 1}};
-            RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s, 3, r->partial, r->partial_capacity, 1, &splits));
-            RC(capmi_lstm_cell_fwd(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, w->att_b_ih, w->att_b_hh, r->fc_gates, n, r->row_img, c_att_prev, h_att, c_att,
-                                   r->gates_att + (size_t)t * N * 4 * R, nullptr, nullptr, N, R, stream));
+            SegSpec s[3] = {{h_lang_prev, R, w->att_w_ih, ld_att_ih, R, 1, t ? pl_h_lang : pl_zero},
+                            {xt, E, w->att_w_ih + 2 * R, ld_att_ih, E, 1, pl_xt},
+                            {h_att_prev, R, w->att_w_hh, R, R, 1, t ? pl_h_att : pl_zero}};
+            RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s, 3, r->partial, r->partial_capacity, 1, &splits, nullptr,
+                    nullptr, 0, pl_zero));
+            RC(capmi_lstm_cell_fwd_pl(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, w->att_b_ih, w->att_b_hh, r->fc_gates, n,
+                                      r->row_img, c_att_prev, h_att, c_att, r->gates_att + (size_t)t * N * 4 * R, nullptr, nullptr,
+                                      N, R, pl_h_att, nullptr, stream));
         }
         // 4-5. att_h = h_att W_h2att^T + b left as K-slice slabs; the fused region attention finishes the reduction
         //      (+ bias), keeps att_h for the backward pass and runs score + softmax + context
         {
-            SegSpec s{h_att, R, w->h2att_w, R, R, 1};
-            RC(gemm(stream, 0, 0, N, A, r->partial, A, &s, 1, r->partial, r->partial_capacity, 1, &splits));
+            SegSpec s{h_att, R, w->h2att_w, R, R, 1, pl_h_att};
+            RC(gemm(stream, 0, 0, N, A, r->partial, A, &s, 1, r->partial, r->partial_capacity, 1, &splits, nullptr, nullptr, 0,
+                    pl_zero));
         }
-        RC(capmi_attention_fwd_partial(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, (int64_t)N * A, w->h2att_b, att_h,
-                                       r->p_att, r->att, r->att_mask, w->alpha_w, w->alpha_b, ctx, alpha, B_feat, n, K, A, R,
-                                       r->row_img, N, stream));
+        RC(capmi_attention_fwd_partial_pl(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, (int64_t)N * A, w->h2att_b, att_h,
+                                          r->p_att, r->att, r->att_mask, w->alpha_w, w->alpha_b, ctx, alpha, B_feat, n, K, A, R,
+                                          r->row_img, N, pl_ctx, stream));
         // 6-7. language LSTM: gates = [ctx | h_att | h_lang_prev] . [W_ih(:, 0:R) | W_ih(:, R:2R) | W_hh]
         {
-            SegSpec s[3] = {{ctx, R, w->lang_w_ih, 2 * R, R, 1},
-                            {h_att, R, w->lang_w_ih + R, 2 * R, R, 1},
-                            {h_lang_prev, R, w->lang_w_hh, R, R, 1}};
-            RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s, 3, r->partial, r->partial_capacity, 1, &splits));
-            RC(capmi_lstm_cell_fwd(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, w->lang_b_ih, w->lang_b_hh, nullptr, 1, nullptr, c_lang_prev, h_lang, c_lang,
-                                   r->gates_lang + (size_t)t * N * 4 * R,
-                                   r->drop_out ? r->drop_out + (size_t)t * NR : nullptr, h_drop, N, R, stream));
+            SegSpec s[3] = {{ctx, R, w->lang_w_ih, 2 * R, R, 1, pl_ctx},
+                            {h_att, R, w->lang_w_ih + R, 2 * R, R, 1, pl_h_att},
+                            {h_lang_prev, R, w->lang_w_hh, R, R, 1, t ? pl_h_lang : pl_zero}};
+            RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s, 3, r->partial, r->partial_capacity, 1, &splits, nullptr,
+                    nullptr, 0, pl_zero));
+            RC(capmi_lstm_cell_fwd_pl(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, w->lang_b_ih, w->lang_b_hh, nullptr, 1, nullptr,
+                                      c_lang_prev, h_lang, c_lang, r->gates_lang + (size_t)t * N * 4 * R,
+                                      r->drop_out ? r->drop_out + (size_t)t * NR : nullptr, h_drop, N, R, pl_h_lang,
+                                      batched_logit ? nullptr : pl_h_drop, stream));
         }
         if (batched_logit) continue;
         // 8-9. vocabulary projection left as K-slice slabs; log-softmax + choice + bookkeeping assemble the row
         //      (slabs + bias) in registers: no split-K reduce launch, no logits round trip
         {
-            SegSpec s{h_drop, R, w->logit_w, R, R, 1};
-            RC(gemm(stream, 0, 0, N, V1, r->partial, V1, &s, 1, r->partial, r->partial_capacity, 1, &splits));
+            SegSpec s{h_drop, R, w->logit_w, R, R, 1, pl_h_drop};
+            RC(gemm(stream, 0, 0, N, V1, r->partial, V1, &s, 1, r->partial, r->partial_capacity, 1, &splits, nullptr, nullptr, 0,
+                    pl_zero));
         }
         capmi_sample_filter flt{r->top_k, r->top_p};
         capmi_next_embed ne{};
@@ -234,6 +265,7 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
             ne.mask = r->drop_xt ? r->drop_xt + (size_t)(t + 1) * N * E : nullptr;
             ne.x = r->xt + (size_t)(t + 1) * N * E;
             ne.it_save = r->it_all ? r->it_all + (size_t)(t + 1) * N : nullptr;
+            ne.x_planes = pl_xt;
         }
         if (sched && t + 1 < T) {
             // AttModel.py:145-154: the token chosen here is the INPUT of step t+1 -- forced[:, t+1] (mode 2 rows) or a
@@ -388,6 +420,14 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         if (e == hipSuccess) e = hipMemsetAsync(Ph, 0, CAPMI_WS_COUNTER_FLOATS * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
+    // A planes of d_gates (round 3, <= 64 gradient rows): [dg_lang | dg_att | one zero image]
+    unsigned char *pl_dg_lang = nullptr, *pl_dg_att = nullptr, *pl_zero = nullptr;
+    if (s->planes && N <= 64 && s->planes_bytes >= capmi_updown_bwd_planes_bytes(R) &&
+        (reinterpret_cast<uintptr_t>(s->planes) & 15) == 0) {
+        unsigned char *q = static_cast<unsigned char *>(s->planes);
+        const int64_t n4 = pl_chunks(4 * R) * PL_CHUNK;
+        pl_dg_lang = q; pl_dg_att = q + n4; pl_zero = q + 2 * n4;
+    }
     const float *x1_slabs = P1 + CAPMI_WS_COUNTER_FLOATS, *h_slabs = Ph + CAPMI_WS_COUNTER_FLOATS;
     const int64_t x1_stride = (int64_t)N * 2 * R, h_stride = (int64_t)NR;
     int x1_splits = 1, h_splits = 1;
@@ -402,17 +442,17 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
 
         // language LSTM cell: dh = d_hdrop*mask + dh_lang(att-LSTM input of step t+1: d_x1 slabs, columns 0..R)
         //                          + dh_lang(own W_hh, t+1)
-        RC(capmi_lstm_cell_bwd_partial(s->d_hdrop + (size_t)t * NR, R, r->drop_out ? r->drop_out + (size_t)t * NRf : nullptr,
-                                       last ? nullptr : x1_slabs, 2 * R, x1_splits, x1_stride,
-                                       d_x2_next ? d_x2_next + 2 * R : nullptr, 3 * R, 1, 0, last ? nullptr : dc_lang_in,
-                                       r->gates_lang + (size_t)t * Nf * 4 * R, r->c_lang + (size_t)t * NRf,
-                                       r->c_lang + (size_t)(t + 1) * NRf, dg_lang, dc_lang_out, N, R, stream));
+        RC(capmi_lstm_cell_bwd_partial_pl(s->d_hdrop + (size_t)t * NR, R, r->drop_out ? r->drop_out + (size_t)t * NRf : nullptr,
+                                          last ? nullptr : x1_slabs, 2 * R, x1_splits, x1_stride,
+                                          d_x2_next ? d_x2_next + 2 * R : nullptr, 3 * R, 1, 0, last ? nullptr : dc_lang_in,
+                                          r->gates_lang + (size_t)t * Nf * 4 * R, r->c_lang + (size_t)t * NRf,
+                                          r->c_lang + (size_t)(t + 1) * NRf, dg_lang, dc_lang_out, N, R, pl_dg_lang, stream));
         // d_x2 = dg_lang [W_ih | W_hh]  -> (d_ctx | dh_att | dh_lang_prev), left as slabs; the attention Jacobian
         // (d_ctx -> d_att_h, and d_e kept for the batched pass) finishes the reduction of its rows and publishes d_x2
         int x2_splits = 1;
         {
-            SegSpec a{dg_lang, 4 * R, s->w_lang_cat, 3 * R, 4 * R, 1};
-            RC(gemm(stream, 0, 1, N, 3 * R, P, 3 * R, &a, 1, P, capm, 1, &x2_splits));
+            SegSpec a{dg_lang, 4 * R, s->w_lang_cat, 3 * R, 4 * R, 1, pl_dg_lang};
+            RC(gemm(stream, 0, 1, N, 3 * R, P, 3 * R, &a, 1, P, capm, 1, &x2_splits, nullptr, nullptr, 0, pl_zero));
         }
         RC(capmi_attention_bwd_partial(P + CAPMI_WS_COUNTER_FLOATS, x2_splits, (int64_t)N * 3 * R, 3 * R, d_x2,
                                        r->att_h + (size_t)t * Nf * A, r->alpha + (size_t)t * Nf * K, r->p_att, r->att,
@@ -424,15 +464,15 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         }
         // attention LSTM cell: dh = dh_att(lang input) + dh_att(attention: slabs) + dh_att(own W_hh, t+1: d_x1 slabs,
         // columns R..2R)
-        RC(capmi_lstm_cell_bwd_partial(d_x2 + R, 3 * R, nullptr, h_slabs, R, h_splits, h_stride,
-                                       last ? nullptr : x1_slabs + R, 2 * R, x1_splits, x1_stride,
-                                       last ? nullptr : dc_att_in, r->gates_att + (size_t)t * Nf * 4 * R,
-                                       r->c_att + (size_t)t * NRf, r->c_att + (size_t)(t + 1) * NRf, dg_att, dc_att_out, N, R,
-                                       stream));
+        RC(capmi_lstm_cell_bwd_partial_pl(d_x2 + R, 3 * R, nullptr, h_slabs, R, h_splits, h_stride,
+                                          last ? nullptr : x1_slabs + R, 2 * R, x1_splits, x1_stride,
+                                          last ? nullptr : dc_att_in, r->gates_att + (size_t)t * Nf * 4 * R,
+                                          r->c_att + (size_t)t * NRf, r->c_att + (size_t)(t + 1) * NRf, dg_att, dc_att_out, N, R,
+                                          t > 0 ? pl_dg_att : nullptr, stream));
         // d_x1 = dg_att [W_ih(:, 0:R) | W_hh] -> (dh_lang_prev | dh_att_prev) as slabs for step t-1; not needed at t = 0
         if (t > 0) {
-            SegSpec a{dg_att, 4 * R, s->w_att_cat, 2 * R, 4 * R, 1};
-            RC(gemm(stream, 0, 1, N, 2 * R, P1, 2 * R, &a, 1, P1, cap1, 1, &x1_splits));
+            SegSpec a{dg_att, 4 * R, s->w_att_cat, 2 * R, 4 * R, 1, pl_dg_att};
+            RC(gemm(stream, 0, 1, N, 2 * R, P1, 2 * R, &a, 1, P1, cap1, 1, &x1_splits, nullptr, nullptr, 0, pl_zero));
         }
     }
 

@@ -50,6 +50,7 @@ struct NextEmbed {
     float *x;
     int64_t *it_save;
     int Edim, relu;
+    unsigned char *pl;      // A planes of x (rows <= 64) for the next step's gate GEMM, or null
 };
 __device__ __forceinline__ void emit_next_embed(const NextEmbed &ne, int r, int token) {
     if (!ne.x) return;
@@ -59,6 +60,7 @@ __device__ __forceinline__ void emit_next_embed(const NextEmbed &ne, int r, int 
         if (ne.relu) v = fmaxf(v, 0.f);
         if (ne.mask) v *= ne.mask[(size_t)r * ne.Edim + c];
         ne.x[(size_t)r * ne.Edim + c] = v;
+        if (ne.pl) capmi::pl_store1(ne.pl, r, c, v);
     }
     if (threadIdx.x == 0 && ne.it_save) ne.it_save[r] = token;
 }
@@ -531,7 +533,9 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
     NextEmbed ne{};
     if (next && next->x) {
         if (!next->E || next->Edim <= 0) return CAPMI_EINVAL;
-        ne = NextEmbed{next->E, next->mask, next->x, next->it_save, next->Edim, next->relu};
+        if (next->x_planes && N > 64) return CAPMI_EINVAL;
+        ne = NextEmbed{next->E, next->mask, next->x, next->it_save, next->Edim, next->relu,
+                       static_cast<unsigned char *>(next->x_planes)};
     }
     const bool al = ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(bias) |
                       reinterpret_cast<uintptr_t>(gumbel) | reinterpret_cast<uintptr_t>(seq_logp)) & 15) == 0 &&

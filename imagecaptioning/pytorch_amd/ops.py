@@ -50,11 +50,17 @@ def default_workspace(device):
 
 
 def gemm(segs, M, N, out, ldc=None, a_layout=0, b_layout=0, bias=None, bias2=None, row_bias=None, row_bias_div=1,
-         mul_mask=None, relu=False, accumulate=False, ws=None, splits=0, defer_reduce=False):
+         mul_mask=None, relu=False, accumulate=False, ws=None, splits=0, defer_reduce=False, a_planes=None):
     """segs: list of (A, lda, B, ldb, K, a_row_div) with tensors (or (tensor, element_offset) pairs).
-    Returns splits_used."""
+    a_planes: optional list (one uint8 tensor per segment, see planes_from_f32) -- the activations also delivered pre-split,
+    staged by LDS-DMA in the M <= 64 decode kernel.  Returns splits_used."""
     d = _lib.GemmDesc()
     d.nseg = len(segs)
+    if a_planes is not None:
+        assert len(a_planes) == len(segs)
+        for i, t in enumerate(a_planes):
+            d.a_planes[i] = t.data_ptr()
+        d.zero_planes = zero_planes(_dev(out)).data_ptr()
     for i, (A, lda, B, ldb, K, div) in enumerate(segs):
         d.seg[i].A = _addr(A)
         d.seg[i].B = _addr(B)
@@ -72,6 +78,39 @@ def gemm(segs, M, N, out, ldc=None, a_layout=0, b_layout=0, bias=None, bias2=Non
     d.splits, d.defer_reduce = splits, int(defer_reduce)
     check(lib.capmi_gemm_f32(C.byref(d), stream_ptr()), 'capmi_gemm_f32')
     return d.splits_used
+
+
+_zero_planes = {}
+_planes_cache = {}
+
+
+def zero_planes(device, chunks=1):
+    """>= `chunks` all-zero chunk images (the padding operand of the A-planes GEMM), allocated once per device."""
+    key = str(device)
+    t = _zero_planes.get(key)
+    if t is None or t.numel() < chunks * 12288:
+        t = _zero_planes[key] = torch.zeros(max(chunks, 4) * 12288, dtype=torch.uint8, device=device)
+    return t
+
+
+def planes_scratch(device, tag, nbytes):
+    """Zero-filled-once scratch for A planes, cached per (device, tag, size): rows >= M / columns >= K of a planes buffer are
+    never written, so a buffer keeps its zero padding across the rollouts that reuse it."""
+    key = (str(device), tag, int(nbytes))
+    t = _planes_cache.get(key)
+    if t is None:
+        t = _planes_cache[key] = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+    return t
+
+
+def planes_from_f32(x, out=None):
+    """A planes (capmi.h capmi_planes_from_f32) of a [M <= 64, K] fp32 matrix (row stride = x.stride(0))."""
+    M, K = x.shape
+    assert x.is_cuda and x.dtype == _f32 and x.stride(1) == 1 and M <= 64
+    if out is None:
+        out = torch.zeros(int(lib.capmi_planes_bytes(K)), dtype=torch.uint8, device=x.device)
+    check(lib.capmi_planes_from_f32(x.data_ptr(), x.stride(0), M, K, out.data_ptr(), stream_ptr()), 'capmi_planes_from_f32')
+    return out
 
 
 def _addr(x):

@@ -173,6 +173,12 @@ class Rollout:
                   'ctx', 'h_drop', 'seq', 'seq_logp', 'sel_logp', 'live', 'fc_gates', 'logits', 'it', 'unfinished'):
             setattr(r, k, getattr(self, k).data_ptr())
         r.partial, r.partial_capacity = self.ws.buf.data_ptr(), self.ws.capacity
+        if N <= 64 and os.environ.get('CAPMI_APL', '1') != '0':
+            # decode GEMMs stage their activations as producer-written bf16x3 planes (capmi.h capmi_updown_rollout.planes);
+            # the scratch is zero-filled once and shared by the rollouts of this stream with the same R / E
+            nb = int(lib.capmi_updown_planes_bytes(R, E))
+            self.planes = ops.planes_scratch(dev, ('updown_fwd', R, E, stream_ptr()), nb)
+            r.planes, r.planes_bytes = self.planes.data_ptr(), nb
         self.r = r
         self.w = weights_struct(P)
 
@@ -212,6 +218,10 @@ class Rollout:
             nb = B * n
             keep['pack'] = z(nb * (T * (4 * R + 2 * E + 2 + A + K) + R) + 64)
             s.n_grad_rows, s.pack, s.pack_capacity = nb, keep['pack'].data_ptr(), keep['pack'].numel()
+        if (s.n_grad_rows or N) <= 64 and os.environ.get('CAPMI_APL', '1') != '0':
+            nb = int(lib.capmi_updown_bwd_planes_bytes(R))
+            keep['planes'] = ops.planes_scratch(dev, ('updown_bwd', R, stream_ptr()), nb)
+            s.planes, s.planes_bytes = keep['planes'].data_ptr(), nb
         g = _lib.UpDownGrads()
         for f, k in _W_FIELDS:
             setattr(g, f, grads[k].data_ptr())

@@ -85,9 +85,23 @@ typedef struct capmi_gemm_desc {
     int splits;                 /* 0 = auto */
     int defer_reduce;           /* leave partials for a fused consumer (e.g. capmi_lstm_cell_fwd) */
     int splits_used;            /* out: number of K slices actually written */
+    /* optional (round 3, M <= 64 decode GEMMs): segment s's activations ALSO delivered pre-split as "A planes" (see
+     * capmi_planes_from_f32); with planes for every segment and zero_planes (>= capmi_planes_bytes(32) bytes of zeros) the
+     * activations are staged by LDS-DMA instead of being split inside every workgroup.  Same result bit for bit. */
+    const void *a_planes[CAPMI_MAX_SEG];
+    const void *zero_planes;
 } capmi_gemm_desc;
 
 int capmi_gemm_f32(capmi_gemm_desc *d, void *stream);
+
+/* "A planes" of an activation matrix X[M <= 64, K] (row pitch ld): K in chunks of 32, chunk = [3 planes][64 rows][32 bf16],
+ * x = h + m + l split exactly into three truncated bf16 values, 16-byte pieces of a row XOR-swizzled by (row >> 2) & 3 -- the
+ * LDS image the decode GEMM reads its MFMA fragments from.  The buffer (capmi_planes_bytes(K) bytes, 16-byte aligned) must
+ * be zero-filled ONCE when it is allocated: rows >= M and columns >= K are never written.  On the hot path the producers of
+ * the activations (capmi_lstm_cell_fwd_pl, capmi_attention_fwd_partial_pl, the select kernel's next-token embedding,
+ * capmi_lstm_cell_bwd_partial_pl) write the planes themselves; this call converts any other operand. */
+int64_t capmi_planes_bytes(int K);
+int capmi_planes_from_f32(const float *X, int ld, int M, int K, void *planes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused additive region attention, forward (AttModel.py:728-748 Attention.forward; the
@@ -113,6 +127,12 @@ int capmi_attention_fwd_partial(const float *h_partial, int h_splits, int64_t h_
                                 float *att_h_out, const float *p_att, const float *att, const float *mask,
                                 const float *w, const float *b, float *ctx, float *alpha,
                                 int B, int n, int K, int A, int R, const int32_t *row_img, int N, void *stream);
+/* Same; ctx is also written as "A planes" (capmi_planes_from_f32 layout, N <= 64) for the language-LSTM gate GEMM. */
+int capmi_attention_fwd_partial_pl(const float *h_partial, int h_splits, int64_t h_stride, const float *h_bias,
+                                   float *att_h_out, const float *p_att, const float *att, const float *mask,
+                                   const float *w, const float *b, float *ctx, float *alpha,
+                                   int B, int n, int K, int A, int R, const int32_t *row_img, int N, void *ctx_planes,
+                                   void *stream);
 
 /* backward of the above for one time step.  Inputs d_ctx [N,R] plus the saved att_h/alpha.
  * Outputs d_att_h [N,A] (feeds h2att backward) and d_e [N,K] (softmax-input gradient, kept for the
@@ -155,6 +175,12 @@ int capmi_lstm_cell_fwd(const float *partial, int splits, const float *b_ih, con
                         const float *row_bias, int row_bias_div, const int32_t *row_bias_idx, const float *c_prev,
                         float *h, float *c, float *gates_act, const float *out_mask, float *h_drop,
                         int N, int R, void *stream);
+/* Same; h and / or h_drop are also written as "A planes" (capmi_planes_from_f32 layout, N <= 64, either may be NULL) for the
+ * GEMMs that consume them next (h2att + both LSTM gate GEMMs / the vocabulary projection). */
+int capmi_lstm_cell_fwd_pl(const float *partial, int splits, const float *b_ih, const float *b_hh,
+                           const float *row_bias, int row_bias_div, const int32_t *row_bias_idx, const float *c_prev,
+                           float *h, float *c, float *gates_act, const float *out_mask, float *h_drop,
+                           int N, int R, void *h_planes, void *h_drop_planes, void *stream);
 
 /* backward: given dh (total gradient reaching h'), dc_next (gradient reaching c' from step t+1),
  * the saved activated gates, c_prev and c': d_gates [N,4R] (pre-activation) and dc_prev [N,R].
@@ -171,11 +197,21 @@ int capmi_lstm_cell_bwd_partial(const float *dh_a, int ld_a, const float *dh_a_m
                                 const float *dh_c, int ld_c, int c_splits, int64_t c_stride,
                                 const float *dc_next, const float *gates_act, const float *c_prev,
                                 const float *c_new, float *d_gates, float *dc_prev, int N, int R, void *stream);
+/* Same; d_gates [N,4R] is also written as "A planes" (N <= 64) for the dX GEMM of the BPTT step. */
+int capmi_lstm_cell_bwd_partial_pl(const float *dh_a, int ld_a, const float *dh_a_mask,
+                                   const float *dh_b, int ld_b, int b_splits, int64_t b_stride,
+                                   const float *dh_c, int ld_c, int c_splits, int64_t c_stride,
+                                   const float *dc_next, const float *gates_act, const float *c_prev,
+                                   const float *c_new, float *d_gates, float *dc_prev, int N, int R,
+                                   void *d_gates_planes, void *stream);
 
 /* token embedding: x[r,:] = relu(E[it[r],:]) * mask[r,:]  (AttModel.py:74-76,168). relu/mask optional. */
 /* it[r*it_stride] is row r's token; it_save [N] (optional) records the tokens consumed. */
 int capmi_embed_fwd(const int64_t *it, int it_stride, int64_t *it_save, const float *E, const float *mask,
                     float *x, int N, int Edim, int relu, void *stream);
+/* Same; x is also written as "A planes" (N <= 64) for the attention-LSTM gate GEMM. */
+int capmi_embed_fwd_pl(const int64_t *it, int it_stride, int64_t *it_save, const float *E, const float *mask,
+                       float *x, int N, int Edim, int relu, void *x_planes, void *stream);
 /* scatter-add backward into dE [V1,Edim] (caller zeroes dE): dE[it[r]] += dx[r]*mask[r]*(x[r]>0) */
 int capmi_embed_bwd(const int64_t *it, const float *dx, const float *x_saved, const float *mask,
                     float *dE, int rows, int Edim, int relu, void *stream);
@@ -212,6 +248,7 @@ typedef struct {
     int64_t *it_save;    /* [N] or NULL */
     int Edim;
     int relu;
+    void *x_planes;      /* optional (N <= 64): the same rows also as "A planes" (capmi_planes_from_f32) for the next gate GEMM */
 } capmi_next_embed;
 
 /* Optional top-k / nucleus filter of the sampling modes (CaptionModel.sample_next_word, CaptionModel.py:388-404,
@@ -445,7 +482,15 @@ typedef struct capmi_updown_rollout {
      * token of row r at step t comes from: 2 = forced[r, t] (teacher forcing), 1 = a draw from the model's own distribution
      * of step t-1 (torch.multinomial(exp(outputs[:, t-1])), here Gumbel-max at temperature 1).  Row t = 0 is ignored (BOS). */
     const uint8_t *ss_mode;
+    /* Round 3, optional (N <= 64): scratch for the "A planes" of the step's activations (h_att, h_lang, ctx, xt, h_drop + a zero
+     * image; capmi_updown_planes_bytes(R, E) bytes, 16-byte aligned, ZERO-FILLED ONCE by the caller when it is allocated and
+     * reusable by later rollouts of the same R / E).  With it the producers of the activations write the bf16x3 planes the
+     * gate / logit GEMMs stage by LDS-DMA (capmi_gemm_desc.a_planes); NULL keeps the in-GEMM split.  Same results. */
+    void *planes;
+    int64_t planes_bytes;
 } capmi_updown_rollout;
+
+int64_t capmi_updown_planes_bytes(int R, int E);
 
 int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout *r, void *stream);
 
@@ -486,7 +531,14 @@ typedef struct capmi_updown_bwd_scratch {
     int n_grad_rows;
     float *pack;
     int64_t pack_capacity;
+    /* Round 3, optional (gradient rows <= 64): scratch for the A planes of d_gates of the two LSTM cells + a zero image
+     * (capmi_updown_bwd_planes_bytes(R) bytes, zero-filled once by the caller); the dX GEMMs of the BPTT then stage their
+     * activations by LDS-DMA.  NULL keeps the in-GEMM split. */
+    void *planes;
+    int64_t planes_bytes;
 } capmi_updown_bwd_scratch;
+
+int64_t capmi_updown_bwd_planes_bytes(int R);
 
 /* g_seq_logp [N,T,V1]: gradient w.r.t. the dense log-probs returned by the forward (NULL when s->sparse carries it). */
 int capmi_updown_rollout_bwd(const capmi_updown_weights *w, const capmi_updown_rollout *r,

@@ -17,7 +17,7 @@ def declared():
     src = open(HEADER).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     out = {}
-    for m in re.finditer(r'\b(?:int|const char \*)\s*(capmi_\w+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
+    for m in re.finditer(r'\b(?:int|int64_t|const char \*)\s*(capmi_\w+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
         name, args = m.group(1), m.group(2).strip()
         n = 0 if args in ('', 'void') else len([a for a in args.split(',')])
         out[name] = n
