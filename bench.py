@@ -94,13 +94,13 @@ def pmc_traffic(instance=False):
     separate rocprofv3 --pmc runs, so they cannot be sampled inside this process): profiles/r0N_pmc_traffic.json,
     written by scripts/tools_pmc_traffic.py with the gfx950 corrections of MI355X_MICROARCH.md.  None if absent."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ('r02k_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r03_pmc_traffic.json',):
         try:
             with open(os.path.join(here, 'profiles', name)) as f:
                 d = json.load(f)
-            if instance:       # the dominant kernel instance alone (LSTM-gate / logit GEMMs)
+            if instance:       # the dominant kernel alone (the weight-streaming launches of gemm_lc_kernel<true,2>: LSTM gates, logit)
                 for k, v in d['kernels'].items():
-                    if 'gemm_ares_kernel<true, 6, 2, true' in k:
+                    if 'gemm_lc_kernel<true, 2, 0> [stream]' in k:
                         return round(v['fetch_bytes_corrected'] + v['write_bytes'])
             return round(d['decode_gemm']['traffic_bytes'])
         except (OSError, KeyError, ValueError):
@@ -293,7 +293,7 @@ def main():
 
     if rank == 0:
         copy_gbs = 0.0 if args.no_prof else measured_copy_gbs(dev)     # kept out of rocprofv3 kernel tables
-        # the dominant kernel = ONE instance, gemm_ares_kernel<true,6,2,x3>: the decode-step GEMMs that stream >= 16 MB of weights
+        # the dominant kernel = ONE instance, gemm_lc_kernel<true,2> (round 3): the decode-step GEMMs that stream >= 16 MB of weights
         # (2 LSTM gate GEMMs + the logit GEMM per step; class 9).  The small decode GEMMs (h2att, prepare: class 0) are latency-
         # bound launches of the same template family and are reported together with it under `all_decode_gemms`.
         s_ms, s_n, s_bytes, s_flops = prof_read(lib, 0)
@@ -304,7 +304,7 @@ def main():
                      'gemm_decode_stream': {'ms_per_step': round(g_ms / n_sampled, 4), 'launches_per_step': g_n / n_sampled},
                      'gemm_decode_small': {'ms_per_step': round(s_ms / n_sampled, 4), 'launches_per_step': s_n / n_sampled},
                      'attention_fwd': {'ms_per_step': round(a_ms / n_sampled, 4), 'launches_per_step': a_n / n_sampled},
-                     'note': 'full per-kernel table: profiles/r02*_scst_kernel_stats.md (rocprofv3 --kernel-trace --stats)'}
+                     'note': 'full per-kernel table: profiles/r03*_scst_kernel_stats.md (rocprofv3 --kernel-trace --stats)'}
         ach = (g_bytes / g_n) / (g_ms / g_n * 1e-3) / 1e9 if g_n else 0.0
         tfl = g_flops / (g_ms * 1e-3) / 1e12 if g_ms else 0.0
         # which roof bounds this launch mix.  The decode GEMMs compute fp32 through the bf16 pipe by the exact 3-way
@@ -316,9 +316,12 @@ def main():
         ai = g_flops / g_bytes if g_bytes else 0.0
         mfma_bound = ai > mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
         all_ach = (all_bytes / all_n) / (all_ms / all_n * 1e-3) / 1e9 if all_n else 0.0
-        roofline = {'kernel': 'gemm_ares_kernel<true,6,2,x3> (LSTM-gate / logit GEMMs of the decode step: weight streaming, M<=64, '
-                              'activations resident in LDS, %s)'
-                              % ('fp32 via exact bf16x3 split, v_mfma_f32_32x32x16_bf16' if x3 else 'v_mfma_f32_32x32x2_f32'),
+        lc = os.environ.get('CAPMI_LC', '1') != '0' and os.environ.get('CAPMI_APL', '1') != '0' and x3
+        roofline = {'kernel': ('gemm_lc_kernel<true,2> (LSTM-gate / logit GEMMs of the decode step: weight streaming, M<=64; loader waves '
+                               'copy producer-written bf16x3 activation planes + fp32 weight tiles into a 5-stage LDS ring by LDS-DMA, '
+                               'consumer waves split the weights and run v_mfma_f32_32x32x16_bf16)') if lc else
+                              ('gemm_ares_kernel<true,6,2> (decode-step GEMMs, activations resident in LDS, %s)'
+                               % ('fp32 via exact bf16x3 split, v_mfma_f32_32x32x16_bf16' if x3 else 'v_mfma_f32_32x32x2_f32')),
                     'launches_per_step': g_n / n_sampled, 'sampled_launches': g_n,
                     'bound': 'mfma' if mfma_bound else 'hbm',
                     'achieved': round(tfl if mfma_bound else ach, 2),

@@ -570,7 +570,9 @@ __global__ __launch_bounds__(AR_NT) void gemm_apl_kernel(const KArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     // ---- request the weights: the whole ring before anything is waited for -----------------------------------------------
     constexpr int LPC = BKC ? 4 : 16;                // loads per chunk per lane
-    constexpr int PFD = PFM > 0 ? PFM : (BKC ? 6 : 3);            // ring slots (vmcnt counts <= 63 loads)
+    // ring slots: 2 for [N][K] weights -- deeper rings are SLOWER (measured 16.0 / 16.9 / 17.9 / 19.2 us at 2 / 3 / 4 / 6 on the gate
+    // GEMM): a wave that issues loads into a full memory queue stalls AT ISSUE and cannot run its MFMAs meanwhile
+    constexpr int PFD = PFM > 0 ? PFM : (BKC ? 2 : 3);
     constexpr int PF = TS < PFD ? TS : PFD;
     float b[PF][16];
     CAPMI_APL_STAMP(1);

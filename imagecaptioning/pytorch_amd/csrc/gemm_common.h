@@ -38,6 +38,7 @@ struct KArgs {
     int *counters;       // per-output-tile arrival tickets (in-launch split-K reduction), zero between launches
     int self_reduce;     // last-arriving K slice of a tile reduces all slices and applies the epilogue
     const unsigned char *zero_planes;   // >= one all-zero chunk image (padding K slots of the A-planes kernel)
+    int sl;              // loader / consumer kernel: K chunks per workgroup slice (runtime)
     int ablate;          // experiments only (CAPMI_GEMM_ABLATE): 1 = skip MFMA phase, 2 = skip global loads, 4 = skip LDS writes
 };
 
@@ -66,6 +67,9 @@ int launch_ares(const KArgs &a, int b_layout, int ts_max, int x3, hipStream_t st
 // the same with the activations delivered as A planes (LDS-DMA staging); ts <= apl_ts_cap(b_layout)
 int apl_ts_cap(int b_layout);
 int launch_apl(const KArgs &a, int b_layout, int ts, hipStream_t st, int pcls, double bytes, double flops);
+// loader / consumer kernel on A planes (gemm_lc.hip): lc_plan picks a.sl and a.splits
+int lc_plan(int N, int tiles, int want_blocks, int *splits);
+int launch_lc(const KArgs &a, int b_layout, hipStream_t st, int pcls, double bytes, double flops);
 
 // fat GEMMs through the bf16 pipe by exact 3-way operand splitting; defined in gemm_x3.hip
 int launch_x3(const KArgs &a, int a_layout, int b_layout, dim3 grid, hipStream_t st, int pcls, double bytes, double flops);

@@ -443,6 +443,35 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     bool ares_ok = d->a_layout == 0 && d->M <= 64 && BK == 32;
     for (int s = 0; s < d->nseg && ares_ok; ++s)     // branch-free 16-byte operand fetch: aligned, K % 4 == 0
         ares_ok = a.seg[s].vecA && (a.seg[s].K % 4 == 0) && (d->b_layout == 1 || a.seg[s].vecB);
+    // ---- round 3: loader / consumer kernel (gemm_lc.hip) when every segment is also delivered as A planes ----
+    static const int env_lc = [] { const char *e = getenv("CAPMI_LC"); return e ? atoi(e) : 1; }();
+    {
+        bool lc_ok = env_lc && env_path != 3 && ares_ok && d->M <= 64;
+        for (int s = 0; s < d->nseg && lc_ok; ++s)
+            lc_ok = d->a_planes[s] != nullptr && a.seg[s].a_row_div == 1 && a.seg[s].vecB;
+        if (lc_ok && d->b_layout == 1) lc_ok = d->N % 4 == 0 && d->N >= 4;
+        if (lc_ok) {
+            static const int env_ab = [] { const char *e = getenv("CAPMI_ARES_BLOCKS"); return e ? atoi(e) : 256; }();
+            static const int env_opt = [] { const char *e = getenv("CAPMI_LC_OPT"); return e ? atoi(e) : 1; }();
+            const int want = d->splits > 0 ? ((d->N + 127) / 128) * d->splits : env_ab;
+            int splits = 0;
+            a.sl = lc_plan(d->N, tiles, want, &splits);
+            const bool partial = splits > 1 || d->defer_reduce;
+            if (!partial || (d->partial && (int64_t)splits * d->M * d->N <= slab_cap)) {
+                a.splits = splits;
+                a.to_partial = partial ? 1 : 0;
+                a.self_reduce = 0;
+                a.ablate = env_opt;              // bit 0: XCD-aware workgroup map
+                d->splits_used = splits;
+                int rc = launch_lc(a, d->b_layout, st, pcls, bytes, flops);
+                if (rc) return rc;
+                if (splits > 1 && !d->defer_reduce)
+                    return capmi_splitk_reduce(a.partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,
+                                               a.row_bias_div, d->mul_mask, d->relu, d->accumulate, stream);
+                return 0;
+            }
+        }
+    }
     if (env_path != 3 && ares_ok) {     // CAPMI_GEMM_PATH=3 forces the LDS-tiled kernel
         // ---- A-resident path (gemm_ares.hip): activations stay in LDS, weights stream straight to VGPRs ----
         static const int env_ab = [] { const char *e = getenv("CAPMI_ARES_BLOCKS"); return e ? atoi(e) : 256; }();

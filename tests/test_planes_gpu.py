@@ -1,7 +1,8 @@
-"""Round 3: the decode GEMMs stage PRODUCER-WRITTEN bf16x3 "A planes" by LDS-DMA (gemm_ares.hip gemm_apl_kernel).
+"""Round 3: the decode GEMMs take PRODUCER-WRITTEN bf16x3 "A planes" and stage them by LDS-DMA (gemm_lc.hip loader / consumer
+kernel; gemm_ares.hip gemm_apl_kernel with CAPMI_LC=0).
 Checked here, through the C ABI: the conversion entry point and every fused producer against the numpy restatement of
-the layout (oracle/planes.py, bit-exact); the planes GEMM against the in-kernel-split GEMM (bit-exact: same arithmetic,
-same summation order) and against fp64; a rollout with planes against the same rollout without."""
+the layout (oracle/planes.py, bit-exact); the planes GEMM against fp64 (fp32-grade error) and against the in-kernel-split
+GEMM; a rollout with planes against the same rollout without."""
 import ctypes as C
 import os
 
@@ -53,7 +54,7 @@ SHAPES = [(60, 4000, [1000, 1000, 1000], 0, True),      # LSTM gate GEMM of the 
 
 
 @pytest.mark.parametrize('M,N,Ks,bl,defer', SHAPES)
-def test_gemm_with_planes_equals_in_kernel_split(dev, M, N, Ks, bl, defer):
+def test_gemm_with_planes_is_fp32_grade_and_agrees_with_in_kernel_split(dev, M, N, Ks, bl, defer):
     ops, _ = mods()
     g = torch.Generator().manual_seed(N + sum(Ks))
     As = [wide((M, K), g, 0.3).to(dev) for K in Ks]
@@ -73,13 +74,13 @@ def test_gemm_with_planes_equals_in_kernel_split(dev, M, N, Ks, bl, defer):
 
     o_pl, s_pl = run(planes)
     o_ref, s_ref = run(None)
-    assert s_pl == s_ref
-    assert torch.equal(o_pl, o_ref), float((o_pl - o_ref).abs().max())
     ref = sum(A.double() @ (B.double() if bl else B.double().t()) for A, B in zip(As, Bs))
     if not defer:
         ref = ref + bias.double()
     mag = sum(A.double().abs() @ (B.double().abs() if bl else B.double().abs().t()) for A, B in zip(As, Bs)) + 1e-30
-    assert float(((o_pl.double() - ref).abs() / mag).max()) < 5e-7
+    # same exact bf16x3 products, another summation order (K slices / chunk order): fp32 accumulation noise only
+    assert float(((o_pl.double() - ref).abs() / mag).max()) < 1e-6
+    assert float(((o_pl.double() - o_ref.double()).abs() / mag).max()) < 1e-6
 
 
 def test_producers_write_the_planes_of_their_outputs(dev):
@@ -108,8 +109,8 @@ def test_producers_write_the_planes_of_their_outputs(dev):
     _lib.check(lib.capmi_lstm_cell_fwd(slabs.data_ptr(), 3, b1.data_ptr(), b2.data_ptr(), None, 1, None, cp.data_ptr(),
                                        h0.data_ptr(), c0.data_ptr(), ga0.data_ptr(), mask.data_ptr(), hd0.data_ptr(), N, R,
                                        sp()), 'cell')
-    for a, b in ((h, h0), (c, c0), (ga, ga0), (hd, hd0)):
-        assert torch.equal(a, b)                     # the 16-byte cell == the scalar cell, bit for bit
+    for a, b in ((h, h0), (c, c0), (ga, ga0), (hd, hd0)):    # the 16-byte cell vs the scalar cell (fma contraction may differ)
+        assert float((a - b).abs().max()) < 1e-6
     same(pl_h, h); same(pl_hd, hd)
 
     # embedding
@@ -149,9 +150,10 @@ def test_producers_write_the_planes_of_their_outputs(dev):
     same(pl_dg, dg)
 
 
-def test_rollout_with_planes_equals_rollout_without(dev, monkeypatch):
-    """Fused SCST rollout at the BASELINE sizes, forward + BPTT: planes on / off give the same tokens, the same selected
-    log-probs and the same gradients bit for bit (the planes are another delivery of the same operands)."""
+def test_rollout_with_planes_agrees_with_rollout_without(dev, monkeypatch):
+    """SCST-shaped rollout at the BASELINE sizes, forward + BPTT, with dropout masks and Gumbel noise injected: the planes are
+    another delivery of the same operands, so the tokens coincide and log-probs / gradients agree to fp32 accumulation noise
+    (the planes-off run is teacher-forced on the planes-on tokens so that a near-tie cannot fork the two)."""
     from imagecaptioning.pytorch_amd import updown_engine as E
     from shapes import full_size_params
     torch.manual_seed(0)
@@ -164,22 +166,35 @@ def test_rollout_with_planes_equals_rollout_without(dev, monkeypatch):
     gum = torch.rand(L, N, V1, device=dev).clamp_min(1e-12).log().neg().log().neg()
     drop_xt = (torch.rand(L, N, Em, device=dev) < 0.5).float() * 2
     drop_out = (torch.rand(L, N, R, device=dev) < 0.5).float() * 2
+    gsel = -torch.rand(N, L, 1, device=dev)
     out = {}
-    for flag in ('1', '0'):
-        monkeypatch.setenv('CAPMI_APL', flag)
-        ro = E.Rollout(P, pr, n=n, T=L, mode='sample', gumbel=gum, drop_xt=drop_xt, drop_out=drop_out)
+    seq_on = None
+    for flag in ('1', '0', 'free'):
+        monkeypatch.setenv('CAPMI_APL', '1' if flag == '1' else '0')
+        kw = dict(mode='sample', gumbel=gum) if flag != '0' else dict(mode='forced', forced=seq_on)
+        ro = E.Rollout(P, pr, n=n, T=L, drop_xt=drop_xt, drop_out=drop_out, **kw)
         assert (ro.r.planes is not None) == (flag == '1')
         seq, slp = ro.run()
+        if flag == 'free':
+            torch.cuda.synchronize()
+            assert float((seq != seq_on).float().mean()) < 0.02       # free-running without planes: same tokens (near-ties aside)
+            continue
+        if flag == '1':
+            seq_on = seq.clone()
         grads = {k: torch.zeros_like(P[k]) for k in E.PARAM_KEYS}
         gsl = torch.zeros_like(slp)
-        gsl.scatter_(2, seq.unsqueeze(-1), -torch.rand(N, L, 1, device=dev))
+        gsl.scatter_(2, seq_on.unsqueeze(-1), gsel)
         d = ro.backward(gsl, grads)
         torch.cuda.synchronize()
-        out[flag] = (seq.clone(), ro.sel_logp.clone(), {k: v.clone() for k, v in grads.items()}, [t.clone() for t in d])
+        out[flag] = (seq.clone(), slp.gather(2, seq_on.unsqueeze(-1)).clone(), {k: v.clone() for k, v in grads.items()},
+                     [t.clone() for t in d])
     a, b = out['1'], out['0']
     assert torch.equal(a[0], b[0])
-    assert torch.equal(a[1], b[1])
-    for k in a[2]:
-        assert torch.equal(a[2][k], b[2][k]), k
-    for x, y in zip(a[3], b[3]):
-        assert torch.equal(x, y)
+    assert float((a[1] - b[1]).abs().max()) < 2e-5
+    # (alpha_net.bias is left out: the softmax is shift invariant, its gradient is rounding noise around an exact 0)
+    errs = {k: float((a[2][k] - b[2][k]).abs().max()) / (float(b[2][k].abs().max()) + 1e-30) for k in a[2]
+            if k != 'core.attention.alpha_net.bias'}
+    errs.update({'d%d' % i: float((x - y).abs().max()) / (float(y.abs().max()) + 1e-30) for i, (x, y) in enumerate(zip(a[3], b[3]))})
+    print('relative gradient differences planes on / off:', {k: '%.1e' % v for k, v in errs.items() if v > 1e-5})
+    # fp32 accumulation-order noise through 20 steps of BPTT (the oracle comparisons of test_full_size_parity_gpu.py allow 1e-3)
+    assert max(errs.values()) < 5e-4, {k: v for k, v in errs.items() if v > 1e-5}
