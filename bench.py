@@ -6,10 +6,14 @@
            bench.py --gpus N --steps K --warmup W
 
 One "step" = one full SCST iteration per GPU on a synthetic batch (configs[2]: bs 10 x train_sample_n 5,
-36x2048 region features, seq_len 20, vocab 9487): greedy rollout + sampled rollout (dropout on) +
-CIDEr-D reward + RewardCriterion + BPTT + (1 RCCL all-reduce of the flat gradient if N > 1) + value
-clip 0.1 + Adam.  Inputs are resident in HBM before the timed region.  Weak scaling: every rank runs its
-own 10 images.  Prints ONE JSON line (rank 0).
+36x2048 region features, seq_len 20, vocab 9487): references packed + cooked for CIDEr-D (on the prefetcher's
+copy stream) + greedy rollout + sampled rollout (dropout on) + CIDEr-D reward + RewardCriterion + BPTT +
+(1 RCCL all-reduce of the flat gradient if N > 1) + value clip 0.1 + Adam.  The steps ROTATE over 4 distinct
+batches whose features are resident in HBM before the timed region (round 3; one batch, references cooked once
+outside the loop before).  Weak scaling: every rank runs its own 10 images.  Prints ONE JSON line (rank 0).
+
+--config selects the other BASELINE.json configurations with the same JSON schema (their own `metric` name):
+updown_xe (configs[1], bs64), transformer_xe (configs[3], bs64), aoa_nsc (configs[4], bs10 x 5), newfc_xe (configs[0]).
 
 Extra objects on the line:
   roofline      dominant kernel (skinny weight-streaming MFMA GEMM of the decode step): algorithmic bytes
@@ -116,6 +120,57 @@ def prof_read(lib, cls):
     return ms.value, n.value, b.value, f.value
 
 
+def _opt(name):
+    from imagecaptioning.pytorch_amd import synthetic
+    if name == 'updown':
+        return synthetic.updown_opt()
+    if name == 'newfc':           # configs/fc.yml: opts.py defaults rnn_size = input_encoding_size = 512
+        return synthetic.updown_opt(caption_model='newfc', input_encoding_size=512, rnn_size=512)
+    if name == 'transformer':     # configs/transformer/transformer.yml:23-28
+        return synthetic.updown_opt(caption_model='transformer', input_encoding_size=512, rnn_size=2048, d_model=512, d_ff=2048,
+                                    N_enc=6, N_dec=6, num_att_heads=8, dropout=0.1, drop_prob_lm=0.5)
+    if name == 'aoa_nsc':         # configs/aoa.yml + aoa_nsc.yml
+        return synthetic.updown_opt(caption_model='aoa', input_encoding_size=1024, rnn_size=1024, att_hid_size=512, num_heads=8,
+                                    multi_head_scale=1, use_multi_head=2, refine=1, refine_aoa=1, use_ff=0, decoder_type='AoA',
+                                    mean_feats=1, ctx_drop=1, dropout_aoa=0.3, drop_prob_lm=0.5, train_sample_n=5,
+                                    structure_loss_type='new_self_critical', structure_loss_weight=1.0, label_smoothing=0.2,
+                                    learning_rate=2e-5)
+    raise KeyError(name)
+
+
+# name -> (opt, per-GPU batch, (sc_flag, struc_flag), BASELINE.json configs[] index, workload text)
+CONFIGS = {
+    'updown_scst': ('updown', 10, (True, False), 2,
+                    'UpDown SCST (BASELINE configs[2]): per-GPU batch 10 x train_sample_n 5, 36x2048 bottom-up feats, R=E=1000 A=512, '
+                    'vocab 9487, seq_len 20, references packed+cooked + greedy baseline + CIDEr-D + RewardCriterion + BPTT + clip 0.1 + Adam'),
+    'updown_xe': ('updown', 64, (False, False), 1,
+                  'UpDown XE (BASELINE configs[1]): per-GPU batch 64 x 5 captions, 36x2048 feats, seq_len 20 (T = 21 teacher-forced steps), '
+                  'LanguageModelCriterion + BPTT + clip 0.1 + Adam'),
+    'transformer_xe': ('transformer', 64, (False, False), 3,
+                       'Transformer XE (BASELINE configs[3]): per-GPU batch 64 x 5 captions, 36x2048 feats, d=512 d_ff=2048 h=8 N=6, '
+                       'seq_len 20, LanguageModelCriterion + backward + clip 0.1 + Adam'),
+    'aoa_nsc': ('aoa_nsc', 10, (False, True), 4,
+                'AoA new-self-critical (BASELINE configs[4]): per-GPU batch 10 x train_sample_n 5, R=E=1024 h=8, 6 refiner layers, '
+                'sampled rollouts + CIDEr-D + StructureLosses(new_self_critical) + BPTT + clip 0.1 + Adam'),
+    'newfc_xe': ('newfc', 10, (False, False), 0,
+                 'NewFC XE (BASELINE configs[0], configs/fc.yml): batch 10 x 5 captions, 2048-d fc feats, R=E=512, seq_len 20, '
+                 'LanguageModelCriterion + BPTT + clip 0.1 + Adam'),
+}
+
+
+class _Rotating:
+    """The reference's loader contract (dataloader.py:229-258 batch dict) over a few distinct synthetic batches whose features
+    already live in HBM; `gts` stay host arrays so that the prefetcher packs + cooks them per batch like for real data."""
+
+    def __init__(self, items):
+        self.items, self.i = items, 0
+
+    def get_batch(self, split):
+        d = dict(self.items[self.i % len(self.items)])
+        self.i += 1
+        return d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -127,7 +182,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='do not bracket kernels with HIP events (for rocprofv3 runs)')
     ap.add_argument('--cpu-iters', type=int, default=5)
+    ap.add_argument('--config', default='updown_scst', choices=sorted(CONFIGS),
+                    help='BASELINE.json configuration (default: configs[2], the one the headline metric is quoted on)')
+    ap.add_argument('--eos-bias', type=float, default=0.0,
+                    help='add this to logit.bias[EOS]: a model that ends its captions (random weights never do), for the early-exit line')
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -161,9 +221,13 @@ def main():
     from imagecaptioning.pytorch_amd.captioning.utils import rewards
     lib = _lib.lib
 
-    opt = synthetic.updown_opt()
+    opt = _opt(cfg[0])
+    sc_flag, struc_flag = cfg[2]
     torch.manual_seed(1234)                       # identical initial weights on every rank
     model = models.setup(opt).to(dev)
+    if args.eos_bias:
+        with torch.no_grad():
+            model.logit.bias[0] += args.eos_bias
     flat = model.flatten_parameters_()
     # Default for N > 1: ONE all-reduce of the whole flat fp32 gradient per step (north_star / SURVEY 8e).
     # CAPMI_DDP_OVERLAP=1 opts into the bucketed variant (6 collectives launched from inside the backward as the phases finish
@@ -191,24 +255,43 @@ def main():
         if args.global_batch % world:
             raise SystemExit('--global-batch must be divisible by the number of ranks')
         args.batch = args.global_batch // world
+    if args.batch == 10 and cfg[1] != 10:
+        args.batch = cfg[1]
     B, n, L = args.batch, opt.train_sample_n, opt.max_length
-    fc, att = synthetic.batch(B, seed=1234 + rank, device=dev)
-    corpus = synthetic.corpus(DF_IMAGES, seed=7)  # DF table: 10000 synthetic "images" x 5 refs
-    df, ref_len = synthetic.document_frequency(corpus)
     rewards.reset_scorer()
-    rewards.init_scorer((df, ref_len), device=dev)
-    # the references travel with the batch as a device image, packed by the loader side (captioning/data/prefetch.py does the
-    # same for real batches): inputs are resident in HBM before the timed region
-    gts = rewards.pack_gts(synthetic.corpus(B, seed=100 + rank))
+    if sc_flag or struc_flag:
+        corpus = synthetic.corpus(DF_IMAGES, seed=7)  # DF table: 10000 synthetic "images" x 5 refs
+        df, ref_len = synthetic.document_frequency(corpus)
+        rewards.init_scorer((df, ref_len), device=dev)
+    # NB distinct batches rotate through the timed steps.  Their features are resident in HBM before the timed region; the
+    # references stay host arrays and are packed + cooked for CIDEr-D per batch by the prefetcher on its copy stream, inside the
+    # timed region, exactly as captioning/data/prefetch.py does for real batches (the full iteration).
+    from imagecaptioning.pytorch_amd.captioning.data.prefetch import DevicePrefetcher
+    NB = 4
+    items = []
+    for b in range(NB):
+        f_, a_ = synthetic.batch(B, seed=1234 + 1000 * b + rank, device=dev)
+        if sc_flag:
+            lab = msk = None
+        else:
+            lab, msk = synthetic.xe_labels(B, n=5, L=L, seed=1234 + 1000 * b + rank)
+            lab, msk = lab.to(dev), msk.to(dev)
+        items.append({'fc_feats': f_, 'att_feats': a_, 'att_masks': None, 'labels': lab, 'masks': msk,
+                      'gts': synthetic.corpus(B, seed=100 + 10 * b + rank), 'infos': [],
+                      'bounds': {'it_pos_now': 0, 'it_max': NB * B, 'wrapped': False}})
+    pf = DevicePrefetcher(_Rotating(items), dev, depth=2)
     gt_indices = torch.arange(B)
-    labels = masks = None
 
     ar_events = None          # (start, end) events around the all-reduce of the steps that measure it
 
     def step():
         nonlocal_ar = ar_events
-        out = lw(fc, att, labels, masks, None, gts, gt_indices, True, False, False)
-        loss = out['loss'].mean()
+        data = pf.get_batch('train')
+        out = lw(data['fc_feats'], data['att_feats'], data['labels'], data['masks'], None, data['gts'], gt_indices, sc_flag,
+                 struc_flag, False)
+        loss = out['loss']
+        if loss.dim():
+            loss = loss.mean()
         flat.zero_grad()
         loss.backward()
         flat.collect_grads()
@@ -255,6 +338,8 @@ def main():
     # and attention launches of every step costs 0.48 ms per step (5.18 vs 4.70 ms measured back to back), 10 % of the metric.
     # Two of the K timed steps (one when K < 10) carry the events: >= 120 samples of the dominant kernel, < 1 % perturbation.
     prof_mask = (1 << 0) | (1 << 3) | (1 << 9)          # decode GEMMs (small / streaming) + fused attention
+    if args.config in ('updown_xe', 'transformer_xe', 'newfc_xe'):
+        prof_mask |= (1 << 2)                           # the time-batched fat GEMMs are the dominant kernels of the XE steps
     if args.no_prof:
         sampled = set()
     elif args.steps >= 10:
@@ -300,6 +385,7 @@ def main():
         g_ms, g_n, g_bytes, g_flops = prof_read(lib, 9)
         all_ms, all_n, all_bytes = s_ms + g_ms, s_n + g_n, s_bytes + g_bytes
         a_ms, a_n, a_bytes, _ = prof_read(lib, 3)
+        f_ms, f_n, f_bytes, f_flops = prof_read(lib, 2)      # fat GEMMs (sampled only for the XE configurations)
         per_class = {'sampled_steps': sorted(sampled),
                      'gemm_decode_stream': {'ms_per_step': round(g_ms / n_sampled, 4), 'launches_per_step': g_n / n_sampled},
                      'gemm_decode_small': {'ms_per_step': round(s_ms / n_sampled, 4), 'launches_per_step': s_n / n_sampled},
@@ -350,27 +436,51 @@ def main():
                      'large_batch': None if args.no_prof else attention_large_batch(dev)}
         if attention['large_batch'] and copy_gbs:
             attention['large_batch']['frac_of_measured_copy'] = round(attention['large_batch']['achieved_gbs'] / copy_gbs, 4)
+        if args.config in ('updown_xe', 'transformer_xe', 'newfc_xe'):
+            # XE steps: the time-batched GEMMs (vocabulary projection over all N*T rows, weight gradients, Transformer QKV / FFN)
+            # dominate and are matrix-pipe problems: bf16 MFMA through the exact 3-way split, fp32-equivalent peak 2500 / 6 TF
+            peak = MFMA_BF16_PEAK_TFLOPS / 6.0
+            tf = f_flops / (f_ms * 1e-3) / 1e12 if f_ms else 0.0
+            roofline = {'kernel': 'gemm_x3_kernel (all fat GEMMs of the step: fp32 operands split exactly into 3 bf16 planes in the '
+                                  'kernel, v_mfma_f32_32x32x16_bf16, 6 MFMAs per fp32 MAC tile)',
+                        'launches_per_step': f_n / n_sampled, 'sampled_launches': f_n, 'bound': 'mfma', 'achieved': round(tf, 2),
+                        'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(tf / peak, 4), 'traffic': None,
+                        'avg_launch_us': round(f_ms / max(f_n, 1) * 1e3, 2),
+                        'algorithmic_flops_per_launch': round(f_flops / max(f_n, 1)),
+                        'algorithmic_bytes_per_launch': round(f_bytes / max(f_n, 1)),
+                        'ms_per_step': round(f_ms / n_sampled, 4),
+                        'note': 'fp32-equivalent FLOPs (2 M N K) over the in-dispatch HIP-event time of every fat GEMM launch of the '
+                                'sampled steps; the bf16 pipe executes 6x as many'}
+        if args.config not in ('updown_scst', 'updown_xe'):
+            attention = None
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(opt, model, B, n, L, args.cpu_iters)
+            cpu = (cpu_baseline(opt, model, B, n, L, args.cpu_iters) if args.config == 'updown_scst'
+                   else cpu_baseline_other(args.config, opt, model, B, L))
+        early = None
+        if args.config == 'updown_scst' and world == 1 and not args.no_prof and os.environ.get('CAPMI_EARLY_EXIT', '4') != '0':
+            early = early_exit_line(model, flat, lw, pf, gt_indices, opt, B, n)
+        names = {'updown_scst': 'captions/sec/node (UpDown SCST, bs10xsample_n5, 36x2048 feats)',
+                 'updown_xe': 'captions/sec/node (UpDown XE, bs64 x 5 captions, 36x2048 feats)',
+                 'transformer_xe': 'captions/sec/node (Transformer XE, bs64 x 5 captions, 36x2048 feats)',
+                 'aoa_nsc': 'captions/sec/node (AoA new-self-critical, bs10xsample_n5, 36x2048 feats)',
+                 'newfc_xe': 'captions/sec/node (NewFC XE, bs10 x 5 captions, 2048-d fc feats)'}
         line = {
-            'metric': 'captions/sec/node (UpDown SCST, bs10xsample_n5, 36x2048 feats)', 'value': round(value, 2),
+            'metric': names[args.config], 'value': round(value, 2),
             'unit': 'captions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'init_steps': INIT_STEPS,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'strong' if args.global_batch else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'numerics': 'fp32 storage and accumulation; GEMMs on the bf16 matrix pipe through an exact 3-way operand split '
                         '(fp32-grade error, DESIGN.md 4); CAPMI_GEMM_X3=0 CAPMI_ARES_X3=0 selects the exact-fp32 MFMA',
-            'config': {'workload': 'UpDown SCST (BASELINE configs[2]): per-GPU batch 10 x train_sample_n 5, 36x2048 '
-                                   'bottom-up feats, R=E=1000 A=512, vocab 9487, seq_len 20, greedy baseline + CIDEr-D + '
-                                   'RewardCriterion + BPTT + clip 0.1 + Adam',
-                       'global_batch': B * world, 'captions_per_step': B * n * world, 'seq_len': L,
+            'config': {'workload': cfg[4], 'baseline_config': 'BASELINE.json configs[%d]' % cfg[3],
+                       'rotating_batches': NB, 'global_batch': B * world, 'captions_per_step': B * n * world, 'seq_len': L,
                        'parallelism': 'dp%d (flat fp32 gradient, %s)' % (world, ('bucketed RCCL all-reduce overlapped with the backward' if overlap else 'one RCCL all-reduce per step') if multi else 'no collective')},
             'collective': None if not multi else {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
                                                    'mode': 'bucketed overlap' if overlap else ('reduce-scatter + sharded Adam + all-gather' if sharded else 'one flat all-reduce per step'),
                                                    'bytes': int(flat.grad.numel() * 4), 'allreduce_ms': None if allreduce_ms is None else round(allreduce_ms, 3)},
             'loss': float(loss.detach()), 'roofline': roofline, 'attention': attention, 'kernel_ms_per_step': per_class,
-            'cpu_baseline': cpu}
+            'early_exit_eos_biased': early, 'cpu_baseline': cpu}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
@@ -406,6 +516,90 @@ def cpu_baseline(opt, model, B, n, L, iters):
     except (OSError, ValueError):
         out['reference_in_build_container'] = None
     return out
+
+
+def early_exit_line(model, flat, lw, pf, gt_indices, opt, B, n, steps=8):
+    """Second, separately labelled measurement of the SAME step with a model that ends its captions: random-init weights never
+    draw the EOS, so the headline loop always runs all 20 steps and the early exit of the rollout driver (AttModel.py:349-350)
+    cannot show.  +12 on logit.bias[EOS] makes every row stop within a few steps; the weights are restored afterwards."""
+    bias0 = model.logit.bias.detach()[0].clone()
+    with torch.no_grad():
+        model.logit.bias[0] += 12.0
+
+    def step():
+        data = pf.get_batch('train')
+        out = lw(data['fc_feats'], data['att_feats'], None, None, None, data['gts'], gt_indices, True, False, False)
+        flat.zero_grad()
+        out['loss'].backward()
+        flat.collect_grads()
+        flat.adam_step(lr=0.0, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon, weight_decay=0.0,
+                       clip_value=opt.grad_clip_value, grad_scale=1.0)
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ro = getattr(model, '_last_rollout', None)
+    with torch.no_grad():
+        model.logit.bias[0] = bias0
+    return {'what': 'the same SCST iteration with +12 on logit.bias[EOS] (every caption ends within a few tokens): the rollout driver '
+                    'stops enqueuing decode steps once no row is left and the BPTT runs over the steps that were enqueued',
+            'ms_per_step': round(dt * 1e3, 3), 'captions_per_s': round(B * n / dt, 1),
+            'decode_steps_enqueued': None if ro is None else int(ro.steps_run), 'decode_steps_max': int(opt.max_length),
+            'check_every': int(os.environ.get('CAPMI_EARLY_EXIT', '4'))}
+
+
+def cpu_baseline_other(config, opt, model, B, L):
+    """CPU baseline of the non-headline configurations: the matching oracle (oracle/att_lstm.py, transformer.py, aoa.py: ports of
+    the reference's CPU path) on a BOUNDED sample of the same workload -- teacher-forced forward + criterion + autograd backward +
+    value clip + Adam on `Bc` images x 5 captions, scaled to captions/s.  (aoa_nsc: the teacher-forced pass over the 50 sampled rows
+    plus a no-grad 20-step decode of the same rows stands in for the sampled rollouts; the CIDEr-D scorer is not timed.)"""
+    from oracle import att_lstm as O, transformer as T, aoa as A
+    from imagecaptioning.pytorch_amd import synthetic
+    cores = min(os.cpu_count() or 1, int(os.environ.get('CAPMI_CPU_THREADS', '16')))
+    torch.set_num_threads(cores)
+    Bc = min(B, 8)
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    fc, att = synthetic.batch(Bc, seed=1234)
+    labels, masks = synthetic.xe_labels(Bc, n=5, L=L)
+    optim = torch.optim.Adam(list(P.values()), lr=opt.learning_rate)
+
+    def fwd():
+        if config == 'updown_xe':
+            return O.forward_teacher(P, fc, att, labels[..., :-1], None)
+        if config == 'newfc_xe':
+            return O.newfc_forward_teacher(P, fc, labels[..., :-1])
+        if config == 'transformer_xe':
+            return T.forward_teacher(P, att, labels[..., :-1], None, h=8, n_enc=6, n_dec=6)
+        return A.forward_teacher(P, att, labels[..., :-1], None, h=8)
+
+    def it():
+        if config == 'aoa_nsc':
+            with torch.no_grad():
+                A.greedy({k: v.detach() for k, v in P.items()}, att.repeat_interleave(5, 0), None, 8, L)
+        logp = fwd()
+        loss = O.lm_criterion(logp, labels[..., 1:], masks[..., 1:])
+        optim.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_value_(list(P.values()), opt.grad_clip_value)
+        optim.step()
+
+    it()
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        it()
+        ts.append(time.perf_counter() - t0)
+    sec = sorted(ts)[0]
+    return {'value': round(Bc * 5 / sec, 2), 'unit': 'captions/s', 'cores': cores, 'kind': 'port',
+            'sample': '2 timed iterations (best) after 1 warm-up of the %s oracle on %d images x 5 captions (the GPU step runs %d): '
+                      'teacher-forced forward + criterion + autograd backward + clip + Adam%s; torch fp32 on %d threads'
+                      % (config, Bc, B, ' + a no-grad 20-step decode of the 5x repeated images standing in for the sampled rollouts'
+                         if config == 'aoa_nsc' else '', cores), 'sec_per_iteration': round(sec, 3)}
 
 
 if __name__ == '__main__':

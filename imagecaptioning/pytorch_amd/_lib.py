@@ -47,7 +47,8 @@ class UpDownRollout(C.Structure):
                                     'att_h', 'alpha', 'ctx', 'h_drop', 'seq', 'seq_logp', 'sel_logp', 'live',
                                     'fc_gates', 'logits', 'it', 'unfinished', 'partial')] +
                 [('partial_capacity', C.c_int64), ('top_k', C.c_int), ('top_p', C.c_float), ('ss_mode', c_f),
-                 ('planes', c_f), ('planes_bytes', C.c_int64)])
+                 ('planes', c_f), ('planes_bytes', C.c_int64), ('early_exit', C.c_int), ('early_exit_from', C.c_int),
+                 ('alive_host', c_f), ('steps_run', C.c_int)])
 
 
 class SampleFilter(C.Structure):

@@ -62,8 +62,17 @@ class DevicePrefetcher:
             self._issue(split)
         out, ev = q.pop(0)
         torch.cuda.current_stream(self.device).wait_event(ev)      # stream-side wait, the host does not block
+        cur = torch.cuda.current_stream(self.device)
         for k in TENSOR_KEYS:
             if torch.is_tensor(out.get(k)):
-                out[k].record_stream(torch.cuda.current_stream(self.device))
+                out[k].record_stream(cur)
+        # the packed + cooked references were allocated on the copy stream and are read by the CIDEr-D kernels on the consumer's
+        # stream: without this the caching allocator may hand their blocks to the next side-stream pack while a queued reward
+        # kernel still reads them
+        packed = getattr(out.get('gts'), 'packed', None)
+        if packed is not None:
+            for t in (packed[0], packed[1], getattr(packed, 'cooked', None)):
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
         self._issue(split)                                          # keep `depth` batches in flight
         return out

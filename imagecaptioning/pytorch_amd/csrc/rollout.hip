@@ -13,6 +13,7 @@
 //    logit layer (forward-saved activations are stored time-major [T,N,...] for exactly this);
 //    only the 4 skinny "dX" GEMMs + the pointwise cells + the attention Jacobian stay in the loop.
 #include "capmi_common.h"
+#include <cstdlib>
 #include "../../../include/capmi.h"
 
 namespace {
@@ -196,7 +197,32 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
         RC(gemm(stream, 0, 0, B_feat, 4 * R, r->fc_gates, 4 * R, &s, 1, r->partial, r->partial_capacity, 0, nullptr));
     }
 
+    // Early exit (AttModel.py:349-350).  The host is hundreds of launches ahead of the device, so it cannot simply ask "is anyone
+    // left?": the select kernel of step t stores 1 in alive_host[t] (pinned host memory) for every row that goes on, an event is
+    // recorded behind every k-th step, and the host reads that word two steps later -- by then the device has two more steps queued
+    // and never waits for the host.  The steps queued behind the decisive one see finished rows only.
+    const int ee = (!r->teacher && r->early_exit > 0 && r->alive_host) ? r->early_exit : 0;
+    static thread_local hipEvent_t ee_ev[4];
+    static thread_local bool ee_init = false;
+    if (ee && !ee_init) {
+        for (auto &e : ee_ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CAPMI_EINVAL;
+        ee_init = true;
+    }
+    if (ee) for (int t = 0; t < L; ++t) r->alive_host[t] = 0;
+    int ee_pending = -1, ee_slot = 0, steps_run = T;
+    const int ee_from = r->early_exit_from > 0 ? r->early_exit_from : 0;
+
     for (int t = 0; t < T; ++t) {
+        if (ee_pending >= 0 && t - ee_pending >= 2) {
+            if (hipEventSynchronize(ee_ev[ee_slot]) != hipSuccess) return CAPMI_EINVAL;
+            if (*const_cast<volatile int32_t *>(r->alive_host + ee_pending) == 0) {    // nobody went on after that step
+                steps_run = t;
+                break;
+            }
+            ee_pending = -1;
+            ee_slot = (ee_slot + 1) & 3;
+        }
         float *xt = r->xt + (size_t)t * N * E;
         const float *h_att_prev = r->h_att + (size_t)t * NR, *c_att_prev = r->c_att + (size_t)t * NR;
         const float *h_lang_prev = r->h_lang + (size_t)t * NR, *c_lang_prev = r->c_lang + (size_t)t * NR;
@@ -267,6 +293,7 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
             ne.it_save = r->it_all ? r->it_all + (size_t)(t + 1) * N : nullptr;
             ne.x_planes = pl_xt;
         }
+        if (ee) ne.alive = r->alive_host + t;
         if (sched && t + 1 < T) {
             // AttModel.py:145-154: the token chosen here is the INPUT of step t+1 -- forced[:, t+1] (mode 2 rows) or a
             // categorical draw from this step's log-probs (mode 1 rows, temperature 1); it is embedded by the same launch
@@ -282,6 +309,22 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
                                            r->gumbel ? r->gumbel + (size_t)t * N * V1 : nullptr, r->seed, r->forced,
                                            r->forced_ld, r->teacher ? 1 : 0, r->seq, L, r->it, r->unfinished, r->seq_logp,
                                            r->sel_logp, r->live, &ne, (r->top_k > 0 || r->top_p > 0.f) ? &flt : nullptr, stream));
+        if (ee && ee_pending < 0 && t >= ee_from && (t + 1 - ee_from) % ee == 0 && t + 3 <= T) {
+            if (hipEventRecord(ee_ev[ee_slot], st) != hipSuccess) return CAPMI_EINVAL;
+            ee_pending = t;
+        }
+    }
+    r->steps_run = steps_run;
+    if (steps_run < T) {     // the steps never run leave pad tokens and zero log-probs like the reference's untouched columns
+        hipError_t e = hipSuccess;
+        const size_t tail = (size_t)(L - steps_run);
+        if (r->seq_logp) e = hipMemset2DAsync(r->seq_logp + (size_t)steps_run * V1, (size_t)L * V1 * sizeof(float), 0,
+                                              tail * V1 * sizeof(float), N, st);
+        if (e == hipSuccess) e = hipMemset2DAsync(r->seq + steps_run, (size_t)L * sizeof(int64_t), 0, tail * sizeof(int64_t), N, st);
+        if (e == hipSuccess && r->sel_logp)
+            e = hipMemset2DAsync(r->sel_logp + steps_run, (size_t)L * sizeof(float), 0, tail * sizeof(float), N, st);
+        if (e == hipSuccess && r->live) e = hipMemset2DAsync(r->live + steps_run, (size_t)L, 0, tail, N, st);
+        if (e != hipSuccess) return (int)e;
     }
     if (batched_logit) {
         float *hd_nt = r->partial + CAPMI_WS_COUNTER_FLOATS;          // the split-K workspace is idle here
@@ -415,7 +458,8 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
     float *P1 = P + capm, *Ph = P + capm + cap1;
     if (phases & CAPMI_BWD_RECURRENT) {
     if (capm <= CAPMI_WS_COUNTER_FLOATS || cap1 <= CAPMI_WS_COUNTER_FLOATS || caph <= CAPMI_WS_COUNTER_FLOATS) return CAPMI_EINVAL;
-    {   // ticket words of the carved regions start zeroed like the main one
+    static const bool self_reduce = [] { const char *e = getenv("CAPMI_GEMM_SELF_REDUCE"); return e && atoi(e); }();
+    if (self_reduce) {   // ticket words of the carved regions start zeroed like the main one (only the in-launch reduction reads them)
         hipError_t e = hipMemsetAsync(P1, 0, CAPMI_WS_COUNTER_FLOATS * sizeof(float), st);
         if (e == hipSuccess) e = hipMemsetAsync(Ph, 0, CAPMI_WS_COUNTER_FLOATS * sizeof(float), st);
         if (e != hipSuccess) return (int)e;

@@ -51,6 +51,7 @@ struct NextEmbed {
     int64_t *it_save;
     int Edim, relu;
     unsigned char *pl;      // A planes of x (rows <= 64) for the next step's gate GEMM, or null
+    int *alive;             // set to 1 by every row that is still unfinished after this step (early exit of rollouts), or null
 };
 __device__ __forceinline__ void emit_next_embed(const NextEmbed &ne, int r, int token) {
     if (!ne.x) return;
@@ -198,6 +199,8 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
         if (sel_logp) sel_logp[(size_t)r * L + step] = prenorm == 2 ? x[chosen] : keep * (x[token] - lse);
         if (live) live[(size_t)r * L + step] = was_unf ? 1 : 0;
         if (!no_finish_mask) unfinished[r] = (was_unf && token != 0) ? 1 : 0;
+        // early exit (AttModel.py:349-350): a row that goes on tells the host so (a word of pinned host memory, only ever set)
+        if (ne.alive && (no_finish_mask || (was_unf && token != 0))) *ne.alive = 1;
     }
 }
 
@@ -392,6 +395,8 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
         if (sel_logp) sel_logp[(size_t)r * L + step] = keep * (s_tok - lse);
         if (live) live[(size_t)r * L + step] = was_unf ? 1 : 0;
         if (!no_finish_mask) unfinished[r] = (was_unf && token != 0) ? 1 : 0;
+        // early exit (AttModel.py:349-350): a row that goes on tells the host so (a word of pinned host memory, only ever set)
+        if (ne.alive && (no_finish_mask || (was_unf && token != 0))) *ne.alive = 1;
     }
 }
 
@@ -535,8 +540,9 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
         if (!next->E || next->Edim <= 0) return CAPMI_EINVAL;
         if (next->x_planes && N > 64) return CAPMI_EINVAL;
         ne = NextEmbed{next->E, next->mask, next->x, next->it_save, next->Edim, next->relu,
-                       static_cast<unsigned char *>(next->x_planes)};
+                       static_cast<unsigned char *>(next->x_planes), nullptr};
     }
+    if (next) ne.alive = next->alive;
     const bool al = ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(bias) |
                       reinterpret_cast<uintptr_t>(gumbel) | reinterpret_cast<uintptr_t>(seq_logp)) & 15) == 0 &&
                     (slab_stride % 4 == 0);

@@ -111,12 +111,26 @@ def _relu_drop_bwd(dy, y_saved, mask):
     return ops.relu_mask_bwd(dy.contiguous(), y_saved.contiguous(), mask)
 
 
+_alive = {}
+
+
+def _alive_buffer(dev, L):
+    """[L] int32 of pinned host memory the select kernels can write (capmi.h capmi_updown_rollout.alive_host), one per stream:
+    the words are only ever SET by kernels and cleared by the host before a rollout is enqueued, so a late store of the
+    previous rollout can at worst postpone an early exit."""
+    key = (str(dev), stream_ptr(), L)
+    t = _alive.get(key)
+    if t is None:
+        t = _alive[key] = torch.zeros(max(L, 32), dtype=torch.int32).pin_memory()
+    return t
+
+
 class Rollout:
     """Device buffers + one native call for a T-step rollout of N = B*n caption rows."""
 
     def __init__(self, P, pr, n, T, L=None, mode='greedy', temperature=1.0, drop_xt=None, drop_out=None,
                  gumbel=None, seed=0, forced=None, teacher=False, row_mode=None, ws=None, keep_for_backward=True,
-                 row_img=None, B_grad=None, top_k=0, top_p=0.0, ss_mode=None):
+                 row_img=None, B_grad=None, top_k=0, top_p=0.0, ss_mode=None, early_exit=None, early_exit_from=4):
         """ss_mode (uint8 [T,N], teacher only): scheduled sampling, 1 = the input of (step, row) is drawn from the previous
         step's distribution, 2 = teacher-forced (capmi.h capmi_updown_rollout.ss_mode).
         row_img (int32 [N]) + B_grad: ragged grouping for the fused SCST rollout -- the first B_grad
@@ -138,12 +152,15 @@ class Rollout:
         self.it_all = torch.empty(T, N, dtype=torch.long, device=dev)
         self.gates_att, self.gates_lang = z(T, N, 4 * R), z(T, N, 4 * R)
         self.att_h, self.alpha, self.ctx, self.h_drop = z(T, N, A), z(T, N, K), z(T, N, R), z(T, N, R)
-        self.seq = torch.zeros(N, L, dtype=torch.long, device=dev)
+        # the select kernel writes every (row, step < T) slot of seq / seq_logp / sel_logp / live, zeros included, and the driver
+        # clears the tail behind an early exit: fills are only needed when fewer steps than the pitch are run
+        zl = torch.empty if T == L else torch.zeros
+        self.seq = zl(N, L, dtype=torch.long, device=dev)
         # the select kernel writes every (row, step < T) slice of the dense log-probs, zeros included: a 45 MB memset per
         # rollout is only needed when fewer steps than the pitch are run (XE with an early all-pad column)
         self.seq_logp = (torch.empty if T == L else torch.zeros)(N, L, V1, dtype=_f32, device=dev)
-        self.sel_logp = torch.zeros(N, L, dtype=_f32, device=dev)
-        self.live = torch.zeros(N, L, dtype=torch.uint8, device=dev)
+        self.sel_logp = zl(N, L, dtype=_f32, device=dev)
+        self.live = zl(N, L, dtype=torch.uint8, device=dev)
         self.fc_gates = z(B_feat, 4 * R)
         self.logits = z(N, V1)
         self.it = torch.empty(N, dtype=torch.long, device=dev)
@@ -179,11 +196,22 @@ class Rollout:
             nb = int(lib.capmi_updown_planes_bytes(R, E))
             self.planes = ops.planes_scratch(dev, ('updown_fwd', R, E, stream_ptr()), nb)
             r.planes, r.planes_bytes = self.planes.data_ptr(), nb
+        # early exit of free-running rollouts (AttModel.py:349-350): behind steps early_exit_from + k * early_exit - 1 (7, 11, 15 by
+        # default) the driver looks, two steps later, at a pinned word the select kernels set and stops enqueuing once every row
+        # has emitted its EOS (CAPMI_EARLY_EXIT=0: never)
+        if early_exit is None:
+            early_exit = int(os.environ.get('CAPMI_EARLY_EXIT', '4'))
+        self.steps_run = T
+        if early_exit > 0 and not teacher and mode != 'forced' and T >= 12:
+            self.alive = _alive_buffer(dev, L)
+            r.early_exit, r.early_exit_from, r.alive_host = int(early_exit), int(early_exit_from), self.alive.data_ptr()
         self.r = r
         self.w = weights_struct(P)
 
     def run(self):
         check(lib.capmi_updown_rollout_fwd(C.byref(self.w), C.byref(self.r), stream_ptr()), 'capmi_updown_rollout_fwd')
+        self.steps_run = int(self.r.steps_run)
+        self.r.T = self.steps_run            # the backward runs over the steps that were enqueued
         return self.seq, self.seq_logp
 
     # backward phases in launch order with the parameter gradients each one completes (capmi.h CAPMI_BWD_*)

@@ -249,6 +249,8 @@ typedef struct {
     int Edim;
     int relu;
     void *x_planes;      /* optional (N <= 64): the same rows also as "A planes" (capmi_planes_from_f32) for the next gate GEMM */
+    int *alive;          /* optional, independent of x: every row that is still unfinished after this step stores 1 here (device-
+                          * visible memory, e.g. pinned host memory: the rollout driver's early exit, AttModel.py:349-350) */
 } capmi_next_embed;
 
 /* Optional top-k / nucleus filter of the sampling modes (CaptionModel.sample_next_word, CaptionModel.py:388-404,
@@ -488,6 +490,17 @@ typedef struct capmi_updown_rollout {
      * gate / logit GEMMs stage by LDS-DMA (capmi_gemm_desc.a_planes); NULL keeps the in-GEMM split.  Same results. */
     void *planes;
     int64_t planes_bytes;
+    /* Round 3: early exit of free-running rollouts (AttModel.py:349-350 `if unfinished.sum() == 0: break`).  early_exit = k > 0:
+     * after every k-th step (from step early_exit_from on) the driver looks, two steps later and through an event, at a word of
+     * `alive_host` ([L] int32 of PINNED HOST memory the device can write: the select kernel of step t stores 1 in alive_host[t]
+     * for every row that goes on) and stops enqueuing when no row is left.  The steps that were queued behind the decisive one
+     * run on finished rows only and write what the reference leaves behind the break (pad tokens, zero log-probs); the
+     * log-probs of the steps never run are zero-filled.  steps_run (out) = steps enqueued; the backward then takes
+     * r->T = steps_run.  0 / NULL: all T steps are enqueued without any host wait. */
+    int early_exit;
+    int early_exit_from;
+    int32_t *alive_host;
+    int steps_run;
 } capmi_updown_rollout;
 
 int64_t capmi_updown_planes_bytes(int R, int E);
