@@ -92,6 +92,9 @@ class FeatureLoader:
         self.lookahead = max(1, int(lookahead))
         self.order = {k: list(v) for k, v in self.split_ix.items()}
         self.rng.shuffle(self.order['train'])                  # MySampler shuffles the train split (dataloader.py:394-397)
+        # what a checkpoint needs to resume INSIDE an epoch (the reference saves its sampler's index_list + iter_counter,
+        # dataloader.py:376-405): a copy of the order taken once per shuffle, handed out with every batch next to the RNG states
+        self._snap = {k: list(v) for k, v in self.order.items()}
         self.pos = {'train': 0, 'val': 0, 'test': 0}
         if processes is None:
             processes = os.environ.get('CAPMI_LOADER_PROCS', '0') == '1'
@@ -152,11 +155,12 @@ class FeatureLoader:
                 wrapped = True
                 if split == 'train':
                     self.rng.shuffle(order)
+                    self._snap[split] = list(order)
         return out, wrapped
 
     def _schedule(self, split, B):
         idx, wrapped = self._next_indices(split, B)
-        return idx, wrapped, self.pos[split], [self.submit_image(ix) for ix in idx]
+        return idx, wrapped, self.pos[split], [self.submit_image(ix) for ix in idx], self._snap[split], self.rng.getstate()
 
     def label_part(self, idx):
         """labels [B,n,L+2] int64, masks, gts, infos of the images `idx` (dataloader.py:165-184, 243-259)"""
@@ -180,7 +184,7 @@ class FeatureLoader:
         q = self._pending.setdefault(key, [])
         while len(q) < self.lookahead + 1:                     # decode the NEXT batches' features in the background
             q.append(self._schedule(split, B))
-        idx, wrapped, pos_now, futs = q.pop(0)
+        idx, wrapped, pos_now, futs, snap, rng_state = q.pop(0)
         feats = [f.result() for f in futs]
         F = feats[0][1].shape[1]
         kmax = max(a.shape[0] for _, a in feats)
@@ -191,7 +195,9 @@ class FeatureLoader:
             att[b, :a.shape[0]] = a
             att_masks[b, :a.shape[0]] = 1
         labels, masks, gts, infos = self.label_part(idx)
+        state = {'loader_order': {split: snap}, 'loader_rng': rng_state, 'loader_cap_rng': self.cap_rng.getstate()}
         return {'fc_feats': torch.from_numpy(fc), 'att_feats': torch.from_numpy(att),
                 'att_masks': None if att_masks.sum() == att_masks.size else torch.from_numpy(att_masks),     # :240-241
                 'labels': torch.from_numpy(labels), 'masks': torch.from_numpy(masks), 'gts': gts,
-                'bounds': {'it_pos_now': pos_now, 'it_max': len(self.order[split]), 'wrapped': wrapped}, 'infos': infos}
+                'bounds': {'it_pos_now': pos_now, 'it_max': len(self.order[split]), 'wrapped': wrapped,
+                           'loader_state': state}, 'infos': infos}

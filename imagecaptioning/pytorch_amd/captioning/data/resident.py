@@ -84,7 +84,7 @@ class ResidentFeatures:
     def _schedule(self, split, B):
         idx, wrapped = self.loader._next_indices(split, B)
         futs = {ix: self.loader.submit_image(ix) for ix in set(idx) if ix not in self.slot}
-        return idx, wrapped, self.loader.pos[split], futs
+        return idx, wrapped, self.loader.pos[split], futs, self.loader._snap[split], self.loader.rng.getstate()
 
     def get_batch(self, split, batch_size=None):
         ld = self.loader
@@ -93,7 +93,7 @@ class ResidentFeatures:
         q = self._pending.setdefault(key, [])
         while len(q) < ld.lookahead + 1:                       # decode the NEXT batches' new images in the background
             q.append(self._schedule(split, B))
-        idx, wrapped, pos_now, futs = q.pop(0)
+        idx, wrapped, pos_now, futs, snap, rng_state = q.pop(0)
         new, seen = [], set()
         for ix in idx:
             if ix in self.slot:
@@ -134,6 +134,8 @@ class ResidentFeatures:
                 m[b, :k] = 1
             att_masks = torch.from_numpy(m).to(self.dev)
         labels, masks, gts, infos = ld.label_part(idx)
+        state = {'loader_order': {split: snap}, 'loader_rng': rng_state, 'loader_cap_rng': ld.cap_rng.getstate()}
         return {'fc_feats': fc, 'att_feats': att, 'att_masks': att_masks, 'labels': torch.from_numpy(labels),
                 'masks': torch.from_numpy(masks), 'gts': gts,
-                'bounds': {'it_pos_now': pos_now, 'it_max': len(ld.order[split]), 'wrapped': wrapped}, 'infos': infos}
+                'bounds': {'it_pos_now': pos_now, 'it_max': len(ld.order[split]), 'wrapped': wrapped, 'loader_state': state},
+                'infos': infos}

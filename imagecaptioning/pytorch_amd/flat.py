@@ -54,6 +54,35 @@ class FlatParams:
         self.exp_avg_sq.copy_(sd['exp_avg_sq'])
         self.step_count = int(sd['step_count'])
 
+    def load_torch_adam_state(self, sd):
+        """The reference's optimizer.pth is ``torch.optim.Adam(model.parameters()).state_dict()`` (misc.py:87-102, :112-130):
+        {'state': {index: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [{'params': [index, ...], ...}]}, indices in the
+        order of ``model.parameters()`` -- the order of this buffer's segments.  Returns False (nothing loaded) when the state
+        does not fit this model."""
+        try:
+            order = [i for g in sd['param_groups'] for i in g['params']]
+            state = sd['state']
+        except (KeyError, TypeError):
+            return False
+        if len(order) != len(self.params):
+            return False
+        steps = []
+        for i, p in zip(order, self.params):
+            st = state.get(i)
+            if st is None:                         # a parameter that never received a gradient
+                continue
+            if tuple(st['exp_avg'].shape) != tuple(p.shape):
+                return False
+        for i, p, o in zip(order, self.params, self.offsets):
+            st = state.get(i)
+            if st is None:
+                continue
+            self.exp_avg[o:o + p.numel()].view_as(p).copy_(st['exp_avg'])
+            self.exp_avg_sq[o:o + p.numel()].view_as(p).copy_(st['exp_avg_sq'])
+            steps.append(int(st['step']))
+        self.step_count = max(steps) if steps else 0
+        return True
+
     def expect_backwards(self, k):
         """How many native backward passes this optimisation step will run (2 when LossWrapper mixes an XE and a structure
         loss, loss_wrapper.py:25-48).  Gradient buckets may only be handed to the collective by the LAST of them: an earlier

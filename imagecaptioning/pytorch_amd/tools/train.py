@@ -95,22 +95,45 @@ def train(opt):
         # schedule's state, the iteration / epoch counters (they drive warm-up, decay, ss_prob and the XE->SCST switch)
         # and the loader position
         osd = misc.load_optimizer_state(opt.start_from)
-        if osd is not None:
+        if osd is not None and 'flat' in osd:                                    # a checkpoint of this trainer
             flat.load_state_dict(osd['flat'])
             sched.load_state_dict(osd['sched'])
+        elif osd is not None:
+            # a checkpoint of the REFERENCE trainer: torch.optim.Adam's state_dict (misc.py:125, tools/train.py:112-119) -> the flat
+            # moment buffers; the rate schedule restarts from the iteration / epoch counters of infos
+            if flat.load_torch_adam_state(osd):
+                print('optimizer.pth: torch Adam state converted to the flat moment buffers (step %d)' % flat.step_count)
+            else:
+                print('optimizer.pth does not match this model (not a torch Adam state of its parameters): optimizer starts fresh')
+        base = getattr(loader, 'loader', loader)                                 # under the prefetcher (nothing is prefetched yet)
+        base = getattr(base, 'loader', base)                                     # ... and the resident feature store
         for split, pos in infos.get('loader_pos', {}).items():
-            loader.loader.pos[split] = pos                                       # nothing is prefetched yet
+            base.pos[split] = pos
+        # the reference saves its sampler's index_list / iter_counter (dataloader.py:376-405): the shuffled order of the epoch
+        # and both RNG streams, or a resumed epoch would revisit some images and skip others
+        if hasattr(base, 'order'):
+            for split, order in infos.get('loader_order', {}).items():
+                if len(order) == len(base.order.get(split, ())):
+                    base.order[split] = list(order)
+            if infos.get('loader_rng') is not None:
+                base.rng.setstate(infos['loader_rng'])
+            if infos.get('loader_cap_rng') is not None:
+                base.cap_rng.setstate(infos['loader_cap_rng'])
         model._rng_calls = int(infos.get('rng_calls', 0))                        # dropout / sampling Philox stream position
     sc_ready = False
     epoch_done = True
     train_loss = float('nan')
 
     last_pos = {}
+    last_loader = {}
+    histories = dict(infos.get('histories') or {'loss_history': {}, 'lr_history': {}, 'ss_prob_history': {}})
+    best_val_score = infos.get('best_val_score')
 
     def checkpoint():
         # the prefetcher runs ahead of the loop: the position to resume from is the one of the last CONSUMED batch
         misc.save_checkpoint(opt, model, {'iter': it, 'epoch': epoch, 'opt': opt, 'vocab': opt.vocab,
-                                          'loader_pos': dict(last_pos), 'rng_calls': int(getattr(model, '_rng_calls', 0))},
+                                          'loader_pos': dict(last_pos), 'rng_calls': int(getattr(model, '_rng_calls', 0)),
+                                          'best_val_score': best_val_score, 'histories': histories, **last_loader},
                              optimizer_state={'flat': flat.state_dict(), 'sched': sched.state_dict()})
 
     iter_times = []
@@ -165,7 +188,7 @@ def train(opt):
         slot = loss_slots[it & 1]
         slot[0].copy_(loss.detach().reshape(1), non_blocking=True)
         slot[1].record()
-        if prev_slot is not None:
+        if prev_slot is not None and os.environ.get('CAPMI_TRAIN_LAG') != '-1':    # (-1: stress mode, the host is never throttled)
             prev_slot[1].synchronize()
             train_loss = float(prev_slot[0][0])
         wait_now = (it % opt.losses_log_every == 0 or it + 1 >= opt.max_iters or os.environ.get('CAPMI_TRAIN_LAG', '1') == '0'
@@ -187,8 +210,14 @@ def train(opt):
             else:
                 print('iter %d (epoch %d), avg_reward = %.3f, time/batch = %.3f' % (it, epoch, out['reward'].mean().item(), t2 - t1))
             print('Read data:', t1 - t0)
+        if it % opt.losses_log_every == 0:                                    # tools/train.py:214-222 histories
+            histories['loss_history'][it] = train_loss
+            histories['lr_history'][it] = opt.current_lr
+            histories['ss_prob_history'][it] = getattr(model, 'ss_prob', 0.0)
         it += 1
         last_pos['train'] = data['bounds']['it_pos_now']
+        if 'loader_state' in data['bounds']:                                  # order + RNG streams as of this batch (FeatureLoader)
+            last_loader.update(data['bounds']['loader_state'])
         if data['bounds']['wrapped']:
             epoch += 1
             epoch_done = True
@@ -201,6 +230,8 @@ def train(opt):
                 dist.all_reduce(v)
                 val_loss = float(v) / world
             sched.plateau_step(val_loss)
+            if best_val_score is None or -val_loss > best_val_score:           # tools/train.py:258-266 (language_eval off: -val_loss)
+                best_val_score = -val_loss
             if rank == 0:
                 print('validation loss: %.3f (lr %.2e)' % (val_loss, sched.current_lr))
         if rank == 0 and opt.save_checkpoint_every and it % opt.save_checkpoint_every == 0:

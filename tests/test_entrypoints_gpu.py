@@ -205,3 +205,92 @@ def test_train_drop_worst_xe_and_scst(tmp_path):
     assert loss == loss
     assert [f for f, _ in seen] == [False, False] + [True] * 6
     assert all(sh == () for f, sh in seen if not f) and all(sh == (8,) for f, sh in seen if f)       # 4 images x 2 rows
+
+
+def _file_dataset(tmp_path, n_img=40):
+    import json
+    import numpy as np
+    rng = np.random.default_rng(0)
+    (tmp_path / 'att').mkdir()
+    labels, start, end, images = [], [], [], []
+    for i in range(n_img):
+        np.savez_compressed(tmp_path / 'att' / ('%d.npz' % i), feat=np.clip(rng.standard_normal((6, 24)), 0, None).astype(np.float32))
+        start.append(len(labels) + 1)
+        for _ in range(5):
+            row = np.zeros(8, dtype=np.uint32)
+            ln = int(rng.integers(3, 8))
+            row[:ln] = rng.integers(1, 50, size=ln)
+            labels.append(row)
+        end.append(len(labels))
+        images.append({'id': i, 'split': 'train'})
+    (tmp_path / 'd.json').write_text(json.dumps({'images': images, 'ix_to_word': {str(i): 'w%d' % i for i in range(1, 50)}}))
+    np.savez(tmp_path / 'l.npz', labels=np.stack(labels), label_start_ix=np.array(start, dtype=np.uint32),
+             label_end_ix=np.array(end, dtype=np.uint32))
+    return ['--caption_model', 'updown', '--rnn_size', '32', '--input_encoding_size', '32', '--att_hid_size', '16', '--att_feat_size', '24',
+            '--fc_feat_size', '24', '--input_json', str(tmp_path / 'd.json'), '--input_label_h5', str(tmp_path / 'l.npz'),
+            '--input_att_dir', str(tmp_path / 'att'), '--batch_size', '4', '--seq_per_img', '3', '--losses_log_every', '1000']
+
+
+def test_unthrottled_host_with_the_resident_store_does_not_wedge(tmp_path, monkeypatch):
+    """VERDICT r2 weak #9 / DESIGN r2 'known issue': with the HBM-resident feature store and a host that is never throttled
+    (no per-iteration loss read-back, no early-exit waits) the process used to wedge after a few dozen iterations.  Root cause:
+    the packed + cooked CIDEr-D references are allocated on the prefetcher's copy stream and read by the reward kernels on
+    the main stream WITHOUT record_stream -- once the host runs several iterations ahead the caching allocator hands their
+    blocks to the next side-stream pack while a queued reward kernel still walks them (prefetch.py now records the stream).
+    500 un-throttled self-critical iterations must finish."""
+    sys.path.insert(0, PKG)
+    from imagecaptioning.pytorch_amd.tools import train as T
+    from captioning.utils import rewards
+    rewards.reset_scorer()
+    monkeypatch.setenv('CAPMI_TRAIN_LAG', '-1')
+    monkeypatch.setenv('CAPMI_EARLY_EXIT', '0')
+    args = _file_dataset(tmp_path) + ['--self_critical_after', '0', '--train_sample_n', '3', '--max_iters', '500', '--max_epochs', '-1',
+                                      '--resident_features', '1', '--checkpoint_path', str(tmp_path / 'ck')]
+    loss = T.train(_opts(args))
+    torch.cuda.synchronize()
+    assert loss == loss
+    rewards.reset_scorer()
+
+
+def test_resume_inside_an_epoch_restores_order_and_rng_and_reads_a_reference_optimizer(tmp_path):
+    """infos carry the shuffled order of the running epoch and both loader RNG streams (the reference saves
+    its sampler's index_list / iter_counter, dataloader.py:376-405), so a run stopped INSIDE epoch 1 and resumed sees exactly the
+    batches of the uninterrupted run; and an optimizer.pth written by the REFERENCE trainer (torch.optim.Adam.state_dict()) is
+    converted into the flat moment buffers instead of raising KeyError."""
+    sys.path.insert(0, PKG)
+    import pickle
+    from imagecaptioning.pytorch_amd.tools import train as T
+    base = _file_dataset(tmp_path) + ['--learning_rate', '0.01', '--resident_features', '0']
+    a, b = tmp_path / 'a', tmp_path / 'b'
+    # 40 images / 4 per batch = 10 iterations per epoch: stop at 13 (inside epoch 1), resume to 17
+    T.train(_opts(base + ['--max_iters', '17', '--save_checkpoint_every', '17', '--checkpoint_path', str(a)]))
+    T.train(_opts(base + ['--max_iters', '13', '--save_checkpoint_every', '13', '--checkpoint_path', str(b)]))
+    infos = pickle.load(open(b / 'infos_capmi.pkl', 'rb'))
+    assert infos['epoch'] == 1 and len(infos['loader_order']['train']) == 40 and infos['loader_rng'] is not None
+    assert set(infos['histories']) >= {'loss_history', 'lr_history', 'ss_prob_history'}
+    T.train(_opts(base + ['--max_iters', '17', '--save_checkpoint_every', '17', '--checkpoint_path', str(b), '--start_from', str(b)]))
+    pa, pb = torch.load(a / 'model.pth'), torch.load(b / 'model.pth')
+    for k in pa:
+        if k == 'core.attention.alpha_net.bias':
+            continue
+        assert float((pa[k] - pb[k]).abs().max()) < 5e-5, (k, float((pa[k] - pb[k]).abs().max()))
+    # a reference-format optimizer.pth: torch Adam over the same parameters, two steps taken
+    from captioning import models
+    opt = _opts(base + ['--max_iters', '1'])
+    opt.vocab_size, opt.seq_length, opt.max_length = 49, 8, 8
+    opt.vocab = {str(i): 'w%d' % i for i in range(1, 50)}
+    ref_model = models.setup(opt)
+    ref_model.load_state_dict(torch.load(b / 'model.pth'))
+    adam = torch.optim.Adam(ref_model.parameters(), lr=1e-3)
+    for _ in range(2):
+        for p in ref_model.parameters():
+            p.grad = torch.full_like(p, 0.5)
+        adam.step()
+    c = tmp_path / 'c'
+    c.mkdir()
+    torch.save({k: v.detach().cpu() for k, v in ref_model.state_dict().items()}, c / 'model.pth')
+    torch.save(adam.state_dict(), c / 'optimizer.pth')
+    pickle.dump({'iter': 2, 'epoch': 0}, open(c / 'infos_capmi.pkl', 'wb'))
+    T.train(_opts(base + ['--max_iters', '4', '--save_checkpoint_every', '4', '--checkpoint_path', str(c), '--start_from', str(c)]))
+    osd = torch.load(c / 'optimizer.pth', weights_only=False)
+    assert osd['flat']['step_count'] == 4                      # 2 converted + 2 new steps
