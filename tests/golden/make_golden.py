@@ -737,8 +737,51 @@ def main_full():
     print('updown_full_grads.npz:', len(out), 'arrays')
 
 
+def main_full2():
+    """BASELINE-SHAPE fixtures of the Transformer and AoA paths from the REAL reference (their config-size
+    tests ran at B = 2, so split-K plans, the DeferredGrads arena and the 6 720-row vocabulary GEMM were never compared):
+    * ``t_*``: TransformerModel (d=512, d_ff=2048, h=8, N=6) teacher-forced XE at bs64 x 5 captions, T=21 (configs[3]),
+    * ``a_*``: AoAModel (R=E=1024, h=8, 6 refiner layers) teacher-forced at bs10 x 5, T=21 (the configs[4] batch), eval mode
+      (its hard-coded 0.1 dropouts, AoAModel.py:18,119, off),
+    weights from tests/shapes.py:seeded_state on both sides; stored compactly: loss, target log-probs, three full
+    distributions, per-parameter gradient norms + 256-element probes."""
+    sys.path.insert(0, REF)
+    root = os.path.dirname(os.path.dirname(HERE))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    import time
+    import shapes
+    import captioning.models as models          # the reference
+    from captioning.modules import losses
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    out = {}
+    for tag, family, B, seed in (('t', 'transformer', 64, 11), ('a', 'aoa', 10, 12)):
+        t0 = time.time()
+        opt = shapes.big_opt(family)
+        model = models.setup(opt)
+        model.load_state_dict(shapes.seeded_state({k: v.shape for k, v in model.state_dict().items()}, seed))
+        model.train() if family == 'transformer' else model.eval()
+        fc, att = shapes.feats(B, seed=seed)
+        labels, masks = shapes.c2_labels(B=B, seed=seed)
+        logp = model(fc, att, labels[..., :-1], None)
+        loss = losses.LanguageModelCriterion()(logp, labels[..., 1:], masks[..., 1:])
+        loss.backward()
+        tgt = labels[..., 1:].reshape(-1, labels.shape[-1] - 1)
+        out[tag + '_loss'] = loss.detach().numpy()
+        out[tag + '_tgt_logp'] = logp.detach().gather(2, tgt[:, :logp.shape[1]].unsqueeze(2)).squeeze(2).numpy()
+        out[tag + '_logp_row0'] = logp.detach()[0, :3].numpy()
+        for k, p in model.named_parameters():
+            out['%s_gnorm.%s' % (tag, k)] = np.array(float(p.grad.double().norm()))
+            out['%s_gprobe.%s' % (tag, k)] = shapes.grad_probe(p.grad).numpy().copy()
+        print('%s (reference %s, N=%d, T=21): %.0f s, loss %.6f' % (tag, family, B * 5, time.time() - t0, float(loss)))
+    np.savez_compressed(os.path.join(HERE, 'big_xe_grads.npz'), **out)
+    print('big_xe_grads.npz:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'struct':
+    if len(sys.argv) > 1 and sys.argv[1] == 'full2':
+        main_full2()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'struct':
         main_struct()
     elif len(sys.argv) > 1 and sys.argv[1] == 'crit':
         main_crit()

@@ -60,3 +60,33 @@ def grad_probe(t, k=256):
     flat = t.reshape(-1)
     step = max(1, flat.numel() // k)
     return flat[::step][:k]
+
+
+def seeded_state(shapes, seed):
+    """Deterministic parameters for ANY model from its state_dict shapes ({name: shape}): the fixture generator (reference
+    model, build container) and the GPU test (HIP mirror, same keys and shapes) draw identical weights without a 200 MB file.
+    Matrices uniform +-fan_in^-0.5, LayerNorm gains around 1, other vectors small."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name in sorted(shapes):
+        shp = tuple(shapes[name])
+        if len(shp) >= 2:
+            a = float(shp[-1]) ** -0.5
+            out[name] = (torch.rand(*shp, generator=g) * 2 - 1) * a
+        elif name.endswith('a_2') or name.endswith('norm.weight') or name.endswith('layer_norm.weight'):
+            out[name] = 1 + 0.1 * torch.randn(*shp, generator=g)
+        else:
+            out[name] = 0.02 * torch.randn(*shp, generator=g)
+    return out
+
+
+def big_opt(family):
+    """configs/transformer/transformer.yml and configs/aoa.yml sizes on the synthetic vocabulary (dropouts off: the reference's
+    RNG stream cannot be reproduced by a kernel)."""
+    from imagecaptioning.pytorch_amd import synthetic
+    if family == 'transformer':
+        return synthetic.updown_opt(caption_model='transformer', input_encoding_size=512, rnn_size=2048, d_model=512, d_ff=2048,
+                                    N_enc=6, N_dec=6, num_att_heads=8, dropout=0.0, drop_prob_lm=0.0)
+    return synthetic.updown_opt(caption_model='aoa', input_encoding_size=1024, rnn_size=1024, att_hid_size=512, num_heads=8,
+                                multi_head_scale=1, use_multi_head=2, refine=1, refine_aoa=1, use_ff=0, decoder_type='AoA',
+                                mean_feats=1, ctx_drop=1, dropout_aoa=0.3, drop_prob_lm=0.0)

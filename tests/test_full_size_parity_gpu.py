@@ -477,3 +477,36 @@ def test_head_size_not_a_multiple_of_4_is_refused_loudly():
     _, att = shapes.feats(2, K=7, F=44, seed=1)
     with pytest.raises(NotImplementedError, match='head size 6'):
         model(None, att.to(DEV), torch.randint(1, 57, (2, 1, 6), device=DEV), None)
+
+
+@pytest.mark.parametrize('tag,family,B,seed', [('t', 'transformer', 64, 11), ('a', 'aoa', 10, 12)])
+def test_transformer_and_aoa_at_the_baseline_batch_vs_the_reference_itself(tag, family, B, seed):
+    """the BASELINE *shapes* -- Transformer XE at bs64 x 5 captions, T=21 (configs[3]; 6 720 decoder rows,
+    the DeferredGrads arena, every split-K plan of that size) and AoA at bs10 x 5, T=21 (the configs[4] batch) -- against
+    outputs of the REAL reference (tests/golden/big_xe_grads.npz, `make_golden.py full2`): loss, target log-probs, three full
+    distributions, every parameter gradient's norm and a 256-element probe."""
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import LanguageModelCriterion
+    z = np.load(os.path.join(GOLDEN, 'big_xe_grads.npz'))
+    model = models.setup(shapes.big_opt(family))
+    model.load_state_dict(shapes.seeded_state({k: v.shape for k, v in model.state_dict().items()}, seed))
+    model = model.to(DEV)
+    model.train() if family == 'transformer' else model.eval()
+    fc, att = shapes.feats(B, seed=seed)
+    labels, masks = shapes.c2_labels(B=B, seed=seed)
+    labels, masks = labels.to(DEV), masks.to(DEV)
+    logp = model(fc.to(DEV), att.to(DEV), labels[..., :-1], None)
+    tgt = labels[..., 1:].reshape(-1, labels.shape[-1] - 1)
+    got = logp.detach().gather(2, tgt[:, :logp.shape[1]].unsqueeze(2)).squeeze(2).cpu().numpy()
+    np.testing.assert_allclose(got, z[tag + '_tgt_logp'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(logp.detach()[0, :3].cpu().numpy(), z[tag + '_logp_row0'], rtol=0, atol=1e-4)
+    loss = LanguageModelCriterion()(logp, labels[..., 1:], masks[..., 1:])
+    assert abs(loss.item() - float(z[tag + '_loss'])) < 1e-4
+    loss.backward()
+    flat = getattr(model, '_flat', None)
+    if flat is not None:
+        flat.collect_grads()
+    grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in model.named_parameters()}
+    # parameters the graph never reaches have an exact-zero reference gradient (norm 0): skip the relative check for them
+    skip = tuple(k for k in grads if float(z['%s_gnorm.%s' % (tag, k)]) == 0.0 or k.endswith('alpha_net.bias'))
+    check_grads_against_fixture(z, tag, grads, skip=skip)
