@@ -27,17 +27,25 @@ import torch
 
 
 def load_labels(path):
-    """-> dict(labels uint32 [M,L], label_start_ix, label_end_ix) from .npz (native) or .h5 (when h5py is importable)"""
+    """-> dict(labels uint32 [M,L], label_start_ix, label_end_ix) from the reference's ``<name>_label.h5``
+    (scripts/prepro_labels.py:158-163: plain contiguous datasets, read by captioning/data/h5lite.py without h5py) or from the
+    ``.npz`` of tools/convert_labels.py.  A file h5lite refuses (chunked / compressed / written with libver='latest') goes to
+    h5py when it is importable."""
+    keys = ('labels', 'label_start_ix', 'label_end_ix')
     if str(path).endswith('.npz'):
         z = np.load(path)
-        return {k: z[k] for k in ('labels', 'label_start_ix', 'label_end_ix')}
+        return {k: z[k] for k in keys}
+    from . import h5lite
     try:
-        import h5py
-    except ImportError as e:
-        raise RuntimeError('%s is HDF5 and h5py is not available here: convert it once with tools/convert_labels.py '
-                           '(on a machine that has h5py) and pass the .npz' % path) from e
-    with h5py.File(path, 'r') as f:
-        return {k: f[k][:] for k in ('labels', 'label_start_ix', 'label_end_ix')}
+        return h5lite.read_datasets(path, keys)
+    except h5lite.H5LiteError as lite_err:
+        try:
+            import h5py
+        except ImportError as e:
+            raise RuntimeError('%s: %s -- and h5py is not available here: convert the file once with tools/convert_labels.py '
+                               '(on a machine that has h5py) and pass the .npz' % (path, lite_err)) from e
+        with h5py.File(path, 'r') as f:
+            return {k: f[k][:] for k in keys}
 
 
 def decode_image(att_dir, fc_dir, img_id, use_fc, norm_att_feat):

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT
+from conftest import ROOT, GOLDEN
 
 PKG = os.path.join(ROOT, 'imagecaptioning', 'pytorch_amd')
 
@@ -112,6 +112,38 @@ def test_h5_labels_need_h5py_or_the_converter(tmp_path):
     except ImportError:
         with pytest.raises(RuntimeError, match='convert_labels'):
             FL.load_labels(str(tmp_path / 'x.h5'))
+
+
+@pytest.mark.parametrize('name', ['labels_small', 'labels_many'])
+def test_h5lite_reads_label_files_written_by_h5py(name):
+    """the label file of scripts/prepro_labels.py:158-163 (h5py.File(path, 'w') + create_dataset(dtype='uint32',
+    data=...)) is read WITHOUT h5py.  The fixtures were written by genuine h5py 3.3 / HDF5 1.10.6 (tests/golden/make_h5.py,
+    build container only); expected arrays travel beside them."""
+    sys.path.insert(0, PKG)
+    from captioning.data import h5lite, feature_loader as FL
+    want = np.load(os.path.join(GOLDEN, name + '_expected.npz'))
+    f = h5lite.H5File(os.path.join(GOLDEN, name + '.h5'))
+    assert f.keys() == sorted(want.files)
+    for k in want.files:
+        got = f[k]
+        assert got.dtype == np.uint32 and got.shape == want[k].shape and np.array_equal(got, want[k]), k
+    got = FL.load_labels(os.path.join(GOLDEN, name + '.h5'))
+    assert set(got) == {'labels', 'label_start_ix', 'label_end_ix'} and np.array_equal(got['labels'], want['labels'])
+
+
+def test_h5lite_refuses_what_it_does_not_read():
+    sys.path.insert(0, PKG)
+    from captioning.data import h5lite
+    with pytest.raises(h5lite.H5LiteError, match='compression|chunked'):
+        h5lite.read_datasets(os.path.join(GOLDEN, 'labels_chunked.h5'))
+
+
+def test_convert_labels_runs_without_h5py(tmp_path):
+    sys.path.insert(0, PKG)
+    from imagecaptioning.pytorch_amd.tools import convert_labels
+    out = convert_labels.convert(os.path.join(GOLDEN, 'labels_small.h5'), str(tmp_path / 'l.npz'))
+    z, want = np.load(out), np.load(os.path.join(GOLDEN, 'labels_small_expected.npz'))
+    assert sorted(z.files) == sorted(want.files) and all(np.array_equal(z[k], want[k]) for k in want.files)
 
 
 @pytest.mark.gpu
