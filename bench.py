@@ -284,8 +284,11 @@ def main():
 
     ar_events = None          # (start, end) events around the all-reduce of the steps that measure it
 
+    mode_now = {'overlap': overlap, 'sharded': sharded, 'none': False}
+
     def step():
         nonlocal_ar = ar_events
+        overlap, sharded = mode_now['overlap'], mode_now['sharded']
         data = pf.get_batch('train')
         out = lw(data['fc_feats'], data['att_feats'], data['labels'], data['masks'], None, data['gts'], gt_indices, sc_flag,
                  struc_flag, False)
@@ -304,7 +307,7 @@ def main():
             flat.finish_overlap_and_step(**adam)
         elif sharded:
             flat.sharded_step(**adam)
-        elif multi:
+        elif multi and not mode_now['none']:
             if nonlocal_ar is not None:
                 nonlocal_ar[0].record()
             scale = flat.all_reduce()
@@ -369,6 +372,39 @@ def main():
             ms.append(ar_events[0].elapsed_time(ar_events[1]))
         ar_events = None
         allreduce_ms = sorted(ms)[len(ms) // 2]
+    mode_ms = None
+    if multi and os.environ.get('CAPMI_BENCH_MODES', '1') != '0':
+        # One driver run decides between the gradient-exchange modes: after the measurement above (the default mode, the line's
+        # `value`) the same step is timed for a few iterations in every other mode and WITHOUT any exchange -- the difference to
+        # the latter is the communication a mode leaves exposed.  (The replicas drift apart in the exchange-free pass: it comes last.)
+        mode_ms = {}
+        default_name = 'overlap' if overlap else ('rsag' if sharded else 'allreduce')
+
+        def timed(name, k=6, w=2):
+            mode_now.update(overlap=(name == 'overlap'), sharded=(name == 'rsag'), none=(name == 'none'))
+            if name == 'overlap':
+                flat.begin_overlap()
+            else:
+                flat.on_grads_ready = None
+            for _ in range(w):
+                step()
+            sync()
+            t0_ = time.perf_counter()
+            for _ in range(k):
+                step()
+            sync()
+            d_ = torch.tensor([(time.perf_counter() - t0_) / k * 1e3], device=dev, dtype=torch.float64)
+            dist.all_reduce(d_, op=dist.ReduceOp.MAX)
+            return float(d_.item())
+
+        mode_ms[default_name] = dt / args.steps * 1e3
+        for name in ('allreduce', 'rsag', 'overlap', 'none'):
+            if name != default_name:
+                try:
+                    mode_ms[name] = timed(name)
+                except Exception as e:          # a mode that cannot run here must not cost the line
+                    mode_ms[name] = 'failed: %s' % type(e).__name__
+        mode_now.update(overlap=overlap, sharded=sharded, none=False)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -478,7 +514,12 @@ def main():
                        'parallelism': 'dp%d (flat fp32 gradient, %s)' % (world, ('bucketed RCCL all-reduce overlapped with the backward' if overlap else 'one RCCL all-reduce per step') if multi else 'no collective')},
             'collective': None if not multi else {'backend': dist.get_backend(), 'ranks': dist.get_world_size(),
                                                    'mode': 'bucketed overlap' if overlap else ('reduce-scatter + sharded Adam + all-gather' if sharded else 'one flat all-reduce per step'),
-                                                   'bytes': int(flat.grad.numel() * 4), 'allreduce_ms': None if allreduce_ms is None else round(allreduce_ms, 3)},
+                                                   'bytes': int(flat.grad.numel() * 4), 'allreduce_ms': None if allreduce_ms is None else round(allreduce_ms, 3),
+                                                   'ms_per_step_by_mode': None if mode_ms is None else {k: (round(v, 3) if isinstance(v, float) else v) for k, v in mode_ms.items()},
+                                                   'exposed_comm_ms': None if not (mode_ms and isinstance(mode_ms.get('none'), float)) else
+                                                   {k: round(v - mode_ms['none'], 3) for k, v in mode_ms.items() if isinstance(v, float) and k != 'none'},
+                                                   'note': 'ms_per_step_by_mode: the default mode over the K timed steps, the others over 6 extra steps each; '
+                                                           '"none" = no gradient exchange (compute only); exposed = mode - none'},
             'loss': float(loss.detach()), 'roofline': roofline, 'attention': attention, 'kernel_ms_per_step': per_class,
             'early_exit_eos_biased': early, 'cpu_baseline': cpu}
         print(json.dumps(line), flush=True)

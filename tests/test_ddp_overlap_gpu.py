@@ -118,3 +118,7 @@ def test_bench_multi_gpu_code_path_on_rccl_with_one_rank(mode):
     assert line['n_gpus'] == 1 and line['value'] > 1000 and np.isfinite(line['loss'])
     if mode == 'allreduce':
         assert col['mode'] == 'one flat all-reduce per step' and col['allreduce_ms'] is not None and col['allreduce_ms'] >= 0
+    # round 3: one run reports every gradient-exchange mode and the exchange-free step, so a single driver run can decide
+    by_mode = col['ms_per_step_by_mode']
+    assert set(by_mode) == {'allreduce', 'rsag', 'overlap', 'none'} and all(isinstance(v, float) and v > 0 for v in by_mode.values()), by_mode
+    assert set(col['exposed_comm_ms']) == {'allreduce', 'rsag', 'overlap'}
