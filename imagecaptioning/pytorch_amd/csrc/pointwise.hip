@@ -3,6 +3,7 @@
 // dropout-mask generation, column sums and the fused clip+Adam update.  All are HBM/latency bound:
 // 16-byte accesses where the layout allows, grid-stride loops capped at 2048 workgroups.
 #include "capmi_common.h"
+#include <cstdlib>
 #include "profile.h"
 #include "../../../include/capmi.h"
 
@@ -138,17 +139,31 @@ __global__ __launch_bounds__(64) void lstm_cell_fwd_vec_kernel(
     const f32x4 cp = *reinterpret_cast<const f32x4 *>(c_prev + i);
     f32x4 om = {1.f, 1.f, 1.f, 1.f};
     if (out_mask) om = *reinterpret_cast<const f32x4 *>(out_mask + i);
-    f32x4 g[4];
+    f32x4 g[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // all 8 slabs x 4 gates of a trip are requested before the first is consumed (one memory round trip per 8 slabs; gate by gate
+    // it was four), clamped + multiplied by 0/1 so that the trip is a fixed run of loads
+    const float *pb = partial + (size_t)r * 4 * R + j;
+    for (int s0 = 0; s0 < splits; s0 += 8) {
+        f32x4 tv[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                tv[u][q] = *reinterpret_cast<const f32x4 *>(pb + (size_t)min(s0 + u, splits - 1) * slab + (size_t)q * R);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float on = (s0 + u < splits) ? 1.f : 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] += tv[u][q] * on;
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const size_t col = (size_t)q * R + j;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int s0 = 0; s0 < splits; s0 += 8) acc = slab_seq8(partial + (size_t)r * 4 * R + col, s0, splits, slab, acc);
-        if (b_ih) acc += *reinterpret_cast<const f32x4 *>(b_ih + col);
-        if (b_hh) acc += *reinterpret_cast<const f32x4 *>(b_hh + col);
+        if (b_ih) g[q] += *reinterpret_cast<const f32x4 *>(b_ih + col);
+        if (b_hh) g[q] += *reinterpret_cast<const f32x4 *>(b_hh + col);
         if (row_bias)
-            acc += *reinterpret_cast<const f32x4 *>(row_bias + (size_t)(row_bias_idx ? row_bias_idx[r] : r / row_bias_div) * 4 * R + col);
-        g[q] = acc;
+            g[q] += *reinterpret_cast<const f32x4 *>(row_bias + (size_t)(row_bias_idx ? row_bias_idx[r] : r / row_bias_div) * 4 * R + col);
     }
     f32x4 ig, fg, gg, og, cn, hn, hd;
 #pragma unroll
@@ -529,6 +544,52 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
     }
 }
 
+// Round 3 variant: two independent quads per trip (8 x 16-byte loads in flight per thread instead of 4) and non-temporal accesses
+// for the streams nobody re-reads before the next optimizer step (g, m, v: 3/4 of the 1.46 GB), so that the 208 MB of updated
+// parameters -- the first thing the next forward streams -- are what stays in the 256 MiB Infinity Cache.
+template <bool NT>
+__global__ void adam2_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                             float *__restrict__ v, size_t quads, float lr, float b1, float b2, float eps, float wd,
+                             float clip, float gscale, float bc1, float bc2_sqrt) {
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g);
+    f32x4 *p4 = reinterpret_cast<f32x4 *>(p), *m4 = reinterpret_cast<f32x4 *>(m), *v4 = reinterpret_cast<f32x4 *>(v);
+    const float step_size = lr / bc1;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t q0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < quads; q0 += 2 * stride) {
+        const size_t q1 = q0 + stride;
+        const bool two = q1 < quads;
+        const size_t q1c = two ? q1 : q0;
+        f32x4 gg[2], pp[2], mm[2], vv[2];
+        if (NT) {
+            gg[0] = __builtin_nontemporal_load(g4 + q0); gg[1] = __builtin_nontemporal_load(g4 + q1c);
+            mm[0] = __builtin_nontemporal_load(m4 + q0); mm[1] = __builtin_nontemporal_load(m4 + q1c);
+            vv[0] = __builtin_nontemporal_load(v4 + q0); vv[1] = __builtin_nontemporal_load(v4 + q1c);
+        } else {
+            gg[0] = g4[q0]; gg[1] = g4[q1c]; mm[0] = m4[q0]; mm[1] = m4[q1c]; vv[0] = v4[q0]; vv[1] = v4[q1c];
+        }
+        pp[0] = p4[q0]; pp[1] = p4[q1c];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float x = gg[u][k] * gscale;
+                if (clip > 0.f) x = fminf(fmaxf(x, -clip), clip);
+                if (wd != 0.f) x += wd * pp[u][k];
+                mm[u][k] = b1 * mm[u][k] + (1.f - b1) * x;
+                vv[u][k] = b2 * vv[u][k] + (1.f - b2) * x * x;
+                pp[u][k] -= step_size * mm[u][k] / (sqrtf(vv[u][k]) / bc2_sqrt + eps);
+            }
+        p4[q0] = pp[0];
+        if (NT) { __builtin_nontemporal_store(mm[0], m4 + q0); __builtin_nontemporal_store(vv[0], v4 + q0); }
+        else { m4[q0] = mm[0]; v4[q0] = vv[0]; }
+        if (two) {
+            p4[q1] = pp[1];
+            if (NT) { __builtin_nontemporal_store(mm[1], m4 + q1); __builtin_nontemporal_store(vv[1], v4 + q1); }
+            else { m4[q1] = mm[1]; v4[q1] = vv[1]; }
+        }
+    }
+}
+
 __global__ void scst_advantage_kernel(const double *__restrict__ scores, int N, int n, float *__restrict__ reward) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < N) reward[r] = (float)(scores[r] - scores[N + r / n]);
@@ -736,6 +797,16 @@ int capmi_adam_step(float *p, const float *g, float *m, float *v, int64_t count,
         return CAPMI_EINVAL;
     const double bc1 = 1.0 - pow((double)beta1, step);
     const double bc2 = 1.0 - pow((double)beta2, step);
+    static const int variant = [] { const char *e = getenv("CAPMI_ADAM_V"); return e ? atoi(e) : 2; }();   // 0: the round-1 kernel
+    if (variant && count % 4 == 0) {
+        const size_t quads = (size_t)count / 4;
+        if (variant == 2) hipLaunchKernelGGL(adam2_kernel<true>, dim3(grid_for(quads / 2 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m,
+                                             v, quads, lr, beta1, beta2, eps, weight_decay, clip, grad_scale, (float)bc1, (float)sqrt(bc2));
+        else hipLaunchKernelGGL(adam2_kernel<false>, dim3(grid_for(quads / 2 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, quads,
+                                lr, beta1, beta2, eps, weight_decay, clip, grad_scale, (float)bc1, (float)sqrt(bc2));
+        CAPMI_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)count / 4 + 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
                        (size_t)count, lr, beta1, beta2, eps, weight_decay, clip, grad_scale, (float)bc1,
                        (float)sqrt(bc2));

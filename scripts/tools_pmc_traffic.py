@@ -23,7 +23,7 @@ def load(d, counter):
                         wgs = int(r['Grid_Size']) // max(1, int(r['Workgroup_Size']))
                     except (KeyError, ValueError):
                         wgs = 0
-                    name = name.split('(')[0] + (' [stream]' if wgs >= 128 else ' [small]') + '('
+                    name = name[:name.rfind('(')] + (' [stream]' if wgs >= 128 else ' [small]') + '('
                 rows[name].append(float(r['Counter_Value']))
     return rows
 
