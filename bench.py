@@ -285,6 +285,7 @@ def main():
     ar_events = None          # (start, end) events around the all-reduce of the steps that measure it
 
     mode_now = {'overlap': overlap, 'sharded': sharded, 'none': False}
+    one = torch.ones((), dtype=torch.float32, device=dev)
 
     def step():
         nonlocal_ar = ar_events
@@ -296,7 +297,7 @@ def main():
         if loss.dim():
             loss = loss.mean()
         flat.zero_grad()
-        loss.backward()
+        loss.backward(gradient=one if loss.dim() == 0 else None)       # (a cached 1.0: autograd's ones_like is an ATen fill launch)
         flat.collect_grads()
         adam = dict(lr=opt.learning_rate, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon,
                     weight_decay=opt.weight_decay, clip_value=opt.grad_clip_value)

@@ -165,6 +165,7 @@ SIGNATURES = {
     'capmi_ciderd_cook_refs': [_P, _P, _I, _I, _I, _P, _P, C.c_uint32, C.c_double, _P, _P],
     'capmi_ciderd_score_cooked': [_P, _I, _I, _P, _P, _P, _I, _P, _P, C.c_uint32, C.c_double, _P, _P],
     'capmi_scst_advantage': [_P, _I, _I, _P, _P],
+    'capmi_scst_advantage_mean': [_P, _I, _I, _P, _P, _P],
     'capmi_prof_enable': [_I],
     'capmi_prof_reset': [],
     'capmi_prof_read': [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)],

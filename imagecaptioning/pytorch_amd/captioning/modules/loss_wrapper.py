@@ -72,6 +72,6 @@ class LossWrapper(torch.nn.Module):
             adv, _scores = self_critical_reward_device(greedy_res, gts, gen_result, opt)      # [N] on device
             reward = adv.unsqueeze(1).expand(-1, gen_result.shape[1])
             loss = self.rl_crit(sample_logprobs, gen_result.data, reward, reduction=reduction)
-            out['reward'] = adv.mean()
+            out['reward'] = getattr(adv, '_capmi_mean', None) if getattr(adv, '_capmi_mean', None) is not None else adv.mean()
         out['loss'] = loss
         return out

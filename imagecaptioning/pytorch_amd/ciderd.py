@@ -175,6 +175,9 @@ class DeviceCiderD:
             img = torch.cat([torch.arange(N, device=hyp.device) // n, torch.arange(B, device=hyp.device)]).to(torch.int32)
             self._img_cache[key] = img
         scores = self.score(hyp, img, refs, n_refs, cooked)
-        reward = torch.empty(N, dtype=torch.float32, device=hyp.device)
-        check(lib.capmi_scst_advantage(ptr(scores), N, n, ptr(reward), stream_ptr()), 'capmi_scst_advantage')
+        buf = torch.empty(N + 1, dtype=torch.float32, device=hyp.device)      # [advantage of the N rows | their mean]
+        reward = buf[:N]
+        check(lib.capmi_scst_advantage_mean(ptr(scores), N, n, ptr(buf), buf.data_ptr() + 4 * N, stream_ptr()),
+              'capmi_scst_advantage_mean')
+        reward._capmi_mean = buf[N]             # 0-dim view: LossWrapper's out['reward'] without an ATen mean launch
         return reward, scores

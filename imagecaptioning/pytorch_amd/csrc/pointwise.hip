@@ -590,9 +590,21 @@ __global__ void adam2_kernel(float *__restrict__ p, const float *__restrict__ g,
     }
 }
 
-__global__ void scst_advantage_kernel(const double *__restrict__ scores, int N, int n, float *__restrict__ reward) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < N) reward[r] = (float)(scores[r] - scores[N + r / n]);
+// one workgroup: N <= a few thousand rows.  reward[N] (written when N > 0 rows exist and mean_out is given) = mean advantage, what
+// LossWrapper reports as out['reward'] (loss_wrapper.py:72) -- an ATen mean launch otherwise
+__global__ void scst_advantage_kernel(const double *__restrict__ scores, int N, int n, float *__restrict__ reward,
+                                      float *__restrict__ mean_out) {
+    __shared__ float scratch[32];
+    float s = 0.f;
+    for (int r = threadIdx.x; r < N; r += blockDim.x) {
+        const float a = (float)(scores[r] - scores[N + r / n]);
+        reward[r] = a;
+        s += a;
+    }
+    if (mean_out) {
+        s = block_sum(s, scratch);
+        if (threadIdx.x == 0) mean_out[0] = s / (float)N;
+    }
 }
 
 }  // namespace
@@ -814,12 +826,15 @@ int capmi_adam_step(float *p, const float *g, float *m, float *v, int64_t count,
     return 0;
 }
 
-int capmi_scst_advantage(const double *scores, int N, int n, float *reward, void *stream) {
+int capmi_scst_advantage_mean(const double *scores, int N, int n, float *reward, float *mean_out, void *stream) {
     if (!scores || !reward || N <= 0 || n <= 0) return CAPMI_EINVAL;
-    hipLaunchKernelGGL(scst_advantage_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, scores, N, n,
-                       reward);
+    hipLaunchKernelGGL(scst_advantage_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scores, N, n, reward, mean_out);
     CAPMI_CHECK_LAUNCH();
     return 0;
+}
+
+int capmi_scst_advantage(const double *scores, int N, int n, float *reward, void *stream) {
+    return capmi_scst_advantage_mean(scores, N, n, reward, nullptr, stream);
 }
 
 }  // extern "C"

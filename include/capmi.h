@@ -402,6 +402,8 @@ int capmi_ciderd_score_cooked(const int64_t *hyp, int H, int L, const int32_t *h
                               void *stream);
 /* advantage + broadcast (rewards.py:76-79): reward[r] = scores[r] - scores[N + r/n]  (float32 [N]) */
 int capmi_scst_advantage(const double *scores, int N, int n, float *reward, void *stream);
+/* same; mean_out[0] = mean of reward[0..N) (what LossWrapper reports as out['reward'], loss_wrapper.py:72) in the same launch */
+int capmi_scst_advantage_mean(const double *scores, int N, int n, float *reward, float *mean_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Launch instrumentation (counterpart of the reference's `time/batch` prints, train.py:198-208).
