@@ -48,7 +48,7 @@ class UpDownRollout(C.Structure):
                                     'fc_gates', 'logits', 'it', 'unfinished', 'partial')] +
                 [('partial_capacity', C.c_int64), ('top_k', C.c_int), ('top_p', C.c_float), ('ss_mode', c_f),
                  ('planes', c_f), ('planes_bytes', C.c_int64), ('early_exit', C.c_int), ('early_exit_from', C.c_int),
-                 ('alive_host', c_f), ('steps_run', C.c_int)])
+                 ('alive_host', c_f), ('steps_run', C.c_int), ('pre_partial', c_f), ('pre_capacity', C.c_int64)])
 
 
 class SampleFilter(C.Structure):
@@ -138,6 +138,7 @@ SIGNATURES = {
     'capmi_attention_bwd_batched': [_P, _I] + [_P] * 9 + [_I] * 7 + [_P],
     'capmi_lstm_cell_fwd': [_P, _I, _P, _P, _P, _I, _P] + [_P] * 6 + [_I, _I, _P],
     'capmi_lstm_cell_fwd_pl': [_P, _I, _P, _P, _P, _I, _P] + [_P] * 6 + [_I, _I, _P, _P, _P],
+    'capmi_lstm_cell_fwd_pl2': [_P, _I, _P, _I, _P, _P, _P, _I, _P] + [_P] * 6 + [_I, _I, _P, _P, _P],
     'capmi_lstm_cell_bwd': [_P, _I, _P, _P, _I, _P, _I] + [_P] * 6 + [_I, _I, _P],
     'capmi_lstm_cell_bwd_partial_pl': [_P, _I, _P, _P, _I, _I, _I64, _P, _I, _I, _I64] + [_P] * 6 + [_I, _I, _P, _P],
     'capmi_embed_fwd_pl': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P],

@@ -204,8 +204,10 @@ class FeatureLoader:
             att_masks[b, :a.shape[0]] = 1
         labels, masks, gts, infos = self.label_part(idx)
         state = {'loader_order': {split: snap}, 'loader_rng': rng_state, 'loader_cap_rng': self.cap_rng.getstate()}
-        return {'fc_feats': torch.from_numpy(fc), 'att_feats': torch.from_numpy(att),
-                'att_masks': None if att_masks.sum() == att_masks.size else torch.from_numpy(att_masks),     # :240-241
+        am = None if att_masks.sum() == att_masks.size else torch.from_numpy(att_masks)      # :240-241
+        if am is not None:
+            am._capmi_kmax = kmax         # clip_att's K, known here on the host: the step never syncs for it (ops.clip_len)
+        return {'fc_feats': torch.from_numpy(fc), 'att_feats': torch.from_numpy(att), 'att_masks': am,
                 'labels': torch.from_numpy(labels), 'masks': torch.from_numpy(masks), 'gts': gts,
                 'bounds': {'it_pos_now': pos_now, 'it_max': len(self.order[split]), 'wrapped': wrapped,
                            'loader_state': state}, 'infos': infos}

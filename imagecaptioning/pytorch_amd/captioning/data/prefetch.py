@@ -47,6 +47,8 @@ class DevicePrefetcher:
                 if torch.is_tensor(t):
                     # (a ResidentFeatures loader hands over features that already live in HBM, gathered on this stream)
                     out[k] = t if t.device.type == 'cuda' else self._pin(split, slot, k, t).to(self.device, non_blocking=True)
+                    if hasattr(t, '_capmi_kmax'):
+                        out[k]._capmi_kmax = t._capmi_kmax        # the loader's host-side clip_att K rides along (ops.clip_len)
             # reference captions travel with the batch as a device image (rewards.GtsBatch): packed here, once per batch, on the
             # copy stream -- the SCST step then never re-packs them and never has to recognise a batch by object identity
             from ..utils import rewards

@@ -133,6 +133,7 @@ class ResidentFeatures:
             for b, k in enumerate(ks):
                 m[b, :k] = 1
             att_masks = torch.from_numpy(m).to(self.dev)
+            att_masks._capmi_kmax = kmax   # clip_att's K (ops.clip_len): no device->host sync in the step
         labels, masks, gts, infos = ld.label_part(idx)
         state = {'loader_order': {split: snap}, 'loader_rng': rng_state, 'loader_cap_rng': ld.cap_rng.getstate()}
         return {'fc_feats': fc, 'att_feats': att, 'att_masks': att_masks, 'labels': torch.from_numpy(labels),

@@ -10,6 +10,7 @@ from .CaptionModel import CaptionModel
 from .TransformerModel import _LayerNorm, _Sublayer, _clones
 from imagecaptioning.pytorch_amd import aoa_engine as engine
 from imagecaptioning.pytorch_amd._lib import CapmiError
+from imagecaptioning.pytorch_amd.ops import clip_len
 
 
 class _MHDot(nn.Module):
@@ -123,7 +124,7 @@ class AoAModel(CaptionModel):
         if not att_feats.is_cuda:
             raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
         if att_masks is not None and not clipped:
-            ml = int(att_masks.long().sum(1).max())
+            ml = clip_len(att_masks)
             att_feats, att_masks = att_feats[:, :ml], att_masks[:, :ml].float().contiguous()
         params = [p for _, p in self.named_parameters()]
         from imagecaptioning.pytorch_amd import sparse_logp
@@ -151,7 +152,7 @@ class AoAModel(CaptionModel):
             if not att_feats.is_cuda:
                 raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
             if att_masks is not None:
-                ml = int(att_masks.long().sum(1).max())
+                ml = clip_len(att_masks)
                 att_feats, att_masks = att_feats[:, :ml], att_masks[:, :ml].float().contiguous()
             with torch.no_grad():
                 P = dict(zip(self._param_names, [p.detach() for _, p in self.named_parameters()]))
@@ -162,7 +163,7 @@ class AoAModel(CaptionModel):
             if not att_feats.is_cuda:
                 raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
             if att_masks is not None:
-                ml = int(att_masks.long().sum(1).max())
+                ml = clip_len(att_masks)
                 att_feats, att_masks = att_feats[:, :ml], att_masks[:, :ml].float().contiguous()
             P = dict(zip(self._param_names, [p.detach() for _, p in self.named_parameters()]))
 
@@ -182,7 +183,7 @@ class AoAModel(CaptionModel):
                 self._graphs = GraphedDecode()
             gcfg = dict(cfg, seed=0)
             if att_masks is not None:                 # the data-dependent clip (a host sync) stays outside the graph
-                ml = int(att_masks.long().sum(1).max())
+                ml = clip_len(att_masks)
                 att_feats, att_masks = att_feats[:, :ml], att_masks[:, :ml].float().contiguous()
             return self._graphs(('greedy', cfg['n'], L), lambda a, m: self._run(gcfg, a, m, clipped=True),
                                 (att_feats.float().contiguous(), att_masks))

@@ -23,7 +23,7 @@ from imagecaptioning.pytorch_amd import ops
 from imagecaptioning.pytorch_amd import sparse_logp
 from imagecaptioning.pytorch_amd._lib import CapmiError
 
-from .utils import parse_sample_method      # noqa: E402
+from .utils import parse_sample_method, clip_len      # noqa: E402
 
 
 class _RolloutFn(torch.autograd.Function):
@@ -38,7 +38,7 @@ class _RolloutFn(torch.autograd.Function):
             # eval-mode features of the same images -> 2B feature images written side by side (no torch.cat), explicit
             # row -> image map
             B = fc_feats.shape[0]
-            K = att_feats.shape[1] if att_masks is None else int(att_masks.long().sum(1).max())
+            K = clip_len(att_masks, att_feats.shape[1])
             R, A = P['fc_embed.0.weight'].shape[0], P['ctx2att.weight'].shape[0]
             dev = fc_feats.device
             pr_run = engine.Prepared()
@@ -245,7 +245,7 @@ class AttModel(CaptionModel):
         colsum = seq[:, 1:].sum(0)
         zero_cols = (colsum == 0).nonzero()
         T_eff = int(zero_cols[0]) + 1 if zero_cols.numel() else T
-        K = att_feats.shape[1] if att_masks is None else int(att_masks.long().sum(1).max())
+        K = clip_len(att_masks, att_feats.shape[1])
         cfg = dict(n=n, T=T_eff, L=T, mode='forced', forced=seq, teacher=True)
         cfg.update(self._dropout_masks(B, K, N, T_eff, fc_feats.device))
         if self.training and self.ss_prob > 0.0:
@@ -287,7 +287,7 @@ class AttModel(CaptionModel):
         B = fc_feats.size(0)
         N = B * sample_n
         L = self.seq_length
-        K = att_feats.shape[1] if att_masks is None else int(att_masks.long().sum(1).max())
+        K = clip_len(att_masks, att_feats.shape[1])
         cfg = dict(n=sample_n, T=L, L=L, mode=mode, temperature=temperature, seed=self._next_seed(), top_k=top_k, top_p=top_p)
         cfg.update(self._dropout_masks(B, K, N, L, fc_feats.device))
         forced = opt.get('_forced_seq')           # test hook: teacher-force a sampled sequence
@@ -310,7 +310,7 @@ class AttModel(CaptionModel):
         self._device_check(fc_feats)
         B, n, L = fc_feats.size(0), int(sample_n), self.seq_length
         N, dev = B * n, fc_feats.device
-        K = att_feats.shape[1] if att_masks is None else int(att_masks.long().sum(1).max())
+        K = clip_len(att_masks, att_feats.shape[1])
         was_training = self.training
         self.train()                               # dropout masks for the sampled rows
         cfg = dict(n=n, T=L, L=L, mode='sample', temperature=temperature, seed=self._next_seed(), fused_greedy=True)

@@ -10,6 +10,7 @@ import torch.nn as nn
 from .CaptionModel import CaptionModel
 from imagecaptioning.pytorch_amd import transformer_engine as engine
 from imagecaptioning.pytorch_amd._lib import CapmiError
+from imagecaptioning.pytorch_amd.ops import clip_len
 
 
 def _clones(m, n):
@@ -183,7 +184,7 @@ class TransformerModel(CaptionModel):
 
     def _clip(self, att_feats, att_masks):
         if att_masks is not None:
-            ml = int(att_masks.long().sum(1).max())
+            ml = clip_len(att_masks)
             att_feats, att_masks = att_feats[:, :ml].contiguous(), att_masks[:, :ml].contiguous().float()
         return att_feats.float().contiguous(), att_masks
 

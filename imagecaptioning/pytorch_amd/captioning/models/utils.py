@@ -5,6 +5,9 @@ parity with callers that expand tensors themselves (beam search, ensembles)."""
 import torch
 
 
+from imagecaptioning.pytorch_amd.ops import clip_len      # noqa: F401  (clip_att's K, cached on the mask)
+
+
 def repeat_tensors(n, x):
     """[B, ...] -> [B*n, ...], rows of one image adjacent (reference: models/utils.py:3-14)."""
     if torch.is_tensor(x):

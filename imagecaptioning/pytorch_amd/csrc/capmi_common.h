@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #define CAPMI_WAVE 64
 
@@ -99,6 +101,17 @@ struct Philox {
 // uniform in (0,1): never 0 so log() is finite
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
+// Profiling ablations (CAPMI_*_ABLATE) drop parts of a kernel's work to time the rest: results are WRONG by design.  They are
+// read once per process through this helper, which says so loudly on stderr, so a stray variable cannot silently corrupt a
+// training run.
+static inline int ablate_env(const char *name) {
+    const char *e = getenv(name);
+    int v = e ? atoi(e) : 0;
+    if (v)
+        fprintf(stderr, "\n*** capmi: %s=%d -- PROFILING ABLATION ACTIVE, kernel results are deliberately incomplete; "
+                        "unset it for any real run ***\n\n", name, v);
+    return v;
+}
 }  // namespace capmi
 
 // ---- "A planes": an activation matrix X[M <= 64, K] pre-split for the decode GEMMs (gemm_ares.hip, round 3) -------------

@@ -795,7 +795,7 @@ static int launch_ts(const KArgs &a, hipStream_t st, int pcls, double bytes, dou
                 dset = true;
             }
             if constexpr (BKC && TS == 6 && TM == 2) {
-                static const int abl = [] { const char *e = getenv("CAPMI_ARES_ABLATE"); return e ? atoi(e) : 0; }();
+                static const int abl = capmi::ablate_env("CAPMI_ARES_ABLATE");
                 if (abl == 16) {
                     static bool tset = false;
                     if (!tset) {
@@ -814,7 +814,7 @@ static int launch_ts(const KArgs &a, hipStream_t st, int pcls, double bytes, dou
         }
     }
     if constexpr (BKC && TS == 6 && TM == 2 && X3) {
-        static const int abl = [] { const char *e = getenv("CAPMI_ARES_ABLATE"); return e ? atoi(e) : 0; }();
+        static const int abl = capmi::ablate_env("CAPMI_ARES_ABLATE");
         if (abl) {
 #define CAPMI_ABL(V) case V: { static bool set = false; if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_ares_kernel<BKC, TS, TM, X3, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
             hipLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM, X3, V>), grid, dim3(AR_NT), lds, st, a); return 0; }
@@ -871,7 +871,7 @@ static int launch_apl_ts(const KArgs &a, hipStream_t st, int pcls, double bytes,
         else hipLaunchKernelGGL((gemm_apl_kernel<BKC, TS, TM, NTW>), grid, dim3(AR_NT), lds, st, a);                       \
     } while (0)
     if constexpr (BKC && TS == 6 && TM == 2) {
-        static const int abl = [] { const char *e = getenv("CAPMI_APL_ABLATE"); return e ? atoi(e) : 0; }();
+        static const int abl = capmi::ablate_env("CAPMI_APL_ABLATE");
         static const int pfm = [] { const char *e = getenv("CAPMI_APL_PF"); return e ? atoi(e) : 0; }();
         if (abl || pfm) {
 #define CAPMI_APL_V(A_, P_)                                                                                                \

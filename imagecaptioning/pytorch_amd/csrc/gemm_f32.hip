@@ -416,7 +416,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
         a.seg[s].tstart = 0x7fffffff;
     }
     a.tiles_total = tiles;
-    static const int env_ablate = [] { const char *e = getenv("CAPMI_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+    static const int env_ablate = capmi::ablate_env("CAPMI_GEMM_ABLATE");
     a.ablate = env_ablate;
     a.M = d->M; a.N = d->N; a.C = d->C; a.ldc = d->ldc;
     a.bias = d->bias; a.bias2 = d->bias2; a.row_bias = d->row_bias;

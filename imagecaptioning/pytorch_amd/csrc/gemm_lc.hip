@@ -348,7 +348,7 @@ static int launch_lc_t(const KArgs &a, hipStream_t st, int pcls, double bytes, d
     dim3 grid((a.N + LC_BN - 1) / LC_BN, a.splits);
     hipEvent_t e0, e1;
     const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
-    static const int abl = [] { const char *e = getenv("CAPMI_LC_ABLATE"); return e ? atoi(e) : 0; }();
+    static const int abl = capmi::ablate_env("CAPMI_LC_ABLATE");
 #define CAPMI_LC_GO(A_)                                                                                                    \
     do {                                                                                                                   \
         static bool set = false;                                                                                           \

@@ -65,12 +65,17 @@ __global__ void lstm_cell_fwd_kernel(const float *__restrict__ partial, int spli
                                      const float *__restrict__ c_prev, float *__restrict__ h,
                                      float *__restrict__ c, float *__restrict__ gates_act,
                                      const float *__restrict__ out_mask, float *__restrict__ h_drop, int N, int R,
-                                     unsigned char *__restrict__ pl_h, unsigned char *__restrict__ pl_hd) {
+                                     unsigned char *__restrict__ pl_h, unsigned char *__restrict__ pl_hd,
+                                     const float *__restrict__ partial2, int splits2) {
     const size_t total = (size_t)N * R;
     const size_t slab = (size_t)N * 4 * R;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / R), j = (int)(i % R);
         float g[4] = {0.f, 0.f, 0.f, 0.f};
+        // second slab set (the h-dependent K segments of the gate GEMM, computed ahead on the side stream)
+        for (int s2 = 0; s2 < splits2; ++s2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] += partial2[(size_t)s2 * slab + (size_t)r * 4 * R + (size_t)q * R + j];
         // K-slice reduction: issue 8 slabs x 4 gates of independent loads per trip (the rolled form
         // waits for every load before the next one: 36 serial HBM latencies, 18 us per launch)
         const float *pb = partial + (size_t)r * 4 * R + j;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(64) void lstm_cell_fwd_vec_kernel(
     const float *__restrict__ row_bias, int row_bias_div, const int *__restrict__ row_bias_idx,
     const float *__restrict__ c_prev, float *__restrict__ h, float *__restrict__ c, float *__restrict__ gates_act,
     const float *__restrict__ out_mask, float *__restrict__ h_drop, int N, int R, unsigned char *__restrict__ pl_h,
-    unsigned char *__restrict__ pl_hd) {
+    unsigned char *__restrict__ pl_hd, const float *__restrict__ partial2, int splits2) {
     const int R4 = R >> 2;
     const int i4 = blockIdx.x * blockDim.x + threadIdx.x;
     if (i4 >= N * R4) return;
@@ -142,17 +147,23 @@ __global__ __launch_bounds__(64) void lstm_cell_fwd_vec_kernel(
     f32x4 g[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     // all 8 slabs x 4 gates of a trip are requested before the first is consumed (one memory round trip per 8 slabs; gate by gate
     // it was four), clamped + multiplied by 0/1 so that the trip is a fixed run of loads
+    // The slabs of BOTH sets (this launch's gate GEMM, and -- when given -- the h-dependent K segments computed ahead on the side
+    // stream) form one list of splits + splits2 slabs, walked 8 at a time.
     const float *pb = partial + (size_t)r * 4 * R + j;
-    for (int s0 = 0; s0 < splits; s0 += 8) {
+    const float *pb2 = partial2 ? partial2 + (size_t)r * 4 * R + j : pb;
+    const int tot = splits + splits2;
+    for (int s0 = 0; s0 < tot; s0 += 8) {
         f32x4 tv[8][4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 8; ++u) {
+            const int si = min(s0 + u, tot - 1);
+            const float *ps = si < splits ? pb + (size_t)si * slab : pb2 + (size_t)(si - splits) * slab;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                tv[u][q] = *reinterpret_cast<const f32x4 *>(pb + (size_t)min(s0 + u, splits - 1) * slab + (size_t)q * R);
+            for (int q = 0; q < 4; ++q) tv[u][q] = *reinterpret_cast<const f32x4 *>(ps + (size_t)q * R);
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const float on = (s0 + u < splits) ? 1.f : 0.f;
+            const float on = (s0 + u < tot) ? 1.f : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) g[q] += tv[u][q] * on;
         }
@@ -638,21 +649,32 @@ int capmi_lstm_cell_fwd_pl(const float *partial, int splits, const float *b_ih, 
                            int row_bias_div, const int32_t *row_bias_idx, const float *c_prev, float *h, float *c,
                            float *gates_act, const float *out_mask, float *h_drop, int N, int R, void *h_planes,
                            void *h_drop_planes, void *stream) {
-    if (!partial || splits < 1 || !c_prev || !h || !c || N <= 0 || R <= 0) return CAPMI_EINVAL;
+    return capmi_lstm_cell_fwd_pl2(partial, splits, nullptr, 0, b_ih, b_hh, row_bias, row_bias_div, row_bias_idx, c_prev, h, c,
+                                   gates_act, out_mask, h_drop, N, R, h_planes, h_drop_planes, stream);
+}
+
+int capmi_lstm_cell_fwd_pl2(const float *partial, int splits, const float *partial2, int splits2, const float *b_ih,
+                            const float *b_hh, const float *row_bias, int row_bias_div, const int32_t *row_bias_idx,
+                            const float *c_prev, float *h, float *c, float *gates_act, const float *out_mask, float *h_drop,
+                            int N, int R, void *h_planes, void *h_drop_planes, void *stream) {
+    if (!partial || splits < 1 || !c_prev || !h || !c || N <= 0 || R <= 0 || splits2 < 0 || (splits2 > 0 && !partial2))
+        return CAPMI_EINVAL;
+    if (splits2 == 0) partial2 = nullptr;
     if ((h_planes || h_drop_planes) && N > 64) return CAPMI_EINVAL;
     unsigned char *pl_h = static_cast<unsigned char *>(h_planes), *pl_hd = static_cast<unsigned char *>(h_drop_planes);
     const int rbd = row_bias_div > 0 ? row_bias_div : 1;
-    if ((pl_h || pl_hd) && R % 4 == 0 &&
-        aligned16(partial, b_ih, b_hh, row_bias, c_prev, h, c, gates_act, out_mask, h_drop)) {
+    if ((pl_h || pl_hd || partial2) && R % 4 == 0 &&
+        aligned16(partial, partial2, b_ih, b_hh, row_bias, c_prev, h, c, gates_act, out_mask, h_drop)) {
         const int quads = N * (R / 4);
         hipLaunchKernelGGL(lstm_cell_fwd_vec_kernel, dim3((quads + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, splits,
-                           b_ih, b_hh, row_bias, rbd, row_bias_idx, c_prev, h, c, gates_act, out_mask, h_drop, N, R, pl_h, pl_hd);
+                           b_ih, b_hh, row_bias, rbd, row_bias_idx, c_prev, h, c, gates_act, out_mask, h_drop, N, R, pl_h, pl_hd,
+                           partial2, splits2);
         CAPMI_CHECK_LAUNCH();
         return 0;
     }
     hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid_for((size_t)N * R)), dim3(256), 0, (hipStream_t)stream, partial,
                        splits, b_ih, b_hh, row_bias, rbd, row_bias_idx, c_prev, h, c, gates_act, out_mask, h_drop, N, R, pl_h,
-                       pl_hd);
+                       pl_hd, partial2, splits2);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

@@ -546,7 +546,7 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
     const bool al = ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(bias) |
                       reinterpret_cast<uintptr_t>(gumbel) | reinterpret_cast<uintptr_t>(seq_logp)) & 15) == 0 &&
                     (slab_stride % 4 == 0);
-    static const int env_abl = [] { const char *e = getenv("CAPMI_SEL_ABLATE"); return e ? atoi(e) : 0; }();   // profiling only
+    static const int env_abl = capmi::ablate_env("CAPMI_SEL_ABLATE");   // profiling only
     if (al && V1 % 4 == 0 && V1 <= 3 * 4 * SEL_THREADS) {
 #define CAPMI_SEL(NQ)                                                                                                   \
     hipLaunchKernelGGL(logsoftmax_select_reg_kernel<NQ>, dim3(N), dim3(SEL_THREADS), 0, st, partial, splits,           \

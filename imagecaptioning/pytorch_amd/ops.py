@@ -137,13 +137,13 @@ class _WsView:
 
 class SlabArena:
     """Bump allocator of split-K workspaces whose reduction is deferred: one region ([tickets | slabs]) per GEMM, the
-    same offsets step after step.  Chunks are zero-initialised (the ticket words of a region must be zero); a region
-    start that lands on former slab data (a different GEMM sequence than the last backward) gets its tickets re-zeroed."""
+    same offsets step after step.  A deferred GEMM never self-reduces (gemm_f32.hip: self_reduce requires !defer_reduce), so
+    the ticket words in front of each region are layout only -- nothing reads them and nothing has to keep them zero."""
 
     CHUNK = 128 * 1024 * 1024          # floats (512 MB)
 
     def __init__(self, device):
-        self.dev, self.chunks, self.dirty, self.starts = device, [], [], set()
+        self.dev, self.chunks = device, []
         self.cur = self.off = 0
 
     def reset(self):
@@ -155,18 +155,10 @@ class SlabArena:
             self.cur, self.off = self.cur + 1, 0
         if self.cur == len(self.chunks):
             self.chunks.append(torch.zeros(self.CHUNK, dtype=_f32, device=self.dev))
-            self.dirty.append(0)
-        view = self.chunks[self.cur][self.off:self.off + floats]
-        key = (self.cur, self.off)
-        if key not in self.starts:
-            if self.off < self.dirty[self.cur]:
-                view[:Workspace.COUNTER_FLOATS].zero_()
-            self.starts.add(key)
-        return view
+        return self.chunks[self.cur][self.off:self.off + floats]
 
     def commit(self, floats):
         self.off += (floats + 63) // 64 * 64
-        self.dirty[self.cur] = max(self.dirty[self.cur], self.off)
 
 
 class DeferredGrads:
@@ -417,3 +409,21 @@ def logsoftmax_select(logits, step, L, mode, temperature, gumbel, seed, forced, 
                                               ptr(it_next), ptr(unfinished), ptr(seq_logp), ptr(sel_logp), ptr(live), None,
                                               C.byref(flt) if (top_k or top_p) else None, stream_ptr()),
           'capmi_logsoftmax_select_partial')
+
+
+def clip_len(att_masks, width=None):
+    """Longest valid region count of the batch -- the K that clip_att (AttModel.py:106-112) truncates to.
+
+    ``int(mask.sum(1).max())`` is a blocking device->host round trip; the value is cached on the mask tensor
+    (``_capmi_kmax``) so one step pays it at most once, and the loaders / DevicePrefetcher stamp it from the host-side
+    batch (they built the mask, they know kmax), so a training step never syncs for it."""
+    if att_masks is None:
+        return width
+    k = getattr(att_masks, '_capmi_kmax', None)
+    if k is None:
+        k = int(att_masks.long().sum(1).max())
+        try:
+            att_masks._capmi_kmax = k
+        except Exception:
+            pass
+    return k

@@ -149,6 +149,8 @@ def fused_reward_criterion(logp, seq, reward, per_row=False):
         return None                                   # not the rollout's own tokens
     if reward.shape[0] != n_used or reward.ndim not in (1, 2) or not reward.is_cuda:
         return None
+    if per_row and n_used > 2048:
+        return None                                   # capmi_reward_criterion keeps the per-row losses in one workgroup's LDS
     sink.sel_taken = True
     return _FusedReward.apply(full, sink, reward.float(), n_used, per_row)
 

@@ -15,6 +15,7 @@ import math
 import torch
 
 from . import _lib, ops
+from .ops import clip_len
 from ._lib import lib, ptr, check, stream_ptr
 
 _f32 = torch.float32
@@ -56,7 +57,7 @@ def prepare(P, fc_feats, att_feats, att_masks=None, drop_fc=None, drop_att=None,
     out: optional (fc [B,R], att [B,K,R], p_att [B,K,A]) contiguous targets (slices of a caller's larger buffers)."""
     B = fc_feats.shape[0]
     if att_masks is not None:
-        max_len = int(att_masks.long().sum(1).max())          # clip_att, AttModel.py:106-112
+        max_len = clip_len(att_masks)          # clip_att, AttModel.py:106-112
         att_feats = att_feats[:, :max_len].contiguous()
         att_masks = att_masks[:, :max_len].contiguous().float()
         if drop_att is not None:
@@ -196,6 +197,12 @@ class Rollout:
             nb = int(lib.capmi_updown_planes_bytes(R, E))
             self.planes = ops.planes_scratch(dev, ('updown_fwd', R, E, stream_ptr()), nb)
             r.planes, r.planes_bytes = self.planes.data_ptr(), nb
+            if not teacher and os.environ.get('CAPMI_PRE_STREAM', '0') == '1':       # opt-in: measured slower (rollout.hip)
+                # workspace of the AHEAD gate GEMMs on the library's side stream (capmi.h capmi_updown_rollout.pre_partial):
+                # two regions of [ticket words | up to 8 K-slice slabs of N x 4R]
+                per = ops.Workspace.COUNTER_FLOATS + 8 * 64 * 4 * R
+                self.pre = ops.planes_scratch(dev, ('updown_pre', R, stream_ptr()), 2 * per * 4).view(torch.float32)
+                r.pre_partial, r.pre_capacity = self.pre.data_ptr(), 2 * per
         # early exit of free-running rollouts (AttModel.py:349-350): behind steps early_exit_from + k * early_exit - 1 (7, 11, 15 by
         # default) the driver looks, two steps later, at a pinned word the select kernels set and stops enqueuing once every row
         # has emitted its EOS (CAPMI_EARLY_EXIT=0: never)

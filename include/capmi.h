@@ -181,6 +181,13 @@ int capmi_lstm_cell_fwd_pl(const float *partial, int splits, const float *b_ih, 
                            const float *row_bias, int row_bias_div, const int32_t *row_bias_idx, const float *c_prev,
                            float *h, float *c, float *gates_act, const float *out_mask, float *h_drop,
                            int N, int R, void *h_planes, void *h_drop_planes, void *stream);
+/* Same; the gate pre-activations are the sum of TWO slab sets (same slab stride N*4R): `partial` and `partial2` -- the K
+ * segments of the gate GEMM that depend only on the previous hidden states are computed ahead on a side stream
+ * (capmi_updown_rollout.pre_partial) and meet the rest here.  splits2 = 0: one set. */
+int capmi_lstm_cell_fwd_pl2(const float *partial, int splits, const float *partial2, int splits2, const float *b_ih,
+                            const float *b_hh, const float *row_bias, int row_bias_div, const int32_t *row_bias_idx,
+                            const float *c_prev, float *h, float *c, float *gates_act, const float *out_mask, float *h_drop,
+                            int N, int R, void *h_planes, void *h_drop_planes, void *stream);
 
 /* backward: given dh (total gradient reaching h'), dc_next (gradient reaching c' from step t+1),
  * the saved activated gates, c_prev and c': d_gates [N,4R] (pre-activation) and dc_prev [N,R].
@@ -503,6 +510,14 @@ typedef struct capmi_updown_rollout {
     int early_exit_from;
     int32_t *alive_host;
     int steps_run;
+    /* Round 3, optional (needs `planes`): workspace of the AHEAD gate GEMMs, 2 regions of pre_capacity / 2 floats (each laid
+     * out like `partial`: CAPMI_WS_COUNTER_FLOATS ticket words + K-slice slabs).  The K segments of the two LSTM gate GEMMs that
+     * depend only on hidden states of the previous launches -- [h_lang | h_att] of the attention LSTM, [h_att | h_lang] of the
+     * language LSTM: 2/3 of their 48 MB -- are enqueued on a second HIP stream of the library's and stream beside the
+     * latency-bound kernels of the step (log-softmax + select, h2att + attention); the gate GEMM on the critical path keeps
+     * the newest segment (token embedding / context) and the LSTM cell sums both slab sets.  NULL: everything on `stream`. */
+    float *pre_partial;
+    int64_t pre_capacity;
 } capmi_updown_rollout;
 
 int64_t capmi_updown_planes_bytes(int R, int E);

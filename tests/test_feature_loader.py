@@ -72,6 +72,8 @@ def test_batch_contract_variable_regions(tmp_path):
             assert float(d['att_feats'][b, k:].abs().sum()) == 0
             if d['att_masks'] is not None:
                 assert d['att_masks'][b].tolist() == [1.0] * k + [0.0] * (K - k)
+                # clip_att's K rides on the mask from the host side, so the step never syncs for it (ops.clip_len)
+                assert d['att_masks']._capmi_kmax == int(d['att_masks'].sum(1).max())
             else:
                 assert k == K
             want_fc = feat.mean(0) + (1.0 if (d['infos'][b]['id'] - 1000) % 2 == 0 else 0.0)
@@ -187,6 +189,7 @@ def test_resident_feature_store_returns_the_streaming_loaders_batches(tmp_path, 
         assert (x['att_masks'] is None) == (y['att_masks'] is None)
         if x['att_masks'] is not None:
             assert torch.equal(x['att_masks'], y['att_masks'])
+            assert x['att_masks']._capmi_kmax == y['att_masks']._capmi_kmax == int(y['att_masks'].sum(1).max())
         assert all(np.array_equal(g, h) for g, h in zip(x['gts'], y['gts']))
         assert x['bounds'] == y['bounds'] and x['infos'] == y['infos']
     if budget_rows is None:

@@ -28,3 +28,14 @@ def test_padding_stays_zero_and_pieces_are_swizzled():
     assert (c1[5:] == 0).all()
     # m / l planes of 1.0 are zero
     assert (pl[(12288 + 4096) // 2:(2 * 12288) // 2] == 0).all()
+
+
+def test_clip_len_is_cached_on_the_mask():
+    """ops.clip_len: clip_att's K (AttModel.py:106-112); one device->host read per mask object, none if stamped by the loader"""
+    import torch
+    from imagecaptioning.pytorch_amd.ops import clip_len
+    m = torch.tensor([[1., 1., 0., 0.], [1., 1., 1., 0.]])
+    assert clip_len(None, 7) == 7
+    assert clip_len(m) == 3 and m._capmi_kmax == 3
+    m._capmi_kmax = 2                      # a loader-stamped value wins (no sum over the mask)
+    assert clip_len(m) == 2

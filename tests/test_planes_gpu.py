@@ -198,3 +198,49 @@ def test_rollout_with_planes_agrees_with_rollout_without(dev, monkeypatch):
     print('relative gradient differences planes on / off:', {k: '%.1e' % v for k, v in errs.items() if v > 1e-5})
     # fp32 accumulation-order noise through 20 steps of BPTT (the oracle comparisons of test_full_size_parity_gpu.py allow 1e-3)
     assert max(errs.values()) < 5e-4, {k: v for k, v in errs.items() if v > 1e-5}
+
+
+def test_side_stream_gate_gemms_agree_with_the_single_stream_step(dev, monkeypatch):
+    """Round 3: the K segments of the LSTM gate GEMMs that depend only on earlier hidden states are computed ahead on a second HIP
+    stream (beside log-softmax + select and h2att + attention) and meet the rest in the LSTM cell.  Same operands, another
+    summation order: free-running tokens coincide, log-probs / gradients agree to fp32 accumulation noise; with early exit and
+    a model that ends its captions the side stream is joined cleanly."""
+    from imagecaptioning.pytorch_amd import updown_engine as E
+    from shapes import full_size_params
+    torch.manual_seed(1)
+    B, n, K, R, Em, V1, L = 10, 5, 36, 1000, 1000, 9488, 20
+    P = {k: v.to(dev).contiguous() for k, v in full_size_params(seed=4).items()}
+    fc = torch.randn(B, 2048, device=dev).clamp_min(0)
+    att = torch.randn(B, K, 2048, device=dev).clamp_min(0)
+    pr = E.prepare(P, fc, att, None)
+    N = B * n
+    gum = torch.rand(L, N, V1, device=dev).clamp_min(1e-12).log().neg().log().neg()
+    drop_xt = (torch.rand(L, N, Em, device=dev) < 0.5).float() * 2
+    drop_out = (torch.rand(L, N, R, device=dev) < 0.5).float() * 2
+    gsel = -torch.rand(N, L, 1, device=dev)
+    out, seq_on = {}, None
+    for flag in ('1', '0'):
+        monkeypatch.setenv('CAPMI_PRE_STREAM', flag)
+        kw = dict(mode='sample', gumbel=gum) if flag == '1' else dict(mode='forced', forced=seq_on)
+        ro = E.Rollout(P, pr, n=n, T=L, drop_xt=drop_xt, drop_out=drop_out, **kw)
+        assert (ro.r.pre_partial is not None) == (flag == '1')
+        seq, slp = ro.run()
+        if flag == '1':
+            seq_on = seq.clone()
+        grads = {k: torch.zeros_like(P[k]) for k in E.PARAM_KEYS}
+        gsl = torch.zeros_like(slp)
+        gsl.scatter_(2, seq_on.unsqueeze(-1), gsel)
+        ro.backward(gsl, grads)
+        torch.cuda.synchronize()
+        out[flag] = (seq.clone(), slp.gather(2, seq_on.unsqueeze(-1)).clone(), {k: v.clone() for k, v in grads.items()})
+    a, b = out['1'], out['0']
+    assert torch.equal(a[0], b[0])
+    assert float((a[1] - b[1]).abs().max()) < 2e-5
+    errs = {k: float((a[2][k] - b[2][k]).abs().max()) / (float(b[2][k].abs().max()) + 1e-30) for k in a[2]
+            if k != 'core.attention.alpha_net.bias'}
+    assert max(errs.values()) < 5e-4, {k: v for k, v in errs.items() if v > 1e-5}
+    # free-running without the side stream: the same tokens (near-ties aside)
+    monkeypatch.setenv('CAPMI_PRE_STREAM', '0')
+    seq0, _ = E.Rollout(P, pr, n=n, T=L, mode='sample', gumbel=gum, drop_xt=drop_xt, drop_out=drop_out).run()
+    torch.cuda.synchronize()
+    assert float((seq0 != seq_on).float().mean()) < 0.02
