@@ -106,8 +106,9 @@ class _Fn(torch.autograd.Function):
         ctx.sink = sink
         ctx.set_materialize_grads(False)        # the dense log-prob gradient may be undefined (sparse route)
         grads = model._grad_targets(P)
+        seed, model._forced_seed = getattr(model, '_forced_seed', None), None      # _sample: the seed its rollout drew under
         g = engine.TransformerGraph(P, grads, model.h, model.N_enc, model.N_dec, model.drop_prob_lm, model.dropout,
-                                    model.training, model._next_seed())
+                                    model.training, model._next_seed() if seed is None else seed)
         g.encode(att_feats, att_masks)
         logp = g.decode(seq, n)
         ctx.g, ctx.model, ctx.grads = g, model, grads
@@ -205,8 +206,13 @@ class TransformerModel(CaptionModel):
 
     def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
         """AttModel._sample for the Transformer.  Tokens are drawn with the KV-cached decoder under no_grad; when a
-        gradient is needed (SCST) the log-probs of the drawn tokens are recomputed by ONE teacher-forced pass, which
-        equals the reference's step-by-step graph whenever dropout is off."""
+        gradient is needed (SCST) the log-probs of the drawn tokens are recomputed by ONE teacher-forced pass.  In train
+        mode both run under ONE dropout realisation (same Philox seed; step t of the rollout applies position t's rows of the
+        teacher-forced pass's masks), so the differentiated pass is the sampled pass, as in the reference, which backpropagates
+        through the very steps it sampled from (loss_wrapper.py:63-68).  (The reference re-decodes the whole prefix at every
+        step, TransformerModel.py:351-362, and so redraws the masks of earlier positions each step; here a position keeps its
+        masks for the whole rollout -- the KV cache's meaning -- which is the same policy-gradient estimator for a slightly
+        different, equally valid, noise model.)"""
         if not att_feats.is_cuda:
             raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
         method = opt.get('sample_method', 'greedy')
@@ -226,6 +232,11 @@ class TransformerModel(CaptionModel):
         mode, temperature, top_k, top_p = parse_sample_method(method, opt.get('temperature', 1.0))
         n = int(opt.get('sample_n', 1))
         att_feats, att_masks = self._clip(att_feats, att_masks)
+        want_grad = torch.is_grad_enabled() and self.training
+        drop, drop_seed = None, None
+        if want_grad and (self.dropout > 0 or self.drop_prob_lm > 0):
+            drop_seed = self._next_seed()
+            drop = (self.drop_prob_lm, self.dropout, drop_seed)
         with torch.no_grad():
             P = self._pdict([p for _, p in self.named_parameters()])
             if mode == 'greedy' and opt.get('_graph', True) and not self.training:
@@ -240,9 +251,10 @@ class TransformerModel(CaptionModel):
             else:
                 seq, logp = engine.sample(P, att_feats, att_masks, self.h, self.N_enc, self.N_dec, self.seq_length, sample_n=n,
                                           mode=mode, temperature=temperature, seed=self._next_seed(),
-                                          gumbel=opt.get('_gumbel'), top_k=top_k, top_p=top_p)
-        if not (torch.is_grad_enabled() and self.training):
+                                          gumbel=opt.get('_gumbel'), top_k=top_k, top_p=top_p, drop=drop)
+        if not want_grad:
             return seq, logp
+        self._forced_seed = drop_seed                     # the teacher-forced pass below draws the rollout's masks again
         # differentiable log-probs of the drawn tokens: inputs [bos, w_0 .. w_{L-2}]
         inp = torch.cat([seq.new_zeros(seq.shape[0], 1), seq[:, :-1]], 1)
         logp_g = self._forward(None, att_feats, inp, att_masks)

@@ -281,17 +281,32 @@ class TransformerGraph:
         self.memory = self.enc_norm.fwd(x)                             # [B*K, D]
         return self.memory
 
+    def decoder_masks(self, N, T):
+        """The decoder's dropout masks of one teacher-forced pass over [N,T] tokens, in the order decode() consumes them:
+        target embedding [N,T,D], then per layer (self-attention probabilities [N,h,T,T], residual [N*T,D], source-attention
+        probabilities [N,h,T,K], residual, feed-forward hidden [N*T,F], residual).  One definition for decode() and for the
+        KV-cached sampler (Decoder), whose step t applies position t's rows of the same masks: with the same seed the
+        differentiated pass is the sampled pass (loss_wrapper.py:63-68)."""
+        D, K, h = self.D, self.K, self.h
+        out = [self.drop(N, T, D)]
+        for i in range(self.n_dec):
+            F = self.P['model.decoder.layers.%d.feed_forward.w_1.weight' % i].shape[0]
+            out += [self.drop(N, h, T, T), self.drop(N * T, D), self.drop(N, h, T, K), self.drop(N * T, D), self.drop(N * T, F),
+                    self.drop(N * T, D)]
+        return out
+
     # ---------------- decoder (teacher forced)
     def decode(self, seq, n):
         P, g = self.P, self.grads
         N, T = seq.shape
         B, K, D = self.B, self.K, self.D
         self.N, self.T, self.n, self.seq = N, T, n, seq
+        masks = iter(self.decoder_masks(N, T))
         pad = (seq != 0)
         pad[:, 0] = True                                               # TransformerModel.py:324-326
         causal = torch.tril(torch.ones(T, T, dtype=torch.bool, device=seq.device))
         tmask = (pad.unsqueeze(-2) & causal.unsqueeze(0)).to(torch.uint8).contiguous()      # [N,T,T]
-        self.drop_tgt = self.drop(N, T, D)
+        self.drop_tgt = next(masks)
         x = torch.empty(N * T, D, dtype=_f32, device=seq.device)
         check(lib.capmi_embed_pe_fwd(ptr(seq), T, ptr(P['model.tgt_embed.0.lut.weight']), ptr(P['model.tgt_embed.1.pe']),
                                      ptr(self.drop_tgt), ptr(x), N, T, D, 0, stream_ptr()), 'embed_pe_fwd')
@@ -301,12 +316,11 @@ class TransformerGraph:
             n0, sa = Norm(P, g, pre + '.sublayer.0.norm'), Attn(P, g, pre + '.self_attn', self.h)
             n1, ca = Norm(P, g, pre + '.sublayer.1.norm'), Attn(P, g, pre + '.src_attn', self.h)
             n2, ff = Norm(P, g, pre + '.sublayer.2.norm'), FFN(P, g, pre + '.feed_forward')
-            x = sa.fwd(n0.fwd(x), N, T, mask=tmask, mask_tq=T, mask_per_q=1, drop_p=self.drop(N, self.h, T, T), residual=x,
-                       res_mask=self.drop(N * T, D))
+            x = sa.fwd(n0.fwd(x), N, T, mask=tmask, mask_tq=T, mask_per_q=1, drop_p=next(masks), residual=x,
+                       res_mask=next(masks))
             x = ca.fwd(n1.fwd(x), N, T, kv=self.memory, Nkv=B, Tk=K, q_per_kv=n, mask=self.smask, mask_tq=1, mask_per_q=0,
-                       drop_p=self.drop(N, self.h, T, K), residual=x, res_mask=self.drop(N * T, D))
-            x = ff.fwd(n2.fwd(x), self.drop(N * T, P[pre + '.feed_forward.w_1.weight'].shape[0]), residual=x,
-                       res_mask=self.drop(N * T, D))
+                       drop_p=next(masks), residual=x, res_mask=next(masks))
+            x = ff.fwd(n2.fwd(x), next(masks), residual=x, res_mask=next(masks))
             self.dec.append((n0, sa, n1, ca, n2, ff))
         self.dec_norm = Norm(P, g, 'model.decoder.norm')
         out = self.dec_norm.fwd(x)
@@ -367,14 +381,29 @@ class Decoder:
     (the self-attention caches of all layers are ONE stacked [2*n_dec, N, L*D] array so that a beam reorder is one
     launch)."""
 
-    def __init__(self, P, att_feats, att_masks, h, n_enc, n_dec, L, rows_per_image_max):
+    def __init__(self, P, att_feats, att_masks, h, n_enc, n_dec, L, rows_per_image_max, drop=None):
+        """drop: None (eval numerics) or (drop_att_embed, dropout, seed): train-mode rollouts -- the encoder runs with the masks
+        a TransformerGraph of that seed draws and step t applies position t's rows of its decoder masks, i.e. the rollout
+        samples from exactly the dropout realisation that a teacher-forced pass with the same seed differentiates."""
         self.P, self.h, self.n_dec, self.L = P, h, n_dec, L
         dev = att_feats.device
-        self.g = g = TransformerGraph(P, {}, h, n_enc, n_dec, 0.0, 0.0, False, 0)
-        memory = g.encode(att_feats, att_masks)            # eval-mode encoder; Lin objects keep refs only
+        if drop is None:
+            self.g = g = TransformerGraph(P, {}, h, n_enc, n_dec, 0.0, 0.0, False, 0)
+        else:
+            self.g = g = TransformerGraph(P, {}, h, n_enc, n_dec, drop[0], drop[1], True, drop[2])
+        memory = g.encode(att_feats, att_masks)            # Lin objects keep refs only
         self.B, self.K, self.D = g.B, g.K, g.D
         self.N = N = self.B * rows_per_image_max
         D = self.D
+        self.masks = None
+        if drop is not None and g.drop.on:
+            # time-major copies: step t reads contiguous [N, ...] slices (the attention rows are cut to their t+1 keys per step)
+            self.masks = []
+            for m in g.decoder_masks(N, L):
+                if m.dim() == 4:                            # [N,h,T,Tk] -> [T,N,h,Tk]
+                    self.masks.append(m.permute(2, 0, 1, 3).contiguous())
+                else:                                       # [N,T,D] or [N*T,D] -> [T,N,D]
+                    self.masks.append(m.reshape(N, L, -1).transpose(0, 1).contiguous())
         self.V1 = P['model.generator.proj.weight'].shape[0]
         z = lambda *s: torch.empty(*s, dtype=_f32, device=dev)       # noqa: E731
         self.z = z
@@ -388,17 +417,17 @@ class Decoder:
         self.logits = z(N, self.V1)
         self.x = z(N, D)
 
-    def _lin(self, xx, wname, bname, out=None, ldc=None, relu=False, residual=None):
+    def _lin(self, xx, wname, bname, out=None, ldc=None, relu=False, residual=None, mask=None):
         P = self.P
         W = P[wname]
         M, Kd = xx.shape
         Nn = W.shape[0]
         if residual is not None:
-            ops.gemm([(xx, Kd, W, Kd, Kd, 1)], M, Nn, residual, bias=P[bname], accumulate=True)
+            ops.gemm([(xx, Kd, W, Kd, Kd, 1)], M, Nn, residual, bias=P[bname], mul_mask=mask, accumulate=True)
             return residual
         if out is None:
             out = self.z(M, Nn)
-        ops.gemm([(xx, Kd, W, Kd, Kd, 1)], M, Nn, out, ldc=ldc, bias=P[bname], relu=relu)
+        ops.gemm([(xx, Kd, W, Kd, Kd, 1)], M, Nn, out, ldc=ldc, bias=P[bname], relu=relu, mul_mask=mask)
         return out
 
     def step(self, t, it, rows_per_image):
@@ -408,26 +437,34 @@ class Decoder:
         lin = self._lin
         st = stream_ptr()
         x = self.x[:rows]
-        check(lib.capmi_embed_pe_fwd(ptr(it), 1, ptr(P['model.tgt_embed.0.lut.weight']), ptr(P['model.tgt_embed.1.pe']), None, ptr(x),
-                                     rows, 1, D, t, st), 'embed_pe_fwd')
+        mk = self.masks
+        if mk is not None and rows != self.N:
+            raise ValueError('train-mode (dropout) decoding serves all %d rows of its masks, got %d' % (self.N, rows))
+        m = (lambda j: mk[j][t]) if mk is not None else (lambda j: None)                     # noqa: E731
+        ma = (lambda j: mk[j][t][..., :t + 1].contiguous().unsqueeze(2)) if mk is not None else (lambda j: None)   # noqa: E731
+        check(lib.capmi_embed_pe_fwd(ptr(it), 1, ptr(P['model.tgt_embed.0.lut.weight']), ptr(P['model.tgt_embed.1.pe']), ptr(m(0)),
+                                     ptr(x), rows, 1, D, t, st), 'embed_pe_fwd')
         xs = x.clone()
         for i in range(self.n_dec):
             pre = 'model.decoder.layers.%d' % i
+            j0 = 1 + 6 * i                                  # TransformerGraph.decoder_masks order
             kc, vc = self.kv[2 * i], self.kv[2 * i + 1]
             y, _, _ = layernorm_fwd(xs, P[pre + '.sublayer.0.norm.a_2'], P[pre + '.sublayer.0.norm.b_2'])
             q = lin(y, pre + '.self_attn.linears.0.weight', pre + '.self_attn.linears.0.bias')
             lin(y, pre + '.self_attn.linears.1.weight', pre + '.self_attn.linears.1.bias', out=(kc, t * D), ldc=L * D)
             lin(y, pre + '.self_attn.linears.2.weight', pre + '.self_attn.linears.2.bias', out=(vc, t * D), ldc=L * D)
-            o, _ = mha_fwd(q, kc, vc, L * D, rows, 1, 1, t + 1, h, want_p=False)
-            xs = lin(o.view(rows, D), pre + '.self_attn.linears.3.weight', pre + '.self_attn.linears.3.bias', residual=xs)
+            o, _ = mha_fwd(q, kc, vc, L * D, rows, 1, 1, t + 1, h, want_p=False, drop=ma(j0))
+            xs = lin(o.view(rows, D), pre + '.self_attn.linears.3.weight', pre + '.self_attn.linears.3.bias', residual=xs,
+                     mask=m(j0 + 1))
             y, _, _ = layernorm_fwd(xs, P[pre + '.sublayer.1.norm.a_2'], P[pre + '.sublayer.1.norm.b_2'])
             q = lin(y, pre + '.src_attn.linears.0.weight', pre + '.src_attn.linears.0.bias')
             o, _ = mha_fwd(q, self.mem_k[i], self.mem_v[i], K * D, rows, rows_per_image, 1, K, h, mask=self.g.smask, mask_tq=1,
-                           mask_per_q=0, want_p=False)
-            xs = lin(o.view(rows, D), pre + '.src_attn.linears.3.weight', pre + '.src_attn.linears.3.bias', residual=xs)
+                           mask_per_q=0, want_p=False, drop=None if mk is None else mk[j0 + 2][t].unsqueeze(2))
+            xs = lin(o.view(rows, D), pre + '.src_attn.linears.3.weight', pre + '.src_attn.linears.3.bias', residual=xs,
+                     mask=m(j0 + 3))
             y, _, _ = layernorm_fwd(xs, P[pre + '.sublayer.2.norm.a_2'], P[pre + '.sublayer.2.norm.b_2'])
-            hdn = lin(y, pre + '.feed_forward.w_1.weight', pre + '.feed_forward.w_1.bias', relu=True)
-            xs = lin(hdn, pre + '.feed_forward.w_2.weight', pre + '.feed_forward.w_2.bias', residual=xs)
+            hdn = lin(y, pre + '.feed_forward.w_1.weight', pre + '.feed_forward.w_1.bias', relu=True, mask=m(j0 + 4))
+            xs = lin(hdn, pre + '.feed_forward.w_2.weight', pre + '.feed_forward.w_2.bias', residual=xs, mask=m(j0 + 5))
         y, _, _ = layernorm_fwd(xs, P['model.decoder.norm.a_2'], P['model.decoder.norm.b_2'])
         logits = self.logits[:rows]
         lin(y, 'model.generator.proj.weight', 'model.generator.proj.bias', out=logits)
@@ -444,11 +481,11 @@ class Decoder:
 
 
 def sample(P, att_feats, att_masks, h, n_enc, n_dec, L, sample_n=1, mode='greedy', temperature=1.0, seed=0, forced=None,
-           gumbel=None, top_k=0, top_p=0.0):
-    """AttModel._sample with TransformerModel.core semantics (eval numerics), KV cache instead of prefix re-decode.
-    Returns (seq [N,L], seq_logp [N,L,V1])."""
+           gumbel=None, top_k=0, top_p=0.0, drop=None):
+    """AttModel._sample with TransformerModel.core semantics, KV cache instead of prefix re-decode.  drop: see Decoder
+    (None = eval numerics).  Returns (seq [N,L], seq_logp [N,L,V1])."""
     dev = att_feats.device
-    dec = Decoder(P, att_feats, att_masks, h, n_enc, n_dec, L, sample_n)
+    dec = Decoder(P, att_feats, att_masks, h, n_enc, n_dec, L, sample_n, drop=drop)
     N, V1, n = dec.N, dec.V1, sample_n
     seq = torch.zeros(N, L, dtype=torch.long, device=dev)
     seq_logp = torch.zeros(N, L, V1, dtype=_f32, device=dev)

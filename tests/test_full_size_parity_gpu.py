@@ -510,3 +510,90 @@ def test_transformer_and_aoa_at_the_baseline_batch_vs_the_reference_itself(tag, 
     # parameters the graph never reaches have an exact-zero reference gradient (norm 0): skip the relative check for them
     skip = tuple(k for k in grads if float(z['%s_gnorm.%s' % (tag, k)]) == 0.0 or k.endswith('alpha_net.bias'))
     check_grads_against_fixture(z, tag, grads, skip=skip)
+
+
+def test_transformer_scst_train_mode_differentiates_the_pass_it_sampled():
+    """Train-mode Transformer SCST (loss_wrapper.py:63-68): the KV-cached rollout and the teacher-forced pass
+    that carries the gradient run under ONE dropout realisation.  With the masks of that realisation injected into
+    oracle/transformer.py: (a) the log-probs the rollout sampled from == the differentiated log-probs == the oracle's
+    (<= 2e-4), (b) every drawn token is arg-max(oracle log-prob + the injected Gumbel noise), i.e. the rollout is ON-policy
+    for the differentiated pass, (c) the RewardCriterion gradient of every parameter matches the oracle's (<= 1e-3 relative)."""
+    from oracle import transformer as T
+    from imagecaptioning.pytorch_amd import synthetic, transformer_engine as E
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd.captioning.modules import losses as Lm
+    d, h, dff, nl, K, V1, B, n, L, F = 48, 4, 100, 2, 7, 101, 3, 2, 6, 44
+    p_embed, p_drop = 0.3, 0.2
+    opt = synthetic.updown_opt(caption_model='transformer', input_encoding_size=d, rnn_size=dff, d_model=d, d_ff=dff, N_enc=nl,
+                               N_dec=nl, num_att_heads=h, dropout=p_drop, drop_prob_lm=p_embed, seq_length=L, max_length=L,
+                               vocab_size=V1 - 1, fc_feat_size=F, att_feat_size=F,
+                               vocab={str(i): 'w%d' % i for i in range(1, V1)})
+    torch.manual_seed(4711)
+    model = models.setup(opt).to(DEV)
+    model.train()
+    _, att = shapes.feats(B, K=K, F=F, seed=5)
+    am = torch.ones(B, K)
+    am[0, K // 2:] = 0
+    N = B * n
+    g = torch.Generator().manual_seed(23)
+    gum = -torch.log(-torch.log(torch.rand(L, N, V1, generator=g).clamp_min(1e-20)))
+    reward = torch.randn(N, L, generator=g)
+    model._rng_calls = 0
+    seq, logp = model(None, att.to(DEV), am.to(DEV), opt={'sample_method': 'sample', 'sample_n': n, '_gumbel': gum.to(DEV)},
+                      mode='sample')
+    assert logp.requires_grad and int((seq > 0).sum()) > N
+    loss = Lm.RewardCriterion()(logp, seq, reward.to(DEV))
+    model.zero_grad()
+    loss.backward()
+
+    # the realisation: the masks a TransformerGraph of the rollout's seed draws, in its order (encode, then decoder_masks)
+    model._rng_calls = 0
+    seed = model._next_seed()
+    de = E.Dropper(p_embed, seed, torch.device(DEV), True)
+    dd = E.Dropper(p_drop, seed ^ 0x5bd1e995, torch.device(DEV), True)
+    named = {'att_embed': de(B * K, d).view(B, K, d)}
+    for i in range(nl):
+        named['enc%d.attn' % i] = dd(B, h, K, K)
+        named['enc%d.res0' % i] = dd(B * K, d).view(B, K, d)
+        named['enc%d.ff' % i] = dd(B * K, dff).view(B, K, dff)
+        named['enc%d.res1' % i] = dd(B * K, d).view(B, K, d)
+    named['tgt_embed'] = dd(N, L, d)
+    for i in range(nl):
+        named['dec%d.self.attn' % i] = dd(N, h, L, L)
+        named['dec%d.res0' % i] = dd(N * L, d).view(N, L, d)
+        named['dec%d.src.attn' % i] = dd(N, h, L, K)
+        named['dec%d.res1' % i] = dd(N * L, d).view(N, L, d)
+        named['dec%d.ff' % i] = dd(N * L, dff).view(N, L, dff)
+        named['dec%d.res2' % i] = dd(N * L, d).view(N, L, d)
+    named = {k: v.cpu() for k, v in named.items()}
+    used = set()
+
+    def drop(name, x):
+        used.add(name)
+        return x * named[name]
+
+    P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    for v in P.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    P['model.tgt_embed.1.pe'] = model.model.tgt_embed[1].pe.cpu()
+    seq_c = seq.cpu()
+    inp = torch.cat([seq_c.new_zeros(N, 1), seq_c[:, :-1]], 1)
+    want = T.forward_teacher(P, att, inp, am, h=h, n_enc=nl, n_dec=nl, drop=drop)
+    assert used == set(named)
+    live = torch.cat([seq_c.new_ones(N, 1), (seq_c[:, :-1] > 0).long()], 1).cumprod(1).bool()
+    # (a) differentiated log-probs == oracle under the same realisation, on the live steps
+    got = logp.detach().cpu()
+    assert float((got - want.detach())[live].abs().max()) <= 2e-4
+    # (b) on-policy: each drawn token is the Gumbel-max of the SAME distribution
+    for t in range(L):
+        pick = (want.detach()[:, t] + gum[t]).argmax(1)
+        assert torch.equal(seq_c[live[:, t], t], pick[live[:, t]]), t
+    # (c) gradients
+    mask = live.float()
+    want_loss = -(want.gather(2, seq_c.unsqueeze(2)).squeeze(2) * reward * mask).sum() / mask.sum()
+    assert abs(float(loss.detach()) - float(want_loss.detach())) <= 1e-4 * max(1.0, abs(float(want_loss.detach())))
+    want_loss.backward()
+    for k, prm in model.named_parameters():
+        w = P[k].grad
+        assert float((prm.grad.cpu() - w).abs().max()) <= 1e-3 * float(w.abs().max()) + 1e-6, k
