@@ -19,6 +19,7 @@ struct Seg {
     int rdiv;         // ceil(65536 / a_row_div): row / a_row_div == (row * rdiv) >> 16 for row < 64
     int tstart;       // index of this segment's first K tile in the flat tile list (INT_MAX for unused slots)
     const unsigned char *Apl;   // the same activations pre-split as "A planes" (capmi_common.h), or null
+    const unsigned char *Bpl;   // operand B's K-contiguous view [N][K] as planes (fat GEMMs, capmi_planes_split), or null
 };
 
 struct KArgs {
@@ -73,5 +74,7 @@ int launch_lc(const KArgs &a, int b_layout, hipStream_t st, int pcls, double byt
 
 // fat GEMMs through the bf16 pipe by exact 3-way operand splitting; defined in gemm_x3.hip
 int launch_x3(const KArgs &a, int a_layout, int b_layout, dim3 grid, hipStream_t st, int pcls, double bytes, double flops);
+// the same with both operands delivered as planes (Seg.Apl / Seg.Bpl): nothing is split inside the GEMM
+int launch_x3pl(const KArgs &a, dim3 grid, hipStream_t st, int pcls, double bytes, double flops);
 
 }  // namespace capmi_gemm

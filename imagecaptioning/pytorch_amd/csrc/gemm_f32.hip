@@ -398,7 +398,8 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     int tiles = 0;
     for (int s = 0; s < d->nseg; ++s) {
         const capmi_gemm_seg &g = d->seg[s];
-        if (!g.A || !g.B || g.K <= 0) return CAPMI_EINVAL;
+        if (g.K <= 0) return CAPMI_EINVAL;
+        if ((!g.A || !g.B) && !(d->a_planes[s] && d->b_planes[s])) return CAPMI_EINVAL;   // fp32 operands may be absent only on the all-planes path
         Seg &o = a.seg[s];
         o.A = g.A; o.B = g.B; o.lda = g.lda; o.ldb = g.ldb; o.K = g.K;
         o.a_row_div = g.a_row_div > 0 ? g.a_row_div : 1;
@@ -408,6 +409,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
         o.rdiv = (65536 + o.a_row_div - 1) / o.a_row_div;
         o.tstart = tiles;
         o.Apl = static_cast<const unsigned char *>(d->a_planes[s]);
+        o.Bpl = static_cast<const unsigned char *>(d->b_planes[s]);
         tiles += (g.K + BK - 1) / BK;
     }
     a.zero_planes = static_cast<const unsigned char *>(d->zero_planes);
@@ -440,7 +442,9 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
 
     static const int env_path = [] { const char *e = getenv("CAPMI_GEMM_PATH"); return e ? atoi(e) : 0; }();
     static const int env_blocks = [] { const char *e = getenv("CAPMI_GEMM_BLOCKS"); return e ? atoi(e) : 512; }();
-    bool ares_ok = d->a_layout == 0 && d->M <= 64 && BK == 32;
+    bool have_f32 = true;
+    for (int s = 0; s < d->nseg; ++s) have_f32 = have_f32 && d->seg[s].A && d->seg[s].B;
+    bool ares_ok = have_f32 && d->a_layout == 0 && d->M <= 64 && BK == 32;
     for (int s = 0; s < d->nseg && ares_ok; ++s)     // branch-free 16-byte operand fetch: aligned, K % 4 == 0
         ares_ok = a.seg[s].vecA && (a.seg[s].K % 4 == 0) && (d->b_layout == 1 || a.seg[s].vecB);
     // ---- round 3: loader / consumer kernel (gemm_lc.hip) when every segment is also delivered as A planes ----
@@ -553,6 +557,14 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
                 // 32-bit per-lane byte offsets in the staging loads
                 (uint64_t)(d->a_layout == 0 ? d->M : 1) * (uint64_t)a.seg[s].lda * 4 < (1ull << 32) &&
                 (uint64_t)(d->b_layout == 0 ? d->N : 1) * (uint64_t)a.seg[s].ldb * 4 < (1ull << 32);
+    // both operands as planes (capmi_planes_split / producer-written): the split-free kernel
+    static const int env_pl = [] { const char *e = getenv("CAPMI_X3PL"); return e ? atoi(e) : 1; }();
+    bool pl_ok = env_pl && BM == 128 && BN == 128 && BK == 32;
+    for (int s = 0; s < d->nseg && pl_ok; ++s)
+        pl_ok = a.seg[s].Apl && a.seg[s].Bpl && a.seg[s].a_row_div == 1 &&
+                ((reinterpret_cast<uintptr_t>(a.seg[s].Apl) | reinterpret_cast<uintptr_t>(a.seg[s].Bpl)) & 15) == 0;
+    if (!pl_ok && !have_f32) return CAPMI_EINVAL;
+    if (pl_ok) x3_ok = true;           // same tiling, same K-split plan
     int splits = d->splits;
     if (splits == 0 && x3_ok) {
         // persistent kernel, one workgroup per CU: pick the K split that minimises (rounds x K tiles per unit) plus the
@@ -596,7 +608,8 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     dim3 grid(gn, gm, splits);
     const ProfInfo pi{pcls, bytes, flops};
     int rc;
-    if (x3_ok) rc = launch_x3(a, d->a_layout, d->b_layout, grid, st, pcls, bytes, flops);
+    if (pl_ok) rc = launch_x3pl(a, grid, st, pcls, bytes, flops);
+    else if (x3_ok) rc = launch_x3(a, d->a_layout, d->b_layout, grid, st, pcls, bytes, flops);
     else if (BM == 32 && BN == 128) rc = launch_cfg<32, 128, 1, 4, 3>(a, d->a_layout, d->b_layout, grid, st, pi);
     else if (BM == 64 && BN == 64) rc = launch_cfg<64, 64, 2, 2, 3>(a, d->a_layout, d->b_layout, grid, st, pi);
         else if (BM == 64 && BN == 128) rc = launch_cfg<64, 128, 1, 4, 2>(a, d->a_layout, d->b_layout, grid, st, pi);

@@ -50,10 +50,11 @@ def default_workspace(device):
 
 
 def gemm(segs, M, N, out, ldc=None, a_layout=0, b_layout=0, bias=None, bias2=None, row_bias=None, row_bias_div=1,
-         mul_mask=None, relu=False, accumulate=False, ws=None, splits=0, defer_reduce=False, a_planes=None):
+         mul_mask=None, relu=False, accumulate=False, ws=None, splits=0, defer_reduce=False, a_planes=None, b_planes=None):
     """segs: list of (A, lda, B, ldb, K, a_row_div) with tensors (or (tensor, element_offset) pairs).
     a_planes: optional list (one uint8 tensor per segment, see planes_from_f32) -- the activations also delivered pre-split,
-    staged by LDS-DMA in the M <= 64 decode kernel.  Returns splits_used."""
+    staged by LDS-DMA in the M <= 64 decode kernel.  b_planes (with a_planes, M > 64: planes_split): both operands of a fat
+    GEMM as planes of their K-contiguous views; A / B of a segment may then be None.  Returns splits_used."""
     d = _lib.GemmDesc()
     d.nseg = len(segs)
     if a_planes is not None:
@@ -61,9 +62,13 @@ def gemm(segs, M, N, out, ldc=None, a_layout=0, b_layout=0, bias=None, bias2=Non
         for i, t in enumerate(a_planes):
             d.a_planes[i] = t.data_ptr()
         d.zero_planes = zero_planes(_dev(out)).data_ptr()
+    if b_planes is not None:
+        assert len(b_planes) == len(segs)
+        for i, t in enumerate(b_planes):
+            d.b_planes[i] = t.data_ptr()
     for i, (A, lda, B, ldb, K, div) in enumerate(segs):
-        d.seg[i].A = _addr(A)
-        d.seg[i].B = _addr(B)
+        d.seg[i].A = None if A is None else _addr(A)
+        d.seg[i].B = None if B is None else _addr(B)
         d.seg[i].lda, d.seg[i].ldb, d.seg[i].K, d.seg[i].a_row_div = lda, ldb, K, div
     d.a_layout, d.b_layout, d.M, d.N = a_layout, b_layout, M, N
     d.C = _addr(out)
@@ -110,6 +115,20 @@ def planes_from_f32(x, out=None):
     if out is None:
         out = torch.zeros(int(lib.capmi_planes_bytes(K)), dtype=torch.uint8, device=x.device)
     check(lib.capmi_planes_from_f32(x.data_ptr(), x.stride(0), M, K, out.data_ptr(), stream_ptr()), 'capmi_planes_from_f32')
+    return out
+
+
+def planes_split(x, transposed=False, out=None):
+    """Planes of a fat GEMM operand (capmi.h capmi_planes_split).  x: the operand's K-contiguous view [rows, K], or with
+    transposed=True its transpose [K, rows] (row stride x.stride(0), unit column stride)."""
+    assert x.is_cuda and x.dtype == _f32 and x.dim() == 2 and x.stride(1) == 1
+    rows, K = (x.shape[1], x.shape[0]) if transposed else (x.shape[0], x.shape[1])
+    nbytes = int(lib.capmi_planes_fat_bytes(rows, K))
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    assert out.numel() >= nbytes
+    check(lib.capmi_planes_split(x.data_ptr(), x.stride(0), rows, K, int(transposed), out.data_ptr(), stream_ptr()),
+          'capmi_planes_split')
     return out
 
 

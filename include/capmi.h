@@ -90,6 +90,11 @@ typedef struct capmi_gemm_desc {
      * activations are staged by LDS-DMA instead of being split inside every workgroup.  Same result bit for bit. */
     const void *a_planes[CAPMI_MAX_SEG];
     const void *zero_planes;
+    /* optional (round 3, fat GEMMs: M > 64): BOTH operands of every segment delivered as planes of their K-contiguous views
+     * -- a_planes[s] = planes of A as [M][K], b_planes[s] = planes of B as [N][K], whatever a_layout / b_layout say about the
+     * fp32 images (capmi_planes_split transposes) -- in the row-blocked format of capmi_planes_split.  The GEMM then stages
+     * by LDS-DMA only and splits nothing; seg[s].A / seg[s].B may be NULL.  Same result bit for bit. */
+    const void *b_planes[CAPMI_MAX_SEG];
 } capmi_gemm_desc;
 
 int capmi_gemm_f32(capmi_gemm_desc *d, void *stream);
@@ -102,6 +107,16 @@ int capmi_gemm_f32(capmi_gemm_desc *d, void *stream);
  * capmi_lstm_cell_bwd_partial_pl) write the planes themselves; this call converts any other operand. */
 int64_t capmi_planes_bytes(int K);
 int capmi_planes_from_f32(const float *X, int ld, int M, int K, void *planes, void *stream);
+
+/* Planes of a FAT operand (any number of rows): the same chunk image in 64-row blocks, chunk (rb, kc) at byte
+ * (rb * ceil(K/32) + kc) * 12288, rows padded to a multiple of 128 and K to a multiple of 32 WITH ZEROS written by this call
+ * (no pre-zeroing needed).  src is the operand's K-contiguous view [rows][K] (transposed = 0, row pitch ld) or its transpose
+ * [K][rows] (transposed = 1: what dW = dG^T X holds for both of its operands; the pass transposes through LDS).  For
+ * rows <= 64 the image is the "A planes" image above.  Replaces the per-workgroup split of the fp32 fat GEMM (the reference's
+ * torch.matmul / F.linear backward at captioning/models/AttModel.py:615-640 run under autograd): one pass per operand instead
+ * of one split per (operand element, output tile that uses it). */
+int64_t capmi_planes_fat_bytes(int rows, int K);
+int capmi_planes_split(const float *src, int ld, int rows, int K, int transposed, void *planes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused additive region attention, forward (AttModel.py:728-748 Attention.forward; the

@@ -244,3 +244,59 @@ def test_side_stream_gate_gemms_agree_with_the_single_stream_step(dev, monkeypat
     seq0, _ = E.Rollout(P, pr, n=n, T=L, mode='sample', gumbel=gum, drop_xt=drop_xt, drop_out=drop_out).run()
     torch.cuda.synchronize()
     assert float((seq0 != seq_on).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize('rows,K,tr,pad', [(130, 70, False, 0), (130, 70, True, 0), (1000, 4000, True, 0), (1000, 1000, False, 0),
+                                           (257, 33, True, 3), (64, 32, False, 1), (9488, 96, True, 0)])
+def test_planes_split_matches_layout_restatement(dev, rows, K, tr, pad):
+    """capmi_planes_split (fat operands, optional transpose through LDS, zero padding written by the pass) == oracle, bit-exact;
+    pad: extra row pitch / misaligned base (the scalar path)"""
+    ops, _ = mods()
+    g = torch.Generator().manual_seed(rows + K)
+    x = wide((rows, K), g)
+    src = x.t().contiguous() if tr else x
+    buf = torch.zeros(src.shape[0], src.shape[1] + pad, device=dev)
+    buf[:, :src.shape[1]] = src.to(dev)
+    view = buf[:, :src.shape[1]]
+    out = torch.full((int(PL.fat_bytes(rows, K)),), 0xAB, dtype=torch.uint8, device=dev)     # the pass must overwrite everything
+    ops.planes_split(view, transposed=tr, out=out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), PL.planes_split(x.numpy()))
+
+
+# (M, N, [K per segment], a_layout, b_layout, splits)
+FAT = [(1000, 1000, [4000], 0, 1, 0),            # dX = dG W (time-batched)
+       (4000, 1000, [1000], 1, 1, 0),            # dW = dG^T X
+       (600, 520, [200], 0, 0, 0),               # edge tiles in M and N
+       (600, 520, [200], 1, 0, 0),
+       (520, 600, [72, 40], 0, 0, 0),            # two K segments, K % 32 != 0
+       (512, 512, [3000], 0, 0, 4),              # split-K slabs
+       (130, 9488, [1000], 0, 0, 0)]
+
+
+@pytest.mark.parametrize('M,N,Ks,al,bl,splits', FAT)
+def test_fat_gemm_on_planes_is_bit_identical_to_the_in_kernel_split(dev, M, N, Ks, al, bl, splits):
+    """gemm_x3pl_kernel (both operands as planes, LDS-DMA staging, nothing split in the GEMM) == gemm_x3_kernel (fp32 operands split
+    per workgroup): same bf16x3 terms, same MFMA order -> the same bits; fp32-grade against fp64."""
+    ops, _ = mods()
+    g = torch.Generator().manual_seed(M + N + sum(Ks))
+    segs, apl, bpl, ref = [], [], [], torch.zeros(M, N, dtype=torch.float64)
+    for K in Ks:
+        A, B = wide((M, K), g, 0.3), wide((N, K), g, 0.3)          # K-contiguous views
+        ref += A.double() @ B.double().t()
+        Ad = (A.t().contiguous() if al else A).to(dev)
+        Bd = (B.t().contiguous() if bl else B).to(dev)
+        segs.append((Ad, Ad.stride(0), Bd, Bd.stride(0), K, 1))
+        apl.append(ops.planes_split(Ad, transposed=bool(al)))
+        bpl.append(ops.planes_split(Bd, transposed=bool(bl)))
+    bias = torch.randn(N, generator=g).to(dev)
+    want = torch.empty(M, N, device=dev)
+    got = torch.full((M, N), float('nan'), device=dev)
+    ops.gemm(segs, M, N, want, a_layout=al, b_layout=bl, bias=bias, splits=splits)
+    ops.gemm([(None, s[1], None, s[3], s[4], 1) for s in segs], M, N, got, a_layout=al, b_layout=bl, bias=bias, splits=splits,
+             a_planes=apl, b_planes=bpl)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    ref = ref + bias.cpu().double()
+    err = float((got.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
