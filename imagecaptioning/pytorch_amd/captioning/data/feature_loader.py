@@ -100,6 +100,8 @@ class FeatureLoader:
         self.lookahead = max(1, int(lookahead))
         self.order = {k: list(v) for k, v in self.split_ix.items()}
         self.rng.shuffle(self.order['train'])                  # MySampler shuffles the train split (dataloader.py:394-397)
+        #                                                        (its permutation comes from numpy's global RNG: the ORDER of a
+        #                                                        pass is not reproducible across the two loaders, its contents are)
         # what a checkpoint needs to resume INSIDE an epoch (the reference saves its sampler's index_list + iter_counter,
         # dataloader.py:376-405): a copy of the order taken once per shuffle, handed out with every batch next to the RNG states
         self._snap = {k: list(v) for k, v in self.order.items()}
@@ -154,17 +156,38 @@ class FeatureLoader:
 
     # ---- batches
     def _next_indices(self, split, B):
+        """The next batch's image indices with MySampler's semantics (dataloader.py:376-391, pinned by
+        tests/golden/loader_ref.npz = batches of the reference loader itself).  train (shuffle, wrap): when the pass is used up
+        the order is reshuffled and the FIRST element of the new pass carries ``wrapped``, so a batch may straddle two passes.
+        val / test (no shuffle, no wrap): the sampler stops at the end of the split -- torch's DataLoader then yields the
+        partial last batch (drop_last=False) and the next get_batch starts the split over (:349-354); never ``wrapped``."""
         order, out, wrapped = self.order[split], [], False
+        if not order:
+            raise ValueError('split %r has no images' % split)
         for _ in range(B):
-            out.append(order[self.pos[split]])
-            self.pos[split] += 1
             if self.pos[split] >= len(order):
-                self.pos[split] = 0
-                wrapped = True
                 if split == 'train':
                     self.rng.shuffle(order)
                     self._snap[split] = list(order)
+                    wrapped = True
+                elif out:
+                    break
+                self.pos[split] = 0
+            out.append(order[self.pos[split]])
+            self.pos[split] += 1
         return out, wrapped
+
+    def reset_iterator(self, split):
+        """DataLoader.reset_iterator (dataloader.py:356-358): the split starts over (batches already scheduled ahead are dropped);
+        the train split is reshuffled, as MySampler._reset_iter does."""
+        for key in [k for k in self._pending if k[0] == split]:
+            for item in self._pending.pop(key):
+                for f in (item[3].values() if isinstance(item[3], dict) else item[3]):
+                    f.cancel()
+        if split == 'train':
+            self.rng.shuffle(self.order[split])
+            self._snap[split] = list(self.order[split])
+        self.pos[split] = 0
 
     def _schedule(self, split, B):
         idx, wrapped = self._next_indices(split, B)
@@ -193,6 +216,7 @@ class FeatureLoader:
         while len(q) < self.lookahead + 1:                     # decode the NEXT batches' features in the background
             q.append(self._schedule(split, B))
         idx, wrapped, pos_now, futs, snap, rng_state = q.pop(0)
+        B = len(idx)                                           # (the last batch of a val / test pass may be short)
         feats = [f.result() for f in futs]
         F = feats[0][1].shape[1]
         kmax = max(a.shape[0] for _, a in feats)

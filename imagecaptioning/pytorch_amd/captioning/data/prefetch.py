@@ -22,6 +22,12 @@ class DevicePrefetcher:
     def __getattr__(self, name):   # vocabulary, document_frequency(), ... of the wrapped loader
         return getattr(self.loader, name)
 
+    def reset_iterator(self, split):
+        """DataLoader.reset_iterator (dataloader.py:356-358): the batches already in flight belong to the old pass"""
+        for _, ev in self._queue.pop(split, []):
+            ev.synchronize()                     # their copies may still be running into the pinned buffers
+        self.loader.reset_iterator(split)
+
     def _pin(self, split, slot, key, t):
         buf = self._pinned.get((split, slot, key))
         if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:

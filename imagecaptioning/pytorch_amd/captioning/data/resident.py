@@ -80,6 +80,12 @@ class ResidentFeatures:
     def resident_bytes(self):
         return 0 if self.rows is None else self.used * self.rows.shape[1] * 4
 
+    def reset_iterator(self, split):
+        """DataLoader.reset_iterator (dataloader.py:356-358): drop what was scheduled ahead, start the split over"""
+        for key in [k for k in self._pending if k[0] == split]:
+            self._pending.pop(key)
+        self.loader.reset_iterator(split)
+
     # ---- batches
     def _schedule(self, split, B):
         idx, wrapped = self.loader._next_indices(split, B)
@@ -94,6 +100,7 @@ class ResidentFeatures:
         while len(q) < ld.lookahead + 1:                       # decode the NEXT batches' new images in the background
             q.append(self._schedule(split, B))
         idx, wrapped, pos_now, futs, snap, rng_state = q.pop(0)
+        B = len(idx)                                           # (the last batch of a val / test pass may be short)
         new, seen = [], set()
         for ix in idx:
             if ix in self.slot:

@@ -31,6 +31,10 @@ class SyntheticLoader:
     def document_frequency(self):
         return synthetic.document_frequency(self.refs)
 
+    def reset_iterator(self, split):
+        """DataLoader.reset_iterator (dataloader.py:356-358)"""
+        self.pos[split] = 0
+
     def get_batch(self, split, batch_size=None):
         B = batch_size or self.batch_size
         n, L, opt = self.seq_per_img, self.seq_length, self.opt

@@ -70,8 +70,14 @@ def eval_split(model, crit, loader, opt):
     dev = next(model.parameters()).device
     model.eval()
     n, loss_sum, loss_n, preds, n_preds = 0, 0.0, 0, [], []
-    while n < opt.num_images:
-        data = loader.get_batch('val')
+    split = getattr(opt, 'split', 'val')
+    if hasattr(loader, 'reset_iterator'):
+        loader.reset_iterator(split)                                                                           # eval_utils.py:145
+    num_images = opt.num_images
+    while num_images < 0 or n < num_images:
+        data = loader.get_batch(split)
+        if num_images < 0:
+            num_images = data['bounds']['it_max']                                                              # :201-205: the whole split
         fc, att, labels, masks = (data[k].to(dev) for k in ('fc_feats', 'att_feats', 'labels', 'masks'))
         kw = eval_kwargs_of(opt)
         kw['sample_n'] = 1                                                                                     # :169-170
@@ -103,7 +109,7 @@ def eval_split(model, crit, loader, opt):
     if n_preds and 'perplexity' in n_preds[0]:
         n_preds = sorted(n_preds, key=lambda x: x['perplexity'])                                               # :217-218
     model.n_predictions = n_preds
-    return loss_sum / max(loss_n, 1), preds[:opt.num_images * max(1, len(preds) // max(n, 1))]
+    return loss_sum / max(loss_n, 1), preds[:num_images * max(1, len(preds) // max(n, 1))]
 
 
 def main(opt):

@@ -90,7 +90,8 @@ def test_batch_contract_variable_regions(tmp_path):
         assert d['bounds']['it_max'] == 7
     assert wraps == 2 and set(seen) == set(ld.split_ix['train'])                  # 20 draws over 7 images: two epoch wraps
     v = ld.get_batch('val', batch_size=2)
-    assert [i['ix'] for i in v['infos']] == ld.split_ix['val'] and v['bounds']['wrapped']
+    # (a val / test pass never sets `wrapped`: MySampler(wrap=False), pinned by test_val_and_test_batches_are_the_reference_loaders)
+    assert [i['ix'] for i in v['infos']] == ld.split_ix['val'] and not v['bounds']['wrapped']
 
 
 def test_fixed_region_count_gives_no_att_masks_and_df_table(tmp_path):
@@ -219,3 +220,85 @@ def test_resident_store_under_the_device_prefetcher_gpu(tmp_path):
                 assert y[k].is_cuda and torch.equal(x[k], y[k]), (it, k)
         assert x['bounds'] == y['bounds']
     assert res.streamed == 0 and res.misses == len(res.split_ix['train']) and res.hits > 0
+
+
+# ---- pinned to the REFERENCE loader: tests/golden/loader_ref.npz holds batches that /root/reference/captioning/data/dataloader.py
+# itself produced on tests/golden/loader_ds (tests/golden/make_loader_golden.py)
+def _ref_loader(B):
+    import argparse
+    from imagecaptioning.pytorch_amd.captioning.data.feature_loader import FeatureLoader
+    ds = os.path.join(GOLDEN, 'loader_ds')
+    opt = argparse.Namespace(batch_size=B, seq_per_img=2, use_fc=True, norm_att_feat=0, train_only=0, seed=3,
+                             input_json=os.path.join(ds, 'dataset.json'), input_label_h5=os.path.join(ds, 'labels.npz'),
+                             input_fc_dir=os.path.join(ds, 'fc'), input_att_dir=os.path.join(ds, 'att'))
+    return FeatureLoader(opt, workers=2, processes=False)
+
+
+def _same_batch(z, pre, d, exact_rows=True):
+    assert [d['bounds'][k] for k in ('it_pos_now', 'it_max')] == z[pre + 'bounds'][:2].tolist(), pre
+    assert bool(d['bounds']['wrapped']) == bool(z[pre + 'bounds'][2]), pre
+    assert d['fc_feats'].shape[0] == len(d['infos']) == len(d['gts']) == z[pre + 'ix'].shape[0], pre
+    assert (d['att_masks'] is not None) == bool(z[pre + 'has_att_masks']) or not exact_rows, pre
+    if not exact_rows:
+        return
+    assert [i['ix'] for i in d['infos']] == z[pre + 'ix'].tolist()
+    assert [i['id'] for i in d['infos']] == z[pre + 'id'].tolist()
+    assert [i['file_path'] for i in d['infos']] == z[pre + 'file_path'].tolist()
+    for k in ('fc_feats', 'att_feats', 'labels', 'masks'):
+        want = z[pre + k]
+        assert d[k].numpy().dtype == want.dtype and d[k].shape == want.shape, (pre, k)
+        assert np.array_equal(d[k].numpy(), want), (pre, k)
+    if d['att_masks'] is not None:
+        assert np.array_equal(d['att_masks'].numpy(), z[pre + 'att_masks'])
+    for i, g in enumerate(d['gts']):
+        assert np.array_equal(np.asarray(g), z[pre + 'gts%d' % i]) and np.asarray(g).dtype == z[pre + 'gts%d' % i].dtype
+
+
+@pytest.mark.parametrize('B', [2, 4])
+def test_val_and_test_batches_are_the_reference_loaders(B):
+    """deterministic splits: every field of every batch, the partial last batch of a pass, the restart of the split, reset_iterator"""
+    z = np.load(os.path.join(GOLDEN, 'loader_ref.npz'))
+    ld = _ref_loader(B)
+    tag = 'b%d.' % B
+    assert ld.vocab_size == int(z[tag + 'vocab_size']) and ld.seq_length == int(z[tag + 'seq_length'])
+    for split, calls in (('val', 5), ('test', 3)):
+        for c in range(calls):
+            _same_batch(z, '%s%s%d.' % (tag, split, c), ld.get_batch(split))
+    ld.get_batch('val')
+    ld.reset_iterator('val')
+    _same_batch(z, tag + 'val_after_reset.', ld.get_batch('val'))
+
+
+@pytest.mark.parametrize('B', [2, 4])
+def test_train_batches_follow_the_reference_samplers_bookkeeping(B):
+    """shuffled split: the order of a pass comes from another RNG, but `bounds` of every batch (position in the pass, the
+    `wrapped` flag on the batch that holds the first image of a new pass), the batch sizes and the contents of a pass must be the
+    reference's; every row must be the image it claims to be, with captions drawn the reference's way (dataloader.py:165-184)"""
+    z = np.load(os.path.join(GOLDEN, 'loader_ref.npz'))
+    ld = _ref_loader(B)
+    tag = 'b%d.' % B
+    lab = np.load(os.path.join(GOLDEN, 'loader_ds', 'labels.npz'))
+    seen, passes = [], []
+    for c in range(8):
+        d = ld.get_batch('train')
+        pre = '%strain%d.' % (tag, c)
+        _same_batch(z, pre, d, exact_rows=False)
+        for b, info in enumerate(d['infos']):
+            ix = info['ix']
+            if d['bounds']['wrapped'] and len(seen) == 6:
+                passes.append(seen)
+                seen = []
+            seen.append(ix)
+            s, e = int(lab['label_start_ix'][ix]) - 1, int(lab['label_end_ix'][ix])
+            own = lab['labels'][s:e].astype(np.int64)
+            rows = d['labels'][b, :, 1:-1].numpy()
+            assert (d['labels'][b, :, 0] == 0).all() and (d['labels'][b, :, -1] == 0).all()
+            if e - s >= 2:                                     # a window of seq_per_img consecutive captions
+                assert any(np.array_equal(rows, own[j:j + 2]) for j in range(e - s - 1)), (c, b)
+            else:                                              # fewer captions than seq_per_img: drawn with replacement
+                assert all(any(np.array_equal(r, o) for o in own) for r in rows)
+            assert np.array_equal(np.asarray(d['gts'][b]), lab['labels'][s:e])
+    assert passes and all(sorted(p) == [0, 2, 3, 5, 7, 10] for p in passes)       # 5 train + 1 restval image, each once per pass
+    # the reference's own passes have the same contents
+    ref_seq = np.concatenate([z['%strain%d.ix' % (tag, c)] for c in range(8)])
+    assert sorted(ref_seq[:6].tolist()) == [0, 2, 3, 5, 7, 10]
