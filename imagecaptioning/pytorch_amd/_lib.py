@@ -138,6 +138,7 @@ SIGNATURES = {
     'capmi_attention_bwd': [_P, _I] + [_P] * 8 + [_I] * 5 + [_P, _I, _P],
     'capmi_attention_bwd_partial': [_P, _I, _I64, _I, _P] + [_P] * 7 + [_I] * 5 + [_P, _I, _P],
     'capmi_attention_bwd_batched': [_P, _I] + [_P] * 9 + [_I] * 7 + [_P],
+    'capmi_attention_bwd_batched_ws': [_P, _I] + [_P] * 9 + [_I] * 7 + [_P, _P],
     'capmi_lstm_cell_fwd': [_P, _I, _P, _P, _P, _I, _P] + [_P] * 6 + [_I, _I, _P],
     'capmi_lstm_cell_fwd_pl': [_P, _I, _P, _P, _P, _I, _P] + [_P] * 6 + [_I, _I, _P, _P, _P],
     'capmi_lstm_cell_fwd_pl2': [_P, _I, _P, _I, _P, _P, _P, _I, _P] + [_P] * 6 + [_I, _I, _P, _P, _P],

@@ -800,26 +800,40 @@ __global__ __launch_bounds__(DATT_T) void attn_datt_kernel(const float *__restri
         if (kc + q < K) d_att[((size_t)b * K + kc + q) * R + r] = acc[q];
 }
 
+// d_w: alpha_net weight gradient, summed over every (image, region) workgroup.  dw_part ([B*K, A], optional): each workgroup
+// writes its own row there and the caller column-sums it -- 184 000 atomicAdds on 512 addresses (360 per address, serialised
+// in L2) were most of this kernel's 52 us.
 __global__ void attn_dpatt_kernel(const float *__restrict__ att_h_all, const float *__restrict__ d_e_all,
                                   const float *__restrict__ p_att, const float *__restrict__ w,
-                                  float *__restrict__ d_p_att, float *__restrict__ d_w, int T, int N, int n, int K,
-                                  int A) {
-    // grid (B*K); threads over a
+                                  float *__restrict__ d_p_att, float *__restrict__ d_w, float *__restrict__ dw_part, int T, int N,
+                                  int n, int K, int A) {
+    // grid (B*K); threads over a.  The T*n rows of an image are walked 8 at a time: the 16 loads of a group are issued before the
+    // first tanh (one memory round trip per 8 rows instead of one per row: 51 -> 15 us at T*n = 100), the sums keep their order.
     const int b = blockIdx.x / K, k = blockIdx.x % K;
+    const int total = T * n;
     for (int a = threadIdx.x; a < A; a += blockDim.x) {
         const float p = p_att[((size_t)b * K + k) * A + a];
         float acc = 0.f, accw = 0.f;
-        for (int t = 0; t < T; ++t) {
-            for (int j = 0; j < n; ++j) {
-                const size_t row = (size_t)t * N + b * n + j;
-                const float de = d_e_all[row * K + k];
-                const float th = tanh_f(p + att_h_all[row * A + a]);
-                acc += de * (1.f - th * th);
-                accw += de * th;
+        for (int i0 = 0; i0 < total; i0 += 8) {
+            float de[8], ah[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u, total - 1);
+                const size_t row = (size_t)(i / n) * N + b * n + (i % n);
+                de[u] = d_e_all[row * K + k];
+                ah[u] = att_h_all[row * A + a];
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u < total) {
+                    const float th = tanh_f(p + ah[u]);
+                    acc += de[u] * (1.f - th * th);
+                    accw += de[u] * th;
+                }
         }
         d_p_att[((size_t)b * K + k) * A + a] = w[a] * acc;
-        atomicAdd(&d_w[a], accw);
+        if (dw_part) dw_part[(size_t)blockIdx.x * A + a] = accw;
+        else atomicAdd(&d_w[a], accw);
     }
 }
 
@@ -974,17 +988,27 @@ int capmi_attention_bwd_batched(const float *d_ctx_all, int ld_dctx, const float
                                 const float *d_e_all, const float *p_att, const float *w, float *d_att,
                                 float *d_p_att, float *d_w, float *d_b, int T, int B, int n, int N_stride, int K, int A,
                                 int R, void *stream) {
-    if (!d_ctx_all || !att_h_all || !alpha_all || !d_e_all || !p_att || !w || !d_att || !d_p_att || !d_w || !d_b)
-        return CAPMI_EINVAL;
+    return capmi_attention_bwd_batched_ws(d_ctx_all, ld_dctx, att_h_all, alpha_all, d_e_all, p_att, w, d_att, d_p_att, d_w, d_b, T,
+                                          B, n, N_stride, K, A, R, nullptr, stream);
+}
+
+int capmi_attention_bwd_batched_ws(const float *d_ctx_all, int ld_dctx, const float *att_h_all, const float *alpha_all,
+                                   const float *d_e_all, const float *p_att, const float *w, float *d_att,
+                                   float *d_p_att, float *d_w, float *d_b, int T, int B, int n, int N_stride, int K, int A,
+                                   int R, float *dw_partial, void *stream) {
+    if (!d_ctx_all || !att_h_all || !alpha_all || !d_e_all || !p_att || !w || !d_att || !d_p_att || !d_b) return CAPMI_EINVAL;
+    if (!d_w && !dw_partial) return CAPMI_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int N = N_stride > 0 ? N_stride : B * n;
     hipLaunchKernelGGL(attn_datt_kernel, dim3(B, (K + KCH - 1) / KCH, (R + DATT_T - 1) / DATT_T), dim3(DATT_T),
                        (size_t)T * n * KCH * sizeof(float), st, d_ctx_all, ld_dctx, alpha_all, d_att, T, N, n, K, R);
     CAPMI_CHECK_LAUNCH();
-    hipError_t e = hipMemsetAsync(d_w, 0, (size_t)A * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    if (!dw_partial) {
+        hipError_t e = hipMemsetAsync(d_w, 0, (size_t)A * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(attn_dpatt_kernel, dim3(B * K), dim3(A >= 512 ? 512 : 256), 0, st, att_h_all, d_e_all, p_att, w,
-                       d_p_att, d_w, T, N, n, K, A);
+                       d_p_att, d_w, dw_partial, T, N, n, K, A);
     CAPMI_CHECK_LAUNCH();
     hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(1024), 0, st, d_e_all, (size_t)T * N * K, d_b);
     CAPMI_CHECK_LAUNCH();

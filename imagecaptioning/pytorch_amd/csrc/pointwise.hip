@@ -508,6 +508,43 @@ __global__ void group_rowsum_kernel(const float *__restrict__ in, int T, size_t 
     }
 }
 
+// The same sum for cols % 4 == 0 and 16-byte aligned operands: one thread per (group, column quad, quarter of the T * group
+// rows), its rows fetched 8 at a time with all loads of a batch in flight, the four quarters combined through LDS.  The
+// scalar kernel above walks its 100 rows (SCST: T = 20, group = 5) one dependent round trip after the other: 31 us for 16 MB.
+constexpr int GRS_PARTS = 4;
+__global__ __launch_bounds__(256) void group_rowsum_v4_kernel(const float *__restrict__ in, int T, size_t slab, int groups,
+                                                              int group, int cols, float *__restrict__ out) {
+    __shared__ f32x4 sh[256];
+    const int q4 = cols >> 2;
+    const int part = threadIdx.x & (GRS_PARTS - 1);
+    const size_t qi = (size_t)blockIdx.x * (256 / GRS_PARTS) + (threadIdx.x >> 2);       // (group, column quad)
+    const size_t nq = (size_t)groups * q4;
+    const int rows = T * group, per = (rows + GRS_PARTS - 1) / GRS_PARTS;
+    const int r0 = part * per, r1 = min(rows, r0 + per);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (qi < nq) {
+        const int g = (int)(qi / q4), c = (int)(qi % q4) * 4;
+        const float *base = in + (size_t)g * group * cols + c;
+        for (int i0 = r0; i0 < r1; i0 += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u, r1 - 1);
+                v[u] = *reinterpret_cast<const f32x4 *>(base + (size_t)(i / group) * slab + (size_t)(i % group) * cols);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u < r1) s += v[u];
+        }
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (part == 0 && qi < nq) {
+        const f32x4 r = ((sh[threadIdx.x] + sh[threadIdx.x + 1]) + sh[threadIdx.x + 2]) + sh[threadIdx.x + 3];
+        *reinterpret_cast<f32x4 *>(out + qi * 4) = r;
+    }
+}
+
 __global__ void relu_mask_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ y_ref,
                                      const float *__restrict__ mask, float *__restrict__ dx, size_t count) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
@@ -808,8 +845,14 @@ int capmi_colsum_batch_args(const capmi_colsum_item *host_items, int n_items, vo
 int capmi_group_rowsum(const float *in, int T, int64_t slab, int groups, int group, int cols, float *out,
                        void *stream) {
     if (!in || !out || T <= 0 || groups <= 0 || group <= 0 || cols <= 0) return CAPMI_EINVAL;
-    hipLaunchKernelGGL(group_rowsum_kernel, dim3(grid_for((size_t)groups * cols)), dim3(256), 0, (hipStream_t)stream, in,
-                       T, (size_t)slab, groups, group, cols, out);
+    if (cols % 4 == 0 && slab % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        const size_t nq = (size_t)groups * (cols / 4);
+        hipLaunchKernelGGL(group_rowsum_v4_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, (hipStream_t)stream, in, T,
+                           (size_t)slab, groups, group, cols, out);
+    } else {
+        hipLaunchKernelGGL(group_rowsum_kernel, dim3(grid_for((size_t)groups * cols)), dim3(256), 0, (hipStream_t)stream, in,
+                           T, (size_t)slab, groups, group, cols, out);
+    }
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

@@ -622,8 +622,13 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         SegSpec a{s->d_att_h_all, A, a_hatt + (compact ? NR : NRf), R, TN, 1};
         RC(gemm(stream, 1, 1, A, R, g->h2att_w, R, &a, 1, P, cap, 0, nullptr));
         RC(colsum(s->d_att_h_all, TN, A, g->h2att_b, nullptr));
-        RC(capmi_attention_bwd_batched(s->d_x2, 3 * R, a_atth, a_alpha, s->d_e_all, r->p_att, w->alpha_w, g->d_att,
-                                       g->d_p_att, g->alpha_w, g->alpha_b, T, B, n, N, K, A, R, stream));
+        // alpha_net's weight gradient: one partial row per (image, region) in the workspace (free again: the GEMM above has
+        // finished its own slabs), summed by the batched column-sum launch below instead of 184 000 atomicAdds on 512 words
+        float *dw_part = (batch_cols && n_cols < CAPMI_COLSUM_ARGS_MAX && cap >= CAPMI_WS_COUNTER_FLOATS + (int64_t)B * K * A)
+                             ? P + CAPMI_WS_COUNTER_FLOATS : nullptr;
+        RC(capmi_attention_bwd_batched_ws(s->d_x2, 3 * R, a_atth, a_alpha, s->d_e_all, r->p_att, w->alpha_w, g->d_att,
+                                          g->d_p_att, g->alpha_w, g->alpha_b, T, B, n, N, K, A, R, dw_part, stream));
+        if (dw_part) RC(colsum(dw_part, B * K, A, g->alpha_w, nullptr));
     }
     if (n_cols) RC(capmi_colsum_batch_args(cols, n_cols, stream));
     return 0;

@@ -176,6 +176,13 @@ int capmi_attention_bwd_batched(const float *d_ctx_all, int ld_dctx, const float
                                 const float *d_e_all, const float *p_att, const float *w,
                                 float *d_att, float *d_p_att, float *d_w, float *d_b,
                                 int T, int B, int n, int N_stride, int K, int A, int R, void *stream);
+/* Same; with dw_partial ([B*K, A] floats of scratch) the alpha_net weight gradient is left as one partial row per (image,
+ * region) -- d_w = column sum of dw_partial, to be taken by the caller (capmi_colsum / capmi_colsum_batch_args; d_w itself is
+ * not touched and may be NULL) -- instead of B*K*A atomicAdds onto A addresses. */
+int capmi_attention_bwd_batched_ws(const float *d_ctx_all, int ld_dctx, const float *att_h_all, const float *alpha_all,
+                                   const float *d_e_all, const float *p_att, const float *w,
+                                   float *d_att, float *d_p_att, float *d_w, float *d_b,
+                                   int T, int B, int n, int N_stride, int K, int A, int R, float *dw_partial, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LSTM cell pointwise stage (torch.nn.LSTMCell gate math, gate order i,f,g,o; AttModel.py:628,635):

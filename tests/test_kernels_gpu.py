@@ -285,6 +285,22 @@ def test_colsum_bias_gradients(dev, rows, cols, accumulate):
     assert rel_err(out, ref) < 2e-6
 
 
+@pytest.mark.parametrize('T,groups,group,cols,pad', [(20, 10, 5, 4000, 0), (20, 10, 6, 4000, 10), (3, 2, 1, 8, 0), (7, 3, 5, 37, 0),
+                                                    (21, 64, 5, 2048, 0)])
+def test_group_rowsum(dev, T, groups, group, cols, pad):
+    """out[g, c] = sum over the T steps and the `group` rows of image g (the fc term's gradient of the attention LSTM: rows of one
+    image share fc_feats); pad: rows of other rollouts between the steps (slab stride > groups * group * cols); unaligned cols
+    take the scalar kernel"""
+    from imagecaptioning.pytorch_amd._lib import lib, check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(T + cols)
+    N = groups * group + pad
+    x = torch.randn(T, N, cols, generator=g).to(dev)
+    out = torch.full((groups, cols), float('nan'), device=dev)
+    check(lib.capmi_group_rowsum(ptr(x), T, N * cols, groups, group, cols, ptr(out), stream_ptr()), 'group_rowsum')
+    ref = x[:, :groups * group].double().view(T, groups, group, cols).sum((0, 2))
+    assert rel_err(out, ref) < 2e-6
+
+
 def test_deferred_grads_batched_reduce_and_colsum(dev):
     """ops.DeferredGrads: weight-gradient GEMMs leave their K-slice slabs, bias column sums are only recorded, flush() finishes
     everything with one capmi_splitk_reduce_batch + one capmi_colsum_batch launch.  Shapes of the Transformer backward (fat
