@@ -18,7 +18,7 @@ def main():
                           "max(end-start)/1e3 from kernels group by name order by 3 desc").fetchall()
     tot = sum(r[2] for r in rows)
     print('# %s\n' % title)
-    print('kernel time %.3f ms/step over %g steps\n' % (tot / steps / 1e3, steps))
+    print('kernel time %.3f ms/step over %g steps, %.0f launches/step\n' % (tot / steps / 1e3, steps, sum(r[1] for r in rows) / steps))
     print('| kernel | calls/step | us/step | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|')
     for r in rows[:32]:
         print('| `%s` | %.1f | %.0f | %.2f | %.2f | %.2f | %.1f |' % (r[0][:100], r[1] / steps, r[2] / steps, r[3], r[4], r[5],
