@@ -302,3 +302,31 @@ def test_train_batches_follow_the_reference_samplers_bookkeeping(B):
     # the reference's own passes have the same contents
     ref_seq = np.concatenate([z['%strain%d.ix' % (tag, c)] for c in range(8)])
     assert sorted(ref_seq[:6].tolist()) == [0, 2, 3, 5, 7, 10]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('resident', [False, True])
+def test_reference_val_batches_through_the_device_wrappers_gpu(resident):
+    """the same golden val / test batches behind ResidentFeatures and DevicePrefetcher: short last batch, restart of the split,
+    reset_iterator with batches already in flight (the wrappers drop what they scheduled ahead)"""
+    from imagecaptioning.pytorch_amd.captioning.data.resident import ResidentFeatures
+    from imagecaptioning.pytorch_amd.captioning.data.prefetch import DevicePrefetcher
+    z = np.load(os.path.join(GOLDEN, 'loader_ref.npz'))
+    dev = torch.device('cuda:0')
+    base = _ref_loader(2)
+    ld = DevicePrefetcher(ResidentFeatures(base, dev, first_rows=8) if resident else base, dev)
+
+    def host(d):
+        out = dict(d)
+        for k in ('fc_feats', 'att_feats', 'labels', 'masks', 'att_masks'):
+            if out[k] is not None:
+                assert out[k].is_cuda or k in ('labels', 'masks')
+                out[k] = out[k].cpu()
+        out['gts'] = list(getattr(out['gts'], 'gts', out['gts']))
+        return out
+    for split, calls in (('val', 5), ('test', 3)):
+        for c in range(calls):
+            _same_batch(z, 'b2.%s%d.' % (split, c), host(ld.get_batch(split)))
+    ld.get_batch('val')
+    ld.reset_iterator('val')
+    _same_batch(z, 'b2.val_after_reset.', host(ld.get_batch('val')))
