@@ -569,7 +569,7 @@ def cpu_baseline(opt, model, B, n, L, iters):
     return out
 
 
-def early_exit_line(model, flat, lw, pf, gt_indices, opt, B, n, steps=8):
+def early_exit_line(model, flat, lw, pf, gt_indices, opt, B, n, steps=20):
     """Second, separately labelled measurement of the SAME step with a model that ends its captions: random-init weights never
     draw the EOS, so the headline loop always runs all 20 steps and the early exit of the rollout driver (AttModel.py:349-350)
     cannot show.  +12 on logit.bias[EOS] makes every row stop within a few steps; the weights are restored afterwards."""
@@ -586,7 +586,7 @@ def early_exit_line(model, flat, lw, pf, gt_indices, opt, B, n, steps=8):
         flat.adam_step(lr=0.0, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon, weight_decay=0.0,
                        clip_value=opt.grad_clip_value, grad_scale=1.0)
 
-    for _ in range(3):
+    for _ in range(8):             # (the shorter rollouts have their own buffer shapes: let the caching allocator settle)
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -12,6 +12,7 @@
 //    GEMMs over all T*N rows after the loop: every weight gradient, the embedding gradient, the
 //    logit layer (forward-saved activations are stored time-major [T,N,...] for exactly this);
 //    only the 4 skinny "dX" GEMMs + the pointwise cells + the attention Jacobian stay in the loop.
+#include <chrono>
 #include "capmi_common.h"
 #include <cstdlib>
 #include "../../../include/capmi.h"
@@ -236,9 +237,14 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
     int ee_pending = -1, ee_slot = 0, steps_run = T;
     const int ee_from = r->early_exit_from > 0 ? r->early_exit_from : 0;
 
+    static const bool ee_trace = [] { const char *e = getenv("CAPMI_EE_TRACE"); return e && atoi(e) != 0; }();
+    const auto ee_t0 = std::chrono::steady_clock::now();
+    double ee_wait_us = 0;
     for (int t = 0; t < T; ++t) {
         if (ee_pending >= 0 && t - ee_pending >= 2) {
+            const auto w0 = std::chrono::steady_clock::now();
             if (hipEventSynchronize(ee_ev[ee_slot]) != hipSuccess) return CAPMI_EINVAL;
+            ee_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
             if (*const_cast<volatile int32_t *>(r->alive_host + ee_pending) == 0) {    // nobody went on after that step
                 steps_run = t;
                 break;
@@ -373,6 +379,9 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
         HIPRC(hipStreamWaitEvent(st, pre_ev[0][0], 0));
     }
 #undef HIPRC
+    if (ee_trace)
+        fprintf(stderr, "capmi rollout: %d of %d steps enqueued in %.0f us of host time, of which %.0f us blocked on the alive flag\n",
+                steps_run, T, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ee_t0).count(), ee_wait_us);
     r->steps_run = steps_run;
     if (steps_run < T) {     // the steps never run leave pad tokens and zero log-probs like the reference's untouched columns
         hipError_t e = hipSuccess;
