@@ -140,7 +140,8 @@ class DeviceCiderD:
     def cook(self, refs, n_refs):
         """references cooked once per batch (capmi_ciderd_cook_refs): uint8 [B*max_refs, COOKED_BYTES] on the device"""
         B, max_refs, w = refs.shape
-        cooked = torch.zeros(B * max_refs, self.COOKED_BYTES, dtype=torch.uint8, device=refs.device)
+        # (slots >= n_refs[image] are never read by the scoring kernel, valid slots are written whole: no zero fill)
+        cooked = torch.empty(B * max_refs, self.COOKED_BYTES, dtype=torch.uint8, device=refs.device)
         check(lib.capmi_ciderd_cook_refs(ptr(refs), ptr(n_refs), B, max_refs, w, ptr(self.keys), ptr(self.vals), self.cap,
                                          self.log_ref_len, ptr(cooked), stream_ptr()), 'capmi_ciderd_cook_refs')
         return cooked

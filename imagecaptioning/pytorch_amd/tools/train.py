@@ -24,6 +24,8 @@ def validation_loss(lw_model, loader, opt, dev):
     model = lw_model.model
     model.eval()
     tot, n = 0.0, 0
+    if hasattr(loader, 'reset_iterator'):
+        loader.reset_iterator('val')                       # eval_utils.py:145: every evaluation starts at the top of the split
     with torch.no_grad():
         while n < max(opt.val_images, opt.batch_size):
             data = loader.get_batch('val')
