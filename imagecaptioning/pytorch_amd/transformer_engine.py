@@ -240,7 +240,10 @@ class Dropper:
         for sh in shapes:
             self.k += 1
             specs.append((tuple(sh), self.k << 36, None, self.dev))
-        return ops.dropout_masks(specs, self.p, self.seed)
+        out = []
+        for i in range(0, len(specs), 4):                  # CAPMI_MAX_MASKS per launch
+            out += ops.dropout_masks(specs[i:i + 4], self.p, self.seed)
+        return out
 
 
 class TransformerGraph:
@@ -268,14 +271,18 @@ class TransformerGraph:
         self.embed = Lin(P, g, 'att_embed.0.weight', 'att_embed.0.bias')
         x = self.embed.fwd(att_feats.reshape(B * K, F), relu=True, mask=m)
         self.enc = []
+        shapes = []
+        for i in range(self.n_enc):                      # the encoder's masks, 4 per launch, in the order they are consumed
+            Fh = self.P['model.encoder.layers.%d.feed_forward.w_1.weight' % i].shape[0]
+            shapes += [(B, self.h, K, K), (B * K, D), (B * K, Fh), (B * K, D)]
+        masks = iter(self.drop.many(shapes))
         for i in range(self.n_enc):
             pre = 'model.encoder.layers.%d' % i
             n0, at = Norm(P, g, pre + '.sublayer.0.norm'), Attn(P, g, pre + '.self_attn', self.h)
             n1, ff = Norm(P, g, pre + '.sublayer.1.norm'), FFN(P, g, pre + '.feed_forward')
-            x = at.fwd(n0.fwd(x), B, K, mask=self.smask, mask_tq=1, mask_per_q=1, drop_p=self.drop(B, self.h, K, K),
-                       residual=x, res_mask=self.drop(B * K, D))
-            x = ff.fwd(n1.fwd(x), self.drop(B * K, self.P[pre + '.feed_forward.w_1.weight'].shape[0]), residual=x,
-                       res_mask=self.drop(B * K, D))
+            x = at.fwd(n0.fwd(x), B, K, mask=self.smask, mask_tq=1, mask_per_q=1, drop_p=next(masks), residual=x,
+                       res_mask=next(masks))
+            x = ff.fwd(n1.fwd(x), next(masks), residual=x, res_mask=next(masks))
             self.enc.append((n0, at, n1, ff))
         self.enc_norm = Norm(P, g, 'model.encoder.norm')
         self.memory = self.enc_norm.fwd(x)                             # [B*K, D]
@@ -288,12 +295,11 @@ class TransformerGraph:
         KV-cached sampler (Decoder), whose step t applies position t's rows of the same masks: with the same seed the
         differentiated pass is the sampled pass (loss_wrapper.py:63-68)."""
         D, K, h = self.D, self.K, self.h
-        out = [self.drop(N, T, D)]
+        shapes = [(N, T, D)]
         for i in range(self.n_dec):
             F = self.P['model.decoder.layers.%d.feed_forward.w_1.weight' % i].shape[0]
-            out += [self.drop(N, h, T, T), self.drop(N * T, D), self.drop(N, h, T, K), self.drop(N * T, D), self.drop(N * T, F),
-                    self.drop(N * T, D)]
-        return out
+            shapes += [(N, h, T, T), (N * T, D), (N, h, T, K), (N * T, D), (N * T, F), (N * T, D)]
+        return self.drop.many(shapes)                      # 4 masks per launch (same Philox offsets as one call per mask)
 
     # ---------------- decoder (teacher forced)
     def decode(self, seq, n):
