@@ -9,6 +9,8 @@ MI355X-first: K/V stay per IMAGE (the attention kernel serves the n caption rows
 key stride 2R inside p_att rows, no repeat_tensors / narrow copies); the mean-feature term of the LSTM gates is
 constant over time and enters as a per-image row bias; every core weight gradient is one time-batched GEMM.
 """
+import os
+
 import torch
 
 from . import _lib, ops
@@ -131,39 +133,68 @@ class AoAGraph:
         a_n, b_n = P['core.attention.norm.a_2'], P['core.attention.norm.b_2']
         Wq, bq = P['core.attention.linears.0.weight'], P['core.attention.linears.0.bias']
         Wc, bc = P['core.att2ctx.0.weight'], P['core.att2ctx.0.bias']
+        # r3: the step's GEMM operands as producer-written bf16x3 planes (N <= 64 rows: the loader / consumer GEMM stages them by
+        # LDS-DMA) and ONE launch behind the att2ctx GEMM -- capmi_glu_fwd_fused finishes its slabs, applies the GLU and writes
+        # out, out_drop (+ planes: the logit GEMM's operand) and the NEXT step's dropped context input (+ planes): 14 -> 11 launches
+        # per step
+        use_pl = (N <= 64 and R % 4 == 0 and E % 4 == 0 and os.environ.get('CAPMI_AOA_PLANES', '1') != '0')
+        if use_pl:
+            nbR, nbE = int(lib.capmi_planes_bytes(R)), int(lib.capmi_planes_bytes(E))
+            pl_xt = ops.planes_scratch(dev, ('aoa_xt', stream_ptr()), nbE)
+            pl_ctx, pl_h, pl_od = (ops.planes_scratch(dev, ('aoa_' + k, stream_ptr()), nbR) for k in ('ctx', 'h', 'od'))
+            pl_zero = ops.zero_planes(dev, max(nbR, nbE) // 12288)
+            self.ctx_in[0].zero_()                               # out_0 = 0 (AoAModel.py:127-129)
         for t in range(T):
             m_xt, m_ctx, m_out, m_p = self.m_xt[t], self.m_ctx[t], self.m_out[t], self.m_patt[t]
-            if teacher:
-                check(lib.capmi_embed_fwd(forced.data_ptr() + 8 * t, forced.shape[1], ptr(self.it_all[t]), ptr(P['embed.0.weight']),
-                                          ptr(m_xt), ptr(self.xt[t]), N, E, 1, st), 'embed_fwd')
+            tok_src = (forced.data_ptr() + 8 * t, forced.shape[1]) if teacher else (ptr(it), 1)
+            if use_pl:
+                check(lib.capmi_embed_fwd_pl(tok_src[0], tok_src[1], ptr(self.it_all[t]), ptr(P['embed.0.weight']), ptr(m_xt),
+                                             ptr(self.xt[t]), N, E, 1, ptr(pl_xt), st), 'embed_fwd_pl')
             else:
-                check(lib.capmi_embed_fwd(ptr(it), 1, ptr(self.it_all[t]), ptr(P['embed.0.weight']), ptr(m_xt), ptr(self.xt[t]), N, E,
-                                          1, st), 'embed_fwd')
-            ctx_prev = self.out[t]
-            if m_ctx is None:
-                self.ctx_in[t].copy_(ctx_prev)
-            else:
-                check(lib.capmi_relu_mask_bwd(ptr(ctx_prev), None, ptr(m_ctx), ptr(self.ctx_in[t]), N * R, st), 'ctx_drop')
+                check(lib.capmi_embed_fwd(tok_src[0], tok_src[1], ptr(self.it_all[t]), ptr(P['embed.0.weight']), ptr(m_xt),
+                                          ptr(self.xt[t]), N, E, 1, st), 'embed_fwd')
+                ctx_prev = self.out[t]
+                if m_ctx is None:
+                    self.ctx_in[t].copy_(ctx_prev)
+                else:
+                    check(lib.capmi_relu_mask_bwd(ptr(ctx_prev), None, ptr(m_ctx), ptr(self.ctx_in[t]), N * R, st), 'ctx_drop')
             splits = ops.gemm([(self.xt[t], E, W_ih, ld_ih, E, 1), (self.ctx_in[t], R, (W_ih, E), ld_ih, R, 1),
-                               (self.h_att[t], R, W_hh, R, R, 1)], N, 4 * R, ws.buf, ws=ws, defer_reduce=True)
-            check(lib.capmi_lstm_cell_fwd(ws.slabs.data_ptr(), splits, ptr(P['core.att_lstm.bias_ih']),
-                                          ptr(P['core.att_lstm.bias_hh']), ptr(self.mean_gates), n, None, ptr(self.c_att[t]),
-                                          ptr(self.h_att[t + 1]), ptr(self.c_att[t + 1]), ptr(self.gates[t]), None, None, N, R, st),
-                  'lstm_cell_fwd')
+                               (self.h_att[t], R, W_hh, R, R, 1)], N, 4 * R, ws.buf, ws=ws, defer_reduce=True,
+                              a_planes=[pl_xt, pl_zero if t == 0 else pl_ctx, pl_zero if t == 0 else pl_h] if use_pl else None)
+            if use_pl:
+                check(lib.capmi_lstm_cell_fwd_pl(ws.slabs.data_ptr(), splits, ptr(P['core.att_lstm.bias_ih']),
+                                                 ptr(P['core.att_lstm.bias_hh']), ptr(self.mean_gates), n, None, ptr(self.c_att[t]),
+                                                 ptr(self.h_att[t + 1]), ptr(self.c_att[t + 1]), ptr(self.gates[t]), None, None, N, R,
+                                                 ptr(pl_h), None, st), 'lstm_cell_fwd_pl')
+            else:
+                check(lib.capmi_lstm_cell_fwd(ws.slabs.data_ptr(), splits, ptr(P['core.att_lstm.bias_ih']),
+                                              ptr(P['core.att_lstm.bias_hh']), ptr(self.mean_gates), n, None, ptr(self.c_att[t]),
+                                              ptr(self.h_att[t + 1]), ptr(self.c_att[t + 1]), ptr(self.gates[t]), None, None, N, R, st),
+                      'lstm_cell_fwd')
             check(lib.capmi_layernorm_fwd(ptr(self.h_att[t + 1]), ptr(a_n), ptr(b_n), ptr(self.qn[t]), ptr(self.q_ln_mean[t]),
                                           ptr(self.q_ln_inv[t]), N, R, EPS, st), 'layernorm_fwd')
             ops.gemm([(self.qn[t], R, Wq, R, R, 1)], N, R, self.q[t], bias=bq)
             # keys = second half of p_att rows, values = first half (AoAModel.py:168); per image, stride 2R
             check(lib.capmi_mha_fwd(ptr(self.q[t]), self.p_att.data_ptr() + 4 * R, ptr(self.p_att), K * 2 * R, 2 * R, ptr(self.smask),
                                     1, 0, 0, 0, ptr(m_p), ptr(self.att_o[t]), ptr(self.p_dec[t]), N, n, 1, K, h, R // h, st), 'mha_fwd')
-            ops.gemm([(self.att_o[t], R, Wc, 2 * R, R, 1), (self.h_att[t + 1], R, (Wc, R), 2 * R, R, 1)], N, 2 * R, self.pre2[t], bias=bc)
-            check(lib.capmi_glu_fwd(ptr(self.pre2[t]), None, None, ptr(self.out[t + 1]), N, R, st), 'glu_fwd')
-            if m_out is None:
-                self.out_drop[t].copy_(self.out[t + 1])
+            c_segs = [(self.att_o[t], R, Wc, 2 * R, R, 1), (self.h_att[t + 1], R, (Wc, R), 2 * R, R, 1)]
+            if use_pl:
+                sp2 = ops.gemm(c_segs, N, 2 * R, ws.buf, ws=ws, defer_reduce=True)
+                nxt = t + 1 < T
+                check(lib.capmi_glu_fwd_fused(ws.slabs.data_ptr(), sp2, N * 2 * R, ptr(bc), ptr(self.pre2[t]), ptr(self.out[t + 1]),
+                                              ptr(m_out), ptr(self.out_drop[t]), ptr(pl_od),
+                                              ptr(self.m_ctx[t + 1]) if nxt else None, ptr(self.ctx_in[t + 1]) if nxt else None,
+                                              ptr(pl_ctx) if nxt else None, N, R, st), 'glu_fwd_fused')
             else:
-                check(lib.capmi_relu_mask_bwd(ptr(self.out[t + 1]), None, ptr(m_out), ptr(self.out_drop[t]), N * R, st), 'out_drop')
+                ops.gemm(c_segs, N, 2 * R, self.pre2[t], bias=bc)
+                check(lib.capmi_glu_fwd(ptr(self.pre2[t]), None, None, ptr(self.out[t + 1]), N, R, st), 'glu_fwd')
+                if m_out is None:
+                    self.out_drop[t].copy_(self.out[t + 1])
+                else:
+                    check(lib.capmi_relu_mask_bwd(ptr(self.out[t + 1]), None, ptr(m_out), ptr(self.out_drop[t]), N * R, st), 'out_drop')
             # the logit GEMM leaves its K-slice slabs; log-softmax + select finishes them with the bias (no reduce launch)
-            sp = ops.gemm([(self.out_drop[t], R, P['logit.weight'], R, R, 1)], N, V1, ws.buf, ws=ws, defer_reduce=True)
+            sp = ops.gemm([(self.out_drop[t], R, P['logit.weight'], R, R, 1)], N, V1, ws.buf, ws=ws, defer_reduce=True,
+                          a_planes=[pl_od] if use_pl else None)
             ops.logsoftmax_select(ws.slabs, t, L, mode_i, temperature, None if gumbel is None else gumbel[t], seed, forced,
                                   1 if teacher else 0, self.seq, it, unf, self.seq_logp, self.sel, self.live, top_k, top_p,
                                   splits=sp, stride=N * V1, bias=P['logit.bias'], shape=(N, V1))

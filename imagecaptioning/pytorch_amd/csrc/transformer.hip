@@ -305,6 +305,60 @@ __global__ void glu_fwd_kernel(const float *__restrict__ pre, const float *__res
     }
 }
 
+// AoA decode step (AoAModel.py:143-158 core: att2ctx Linear -> GLU -> dropouts): finishes the att2ctx GEMM's K-slice slabs
+// (+ bias, in the order of splitk_reduce_kernel), applies the GLU and writes every consumer's operand in ONE launch --
+//   pre [M,2R] (kept for the backward), out = pre[:, :R] * sigmoid(pre[:, R:]),
+//   out_a = out * mask_a (the logit GEMM's input, F.dropout of the output), out_b = out * mask_b (the NEXT step's context input)
+// -- the last two also as "A planes" (M <= 64) so that both GEMMs stage them by LDS-DMA.  Replaces a split-K reduce launch, the
+// GLU launch and two mask launches per step.  4 columns per thread (R % 4 == 0, 16-byte aligned operands).
+__global__ __launch_bounds__(256) void glu_fwd_fused_kernel(const float *__restrict__ slabs, int splits, size_t stride,
+                                                            const float *__restrict__ bias, float *__restrict__ pre,
+                                                            float *__restrict__ out, const float *__restrict__ mask_a,
+                                                            float *__restrict__ out_a, unsigned char *__restrict__ pl_a,
+                                                            const float *__restrict__ mask_b, float *__restrict__ out_b,
+                                                            unsigned char *__restrict__ pl_b, int M, int R) {
+    const int q4 = R >> 2;
+    const size_t nq = (size_t)M * q4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(q / q4), c = (int)(q % q4) * 4;
+        const size_t ia = (size_t)r * 2 * R + c, ig = ia + R;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < splits; s0 += 4) {               // 8 independent 16-byte loads in flight
+            f32x4 ta[4], tg[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t o = (size_t)min(s0 + u, splits - 1) * stride;
+                ta[u] = *reinterpret_cast<const f32x4 *>(slabs + o + ia);
+                tg[u] = *reinterpret_cast<const f32x4 *>(slabs + o + ig);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (s0 + u < splits) { a += ta[u]; g += tg[u]; }
+        }
+        if (bias) {
+            a += *reinterpret_cast<const f32x4 *>(bias + c);
+            g += *reinterpret_cast<const f32x4 *>(bias + R + c);
+        }
+        *reinterpret_cast<f32x4 *>(pre + ia) = a;
+        *reinterpret_cast<f32x4 *>(pre + ig) = g;
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = a[k] * sigmoid_f(g[k]);
+        const size_t io = (size_t)r * R + c;
+        *reinterpret_cast<f32x4 *>(out + io) = o;
+        if (out_a) {
+            const f32x4 v = mask_a ? o * *reinterpret_cast<const f32x4 *>(mask_a + io) : o;
+            *reinterpret_cast<f32x4 *>(out_a + io) = v;
+            if (pl_a) capmi::pl_store4(pl_a, r, c, v);
+        }
+        if (out_b) {
+            const f32x4 v = mask_b ? o * *reinterpret_cast<const f32x4 *>(mask_b + io) : o;
+            *reinterpret_cast<f32x4 *>(out_b + io) = v;
+            if (pl_b) capmi::pl_store4(pl_b, r, c, v);
+        }
+    }
+}
+
 __global__ void glu_bwd_kernel(const float *__restrict__ d_out, const float *__restrict__ mask, const float *__restrict__ pre,
                                float *__restrict__ d_pre, int M, int R) {
     const size_t total = (size_t)M * R;
@@ -461,6 +515,24 @@ int capmi_glu_fwd(const float *pre, const float *mask, const float *residual, fl
     if (!pre || !out || M <= 0 || R <= 0) return CAPMI_EINVAL;
     hipLaunchKernelGGL(glu_fwd_kernel, dim3(grid_for((size_t)M * R)), dim3(256), 0, (hipStream_t)stream, pre, mask, residual, out,
                        M, R);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_glu_fwd_fused(const float *slabs, int splits, int64_t stride, const float *bias, float *pre, float *out,
+                        const float *mask_a, float *out_a, void *planes_a, const float *mask_b, float *out_b, void *planes_b,
+                        int M, int R, void *stream) {
+    if (!slabs || !pre || !out || splits < 1 || M <= 0 || R <= 0 || R % 4 || stride % 4) return CAPMI_EINVAL;
+    if ((planes_a || planes_b) && M > 64) return CAPMI_EINVAL;
+    if ((planes_a && !out_a) || (planes_b && !out_b)) return CAPMI_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(pre) |
+         reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(mask_a) | reinterpret_cast<uintptr_t>(out_a) |
+         reinterpret_cast<uintptr_t>(mask_b) | reinterpret_cast<uintptr_t>(out_b) | reinterpret_cast<uintptr_t>(planes_a) |
+         reinterpret_cast<uintptr_t>(planes_b)) & 15)
+        return CAPMI_EINVAL;
+    hipLaunchKernelGGL(glu_fwd_fused_kernel, dim3(grid_for((size_t)M * (R / 4))), dim3(256), 0, (hipStream_t)stream, slabs, splits,
+                       (size_t)stride, bias, pre, out, mask_a, out_a, static_cast<unsigned char *>(planes_a), mask_b, out_b,
+                       static_cast<unsigned char *>(planes_b), M, R);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

@@ -738,6 +738,13 @@ int capmi_embed_pe_bwd(const int64_t *tok, int tok_ld, const float *dx, const fl
                        void *stream);
 /* AoA / GLU blocks (AoAModel.py:44, 143): out = [residual +] mask * (pre[:, :R] * sigmoid(pre[:, R:2R])), pre [M,2R] */
 int capmi_glu_fwd(const float *pre, const float *mask, const float *residual, float *out, int M, int R, void *stream);
+/* The same for one AoA decode step, finishing the att2ctx GEMM's K-slice slabs itself (slabs [splits][M,2R] + bias -> pre, kept
+ * for the backward) and writing every consumer's operand: out, out_a = out * mask_a (input of the logit GEMM), out_b = out * mask_b
+ * (context input of the NEXT step) -- masks NULL = plain copies, out_a / out_b NULL = not wanted -- the last two also as "A planes"
+ * (M <= 64; capmi_planes_from_f32 layout, buffers zero-filled once by the caller).  R % 4 == 0, 16-byte aligned operands. */
+int capmi_glu_fwd_fused(const float *slabs, int splits, int64_t stride, const float *bias, float *pre, float *out,
+                        const float *mask_a, float *out_a, void *planes_a, const float *mask_b, float *out_b, void *planes_b,
+                        int M, int R, void *stream);
 /* d_pre [M,2R] from d_out [M,R] (mask applied first) */
 int capmi_glu_bwd(const float *d_out, const float *mask, const float *pre, float *d_pre, int M, int R, void *stream);
 /* masked mean over regions (AoAModel.py:214-219): mean[b,:] = sum_k m[b,k] x[b,k,:] / sum_k m[b,k] (m NULL = ones) */
