@@ -151,7 +151,10 @@ __global__ __launch_bounds__(LC_NT) void gemm_lc_kernel(const KArgs a) {
         CAPMI_LC_STAMP(1);
         int fill = pre;                              // next stage to request, into slot fslot = fill % LC_NS
         int fslot = pre;
+        unsigned long long q_land = 0, q_bar = 0, q_issue = 0;      // ABL & 128: where a loader's cycles go
         for (int k = 0; k <= nst; ++k) {             // nst + 1 barriers (the last one ends the second half of the last stage)
+            unsigned long long q0 = 0, q1 = 0, q2 = 0;
+            if (ABL & 128) q0 = clock64();
             if (k < nst) {
                 // stage k has landed when at most the DMAs of the younger stages are outstanding (a wave's LDS-DMAs retire in order)
                 const int younger = fill - 1 - k;    // 0 .. LC_NS - 1
@@ -165,7 +168,9 @@ __global__ __launch_bounds__(LC_NT) void gemm_lc_kernel(const KArgs a) {
                 else CAPMI_VMCNT(0);
             }
             if (k == 0) CAPMI_LC_STAMP(2);
+            if (ABL & 128) q1 = clock64();
             __builtin_amdgcn_s_barrier();
+            if (ABL & 128) q2 = clock64();
 #pragma unroll
             for (int r = 0; r < 2; ++r)
                 if (fill < nst && fill <= k - 2 + LC_NS) {
@@ -173,7 +178,11 @@ __global__ __launch_bounds__(LC_NT) void gemm_lc_kernel(const KArgs a) {
                     ++fill;
                     fslot = fslot == LC_NS - 1 ? 0 : fslot + 1;
                 }
+            if (ABL & 128) { q_land += q1 - q0; q_bar += q2 - q1; q_issue += clock64() - q2; }
         }
+        if ((ABL & 128) && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && j == 0)
+            printf("lc loader 0: %d stages; cycles per stage: waiting for its DMAs to land %.0f, in the barrier %.0f, issuing %.0f\n", nst,
+                   (double)q_land / (nst + 1), (double)q_bar / (nst + 1), (double)q_issue / (nst + 1));
         __builtin_amdgcn_s_barrier();                // the two barriers of the parity merge below
         __builtin_amdgcn_s_barrier();
         CAPMI_LC_STAMP(3);
@@ -200,6 +209,7 @@ __global__ __launch_bounds__(LC_NT) void gemm_lc_kernel(const KArgs a) {
     for (int q = 0; q < 4; ++q) wo[q] = LC_AB + (BKC ? cl * 128 + (((4 * half + q) ^ wsw) << 4) : (16 * half + 4 * q) * 512 + cl * 4);
     // weight fragment of a stage: ds_read + exact 3-way split (x = h + m + l, truncated bf16 values; see gemm_x3.hip)
     auto wfrag = [&](const unsigned char *slot, u32x4 (&wb)[2][3]) {
+        if (ABL & 64) return;                        // (probe: MFMAs on stale registers -- no LDS reads, no split)
         float bb[16];
         if (BKC) {
 #pragma unroll
@@ -232,13 +242,19 @@ __global__ __launch_bounds__(LC_NT) void gemm_lc_kernel(const KArgs a) {
             }
     };
     auto mma = [&](const unsigned char *slot, const u32x4 (&wb)[2][3], int ks) {
-        bf16x8 bw[3], x0[3], x1[3];
+        bf16x8 bw[3], x0[3] = {}, x1[3] = {};
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             bw[pl] = __builtin_bit_cast(bf16x8, wb[ks][pl]);
+            if (ABL & 64) continue;
             const unsigned char *q = slot + pl * CAPMI_PL_PLANE_BYTES + ao[ks];
             x0[pl] = *reinterpret_cast<const bf16x8 *>(q);
             if (TM == 2) x1[pl] = *reinterpret_cast<const bf16x8 *>(q + 32 * 64);
+        }
+        if (ABL & 32) {                              // (probe: split + LDS reads stay, nothing is multiplied)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) asm volatile("" ::"v"(bw[pl]), "v"(x0[pl]), "v"(x1[pl]));
+            return;
         }
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // six of nine cross terms, small ones first
 #pragma unroll
@@ -248,12 +264,15 @@ __global__ __launch_bounds__(LC_NT) void gemm_lc_kernel(const KArgs a) {
         }
     };
     // (s_barrier is IntrNoMem for the compiler: the asm memory clobbers keep the LDS reads on their side of it)
-#define CAPMI_LC_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+    unsigned long long c_bar = 0, c_t0 = 0;
+    if (ABL & 128) c_t0 = clock64();
+#define CAPMI_LC_BARRIER() do { unsigned long long b0_ = 0; if (ABL & 128) b0_ = clock64(); asm volatile("" ::: "memory"); \
+                                __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); if (ABL & 128) c_bar += clock64() - b0_; } while (0)
     int bars = 0;                                    // ring barriers passed (every wave passes nst + 1 of them)
     if (par) { CAPMI_LC_BARRIER(); ++bars; }         // barrier 0 hands over an even stage
     if (par == 0) CAPMI_LC_STAMP(1);
     {
-        u32x4 wb[2][3];
+        u32x4 wb[2][3] = {};
         int sidx = par;                              // slot of stage j
         for (int j = par; j < nst; j += 2) {
             CAPMI_LC_BARRIER();                      // barrier j: stage j has landed
@@ -261,13 +280,22 @@ __global__ __launch_bounds__(LC_NT) void gemm_lc_kernel(const KArgs a) {
             if (j == 0) CAPMI_LC_STAMP(4);
             const unsigned char *slot = ldsb + sidx * LC_STAGE;
             sidx = sidx >= LC_NS - 2 ? sidx + 2 - LC_NS : sidx + 2;
-            if (!(ABL & 2)) { wfrag(slot, wb); mma(slot, wb, 0); }
+            // Interval j: this wave fetches and SPLITS the stage's weights (VALU) while its SIMD partner of the other parity
+            // multiplies the previous stage (matrix pipe); interval j + 1: the roles swap.  (With the first k-step's MFMAs in
+            // interval j as well -- CAPMI_LC_OPT bit 1 clear... the r3a arrangement -- the interval was this wave's serial
+            // read -> split -> read -> 12 MFMAs, 1.69k cycles, and the partner idled behind its 12: consumers, not the weight
+            // stream, set the pace; the copy rate it happened to equal, 5.1 TB/s, is not the Infinity Cache's.)
+            const bool late = (a.ablate & 2) != 0;
+            if (!(ABL & 2)) { wfrag(slot, wb); if (!late) mma(slot, wb, 0); }
             CAPMI_LC_BARRIER();                      // barrier j + 1 (the other parity's hand-over, or the closing one)
             ++bars;
-            if (!(ABL & 2)) mma(slot, wb, 1);
+            if (!(ABL & 2)) { if (late) mma(slot, wb, 0); mma(slot, wb, 1); }
         }
     }
     while (bars <= nst) { CAPMI_LC_BARRIER(); ++bars; }
+    if ((ABL & 128) && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && cg == 0)
+        printf("lc consumer parity %d: %d ring barriers, %.0f cycles per stage interval, of which %.0f in the barrier\n", par, bars,
+               (double)(clock64() - c_t0) / bars, (double)c_bar / bars);
     // ---- the two parities of a column group meet in LDS (the ring is dead behind the first barrier) -------------------------
     constexpr int RP = LC_BN + 4;
     float *red = reinterpret_cast<float *>(ldsb);   // [64][RP]
@@ -371,6 +399,11 @@ static int launch_lc_t(const KArgs &a, hipStream_t st, int pcls, double bytes, d
             case 11: CAPMI_LC_GO(11); break;
             case 15: CAPMI_LC_GO(15); break;
             case 16: CAPMI_LC_GO(16); break;
+            case 32: CAPMI_LC_GO(32); break;
+            case 64: CAPMI_LC_GO(64); break;
+            case 128: CAPMI_LC_GO(128); break;
+            case 192: CAPMI_LC_GO(192); break;
+            case 160: CAPMI_LC_GO(160); break;
             default: CAPMI_LC_GO(0); break;
         }
     } else {
