@@ -284,8 +284,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_kernel(
 // then reduces the slabs, scores, normalises and accumulates the context out of registers: ONE memory round trip per launch.
 // Shapes outside the fast path (A > 512, R > 1024, K > 40, unaligned) keep the kernel above.
 constexpr int V2_KMAX = 40;          // regions held in registers: 5 score regions per wave x 8 waves, 20 att rows per half
-constexpr int V2_SREG = 5, V2_CREG = 20;
-template <int NR>      // rows per workgroup held in registers (1 or 2; larger groups use the kernel above)
+constexpr int V2_SREG = 5;
+// CS (r3): the context's R columns of a row are split over CS workgroups (blockIdx.y): each scores and normalises
+// the row itself (p_att in full) but fetches and accumulates only its R / CS columns of the image's att tile -- a CU pulls at most
+// ~250 cache lines at a time, so a 217 KB working set per workgroup is three or four queue-fulls.
+template <int NR, int CS = 1>      // rows per workgroup held in registers (1 or 2; larger groups use the kernel above)
 __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_v2_kernel(
     const float *__restrict__ att_h, const float *__restrict__ p_att, const float *__restrict__ att,
     const float *__restrict__ mask, const float *__restrict__ w, const float *__restrict__ bptr,
@@ -340,14 +343,19 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_v2_kernel(
         p0[g] = *reinterpret_cast<const f32x4 *>(pb + (size_t)k * A + a0c);
         p1[g] = *reinterpret_cast<const f32x4 *>(pb + (size_t)k * A + a1c);
     }
-    // (c) att: thread (cg, half) owns columns 4 cg .. 4 cg + 3 and regions half, half + 2, ...
+    // (c) att: thread (cg, half) owns columns 4 cg .. 4 cg + 3 and regions half, half + GR, ...  (CS = 1: 256 column quads x 2
+    //     region groups; CS workgroups per row: 256 / CS quads x 2 CS groups, the workgroup's quads start at blockIdx.y * QPW)
+    constexpr int QD = 256 / CS, GR = 2 * CS, CREG = (V2_KMAX + GR - 1) / GR;
     const float *ab = att + (size_t)b * K * R;
-    const int cg = threadIdx.x & 255, half = threadIdx.x >> 8;
-    const int r = cg * 4, rc = min(r, R - 4);
-    f32x4 av[V2_CREG];
+    const int qpw = CS == 1 ? 256 : ((R >> 2) + CS - 1) / CS;       // column quads per workgroup
+    const int q_lo = CS == 1 ? 0 : (int)blockIdx.y * qpw, q_hi = CS == 1 ? (R >> 2) : min((R >> 2), q_lo + qpw);
+    const int cg = threadIdx.x & (QD - 1), half = threadIdx.x / QD;
+    const int r = (q_lo + cg) * 4, rc = min(r, R - 4);
+    const bool own = q_lo + cg < q_hi;
+    f32x4 av[CREG];
 #pragma unroll
-    for (int g = 0; g < V2_CREG; ++g) {
-        const int k = min(half + 2 * g, K - 1);
+    for (int g = 0; g < CREG; ++g) {
+        const int k = min(half + GR * g, K - 1);
         av[g] = *reinterpret_cast<const f32x4 *>(ab + (size_t)k * R + rc);
     }
     const f32x4 w0 = *reinterpret_cast<const f32x4 *>(w + a0c), w1 = *reinterpret_cast<const f32x4 *>(w + a1c);
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_v2_kernel(
             for (int q = 1; q < 4; ++q) v += *reinterpret_cast<const f32x4 *>(s_p + (size_t)q * NR * 512 + pc * 4);
             if (h_bias) v += *reinterpret_cast<const f32x4 *>(h_bias + (pc * 4) % A);
             *reinterpret_cast<f32x4 *>(s_h + pc * 4) = v;
-            if (att_h_out) *reinterpret_cast<f32x4 *>(att_h_out + (size_t)row0 * A + pc * 4) = v;
+            if (att_h_out && (CS == 1 || blockIdx.y == 0)) *reinterpret_cast<f32x4 *>(att_h_out + (size_t)row0 * A + pc * 4) = v;
         }
     } else {
         if (sgrp == 0) {
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_v2_kernel(
         }
         if (lane < K) {
             e[lane] = ex;
-            alpha[(size_t)(row0 + j) * K + lane] = ex;
+            if (CS == 1 || blockIdx.y == 0) alpha[(size_t)(row0 + j) * K + lane] = ex;
         }
     }
     __syncthreads();
@@ -434,9 +442,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_v2_kernel(
 #pragma unroll
     for (int j = 0; j < NR; ++j) c0[j] = c1[j] = c2[j] = c3[j] = 0.f;
 #pragma unroll
-    for (int g = 0; g < V2_CREG; ++g) {
-        const int k = half + 2 * g;
-        if (k < K) {              // workgroup-half-uniform
+    for (int g = 0; g < CREG; ++g) {
+        const int k = half + GR * g;
+        if (k < K) {              // uniform per region group
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
                 if (j < n) {
@@ -446,20 +454,21 @@ __global__ __launch_bounds__(ATT_THREADS) void attention_fwd_v2_kernel(
             }
         }
     }
-    __syncthreads();                          // s_h is dead: reuse it as the combine buffer [NMAX][1024]
-    float *s_c = s_h;
-    if (half == 1 && r < R) {
+    __syncthreads();                          // s_h / s_p are dead: the combine buffer [GR - 1][NR][QD * 4] (<= 4 * NR * 512 floats)
+    float *s_c = CS == 1 ? s_h : s_p;
+    if (half > 0 && own) {
 #pragma unroll
         for (int j = 0; j < NR; ++j)
-            if (j < n) *reinterpret_cast<f32x4 *>(s_c + j * 1024 + r) = f32x4{c0[j], c1[j], c2[j], c3[j]};
+            if (j < n) *reinterpret_cast<f32x4 *>(s_c + ((size_t)(half - 1) * NR + j) * (QD * 4) + cg * 4) = f32x4{c0[j], c1[j], c2[j], c3[j]};
     }
     __syncthreads();
-    if (half == 0 && r < R) {
+    if (half == 0 && own) {
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             if (j < n) {
-                const f32x4 o = *reinterpret_cast<const f32x4 *>(s_c + j * 1024 + r);
-                const f32x4 cv = f32x4{c0[j] + o[0], c1[j] + o[1], c2[j] + o[2], c3[j] + o[3]};
+                f32x4 cv = f32x4{c0[j], c1[j], c2[j], c3[j]};
+#pragma unroll
+                for (int q = 1; q < GR; ++q) cv += *reinterpret_cast<const f32x4 *>(s_c + ((size_t)(q - 1) * NR + j) * (QD * 4) + cg * 4);
                 *reinterpret_cast<f32x4 *>(ctx + (size_t)(row0 + j) * R + r) = cv;
                 if (pl_ctx) pl_store4(pl_ctx, row0 + j, r, cv);         // A planes of ctx for the language-LSTM gate GEMM
             }
@@ -886,15 +895,24 @@ static int attention_fwd_launch(const float *att_h, int h_splits, int64_t h_stri
         h_splits <= 16 && (h_stride & 3) == 0) {
         const size_t lds2 = ((size_t)rpb * 1024 + (size_t)rpb * V2_KMAX + (size_t)4 * rpb * 512) * sizeof(float);
         const bool prof = capmi_prof::take_events(CAPMI_PROF_ATTENTION_FWD, &e0, &e1, abytes, (double)N * K * (2.0 * A + 2.0 * R));
-        const dim3 grid(row_img ? N : grid_blocks(B, chunks));
-#define CAPMI_ATT_V2(NR_)                                                                                                   \
-        if (prof) hipExtLaunchKernelGGL(attention_fwd_v2_kernel<NR_>, grid, dim3(ATT_THREADS), lds2, (hipStream_t)stream, e0,   \
+        const int gx = row_img ? N : grid_blocks(B, chunks);
+        // default 4 (when every workgroup still gets its own CU): 10.3 -> 9.3 us per launch at the SCST shape; CAPMI_ATT_CS=1: one
+        // workgroup per row as in round 2
+        static const int env_cs = [] { const char *e = getenv("CAPMI_ATT_CS"); return e ? atoi(e) : 4; }();
+        const int cs = (env_cs == 2 || env_cs == 4) && gx * env_cs <= 256 ? env_cs : 1;     // every workgroup on its own CU
+        const dim3 grid(gx, cs);
+#define CAPMI_ATT_V2(NR_, CS_)                                                                                              \
+        if (prof) hipExtLaunchKernelGGL((attention_fwd_v2_kernel<NR_, CS_>), grid, dim3(ATT_THREADS), lds2, (hipStream_t)stream, e0, \
                                         e1, 0, att_h, p_att, att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K, A, R, row_img,  \
                                         h_splits, (size_t)h_stride, h_bias, att_h_out, pl_ctx);                                \
-        else hipLaunchKernelGGL(attention_fwd_v2_kernel<NR_>, grid, dim3(ATT_THREADS), lds2, (hipStream_t)stream, att_h, p_att, \
+        else hipLaunchKernelGGL((attention_fwd_v2_kernel<NR_, CS_>), grid, dim3(ATT_THREADS), lds2, (hipStream_t)stream, att_h, p_att, \
                                 att, mask, w, b, ctx, alpha, B, n, rpb, chunks, K, A, R, row_img, h_splits, (size_t)h_stride,   \
                                 h_bias, att_h_out, pl_ctx)
-        if (rpb == 1) { CAPMI_ATT_V2(1); } else { CAPMI_ATT_V2(2); }
+        if (rpb == 1) {
+            if (cs == 4) { CAPMI_ATT_V2(1, 4); } else if (cs == 2) { CAPMI_ATT_V2(1, 2); } else { CAPMI_ATT_V2(1, 1); }
+        } else {
+            if (cs == 4) { CAPMI_ATT_V2(2, 4); } else if (cs == 2) { CAPMI_ATT_V2(2, 2); } else { CAPMI_ATT_V2(2, 1); }
+        }
 #undef CAPMI_ATT_V2
         CAPMI_CHECK_LAUNCH();
         return 0;
