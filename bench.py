@@ -233,6 +233,7 @@ def main():
     # Default for N > 1: ONE all-reduce of the whole flat fp32 gradient per step (north_star / SURVEY 8e).
     # CAPMI_DDP_OVERLAP=1 opts into the bucketed variant (6 collectives launched from inside the backward as the phases finish
     # their gradients, clip+Adam pipelined behind them).
+    WATCH = {'phase': 'main', 'line': None, 'mode': None}
     overlap = multi and os.environ.get('CAPMI_DDP_OVERLAP', '0') == '1'
     # CAPMI_DDP_MODE=rsag: reduce-scatter -> clip+Adam on the rank's 1/N shard -> all-gather of the parameters
     sharded = multi and not overlap and os.environ.get('CAPMI_DDP_MODE', 'allreduce') == 'rsag'
@@ -245,8 +246,14 @@ def main():
         limit = float(os.environ.get('CAPMI_BENCH_WATCHDOG_S', '600'))
 
         def _bark():
-            print('rank %d: bench.py exceeded its %.0f s watchdog (a hung RCCL collective?); aborting' % (rank, limit),
-                  file=sys.stderr, flush=True)
+            print('rank %d: bench.py exceeded its %.0f s watchdog (a hung RCCL collective?) in phase %r; aborting'
+                  % (rank, limit, WATCH.get('phase')), file=sys.stderr, flush=True)
+            if WATCH.get('phase') == 'mode sweep':
+                # the K timed steps and the line are done: a mode of the optional sweep hanging must not cost the measurement
+                if rank == 0 and WATCH.get('line') is not None:
+                    WATCH['line']['collective']['ms_per_step_by_mode'] = 'sweep hung in mode %r' % WATCH.get('mode')
+                    print(json.dumps(WATCH['line']), flush=True)
+                os._exit(0)
             os._exit(3)
         watchdog = threading.Timer(limit, _bark)
         watchdog.daemon = True
@@ -382,15 +389,15 @@ def main():
             ms.append(ar_events[0].elapsed_time(ar_events[1]))
         ar_events = None
         allreduce_ms = sorted(ms)[len(ms) // 2]
-    mode_ms = None
-    if multi and os.environ.get('CAPMI_BENCH_MODES', '1') != '0':
+    def run_mode_sweep():
+        mode_ms = {}
         # One driver run decides between the gradient-exchange modes: after the measurement above (the default mode, the line's
         # `value`) the same step is timed for a few iterations in every other mode and WITHOUT any exchange -- the difference to
         # the latter is the communication a mode leaves exposed.  (The replicas drift apart in the exchange-free pass: it comes last.)
-        mode_ms = {}
         default_name = 'overlap' if overlap else ('rsag' if sharded else 'allreduce')
 
         def timed(name, k=6, w=2):
+            WATCH['mode'] = name
             mode_now.update(overlap=(name == 'overlap'), sharded=(name == 'rsag'), none=(name == 'none'))
             if name == 'overlap':
                 flat.begin_overlap()
@@ -415,6 +422,9 @@ def main():
                 except Exception as e:          # a mode that cannot run here must not cost the line
                     mode_ms[name] = 'failed: %s' % type(e).__name__
         mode_now.update(overlap=overlap, sharded=sharded, none=False)
+        return mode_ms
+
+    mode_ms = None
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -532,6 +542,19 @@ def main():
                                                            '"none" = no gradient exchange (compute only); exposed = mode - none'},
             'loss': float(loss.detach()), 'roofline': roofline, 'attention': attention, 'kernel_ms_per_step': per_class,
             'early_exit_eos_biased': early, 'cpu_baseline': cpu}
+        WATCH['line'] = line
+    if multi and os.environ.get('CAPMI_BENCH_MODES', '1') != '0':
+        # every exchange mode in the same run, AFTER the measurement and its line are complete: if a mode hangs on a topology that
+        # could not be tested here, the watchdog prints the line without the sweep instead of losing it
+        WATCH['phase'] = 'mode sweep'
+        mode_ms = run_mode_sweep()
+        WATCH['phase'] = 'done'
+        if rank == 0:
+            c = line['collective']
+            c['ms_per_step_by_mode'] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in mode_ms.items()}
+            if isinstance(mode_ms.get('none'), float):
+                c['exposed_comm_ms'] = {k: round(v - mode_ms['none'], 3) for k, v in mode_ms.items() if isinstance(v, float) and k != 'none'}
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
