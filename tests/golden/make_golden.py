@@ -778,8 +778,123 @@ def main_full2():
     print('big_xe_grads.npz:', len(out), 'arrays')
 
 
+def main_full3():
+    """BASELINE configs[1] at its OWN batch (VERDICT r3 missing #1(i)): the REAL reference UpDown model
+    (captioning.models.setup('updown'), AttModel.py:126-164) teacher-forced at bs64 x 5 captions, T=21, R=E=1000, V1=9488 --
+    N = 320 rows, i.e. the fat-GEMM decode path on the HIP side, not the 64-row weight-streaming one the bs10 fixtures take.
+    Stored like full2: loss, target log-probs, three full distributions, per-parameter gradient norms + 256-element probes.
+    Two cases: ``u_*`` without masks, ``um_*`` with att_masks (ragged region counts, dataloader.py:221-229)."""
+    sys.path.insert(0, REF)
+    root = os.path.dirname(os.path.dirname(HERE))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    import time
+    import shapes
+    import captioning.models as models          # the reference
+    from captioning.modules import losses
+    from imagecaptioning.pytorch_amd import synthetic
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    out = {}
+    for tag, seed, masked in (('u', 21, False), ('um', 22, True)):
+        t0 = time.time()
+        opt = synthetic.updown_opt(drop_prob_lm=0.0)
+        model = models.setup(opt)
+        model.load_state_dict(shapes.full_size_params(seed=seed))
+        model.train()
+        B = 64
+        fc, att = shapes.feats(B, seed=seed)
+        am = shapes.ragged_masks(B, seed=seed) if masked else None
+        labels, masks = shapes.c2_labels(B=B, seed=seed)
+        logp = model(fc, att, labels[..., :-1], am)
+        loss = losses.LanguageModelCriterion()(logp, labels[..., 1:], masks[..., 1:])
+        loss.backward()
+        tgt = labels[..., 1:].reshape(-1, labels.shape[-1] - 1)
+        out[tag + '_loss'] = loss.detach().numpy()
+        out[tag + '_tgt_logp'] = logp.detach().gather(2, tgt[:, :logp.shape[1]].unsqueeze(2)).squeeze(2).numpy()
+        out[tag + '_logp_row0'] = logp.detach()[0, :3].numpy()
+        for k, p in model.named_parameters():
+            out['%s_gnorm.%s' % (tag, k)] = np.array(float(p.grad.double().norm()))
+            out['%s_gprobe.%s' % (tag, k)] = shapes.grad_probe(p.grad).numpy().copy()
+        print('%s (reference updown, N=%d, T=21, masks=%s): %.0f s, loss %.6f' % (tag, B * 5, masked, time.time() - t0, float(loss)))
+    np.savez_compressed(os.path.join(HERE, 'updown_xe_bs64.npz'), **out)
+    print('updown_xe_bs64.npz:', len(out), 'arrays')
+
+
+def main_beam5():
+    """BASELINE configs[4] evaluates with beam_size 5 (MODEL_ZOO.md:3) -- the reference's AttModel._sample_beam
+    (AttModel.py:218-256) / CaptionModel.beam_search (CaptionModel.py:35-209, the sort over [B, b*V1] at :79-84) at CONFIG size:
+    V1 = 9488 (47 440 candidates per image and step), L = 20, B = 3 images, +- att_masks, for AoA (configs/aoa.yml sizes) and
+    UpDown (configs/updown sizes).  Weights from tests/shapes.py:beam5_state (seeded on both sides): the logit layer sharpened
+    to a trained model's entropy and the EOS bias raised, so that candidates are not 1e-5 apart and some beams END early
+    (cases b5 / b5m / b5n) while 'b5long' never sees EOS and finishes every beam at L.  Stored: seq, the selected log-probs (the dense [B, L, V1] seqLogprobs would be
+    2 MB per case: its gather at seq plus two full rows are kept), every done beam's seq / p / unaug_p, and the smallest
+    gap between the b-th and (b+1)-th candidate the reference saw (how far the fixture is from a tie)."""
+    sys.path.insert(0, REF)
+    root = os.path.dirname(os.path.dirname(HERE))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    import shapes
+    import captioning.models as models
+    from imagecaptioning.pytorch_amd import synthetic
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    # record the reference's own top-b margins: wrap torch.sort as seen from beam_step (CaptionModel.py:79)
+    margins = []
+    real_sort = torch.sort
+
+    def spy_sort(x, *a, **k):
+        ys, ix = real_sort(x, *a, **k)
+        if x.dim() == 2 and x.shape[1] > 1000 and len(a) >= 2 and a[1] is True:
+            margins.append((x.shape[1], ys))
+        return ys, ix
+    out = {}
+    B, bs = 3, 5
+    for name in ('aoa', 'updown'):
+        seed = int(os.environ.get('CAPMI_BEAM5_SEED_' + name.upper(), shapes.BEAM5_SEED[name]))
+        opt = shapes.big_opt('aoa') if name == 'aoa' else synthetic.updown_opt(drop_prob_lm=0.0)
+        model = models.setup(opt)
+        fc, att = shapes.feats(B, seed=seed)
+        am = shapes.ragged_masks(B, seed=seed)
+        with torch.no_grad():
+            for tag, masks, kw, eos in (('b5', None, {}, 'end'), ('b5m', am, {}, 'end'), ('b5n', None, {'sample_n': 5}, 'end'),
+                                        ('b5long', am, {}, 'long')):
+                model.load_state_dict(shapes.beam5_state(name, {k: v.shape for k, v in model.state_dict().items()}, seed, eos))
+                model.eval()
+                o = {'sample_method': 'beam_search', 'beam_size': bs, 'sample_n': 1}
+                o.update(kw)
+                del margins[:]
+                torch.sort = spy_sort
+                try:
+                    seq, slp = model(fc, att, masks, opt=o, mode='sample')
+                finally:
+                    torch.sort = real_sort
+                t = name + '_' + tag
+                out[t + '_seq'] = seq.numpy()
+                out[t + '_sel_logp'] = slp.gather(2, seq.unsqueeze(2)).squeeze(2).numpy()
+                out[t + '_logp_rows'] = slp[0, :2].numpy()
+                for k, beams in enumerate(model.done_beams):
+                    out['%s_n%d' % (t, k)] = np.array(len(beams))
+                    for j, bm in enumerate(beams):
+                        out['%s_%d_%d_seq' % (t, k, j)] = bm['seq'].numpy()
+                        out['%s_%d_%d_p' % (t, k, j)] = np.array(bm['p'])
+                        out['%s_%d_%d_unaug' % (t, k, j)] = np.array(bm['unaug_p'])
+                # candidates of beams that already ended sit at sum - 1000 (CaptionModel.py:176), where an fp32 ulp is 6e-5: they
+                # tie among themselves but never reach done_beams' top b once b real beams are there; measure the live ones
+                gap = min(float(torch.where(ys[:, bs - 1] > -500, ys[:, bs - 1] - ys[:, bs], torch.tensor(1e9)).min())
+                          for w, ys in margins if w > bs)
+                out[t + '_min_gap'] = np.array(gap)
+                assert gap >= 1e-4 or os.environ.get('CAPMI_BEAM5_ANY_GAP'), 'near-tie in the fixture: pick the next seed (shapes.BEAM5_SEED)'
+                lens = [[int((bm['seq'] > 0).sum()) for bm in beams] for beams in model.done_beams]
+                print('%s: %d sorts, smallest top-%d gap %.3g, lengths of the done beams %s' % (t, len(margins), bs, gap, lens))
+    np.savez_compressed(os.path.join(HERE, 'beam5_config_size.npz'), **out)
+    print('beam5_config_size.npz:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'full2':
+    if len(sys.argv) > 1 and sys.argv[1] == 'full3':
+        main_full3()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'beam5':
+        main_beam5()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'full2':
         main_full2()
     elif len(sys.argv) > 1 and sys.argv[1] == 'struct':
         main_struct()

