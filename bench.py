@@ -99,7 +99,7 @@ def pmc_traffic(instance=False):
     separate rocprofv3 --pmc runs, so they cannot be sampled inside this process): profiles/r0N_pmc_traffic.json,
     written by scripts/tools_pmc_traffic.py with the gfx950 corrections of MI355X_MICROARCH.md.  None if absent."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ('r03_pmc_traffic.json',):
+    for name in (PMC_FILE,):
         try:
             with open(os.path.join(here, 'profiles', name)) as f:
                 d = json.load(f)
@@ -111,7 +111,7 @@ def pmc_traffic(instance=False):
         except (OSError, KeyError, ValueError):
             continue
     return None
-F32_MFMA_PEAK_TF = 157.3
+PMC_FILE = 'r03_pmc_traffic.json'
 
 
 def prof_read(lib, cls):
@@ -172,6 +172,55 @@ class _Rotating:
         return d
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: re-run this command under `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>` (the driver's documented form)
+    and hand its output through -- rank 0 still prints the ONE JSON line.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('OMP_NUM_THREADS', '8')      # (torchrun would set 1 and warn)
+    print('bench.py: launching %d ranks: %s' % (n, ' '.join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+OTHER_CONFIGS = ('updown_xe', 'transformer_xe', 'aoa_nsc', 'newfc_xe')
+
+
+def other_configs(budget_s=150.0):
+    """The four BASELINE configurations the headline is NOT quoted on, each as a short pass of this same script in a child process
+    (`--config X --brief`: 8 init + 3 warm-up + 8 timed steps, its own CPU baseline on a smaller sample), AFTER the headline
+    measurement is complete; a child that fails or exceeds its budget becomes {'error': ...} and never costs the headline."""
+    import subprocess
+    out = {}
+    for name in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--config', name, '--steps', '8', '--warmup', '3', '--brief']
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=budget_s, text=True)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            if r.returncode != 0 or not lines:
+                out[name] = {'error': 'rc %d: %s' % (r.returncode, (r.stderr or '').strip().splitlines()[-1:] or '')}
+                continue
+            d = json.loads(lines[-1])
+            rf, cb = d.get('roofline') or {}, d.get('cpu_baseline') or {}
+            out[name] = {'metric': d['metric'], 'baseline_config': d['config']['baseline_config'], 'ms_per_step': d['ms_per_step'],
+                         'captions_per_s': d['value'], 'steps': d['steps'], 'warmup': d['warmup'], 'dtype': d['dtype'],
+                         'roofline': {k: rf.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us')},
+                         'cpu_baseline': {k: cb.get(k) for k in ('value', 'unit', 'cores', 'kind', 'sample')} if cb else None,
+                         'wall_s': round(time.perf_counter() - t0, 1)}
+        except subprocess.TimeoutExpired:
+            out[name] = {'error': 'exceeded its %.0f s budget' % budget_s}
+        except Exception as e:                      # noqa: BLE001 -- nothing here may cost the headline line
+            out[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -185,17 +234,24 @@ def main():
     ap.add_argument('--cpu-iters', type=int, default=5)
     ap.add_argument('--config', default='updown_scst', choices=sorted(CONFIGS),
                     help='BASELINE.json configuration (default: configs[2], the one the headline metric is quoted on)')
+    ap.add_argument('--brief', action='store_true',
+                    help='the headline objects only: no large-batch attention pass, no copy measurement, no early-exit line, no other '
+                         'configurations, a 1-iteration CPU sample (how the default run times the other BASELINE configurations)')
+    ap.add_argument('--no-other-configs', action='store_true', help='do not append the other BASELINE configurations to the line')
     ap.add_argument('--eos-bias', type=float, default=0.0,
                     help='add this to logit.bias[EOS]: a model that ends its captions (random weights never do), for the early-exit line')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (one rank per GPU, as tools/train_pl.py:470-480 asks of Lightning)
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus %d needs torch.distributed.run with %d processes' % (args.gpus, args.gpus))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or run plain `python bench.py --gpus %d`)'
+                         % (args.gpus, world, args.gpus, args.gpus))
     if os.environ.get('CAPMI_DIST_BACKEND') == 'gloo':
         local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
@@ -433,7 +489,7 @@ def main():
     value = captions / dt
 
     if rank == 0:
-        copy_gbs = 0.0 if args.no_prof else measured_copy_gbs(dev)     # kept out of rocprofv3 kernel tables
+        copy_gbs = 0.0 if (args.no_prof or args.brief) else measured_copy_gbs(dev)     # kept out of rocprofv3 kernel tables
         # the dominant kernel = ONE instance, gemm_lc_kernel<true,2> (round 3): the decode-step GEMMs that stream >= 16 MB of weights
         # (2 LSTM gate GEMMs + the logit GEMM per step; class 9).  The small decode GEMMs (h2att, prepare: class 0) are latency-
         # bound launches of the same template family and are reported together with it under `all_decode_gemms`.
@@ -470,7 +526,9 @@ def main():
                     'peak': round(mfma_peak, 1) if mfma_bound else HBM_PEAK_GBS,
                     'unit': 'TFLOP/s' if mfma_bound else 'GB/s',
                     'frac': round(tfl / mfma_peak if mfma_bound else ach / HBM_PEAK_GBS, 4),
-                    'traffic': pmc_traffic(instance=True), 'hbm_copy_measured_gbs': round(copy_gbs, 1),
+                    'traffic': pmc_traffic(instance=True),
+                    'traffic_source': 'imported: profiles/%s (separate rocprofv3 --pmc passes of this command, scripts/tools_pmc_traffic.py); not measured in this run' % PMC_FILE,
+                    'hbm_copy_measured_gbs': round(copy_gbs, 1),
                     'hbm_frac_of_measured_copy': round(ach / copy_gbs, 4) if copy_gbs else None, 'avg_launch_us': round(g_ms / max(g_n, 1) * 1e3, 2),
                     'algorithmic_bytes_per_launch': round(g_bytes / max(g_n, 1)),
                     'algorithmic_flops_per_launch': round(g_flops / max(g_n, 1)),
@@ -483,13 +541,13 @@ def main():
                                          'note': 'round-1 definition of this object: the streaming launches above + the '
                                                  '~22 latency-bound small decode GEMMs (h2att, prepare) per step'}}
         a_ach = (a_bytes / a_n) / (a_ms / a_n * 1e-3) / 1e9 if a_n else 0.0
-        attention = {'kernel': 'attention_fwd (fused score+softmax+context, one workgroup per image)', 'bound': 'hbm',
+        attention = {'kernel': 'attention_fwd_v2 (fused score + softmax + context; one caption row per workgroup group, the row\'s context columns split over CS workgroups)', 'bound': 'hbm',
                      'achieved': round(a_ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': round(a_ach / HBM_PEAK_GBS, 4), 'avg_launch_us': round(a_ms / max(a_n, 1) * 1e3, 2),
                      'algorithmic_bytes_per_launch': round(a_bytes / max(a_n, 1)),
                      'note': 'bs10 x n5: 2.4-4.7 MB unique bytes per launch is below the HBM bandwidth-delay product '
                              '(latency-bound); large_batch is the same kernel at an evaluation-sized batch',
-                     'large_batch': None if args.no_prof else attention_large_batch(dev)}
+                     'large_batch': None if (args.no_prof or args.brief) else attention_large_batch(dev)}
         if attention['large_batch'] and copy_gbs:
             attention['large_batch']['frac_of_measured_copy'] = round(attention['large_batch']['achieved_gbs'] / copy_gbs, 4)
         if args.config in ('updown_xe', 'transformer_xe', 'newfc_xe'):
@@ -511,10 +569,10 @@ def main():
             attention = None
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = (cpu_baseline(opt, model, B, n, L, args.cpu_iters) if args.config == 'updown_scst'
-                   else cpu_baseline_other(args.config, opt, model, B, L))
+            cpu = (cpu_baseline(opt, model, B, n, L, 1 if args.brief else args.cpu_iters) if args.config == 'updown_scst'
+                   else cpu_baseline_other(args.config, opt, model, B, L, brief=args.brief))
         early = None
-        if args.config == 'updown_scst' and world == 1 and not args.no_prof and os.environ.get('CAPMI_EARLY_EXIT', '4') != '0':
+        if args.config == 'updown_scst' and world == 1 and not args.no_prof and not args.brief and os.environ.get('CAPMI_EARLY_EXIT', '4') != '0':
             early = early_exit_line(model, flat, lw, pf, gt_indices, opt, B, n)
         names = {'updown_scst': 'captions/sec/node (UpDown SCST, bs10xsample_n5, 36x2048 feats)',
                  'updown_xe': 'captions/sec/node (UpDown XE, bs64 x 5 captions, 36x2048 feats)',
@@ -543,6 +601,10 @@ def main():
             'loss': float(loss.detach()), 'roofline': roofline, 'attention': attention, 'kernel_ms_per_step': per_class,
             'early_exit_eos_biased': early, 'cpu_baseline': cpu}
         WATCH['line'] = line
+        if (args.config == 'updown_scst' and world == 1 and not (args.brief or args.no_prof or args.no_other_configs)
+                and os.environ.get('CAPMI_BENCH_OTHER_CONFIGS', '1') != '0'):
+            # every BASELINE configuration on the driver's line, measured after the headline is complete
+            line['other_configs'] = other_configs()
     if multi and os.environ.get('CAPMI_BENCH_MODES', '1') != '0':
         # every exchange mode in the same run, AFTER the measurement and its line are complete: if a mode hangs on a topology that
         # could not be tested here, the watchdog prints the line without the sweep instead of losing it
@@ -627,7 +689,7 @@ def early_exit_line(model, flat, lw, pf, gt_indices, opt, B, n, steps=20):
             'check_every': int(os.environ.get('CAPMI_EARLY_EXIT', '4'))}
 
 
-def cpu_baseline_other(config, opt, model, B, L):
+def cpu_baseline_other(config, opt, model, B, L, brief=False):
     """CPU baseline of the non-headline configurations: the matching oracle (oracle/att_lstm.py, transformer.py, aoa.py: ports of
     the reference's CPU path) on a BOUNDED sample of the same workload -- teacher-forced forward + criterion + autograd backward +
     value clip + Adam on `Bc` images x 5 captions, scaled to captions/s.  (aoa_nsc: the teacher-forced pass over the 50 sampled rows
@@ -636,7 +698,7 @@ def cpu_baseline_other(config, opt, model, B, L):
     from imagecaptioning.pytorch_amd import synthetic
     cores = min(os.cpu_count() or 1, int(os.environ.get('CAPMI_CPU_THREADS', '16')))
     torch.set_num_threads(cores)
-    Bc = min(B, 8)
+    Bc = min(B, 4 if brief else 8)
     P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     fc, att = synthetic.batch(Bc, seed=1234)
     labels, masks = synthetic.xe_labels(Bc, n=5, L=L)
@@ -664,15 +726,15 @@ def cpu_baseline_other(config, opt, model, B, L):
 
     it()
     ts = []
-    for _ in range(2):
+    for _ in range(1 if brief else 2):
         t0 = time.perf_counter()
         it()
         ts.append(time.perf_counter() - t0)
     sec = sorted(ts)[0]
     return {'value': round(Bc * 5 / sec, 2), 'unit': 'captions/s', 'cores': cores, 'kind': 'port',
-            'sample': '2 timed iterations (best) after 1 warm-up of the %s oracle on %d images x 5 captions (the GPU step runs %d): '
+            'sample': '%d timed iterations (best) after 1 warm-up of the %s oracle on %d images x 5 captions (the GPU step runs %d): '
                       'teacher-forced forward + criterion + autograd backward + clip + Adam%s; torch fp32 on %d threads'
-                      % (config, Bc, B, ' + a no-grad 20-step decode of the 5x repeated images standing in for the sampled rollouts'
+                      % (len(ts), config, Bc, B, ' + a no-grad 20-step decode of the 5x repeated images standing in for the sampled rollouts'
                          if config == 'aoa_nsc' else '', cores), 'sec_per_iteration': round(sec, 3)}
 
 

@@ -67,8 +67,8 @@ def decode_image(att_dir, fc_dir, img_id, use_fc, norm_att_feat):
 
 
 class FeatureLoader:
-    def __init__(self, opt, workers=4, processes=None, lookahead=3):
-        """workers: size of the decode pool; processes: worker PROCESSES instead of threads (default: CAPMI_LOADER_PROCS=1).
+    def __init__(self, opt, workers=4, processes=None, lookahead=3, rank=0, world=1):
+        """rank / world: data-parallel partition of every pass (below).  workers: size of the decode pool; processes: worker PROCESSES instead of threads (default: CAPMI_LOADER_PROCS=1).
         np.load of a compressed .npz holds the GIL for most of its time: threads top out at ~400 images/s of 36 x 2048
         features whatever their number, N processes scale to ~N x 400 (scripts/loader_bench.py)."""
         self.opt = opt
@@ -94,17 +94,25 @@ class FeatureLoader:
                 self.split_ix[sp].append(ix)
             elif getattr(opt, 'train_only', 0) == 0:            # restval
                 self.split_ix['train'].append(ix)
-        self.rng = random.Random(getattr(opt, 'seed', 1234))                  # epoch order
-        self.cap_rng = random.Random(getattr(opt, 'seed', 1234) + 7919)       # which captions of an image (own stream: the
-        #                                                                       order RNG is drawn `lookahead` batches ahead)
+        # Data-parallel ranks PARTITION one shuffled pass (tools/train_pl.py:60-73 + the DistributedSampler Lightning injects:
+        # `seed` is shared, rank r takes elements r, r + world, ... of the permutation, the tail padded from its head so that all
+        # ranks hold equally many and wrap -- i.e. reshuffle -- on the same batch).  The order RNG is therefore seeded alike on
+        # every rank; which captions of an image are drawn is per rank.
+        self.rank, self.world = int(rank), max(1, int(world))
+        assert 0 <= self.rank < self.world
+        self.rng = random.Random(getattr(opt, 'seed', 1234))                  # epoch order (shared by the ranks)
+        self.cap_rng = random.Random(getattr(opt, 'seed', 1234) + 7919 + 104729 * self.rank)   # which captions of an image (own
+        #                                                       stream: the order RNG is drawn `lookahead` batches ahead)
         self.lookahead = max(1, int(lookahead))
-        self.order = {k: list(v) for k, v in self.split_ix.items()}
-        self.rng.shuffle(self.order['train'])                  # MySampler shuffles the train split (dataloader.py:394-397)
+        self.full_order = {k: list(v) for k, v in self.split_ix.items()}       # the whole pass, identical on every rank
+        self.rng.shuffle(self.full_order['train'])             # MySampler shuffles the train split (dataloader.py:394-397)
         #                                                        (its permutation comes from numpy's global RNG: the ORDER of a
         #                                                        pass is not reproducible across the two loaders, its contents are)
+        self.order = {k: self._mine(k) for k in self.full_order}               # this rank's part of the pass
         # what a checkpoint needs to resume INSIDE an epoch (the reference saves its sampler's index_list + iter_counter,
-        # dataloader.py:376-405): a copy of the order taken once per shuffle, handed out with every batch next to the RNG states
-        self._snap = {k: list(v) for k, v in self.order.items()}
+        # dataloader.py:376-405): a copy of the (whole) order taken once per shuffle, handed out with every batch next to the RNG
+        # states
+        self._snap = {k: list(v) for k, v in self.full_order.items()}
         self.pos = {'train': 0, 'val': 0, 'test': 0}
         if processes is None:
             processes = os.environ.get('CAPMI_LOADER_PROCS', '0') == '1'
@@ -114,6 +122,36 @@ class FeatureLoader:
         else:
             self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
         self._pending = {}
+
+    def _mine(self, split):
+        """this rank's elements of the split's current pass: every world-th one; train passes are padded from their head to
+        a multiple of `world` (DistributedSampler's rule), val / test are not (a short last batch is part of their contract)"""
+        full = self.full_order[split]
+        if self.world == 1:
+            return list(full)
+        if split == 'train' and full:
+            pad = (-len(full)) % self.world
+            full = full + full[:pad]
+        return full[self.rank::self.world]
+
+    def _reshuffle(self, split):
+        self.rng.shuffle(self.full_order[split])
+        self.order[split] = self._mine(split)
+        self._snap[split] = list(self.full_order[split])
+
+    def load_state(self, split, order=None, pos=None, rng=None, cap_rng=None):
+        """resume inside an epoch (tools/train.py): the pass's order as a checkpoint stored it (`loader_order`), the position in
+        this rank's part, both RNG states -- everything a later checkpoint of the same epoch hands out again"""
+        if order is not None and len(order) == len(self.full_order.get(split, ())):
+            self.full_order[split] = list(order)
+            self.order[split] = self._mine(split)
+            self._snap[split] = list(order)
+        if pos is not None:
+            self.pos[split] = int(pos)
+        if rng is not None:
+            self.rng.setstate(rng)
+        if cap_rng is not None:
+            self.cap_rng.setstate(cap_rng)
 
     # ---- reference accessors
     def get_vocab(self):
@@ -167,8 +205,8 @@ class FeatureLoader:
         for _ in range(B):
             if self.pos[split] >= len(order):
                 if split == 'train':
-                    self.rng.shuffle(order)
-                    self._snap[split] = list(order)
+                    self._reshuffle(split)
+                    order = self.order[split]
                     wrapped = True
                 elif out:
                     break
@@ -185,8 +223,7 @@ class FeatureLoader:
                 for f in (item[3].values() if isinstance(item[3], dict) else item[3]):
                     f.cancel()
         if split == 'train':
-            self.rng.shuffle(self.order[split])
-            self._snap[split] = list(self.order[split])
+            self._reshuffle(split)
         self.pos[split] = 0
 
     def _schedule(self, split, B):

@@ -10,8 +10,11 @@ from imagecaptioning.pytorch_amd import synthetic
 
 
 class SyntheticLoader:
-    def __init__(self, opt):
+    def __init__(self, opt, rank=0, world=1):
+        """rank / world: the synthetic images are dealt out to the data-parallel ranks (image i belongs to rank i % world), so
+        the ranks of a pass see disjoint images of ONE corpus (same `seed`, hence the same document-frequency table everywhere)"""
         self.opt = opt
+        self.rank, self.world = int(rank), max(1, int(world))
         self.batch_size = opt.batch_size
         self.seq_per_img = opt.seq_per_img
         self.seq_length = opt.seq_length
@@ -38,9 +41,10 @@ class SyntheticLoader:
     def get_batch(self, split, batch_size=None):
         B = batch_size or self.batch_size
         n, L, opt = self.seq_per_img, self.seq_length, self.opt
-        idx = [(self.pos[split] + i) % len(self.refs) for i in range(B)]
-        wrapped = self.pos[split] + B >= len(self.refs)
-        self.pos[split] = (self.pos[split] + B) % len(self.refs)
+        mine = len(range(self.rank, len(self.refs), self.world))       # images of this rank
+        idx = [self.rank + self.world * ((self.pos[split] + i) % mine) for i in range(B)]
+        wrapped = self.pos[split] + B >= mine
+        self.pos[split] = (self.pos[split] + B) % mine
         fc = np.zeros((B, opt.fc_feat_size), dtype=np.float32)
         att = np.zeros((B, opt.synthetic_regions, opt.att_feat_size), dtype=np.float32)
         labels = np.zeros((B, n, L + 2), dtype=np.int64)
@@ -58,4 +62,4 @@ class SyntheticLoader:
             infos.append({'ix': ix, 'id': ix, 'file_path': 'synthetic/%d' % ix})
         return {'fc_feats': torch.from_numpy(fc), 'att_feats': torch.from_numpy(att), 'att_masks': None,
                 'labels': torch.from_numpy(labels), 'masks': torch.from_numpy(masks), 'gts': gts,
-                'bounds': {'it_pos_now': self.pos[split], 'it_max': len(self.refs), 'wrapped': wrapped}, 'infos': infos}
+                'bounds': {'it_pos_now': self.pos[split], 'it_max': mine, 'wrapped': wrapped}, 'infos': infos}

@@ -76,8 +76,9 @@ def eval_split(model, crit, loader, opt):
     num_images = opt.num_images
     while num_images < 0 or n < num_images:
         data = loader.get_batch(split)
-        if num_images < 0:
-            num_images = data['bounds']['it_max']                                                              # :201-205: the whole split
+        # eval_utils.py:200-207: ix1 = min(it_max, num_images) -- never more than the split holds (a larger request would make the
+        # non-wrapping loader start the split over and every image would be predicted twice)
+        num_images = data['bounds']['it_max'] if num_images < 0 else min(num_images, data['bounds']['it_max'])
         fc, att, labels, masks = (data[k].to(dev) for k in ('fc_feats', 'att_feats', 'labels', 'masks'))
         kw = eval_kwargs_of(opt)
         kw['sample_n'] = 1                                                                                     # :169-170

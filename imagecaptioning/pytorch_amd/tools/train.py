@@ -63,15 +63,16 @@ def train(opt):
     if opt.grad_clip_mode not in ('value',) and opt.grad_clip_value > 0:
         raise NotImplementedError("grad_clip_mode %r: only clip_grad_value_ (train.py:194-195, the default) is fused into the "
                                   "Adam kernel" % opt.grad_clip_mode)
-    opt.seed = opt.seed + rank                        # each rank draws its own images
+    # Every rank draws its own images -- as a PARTITION of one shuffled pass: the loaders share `seed` and take
+    # every world-th element of the permutation (tools/train_pl.py:60-73 + Lightning's DistributedSampler; per-GPU batch :459-460)
     if opt.input_json:                                # precomputed bottom-up features + labels (variable region counts)
         from captioning.data.feature_loader import FeatureLoader
-        loader = FeatureLoader(opt)
+        loader = FeatureLoader(opt, rank=rank, world=world)
         opt.vocab_size, opt.seq_length = loader.vocab_size, loader.seq_length
         if not getattr(opt, 'max_length', None) or opt.max_length > opt.seq_length:
             opt.max_length = opt.seq_length
     else:
-        loader = SyntheticLoader(opt)
+        loader = SyntheticLoader(opt, rank=rank, world=world)
     opt.vocab = loader.get_vocab()
     if opt.input_json and getattr(opt, 'resident_features', 1):
         # the whole feature set lives in HBM after its first epoch (36 GB for COCO at 36 regions; budget: half the device memory)
@@ -80,6 +81,7 @@ def train(opt):
     loader = DevicePrefetcher(loader, dev)             # batches arrive already resident in HBM (pinned, side stream)
     torch.manual_seed(1234)                           # identical weights on every rank
     model = models.setup(opt).to(dev)
+    torch.manual_seed(opt.seed + 7919 * rank)         # ... and its own dropout masks / sampling noise (Philox seed = f(initial_seed))
     infos = {}
     if opt.start_from:
         model.load_state_dict(torch.load(os.path.join(opt.start_from, 'model.pth'), map_location=dev))
@@ -109,18 +111,15 @@ def train(opt):
                 print('optimizer.pth does not match this model (not a torch Adam state of its parameters): optimizer starts fresh')
         base = getattr(loader, 'loader', loader)                                 # under the prefetcher (nothing is prefetched yet)
         base = getattr(base, 'loader', base)                                     # ... and the resident feature store
-        for split, pos in infos.get('loader_pos', {}).items():
-            base.pos[split] = pos
         # the reference saves its sampler's index_list / iter_counter (dataloader.py:376-405): the shuffled order of the epoch
         # and both RNG streams, or a resumed epoch would revisit some images and skip others
-        if hasattr(base, 'order'):
-            for split, order in infos.get('loader_order', {}).items():
-                if len(order) == len(base.order.get(split, ())):
-                    base.order[split] = list(order)
-            if infos.get('loader_rng') is not None:
-                base.rng.setstate(infos['loader_rng'])
-            if infos.get('loader_cap_rng') is not None:
-                base.cap_rng.setstate(infos['loader_cap_rng'])
+        if hasattr(base, 'load_state'):
+            for split, pos in infos.get('loader_pos', {}).items():
+                base.load_state(split, order=infos.get('loader_order', {}).get(split), pos=pos)
+            base.load_state('train', rng=infos.get('loader_rng'), cap_rng=infos.get('loader_cap_rng'))
+        else:
+            for split, pos in infos.get('loader_pos', {}).items():
+                base.pos[split] = pos
         model._rng_calls = int(infos.get('rng_calls', 0))                        # dropout / sampling Philox stream position
     sc_ready = False
     epoch_done = True

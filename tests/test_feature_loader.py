@@ -330,3 +330,36 @@ def test_reference_val_batches_through_the_device_wrappers_gpu(resident):
     ld.get_batch('val')
     ld.reset_iterator('val')
     _same_batch(z, 'b2.val_after_reset.', host(ld.get_batch('val')))
+
+
+@pytest.mark.parametrize('world', [1, 2])
+def test_resume_twice_inside_an_epoch_keeps_the_epochs_sequence(world):
+    """a checkpoint written AFTER a resume and before the next epoch wrap must carry the same permutation as
+    the first one -- tools/train.py restores the loader through FeatureLoader.load_state (order, position, both RNG states, and
+    the snapshot later checkpoints hand out).  save -> resume -> save -> resume: the index sequence equals the uninterrupted run's,
+    also across the following reshuffle, for one rank and for a rank of a 2-way partition."""
+    def mk():
+        ld = _ref_loader(2)
+        return type(ld)(ld.opt, workers=1, processes=False, lookahead=2, rank=world - 1, world=world)
+
+    def take(ld, k):
+        out, states = [], []
+        for _ in range(k):
+            d = ld.get_batch('train')
+            out.append([i['ix'] for i in d['infos']])
+            states.append((d['bounds']['it_pos_now'], d['bounds']['loader_state']))
+        return out, states
+
+    want, _ = take(mk(), 12)                       # 12 batches of 2: several passes of the small train split
+
+    def resume(state):
+        pos, st = state
+        ld = mk()
+        ld.load_state('train', order=st['loader_order']['train'], pos=pos, rng=st['loader_rng'], cap_rng=st['loader_cap_rng'])
+        return ld
+    a, sa = take(mk(), 3)
+    ld = resume(sa[-1])                            # first resume (the "checkpoint" = the last CONSUMED batch's state)
+    b, sb = take(ld, 1)                            # one more batch inside the same epoch ...
+    ld = resume(sb[-1])                            # ... checkpoint again, resume again
+    c, _ = take(ld, 8)
+    assert a + b + c == want
