@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ('M', C.c_int), ('N', C.c_int), ('C', c_f), ('ldc', C.c_int), ('bias', c_f), ('bias2', c_f),
                 ('row_bias', c_f), ('row_bias_div', C.c_int), ('mul_mask', c_f), ('relu', C.c_int),
                 ('accumulate', C.c_int), ('partial', c_f), ('partial_capacity', C.c_int64), ('splits', C.c_int),
-                ('defer_reduce', C.c_int), ('splits_used', C.c_int), ('a_planes', c_f * MAX_SEG), ('zero_planes', c_f), ('b_planes', c_f * MAX_SEG)]
+                ('defer_reduce', C.c_int), ('splits_used', C.c_int), ('a_planes', c_f * MAX_SEG)]
 
 
 class UpDownWeights(C.Structure):
@@ -48,7 +48,7 @@ class UpDownRollout(C.Structure):
                                     'fc_gates', 'logits', 'it', 'unfinished', 'partial')] +
                 [('partial_capacity', C.c_int64), ('top_k', C.c_int), ('top_p', C.c_float), ('ss_mode', c_f),
                  ('planes', c_f), ('planes_bytes', C.c_int64), ('early_exit', C.c_int), ('early_exit_from', C.c_int),
-                 ('alive_host', c_f), ('steps_run', C.c_int), ('pre_partial', c_f), ('pre_capacity', C.c_int64)])
+                 ('alive_host', c_f), ('steps_run', C.c_int)])
 
 
 class SampleFilter(C.Structure):
@@ -128,8 +128,6 @@ SIGNATURES = {
     'capmi_gemm_f32': [C.POINTER(GemmDesc), _P],
     'capmi_planes_bytes': [_I],
     'capmi_planes_from_f32': [_P, _I, _I, _I, _P, _P],
-    'capmi_planes_fat_bytes': [_I, _I],
-    'capmi_planes_split': [_P, _I, _I, _I, _I, _P, _P],
     'capmi_updown_planes_bytes': [_I, _I],
     'capmi_updown_bwd_planes_bytes': [_I],
     'capmi_attention_fwd': [_P] * 8 + [_I] * 5 + [_P, _I, _P],
@@ -224,7 +222,7 @@ def _load():
             raise ImportError('libcapmi.so does not export %s (stale build?)' % name) from e
         fn.argtypes = argtypes
         fn.restype = (C.c_char_p if name == 'capmi_arch' else
-                      C.c_int64 if name in ('capmi_planes_bytes', 'capmi_planes_fat_bytes', 'capmi_updown_planes_bytes',
+                      C.c_int64 if name in ('capmi_planes_bytes', 'capmi_updown_planes_bytes',
                                                    'capmi_updown_bwd_planes_bytes')
                       else C.c_int)
     return lib

@@ -142,8 +142,8 @@ class AoAGraph:
             nbR, nbE = int(lib.capmi_planes_bytes(R)), int(lib.capmi_planes_bytes(E))
             # (keyed by the exact K: columns >= K of a buffer are never written and must stay zero -- a buffer of another width with
             #  the same number of chunks would leave stale values there)
-            pl_xt = ops.planes_scratch(dev, ('aoa_xt', E, stream_ptr()), nbE)
-            pl_ctx, pl_h, pl_od = (ops.planes_scratch(dev, ('aoa_' + k, R, stream_ptr()), nbR) for k in ('ctx', 'h', 'od'))
+            pl_xt = ops.planes_scratch(dev, ('aoa_xt', E), nbE)
+            pl_ctx, pl_h, pl_od = (ops.planes_scratch(dev, ('aoa_' + k, R), nbR) for k in ('ctx', 'h', 'od'))
             pl_zero = ops.zero_planes(dev, max(nbR, nbE) // 12288)
             self.ctx_in[0].zero_()                               # out_0 = 0 (AoAModel.py:127-129)
         for t in range(T):

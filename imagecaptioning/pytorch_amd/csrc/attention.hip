@@ -885,7 +885,7 @@ static int attention_fwd_launch(const float *att_h, int h_splits, int64_t h_stri
     const int rpb = row_img ? 1 : pick_rpb(B, n), chunks = row_img ? 1 : (n + rpb - 1) / rpb;
     hipEvent_t e0, e1;
     // round-2 kernel: all loads up front, one memory round trip (BASELINE shapes: K = 36, A = 512, R = 1000)
-    static const int env_v2 = [] { const char *e = getenv("CAPMI_ATT_V2"); return e ? atoi(e) : 1; }();
+    static const int env_v2 = capmi::research("CAPMI_ATT_V2", 1);
     const bool al16 = ((reinterpret_cast<uintptr_t>(att_h) | reinterpret_cast<uintptr_t>(p_att) | reinterpret_cast<uintptr_t>(att) |
                         reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(h_bias) |
                         reinterpret_cast<uintptr_t>(att_h_out)) & 15) == 0;
@@ -898,7 +898,7 @@ static int attention_fwd_launch(const float *att_h, int h_splits, int64_t h_stri
         const int gx = row_img ? N : grid_blocks(B, chunks);
         // default 4 (when every workgroup still gets its own CU): 10.3 -> 9.3 us per launch at the SCST shape; CAPMI_ATT_CS=1: one
         // workgroup per row as in round 2
-        static const int env_cs = [] { const char *e = getenv("CAPMI_ATT_CS"); return e ? atoi(e) : 4; }();
+        static const int env_cs = capmi::research("CAPMI_ATT_CS", 4);
         const int cs = (env_cs == 2 || env_cs == 4) && gx * env_cs <= 256 ? env_cs : 1;     // every workgroup on its own CU
         const dim3 grid(gx, cs);
 #define CAPMI_ATT_V2(NR_, CS_)                                                                                              \
@@ -964,7 +964,7 @@ static int attention_bwd_launch(const float *d_ctx, int ld_dctx, const float *x_
     const size_t lds = ((size_t)NMAX * ((R + 3) & ~3) + (size_t)NMAX * K) * sizeof(float);
     if (lds > 64 * 1024) return CAPMI_EINVAL;
     const int rpb = row_img ? 1 : pick_rpb(B, n), chunks = row_img ? 1 : (n + rpb - 1) / rpb;
-    static const int env_v2 = [] { const char *e = getenv("CAPMI_ATT_BWD_V2"); return e ? atoi(e) : 1; }();
+    static const int env_v2 = capmi::research("CAPMI_ATT_BWD_V2", 1);
     if (env_v2 && rpb == 1 && K <= BW2_KMAX && A <= ATT_THREADS && R % 4 == 0 && R <= 1024 &&
         (reinterpret_cast<uintptr_t>(att) & 15) == 0 && (!x_slabs || (x_cols - R) % 4 == 0)) {
         int roles = 1;

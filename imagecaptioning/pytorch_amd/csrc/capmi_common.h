@@ -101,9 +101,23 @@ struct Philox {
 // uniform in (0,1): never 0 so log() is finite
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
-// Profiling ablations (CAPMI_*_ABLATE) drop parts of a kernel's work to time the rest: results are WRONG by design.  They are
-// read once per process through this helper, which says so loudly on stderr, so a stray variable cannot silently corrupt a
-// training run.
+// Environment switches of the library, all read once per process through these three helpers:
+//  * knob():     the documented product switches: CAPMI_GEMM_X3, CAPMI_ARES_X3, CAPMI_LC, CAPMI_GEMM_LOG.
+//  * research(): tuning constants of experiments (grid sizes, kernel flavours).  The product build compiles them to their
+//                measured-best defaults; only a -DCAPMI_VARIANTS build (scripts/build_variants.sh) reads the environment,
+//                and says so on stderr for every variable it finds set.
+//  * ablate_env(): profiling ablations (CAPMI_*_ABLATE) drop parts of a kernel's work to time the rest: results are WRONG
+//                by design; -DCAPMI_VARIANTS builds only, loud on stderr.
+static inline int knob(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#ifdef CAPMI_VARIANTS
+static inline int research(const char *name, int dflt) {
+    const char *e = getenv(name);
+    if (e) fprintf(stderr, "*** capmi (variants build): research switch %s=%s ***\n", name, e);
+    return e ? atoi(e) : dflt;
+}
 static inline int ablate_env(const char *name) {
     const char *e = getenv(name);
     int v = e ? atoi(e) : 0;
@@ -112,6 +126,10 @@ static inline int ablate_env(const char *name) {
                         "unset it for any real run ***\n\n", name, v);
     return v;
 }
+#else
+static inline constexpr int research(const char *, int dflt) { return dflt; }
+static inline constexpr int ablate_env(const char *) { return 0; }
+#endif
 }  // namespace capmi
 
 // ---- "A planes": an activation matrix X[M <= 64, K] pre-split for the decode GEMMs (gemm_ares.hip, round 3) -------------

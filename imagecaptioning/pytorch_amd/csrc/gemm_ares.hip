@@ -448,294 +448,6 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
 }
 
 
-// =============================================================================================================
-// Round 3: the same GEMM with the activations delivered as A PLANES (capmi_common.h) and staged by LDS-DMA.
-//
-// Phase trace of the kernel above at the gate-GEMM shape (48 MB, 33k cycles): 2.1k tile table, activation slice landed at
-// 8.7-12.4k (global -> VGPR), split + ds_write + barrier until 14.9k, and only THEN the MFMA loop -- with one weight chunk
-// per wave requested so far.  The weight stream itself runs at the chip's rate once it runs; the kernel's problem is that
-// 45 % of its life is a prologue in which nothing streams.  Here
-//  * the producer of an activation already wrote its three bf16 planes in the exact LDS image this kernel wants
-//    (XOR-swizzled 64-byte rows, conflict-free ds_read_b128 fragments), so staging the K slice is 18 global_load_lds_dwordx4
-//    per wave: no VGPR round trip, no split VALU, no ds_write, nothing for the waves to wait on;
-//  * the whole weight slice of a wave (TS <= 6 chunks, 96 VGPRs) is requested right behind the DMAs, before anything is
-//    waited for: the HBM / Infinity-Cache stream starts ~1k cycles into the kernel instead of ~13k;
-//  * one manual s_waitcnt vmcnt(weight loads) + s_barrier publishes the DMA'd slice (hipcc does not order a ds_read behind a
-//    pending LDS-DMA, and __syncthreads() would drain the weight ring with a vmcnt(0));
-//  * no tile table in LDS: a chunk's segment / pointer is resolved on the scalar unit from SGPR-pinned segment fields.
-// Everything after the barrier (weight split one chunk ahead, 6-term bf16x3 MFMA, K halves meeting in LDS, slab stores) is
-// the kernel above.
-// =============================================================================================================
-typedef const void __attribute__((address_space(1))) *gvoid;
-typedef void __attribute__((address_space(3))) *lvoid;
-
-template <bool BKC, bool NTW>
-__device__ __forceinline__ void load_bw(float (&b)[16], const float *B, int ldb, int brem, int colc, int half) {
-    if (BKC) {
-        gcf p = as_global(B) + (size_t)colc * ldb;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int kk = min(16 * half + 4 * q, brem - 4);
-            const f32x4 v = NTW ? __builtin_nontemporal_load((gcf4)(p + kk)) : *(gcf4)(p + kk);
-            b[4 * q] = v[0]; b[4 * q + 1] = v[1]; b[4 * q + 2] = v[2]; b[4 * q + 3] = v[3];
-        }
-    } else {
-        gcf p = as_global(B) + colc;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            gcf q = p + (size_t)min(16 * half + j, brem - 1) * ldb;
-            b[j] = NTW ? __builtin_nontemporal_load(q) : *q;
-        }
-    }
-}
-
-// ABL / PFM (profiling builds of the <true,6,2> instance only, CAPMI_APL_ABLATE / CAPMI_APL_PF; never for results):
-// ABL 1 = no activation DMAs, 2 = no split / MFMA, 4 = no weight loads, 8 = no K-half reduction / stores, 16 = s_memtime phase
-// stamps of waves 0 and 4 into the ticket words of the workspace; PFM = weight ring depth (0: default).
-#define CAPMI_APL_STAMP(slot)                                                                                              \
-    do {                                                                                                                   \
-        if ((ABL & 16) && lane == 0 && (widu & 3) == 0) {                                                                  \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-            reinterpret_cast<unsigned long long *>(a.counters)[((blockIdx.y * gridDim.x + blockIdx.x) * 2 + (widu >> 2)) * 10 + (slot)] = \
-                __builtin_readcyclecounter();                                                                              \
-            __builtin_amdgcn_sched_barrier(0);                                                                             \
-        }                                                                                                                  \
-    } while (0)
-template <bool BKC, int TS, int TM, bool NTW, int ABL = 0, int PFM = 0>
-__global__ __launch_bounds__(AR_NT) void gemm_apl_kernel(const KArgs a) {
-    constexpr int SL = 2 * TS;                       // K chunks per workgroup slice
-    constexpr int CHB = CAPMI_PL_CHUNK_BYTES;        // LDS image of one chunk = its global image
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-    int bx = blockIdx.x, z = blockIdx.y;
-    if (a.ablate & 1) {                              // XCD-aware map (see the kernel above): one K slice per XCD's L2
-        const int L = blockIdx.y * gridDim.x + blockIdx.x, total = gridDim.x * gridDim.y;
-        const int q = total >> 3, r = total & 7, xcd = L & 7;
-        const int p = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-        z = p / (int)gridDim.x;
-        bx = p - z * (int)gridDim.x;
-    }
-    const int n0 = bx * AR_BN;
-    const int t0 = z * SL;
-    const int lane = threadIdx.x & 63;
-    const int widu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int cg = widu & 3, kh = widu >> 2;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int col = n0 + 32 * cg + l31;
-    const int colc = min(col, a.N - 1);
-    CAPMI_APL_STAMP(0);
-
-    // Segment fields as wave-uniform scalars pinned in SGPRs, selected per chunk by compare/select chains on the scalar unit.
-    // (Plain locals used in the kernel body: routed through a lambda's by-reference capture, hipcc turns the select of two
-    //  loads into a load through a selected POINTER -- dependent s_loads from the kernel-argument segment, or scratch.)
-    static_assert(CAPMI_MAX_SEG == 4, "segment selects are written out for 4 segments");
-#define CAPMI_PIN(i)                                                                                                       \
-    const unsigned char *sgP##i = a.seg[i].Apl; const float *sgB##i = a.seg[i].B;                                          \
-    int sgL##i = a.seg[i].ldb, sgK##i = a.seg[i].K, sgT##i = a.seg[i].tstart;                                              \
-    asm volatile("" : "+s"(sgP##i), "+s"(sgB##i), "+s"(sgL##i), "+s"(sgK##i), "+s"(sgT##i));
-    CAPMI_PIN(0) CAPMI_PIN(1) CAPMI_PIN(2) CAPMI_PIN(3)
-#undef CAPMI_PIN
-    const int tiles_total = a.tiles_total;
-    const unsigned char *zero_planes = a.zero_planes;
-    // tstart is increasing over the used segments and INT_MAX for unused slots
-#define CAPMI_SEL(F, tl) ((tl) >= sgT3 ? F##3 : (tl) >= sgT2 ? F##2 : (tl) >= sgT1 ? F##1 : F##0)
-
-    // ---- stage the activation slice.  Unit = one plane of one chunk (rows < 32 TM: 2 TM KB, contiguous in the global image and
-    //      in LDS), dealt round-robin to the 8 waves; its 2 TM LDS-DMAs share base address and M0 and differ by the
-    //      instruction offset, which applies to both sides. ------------------------------------------------------------------
-    constexpr int NU = SL * 3;
-    constexpr int NUW = (ABL & 1) ? 0 : (NU + 7) / 8;
-#pragma unroll
-    for (int i = 0; i < NUW; ++i) {
-        // branch-free (a conditional DMA makes hipcc's waitcnt pass lose count and drain the weight ring with vmcnt(0)): surplus
-        // slots re-copy the last unit -- same bytes to the same LDS address
-        const int unit = min(widu + 8 * i, NU - 1);
-        {
-            const int ch = unit / 3, pl = unit - 3 * ch;
-            const int tile = t0 + ch;
-            const bool real = tile < tiles_total;
-            const int tl = real ? tile : 0;
-            const unsigned char *img = CAPMI_SEL(sgP, tl) + (size_t)(tl - CAPMI_SEL(sgT, tl)) * CHB;
-            img = real ? img : zero_planes;          // padding slots past the last K tile: the all-zero image
-            uintptr_t srcv = (uintptr_t)(img + pl * CAPMI_PL_PLANE_BYTES + lane * 16);
-            gvoid src = (gvoid)srcv;
-            lvoid dst = (lvoid)(ldsb + ch * CHB + pl * CAPMI_PL_PLANE_BYTES);
-            __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
-            if (TM == 2) {
-                __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
-                __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
-            }
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- request the weights: the whole ring before anything is waited for -----------------------------------------------
-    constexpr int LPC = BKC ? 4 : 16;                // loads per chunk per lane
-    // ring slots: 2 for [N][K] weights -- deeper rings are SLOWER (measured 16.0 / 16.9 / 17.9 / 19.2 us at 2 / 3 / 4 / 6 on the gate
-    // GEMM): a wave that issues loads into a full memory queue stalls AT ISSUE and cannot run its MFMAs meanwhile
-    constexpr int PFD = PFM > 0 ? PFM : (BKC ? 2 : 3);
-    constexpr int PF = TS < PFD ? TS : PFD;
-    float b[PF][16];
-    CAPMI_APL_STAMP(1);
-    if (ABL & 32) __builtin_amdgcn_s_barrier();      // every wave's DMAs are queued before any weight load is
-    // weight chunk u of this wave (padding slots: chunk 0 of segment 0, it meets zero activations)
-#define CAPMI_LOAD_W(bb, u)                                                                                                \
-    do {                                                                                                                   \
-        const int tile_ = t0 + kh * TS + (u);                                                                              \
-        const int tl_ = tile_ < tiles_total ? tile_ : 0;                                                                   \
-        const int k0_ = (tl_ - CAPMI_SEL(sgT, tl_)) * 32;                                                                  \
-        const int ldb_ = CAPMI_SEL(sgL, tl_);                                                                              \
-        const float *B_ = BKC ? CAPMI_SEL(sgB, tl_) + k0_ : CAPMI_SEL(sgB, tl_) + (size_t)k0_ * ldb_;                      \
-        if (ABL & 4) { for (int q_ = 0; q_ < 16; ++q_) bb[q_] = (float)(q_ + (u) + lane); }                                \
-        else load_bw<BKC, NTW>(bb, B_, ldb_, CAPMI_SEL(sgK, tl_) - k0_, colc, half);                                       \
-    } while (0)
-#pragma unroll
-    for (int u = 0; u < PF; ++u) CAPMI_LOAD_W(b[u], u);
-    __builtin_amdgcn_sched_barrier(0);
-    // the DMAs are older than every weight load and complete in order: at most PF * LPC loads outstanding <=> slice landed
-    // (the builtin, not an asm string, and with lgkmcnt(0) in it: hipcc's waitcnt pass files global_load_lds as a FLAT access
-    //  that may touch both memory and LDS and, while one is pending on EITHER counter, drains every later vmcnt use with
-    //  vmcnt(0) -- the weight ring would be serialised.  A modelled wait on both counters retires them; nothing is
-    //  outstanding on lgkmcnt here.)
-    constexpr int VMW = (ABL & 4) ? 0 : PF * LPC;
-    CAPMI_APL_STAMP(2);
-    __builtin_amdgcn_s_waitcnt(((VMW >> 4) << 14) | (VMW & 15) | 0x0070);
-    CAPMI_APL_STAMP(3);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    CAPMI_APL_STAMP(4);
-
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-    // fragment of lane (row l31 [+32], half) for k-step ks: piece 2 half + ks of the row, swizzled by (row >> 2) & 3
-    const unsigned char *abase = ldsb + (size_t)kh * TS * CHB + l31 * 64;
-    const int sw = (l31 >> 2) & 3;
-    const int po[2] = {((2 * half) ^ sw) << 4, ((2 * half + 1) ^ sw) << 4};
-    auto wsplit = [&](const float (&bb)[16], u32x4 (&wb)[2][3]) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) {
-                uint32_t hh[2], mm[2], ll[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const float x = bb[8 * ks + 2 * e2 + t];
-                    hh[t] = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
-                    const float r1 = x - __builtin_bit_cast(float, hh[t]);
-                    mm[t] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
-                    ll[t] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, mm[t]));
-                }
-                wb[ks][0][e2] = (hh[0] >> 16) | (hh[1] & 0xffff0000u);
-                wb[ks][1][e2] = (mm[0] >> 16) | (mm[1] & 0xffff0000u);
-                wb[ks][2][e2] = (ll[0] >> 16) | (ll[1] & 0xffff0000u);
-            }
-    };
-    auto mma3 = [&](const u32x4 (&wb)[2][3], int c) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 bw[3], x0[3], x1[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                bw[pl] = __builtin_bit_cast(bf16x8, wb[ks][pl]);
-                const unsigned char *q = abase + (size_t)c * CHB + pl * CAPMI_PL_PLANE_BYTES + po[ks];
-                x0[pl] = *reinterpret_cast<const bf16x8 *>(q);
-                if (TM == 2) x1[pl] = *reinterpret_cast<const bf16x8 *>(q + 32 * 64);
-            }
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // small cross terms first
-#pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[PA[t]], bw[PB[t]], acc0, 0, 0, 0);
-                if (TM == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[PA[t]], bw[PB[t]], acc1, 0, 0, 0);
-            }
-        }
-    };
-    {
-        u32x4 w0[2][3], w1[2][3];                      // split weights of the even / odd chunks
-        wsplit(b[0], w0);
-#pragma unroll
-        for (int c = 0; c < TS; ++c) {
-            // slot c % PF was split into registers during chunk c - 1: refill it with chunk c + PF
-            if (c + PF < TS) CAPMI_LOAD_W(b[c % PF], c + PF);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ABL & 2) {                           // keep the loads live without the split / MFMA work
-#pragma unroll
-                for (int q = 0; q < 16; ++q) asm volatile("" ::"v"(b[(c + 1) % PF][q]));
-                if (c == TS - 1) CAPMI_APL_STAMP(6);
-                continue;
-            }
-            if (c & 1) {
-                if (c + 1 < TS) wsplit(b[(c + 1) % PF], w0);
-                mma3(w1, c);
-            } else {
-                if (c + 1 < TS) wsplit(b[(c + 1) % PF], w1);
-                mma3(w0, c);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (ABL & 16) {
-                if (c == 0) { asm volatile("" ::"v"(acc0[0]), "v"(acc1[0])); CAPMI_APL_STAMP(5); }
-                if (c == TS - 1) { asm volatile("" ::"v"(acc0[15]), "v"(acc1[15])); CAPMI_APL_STAMP(6); }
-            }
-        }
-    }
-    if (ABL & 8) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { asm volatile("" ::"v"(acc0[r])); asm volatile("" ::"v"(acc1[r])); }
-        return;
-    }
-
-#undef CAPMI_LOAD_W
-#undef CAPMI_SEL
-    // K halves meet in LDS (the activation slice is dead): waves 4-7 park their 64x32 sums, waves 0-3 add and store
-    constexpr int RP = AR_BN + 4;
-    __syncthreads();
-    float *red = reinterpret_cast<float *>(ldsb);               // [64][RP]
-    if (kh == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            red[row * RP + 32 * cg + l31] = acc0[r];
-            if (TM == 2) red[(32 + row) * RP + 32 * cg + l31] = acc1[r];
-        }
-    }
-    __syncthreads();
-    CAPMI_APL_STAMP(7);
-    if (kh == 1 || col >= a.N) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        acc0[r] += red[row * RP + 32 * cg + l31];
-        if (TM == 2) acc1[r] += red[(32 + row) * RP + 32 * cg + l31];
-    }
-    if (a.to_partial) {
-        float *out = a.partial + (size_t)z * a.M * a.N + col;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (row < a.M) out[(size_t)row * a.N] = acc0[r];
-            if (TM == 2 && row + 32 < a.M) out[(size_t)(row + 32) * a.N] = acc1[r];
-        }
-        if (ABL & 16) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CAPMI_APL_STAMP(8); }
-        return;
-    }
-    float cb = 0.f;
-    if (a.bias) cb += a.bias[col];
-    if (a.bias2) cb += a.bias2[col];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (row >= a.M) continue;
-            float v = (i == 0 ? acc0[r] : acc1[r]) + cb;
-            if (a.row_bias) v += a.row_bias[(size_t)(row / a.row_bias_div) * a.N + col];
-            if (a.relu) v = fmaxf(v, 0.f);
-            if (a.mul_mask) v *= a.mul_mask[(size_t)row * a.N + col];
-            if (a.accumulate) v += a.C[(size_t)row * a.ldc + col];
-            a.C[(size_t)row * a.ldc + col] = v;
-        }
-    }
-}
-#undef CAPMI_APL_STAMP
 
 // X[M, K] (row pitch ld) -> A planes.  Producers on the hot path write their planes themselves (pl_store4); this kernel serves
 // operands that have no fused producer and the tests.
@@ -794,6 +506,7 @@ static int launch_ts(const KArgs &a, hipStream_t st, int pcls, double bytes, dou
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 dset = true;
             }
+#ifdef CAPMI_VARIANTS
             if constexpr (BKC && TS == 6 && TM == 2) {
                 static const int abl = capmi::ablate_env("CAPMI_ARES_ABLATE");
                 if (abl == 16) {
@@ -807,12 +520,14 @@ static int launch_ts(const KArgs &a, hipStream_t st, int pcls, double bytes, dou
                     return 0;
                 }
             }
+#endif
             if (prof) hipExtLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM, X3, 0, true>), grid, dim3(AR_NT), lds, st, e0, e1, 0, a);
             else hipLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM, X3, 0, true>), grid, dim3(AR_NT), lds, st, a);
             CAPMI_CHECK_LAUNCH();
             return 0;
         }
     }
+#ifdef CAPMI_VARIANTS
     if constexpr (BKC && TS == 6 && TM == 2 && X3) {
         static const int abl = capmi::ablate_env("CAPMI_ARES_ABLATE");
         if (abl) {
@@ -822,6 +537,7 @@ static int launch_ts(const KArgs &a, hipStream_t st, int pcls, double bytes, dou
 #undef CAPMI_ABL
         }
     }
+#endif
     if (prof) hipExtLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM, X3>), grid, dim3(AR_NT), lds, st, e0, e1, 0, a);
     else hipLaunchKernelGGL((gemm_ares_kernel<BKC, TS, TM, X3>), grid, dim3(AR_NT), lds, st, a);
     CAPMI_CHECK_LAUNCH();
@@ -847,78 +563,6 @@ int launch_ares(const KArgs &a, int b_layout, int ts, int x3, hipStream_t st, in
                          : launch_layout<false, false>(a, ts, st, pcls, bytes, flops);
 }
 
-int apl_ts_cap(int b_layout) { return b_layout == 0 ? 6 : 6; }
-
-template <bool BKC, int TS, int TM>
-static int launch_apl_ts(const KArgs &a, hipStream_t st, int pcls, double bytes, double flops) {
-    constexpr size_t slice = (size_t)2 * TS * CAPMI_PL_CHUNK_BYTES;
-    constexpr size_t red = (size_t)64 * (AR_BN + 4) * sizeof(float);
-    constexpr size_t lds = slice > red ? slice : red;
-    static_assert(lds <= 160 * 1024, "activation slice does not fit the CU's LDS");
-    static const int nt = [] { const char *e = getenv("CAPMI_APL_NT"); return e ? atoi(e) : 0; }();
-    dim3 grid((a.N + AR_BN - 1) / AR_BN, a.splits);
-    hipEvent_t e0, e1;
-    const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
-#define CAPMI_APL_GO(NTW)                                                                                                  \
-    do {                                                                                                                   \
-        static bool set = false;                                                                                           \
-        if (!set) {                                                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_apl_kernel<BKC, TS, TM, NTW>),                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
-            set = true;                                                                                                    \
-        }                                                                                                                  \
-        if (prof) hipExtLaunchKernelGGL((gemm_apl_kernel<BKC, TS, TM, NTW>), grid, dim3(AR_NT), lds, st, e0, e1, 0, a);    \
-        else hipLaunchKernelGGL((gemm_apl_kernel<BKC, TS, TM, NTW>), grid, dim3(AR_NT), lds, st, a);                       \
-    } while (0)
-    if constexpr (BKC && TS == 6 && TM == 2) {
-        static const int abl = capmi::ablate_env("CAPMI_APL_ABLATE");
-        static const int pfm = [] { const char *e = getenv("CAPMI_APL_PF"); return e ? atoi(e) : 0; }();
-        if (abl || pfm) {
-#define CAPMI_APL_V(A_, P_)                                                                                                \
-    if (abl == A_ && pfm == P_) {                                                                                          \
-        static bool set = false;                                                                                           \
-        if (!set) {                                                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_apl_kernel<BKC, TS, TM, false, A_, P_>),        \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
-            set = true;                                                                                                    \
-        }                                                                                                                  \
-        if (prof) hipExtLaunchKernelGGL((gemm_apl_kernel<BKC, TS, TM, false, A_, P_>), grid, dim3(AR_NT), lds, st, e0, e1, 0, a); \
-        else hipLaunchKernelGGL((gemm_apl_kernel<BKC, TS, TM, false, A_, P_>), grid, dim3(AR_NT), lds, st, a);             \
-        CAPMI_CHECK_LAUNCH();                                                                                              \
-        return 0;                                                                                                          \
-    }
-            CAPMI_APL_V(0, 2) CAPMI_APL_V(0, 3) CAPMI_APL_V(0, 4)
-            CAPMI_APL_V(1, 0) CAPMI_APL_V(2, 0) CAPMI_APL_V(4, 0) CAPMI_APL_V(8, 0) CAPMI_APL_V(3, 0) CAPMI_APL_V(9, 0)
-            CAPMI_APL_V(10, 0) CAPMI_APL_V(11, 0) CAPMI_APL_V(6, 0) CAPMI_APL_V(14, 0) CAPMI_APL_V(15, 0) CAPMI_APL_V(16, 0)
-            CAPMI_APL_V(1, 3) CAPMI_APL_V(2, 3) CAPMI_APL_V(8, 3) CAPMI_APL_V(11, 3) CAPMI_APL_V(16, 3)
-            CAPMI_APL_V(32, 0) CAPMI_APL_V(32, 2) CAPMI_APL_V(32, 3) CAPMI_APL_V(48, 2) CAPMI_APL_V(48, 3) CAPMI_APL_V(16, 2)
-            CAPMI_APL_V(34, 2) CAPMI_APL_V(40, 2) CAPMI_APL_V(33, 2)
-#undef CAPMI_APL_V
-        }
-    }
-    if (nt) CAPMI_APL_GO(true); else CAPMI_APL_GO(false);
-#undef CAPMI_APL_GO
-    CAPMI_CHECK_LAUNCH();
-    return 0;
-}
-
-template <bool BKC>
-static int launch_apl_layout(const KArgs &a, int ts, hipStream_t st, int pcls, double bytes, double flops) {
-    switch (ts) {
-#define CAPMI_TS(T) case T: return a.M <= 32 ? launch_apl_ts<BKC, T, 1>(a, st, pcls, bytes, flops) : launch_apl_ts<BKC, T, 2>(a, st, pcls, bytes, flops);
-        CAPMI_TS(1) CAPMI_TS(2) CAPMI_TS(3) CAPMI_TS(4) CAPMI_TS(5) CAPMI_TS(6)
-#undef CAPMI_TS
-    }
-    return CAPMI_EINVAL;
-}
-
-// a.splits * 2 * ts must cover a.tiles_total; every segment carries planes; a.zero_planes set
-int launch_apl(const KArgs &a, int b_layout, int ts, hipStream_t st, int pcls, double bytes, double flops) {
-    if (ts < 1 || ts > apl_ts_cap(b_layout) || a.M > 64 || (long long)a.splits * 2 * ts < a.tiles_total || !a.zero_planes)
-        return CAPMI_EINVAL;
-    return b_layout == 0 ? launch_apl_layout<true>(a, ts, st, pcls, bytes, flops)
-                         : launch_apl_layout<false>(a, ts, st, pcls, bytes, flops);
-}
 
 }  // namespace capmi_gemm
 

@@ -19,7 +19,6 @@ struct Seg {
     int rdiv;         // ceil(65536 / a_row_div): row / a_row_div == (row * rdiv) >> 16 for row < 64
     int tstart;       // index of this segment's first K tile in the flat tile list (INT_MAX for unused slots)
     const unsigned char *Apl;   // the same activations pre-split as "A planes" (capmi_common.h), or null
-    const unsigned char *Bpl;   // operand B's K-contiguous view [N][K] as planes (fat GEMMs, capmi_planes_split), or null
 };
 
 struct KArgs {
@@ -38,7 +37,6 @@ struct KArgs {
     int tiles_total;     // sum over segments of ceil(K/BK)
     int *counters;       // per-output-tile arrival tickets (in-launch split-K reduction), zero between launches
     int self_reduce;     // last-arriving K slice of a tile reduces all slices and applies the epilogue
-    const unsigned char *zero_planes;   // >= one all-zero chunk image (padding K slots of the A-planes kernel)
     int sl;              // loader / consumer kernel: K chunks per workgroup slice (runtime)
     int ablate;          // experiments only (CAPMI_GEMM_ABLATE): 1 = skip MFMA phase, 2 = skip global loads, 4 = skip LDS writes
 };
@@ -65,16 +63,11 @@ __device__ __forceinline__ void locate(const KArgs &a, int tile, int &s, int &k0
 int ares_plan(int N, int tiles, int want_blocks, int ts_cap, int *splits);
 int ares_ts_cap(int M, int x3);
 int launch_ares(const KArgs &a, int b_layout, int ts_max, int x3, hipStream_t st, int pcls, double bytes, double flops);
-// the same with the activations delivered as A planes (LDS-DMA staging); ts <= apl_ts_cap(b_layout)
-int apl_ts_cap(int b_layout);
-int launch_apl(const KArgs &a, int b_layout, int ts, hipStream_t st, int pcls, double bytes, double flops);
 // loader / consumer kernel on A planes (gemm_lc.hip): lc_plan picks a.sl and a.splits
 int lc_plan(int N, int tiles, int want_blocks, int *splits);
 int launch_lc(const KArgs &a, int b_layout, hipStream_t st, int pcls, double bytes, double flops);
 
 // fat GEMMs through the bf16 pipe by exact 3-way operand splitting; defined in gemm_x3.hip
 int launch_x3(const KArgs &a, int a_layout, int b_layout, dim3 grid, hipStream_t st, int pcls, double bytes, double flops);
-// the same with both operands delivered as planes (Seg.Apl / Seg.Bpl): nothing is split inside the GEMM
-int launch_x3pl(const KArgs &a, dim3 grid, hipStream_t st, int pcls, double bytes, double flops);
 
 }  // namespace capmi_gemm

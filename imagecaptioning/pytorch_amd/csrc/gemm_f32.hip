@@ -399,7 +399,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     for (int s = 0; s < d->nseg; ++s) {
         const capmi_gemm_seg &g = d->seg[s];
         if (g.K <= 0) return CAPMI_EINVAL;
-        if ((!g.A || !g.B) && !(d->a_planes[s] && d->b_planes[s])) return CAPMI_EINVAL;   // fp32 operands may be absent only on the all-planes path
+        if (!g.A || !g.B) return CAPMI_EINVAL;
         Seg &o = a.seg[s];
         o.A = g.A; o.B = g.B; o.lda = g.lda; o.ldb = g.ldb; o.K = g.K;
         o.a_row_div = g.a_row_div > 0 ? g.a_row_div : 1;
@@ -409,16 +409,14 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
         o.rdiv = (65536 + o.a_row_div - 1) / o.a_row_div;
         o.tstart = tiles;
         o.Apl = static_cast<const unsigned char *>(d->a_planes[s]);
-        o.Bpl = static_cast<const unsigned char *>(d->b_planes[s]);
         tiles += (g.K + BK - 1) / BK;
     }
-    a.zero_planes = static_cast<const unsigned char *>(d->zero_planes);
     for (int s = d->nseg; s < CAPMI_MAX_SEG; ++s) {      // unused slots: never selected, but always valid to read
         a.seg[s] = a.seg[0];
         a.seg[s].tstart = 0x7fffffff;
     }
     a.tiles_total = tiles;
-    static const int env_ablate = capmi::ablate_env("CAPMI_GEMM_ABLATE");
+    static const int env_ablate = capmi::ablate_env("CAPMI_GEMM_ABLATE");   // (variants builds only)
     a.ablate = env_ablate;
     a.M = d->M; a.N = d->N; a.C = d->C; a.ldc = d->ldc;
     a.bias = d->bias; a.bias2 = d->bias2; a.row_bias = d->row_bias;
@@ -440,23 +438,22 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
                                                  : CAPMI_PROF_GEMM_FAT;
     if (pcls == CAPMI_PROF_GEMM_DECODE && bytes >= 16e6) pcls = CAPMI_PROF_GEMM_DECODE_STREAM;
 
-    static const int env_path = [] { const char *e = getenv("CAPMI_GEMM_PATH"); return e ? atoi(e) : 0; }();
-    static const int env_blocks = [] { const char *e = getenv("CAPMI_GEMM_BLOCKS"); return e ? atoi(e) : 512; }();
-    bool have_f32 = true;
-    for (int s = 0; s < d->nseg; ++s) have_f32 = have_f32 && d->seg[s].A && d->seg[s].B;
-    bool ares_ok = have_f32 && d->a_layout == 0 && d->M <= 64 && BK == 32;
+    static const int env_path = capmi::research("CAPMI_GEMM_PATH", 0);
+    static const int env_blocks = capmi::research("CAPMI_GEMM_BLOCKS", 512);
+    bool ares_ok = d->a_layout == 0 && d->M <= 64 && BK == 32;
     for (int s = 0; s < d->nseg && ares_ok; ++s)     // branch-free 16-byte operand fetch: aligned, K % 4 == 0
         ares_ok = a.seg[s].vecA && (a.seg[s].K % 4 == 0) && (d->b_layout == 1 || a.seg[s].vecB);
-    // ---- round 3: loader / consumer kernel (gemm_lc.hip) when every segment is also delivered as A planes ----
-    static const int env_lc = [] { const char *e = getenv("CAPMI_LC"); return e ? atoi(e) : 1; }();
+    // ---- loader / consumer kernel (gemm_lc.hip) when every segment is also delivered as A planes ----
+    // CAPMI_LC=0 (documented knob): the A-resident kernel below serves those GEMMs too (tests/test_planes_gpu.py compares the two)
+    static const int env_lc = capmi::knob("CAPMI_LC", 1);
     {
         bool lc_ok = env_lc && env_path != 3 && ares_ok && d->M <= 64;
         for (int s = 0; s < d->nseg && lc_ok; ++s)
             lc_ok = d->a_planes[s] != nullptr && a.seg[s].a_row_div == 1 && a.seg[s].vecB;
         if (lc_ok && d->b_layout == 1) lc_ok = d->N % 4 == 0 && d->N >= 4;
         if (lc_ok) {
-            static const int env_ab = [] { const char *e = getenv("CAPMI_ARES_BLOCKS"); return e ? atoi(e) : 256; }();
-            static const int env_opt = [] { const char *e = getenv("CAPMI_LC_OPT"); return e ? atoi(e) : 1; }();
+            static const int env_ab = capmi::research("CAPMI_ARES_BLOCKS", 256);
+            static const int env_opt = capmi::research("CAPMI_LC_OPT", 1);
             const int want = d->splits > 0 ? ((d->N + 127) / 128) * d->splits : env_ab;
             int splits = 0;
             a.sl = lc_plan(d->N, tiles, want, &splits);
@@ -478,11 +475,11 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     }
     if (env_path != 3 && ares_ok) {     // CAPMI_GEMM_PATH=3 forces the LDS-tiled kernel
         // ---- A-resident path (gemm_ares.hip): activations stay in LDS, weights stream straight to VGPRs ----
-        static const int env_ab = [] { const char *e = getenv("CAPMI_ARES_BLOCKS"); return e ? atoi(e) : 256; }();
+        static const int env_ab = capmi::research("CAPMI_ARES_BLOCKS", 256);
         // bf16x3 split (see gemm_x3.hip) for the decode GEMMs too: activations split once when staged, weights split in
         // registers by the wave that streams them.  Gate GEMM 24.9 -> 19.9 us; greedy decodes stay token-exact on
         // the reference fixtures.  CAPMI_ARES_X3=0 restores the exact-fp32 MFMA.
-        static const int env_ax3 = [] { const char *e = getenv("CAPMI_ARES_X3"); return e ? atoi(e) : 1; }();
+        static const int env_ax3 = capmi::knob("CAPMI_ARES_X3", 1);
         int use_x3 = env_ax3;
         const int want = d->splits > 0 ? ((d->N + 127) / 128) * d->splits : env_ab;
         int splits = 0;
@@ -511,22 +508,11 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
             a.splits = splits;
             a.to_partial = (splits > 1 || d->defer_reduce) ? 1 : 0;
             a.self_reduce = 0;
-            static const int env_aopt = [] { const char *e = getenv("CAPMI_ARES_OPT"); return e ? atoi(e) : 2; }();
+            static const int env_aopt = capmi::research("CAPMI_ARES_OPT", 2);
             a.ablate = env_aopt;             // speed-only switches of the A-resident kernel (see gemm_ares.hip)
             if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > slab_cap)) return CAPMI_EINVAL;
             d->splits_used = splits;
-            // round 3: every segment also delivered as A planes -> LDS-DMA staged kernel (CAPMI_APL=0 keeps the kernel above)
-            static const int env_apl = [] { const char *e = getenv("CAPMI_APL"); return e ? atoi(e) : 1; }();
-            static const int env_apl_opt = [] { const char *e = getenv("CAPMI_APL_OPT"); return e ? atoi(e) : 1; }();
-            bool apl_ok = env_apl && use_x3 && d->zero_planes && ts_max <= apl_ts_cap(d->b_layout);
-            for (int s = 0; s < d->nseg && apl_ok; ++s) apl_ok = d->a_planes[s] != nullptr && a.seg[s].a_row_div == 1;
-            int rc;
-            if (apl_ok) {
-                a.ablate = env_apl_opt;          // bit 0: XCD-aware workgroup map
-                rc = launch_apl(a, d->b_layout, ts_max, st, pcls, bytes, flops);
-            } else {
-                rc = launch_ares(a, d->b_layout, ts_max, use_x3, st, pcls, bytes, flops);
-            }
+            int rc = launch_ares(a, d->b_layout, ts_max, use_x3, st, pcls, bytes, flops);
             if (rc) return rc;
             if (splits > 1 && !d->defer_reduce)
                 return capmi_splitk_reduce(a.partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,
@@ -537,7 +523,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
 
     // tile shape by M: decode batches are skinny.  Every configuration gives each wave >= 2 independent
     // accumulator chains (a lone dependent v_mfma_f32_32x32x2 chain loses ~40 % to issue gaps).
-    static const int env_cfg = [] { const char *e = getenv("CAPMI_GEMM_CFG"); return e ? atoi(e) : 1; }();
+    static const int env_cfg = capmi::research("CAPMI_GEMM_CFG", 1);
     int BM, BN;
     (void)env_cfg;
     if (d->M <= 32) { BM = 32; BN = 128; }
@@ -549,7 +535,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     const int gm = (d->M + BM - 1) / BM, gn = (d->N + BN - 1) / BN;
     // fat GEMMs (time-batched BPTT): fp32 through the bf16 pipe by exact 3-way splitting (gemm_x3.hip);
     // CAPMI_GEMM_X3=0 keeps them on the exact-fp32 MFMA
-    static const int env_x3 = [] { const char *e = getenv("CAPMI_GEMM_X3"); return e ? atoi(e) : 1; }();
+    static const int env_x3 = capmi::knob("CAPMI_GEMM_X3", 1);
     bool x3_ok = env_x3 && BM == 128 && BN == 128 && BK == 32 &&
                  (d->a_layout == 0 || d->M % 4 == 0) && (d->b_layout == 0 || d->N % 4 == 0);   // 4-row quads of [K][rows] operands
     for (int s = 0; s < d->nseg && x3_ok; ++s)      // branch-free 16-byte staging loads: aligned operands, K % 4 == 0
@@ -557,14 +543,6 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
                 // 32-bit per-lane byte offsets in the staging loads
                 (uint64_t)(d->a_layout == 0 ? d->M : 1) * (uint64_t)a.seg[s].lda * 4 < (1ull << 32) &&
                 (uint64_t)(d->b_layout == 0 ? d->N : 1) * (uint64_t)a.seg[s].ldb * 4 < (1ull << 32);
-    // both operands as planes (capmi_planes_split / producer-written): the split-free kernel
-    static const int env_pl = [] { const char *e = getenv("CAPMI_X3PL"); return e ? atoi(e) : 1; }();
-    bool pl_ok = env_pl && BM == 128 && BN == 128 && BK == 32;
-    for (int s = 0; s < d->nseg && pl_ok; ++s)
-        pl_ok = a.seg[s].Apl && a.seg[s].Bpl && a.seg[s].a_row_div == 1 &&
-                ((reinterpret_cast<uintptr_t>(a.seg[s].Apl) | reinterpret_cast<uintptr_t>(a.seg[s].Bpl)) & 15) == 0;
-    if (!pl_ok && !have_f32) return CAPMI_EINVAL;
-    if (pl_ok) x3_ok = true;           // same tiling, same K-split plan
     int splits = d->splits;
     if (splits == 0 && x3_ok) {
         // persistent kernel, one workgroup per CU: pick the K split that minimises (rounds x K tiles per unit) plus the
@@ -596,20 +574,19 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     a.to_partial = (splits > 1 || d->defer_reduce) ? 1 : 0;
     // in-launch last-arriver reduction is implemented (G16 recipe) but measured SLOWER than the follow-up reduce
     // kernel at decode sizes (logit 33.5 vs 27.9 us, dX 34.2 vs 27-31 us): opt-in via CAPMI_GEMM_SELF_REDUCE=1.
-    static const int env_self = [] { const char *e = getenv("CAPMI_GEMM_SELF_REDUCE"); return e ? atoi(e) : 0; }();
+    static const int env_self = capmi::research("CAPMI_GEMM_SELF_REDUCE", 0);
     a.self_reduce = (env_self && splits > 1 && !d->defer_reduce && gn * gm <= CAPMI_WS_COUNTER_FLOATS) ? 1 : 0;
     if (x3_ok) a.self_reduce = 0;      // the persistent kernel always leaves plain slabs
     if (a.to_partial && (!d->partial || (int64_t)splits * d->M * d->N > slab_cap)) return CAPMI_EINVAL;
     d->splits_used = splits;
-    static const int env_log = [] { const char *e = getenv("CAPMI_GEMM_LOG"); return e ? atoi(e) : 0; }();   // shape census (profiling)
+    static const int env_log = capmi::knob("CAPMI_GEMM_LOG", 0);   // shape census on stderr (profiling)
     if (env_log)
         fprintf(stderr, "capmi_gemm M=%d N=%d tiles=%d al=%d bl=%d x3=%d splits=%d defer=%d acc=%d\n", d->M, d->N, tiles, d->a_layout,
                 d->b_layout, (int)x3_ok, splits, d->defer_reduce, d->accumulate);
     dim3 grid(gn, gm, splits);
     const ProfInfo pi{pcls, bytes, flops};
     int rc;
-    if (pl_ok) rc = launch_x3pl(a, grid, st, pcls, bytes, flops);
-    else if (x3_ok) rc = launch_x3(a, d->a_layout, d->b_layout, grid, st, pcls, bytes, flops);
+    if (x3_ok) rc = launch_x3(a, d->a_layout, d->b_layout, grid, st, pcls, bytes, flops);
     else if (BM == 32 && BN == 128) rc = launch_cfg<32, 128, 1, 4, 3>(a, d->a_layout, d->b_layout, grid, st, pi);
     else if (BM == 64 && BN == 64) rc = launch_cfg<64, 64, 2, 2, 3>(a, d->a_layout, d->b_layout, grid, st, pi);
         else if (BM == 64 && BN == 128) rc = launch_cfg<64, 128, 1, 4, 2>(a, d->a_layout, d->b_layout, grid, st, pi);

@@ -356,286 +356,6 @@ __global__ __launch_bounds__(LC_NT) void gemm_lc_kernel(const KArgs a) {
 }
 
 
-// =====================================================================================================================
-// Self-loading variant (end of round 3).  The wait / issue probes of the kernel above (profiles/r03_gemm_lc_ablation.log) show
-// its LOADER waves stalled at issue for most of every stage interval while the consumers sit in the barrier -- and neither
-// stream's bytes are the reason (without the activation copies: same time; without the weight copies: -10 %): a wave's VMEM issue
-// is held back while OTHER waves of its SIMD execute MFMA / VALU / LDS work (the same effect gemm_x3pl's probes isolate,
-// profiles/r03_x3pl_probe.md), and there DMAs issued by the MFMA waves THEMSELVES, between their own MFMAs, did overlap.
-// So here there are no loader waves: 512 threads, the 8 consumers of the kernel above, and every wave copies its own share of
-// every stage -- 4 of the stage's 28 one-KB pieces (two of the weight tile, two of the activation image; waves whose share is 3
-// repeat one) -- one DMA behind each of the first four MFMA groups of the k-step it runs in that interval.  Ring protocol and
-// arithmetic are the kernel's above (same results bit for bit); each wave waits, counted, for ITS pieces of stage k before
-// barrier k.  hipcc: every wait that follows an LDS-DMA is the builtin s_waitcnt with vmcnt(n) AND lgkmcnt(0) -- a wait the
-// compiler inserts on its own behind a pending LDS-DMA is vmcnt(0) -- and all ds_reads of an interval precede its first DMA.
-// MEASURED (CAPMI_LC_V=3; same tests green): SLOWER -- gate GEMM 18.4 vs 16.2 us, logit 16.6 vs 14.6, dX 18.0 vs 16.2: a DMA
-// that stalls at issue now stalls the MFMAs queued behind it in the same wave (consumers busy 1 700 of 2 120 cycles per interval
-// instead of waiting in the barrier half of 1 830).  The stall is the CU's memory queue, whoever issues: ~250 cache lines in
-// flight per CU x the Infinity Cache's latency = ~32 GB/s per CU, 8 TB/s over the chip -- the pace of both variants' loops.  Kept as
-// an option and as the record of the experiment; the loader / consumer kernel above stays the default.
-constexpr int LC3_NT = 512;
-#define CAPMI_VMCNT_LGKM0(n) __builtin_amdgcn_s_waitcnt((((n) >> 4) << 14) | ((n) & 15) | 0x0070)
-
-template <bool BKC, int TM, int ABL = 0>
-__global__ __launch_bounds__(LC3_NT) void gemm_lc3_kernel(const KArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
-    int bx = blockIdx.x, z = blockIdx.y;
-    if (a.ablate & 1) {                              // XCD-aware map: the column blocks of one K slice share an XCD's L2
-        const int L = blockIdx.y * gridDim.x + blockIdx.x, total = gridDim.x * gridDim.y;
-        const int q = total >> 3, r = total & 7, xcd = L & 7;
-        const int p = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-        z = p / (int)gridDim.x;
-        bx = p - z * (int)gridDim.x;
-    }
-    const int n0 = bx * LC_BN;
-    const int SL = a.sl;
-    const int t0 = z * SL;
-    const int nst = min(SL, a.tiles_total - t0);
-    const int lane = threadIdx.x & 63;
-    const int widu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int cg = widu & 3, par = widu >> 2;
-    static_assert(CAPMI_MAX_SEG == 4, "segment selects are written out for 4 segments");
-#define CAPMI_PIN(i)                                                                                                       \
-    const unsigned char *sgP##i = a.seg[i].Apl; const float *sgB##i = a.seg[i].B;                                          \
-    int sgL##i = a.seg[i].ldb, sgK##i = a.seg[i].K, sgT##i = a.seg[i].tstart;                                              \
-    asm volatile("" : "+s"(sgP##i), "+s"(sgB##i), "+s"(sgL##i), "+s"(sgK##i), "+s"(sgT##i));
-    CAPMI_PIN(0) CAPMI_PIN(1) CAPMI_PIN(2) CAPMI_PIN(3)
-#undef CAPMI_PIN
-#define CAPMI_SEL(F, tl) ((tl) >= sgT3 ? F##3 : (tl) >= sgT2 ? F##2 : (tl) >= sgT1 ? F##1 : F##0)
-    const int N = a.N;
-    // this wave's pieces of a stage: weight pieces cg + 4 u for u = 2 par, 2 par + 1 (of the tile's 16); activation pieces
-    // cg + 4 v for v = par and par + 2 (TM = 2: 12 pieces, v < 3; TM = 1: the 6 pieces of rows 0-31) -- a v out of range repeats
-    int wrow[2], wk[2], wpc[2], apc[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int p = cg + 4 * (2 * par + q);
-        wpc[q] = p;
-        if (BKC) {
-            const int cl_ = 8 * p + (lane >> 3);
-            wrow[q] = min(n0 + cl_, N - 1);
-            wk[q] = 4 * ((lane & 7) ^ ((cl_ >> 1) & 7));
-        } else {
-            wrow[q] = 2 * p + (lane >> 5);
-            wk[q] = min(n0 + 4 * (lane & 31), N - 4);
-        }
-        const int v = (par + 2 * q < (TM == 2 ? 3 : 2)) ? par + 2 * q : par;
-        if (TM == 2) apc[q] = cg + 4 * v;
-        else { const int q_ = min(cg + 4 * v, 5); apc[q] = (q_ >> 1) * 4 + (q_ & 1); }
-    }
-    // addresses of the four DMAs of the stage being requested (set by CAPMI_LC3_PREP, used by CAPMI_LC3_DMA)
-    const float *g0 = nullptr, *g1 = nullptr;
-    const unsigned char *g2 = nullptr, *g3 = nullptr;
-    unsigned char *l0 = nullptr, *l1 = nullptr, *l2 = nullptr, *l3 = nullptr;
-#define CAPMI_LC3_PREP(i_, slot_idx_)                                                                                      \
-    do {                                                                                                                   \
-        const int tl_ = t0 + (i_);                                                                                         \
-        unsigned char *slot_ = ldsb + (slot_idx_) * LC_STAGE;                                                              \
-        const int tb_ = CAPMI_SEL(sgT, tl_);                                                                               \
-        const unsigned char *img_ = CAPMI_SEL(sgP, tl_) + (size_t)(tl_ - tb_) * LC_AB + lane * 16;                         \
-        const int k0_ = (tl_ - tb_) * 32;                                                                                  \
-        const int ldb_ = CAPMI_SEL(sgL, tl_), brem_ = CAPMI_SEL(sgK, tl_) - k0_;                                           \
-        const float *B_ = CAPMI_SEL(sgB, tl_);                                                                             \
-        g0 = BKC ? B_ + (size_t)wrow[0] * ldb_ + k0_ + min(wk[0], brem_ - 4) : B_ + (size_t)(k0_ + min(wrow[0], brem_ - 1)) * ldb_ + wk[0]; \
-        g1 = BKC ? B_ + (size_t)wrow[1] * ldb_ + k0_ + min(wk[1], brem_ - 4) : B_ + (size_t)(k0_ + min(wrow[1], brem_ - 1)) * ldb_ + wk[1]; \
-        l0 = slot_ + LC_AB + wpc[0] * 1024; l1 = slot_ + LC_AB + wpc[1] * 1024;                                            \
-        g2 = img_ + apc[0] * 1024; g3 = img_ + apc[1] * 1024;                                                              \
-        l2 = slot_ + apc[0] * 1024; l3 = slot_ + apc[1] * 1024;                                                            \
-    } while (0)
-#define CAPMI_LC3_DMA(d_) __builtin_amdgcn_global_load_lds((gvoid)(uintptr_t)g##d_, (lvoid)l##d_, 16, 0, 0)
-    int fill = 0, fslot = 0;                         // next stage to request, into slot fslot = fill % LC_NS
-#define CAPMI_LC3_ADV() do { ++fill; fslot = fslot == LC_NS - 1 ? 0 : fslot + 1; } while (0)
-    // stage f may be requested once stage f - LC_NS is finished, i.e. behind barrier f - LC_NS + 2 (see the kernel above)
-#define CAPMI_LC3_MAY(k_) (fill < nst && fill <= (k_) - 2 + LC_NS)
-#define CAPMI_LC3_BURST(k_)                                                                                                \
-    do {                                                                                                                   \
-        if (CAPMI_LC3_MAY(k_)) { CAPMI_LC3_PREP(fill, fslot); CAPMI_LC3_DMA(0); CAPMI_LC3_DMA(1); CAPMI_LC3_DMA(2); CAPMI_LC3_DMA(3); \
-                                 CAPMI_LC3_ADV(); }                                                                        \
-    } while (0)
-    {
-        const int pre = min(nst, 2);                 // (a wave stalls AT ISSUE once the CU's queue is full: stage 0 first)
-        for (int s = 0; s < pre; ++s) { CAPMI_LC3_PREP(fill, fslot); CAPMI_LC3_DMA(0); CAPMI_LC3_DMA(1); CAPMI_LC3_DMA(2); CAPMI_LC3_DMA(3);
-                                        CAPMI_LC3_ADV(); }
-    }
-
-    const int l31 = lane & 31, half = lane >> 5;
-    const int cl = 32 * cg + l31;                    // column within the workgroup's tile
-    const int col = n0 + cl;
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-    const int sw = (l31 >> 2) & 3;
-    const int ao[2] = {l31 * 64 + (((2 * half) ^ sw) << 4), l31 * 64 + (((2 * half + 1) ^ sw) << 4)};
-    const int wsw = (cl >> 1) & 7;
-    int wo[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wo[q] = LC_AB + (BKC ? cl * 128 + (((4 * half + q) ^ wsw) << 4) : (16 * half + 4 * q) * 512 + cl * 4);
-    auto wfrag = [&](const unsigned char *slot, u32x4 (&wb)[2][3]) {
-        float bb[16];
-        if (BKC) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(slot + wo[q]);
-                bb[4 * q] = v[0]; bb[4 * q + 1] = v[1]; bb[4 * q + 2] = v[2]; bb[4 * q + 3] = v[3];
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bb[4 * q + e] = *reinterpret_cast<const float *>(slot + wo[q] + e * 512);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) {
-                uint32_t hh[2], mm[2], ll[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const float x = bb[8 * ks + 2 * e2 + t];
-                    hh[t] = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
-                    const float r1 = x - __builtin_bit_cast(float, hh[t]);
-                    mm[t] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
-                    ll[t] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, mm[t]));
-                }
-                wb[ks][0][e2] = (hh[0] >> 16) | (hh[1] & 0xffff0000u);
-                wb[ks][1][e2] = (mm[0] >> 16) | (mm[1] & 0xffff0000u);
-                wb[ks][2][e2] = (ll[0] >> 16) | (ll[1] & 0xffff0000u);
-            }
-    };
-    // one k-step of a stage; `have`: this wave's four DMAs of the stage being requested go out behind the first four MFMA groups
-    auto mma = [&](const unsigned char *slot, const u32x4 (&wb)[2][3], int ks, bool have) {
-        bf16x8 bw[3], x0[3], x1[3];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            bw[pl] = __builtin_bit_cast(bf16x8, wb[ks][pl]);
-            const unsigned char *q = slot + pl * CAPMI_PL_PLANE_BYTES + ao[ks];
-            x0[pl] = *reinterpret_cast<const bf16x8 *>(q);
-            if (TM == 2) x1[pl] = *reinterpret_cast<const bf16x8 *>(q + 32 * 64);
-        }
-        __builtin_amdgcn_sched_barrier(0);           // every LDS read of the interval is issued before its first DMA
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // six of nine cross terms, small ones first
-#define CAPMI_LC3_STEP(T_)                                                                                                 \
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x0[PA[T_]], bw[PB[T_]], acc0, 0, 0, 0);                             \
-        if (TM == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[PA[T_]], bw[PB[T_]], acc1, 0, 0, 0);
-        CAPMI_LC3_STEP(0) if (have) CAPMI_LC3_DMA(0);
-        CAPMI_LC3_STEP(1) if (have) CAPMI_LC3_DMA(1);
-        CAPMI_LC3_STEP(2) if (have) CAPMI_LC3_DMA(2);
-        CAPMI_LC3_STEP(3) if (have) CAPMI_LC3_DMA(3);
-        CAPMI_LC3_STEP(4)
-        CAPMI_LC3_STEP(5)
-#undef CAPMI_LC3_STEP
-    };
-    unsigned long long c_bar = 0, c_t0 = 0;
-    if (ABL & 128) c_t0 = clock64();
-    // ring barrier k_: this wave's pieces of stage k_ have landed when at most its DMAs of the younger stages are outstanding
-#define CAPMI_LC3_BARRIER(k_)                                                                                              \
-    do {                                                                                                                   \
-        unsigned long long b0_ = 0;                                                                                        \
-        if (ABL & 128) b0_ = clock64();                                                                                    \
-        const int y_ = fill - 1 - (k_);                                                                                    \
-        if ((k_) >= nst || y_ >= 4) CAPMI_VMCNT_LGKM0(16);                                                                 \
-        else if (y_ == 3) CAPMI_VMCNT_LGKM0(12);                                                                           \
-        else if (y_ == 2) CAPMI_VMCNT_LGKM0(8);                                                                            \
-        else if (y_ == 1) CAPMI_VMCNT_LGKM0(4);                                                                            \
-        else CAPMI_VMCNT_LGKM0(0);                                                                                         \
-        asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");                        \
-        if (ABL & 128) c_bar += clock64() - b0_;                                                                           \
-    } while (0)
-    int bars = 0;                                    // ring barriers passed (every wave passes nst + 1 of them)
-    if (par) {                                       // an odd-stage wave has nothing to multiply in interval 0
-        CAPMI_LC3_BARRIER(0); ++bars;
-        CAPMI_LC3_BURST(0); CAPMI_LC3_BURST(0);
-    }
-    {
-        u32x4 wb[2][3];
-        int sidx = par;                              // slot of stage j
-        for (int j = par; j < nst; j += 2) {
-            CAPMI_LC3_BARRIER(j);                    // barrier j: stage j has landed; interval j
-            ++bars;
-            const unsigned char *slot = ldsb + sidx * LC_STAGE;
-            sidx = sidx >= LC_NS - 2 ? sidx + 2 - LC_NS : sidx + 2;
-            bool have = CAPMI_LC3_MAY(j);
-            if (have) CAPMI_LC3_PREP(fill, fslot);
-            wfrag(slot, wb);
-            mma(slot, wb, 0, have);
-            if (have) CAPMI_LC3_ADV();
-            CAPMI_LC3_BURST(j);                      // (the ring fills up two stages per interval at the start)
-            CAPMI_LC3_BARRIER(j + 1);                // barrier j + 1; interval j + 1
-            ++bars;
-            have = CAPMI_LC3_MAY(j + 1);
-            if (have) CAPMI_LC3_PREP(fill, fslot);
-            mma(slot, wb, 1, have);
-            if (have) CAPMI_LC3_ADV();
-            CAPMI_LC3_BURST(j + 1);
-        }
-    }
-    while (bars <= nst) {                            // (an interval without work of its own: the wave still requests its pieces)
-        CAPMI_LC3_BARRIER(bars);
-        ++bars;
-        CAPMI_LC3_BURST(bars - 1); CAPMI_LC3_BURST(bars - 1);
-    }
-    if ((ABL & 128) && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && cg == 0)
-        printf("lc3 consumer parity %d: %d ring barriers, %.0f cycles per stage interval, of which %.0f in the wait + barrier\n", par,
-               bars, (double)(clock64() - c_t0) / bars, (double)c_bar / bars);
-    // ---- the two parities of a column group meet in LDS (the ring is dead behind the first barrier) -------------------------
-    constexpr int RP = LC_BN + 4;
-    float *red = reinterpret_cast<float *>(ldsb);   // [64][RP]
-#define CAPMI_LC3_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-    CAPMI_LC3_SYNC();
-    if (par == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            red[row * RP + cl] = acc0[r];
-            if (TM == 2) red[(32 + row) * RP + cl] = acc1[r];
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    CAPMI_LC3_SYNC();
-#undef CAPMI_LC3_SYNC
-    if (par == 1) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        acc0[r] += red[row * RP + cl];
-        if (TM == 2) acc1[r] += red[(32 + row) * RP + cl];
-    }
-    if (col >= a.N) return;
-    if (a.to_partial) {
-        float *out = a.partial + (size_t)z * a.M * a.N + col;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (row < a.M) out[(size_t)row * a.N] = acc0[r];
-            if (TM == 2 && row + 32 < a.M) out[(size_t)(row + 32) * a.N] = acc1[r];
-        }
-        return;
-    }
-    float cb = 0.f;
-    if (a.bias) cb += a.bias[col];
-    if (a.bias2) cb += a.bias2[col];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (row >= a.M) continue;
-            float v = (i == 0 ? acc0[r] : acc1[r]) + cb;
-            if (a.row_bias) v += a.row_bias[(size_t)(row / a.row_bias_div) * a.N + col];
-            if (a.relu) v = fmaxf(v, 0.f);
-            if (a.mul_mask) v *= a.mul_mask[(size_t)row * a.N + col];
-            if (a.accumulate) v += a.C[(size_t)row * a.ldc + col];
-            a.C[(size_t)row * a.ldc + col] = v;
-        }
-    }
-#undef CAPMI_LC3_PREP
-#undef CAPMI_LC3_DMA
-#undef CAPMI_LC3_ADV
-#undef CAPMI_LC3_MAY
-#undef CAPMI_LC3_BURST
-#undef CAPMI_LC3_BARRIER
-#undef CAPMI_SEL
-}
-
 }  // namespace
 
 // K chunks per workgroup slice and the number of slices for ~want_blocks workgroups (one per CU: the ring takes 140 KB of LDS)
@@ -658,25 +378,6 @@ static int launch_lc_t(const KArgs &a, hipStream_t st, int pcls, double bytes, d
     hipEvent_t e0, e1;
     const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
     static const int abl = capmi::ablate_env("CAPMI_LC_ABLATE");
-    static const int env_v = [] { const char *e = getenv("CAPMI_LC_V"); return e ? atoi(e) : 2; }();   // 3: self-loading consumers
-    if (env_v == 3) {
-#define CAPMI_LC3_GO(A_)                                                                                                   \
-        do {                                                                                                               \
-            static bool set3 = false;                                                                                      \
-            if (!set3) {                                                                                                   \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_lc3_kernel<BKC, TM, A_>),                   \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                         \
-                set3 = true;                                                                                               \
-            }                                                                                                              \
-            if (prof) hipExtLaunchKernelGGL((gemm_lc3_kernel<BKC, TM, A_>), grid, dim3(LC3_NT), lds, st, e0, e1, 0, a);    \
-            else hipLaunchKernelGGL((gemm_lc3_kernel<BKC, TM, A_>), grid, dim3(LC3_NT), lds, st, a);                       \
-        } while (0)
-        if (abl == 128) CAPMI_LC3_GO(128);
-        else CAPMI_LC3_GO(0);
-#undef CAPMI_LC3_GO
-        CAPMI_CHECK_LAUNCH();
-        return 0;
-    }
 #define CAPMI_LC_GO(A_)                                                                                                    \
     do {                                                                                                                   \
         static bool set = false;                                                                                           \
@@ -688,6 +389,7 @@ static int launch_lc_t(const KArgs &a, hipStream_t st, int pcls, double bytes, d
         if (prof) hipExtLaunchKernelGGL((gemm_lc_kernel<BKC, TM, A_>), grid, dim3(LC_NT), lds, st, e0, e1, 0, a);          \
         else hipLaunchKernelGGL((gemm_lc_kernel<BKC, TM, A_>), grid, dim3(LC_NT), lds, st, a);                             \
     } while (0)
+#ifdef CAPMI_VARIANTS
     if constexpr (BKC && TM == 2) {
         switch (abl) {
             case 1: CAPMI_LC_GO(1); break;
@@ -709,6 +411,10 @@ static int launch_lc_t(const KArgs &a, hipStream_t st, int pcls, double bytes, d
     } else {
         CAPMI_LC_GO(0);
     }
+#else
+    (void)abl;
+    CAPMI_LC_GO(0);
+#endif
 #undef CAPMI_LC_GO
     CAPMI_CHECK_LAUNCH();
     return 0;

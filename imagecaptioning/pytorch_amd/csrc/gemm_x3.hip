@@ -169,7 +169,7 @@ __device__ __forceinline__ void x3_r2s(const float (&r)[16], const float (&f)[4]
 // ping-pong and ONE workgroup barrier per K tile hands a stage over.  The workgroups are PERSISTENT (one per CU, 120 KB
 // of LDS): each walks a list of (output tile, K slice) units and the staging waves run ahead across unit boundaries,
 // so the HBM latency of a unit's first tiles and the MFMA waves' epilogue stores overlap with useful work.
-constexpr int XNT = 512;
+[[maybe_unused]] constexpr int XNT = 512;   // (ablation builds)
 constexpr int XSTAGE = 6 * XPLANE;            // bf16 elements per stage: 3 planes x (A, B) = 60 KB
 
 struct Unit {
@@ -430,271 +430,14 @@ __global__ __launch_bounds__(256 + 64 * NSW) void gemm_x3_kernel(const KArgs a, 
     }
 }
 
-// =====================================================================================================================
-// Round 3: the same GEMM with BOTH operands delivered as bf16x3 PLANES (capmi.h capmi_planes_split: K-contiguous views
-// [rows][K] of the logical operands in the chunk format of capmi_common.h, 64-row blocks x 32-k chunks, written once by
-// the operand's producer or by one split pass).  The split leaves the GEMM: nothing is converted inside it, a K tile of
-// an operand (128 rows x 32 k x 3 planes = two 12-KB chunks) is a straight LDS-DMA copy (global_load_lds_dwordx4: no
-// VGPRs, no VALU, no ds_write), and transposed operands (dW = dG^T X) were transposed by the split pass, so every fragment
-// read is the conflict-free ds_read_b128 of the chunk image.
-//   768 threads: waves 0-7 MFMA (64x32 each, the software-pipelined loop of gemm_x3_kernel), waves 8-11 LOADERS, one per
-//   (operand, 64-row block): 12 DMAs of 1 KB per K tile each.  Three 48-KB stages; ONE workgroup barrier per K tile:
-//   at barrier g the MFMA waves have finished reading tile g-1 and the loaders have waited (counted vmcnt) for tile g,
-//   then the loaders request tile g+2 into the stage tile g-1 just left.
-constexpr int PL_CH = CAPMI_PL_CHUNK_BYTES;         // 12288: [3 planes][64 rows][64 B]
-constexpr int PL_OP = 2 * PL_CH;                    // one operand's 128 rows of a K tile
-constexpr int PL_STG = 2 * PL_OP;                   // A + B: 48 KB
-typedef const void __attribute__((address_space(1))) *gvoid_t;
-typedef void __attribute__((address_space(3))) *lvoid_t;
-// s_waitcnt vmcnt(n), expcnt / lgkmcnt untouched (gfx9 encoding)
-#define CAPMI_X3_VMCNT(n) __builtin_amdgcn_s_waitcnt((((n) >> 4) << 14) | ((n) & 15) | 0x0f70)
-
-// OP: operand (0 = A, 1 = B) -- compile-time: a run-time select between two kernel-argument fields becomes a load through a
-// selected POINTER and hipcc then copies the whole argument block to scratch memory.  hb: 64-row block of the 128-row tile.
-template <int ABL, int OP, int PL_NS>
-__device__ __forceinline__ void x3pl_loader(const KArgs &a, int gm, int gn, int units, int hb, int lane, unsigned char *lds) {
-    constexpr int op = OP;
-    const unsigned char *p = nullptr;                // this lane's 16 bytes of the next chunk
-    int fu = blockIdx.x, f_left = 0, f_sleft = 0, f_s = 0, f_rb = 0;
-    auto bind = [&](int sidx, int kc) {
-        const unsigned char *base = nullptr;
-        int K = 1;
-#define CAPMI_X3PL_SEG(I)                                        \
-    case I:                                                      \
-        base = op ? a.seg[I].Bpl : a.seg[I].Apl;                 \
-        K = a.seg[I].K;                                          \
-        break;
-        switch (sidx) {
-            CAPMI_X3PL_SEG(0) CAPMI_X3PL_SEG(1) CAPMI_X3PL_SEG(2) CAPMI_X3PL_SEG(3)
-        }
-#undef CAPMI_X3PL_SEG
-        const int nkc = (K + 31) >> 5;
-        p = base + ((size_t)f_rb * nkc + kc) * PL_CH + lane * 16;
-        f_sleft = nkc - kc;
-    };
-    auto open_unit = [&]() {
-        const Unit un = unit_of(a, fu, gm, gn);
-        int sidx, k0;
-        locate(a, un.t_begin, sidx, k0);
-        f_s = __builtin_amdgcn_readfirstlane(sidx);
-        f_rb = ((op ? un.n0 : un.m0) >> 6) + hb;
-        f_left = un.nt;
-        bind(f_s, k0 >> 5);
-    };
-    if (fu < units) open_unit();
-    if (a.ablate & 8) __builtin_amdgcn_s_setprio(3);
-    // exactly 12 DMAs per call (the counted waits below rely on it); past the last tile the cursor stays put and the copy is
-    // repeated into a stage nobody reads
-    auto issue = [&](int stage) {
-        unsigned char *dst = lds + stage * PL_STG + op * PL_OP + hb * PL_CH;
-        if (!(ABL & 2)) {
-#pragma unroll
-            for (int i = 0; i < 12; ++i)
-                __builtin_amdgcn_global_load_lds((gvoid_t)(uintptr_t)(p + i * 1024), (lvoid_t)(dst + i * 1024), 16, 0, 0);
-        }
-        if (f_left > 0) {                            // workgroup-uniform
-            if (--f_left == 0) {
-                fu += gridDim.x;
-                if (fu < units) open_unit();
-            } else if (--f_sleft == 0) {
-                bind(++f_s, 0);
-            } else {
-                p += PL_CH;
-            }
-        }
-    };
-    int steps = 0;
-    for (int u = blockIdx.x; u < units; u += gridDim.x) steps += unit_of(a, u, gm, gn).nt;
-    issue(0);
-    if (PL_NS == 3) issue(1);
-    CAPMI_X3_VMCNT(12 * (PL_NS - 2));                // tile 0 landed (a wave's LDS-DMAs retire in order)
-    __builtin_amdgcn_s_barrier();
-    int st = PL_NS - 1;
-    unsigned long long t_issue = 0, t_land = 0, t_bar = 0;       // ABL & 4: where a loader's time goes
-    for (int g = 0; g < steps; ++g) {
-        unsigned long long t0 = 0, t1 = 0, t2 = 0;
-        if (ABL & 4) t0 = clock64();
-        issue(st);                                   // tile g+2 -> the stage tile g-1 left at the last barrier
-        st = st == PL_NS - 1 ? 0 : st + 1;
-        if (ABL & 4) t1 = clock64();
-        CAPMI_X3_VMCNT(12 * (PL_NS - 2));            // tile g+1 landed
-        if (ABL & 4) t2 = clock64();
-        __builtin_amdgcn_s_barrier();
-        if (ABL & 4) { t_issue += t1 - t0; t_land += t2 - t1; t_bar += clock64() - t2; }
-    }
-    if ((ABL & 4) && blockIdx.x == 0 && lane == 0 && hb == 0)
-        printf("x3pl loader %d: %d tiles, cycles per tile: issue %.0f, wait-landed %.0f, wait-barrier %.0f\n", OP, steps,
-               (double)t_issue / steps, (double)t_land / steps, (double)t_bar / steps);
-    CAPMI_X3_VMCNT(0);                               // nothing may still be in flight towards this workgroup's LDS at exit
-}
-
-// ABL (profiling builds only): 1 = no MFMAs (and, the fragments being dead, no LDS reads), 2 = no DMAs, 4 = s_memtime stamps and
-// the shader-clock / 100-MHz-clock ratio printed by workgroup 0, 16 = MFMAs on stale registers (no LDS reads), 32 = LDS reads
-// but no MFMAs.  What they showed (profiles/r03_x3pl_probe.md): MFMA + LDS reads alone run at the matrix pipe's rate for the
-// clock the chip sustains (1.9 GHz, not 2.4); LDS-DMA alone moves a K tile in 0.36 us; TOGETHER the loaders stall AT ISSUE
-// (2 100 of 2 500 cycles per K tile) whenever MFMAs execute on their SIMD -- whether or not anybody reads LDS -- so copy and
-// multiply add up instead of overlapping.  DMAs issued by the MFMA waves themselves, one per MFMA pair, do overlap (2 081 vs
-// 2 505 cycles per tile), and then the clock drops to 1.69 GHz: the power limit is the next wall.
-// 768 threads: waves 0-7 MFMA, TWO per SIMD (64 rows x 32 columns each: while one waits for its fragments or at the barrier the
-// other keeps the SIMD's matrix pipe busy; with one 64x64 wave per SIMD the K tile took 0.89 us for 0.64 us of MFMAs), waves
-// 8-11 loaders.
-template <int ABL = 0, int PL_NS = 3>
-__global__ __launch_bounds__(768) void gemm_x3pl_kernel(const KArgs a, int gm, int gn) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];      // 3 stages = 144 KB
-    const int units = gm * gn * a.splits;
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wid >= 8) {
-        if (wid & 1) x3pl_loader<ABL, 1, PL_NS>(a, gm, gn, units, (wid - 8) >> 1, lane, ldsb);
-        else x3pl_loader<ABL, 0, PL_NS>(a, gm, gn, units, (wid - 8) >> 1, lane, ldsb);
-        return;
-    }
-    const int wm0 = (wid >> 2) * 64, wn0 = (wid & 3) * 32;
-    const int l31 = lane & 31, half = lane >> 5;
-    unsigned long long c0 = 0, r0 = 0, t_sync = 0;
-    int n_sync = 0;
-    if (ABL & 4) { c0 = clock64(); r0 = wall_clock64(); }      // shader-clock vs 100 MHz constant clock: the sustained frequency
-    // fragment of lane (row l31 [+32 q], half) at k-step ks: the row's 16-byte piece 2 ks + half, swizzled by (row >> 2) & 3
-    const int sw = (l31 >> 2) & 3;
-    const int fo[2] = {l31 * 64 + (((0 + half) ^ sw) << 4), l31 * 64 + (((2 + half) ^ sw) << 4)};
-    const unsigned char *Ab = ldsb + (wm0 >> 6) * PL_CH, *Bb = ldsb + PL_OP + (wn0 >> 6) * PL_CH + (wn0 & 32) * 64;
-    auto read_frag = [&](bf16x8 (&av)[2][3], bf16x8 (&bv)[3], int stage, int ks) {
-        if (ABL & 16) return;                              // (probe: MFMAs on stale registers, no LDS reads)
-        const unsigned char *As = Ab + stage * PL_STG + fo[ks], *Bs = Bb + stage * PL_STG + fo[ks];
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            av[0][pl] = *reinterpret_cast<const bf16x8 *>(As + pl * CAPMI_PL_PLANE_BYTES);
-            av[1][pl] = *reinterpret_cast<const bf16x8 *>(As + pl * CAPMI_PL_PLANE_BYTES + 2048);
-            bv[pl] = *reinterpret_cast<const bf16x8 *>(Bs + pl * CAPMI_PL_PLANE_BYTES);
-        }
-    };
-    __syncthreads();                                       // tile 0 ready
-    int st = 0;                                            // stage of the tile being multiplied
-    bf16x8 av0[2][3] = {}, bv0[3] = {}, av1[2][3] = {}, bv1[3] = {};
-    read_frag(av0, bv0, 0, 0);
-    for (int u = blockIdx.x; u < units; u += gridDim.x) {
-        const Unit un = unit_of(a, u, gm, gn);
-        f32x16 acc[2][1];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
-        // six of the nine cross terms, small ones first (planes: 0 = h, 1 = m, 2 = l) -- the order of gemm_x3_kernel
-        auto mfma12 = [&](const bf16x8 (&av)[2][3], const bf16x8 (&bv)[3]) {
-            if (ABL & 32) {                                // (probe: the LDS reads stay, nothing is multiplied)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) asm volatile("" ::"v"(av[0][pl]), "v"(av[1][pl]), "v"(bv[pl]));
-                return;
-            }
-            if (ABL & 1) return;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][2], bv[0], acc[q][0], 0, 0, 0);
-                acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[2], acc[q][0], 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[1], acc[q][0], 0, 0, 0);
-                acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[0], acc[q][0], 0, 0, 0);
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[1], acc[q][0], 0, 0, 0);
-                acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[0], acc[q][0], 0, 0, 0);
-            }
-        };
-        for (int i = 0; i < un.nt; ++i) {
-            const int nx = st == PL_NS - 1 ? 0 : st + 1;
-            read_frag(av1, bv1, st, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma12(av0, bv0);
-            __builtin_amdgcn_sched_barrier(0);
-            unsigned long long tb = 0;
-            if (ABL & 4) tb = clock64();
-            __syncthreads();                               // tile g released (all its reads have completed), tile g+1 ready
-            if (ABL & 4) { t_sync += clock64() - tb; ++n_sync; }
-            read_frag(av0, bv0, nx, 0);                    // (past the last tile: a harmless read of whatever the stage holds)
-            __builtin_amdgcn_sched_barrier(0);
-            mfma12(av1, bv1);
-            __builtin_amdgcn_sched_barrier(0);
-            st = nx;
-        }
-        x3_epilogue<1>(a, un, acc, wm0, wn0, l31, half);
-    }
-    if ((ABL & 4) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const unsigned long long dc = clock64() - c0, dr = wall_clock64() - r0;
-        printf("x3pl clock probe: %llu shader cycles in %llu ticks of 100 MHz = %.0f MHz; MFMA wave 0: %d tiles, %.0f cycles per tile "
-               "of which %.0f in the barrier\n", dc, dr, dr ? 100.0 * dc / dr : 0.0, n_sync, (double)dc / (n_sync ? n_sync : 1),
-               (double)t_sync / (n_sync ? n_sync : 1));
-    }
-}
-
-// fp32 [rows][K] (TR = false) or [K][rows] (TR = true) -> planes of the K-contiguous view: one workgroup per chunk
-// (64 rows x 32 k), rows >= `rows` and k >= K written as zeros (the GEMM never looks at M / K edges of its operands).
-template <bool TR>
-__global__ __launch_bounds__(256) void planes_split_kernel(const float *__restrict__ src, int ld, int rows, int K, int nkc,
-                                                           unsigned char *__restrict__ dst, int vec) {
-    __shared__ float tile[32][65];
-    const int kc = blockIdx.x, rb = blockIdx.y, t = threadIdx.x;
-    const int row = t >> 2, piece = t & 3;           // this thread's output: row, k = 8 piece .. 8 piece + 7 of the chunk
-    float x[8];
-    if (!TR) {
-        const int gr = rb * 64 + row, k0 = kc * 32 + piece * 8;
-        const float *s = src + (size_t)min(gr, rows - 1) * ld + k0;
-        if (vec && gr < rows && k0 + 8 <= K) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(s), a1 = *reinterpret_cast<const f32x4 *>(s + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { x[j] = a0[j]; x[4 + j] = a1[j]; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = (gr < rows && k0 + j < K) ? s[j] : 0.f;
-        }
-    } else {
-        // 32 k rows of 64 contiguous source elements each: 8 lanes x 32 bytes per k row, transposed through LDS
-        const int lk = t >> 3, c0 = (t & 7) * 8;
-        const int gk = kc * 32 + lk, gc = rb * 64 + c0;
-        const float *s = src + (size_t)min(gk, K - 1) * ld + gc;
-        float y[8];
-        if (vec && gk < K && gc + 8 <= rows) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(s), a1 = *reinterpret_cast<const f32x4 *>(s + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { y[j] = a0[j]; y[4 + j] = a1[j]; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) y[j] = (gk < K && gc + j < rows) ? s[j] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) tile[lk][c0 + j] = y[j];
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = tile[piece * 8 + j][row];
-    }
-    uint32_t h[8], m[8], l[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        h[j] = fbits(x[j]);
-        const float r1 = x[j] - bfloat(h[j] & 0xffff0000u);
-        m[j] = fbits(r1);
-        l[j] = fbits(r1 - bfloat(m[j] & 0xffff0000u));
-    }
-    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-    unsigned char *o = dst + ((size_t)rb * nkc + kc) * PL_CH + row * 64 + (((piece ^ (row >> 2)) & 3) << 4);
-    *reinterpret_cast<u32x4_ *>(o) = u32x4_{pack2(h[0], h[1]), pack2(h[2], h[3]), pack2(h[4], h[5]), pack2(h[6], h[7])};
-    *reinterpret_cast<u32x4_ *>(o + CAPMI_PL_PLANE_BYTES) =
-        u32x4_{pack2(m[0], m[1]), pack2(m[2], m[3]), pack2(m[4], m[5]), pack2(m[6], m[7])};
-    *reinterpret_cast<u32x4_ *>(o + 2 * CAPMI_PL_PLANE_BYTES) =
-        u32x4_{pack2(l[0], l[1]), pack2(l[2], l[3]), pack2(l[4], l[5]), pack2(l[6], l[7])};
-}
-
 }  // namespace
 
 int launch_x3(const KArgs &a, int a_layout, int b_layout, dim3 tiles, hipStream_t st, int pcls, double bytes, double flops) {
     // tiles = (gn, gm, splits) of the 128x128 tiling; persistent grid: one workgroup per CU walks the unit list
     const int gn = tiles.x, gm = tiles.y;
     const int units = gn * gm * a.splits;
-    static const int env_wg = [] { const char *e = getenv("CAPMI_X3_WGS"); return e ? atoi(e) : 256; }();
+    static const int env_wg = capmi::research("CAPMI_X3_WGS", 256);
     const dim3 grid(units < env_wg ? units : env_wg);
-    static const int env_nsw = [] { const char *e = getenv("CAPMI_X3_NSW"); return e ? atoi(e) : 8; }();
     hipEvent_t e0, e1;
     const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
     constexpr size_t lds = 2 * (size_t)XSTAGE * sizeof(unsigned short);
@@ -712,9 +455,9 @@ int launch_x3(const KArgs &a, int a_layout, int b_layout, dim3 tiles, hipStream_
     } while (0)
 #define CAPMI_X3(AK, BK_)                                                                                       \
     do {                                                                                                        \
-        if (env_nsw == 8) CAPMI_X3N(AK, BK_, 8);                                                                \
-        else CAPMI_X3N(AK, BK_, 4);                                                                             \
+        CAPMI_X3N(AK, BK_, 8);                                                                                  \
     } while (0)
+#ifdef CAPMI_VARIANTS
 #define CAPMI_X3A(AK, BK_, ABL_)                                                                                \
     do {                                                                                                        \
         static bool attr_set = false;                                                                           \
@@ -740,6 +483,8 @@ int launch_x3(const KArgs &a, int a_layout, int b_layout, dim3 tiles, hipStream_
         CAPMI_CHECK_LAUNCH();
         return 0;
     }
+#undef CAPMI_X3A
+#endif
     if (a_layout == 0 && b_layout == 0) CAPMI_X3(true, true);
     else if (a_layout == 0 && b_layout == 1) CAPMI_X3(true, false);
     else if (a_layout == 1 && b_layout == 1) CAPMI_X3(false, false);
@@ -749,75 +494,4 @@ int launch_x3(const KArgs &a, int a_layout, int b_layout, dim3 tiles, hipStream_
     return 0;
 }
 
-int launch_x3pl(const KArgs &a, dim3 tiles, hipStream_t st, int pcls, double bytes, double flops) {
-    const int gn = tiles.x, gm = tiles.y;
-    const int units = gn * gm * a.splits;
-    static const int env_wg = [] { const char *e = getenv("CAPMI_X3_WGS"); return e ? atoi(e) : 256; }();
-    const dim3 grid(units < env_wg ? units : env_wg);
-    hipEvent_t e0, e1;
-    const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
-    static const int env_ns = [] { const char *e = getenv("CAPMI_X3PL_NS"); return e ? atoi(e) : 3; }();   // experiments: 2
-    if (env_ns == 2) {
-        constexpr size_t lds2 = (size_t)2 * PL_STG;
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_x3pl_kernel<0, 2>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            attr2 = true;
-        }
-        hipLaunchKernelGGL((gemm_x3pl_kernel<0, 2>), grid, dim3(768), lds2, st, a, gm, gn);
-        CAPMI_CHECK_LAUNCH();
-        return 0;
-    }
-    constexpr size_t lds = (size_t)3 * PL_STG;
-#define CAPMI_X3PL(ABL_)                                                                                        \
-    do {                                                                                                        \
-        static bool attr_set = false;                                                                           \
-        if (!attr_set) {                                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_x3pl_kernel<ABL_>),                  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
-            attr_set = true;                                                                                    \
-        }                                                                                                       \
-        if (prof) hipExtLaunchKernelGGL((gemm_x3pl_kernel<ABL_>), grid, dim3(768), lds, st, e0, e1, 0, a, gm, gn);  \
-        else hipLaunchKernelGGL((gemm_x3pl_kernel<ABL_>), grid, dim3(768), lds, st, a, gm, gn);                 \
-    } while (0)
-    if ((a.ablate & 63) == 20) CAPMI_X3PL(20);
-    else if ((a.ablate & 63) == 36) CAPMI_X3PL(36);
-    else if ((a.ablate & 7) == 4) CAPMI_X3PL(4);
-    else if ((a.ablate & 7) == 6) CAPMI_X3PL(6);
-    else if ((a.ablate & 3) == 1) CAPMI_X3PL(1);
-    else if ((a.ablate & 3) == 2) CAPMI_X3PL(2);
-    else if ((a.ablate & 3) == 3) CAPMI_X3PL(3);
-    else CAPMI_X3PL(0);
-#undef CAPMI_X3PL
-    CAPMI_CHECK_LAUNCH();
-    return 0;
-}
-
 }  // namespace capmi_gemm
-
-extern "C" {
-
-int64_t capmi_planes_fat_bytes(int rows, int K) {
-    if (rows <= 0 || K <= 0) return 0;
-    return (int64_t)((rows + 127) / 128) * 2 * ((K + 31) / 32) * CAPMI_PL_CHUNK_BYTES;
-}
-
-int capmi_planes_split(const float *src, int ld, int rows, int K, int transposed, void *planes, void *stream) {
-    if (!src || !planes || rows <= 0 || K <= 0 || ld < (transposed ? rows : K)) return CAPMI_EINVAL;
-    if (reinterpret_cast<uintptr_t>(planes) & 15) return CAPMI_EINVAL;
-    const int nkc = (K + 31) / 32, nrb = ((rows + 127) / 128) * 2;
-    const int vec = ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && ld % 4 == 0) ? 1 : 0;
-    const dim3 grid(nkc, nrb);
-    using namespace capmi_gemm;
-    if (transposed)
-        hipLaunchKernelGGL(planes_split_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, ld, rows, K, nkc,
-                           static_cast<unsigned char *>(planes), vec);
-    else
-        hipLaunchKernelGGL(planes_split_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, ld, rows, K, nkc,
-                           static_cast<unsigned char *>(planes), vec);
-    CAPMI_CHECK_LAUNCH();
-    return 0;
-}
-
-}  // extern "C"

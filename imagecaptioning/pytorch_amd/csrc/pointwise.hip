@@ -874,19 +874,14 @@ int capmi_adam_step(float *p, const float *g, float *m, float *v, int64_t count,
         return CAPMI_EINVAL;
     const double bc1 = 1.0 - pow((double)beta1, step);
     const double bc2 = 1.0 - pow((double)beta2, step);
-    static const int variant = [] { const char *e = getenv("CAPMI_ADAM_V"); return e ? atoi(e) : 2; }();   // 0: the round-1 kernel
-    if (variant && count % 4 == 0) {
+    if (count % 4 == 0) {                           // the flat buffers are padded to 64 floats (flat.py): always this branch on the path
         const size_t quads = (size_t)count / 4;
-        if (variant == 2) hipLaunchKernelGGL(adam2_kernel<true>, dim3(grid_for(quads / 2 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m,
-                                             v, quads, lr, beta1, beta2, eps, weight_decay, clip, grad_scale, (float)bc1, (float)sqrt(bc2));
-        else hipLaunchKernelGGL(adam2_kernel<false>, dim3(grid_for(quads / 2 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, quads,
-                                lr, beta1, beta2, eps, weight_decay, clip, grad_scale, (float)bc1, (float)sqrt(bc2));
-        CAPMI_CHECK_LAUNCH();
-        return 0;
+        hipLaunchKernelGGL(adam2_kernel<true>, dim3(grid_for(quads / 2 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, quads, lr,
+                           beta1, beta2, eps, weight_decay, clip, grad_scale, (float)bc1, (float)sqrt(bc2));
+    } else {                                        // any other count: plain quads + scalar tail
+        hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)count / 4 + 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                           (size_t)count, lr, beta1, beta2, eps, weight_decay, clip, grad_scale, (float)bc1, (float)sqrt(bc2));
     }
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)count / 4 + 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                       (size_t)count, lr, beta1, beta2, eps, weight_decay, clip, grad_scale, (float)bc1,
-                       (float)sqrt(bc2));
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

@@ -51,7 +51,6 @@ int gemm(void *stream, int a_layout, int b_layout, int M, int N, float *C, int l
         d.seg[i].K = segs[i].K; d.seg[i].a_row_div = segs[i].a_row_div > 0 ? segs[i].a_row_div : 1;
         d.a_planes[i] = zero_planes ? segs[i].Apl : nullptr;
     }
-    d.zero_planes = zero_planes;
     d.a_layout = a_layout; d.b_layout = b_layout;
     d.M = M; d.N = N; d.C = C; d.ldc = ldc;
     d.bias = bias; d.bias2 = bias2;
@@ -189,28 +188,6 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
         pl_zero = q + 4 * nR + nE;
     }
 
-    // Side stream of the AHEAD gate GEMMs (capmi.h capmi_updown_rollout.pre_partial): 2/3 of each LSTM gate GEMM's K depends only
-    // on hidden states of earlier launches and can stream beside the step's latency-bound kernels instead of on its critical path.
-    // OPT-IN (CAPMI_PRE_STREAM=1), because it measured WORSE: the gate GEMMs on the critical path drop from 16.4 to 11.8 / 9.0 us
-    // as predicted and the side GEMMs do hide under select / attention, but every hipEventRecord / hipStreamWaitEvent on the
-    // main stream leaves a ~7 us hole in it (rocprofv3 timeline, profiles/r03_pre_stream_timeline.md): 4 per step = +28 us
-    // against -12 us, 4.65 vs 4.36 ms per iteration.  Cross-queue dependencies cost more than a kernel boundary on this stack.
-    static const bool pre_env = [] { const char *e = getenv("CAPMI_PRE_STREAM"); return e && atoi(e) != 0; }();
-    const bool use_pre = pre_env && pl_zero && r->pre_partial && !r->teacher &&
-                         r->pre_capacity / 2 >= CAPMI_WS_COUNTER_FLOATS + (int64_t)8 * N * 4 * R;
-    static thread_local hipStream_t s2 = nullptr;
-    static thread_local hipEvent_t pre_ev[4][8];        // [E_a | P_l | E_l | P_a][step & 7]
-    if (use_pre && !s2) {
-        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return CAPMI_EINVAL;
-        for (auto &k : pre_ev)
-            for (auto &e : k)
-                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CAPMI_EINVAL;
-    }
-    float *preA = use_pre ? r->pre_partial : nullptr, *preL = use_pre ? r->pre_partial + r->pre_capacity / 2 : nullptr;
-    const int64_t pre_cap = r->pre_capacity / 2;
-    int preA_splits = 0, preL_splits = 0;
-    bool preA_pending = false;
-#define HIPRC(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return (int)e__; } while (0)
 
     // initial state (slot 0) and flags
     RC(capmi_rollout_init(r->h_att, r->c_att, r->h_lang, r->c_lang, (int64_t)NR, r->it, r->unfinished, N, stream));   // bos = 0
@@ -237,7 +214,7 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
     int ee_pending = -1, ee_slot = 0, steps_run = T;
     const int ee_from = r->early_exit_from > 0 ? r->early_exit_from : 0;
 
-    static const bool ee_trace = [] { const char *e = getenv("CAPMI_EE_TRACE"); return e && atoi(e) != 0; }();
+    static const bool ee_trace = capmi::research("CAPMI_EE_TRACE", 0) != 0;
     const auto ee_t0 = std::chrono::steady_clock::now();
     double ee_wait_us = 0;
     for (int t = 0; t < T; ++t) {
@@ -277,29 +254,11 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
             SegSpec s[3] = {{h_lang_prev, R, w->att_w_ih, ld_att_ih, R, 1, t ? pl_h_lang : pl_zero},
                             {xt, E, w->att_w_ih + 2 * R, ld_att_ih, E, 1, pl_xt},
                             {h_att_prev, R, w->att_w_hh, R, R, 1, t ? pl_h_att : pl_zero}};
-            if (use_pre)        // the h_lang / h_att segments were requested on the side stream behind the previous step's logit GEMM
-                RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s + 1, 1, r->partial, r->partial_capacity, 1, &splits, nullptr,
-                        nullptr, 0, pl_zero));
-            else
-                RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s, 3, r->partial, r->partial_capacity, 1, &splits, nullptr,
-                        nullptr, 0, pl_zero));
-            if (preA_pending) {
-                HIPRC(hipStreamWaitEvent(st, pre_ev[3][t & 7], 0));
-                preA_pending = false;
-            }
-            RC(capmi_lstm_cell_fwd_pl2(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, use_pre && t ? preA + CAPMI_WS_COUNTER_FLOATS : nullptr,
-                                       use_pre && t ? preA_splits : 0, w->att_b_ih, w->att_b_hh, r->fc_gates, n, r->row_img,
+            RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s, 3, r->partial, r->partial_capacity, 1, &splits, nullptr,
+                    nullptr, 0, pl_zero));
+            RC(capmi_lstm_cell_fwd_pl2(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, nullptr, 0, w->att_b_ih, w->att_b_hh, r->fc_gates, n, r->row_img,
                                        c_att_prev, h_att, c_att, r->gates_att + (size_t)t * N * 4 * R, nullptr, nullptr, N, R,
                                        pl_h_att, nullptr, stream));
-            if (use_pre) {
-                // language-LSTM segments [h_att(t) | h_lang(t-1)] beside h2att + attention
-                HIPRC(hipEventRecord(pre_ev[0][t & 7], st));
-                HIPRC(hipStreamWaitEvent(s2, pre_ev[0][t & 7], 0));
-                SegSpec p[2] = {{h_att, R, w->lang_w_ih + R, 2 * R, R, 1, pl_h_att},
-                                {h_lang_prev, R, w->lang_w_hh, R, R, 1, t ? pl_h_lang : pl_zero}};
-                RC(gemm(s2, 0, 0, N, 4 * R, preL, 4 * R, p, 2, preL, pre_cap, 1, &preL_splits, nullptr, nullptr, 0, pl_zero, 6));
-                HIPRC(hipEventRecord(pre_ev[1][t & 7], s2));
-            }
         }
         // 4-5. att_h = h_att W_h2att^T + b left as K-slice slabs; the fused region attention finishes the reduction
         //      (+ bias), keeps att_h for the backward pass and runs score + softmax + context
@@ -316,11 +275,9 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
             SegSpec s[3] = {{ctx, R, w->lang_w_ih, 2 * R, R, 1, pl_ctx},
                             {h_att, R, w->lang_w_ih + R, 2 * R, R, 1, pl_h_att},
                             {h_lang_prev, R, w->lang_w_hh, R, R, 1, t ? pl_h_lang : pl_zero}};
-            RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s, use_pre ? 1 : 3, r->partial, r->partial_capacity, 1, &splits,
+            RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s, 3, r->partial, r->partial_capacity, 1, &splits,
                     nullptr, nullptr, 0, pl_zero));
-            if (use_pre) HIPRC(hipStreamWaitEvent(st, pre_ev[1][t & 7], 0));
-            RC(capmi_lstm_cell_fwd_pl2(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, use_pre ? preL + CAPMI_WS_COUNTER_FLOATS : nullptr,
-                                       use_pre ? preL_splits : 0, w->lang_b_ih, w->lang_b_hh, nullptr, 1, nullptr, c_lang_prev,
+            RC(capmi_lstm_cell_fwd_pl2(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, nullptr, 0, w->lang_b_ih, w->lang_b_hh, nullptr, 1, nullptr, c_lang_prev,
                                        h_lang, c_lang, r->gates_lang + (size_t)t * N * 4 * R,
                                        r->drop_out ? r->drop_out + (size_t)t * NR : nullptr, h_drop, N, R, pl_h_lang,
                                        batched_logit ? nullptr : pl_h_drop, stream));
@@ -332,15 +289,6 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
             SegSpec s{h_drop, R, w->logit_w, R, R, 1, pl_h_drop};
             RC(gemm(stream, 0, 0, N, V1, r->partial, V1, &s, 1, r->partial, r->partial_capacity, 1, &splits, nullptr, nullptr, 0,
                     pl_zero));
-        }
-        if (use_pre && t + 1 < T) {
-            // attention-LSTM segments [h_lang(t) | h_att(t)] of step t + 1 beside log-softmax + select
-            HIPRC(hipEventRecord(pre_ev[2][t & 7], st));
-            HIPRC(hipStreamWaitEvent(s2, pre_ev[2][t & 7], 0));
-            SegSpec p[2] = {{h_lang, R, w->att_w_ih, ld_att_ih, R, 1, pl_h_lang}, {h_att, R, w->att_w_hh, R, R, 1, pl_h_att}};
-            RC(gemm(s2, 0, 0, N, 4 * R, preA, 4 * R, p, 2, preA, pre_cap, 1, &preA_splits, nullptr, nullptr, 0, pl_zero, 6));
-            HIPRC(hipEventRecord(pre_ev[3][(t + 1) & 7], s2));
-            preA_pending = true;
         }
         capmi_sample_filter flt{r->top_k, r->top_p};
         capmi_next_embed ne{};
@@ -374,11 +322,6 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
             ee_pending = t;
         }
     }
-    if (use_pre) {      // whatever the side stream still holds (an early exit leaves one GEMM behind) is ordered before what follows
-        HIPRC(hipEventRecord(pre_ev[0][0], s2));
-        HIPRC(hipStreamWaitEvent(st, pre_ev[0][0], 0));
-    }
-#undef HIPRC
     if (ee_trace)
         fprintf(stderr, "capmi rollout: %d of %d steps enqueued in %.0f us of host time, of which %.0f us blocked on the alive flag\n",
                 steps_run, T, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ee_t0).count(), ee_wait_us);
@@ -526,7 +469,7 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
     float *P1 = P + capm, *Ph = P + capm + cap1;
     if (phases & CAPMI_BWD_RECURRENT) {
     if (capm <= CAPMI_WS_COUNTER_FLOATS || cap1 <= CAPMI_WS_COUNTER_FLOATS || caph <= CAPMI_WS_COUNTER_FLOATS) return CAPMI_EINVAL;
-    static const bool self_reduce = [] { const char *e = getenv("CAPMI_GEMM_SELF_REDUCE"); return e && atoi(e); }();
+    static const bool self_reduce = capmi::research("CAPMI_GEMM_SELF_REDUCE", 0) != 0;
     if (self_reduce) {   // ticket words of the carved regions start zeroed like the main one (only the in-launch reduction reads them)
         hipError_t e = hipMemsetAsync(P1, 0, CAPMI_WS_COUNTER_FLOATS * sizeof(float), st);
         if (e == hipSuccess) e = hipMemsetAsync(Ph, 0, CAPMI_WS_COUNTER_FLOATS * sizeof(float), st);

@@ -8,6 +8,8 @@ would be frozen into the graph.
 """
 import torch
 
+from . import ops
+
 
 class GraphedDecode:
     def __init__(self, max_entries=8):
@@ -23,8 +25,8 @@ class GraphedDecode:
             torch.cuda.synchronize()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):                       # warm-up outside capture: lazy module loads, attributes
-                fn(*static)
+            with torch.cuda.stream(side), ops.capture_scratch():  # warm-up outside capture: lazy module loads, attributes,
+                fn(*static)                                       # and the zero-filled scratch the capture will reuse
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()

@@ -50,22 +50,16 @@ def default_workspace(device):
 
 
 def gemm(segs, M, N, out, ldc=None, a_layout=0, b_layout=0, bias=None, bias2=None, row_bias=None, row_bias_div=1,
-         mul_mask=None, relu=False, accumulate=False, ws=None, splits=0, defer_reduce=False, a_planes=None, b_planes=None):
+         mul_mask=None, relu=False, accumulate=False, ws=None, splits=0, defer_reduce=False, a_planes=None):
     """segs: list of (A, lda, B, ldb, K, a_row_div) with tensors (or (tensor, element_offset) pairs).
     a_planes: optional list (one uint8 tensor per segment, see planes_from_f32) -- the activations also delivered pre-split,
-    staged by LDS-DMA in the M <= 64 decode kernel.  b_planes (with a_planes, M > 64: planes_split): both operands of a fat
-    GEMM as planes of their K-contiguous views; A / B of a segment may then be None.  Returns splits_used."""
+    staged by LDS-DMA in the M <= 64 decode kernel.  Returns splits_used."""
     d = _lib.GemmDesc()
     d.nseg = len(segs)
     if a_planes is not None:
         assert len(a_planes) == len(segs)
         for i, t in enumerate(a_planes):
             d.a_planes[i] = t.data_ptr()
-        d.zero_planes = zero_planes(_dev(out)).data_ptr()
-    if b_planes is not None:
-        assert len(b_planes) == len(segs)
-        for i, t in enumerate(b_planes):
-            d.b_planes[i] = t.data_ptr()
     for i, (A, lda, B, ldb, K, div) in enumerate(segs):
         d.seg[i].A = None if A is None else _addr(A)
         d.seg[i].B = None if B is None else _addr(B)
@@ -90,20 +84,45 @@ _planes_cache = {}
 
 
 def zero_planes(device, chunks=1):
-    """>= `chunks` all-zero chunk images (the padding operand of the A-planes GEMM), allocated once per device."""
+    """>= `chunks` all-zero chunk images (the planes of an all-zero activation, e.g. the initial LSTM state), allocated once per device."""
     key = str(device)
     t = _zero_planes.get(key)
     if t is None or t.numel() < chunks * 12288:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('zero planes requested for the first time inside a graph capture (warm the function up first)')
         t = _zero_planes[key] = torch.zeros(max(chunks, 4) * 12288, dtype=torch.uint8, device=device)
     return t
 
 
+_capture_scratch = [0]
+
+
+class capture_scratch:
+    """`with ops.capture_scratch():` around the eager WARM-UP of a function that is about to be captured into a hipGraph
+    (graphs.GraphedDecode): scratch requested inside is filed under the key the capture will ask for, so it is allocated and
+    zero-filled eagerly -- a torch.zeros recorded INTO a graph would only run when that graph replays, while the buffer is
+    cached process-wide."""
+
+    def __enter__(self):
+        _capture_scratch[0] += 1
+
+    def __exit__(self, *a):
+        _capture_scratch[0] -= 1
+        return False
+
+
 def planes_scratch(device, tag, nbytes):
-    """Zero-filled-once scratch for A planes, cached per (device, tag, size): rows >= M / columns >= K of a planes buffer are
-    never written, so a buffer keeps its zero padding across the rollouts that reuse it."""
-    key = (str(device), tag, int(nbytes))
+    """Zero-filled-once scratch for A planes, cached per (device, tag, size, stream): rows >= M / columns >= K of a planes buffer
+    are never written, so a buffer keeps its zero padding across the rollouts that reuse it; concurrent streams get their own.
+    Graph captures share one slot that their warm-up fills (capture_scratch); allocating while capturing is refused."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    slot = 'capture' if (capturing or _capture_scratch[0]) else stream_ptr()
+    key = (str(device), tag, int(nbytes), slot)
     t = _planes_cache.get(key)
     if t is None:
+        if capturing:
+            raise RuntimeError('planes scratch %r requested for the first time inside a graph capture: run the function once '
+                               'under ops.capture_scratch() before capturing it' % (tag,))
         t = _planes_cache[key] = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
     return t
 
@@ -115,20 +134,6 @@ def planes_from_f32(x, out=None):
     if out is None:
         out = torch.zeros(int(lib.capmi_planes_bytes(K)), dtype=torch.uint8, device=x.device)
     check(lib.capmi_planes_from_f32(x.data_ptr(), x.stride(0), M, K, out.data_ptr(), stream_ptr()), 'capmi_planes_from_f32')
-    return out
-
-
-def planes_split(x, transposed=False, out=None):
-    """Planes of a fat GEMM operand (capmi.h capmi_planes_split).  x: the operand's K-contiguous view [rows, K], or with
-    transposed=True its transpose [K, rows] (row stride x.stride(0), unit column stride)."""
-    assert x.is_cuda and x.dtype == _f32 and x.dim() == 2 and x.stride(1) == 1
-    rows, K = (x.shape[1], x.shape[0]) if transposed else (x.shape[0], x.shape[1])
-    nbytes = int(lib.capmi_planes_fat_bytes(rows, K))
-    if out is None:
-        out = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    assert out.numel() >= nbytes
-    check(lib.capmi_planes_split(x.data_ptr(), x.stride(0), rows, K, int(transposed), out.data_ptr(), stream_ptr()),
-          'capmi_planes_split')
     return out
 
 

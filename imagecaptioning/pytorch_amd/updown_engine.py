@@ -191,18 +191,12 @@ class Rollout:
                   'ctx', 'h_drop', 'seq', 'seq_logp', 'sel_logp', 'live', 'fc_gates', 'logits', 'it', 'unfinished'):
             setattr(r, k, getattr(self, k).data_ptr())
         r.partial, r.partial_capacity = self.ws.buf.data_ptr(), self.ws.capacity
-        if N <= 64 and os.environ.get('CAPMI_APL', '1') != '0':
+        if N <= 64 and os.environ.get('CAPMI_PLANES', '1') != '0':
             # decode GEMMs stage their activations as producer-written bf16x3 planes (capmi.h capmi_updown_rollout.planes);
             # the scratch is zero-filled once and shared by the rollouts of this stream with the same R / E
             nb = int(lib.capmi_updown_planes_bytes(R, E))
-            self.planes = ops.planes_scratch(dev, ('updown_fwd', R, E, stream_ptr()), nb)
+            self.planes = ops.planes_scratch(dev, ('updown_fwd', R, E), nb)
             r.planes, r.planes_bytes = self.planes.data_ptr(), nb
-            if not teacher and os.environ.get('CAPMI_PRE_STREAM', '0') == '1':       # opt-in: measured slower (rollout.hip)
-                # workspace of the AHEAD gate GEMMs on the library's side stream (capmi.h capmi_updown_rollout.pre_partial):
-                # two regions of [ticket words | up to 8 K-slice slabs of N x 4R]
-                per = ops.Workspace.COUNTER_FLOATS + 8 * 64 * 4 * R
-                self.pre = ops.planes_scratch(dev, ('updown_pre', R, stream_ptr()), 2 * per * 4).view(torch.float32)
-                r.pre_partial, r.pre_capacity = self.pre.data_ptr(), 2 * per
         # early exit of free-running rollouts (AttModel.py:349-350): behind steps early_exit_from + k * early_exit - 1 (7, 11, 15 by
         # default) the driver looks, two steps later, at a pinned word the select kernels set and stops enqueuing once every row
         # has emitted its EOS (CAPMI_EARLY_EXIT=0: never)
@@ -253,9 +247,9 @@ class Rollout:
             nb = B * n
             keep['pack'] = z(nb * (T * (4 * R + 2 * E + 2 + A + K) + R) + 64)
             s.n_grad_rows, s.pack, s.pack_capacity = nb, keep['pack'].data_ptr(), keep['pack'].numel()
-        if (s.n_grad_rows or N) <= 64 and os.environ.get('CAPMI_APL', '1') != '0':
+        if (s.n_grad_rows or N) <= 64 and os.environ.get('CAPMI_PLANES', '1') != '0':
             nb = int(lib.capmi_updown_bwd_planes_bytes(R))
-            keep['planes'] = ops.planes_scratch(dev, ('updown_bwd', R, stream_ptr()), nb)
+            keep['planes'] = ops.planes_scratch(dev, ('updown_bwd', R), nb)
             s.planes, s.planes_bytes = keep['planes'].data_ptr(), nb
         g = _lib.UpDownGrads()
         for f, k in _W_FIELDS:

@@ -85,16 +85,10 @@ typedef struct capmi_gemm_desc {
     int splits;                 /* 0 = auto */
     int defer_reduce;           /* leave partials for a fused consumer (e.g. capmi_lstm_cell_fwd) */
     int splits_used;            /* out: number of K slices actually written */
-    /* optional (round 3, M <= 64 decode GEMMs): segment s's activations ALSO delivered pre-split as "A planes" (see
-     * capmi_planes_from_f32); with planes for every segment and zero_planes (>= capmi_planes_bytes(32) bytes of zeros) the
-     * activations are staged by LDS-DMA instead of being split inside every workgroup.  Same result bit for bit. */
+    /* optional (M <= 64 decode GEMMs): segment s's activations ALSO delivered pre-split as "A planes" (see
+     * capmi_planes_from_f32); with planes for every segment the loader / consumer kernel stages them by LDS-DMA instead of
+     * splitting them inside every workgroup.  Same result bit for bit. */
     const void *a_planes[CAPMI_MAX_SEG];
-    const void *zero_planes;
-    /* optional (round 3, fat GEMMs: M > 64): BOTH operands of every segment delivered as planes of their K-contiguous views
-     * -- a_planes[s] = planes of A as [M][K], b_planes[s] = planes of B as [N][K], whatever a_layout / b_layout say about the
-     * fp32 images (capmi_planes_split transposes) -- in the row-blocked format of capmi_planes_split.  The GEMM then stages
-     * by LDS-DMA only and splits nothing; seg[s].A / seg[s].B may be NULL.  Same result bit for bit. */
-    const void *b_planes[CAPMI_MAX_SEG];
 } capmi_gemm_desc;
 
 int capmi_gemm_f32(capmi_gemm_desc *d, void *stream);
@@ -107,16 +101,6 @@ int capmi_gemm_f32(capmi_gemm_desc *d, void *stream);
  * capmi_lstm_cell_bwd_partial_pl) write the planes themselves; this call converts any other operand. */
 int64_t capmi_planes_bytes(int K);
 int capmi_planes_from_f32(const float *X, int ld, int M, int K, void *planes, void *stream);
-
-/* Planes of a FAT operand (any number of rows): the same chunk image in 64-row blocks, chunk (rb, kc) at byte
- * (rb * ceil(K/32) + kc) * 12288, rows padded to a multiple of 128 and K to a multiple of 32 WITH ZEROS written by this call
- * (no pre-zeroing needed).  src is the operand's K-contiguous view [rows][K] (transposed = 0, row pitch ld) or its transpose
- * [K][rows] (transposed = 1: what dW = dG^T X holds for both of its operands; the pass transposes through LDS).  For
- * rows <= 64 the image is the "A planes" image above.  Replaces the per-workgroup split of the fp32 fat GEMM (the reference's
- * torch.matmul / F.linear backward at captioning/models/AttModel.py:615-640 run under autograd): one pass per operand instead
- * of one split per (operand element, output tile that uses it). */
-int64_t capmi_planes_fat_bytes(int rows, int K);
-int capmi_planes_split(const float *src, int ld, int rows, int K, int transposed, void *planes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused additive region attention, forward (AttModel.py:728-748 Attention.forward; the
@@ -203,9 +187,8 @@ int capmi_lstm_cell_fwd_pl(const float *partial, int splits, const float *b_ih, 
                            const float *row_bias, int row_bias_div, const int32_t *row_bias_idx, const float *c_prev,
                            float *h, float *c, float *gates_act, const float *out_mask, float *h_drop,
                            int N, int R, void *h_planes, void *h_drop_planes, void *stream);
-/* Same; the gate pre-activations are the sum of TWO slab sets (same slab stride N*4R): `partial` and `partial2` -- the K
- * segments of the gate GEMM that depend only on the previous hidden states are computed ahead on a side stream
- * (capmi_updown_rollout.pre_partial) and meet the rest here.  splits2 = 0: one set. */
+/* Same; the gate pre-activations are the sum of TWO slab sets (same slab stride N*4R): `partial` and `partial2` (K segments of
+ * the gate GEMM computed by separate launches meet here).  splits2 = 0: one set. */
 int capmi_lstm_cell_fwd_pl2(const float *partial, int splits, const float *partial2, int splits2, const float *b_ih,
                             const float *b_hh, const float *row_bias, int row_bias_div, const int32_t *row_bias_idx,
                             const float *c_prev, float *h, float *c, float *gates_act, const float *out_mask, float *h_drop,
@@ -532,14 +515,6 @@ typedef struct capmi_updown_rollout {
     int early_exit_from;
     int32_t *alive_host;
     int steps_run;
-    /* Round 3, optional (needs `planes`): workspace of the AHEAD gate GEMMs, 2 regions of pre_capacity / 2 floats (each laid
-     * out like `partial`: CAPMI_WS_COUNTER_FLOATS ticket words + K-slice slabs).  The K segments of the two LSTM gate GEMMs that
-     * depend only on hidden states of the previous launches -- [h_lang | h_att] of the attention LSTM, [h_att | h_lang] of the
-     * language LSTM: 2/3 of their 48 MB -- are enqueued on a second HIP stream of the library's and stream beside the
-     * latency-bound kernels of the step (log-softmax + select, h2att + attention); the gate GEMM on the critical path keeps
-     * the newest segment (token embedding / context) and the LSTM cell sums both slab sets.  NULL: everything on `stream`. */
-    float *pre_partial;
-    int64_t pre_capacity;
 } capmi_updown_rollout;
 
 int64_t capmi_updown_planes_bytes(int R, int E);

@@ -54,23 +54,3 @@ def planes_to_f32(pl, M, K):
     for p in (2, 1, 0):
         acc = acc + (u16[(off + p * PLANE) // 2].astype(np.uint32) << 16).view(np.float32)
     return acc
-
-
-def fat_bytes(rows, K):
-    """capmi_planes_fat_bytes: rows padded to 128, K to 32"""
-    return (rows + 127) // 128 * 2 * ((K + 31) // 32) * CHUNK
-
-
-def planes_split(x):
-    """capmi_planes_split of the K-contiguous view x [rows, K] (callers pass src.T for transposed = 1): 64-row blocks,
-    chunk (rb, kc) at (rb * ceil(K/32) + kc) * CHUNK, padding rows / columns zero."""
-    rows, K = x.shape
-    nkc = (K + 31) // 32
-    out = np.zeros(fat_bytes(rows, K) // 2, dtype=np.uint16)
-    parts = split3(x)
-    r, ks = np.meshgrid(np.arange(rows), np.arange(K), indexing='ij')
-    kk, rr = ks & 31, r & 63
-    off = ((r >> 6) * nkc + (ks >> 5)) * CHUNK + rr * 64 + ((((kk >> 3) ^ (rr >> 2)) & 3) << 4) + ((kk & 7) << 1)
-    for p in range(3):
-        out[(off + p * PLANE) // 2] = parts[p]
-    return out.view(np.uint8)

@@ -39,21 +39,3 @@ def test_clip_len_is_cached_on_the_mask():
     assert clip_len(m) == 3 and m._capmi_kmax == 3
     m._capmi_kmax = 2                      # a loader-stamped value wins (no sum over the mask)
     assert clip_len(m) == 2
-
-
-def test_fat_planes_are_row_blocked_a_planes():
-    """oracle planes_split: for rows <= 64 the fat image is the A-planes image; block (rb, kc) sits at (rb * nkc + kc) chunks and
-    the padding (rows to 128, K to 32) is zero"""
-    rng = np.random.default_rng(1)
-    x = rng.standard_normal((60, 70)).astype(np.float32)
-    a, f = PL.planes_from_f32(x), PL.planes_split(x)
-    assert f.size == PL.fat_bytes(60, 70) == 2 * 3 * 12288
-    assert np.array_equal(f[:a.size], a) and not f[a.size:].any()
-    y = rng.standard_normal((130, 40)).astype(np.float32)
-    f = PL.planes_split(y)
-    assert f.size == 4 * 2 * 12288
-    for rb in range(3):
-        blk = y[64 * rb:64 * rb + 64]
-        want = PL.planes_from_f32(blk)
-        assert np.array_equal(f[rb * 2 * 12288:(rb + 1) * 2 * 12288], want), rb
-    assert not f[3 * 2 * 12288:].any()

@@ -1,5 +1,4 @@
-"""Round 3: the decode GEMMs take PRODUCER-WRITTEN bf16x3 "A planes" and stage them by LDS-DMA (gemm_lc.hip loader / consumer
-kernel; gemm_ares.hip gemm_apl_kernel with CAPMI_LC=0).
+"""The decode GEMMs take PRODUCER-WRITTEN bf16x3 "A planes" and stage them by LDS-DMA (gemm_lc.hip loader / consumer kernel).
 Checked here, through the C ABI: the conversion entry point and every fused producer against the numpy restatement of
 the layout (oracle/planes.py, bit-exact); the planes GEMM against fp64 (fp32-grade error) and against the in-kernel-split
 GEMM; a rollout with planes against the same rollout without."""
@@ -170,7 +169,7 @@ def test_rollout_with_planes_agrees_with_rollout_without(dev, monkeypatch):
     out = {}
     seq_on = None
     for flag in ('1', '0', 'free'):
-        monkeypatch.setenv('CAPMI_APL', '1' if flag == '1' else '0')
+        monkeypatch.setenv('CAPMI_PLANES', '1' if flag == '1' else '0')
         kw = dict(mode='sample', gumbel=gum) if flag != '0' else dict(mode='forced', forced=seq_on)
         ro = E.Rollout(P, pr, n=n, T=L, drop_xt=drop_xt, drop_out=drop_out, **kw)
         assert (ro.r.planes is not None) == (flag == '1')
@@ -198,105 +197,3 @@ def test_rollout_with_planes_agrees_with_rollout_without(dev, monkeypatch):
     print('relative gradient differences planes on / off:', {k: '%.1e' % v for k, v in errs.items() if v > 1e-5})
     # fp32 accumulation-order noise through 20 steps of BPTT (the oracle comparisons of test_full_size_parity_gpu.py allow 1e-3)
     assert max(errs.values()) < 5e-4, {k: v for k, v in errs.items() if v > 1e-5}
-
-
-def test_side_stream_gate_gemms_agree_with_the_single_stream_step(dev, monkeypatch):
-    """Round 3: the K segments of the LSTM gate GEMMs that depend only on earlier hidden states are computed ahead on a second HIP
-    stream (beside log-softmax + select and h2att + attention) and meet the rest in the LSTM cell.  Same operands, another
-    summation order: free-running tokens coincide, log-probs / gradients agree to fp32 accumulation noise; with early exit and
-    a model that ends its captions the side stream is joined cleanly."""
-    from imagecaptioning.pytorch_amd import updown_engine as E
-    from shapes import full_size_params
-    torch.manual_seed(1)
-    B, n, K, R, Em, V1, L = 10, 5, 36, 1000, 1000, 9488, 20
-    P = {k: v.to(dev).contiguous() for k, v in full_size_params(seed=4).items()}
-    fc = torch.randn(B, 2048, device=dev).clamp_min(0)
-    att = torch.randn(B, K, 2048, device=dev).clamp_min(0)
-    pr = E.prepare(P, fc, att, None)
-    N = B * n
-    gum = torch.rand(L, N, V1, device=dev).clamp_min(1e-12).log().neg().log().neg()
-    drop_xt = (torch.rand(L, N, Em, device=dev) < 0.5).float() * 2
-    drop_out = (torch.rand(L, N, R, device=dev) < 0.5).float() * 2
-    gsel = -torch.rand(N, L, 1, device=dev)
-    out, seq_on = {}, None
-    for flag in ('1', '0'):
-        monkeypatch.setenv('CAPMI_PRE_STREAM', flag)
-        kw = dict(mode='sample', gumbel=gum) if flag == '1' else dict(mode='forced', forced=seq_on)
-        ro = E.Rollout(P, pr, n=n, T=L, drop_xt=drop_xt, drop_out=drop_out, **kw)
-        assert (ro.r.pre_partial is not None) == (flag == '1')
-        seq, slp = ro.run()
-        if flag == '1':
-            seq_on = seq.clone()
-        grads = {k: torch.zeros_like(P[k]) for k in E.PARAM_KEYS}
-        gsl = torch.zeros_like(slp)
-        gsl.scatter_(2, seq_on.unsqueeze(-1), gsel)
-        ro.backward(gsl, grads)
-        torch.cuda.synchronize()
-        out[flag] = (seq.clone(), slp.gather(2, seq_on.unsqueeze(-1)).clone(), {k: v.clone() for k, v in grads.items()})
-    a, b = out['1'], out['0']
-    assert torch.equal(a[0], b[0])
-    assert float((a[1] - b[1]).abs().max()) < 2e-5
-    errs = {k: float((a[2][k] - b[2][k]).abs().max()) / (float(b[2][k].abs().max()) + 1e-30) for k in a[2]
-            if k != 'core.attention.alpha_net.bias'}
-    assert max(errs.values()) < 5e-4, {k: v for k, v in errs.items() if v > 1e-5}
-    # free-running without the side stream: the same tokens (near-ties aside)
-    monkeypatch.setenv('CAPMI_PRE_STREAM', '0')
-    seq0, _ = E.Rollout(P, pr, n=n, T=L, mode='sample', gumbel=gum, drop_xt=drop_xt, drop_out=drop_out).run()
-    torch.cuda.synchronize()
-    assert float((seq0 != seq_on).float().mean()) < 0.02
-
-
-@pytest.mark.parametrize('rows,K,tr,pad', [(130, 70, False, 0), (130, 70, True, 0), (1000, 4000, True, 0), (1000, 1000, False, 0),
-                                           (257, 33, True, 3), (64, 32, False, 1), (9488, 96, True, 0)])
-def test_planes_split_matches_layout_restatement(dev, rows, K, tr, pad):
-    """capmi_planes_split (fat operands, optional transpose through LDS, zero padding written by the pass) == oracle, bit-exact;
-    pad: extra row pitch / misaligned base (the scalar path)"""
-    ops, _ = mods()
-    g = torch.Generator().manual_seed(rows + K)
-    x = wide((rows, K), g)
-    src = x.t().contiguous() if tr else x
-    buf = torch.zeros(src.shape[0], src.shape[1] + pad, device=dev)
-    buf[:, :src.shape[1]] = src.to(dev)
-    view = buf[:, :src.shape[1]]
-    out = torch.full((int(PL.fat_bytes(rows, K)),), 0xAB, dtype=torch.uint8, device=dev)     # the pass must overwrite everything
-    ops.planes_split(view, transposed=tr, out=out)
-    torch.cuda.synchronize()
-    assert np.array_equal(out.cpu().numpy(), PL.planes_split(x.numpy()))
-
-
-# (M, N, [K per segment], a_layout, b_layout, splits)
-FAT = [(1000, 1000, [4000], 0, 1, 0),            # dX = dG W (time-batched)
-       (4000, 1000, [1000], 1, 1, 0),            # dW = dG^T X
-       (600, 520, [200], 0, 0, 0),               # edge tiles in M and N
-       (600, 520, [200], 1, 0, 0),
-       (520, 600, [72, 40], 0, 0, 0),            # two K segments, K % 32 != 0
-       (512, 512, [3000], 0, 0, 4),              # split-K slabs
-       (130, 9488, [1000], 0, 0, 0)]
-
-
-@pytest.mark.parametrize('M,N,Ks,al,bl,splits', FAT)
-def test_fat_gemm_on_planes_is_bit_identical_to_the_in_kernel_split(dev, M, N, Ks, al, bl, splits):
-    """gemm_x3pl_kernel (both operands as planes, LDS-DMA staging, nothing split in the GEMM) == gemm_x3_kernel (fp32 operands split
-    per workgroup): same bf16x3 terms, same MFMA order -> the same bits; fp32-grade against fp64."""
-    ops, _ = mods()
-    g = torch.Generator().manual_seed(M + N + sum(Ks))
-    segs, apl, bpl, ref = [], [], [], torch.zeros(M, N, dtype=torch.float64)
-    for K in Ks:
-        A, B = wide((M, K), g, 0.3), wide((N, K), g, 0.3)          # K-contiguous views
-        ref += A.double() @ B.double().t()
-        Ad = (A.t().contiguous() if al else A).to(dev)
-        Bd = (B.t().contiguous() if bl else B).to(dev)
-        segs.append((Ad, Ad.stride(0), Bd, Bd.stride(0), K, 1))
-        apl.append(ops.planes_split(Ad, transposed=bool(al)))
-        bpl.append(ops.planes_split(Bd, transposed=bool(bl)))
-    bias = torch.randn(N, generator=g).to(dev)
-    want = torch.empty(M, N, device=dev)
-    got = torch.full((M, N), float('nan'), device=dev)
-    ops.gemm(segs, M, N, want, a_layout=al, b_layout=bl, bias=bias, splits=splits)
-    ops.gemm([(None, s[1], None, s[3], s[4], 1) for s in segs], M, N, got, a_layout=al, b_layout=bl, bias=bias, splits=splits,
-             a_planes=apl, b_planes=bpl)
-    torch.cuda.synchronize()
-    assert torch.equal(got, want)
-    ref = ref + bias.cpu().double()
-    err = float((got.cpu().double() - ref).abs().max() / ref.abs().max())
-    assert err < 2e-6, err
