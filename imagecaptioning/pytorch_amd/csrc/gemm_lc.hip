@@ -49,11 +49,14 @@ typedef const void __attribute__((address_space(1))) *gvoid;
 typedef void __attribute__((address_space(3))) *lvoid;
 
 // s_waitcnt vmcnt(n) with expcnt / lgkmcnt left alone (gfx9 encoding: vmcnt[3:0] | expcnt << 4 | lgkmcnt << 8 | vmcnt[5:4] << 14)
+constexpr int LC_WAUX = 0;     // default cache policy of the weight DMAs (A/B: profiles/r04_gemm_lc_nt.md)
 #define CAPMI_VMCNT(n) __builtin_amdgcn_s_waitcnt((((n) >> 4) << 14) | ((n) & 15) | 0x0f70)
 
 // ABL (profiling builds, CAPMI_LC_ABLATE; never for results): 1 = loaders copy no activations, 2 = consumers skip split / MFMA,
 // 4 = loaders copy no weights, 8 = no stores, 16 = s_memtime stamps of waves 0 and 4 into the ticket words of the workspace
-template <bool BKC, int TM, int ABL = 0>
+// WAUX: cache policy of the WEIGHT DMAs (aux field of global_load_lds): 0 = default, 2 = nt (MI355X_MICROARCH.md row nt-weights);
+// the activation planes keep the default policy (32 column blocks re-read them from L2)
+template <bool BKC, int TM, int ABL = 0, int WAUX = 0>
 __global__ __launch_bounds__(LC_NT) void gemm_lc_kernel(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsb[];
     int bx = blockIdx.x, z = blockIdx.y;
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(LC_NT) void gemm_lc_kernel(const KArgs a) {
                 _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                                                         \
                     const float *src_ = BKC ? B_ + (size_t)wrow[u_] * ldb_ + k0_ + min(wk[u_], brem_ - 4)                  \
                                             : B_ + (size_t)(k0_ + min(wrow[u_], brem_ - 1)) * ldb_ + wk[u_];               \
-                    __builtin_amdgcn_global_load_lds((gvoid)(uintptr_t)src_, (lvoid)(slot_ + LC_AB + (j + 4 * u_) * 1024), 16, 0, 0); \
+                    __builtin_amdgcn_global_load_lds((gvoid)(uintptr_t)src_, (lvoid)(slot_ + LC_AB + (j + 4 * u_) * 1024), 16, 0, WAUX); \
                 }                                                                                                          \
             }                                                                                                              \
         } while (0)
@@ -378,19 +381,23 @@ static int launch_lc_t(const KArgs &a, hipStream_t st, int pcls, double bytes, d
     hipEvent_t e0, e1;
     const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
     static const int abl = capmi::ablate_env("CAPMI_LC_ABLATE");
-#define CAPMI_LC_GO(A_)                                                                                                    \
+#define CAPMI_LC_GO2(A_, W_)                                                                                               \
     do {                                                                                                                   \
         static bool set = false;                                                                                           \
         if (!set) {                                                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_lc_kernel<BKC, TM, A_>),                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_lc_kernel<BKC, TM, A_, W_>),                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
             set = true;                                                                                                    \
         }                                                                                                                  \
-        if (prof) hipExtLaunchKernelGGL((gemm_lc_kernel<BKC, TM, A_>), grid, dim3(LC_NT), lds, st, e0, e1, 0, a);          \
-        else hipLaunchKernelGGL((gemm_lc_kernel<BKC, TM, A_>), grid, dim3(LC_NT), lds, st, a);                             \
+        if (prof) hipExtLaunchKernelGGL((gemm_lc_kernel<BKC, TM, A_, W_>), grid, dim3(LC_NT), lds, st, e0, e1, 0, a);      \
+        else hipLaunchKernelGGL((gemm_lc_kernel<BKC, TM, A_, W_>), grid, dim3(LC_NT), lds, st, a);                         \
     } while (0)
+#define CAPMI_LC_GO(A_) CAPMI_LC_GO2(A_, LC_WAUX)
 #ifdef CAPMI_VARIANTS
-    if constexpr (BKC && TM == 2) {
+    static const int env_nt = capmi::research("CAPMI_LC_NT", LC_WAUX);
+    if (env_nt != LC_WAUX && abl == 0) {
+        if (env_nt == 2) CAPMI_LC_GO2(0, 2); else CAPMI_LC_GO2(0, 0);
+    } else if constexpr (BKC && TM == 2) {
         switch (abl) {
             case 1: CAPMI_LC_GO(1); break;
             case 2: CAPMI_LC_GO(2); break;
@@ -416,6 +423,7 @@ static int launch_lc_t(const KArgs &a, hipStream_t st, int pcls, double bytes, d
     CAPMI_LC_GO(0);
 #endif
 #undef CAPMI_LC_GO
+#undef CAPMI_LC_GO2
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
