@@ -37,6 +37,17 @@ def mul_mask(x, mask):
     return x if mask is None else ops.relu_mask_bwd(x.contiguous(), None, mask)
 
 
+_dh_ws = {}
+
+
+def _dh_workspace(dev):
+    """split-K slabs of d_gates W_hh between two steps of the BPTT (the default workspace is reused by the GEMMs in between)"""
+    key = str(dev)
+    if key not in _dh_ws:
+        _dh_ws[key] = ops.Workspace(dev, floats=2 * 1024 * 1024)
+    return _dh_ws[key]
+
+
 class AoAGraph:
     def __init__(self, P, grads, h, drop_prob_lm, dropout_aoa, training, seed):
         self.P, self.g, self.h = P, grads, h
@@ -222,16 +233,22 @@ class AoAGraph:
         Wq, Wc = P['core.attention.linears.0.weight'], P['core.att2ctx.0.weight']
         a_n = P['core.attention.norm.a_2']
         d_pre2_all, dq_all, dg_all, ln_g, ln_dy = z(T, N, 2 * R), z(T, N, R), z(T, N, 4 * R), z(T, N, R), z(T, N, R)
-        d_sum_all = z(T, N, R)                  # gradient reaching (mean + Drop(ctx_prev)) at each step
         d_p_att = torch.zeros(B * K, 2 * R, dtype=_f32, device=dev)
-        dh_next, dc_next, d_ctx_next = None, None, None
+        dc_next = None
         d_out_all = mul_mask(d_outdrop, self.m_out_all)              # the out_drop Jacobian of all steps in one launch
+        # r4 launch diet of the time loop (15 -> 11 launches per step):
+        #  * the gradient reaching step t's context input, Drop(d_gates W_ih[:, E:]), is ACCUMULATED into d_out of step t-1 by the
+        #    epilogue of that GEMM's split-K reduction (mask + accumulate) -- no mul_mask launch, no elementwise add;
+        #  * dh_next = d_gates W_hh stays as K-slice slabs (its own workspace) and the next LSTM-cell backward sums them -- no reduce;
+        #  * N <= 64: the cell backward also writes d_gates as bf16x3 planes, so both dX GEMMs run on the loader / consumer kernel;
+        #  * step 0 needs neither product (out_0 = 0 and there is no earlier state).
+        use_pl = N <= 64 and R % 4 == 0 and os.environ.get('CAPMI_AOA_PLANES', '1') != '0'
+        pl_dg = ops.planes_scratch(dev, ('aoa_dg', 4 * R), int(lib.capmi_planes_bytes(4 * R))) if use_pl else None
+        ws2 = _dh_workspace(dev)
+        dh_slabs, dh_splits = None, 0
         for t in range(T - 1, -1, -1):
-            # out_{t+1}: from the logit (through out_drop) and from step t+1's ctx input
-            d_out = d_out_all[t]
-            if d_ctx_next is not None:
-                d_out = d_out + d_ctx_next
-            check(lib.capmi_glu_bwd(ptr(d_out), None, ptr(self.pre2[t]), ptr(d_pre2_all[t]), N, R, st), 'glu_bwd')
+            # out_{t+1}: from the logit (through out_drop) and -- accumulated by step t+1 -- from its ctx input
+            check(lib.capmi_glu_bwd(ptr(d_out_all[t]), None, ptr(self.pre2[t]), ptr(d_pre2_all[t]), N, R, st), 'glu_bwd')
             d_cat = ops.matmul_nn(d_pre2_all[t], Wc)                                   # [N,2R] = [d_att | d_h_att]
             d_att = d_cat[:, :R].contiguous()
             dh = d_cat[:, R:].contiguous()
@@ -243,18 +260,25 @@ class AoAGraph:
             d_qn = ops.matmul_nn(dq_all[t], Wq, out=ln_dy[t])
             check(lib.capmi_layernorm_bwd(ptr(d_qn), ptr(self.h_att[t + 1]), ptr(a_n), ptr(self.q_ln_mean[t]), ptr(self.q_ln_inv[t]),
                                           ptr(dh), 1, ptr(ln_g[t]), N, R, EPS, st), 'layernorm_bwd')
-            # LSTM cell
+            # LSTM cell: dh = (att2ctx + query path) + the slabs of d_gates(t+1) W_hh
             dc_prev = z(N, R)
-            check(lib.capmi_lstm_cell_bwd(ptr(dh), R, None, ptr(dh_next), R, None, R, ptr(dc_next), ptr(self.gates[t]),
-                                          ptr(self.c_att[t]), ptr(self.c_att[t + 1]), ptr(dg_all[t]), ptr(dc_prev), N, R, st),
-                  'lstm_cell_bwd')
+            dh_b = None if dh_slabs is None else dh_slabs.data_ptr()
+            if use_pl:
+                check(lib.capmi_lstm_cell_bwd_partial_pl(ptr(dh), R, None, dh_b, R, max(dh_splits, 1), N * R, None, R, 1, 0,
+                                                         ptr(dc_next), ptr(self.gates[t]), ptr(self.c_att[t]), ptr(self.c_att[t + 1]),
+                                                         ptr(dg_all[t]), ptr(dc_prev), N, R, ptr(pl_dg), st), 'lstm_cell_bwd_partial_pl')
+            else:
+                check(lib.capmi_lstm_cell_bwd_partial(ptr(dh), R, None, dh_b, R, max(dh_splits, 1), N * R, None, R, 1, 0,
+                                                      ptr(dc_next), ptr(self.gates[t]), ptr(self.c_att[t]), ptr(self.c_att[t + 1]),
+                                                      ptr(dg_all[t]), ptr(dc_prev), N, R, st), 'lstm_cell_bwd_partial')
             dc_next = dc_prev
             if t > 0:
-                ops.gemm([(dg_all[t], 4 * R, (W_ih, E), ld_ih, 4 * R, 1)], N, R, d_sum_all[t], a_layout=0, b_layout=1)
-                d_ctx_next = mul_mask(d_sum_all[t], self.m_ctx[t])
-                dh_next = ops.matmul_nn(dg_all[t], W_hh)
-            else:
-                ops.gemm([(dg_all[t], 4 * R, (W_ih, E), ld_ih, 4 * R, 1)], N, R, d_sum_all[t], a_layout=0, b_layout=1)
+                pl = [pl_dg] if use_pl else None
+                ops.gemm([(dg_all[t], 4 * R, (W_ih, E), ld_ih, 4 * R, 1)], N, R, d_out_all[t - 1], a_layout=0, b_layout=1,
+                         mul_mask=self.m_ctx[t], accumulate=True, a_planes=pl)
+                dh_splits = ops.gemm([(dg_all[t], 4 * R, W_hh, R, 4 * R, 1)], N, R, ws2.buf, a_layout=0, b_layout=1, ws=ws2,
+                                     defer_reduce=True, a_planes=pl)
+                dh_slabs = ws2.slabs
         # ---- time-batched core gradients
         dg2 = dg_all.view(TN, 4 * R)
         ops.gemm([(dg2, 4 * R, self.xt.view(TN, E), E, TN, 1)], 4 * R, E, g['core.att_lstm.weight_ih'], ldc=ld_ih, a_layout=1, b_layout=1)
