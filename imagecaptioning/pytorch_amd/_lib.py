@@ -184,6 +184,8 @@ SIGNATURES = {
     'capmi_layernorm_bwd': [_P] * 6 + [_I, _P, _I, _I, _F, _P],
     'capmi_mha_fwd': [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'capmi_mha_bwd': [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'capmi_mha_fwd_s': [_P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'capmi_mha_bwd_s': [_P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'capmi_glu_fwd': [_P, _P, _P, _P, _I, _I, _P],
     'capmi_glu_fwd_fused': [_P, _I, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     'capmi_glu_bwd': [_P, _P, _P, _P, _I, _I, _P],

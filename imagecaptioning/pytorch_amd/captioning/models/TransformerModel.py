@@ -168,6 +168,20 @@ class TransformerModel(CaptionModel):
             return self._flat.grad_views
         return {k: torch.empty_like(v) for k, v in P.items() if k != 'model.tgt_embed.1.pe'}
 
+    def _flat_groups(self):
+        """parameters the engine wants back to back in the flat buffers (transformer_engine.fused_lin): Wq | Wk | Wv (and their
+        biases) of every self-attention block, and Wk | Wv of the cross-attention of ALL decoder layers"""
+        names = [n for n, _ in self.named_parameters()]
+        blocks = sorted({n[:n.index('.self_attn.') + len('.self_attn')] for n in names if '.self_attn.linears.' in n})
+        groups = []
+        for b in blocks:
+            for kind in ('weight', 'bias'):
+                groups.append(['%s.linears.%d.%s' % (b, i, kind) for i in range(3)])
+        n_dec = len({n.split('.')[3] for n in names if n.startswith('model.decoder.layers.')})
+        for kind in ('weight', 'bias'):
+            groups.append(['model.decoder.layers.%d.src_attn.linears.%d.%s' % (i, j, kind) for i in range(n_dec) for j in (1, 2)])
+        return groups
+
     def flatten_parameters_(self):
         from imagecaptioning.pytorch_amd.flat import FlatParams
         self._flat = FlatParams(self)

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(MHA_T) void mha_fwd_kernel(const float *__restrict_
                                                        const uint8_t *__restrict__ mask, int mask_tq, int mask_per_q,
                                                        int causal, int q_pos0, const float *__restrict__ drop,
                                                        float *__restrict__ o, float *__restrict__ p, int q_per_kv, int Tq,
-                                                       int Tk, int h, int dk, int CH) {
+                                                       int Tk, int h, int dk, int CH, int qstride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int D = h * dk, P1 = dk + 4, S1 = Tk + 1, d4 = dk >> 2;
     float *sK = lds, *sV = sK + Tk * P1, *sQ = sV + Tk * P1, *sS = sQ + CH * P1;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(MHA_T) void mha_fwd_kernel(const float *__restrict_
         for (int i = threadIdx.x; i < rows * d4; i += blockDim.x) {
             const int lr = i / d4, c = (i - lr * d4) * 4, gr = row0 + lr;
             const int r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
-            *reinterpret_cast<f32x4 *>(sQ + lr * P1 + c) = *reinterpret_cast<const f32x4 *>(q + ((size_t)r * Tq + t) * D + hd * dk + c);
+            *reinterpret_cast<f32x4 *>(sQ + lr * P1 + c) = *reinterpret_cast<const f32x4 *>(q + ((size_t)r * Tq + t) * qstride + hd * dk + c);
         }
         __syncthreads();
         for (int i = threadIdx.x; i < rows * Tk; i += blockDim.x) {
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict_
                                                        const float *__restrict__ drop, float *__restrict__ dq,
                                                        float *__restrict__ dk_out, float *__restrict__ dv_out, int dkv_ld,
                                                        int dkv_stride, int accumulate, int q_per_kv, int Tq, int Tk, int h,
-                                                       int dk, int CH) {
+                                                       int dk, int CH, int qstride, int dq_stride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int D = h * dk, P1 = dk + 4, S1 = Tk + 1, d4 = dk >> 2;
     float *sK = lds, *sV = sK + Tk * P1, *sdK = sV + Tk * P1, *sdV = sdK + Tk * P1;
@@ -187,7 +187,8 @@ __global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict_
         for (int i = threadIdx.x; i < rows * d4; i += blockDim.x) {
             const int lr = i / d4, c = (i - lr * d4) * 4, gr = row0 + lr;
             const size_t gi = ((size_t)(kvr * q_per_kv + gr / Tq) * Tq + gr % Tq) * D + hd * dk + c;
-            *reinterpret_cast<f32x4 *>(sQ + lr * P1 + c) = *reinterpret_cast<const f32x4 *>(q + gi);
+            const size_t gq = ((size_t)(kvr * q_per_kv + gr / Tq) * Tq + gr % Tq) * qstride + hd * dk + c;
+            *reinterpret_cast<f32x4 *>(sQ + lr * P1 + c) = *reinterpret_cast<const f32x4 *>(q + gq);
             *reinterpret_cast<f32x4 *>(sdO + lr * P1 + c) = *reinterpret_cast<const f32x4 *>(d_o + gi);
         }
         for (int i = threadIdx.x; i < rows * Tk; i += blockDim.x) {
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict_
             const float *ds = sdS + lr * S1;
             f32x4 acc = zero4;
             for (int j = 0; j < Tk; ++j) acc += ds[j] * LDS4(sK + j * P1 + c);
-            *reinterpret_cast<f32x4 *>(dq + ((size_t)(kvr * q_per_kv + gr / Tq) * Tq + gr % Tq) * D + hd * dk + c) = acc;
+            *reinterpret_cast<f32x4 *>(dq + ((size_t)(kvr * q_per_kv + gr / Tq) * Tq + gr % Tq) * dq_stride + hd * dk + c) = acc;
         }
         for (int i = threadIdx.x; i < Tk * d4; i += blockDim.x) {       // dK += dS^T Q ; dV += (P*drop)^T dO
             const int j = i / d4, c = (i - j * d4) * 4;
@@ -432,6 +433,15 @@ int capmi_layernorm_bwd(const float *dy, const float *x, const float *a, const f
 int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, int kstride, const uint8_t *mask, int mask_tq,
                   int mask_per_q, int causal, int q_pos0, const float *drop, float *o, float *p, int Nq, int q_per_kv,
                   int Tq, int Tk, int h, int dk, void *stream) {
+    return capmi_mha_fwd_s(q, 0, k, v, ldkv, kstride, mask, mask_tq, mask_per_q, causal, q_pos0, drop, o, p, Nq, q_per_kv, Tq, Tk, h, dk,
+                           stream);
+}
+
+int capmi_mha_fwd_s(const float *q, int qstride, const float *k, const float *v, int ldkv, int kstride, const uint8_t *mask,
+                    int mask_tq, int mask_per_q, int causal, int q_pos0, const float *drop, float *o, float *p, int Nq,
+                    int q_per_kv, int Tq, int Tk, int h, int dk, void *stream) {
+    if (qstride <= 0) qstride = h * dk;
+    if (qstride % 4) return CAPMI_EINVAL;
     if (kstride <= 0) kstride = h * dk;
     if (!q || !k || !v || !o || Nq <= 0 || q_per_kv <= 0 || Nq % q_per_kv || Tq <= 0 || Tk <= 0 || h <= 0 || dk <= 0)
         return CAPMI_EINVAL;
@@ -456,7 +466,7 @@ int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, int 
         attr_f = true;
     }
     hipLaunchKernelGGL(mha_fwd_kernel, dim3(Nq / q_per_kv, h), dim3(MHA_T), lds, (hipStream_t)stream, q, k, v, ldkv, kstride,
-                       mask, mask_tq, mask_per_q, causal, q_pos0, drop, o, p, q_per_kv, Tq, Tk, h, dk, CH);
+                       mask, mask_tq, mask_per_q, causal, q_pos0, drop, o, p, q_per_kv, Tq, Tk, h, dk, CH, qstride);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -464,6 +474,16 @@ int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, int 
 int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float *v, int ldkv, int kstride, const float *p,
                   const float *drop, float *dq, float *dk_out, float *dv_out, int dkv_ld, int dkv_stride, int accumulate,
                   int Nq, int q_per_kv, int Tq, int Tk, int h, int dk, void *stream) {
+    return capmi_mha_bwd_s(d_o, q, 0, k, v, ldkv, kstride, p, drop, dq, 0, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, Nq, q_per_kv,
+                           Tq, Tk, h, dk, stream);
+}
+
+int capmi_mha_bwd_s(const float *d_o, const float *q, int qstride, const float *k, const float *v, int ldkv, int kstride,
+                    const float *p, const float *drop, float *dq, int dq_stride, float *dk_out, float *dv_out, int dkv_ld,
+                    int dkv_stride, int accumulate, int Nq, int q_per_kv, int Tq, int Tk, int h, int dk, void *stream) {
+    if (qstride <= 0) qstride = h * dk;
+    if (dq_stride <= 0) dq_stride = h * dk;
+    if (qstride % 4 || dq_stride % 4) return CAPMI_EINVAL;
     if (kstride <= 0) kstride = h * dk;
     if (dkv_stride <= 0) dkv_stride = h * dk;
     if (dkv_ld <= 0) dkv_ld = Tk * dkv_stride;
@@ -488,7 +508,7 @@ int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float 
         attr_b = true;
     }
     hipLaunchKernelGGL(mha_bwd_kernel, dim3(Nq / q_per_kv, h), dim3(MHA_T), lds, (hipStream_t)stream, d_o, q, k, v, ldkv, kstride,
-                       p, drop, dq, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, q_per_kv, Tq, Tk, h, dk, CH);
+                       p, drop, dq, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, q_per_kv, Tq, Tk, h, dk, CH, qstride, dq_stride);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

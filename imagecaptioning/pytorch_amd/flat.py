@@ -21,11 +21,29 @@ class FlatParams:
         self.names = [n for n, _ in params]
         self.params = [p for _, p in params]
         sizes = [p.numel() for p in self.params]
-        # 16-byte align every segment so the MFMA loaders can use 16-byte vector loads
-        self.offsets, off = [], 0
-        for s in sizes:
-            self.offsets.append(off)
-            off += (s + 3) // 4 * 4
+        # 16-byte align every segment so the MFMA loaders can use 16-byte vector loads.  Segments are laid out in the order of
+        # model.parameters() except for the module's `_flat_groups()`: lists of parameter names that must sit back to back so
+        # that ONE GEMM can take them as a single operand (e.g. [Wq; Wk; Wv] of an attention block as a [3D, D] matrix, r4).
+        # names / params / offsets stay indexed in model.parameters() order (optimizer.pth of the reference relies on it).
+        index = {n: i for i, n in enumerate(self.names)}
+        order, placed = [], set()
+        groups = module._flat_groups() if hasattr(module, '_flat_groups') else []
+        first_of = {}
+        for g in groups:
+            g = [n for n in g if n in index]
+            if len(g) > 1 and not placed.intersection(g):
+                first_of[min(index[n] for n in g)] = g
+                placed.update(g)
+        for i, n in enumerate(self.names):
+            if i in first_of:
+                order += [index[m] for m in first_of[i]]
+            elif n not in placed:
+                order.append(i)
+        assert sorted(order) == list(range(len(self.names)))
+        self.offsets, off = [0] * len(sizes), 0
+        for i in order:
+            self.offsets[i] = off
+            off += (sizes[i] + 3) // 4 * 4
         self.used = off
         self.total = (off + 63) // 64 * 64          # equal 16-byte-aligned shards for up to 16 ranks (sharded_step)
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
@@ -145,17 +163,16 @@ class FlatParams:
         """all-reduce the flat ranges covering `names` (all final): parameters adjacent in the buffer share a launch."""
         import torch.distributed as dist
         ov = self._ov
-        idx = sorted(self.names.index(n) for n in names)
-        run = [idx[0]]
-        for i in idx[1:] + [None]:
-            if i is not None and i == run[-1] + 1:
-                run.append(i)
+        segs = sorted((self.offsets[i], self.offsets[i] + (self.params[i].numel() + 3) // 4 * 4)
+                      for i in (self.names.index(n) for n in names))
+        lo, hi = segs[0]
+        for a, b in segs[1:] + [(None, None)]:
+            if a is not None and a == hi:         # adjacent in the BUFFER (layout order, not model.parameters() order)
+                hi = b
                 continue
-            lo = self.offsets[run[0]]
-            hi = self.offsets[run[-1]] + (self.params[run[-1]].numel() + 3) // 4 * 4
             ov['works'].append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=ov['group'], async_op=True))
             ov['done'].append((lo, hi))
-            run = [i]
+            lo, hi = a, b
 
     def _launch_leftovers(self):
         import torch.distributed as dist

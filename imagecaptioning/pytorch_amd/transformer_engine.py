@@ -52,15 +52,17 @@ def layernorm_bwd(dy, x, a, mean, inv, dx_accum, d_a=None, d_b=None):
 
 
 def mha_fwd(q, k, v, ldkv, Nq, q_per_kv, Tq, Tk, h, mask=None, mask_tq=1, mask_per_q=0, causal=0, q_pos0=0, drop=None,
-            want_p=True, kstride=0):
-    D = q.shape[-1]
+            want_p=True, kstride=0, qstride=0, D=None):
+    """q / k / v: tensors or (tensor, element offset) column blocks of a fused projection (then pass D and the row pitches)"""
+    dev = (q[0] if isinstance(q, tuple) else q).device
+    D = D or q.shape[-1]
     if (D // h) % 4:
         raise NotImplementedError('multi-head attention with head size %d: the kernels move the head dimension in 16-byte pieces '
                                   '(head size %% 4 == 0; every BASELINE config uses 64 or 128)' % (D // h))
-    o = torch.empty(Nq, Tq, D, dtype=_f32, device=q.device)
-    p = torch.empty(Nq, h, Tq, Tk, dtype=_f32, device=q.device) if want_p else None
-    check(lib.capmi_mha_fwd(_a(q), _a(k), _a(v), ldkv, kstride, ptr(mask), mask_tq, mask_per_q, causal, q_pos0, ptr(drop), ptr(o),
-                            ptr(p), Nq, q_per_kv, Tq, Tk, h, D // h, stream_ptr()), 'mha_fwd')
+    o = torch.empty(Nq, Tq, D, dtype=_f32, device=dev)
+    p = torch.empty(Nq, h, Tq, Tk, dtype=_f32, device=dev) if want_p else None
+    check(lib.capmi_mha_fwd_s(_a(q), qstride, _a(k), _a(v), ldkv, kstride, ptr(mask), mask_tq, mask_per_q, causal, q_pos0, ptr(drop),
+                              ptr(o), ptr(p), Nq, q_per_kv, Tq, Tk, h, D // h, stream_ptr()), 'mha_fwd')
     return o, p
 
 
@@ -72,15 +74,16 @@ def _a(x):
 
 
 def mha_bwd(d_o, q, k, v, ldkv, p, drop, Nq, q_per_kv, Tq, Tk, h, kstride=0, dk_out=None, dv_out=None, dkv_ld=0, dkv_stride=0,
-            accumulate=False):
-    D = q.shape[-1]
+            accumulate=False, qstride=0, dq=None, dq_stride=0):
+    D = d_o.shape[-1]
     Nkv = Nq // q_per_kv
-    dq = torch.empty(Nq, Tq, D, dtype=_f32, device=q.device)
+    if dq is None:
+        dq = torch.empty(Nq, Tq, D, dtype=_f32, device=d_o.device)
     if dk_out is None:
-        dk_out = torch.empty(Nkv, Tk, D, dtype=_f32, device=q.device)
-        dv_out = torch.empty(Nkv, Tk, D, dtype=_f32, device=q.device)
-    check(lib.capmi_mha_bwd(ptr(d_o), _a(q), _a(k), _a(v), ldkv, kstride, ptr(p), ptr(drop), ptr(dq), _a(dk_out), _a(dv_out),
-                            dkv_ld, dkv_stride, int(accumulate), Nq, q_per_kv, Tq, Tk, h, D // h, stream_ptr()), 'mha_bwd')
+        dk_out = torch.empty(Nkv, Tk, D, dtype=_f32, device=d_o.device)
+        dv_out = torch.empty(Nkv, Tk, D, dtype=_f32, device=d_o.device)
+    check(lib.capmi_mha_bwd_s(ptr(d_o), _a(q), qstride, _a(k), _a(v), ldkv, kstride, ptr(p), ptr(drop), _a(dq), dq_stride, _a(dk_out),
+                              _a(dv_out), dkv_ld, dkv_stride, int(accumulate), Nq, q_per_kv, Tq, Tk, h, D // h, stream_ptr()), 'mha_bwd')
     return dq, dk_out, dv_out
 
 
@@ -175,34 +178,90 @@ class Norm:
                       self.grads[self.pre + '.b_2'])
 
 
-class Attn:
-    """MultiHeadedAttention (TransformerModel.py:164-195) with projections; kv_src None => self-attention."""
+def _back_to_back(ts):
+    """views of ONE storage (the flat buffer) that follow each other without a gap"""
+    if any(t is None for t in ts):
+        return False
+    base = ts[0].untyped_storage().data_ptr()
+    return all(t.untyped_storage().data_ptr() == base for t in ts) and \
+        all(a.data_ptr() + 4 * a.numel() == b.data_ptr() for a, b in zip(ts, ts[1:]))
 
-    def __init__(self, P, grads, pre, h):
+
+def fused_lin(P, grads, wnames, bnames):
+    """ONE Lin over several Linear layers of the same input when their weights, biases and gradient views sit back to back in the
+    flat buffers (FlatParams lays out a model's `_flat_groups()` that way): y = x [W0; W1; ...]^T, one dW, one column sum, one dX.
+    None when they do not (a model that was not flattened: the per-layer path runs)."""
+    Ws, bs = [P.get(n) for n in wnames], [P.get(n) for n in bnames]
+    gW, gb = [grads.get(n) for n in wnames], [grads.get(n) for n in bnames]
+    if not (_back_to_back(Ws) and _back_to_back(bs)):
+        return None
+    if grads and not (_back_to_back(gW) and _back_to_back(gb)):
+        return None
+    rows, K = sum(w.shape[0] for w in Ws), Ws[0].shape[1]
+    view = lambda t, shape: t.as_strided(shape, (shape[1], 1) if len(shape) == 2 else (1,))     # noqa: E731
+    Pf = {'w': view(Ws[0], (rows, K)), 'b': view(bs[0], (rows,))}
+    gf = {'w': view(gW[0], (rows, K)), 'b': view(gb[0], (rows,))} if grads else {}
+    return Lin(Pf, gf, 'w', 'b')
+
+
+class Attn:
+    """MultiHeadedAttention (TransformerModel.py:164-195) with projections; kv_src None => self-attention.
+    r4: self-attention projects q, k, v with ONE GEMM (N = 3D) when the three weights are one flat-buffer group; cross-attention
+    may be handed K / V that one GEMM projected for all layers (`kv_fused`)."""
+
+    def __init__(self, P, grads, pre, h, fuse_qkv=True):
         self.h = h
         self.lq, self.lk, self.lv, self.lo = (Lin(P, grads, '%s.linears.%d.weight' % (pre, i), '%s.linears.%d.bias' % (pre, i))
                                               for i in range(4))
+        self.lqkv = fused_lin(P, grads, ['%s.linears.%d.weight' % (pre, i) for i in range(3)],
+                              ['%s.linears.%d.bias' % (pre, i) for i in range(3)]) if fuse_qkv else None
 
     def fwd(self, x, Nq, Tq, kv=None, Nkv=None, Tk=None, q_per_kv=1, mask=None, mask_tq=1, mask_per_q=0, drop_p=None,
-            residual=None, res_mask=None):
+            residual=None, res_mask=None, kv_fused=None):
+        """kv_fused = (buffer [Nkv*Tk, W], column of K, column of V, gradient buffer): K / V already projected"""
         D = x.shape[1]
-        self.self_attn = kv is None
-        if kv is None:
+        self.self_attn = kv is None and kv_fused is None
+        if self.self_attn:
             kv, Nkv, Tk = x, Nq, Tq
         self.dims = (Nq, Tq, Nkv, Tk, q_per_kv)
-        self.q = self.lq.fwd(x)
-        self.k = self.lk.fwd(kv)
-        self.v = self.lv.fwd(kv)
         self.drop_p = drop_p
-        o, self.p = mha_fwd(self.q, self.k, self.v, Tk * D, Nq, q_per_kv, Tq, Tk, self.h, mask, mask_tq, mask_per_q, 0, 0, drop_p)
+        self.kv_fused = kv_fused
+        self.qs = self.ks = 0
+        if self.self_attn and self.lqkv is not None:
+            y = self.lqkv.fwd(x)                                   # [rows, 3D]: q | k | v
+            self.q, self.k, self.v, self.qs, self.ks = (y, 0), (y, D), (y, 2 * D), 3 * D, 3 * D
+        else:
+            self.q = self.lq.fwd(x)
+            if kv_fused is not None:
+                buf, ck, cv, _ = kv_fused
+                self.k, self.v, self.ks = (buf, ck), (buf, cv), buf.shape[1]
+            else:
+                self.k = self.lk.fwd(kv)
+                self.v = self.lv.fwd(kv)
+        o, self.p = mha_fwd(self.q, self.k, self.v, Tk * (self.ks or D), Nq, q_per_kv, Tq, Tk, self.h, mask, mask_tq, mask_per_q, 0, 0,
+                            drop_p, kstride=self.ks, qstride=self.qs, D=D)
         return self.lo.fwd(o.view(Nq * Tq, D), mask=res_mask, residual=residual)
 
     def bwd(self, dy):
         """returns (dx_query_side, dkv) -- for self-attention both are summed into one tensor."""
         Nq, Tq, Nkv, Tk, q_per_kv = self.dims
-        D = self.q.shape[1]
         d_o = self.lo.bwd(dy)
-        dq, dk, dv = mha_bwd(d_o.view(Nq, Tq, D), self.q, self.k, self.v, Tk * D, self.p, self.drop_p, Nq, q_per_kv, Tq, Tk,
+        D = d_o.shape[1]
+        ldkv = Tk * (self.ks or D)
+        if self.self_attn and self.lqkv is not None:
+            # dq | dk | dv land in the column blocks of ONE [rows, 3D] buffer: one dW GEMM, one column sum, one dX GEMM (K = 3D)
+            dqkv = torch.empty(Nq * Tq, 3 * D, dtype=_f32, device=d_o.device)
+            mha_bwd(d_o.view(Nq, Tq, D), self.q, self.k, self.v, ldkv, self.p, self.drop_p, Nq, q_per_kv, Tq, Tk, self.h,
+                    kstride=self.ks, qstride=self.qs, dq=(dqkv, 0), dq_stride=3 * D, dk_out=(dqkv, D), dv_out=(dqkv, 2 * D),
+                    dkv_ld=Tk * 3 * D, dkv_stride=3 * D)
+            return self.lqkv.bwd(dqkv, fresh=True), None
+        if self.kv_fused is not None:
+            buf, ck, cv, dbuf = self.kv_fused                     # dK / dV into this layer's columns of the shared gradient buffer
+            dq, _, _ = mha_bwd(d_o.view(Nq, Tq, D), self.q, self.k, self.v, ldkv, self.p, self.drop_p, Nq, q_per_kv, Tq, Tk, self.h,
+                               kstride=self.ks, dk_out=(dbuf, ck), dv_out=(dbuf, cv), dkv_ld=Tk * dbuf.shape[1],
+                               dkv_stride=dbuf.shape[1])
+            return self.lq.bwd(dq.view(Nq * Tq, D), fresh=True), None
+        dq, dk, dv = mha_bwd(d_o.view(Nq, Tq, D), self.q, self.k, self.v, ldkv, self.p, self.drop_p, Nq, q_per_kv, Tq, Tk,
                              self.h)
         if self.self_attn:
             return bwd_sum((self.lq, self.lk, self.lv), (dq.view(Nq * Tq, D), dk.view(Nkv * Tk, D), dv.view(Nkv * Tk, D))), None
@@ -317,15 +376,23 @@ class TransformerGraph:
         check(lib.capmi_embed_pe_fwd(ptr(seq), T, ptr(P['model.tgt_embed.0.lut.weight']), ptr(P['model.tgt_embed.1.pe']),
                                      ptr(self.drop_tgt), ptr(x), N, T, D, 0, stream_ptr()), 'embed_pe_fwd')
         self.dec = []
+        # r4: the cross-attention K / V of ALL decoder layers are one GEMM over the memory (N = n_dec * 2D) when their weights are
+        # one flat-buffer group; each layer reads -- and its backward fills -- its own column blocks
+        names = [('model.decoder.layers.%d.src_attn.linears.%d' % (i, j)) for i in range(self.n_dec) for j in (1, 2)]
+        self.kv_all = fused_lin(P, g, [nm + '.weight' for nm in names], [nm + '.bias' for nm in names]) if self.n_dec else None
+        if self.kv_all is not None:
+            self.kv_buf = self.kv_all.fwd(self.memory)                          # [B*K, n_dec * 2D]
+            self.dkv_buf = torch.empty_like(self.kv_buf) if g else None
         for i in range(self.n_dec):
             pre = 'model.decoder.layers.%d' % i
             n0, sa = Norm(P, g, pre + '.sublayer.0.norm'), Attn(P, g, pre + '.self_attn', self.h)
-            n1, ca = Norm(P, g, pre + '.sublayer.1.norm'), Attn(P, g, pre + '.src_attn', self.h)
+            n1, ca = Norm(P, g, pre + '.sublayer.1.norm'), Attn(P, g, pre + '.src_attn', self.h, fuse_qkv=False)
             n2, ff = Norm(P, g, pre + '.sublayer.2.norm'), FFN(P, g, pre + '.feed_forward')
             x = sa.fwd(n0.fwd(x), N, T, mask=tmask, mask_tq=T, mask_per_q=1, drop_p=next(masks), residual=x,
                        res_mask=next(masks))
-            x = ca.fwd(n1.fwd(x), N, T, kv=self.memory, Nkv=B, Tk=K, q_per_kv=n, mask=self.smask, mask_tq=1, mask_per_q=0,
-                       drop_p=next(masks), residual=x, res_mask=next(masks))
+            kvf = None if self.kv_all is None else (self.kv_buf, 2 * i * D, (2 * i + 1) * D, self.dkv_buf)
+            x = ca.fwd(n1.fwd(x), N, T, kv=None if kvf else self.memory, Nkv=B, Tk=K, q_per_kv=n, mask=self.smask, mask_tq=1,
+                       mask_per_q=0, drop_p=next(masks), residual=x, res_mask=next(masks), kv_fused=kvf)
             x = ff.fwd(n2.fwd(x), next(masks), residual=x, res_mask=next(masks))
             self.dec.append((n0, sa, n1, ca, n2, ff))
         self.dec_norm = Norm(P, g, 'model.decoder.norm')
@@ -362,10 +429,13 @@ class TransformerGraph:
             # x3 = x2 + m*ff(n2(x2)) ; dx currently = d x3
             n2.bwd(ff.bwd(dx), dx)
             dq, dkv = ca.bwd(dx)
-            d_mem += dkv
+            if dkv is not None:
+                d_mem += dkv
             n1.bwd(dq, dx)
             dself, _ = sa.bwd(dx)
             n0.bwd(dself, dx)
+        if self.kv_all is not None:                     # every layer's dK | dV -> d(memory), dW and db of all 2 n_dec projections at once
+            d_mem = self.kv_all.bwd(self.dkv_buf, fresh=True)
         g['model.tgt_embed.0.lut.weight'].zero_()
         check(lib.capmi_embed_pe_bwd(ptr(self.seq), T, ptr(dx), ptr(self.drop_tgt), ptr(g['model.tgt_embed.0.lut.weight']), N, T,
                                      D, stream_ptr()), 'embed_pe_bwd')

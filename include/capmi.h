@@ -700,11 +700,22 @@ int capmi_layernorm_bwd(const float *dy, const float *x, const float *a, const f
 int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, int kstride, const uint8_t *mask, int mask_tq,
                   int mask_per_q, int causal, int q_pos0, const float *drop, float *o, float *p, int Nq, int q_per_kv,
                   int Tq, int Tk, int h, int dk, void *stream);
+/* Same with a query row pitch: qstride floats between consecutive query rows (0 = D).  Lets q, k, v be the three column blocks
+ * of ONE fused projection y = x [Wq; Wk; Wv]^T of pitch 3D (r4: the three Linear calls of TransformerModel.py:179-181 as one
+ * GEMM with N = 3D; k, v then use kstride = 3D). */
+int capmi_mha_fwd_s(const float *q, int qstride, const float *k, const float *v, int ldkv, int kstride, const uint8_t *mask,
+                    int mask_tq, int mask_per_q, int causal, int q_pos0, const float *drop, float *o, float *p, int Nq,
+                    int q_per_kv, int Tq, int Tk, int h, int dk, void *stream);
 /* backward: d_o [Nq,Tq,D] -> dq [Nq,Tq,D], dk/dv summed over the q_per_kv query rows of a kv row, written at
  * out + kv_row*dkv_ld + key*dkv_stride (+= when accumulate: BPTT over time steps) */
 int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float *v, int ldkv, int kstride, const float *p,
                   const float *drop, float *dq, float *dk_out, float *dv_out, int dkv_ld, int dkv_stride, int accumulate,
                   int Nq, int q_per_kv, int Tq, int Tk, int h, int dk, void *stream);
+/* Same with query / dq row pitches (0 = D): dq may be a column block of the fused [rows, 3D] gradient that one dX GEMM
+ * (K = 3D) and one dW GEMM consume. */
+int capmi_mha_bwd_s(const float *d_o, const float *q, int qstride, const float *k, const float *v, int ldkv, int kstride,
+                    const float *p, const float *drop, float *dq, int dq_stride, float *dk_out, float *dv_out, int dkv_ld,
+                    int dkv_stride, int accumulate, int Nq, int q_per_kv, int Tq, int Tk, int h, int dk, void *stream);
 /* x[r,t,:] = E[tok[r,t]]*sqrt(D) + pe[pos0+t,:], then * drop (TransformerModel.py:215, 231-233) */
 int capmi_embed_pe_fwd(const int64_t *tok, int tok_ld, const float *E, const float *pe, const float *drop, float *x,
                        int N, int T, int D, int pos0, void *stream);

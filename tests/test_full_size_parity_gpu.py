@@ -479,8 +479,9 @@ def test_head_size_not_a_multiple_of_4_is_refused_loudly():
         model(None, att.to(DEV), torch.randint(1, 57, (2, 1, 6), device=DEV), None)
 
 
-@pytest.mark.parametrize('tag,family,B,seed', [('t', 'transformer', 64, 11), ('a', 'aoa', 10, 12)])
-def test_transformer_and_aoa_at_the_baseline_batch_vs_the_reference_itself(tag, family, B, seed):
+@pytest.mark.parametrize('tag,family,B,seed,flat', [('t', 'transformer', 64, 11, False), ('t', 'transformer', 64, 11, True),
+                                                    ('a', 'aoa', 10, 12, False), ('a', 'aoa', 10, 12, True)])
+def test_transformer_and_aoa_at_the_baseline_batch_vs_the_reference_itself(tag, family, B, seed, flat):
     """the BASELINE *shapes* -- Transformer XE at bs64 x 5 captions, T=21 (configs[3]; 6 720 decoder rows,
     the DeferredGrads arena, every split-K plan of that size) and AoA at bs10 x 5, T=21 (the configs[4] batch) -- against
     outputs of the REAL reference (tests/golden/big_xe_grads.npz, `make_golden.py full2`): loss, target log-probs, three full
@@ -491,6 +492,8 @@ def test_transformer_and_aoa_at_the_baseline_batch_vs_the_reference_itself(tag, 
     model = models.setup(shapes.big_opt(family))
     model.load_state_dict(shapes.seeded_state({k: v.shape for k, v in model.state_dict().items()}, seed))
     model = model.to(DEV)
+    if flat:                                  # the training layout: fused q | k | v and cross-attention K | V GEMMs (r4)
+        model.flatten_parameters_()
     model.train() if family == 'transformer' else model.eval()
     fc, att = shapes.feats(B, seed=seed)
     labels, masks = shapes.c2_labels(B=B, seed=seed)

@@ -247,9 +247,12 @@ def test_newfc_golden_xe_grads_and_greedy():
     np.testing.assert_allclose(slp.cpu().numpy(), z['greedy_logp'], rtol=2e-5, atol=5e-6)
 
 
+@pytest.mark.parametrize('flat', [False, True])
 @pytest.mark.parametrize('tag', ['nomask', 'mask'])
-def test_transformer_golden_xe_grads_and_greedy(tag):
-    """BASELINE configs[3] model family against the real reference's fixture (tiny size)."""
+def test_transformer_golden_xe_grads_and_greedy(tag, flat):
+    """BASELINE configs[3] model family against the real reference's fixture (tiny size).  flat: the parameters live in the
+    flat buffers (as in training), where q | k | v of every self-attention and the cross-attention K | V of all decoder layers are
+    single fused GEMMs (r4); without it every projection is its own GEMM -- both must reproduce the reference."""
     from imagecaptioning.pytorch_amd.captioning import models
     from imagecaptioning.pytorch_amd.captioning.modules.losses import LanguageModelCriterion
     z = np.load(os.path.join(GOLDEN, 'transformer_tiny.npz'))
@@ -260,6 +263,12 @@ def test_transformer_golden_xe_grads_and_greedy(tag):
     assert set(sd.keys()) == set(model.state_dict().keys())
     model.load_state_dict(sd)
     model = model.to(DEV)
+    if flat:
+        fp = model.flatten_parameters_()
+        from imagecaptioning.pytorch_amd import transformer_engine as TE
+        P = dict(model.named_parameters())
+        assert TE.fused_lin(P, fp.grad_views, ['model.encoder.layers.0.self_attn.linears.%d.weight' % i for i in range(3)],
+                            ['model.encoder.layers.0.self_attn.linears.%d.bias' % i for i in range(3)]) is not None
     model.train()
     att = torch.from_numpy(u['att']).to(DEV)
     am = torch.from_numpy(u['att_masks']).to(DEV) if tag == 'mask' else None
@@ -269,6 +278,8 @@ def test_transformer_golden_xe_grads_and_greedy(tag):
     loss = LanguageModelCriterion()(logp, labels[..., 1:], masks[..., 1:])
     np.testing.assert_allclose(loss.item(), z['xe_loss_' + tag], rtol=1e-5)
     loss.backward()
+    if flat:
+        fp.collect_grads()
     for k, p in model.named_parameters():
         ref = z['xe_grad_%s.%s' % (tag, k)]
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-3, atol=1e-6 + 5e-5 * np.abs(ref).max(), err_msg=k)
