@@ -15,7 +15,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import lib, ptr, check, stream_ptr
-from .transformer_engine import Lin, Norm, Dropper, mha_fwd, mha_bwd, layernorm_fwd, layernorm_bwd, EPS
+from .transformer_engine import Lin, Norm, Dropper, mha_fwd, mha_bwd, layernorm_fwd, layernorm_bwd, EPS, fused_lin
 
 _f32 = torch.float32
 
@@ -81,9 +81,18 @@ class AoAGraph:
             y = n0.fwd(x)
             lq, lk, lv = (Lin(P, g, '%s.self_attn.linears.%d.weight' % (pre, j), '%s.self_attn.linears.%d.bias' % (pre, j))
                           for j in range(3))
-            q, k, v = lq.fwd(y), lk.fwd(y), lv.fwd(y)
+            # r4: q | k | v as ONE GEMM (N = 3R) when the model is flattened (AoAModel._flat_groups keeps the three weights back to
+            # back); the attention kernels read / write the column blocks in place
+            lqkv = fused_lin(P, g, ['%s.self_attn.linears.%d.weight' % (pre, j) for j in range(3)],
+                             ['%s.self_attn.linears.%d.bias' % (pre, j) for j in range(3)])
             dp = self.d_att(B, h, K, K)
-            o, p = mha_fwd(q, k, v, K * R, B, 1, K, K, h, self.smask, 1, 1, 0, 0, dp)
+            if lqkv is not None:
+                qkv = lqkv.fwd(y)
+                q, k, v = (qkv, 0), (qkv, R), (qkv, 2 * R)
+                o, p = mha_fwd(q, k, v, K * 3 * R, B, 1, K, K, h, self.smask, 1, 1, 0, 0, dp, kstride=3 * R, qstride=3 * R, D=R)
+            else:
+                q, k, v = lq.fwd(y), lk.fwd(y), lv.fwd(y)
+                o, p = mha_fwd(q, k, v, K * R, B, 1, K, K, h, self.smask, 1, 1, 0, 0, dp)
             o2 = o.view(B * K, R)
             m_o, m_y = self.d_aoa(B * K, R), self.d_aoa(B * K, R)
             od, yd = mul_mask(o2, m_o), mul_mask(y, m_y)
@@ -93,7 +102,7 @@ class AoAGraph:
                      bias=P[pre + '.self_attn.aoa_layer.0.bias'])
             m_res = self.d_res(B * K, R)
             x_new = glu_fwd(pre_act, m_res, x)
-            self.ref.append(dict(pre=pre, n0=n0, lq=lq, lk=lk, lv=lv, q=q, k=k, v=v, p=p, dp=dp, od=od, yd=yd, m_o=m_o, m_y=m_y,
+            self.ref.append(dict(pre=pre, n0=n0, lq=lq, lk=lk, lv=lv, lqkv=lqkv, q=q, k=k, v=v, p=p, dp=dp, od=od, yd=yd, m_o=m_o, m_y=m_y,
                                  pre_act=pre_act, m_res=m_res))
             x = x_new
         self.ref_norm = Norm(P, g, 'refiner.norm')
@@ -326,10 +335,17 @@ class AoAGraph:
             d_cat = ops.matmul_nn(d_pre, W)                                            # [BK,2R] = [d_od | d_yd]
             d_o = mul_mask(d_cat[:, :R].contiguous(), lay['m_o'])
             d_y = mul_mask(d_cat[:, R:].contiguous(), lay['m_y'])
-            dq, dk, dv = mha_bwd(d_o.view(B, K, R), lay['q'], lay['k'], lay['v'], K * R, lay['p'], lay['dp'], B, 1, K, K, h)
-            d_y = d_y + lay['lq'].bwd(dq.view(BK, R))
-            d_y += lay['lk'].bwd(dk.view(BK, R))
-            d_y += lay['lv'].bwd(dv.view(BK, R))
+            if lay['lqkv'] is not None:
+                dqkv = torch.empty(BK, 3 * R, dtype=_f32, device=dev)
+                mha_bwd(d_o.view(B, K, R), lay['q'], lay['k'], lay['v'], K * 3 * R, lay['p'], lay['dp'], B, 1, K, K, h, kstride=3 * R,
+                        qstride=3 * R, dq=(dqkv, 0), dq_stride=3 * R, dk_out=(dqkv, R), dv_out=(dqkv, 2 * R), dkv_ld=K * 3 * R,
+                        dkv_stride=3 * R)
+                d_y = d_y + lay['lqkv'].bwd(dqkv, fresh=True)                   # one dW, one column sum, one dX (K = 3R)
+            else:
+                dq, dk, dv = mha_bwd(d_o.view(B, K, R), lay['q'], lay['k'], lay['v'], K * R, lay['p'], lay['dp'], B, 1, K, K, h)
+                d_y = d_y + lay['lq'].bwd(dq.view(BK, R))
+                d_y += lay['lk'].bwd(dk.view(BK, R))
+                d_y += lay['lv'].bwd(dv.view(BK, R))
             lay['n0'].bwd(d_y, dx)
         self.embed.bwd(dx, need_dx=False)
 

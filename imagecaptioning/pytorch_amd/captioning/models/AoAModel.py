@@ -111,6 +111,12 @@ class AoAModel(CaptionModel):
     def _param_names(self):
         return [n for n, _ in self.named_parameters()]
 
+    def _flat_groups(self):
+        """Wq | Wk | Wv (and biases) of every refiner layer back to back in the flat buffers: one fused projection GEMM each"""
+        names = [n for n, _ in self.named_parameters()]
+        blocks = sorted({n[:n.index('.self_attn.') + len('.self_attn')] for n in names if n.startswith('refiner.') and '.self_attn.linears.' in n})
+        return [['%s.linears.%d.%s' % (b, i, kind) for i in range(3)] for b in blocks for kind in ('weight', 'bias')]
+
     def flatten_parameters_(self):
         from imagecaptioning.pytorch_amd.flat import FlatParams
         self._flat = FlatParams(self)
