@@ -15,7 +15,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import lib, ptr, check, stream_ptr
-from .transformer_engine import Lin, Norm, Dropper, mha_fwd, mha_bwd, layernorm_fwd, layernorm_bwd, EPS, fused_lin
+from .transformer_engine import Lin, Norm, Dropper, mha_fwd, mha_bwd, layernorm_fwd, layernorm_bwd, EPS, fused_lin, deferred_grads
 
 _f32 = torch.float32
 
@@ -75,6 +75,11 @@ class AoAGraph:
         self.embed = Lin(P, g, 'att_embed.0.weight', 'att_embed.0.bias')
         x = self.embed.fwd(att_feats.reshape(B * K, F), relu=True, mask=m)
         self.ref = []
+        # the refiner's dropout masks of all 6 layers, 4 per launch and per dropper, drawn in the order the layers consume them
+        # (same Philox offsets as one launch per mask: 24 -> 7 launches)
+        att_masks_it = iter(self.d_att.many([(B, h, K, K)] * 6))
+        aoa_masks_it = iter(self.d_aoa.many([(B * K, R)] * 12))
+        res_masks_it = iter(self.d_res.many([(B * K, R)] * 6))
         for i in range(6):
             pre = 'refiner.layers.%d' % i
             n0 = Norm(P, g, pre + '.sublayer.0.norm')
@@ -85,7 +90,7 @@ class AoAGraph:
             # back); the attention kernels read / write the column blocks in place
             lqkv = fused_lin(P, g, ['%s.self_attn.linears.%d.weight' % (pre, j) for j in range(3)],
                              ['%s.self_attn.linears.%d.bias' % (pre, j) for j in range(3)])
-            dp = self.d_att(B, h, K, K)
+            dp = next(att_masks_it)
             if lqkv is not None:
                 qkv = lqkv.fwd(y)
                 q, k, v = (qkv, 0), (qkv, R), (qkv, 2 * R)
@@ -94,13 +99,13 @@ class AoAGraph:
                 q, k, v = lq.fwd(y), lk.fwd(y), lv.fwd(y)
                 o, p = mha_fwd(q, k, v, K * R, B, 1, K, K, h, self.smask, 1, 1, 0, 0, dp)
             o2 = o.view(B * K, R)
-            m_o, m_y = self.d_aoa(B * K, R), self.d_aoa(B * K, R)
+            m_o, m_y = next(aoa_masks_it), next(aoa_masks_it)
             od, yd = mul_mask(o2, m_o), mul_mask(y, m_y)
             W = P[pre + '.self_attn.aoa_layer.0.weight']                      # [2R, 2R], input [att | query]
             pre_act = torch.empty(B * K, 2 * R, dtype=_f32, device=self.dev)
             ops.gemm([(od, R, W, 2 * R, R, 1), (yd, R, (W, R), 2 * R, R, 1)], B * K, 2 * R, pre_act,
                      bias=P[pre + '.self_attn.aoa_layer.0.bias'])
-            m_res = self.d_res(B * K, R)
+            m_res = next(res_masks_it)
             x_new = glu_fwd(pre_act, m_res, x)
             self.ref.append(dict(pre=pre, n0=n0, lq=lq, lk=lk, lv=lv, lqkv=lqkv, q=q, k=k, v=v, p=p, dp=dp, od=od, yd=yd, m_o=m_o, m_y=m_y,
                                  pre_act=pre_act, m_res=m_res))
@@ -224,6 +229,12 @@ class AoAGraph:
 
     # ------------------------------------------------------------------ backward
     def backward(self, g_logp, sparse=None):
+        # weight-gradient reductions and bias column sums of the Lin / Norm objects (refiner, att_embed, ctx2att) are finished by
+        # two batched launches at the end (ops.DeferredGrads), as in the Transformer's backward
+        with deferred_grads(self.dev):
+            self._backward(g_logp, sparse)
+
+    def _backward(self, g_logp, sparse=None):
         P, g, h, B, K, R, n, N, T, L = self.P, self.g, self.h, self.B, self.K, self.R, self.n, self.N, self.T, self.L
         V1, E = P['embed.0.weight'].shape
         dev = self.dev
