@@ -97,21 +97,22 @@ def attention_large_batch(dev, B=1024, sets=6, iters=30):
 def pmc_traffic(instance=False):
     """HBM bytes per decode-GEMM launch from the PMC passes of this same command (FETCH_SIZE and WRITE_SIZE need
     separate rocprofv3 --pmc runs, so they cannot be sampled inside this process): profiles/r0N_pmc_traffic.json,
-    written by scripts/tools_pmc_traffic.py with the gfx950 corrections of MI355X_MICROARCH.md.  None if absent."""
+    written by scripts/tools_pmc_traffic.py with the gfx950 corrections of MI355X_MICROARCH.md.  None if absent.
+    The line says so itself (`roofline.traffic_source`): imported, not measured in this run."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in (PMC_FILE,):
-        try:
-            with open(os.path.join(here, 'profiles', name)) as f:
-                d = json.load(f)
-            if instance:       # the dominant kernel alone (the weight-streaming launches of gemm_lc_kernel<true,2>: LSTM gates, logit)
-                for k, v in d['kernels'].items():
-                    if 'gemm_lc_kernel<true, 2, 0> [stream]' in k:
-                        return round(v['fetch_bytes_corrected'] + v['write_bytes'])
-            return round(d['decode_gemm']['traffic_bytes'])
-        except (OSError, KeyError, ValueError):
-            continue
-    return None
-PMC_FILE = 'r03_pmc_traffic.json'
+    try:
+        with open(os.path.join(here, 'profiles', PMC_FILE)) as f:
+            d = json.load(f)
+        if instance:       # the dominant kernel alone (the weight-streaming launches of gemm_lc_kernel<true,2>: LSTM gates, logit)
+            for k, v in d['kernels'].items():
+                if 'gemm_lc_kernel<true, 2' in k and '[stream]' in k:
+                    return round(v['fetch_bytes_corrected'] + v['write_bytes'])
+        return round(d['decode_gemm']['traffic_bytes'])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+PMC_FILE = 'r04_pmc_traffic.json'
 
 
 def prof_read(lib, cls):
@@ -502,7 +503,7 @@ def main():
                      'gemm_decode_stream': {'ms_per_step': round(g_ms / n_sampled, 4), 'launches_per_step': g_n / n_sampled},
                      'gemm_decode_small': {'ms_per_step': round(s_ms / n_sampled, 4), 'launches_per_step': s_n / n_sampled},
                      'attention_fwd': {'ms_per_step': round(a_ms / n_sampled, 4), 'launches_per_step': a_n / n_sampled},
-                     'note': 'full per-kernel table: profiles/r03*_scst_kernel_stats.md (rocprofv3 --kernel-trace --stats)'}
+                     'note': 'full per-kernel table: profiles/r04_scst_kernel_stats.md (rocprofv3 --kernel-trace --stats)'}
         ach = (g_bytes / g_n) / (g_ms / g_n * 1e-3) / 1e9 if g_n else 0.0
         tfl = g_flops / (g_ms * 1e-3) / 1e12 if g_ms else 0.0
         # which roof bounds this launch mix.  The decode GEMMs compute fp32 through the bf16 pipe by the exact 3-way

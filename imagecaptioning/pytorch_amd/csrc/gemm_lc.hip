@@ -11,7 +11,7 @@
 //  * no MFMA can start before the WHOLE activation slice (147 KB) has landed and been published by a barrier: ~10k cycles;
 //  * the two K halves of a column group meet in LDS behind the loop: 4-5k cycles more.
 // Here the roles are split (MI355X_MICROARCH.md, rows ldsdma-fill / prefetch-credit):
-//  * waves 4-7 are LOADERS: they copy one K chunk per stage -- its activation image (12 KB, three bf16 planes of 64 rows) and
+//  * waves 8-11 are LOADERS: they copy one K chunk per stage -- its activation image (12 KB, three bf16 planes of 64 rows) and
 //    its weight tile (128 columns x 32 k fp32 = 16 KB) -- into a 5-stage LDS ring with global_load_lds_dwordx4.  LDS-DMA has no
 //    register destination: a stalled loader holds up nobody, and 4 stages (112 KB) are in flight per CU from the first cycle;
 //  * waves 0-7 are CONSUMERS, two per SIMD: column group cg = w & 3 (32 columns, all 64 rows) x stage parity w >> 2 (even / odd
