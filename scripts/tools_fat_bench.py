@@ -45,13 +45,4 @@ for name, M, N, K, al, bl in shapes:
     t = timeit(lambda: ops.gemm([(A, lda, B, ldb, K, 1)], M, N, out, a_layout=al, b_layout=bl, ws=ws))
     ref = (A.t() if al else A) @ (B if bl else B.t())
     err = (out - ref).abs().max().item() / ref.abs().max().item()
-    # round 3: both operands as planes (capmi_planes_split once per operand + the split-free kernel)
-    apl, bpl = ops.planes_split(A, transposed=bool(al)), ops.planes_split(B, transposed=bool(bl))
-    out2 = torch.empty(M, N, device=dev)
-    tp = timeit(lambda: ops.gemm([(None, lda, None, ldb, K, 1)], M, N, out2, a_layout=al, b_layout=bl, ws=ws, a_planes=[apl],
-                                 b_planes=[bpl]))
-    tsa = timeit(lambda: ops.planes_split(A, transposed=bool(al), out=apl))
-    tsb = timeit(lambda: ops.planes_split(B, transposed=bool(bl), out=bpl))
-    same = bool(torch.equal(out, out2))
-    print('%-40s %7.1f us  %6.1f TF/s  relerr %.1e | planes %7.1f us %6.1f TF/s  split A %5.1f B %5.1f us  bit-equal %s'
-          % (name, t, 2.0 * M * N * K / t / 1e6, err, tp, 2.0 * M * N * K / tp / 1e6, tsa, tsb, same), flush=True)
+    print('%-40s %7.1f us  %6.1f TF/s  relerr %.1e' % (name, t, 2.0 * M * N * K / t / 1e6, err), flush=True)
