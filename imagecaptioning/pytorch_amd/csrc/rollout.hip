@@ -203,12 +203,17 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
     // recorded behind every k-th step, and the host reads that word two steps later -- by then the device has two more steps queued
     // and never waits for the host.  The steps queued behind the decisive one see finished rows only.
     const int ee = (!r->teacher && r->early_exit > 0 && r->alive_host) ? r->early_exit : 0;
-    static thread_local hipEvent_t ee_ev[4];
-    static thread_local bool ee_init = false;
-    if (ee && !ee_init) {
-        for (auto &e : ee_ev)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return CAPMI_EINVAL;
-        ee_init = true;
+    // (events belong to the device they were created on: one set per thread AND device)
+    constexpr int EE_MAX_DEV = 16;
+    static thread_local hipEvent_t ee_evs[EE_MAX_DEV][4];
+    static thread_local bool ee_inits[EE_MAX_DEV] = {};
+    int ee_dev = 0;
+    if (ee && (hipGetDevice(&ee_dev) != hipSuccess || ee_dev < 0 || ee_dev >= EE_MAX_DEV)) return CAPMI_EINVAL;
+    hipEvent_t *ee_ev = ee_evs[ee_dev];
+    if (ee && !ee_inits[ee_dev]) {
+        for (int i = 0; i < 4; ++i)
+            if (hipEventCreateWithFlags(&ee_ev[i], hipEventDisableTiming) != hipSuccess) return CAPMI_EINVAL;
+        ee_inits[ee_dev] = true;
     }
     if (ee) for (int t = 0; t < L; ++t) r->alive_host[t] = 0;
     int ee_pending = -1, ee_slot = 0, steps_run = T;

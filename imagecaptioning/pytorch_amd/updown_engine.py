@@ -207,9 +207,11 @@ class Rollout:
             self.alive = _alive_buffer(dev, L)
             r.early_exit, r.early_exit_from, r.alive_host = int(early_exit), int(early_exit_from), self.alive.data_ptr()
         self.r = r
+        self.T_cfg = int(r.T)
         self.w = weights_struct(P)
 
     def run(self):
+        self.r.T = self.T_cfg                # (a previous run on this object may have ended early: every run starts from the configured T)
         check(lib.capmi_updown_rollout_fwd(C.byref(self.w), C.byref(self.r), stream_ptr()), 'capmi_updown_rollout_fwd')
         self.steps_run = int(self.r.steps_run)
         self.r.T = self.steps_run            # the backward runs over the steps that were enqueued

@@ -70,3 +70,26 @@ def test_early_exit_never_fires_on_a_model_that_never_ends():
     seq, _ = ro.run()
     torch.cuda.synchronize()
     assert ro.steps_run == 20 and bool((seq > 0).all())
+
+
+def test_a_rollout_object_can_be_run_again_after_an_early_exit():
+    """run() used to leave r.T at the number of steps the early exit had enqueued, so a SECOND run() on the same object
+    was capped at that length.  With weights that end captions early on the first run and never on the second, the second run must
+    enqueue all T steps again."""
+    from imagecaptioning.pytorch_amd import updown_engine as E
+    from shapes import full_size_params
+    dev = torch.device('cuda:0')
+    P = {k: v.to(dev).contiguous() for k, v in full_size_params(seed=6).items()}
+    P['logit.bias'] = P['logit.bias'].clone()
+    P['logit.bias'][0] += 12.0
+    fc = torch.randn(4, 2048, device=dev).clamp_min(0)
+    att = torch.randn(4, 36, 2048, device=dev).clamp_min(0)
+    pr = E.prepare(P, fc, att, None)
+    ro = E.Rollout(P, pr, n=5, T=20, mode='sample', seed=3, early_exit=2, early_exit_from=0)
+    ro.run()
+    torch.cuda.synchronize()
+    assert ro.steps_run < 20
+    P['logit.bias'][0] -= 62.0                     # the same weight tensors, now a model that never ends (the structs hold pointers)
+    seq, _ = ro.run()
+    torch.cuda.synchronize()
+    assert ro.steps_run == 20 and bool((seq > 0).all())
