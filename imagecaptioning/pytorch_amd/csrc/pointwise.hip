@@ -152,6 +152,20 @@ __global__ __launch_bounds__(64) void lstm_cell_fwd_vec_kernel(
     const float *pb = partial + (size_t)r * 4 * R + j;
     const float *pb2 = partial2 ? partial2 + (size_t)r * 4 * R + j : pb;
     const int tot = splits + splits2;
+    // r4: the bias rows are requested in the same round trip as the slabs (they used to be requested behind the slab sum: a
+    // second trip); added afterwards in the old order, so the results are bit-identical
+    f32x4 bi[4], bh[4], br[4];
+    {
+        const float *rb = row_bias ? row_bias + (size_t)(row_bias_idx ? row_bias_idx[r] : r / row_bias_div) * 4 * R : nullptr;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t col = (size_t)q * R + j;
+            bi[q] = b_ih ? *reinterpret_cast<const f32x4 *>(b_ih + col) : z4;
+            bh[q] = b_hh ? *reinterpret_cast<const f32x4 *>(b_hh + col) : z4;
+            br[q] = rb ? *reinterpret_cast<const f32x4 *>(rb + col) : z4;
+        }
+    }
     for (int s0 = 0; s0 < tot; s0 += 8) {
         f32x4 tv[8][4];
 #pragma unroll
@@ -170,11 +184,9 @@ __global__ __launch_bounds__(64) void lstm_cell_fwd_vec_kernel(
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const size_t col = (size_t)q * R + j;
-        if (b_ih) g[q] += *reinterpret_cast<const f32x4 *>(b_ih + col);
-        if (b_hh) g[q] += *reinterpret_cast<const f32x4 *>(b_hh + col);
-        if (row_bias)
-            g[q] += *reinterpret_cast<const f32x4 *>(row_bias + (size_t)(row_bias_idx ? row_bias_idx[r] : r / row_bias_div) * 4 * R + col);
+        if (b_ih) g[q] += bi[q];
+        if (b_hh) g[q] += bh[q];
+        if (row_bias) g[q] += br[q];
     }
     f32x4 ig, fg, gg, og, cn, hn, hd;
 #pragma unroll
