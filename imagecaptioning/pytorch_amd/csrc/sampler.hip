@@ -208,17 +208,27 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
 // sum of the logit GEMM's K-slice slabs + bias (so the split-K reduce launch and the logits round trip disappear),
 // then max / sum-exp / choice / dense log-prob write all run from registers.  Same thread->vocabulary-quad map as
 // the streaming kernel above, hence identical Philox counters and identical samples.
+// The arguments of one select launch (one struct so that the fused select + GEMM launch can carry them next to the GEMM's).
+struct SelArgs {
+    const float *src; int splits; size_t slab_stride; const float *bias; int V1, step, L, mode; const uint8_t *row_mode;
+    float temperature; const float *gumbel; uint64_t seed; const int64_t *forced; int forced_ld, no_finish_mask; int64_t *seq;
+    int seq_ld; int64_t *it_next; uint8_t *unfinished; float *seq_logp, *sel_logp; uint8_t *live; NextEmbed ne; int top_k;
+    float top_p; int abl;
+};
+
+// Body of the register-resident select for caption row r; s_f [32] / s_i [32] / s_tok [1] are workgroup scratch in LDS (static in the
+// stand-alone kernel, carved out of the dynamic region in the fused launch, where static LDS would misalign the GEMM's ring).
 template <int NQ>
-__global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
-    const float *__restrict__ src, int splits, size_t slab_stride, const float *__restrict__ bias, int V1, int step, int L,
-    int mode, const uint8_t *__restrict__ row_mode, float temperature, const float *__restrict__ gumbel, uint64_t seed,
-    const int64_t *__restrict__ forced, int forced_ld, int no_finish_mask, int64_t *__restrict__ seq, int seq_ld,
-    int64_t *__restrict__ it_next, uint8_t *__restrict__ unfinished, float *__restrict__ seq_logp,
-    float *__restrict__ sel_logp, uint8_t *__restrict__ live, const NextEmbed ne, int top_k, float top_p, int abl) {
-    __shared__ float s_f[32];
-    __shared__ int s_i[32];
-    __shared__ float s_tok;
-    const int r = blockIdx.x;
+__device__ __forceinline__ void select_reg_body(const SelArgs &A, const int r, float *s_f, int *s_i, float *s_tok_p) {
+    const float *__restrict__ src = A.src; const int splits = A.splits; const size_t slab_stride = A.slab_stride;
+    const float *__restrict__ bias = A.bias; const int V1 = A.V1, step = A.step, L = A.L, mode = A.mode;
+    const uint8_t *__restrict__ row_mode = A.row_mode; const float temperature = A.temperature;
+    const float *__restrict__ gumbel = A.gumbel; const uint64_t seed = A.seed; const int64_t *__restrict__ forced = A.forced;
+    const int forced_ld = A.forced_ld, no_finish_mask = A.no_finish_mask; int64_t *__restrict__ seq = A.seq; const int seq_ld = A.seq_ld;
+    int64_t *__restrict__ it_next = A.it_next; uint8_t *__restrict__ unfinished = A.unfinished; float *__restrict__ seq_logp = A.seq_logp;
+    float *__restrict__ sel_logp = A.sel_logp; uint8_t *__restrict__ live = A.live; const NextEmbed &ne = A.ne; const int top_k = A.top_k;
+    const float top_p = A.top_p; const int abl = A.abl;
+#define s_tok (*s_tok_p)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = SEL_THREADS >> 6;
     const int my_mode = row_mode ? (int)row_mode[r] : mode;
     const int nq = V1 >> 2;
@@ -399,6 +409,15 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(
         if (ne.alive && (no_finish_mask || (was_unf && token != 0))) *ne.alive = 1;
     }
 }
+#undef s_tok
+
+template <int NQ>
+__global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(const SelArgs A) {
+    __shared__ float s_f[32];
+    __shared__ int s_i[32];
+    __shared__ float s_tok;
+    select_reg_body<NQ>(A, blockIdx.x, s_f, s_i, &s_tok);
+}
 
 __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_bwd_kernel(const float *__restrict__ g,
                                                                       const float *__restrict__ seq_logp,
@@ -548,10 +567,9 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
                     (slab_stride % 4 == 0);
     static const int env_abl = capmi::ablate_env("CAPMI_SEL_ABLATE");   // profiling only
     if (al && V1 % 4 == 0 && V1 <= 3 * 4 * SEL_THREADS) {
-#define CAPMI_SEL(NQ)                                                                                                   \
-    hipLaunchKernelGGL(logsoftmax_select_reg_kernel<NQ>, dim3(N), dim3(SEL_THREADS), 0, st, partial, splits,           \
-                       (size_t)slab_stride, bias, V1, step, L, mode, row_mode, temperature, gumbel, seed, forced,       \
-                       forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live, ne, top_k, top_p, env_abl)
+        const SelArgs sa{partial, splits, (size_t)slab_stride, bias, V1, step, L, mode, row_mode, temperature, gumbel, seed, forced,
+                         forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live, ne, top_k, top_p, env_abl};
+#define CAPMI_SEL(NQ) hipLaunchKernelGGL(logsoftmax_select_reg_kernel<NQ>, dim3(N), dim3(SEL_THREADS), 0, st, sa)
         if (V1 <= 4 * SEL_THREADS) CAPMI_SEL(1);
         else if (V1 <= 8 * SEL_THREADS) CAPMI_SEL(2);
         else CAPMI_SEL(3);
