@@ -48,7 +48,7 @@ class UpDownRollout(C.Structure):
                                     'fc_gates', 'logits', 'it', 'unfinished', 'partial')] +
                 [('partial_capacity', C.c_int64), ('top_k', C.c_int), ('top_p', C.c_float), ('ss_mode', c_f),
                  ('planes', c_f), ('planes_bytes', C.c_int64), ('early_exit', C.c_int), ('early_exit_from', C.c_int),
-                 ('alive_host', c_f), ('steps_run', C.c_int)])
+                 ('alive_host', c_f), ('steps_run', C.c_int), ('pre_partial', c_f), ('pre_capacity', C.c_int64)])
 
 
 class SampleFilter(C.Structure):
@@ -149,6 +149,8 @@ SIGNATURES = {
     'capmi_logsoftmax_select': [_P, _I, _I, _I, _I, _I, _P, _F, _P, _U64, _P, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P],
     'capmi_logsoftmax_select_partial': [_P, _I, _I64, _P, _I, _I, _I, _I, _I, _P, _F, _P, _U64, _P, _I, _I, _P, _I, _P, _P, _P,
                                         _P, _P, _P, _P, _P],
+    'capmi_logsoftmax_select_partial_gemm': [_P, _I, _I64, _P, _I, _I, _I, _I, _I, _P, _F, _P, _U64, _P, _I, _I, _P, _I, _P, _P, _P,
+                                        _P, _P, _P, _P, _P, _P],
     'capmi_logsoftmax_bwd': [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     'capmi_logsoftmax_bwd_sparse': [C.POINTER(SparseLogpGrad), _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'capmi_splitk_reduce': [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _P],

@@ -63,6 +63,15 @@ __device__ __forceinline__ void locate(const KArgs &a, int tile, int &s, int &k0
 int ares_plan(int N, int tiles, int want_blocks, int ts_cap, int *splits);
 int ares_ts_cap(int M, int x3);
 int launch_ares(const KArgs &a, int b_layout, int ts_max, int x3, hipStream_t st, int pcls, double bytes, double flops);
+// r4: a caller that wants to run the loader / consumer GEMM INSIDE another launch (sampler.hip: select + GEMM in one grid) sets this
+// pointer around capmi_gemm_f32(); launch_lc() then stores its arguments here instead of launching.  filled stays false when the
+// dispatcher took another path (that GEMM was launched normally).
+struct LcCapture {
+    KArgs a;
+    int b_layout, grid_x, grid_y, tm;
+    bool filled;
+};
+extern thread_local LcCapture *g_lc_capture;
 // loader / consumer kernel on A planes (gemm_lc.hip): lc_plan picks a.sl and a.splits
 int lc_plan(int N, int tiles, int want_blocks, int *splits);
 int launch_lc(const KArgs &a, int b_layout, hipStream_t st, int pcls, double bytes, double flops);

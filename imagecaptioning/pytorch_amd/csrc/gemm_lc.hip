@@ -112,9 +112,17 @@ static int launch_lc_t(const KArgs &a, hipStream_t st, int pcls, double bytes, d
 }
 
 // a.splits * a.sl must cover a.tiles_total with no empty slice; every segment carries planes
+thread_local LcCapture *g_lc_capture = nullptr;
+
 int launch_lc(const KArgs &a, int b_layout, hipStream_t st, int pcls, double bytes, double flops) {
     if (a.sl < 1 || a.M > 64 || (long long)a.splits * a.sl < a.tiles_total || (long long)(a.splits - 1) * a.sl >= a.tiles_total)
         return CAPMI_EINVAL;
+    if (g_lc_capture) {                              // the caller launches the body itself (fused select + GEMM)
+        LcCapture &c = *g_lc_capture;
+        c.a = a; c.b_layout = b_layout; c.grid_x = (a.N + LC_BN - 1) / LC_BN; c.grid_y = a.splits; c.tm = a.M <= 32 ? 1 : 2;
+        c.filled = true;
+        return 0;
+    }
     if (b_layout == 0) return a.M <= 32 ? launch_lc_t<true, 1>(a, st, pcls, bytes, flops) : launch_lc_t<true, 2>(a, st, pcls, bytes, flops);
     return a.M <= 32 ? launch_lc_t<false, 1>(a, st, pcls, bytes, flops) : launch_lc_t<false, 2>(a, st, pcls, bytes, flops);
 }

@@ -189,6 +189,14 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
     }
 
 
+    // r4: the h_lang / h_att segments of the NEXT step's attention-LSTM gates ride in the idle workgroups of this step's select launch
+    // (capmi.h capmi_updown_rollout.pre_partial, capmi_logsoftmax_select_partial_gemm)
+    const bool use_pre = pl_zero && r->pre_partial && !r->teacher &&
+                         r->pre_capacity >= CAPMI_WS_COUNTER_FLOATS + (int64_t)8 * N * 4 * R;
+    float *preA = use_pre ? r->pre_partial : nullptr;
+    int preA_splits = 0;
+    bool preA_valid = false;                          // slabs of the ahead part for the step about to run
+
     // initial state (slot 0) and flags
     RC(capmi_rollout_init(r->h_att, r->c_att, r->h_lang, r->c_lang, (int64_t)NR, r->it, r->unfinished, N, stream));   // bos = 0
 
@@ -259,9 +267,14 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
             SegSpec s[3] = {{h_lang_prev, R, w->att_w_ih, ld_att_ih, R, 1, t ? pl_h_lang : pl_zero},
                             {xt, E, w->att_w_ih + 2 * R, ld_att_ih, E, 1, pl_xt},
                             {h_att_prev, R, w->att_w_hh, R, R, 1, t ? pl_h_att : pl_zero}};
-            RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s, 3, r->partial, r->partial_capacity, 1, &splits, nullptr,
-                    nullptr, 0, pl_zero));
-            RC(capmi_lstm_cell_fwd_pl2(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, nullptr, 0, w->att_b_ih, w->att_b_hh, r->fc_gates, n, r->row_img,
+            if (preA_valid)     // the h_lang / h_att segments were computed inside the previous step's select launch
+                RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s + 1, 1, r->partial, r->partial_capacity, 1, &splits, nullptr,
+                        nullptr, 0, pl_zero));
+            else
+                RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s, 3, r->partial, r->partial_capacity, 1, &splits, nullptr,
+                        nullptr, 0, pl_zero));
+            RC(capmi_lstm_cell_fwd_pl2(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, preA_valid ? preA + CAPMI_WS_COUNTER_FLOATS : nullptr,
+                                       preA_valid ? preA_splits : 0, w->att_b_ih, w->att_b_hh, r->fc_gates, n, r->row_img,
                                        c_att_prev, h_att, c_att, r->gates_att + (size_t)t * N * 4 * R, nullptr, nullptr, N, R,
                                        pl_h_att, nullptr, stream));
         }
@@ -315,6 +328,26 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
                                                r->live, &ne, nullptr, stream));
             continue;
         }
+        preA_valid = false;
+        if (use_pre && t + 1 < T) {
+            // select of step t + [h_lang(t) | h_att(t)] . [W_ih(:, 0:R) | W_hh]^T of step t+1's attention LSTM in ONE launch
+            capmi_gemm_desc ah{};
+            ah.nseg = 2;
+            ah.seg[0].A = h_lang; ah.seg[0].lda = R; ah.seg[0].B = w->att_w_ih; ah.seg[0].ldb = ld_att_ih; ah.seg[0].K = R; ah.seg[0].a_row_div = 1;
+            ah.seg[1].A = h_att; ah.seg[1].lda = R; ah.seg[1].B = w->att_w_hh; ah.seg[1].ldb = R; ah.seg[1].K = R; ah.seg[1].a_row_div = 1;
+            ah.a_planes[0] = pl_h_lang; ah.a_planes[1] = pl_h_att;
+            ah.M = N; ah.N = 4 * R; ah.C = preA; ah.ldc = 4 * R;
+            ah.partial = preA; ah.partial_capacity = r->pre_capacity;
+            ah.splits = 6;                            // 32 column blocks x 6 K slices = 192 workgroups beside the N select rows
+            ah.defer_reduce = 1;
+            RC(capmi_logsoftmax_select_partial_gemm(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, (int64_t)N * V1, w->logit_b, N, V1, t, L,
+                                                    r->mode, r->row_mode, r->temperature,
+                                                    r->gumbel ? r->gumbel + (size_t)t * N * V1 : nullptr, r->seed, r->forced,
+                                                    r->forced_ld, 0, r->seq, L, r->it, r->unfinished, r->seq_logp, r->sel_logp,
+                                                    r->live, &ne, (r->top_k > 0 || r->top_p > 0.f) ? &flt : nullptr, &ah, stream));
+            preA_splits = ah.splits_used;
+            preA_valid = true;
+        } else
         RC(capmi_logsoftmax_select_partial(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, (int64_t)N * V1, w->logit_b, N, V1, t,
                                            L, r->teacher ? 2 : r->mode, r->teacher ? nullptr : r->row_mode, r->temperature,
                                            r->gumbel ? r->gumbel + (size_t)t * N * V1 : nullptr, r->seed, r->forced,

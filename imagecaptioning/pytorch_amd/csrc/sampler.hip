@@ -10,6 +10,7 @@
 #include "capmi_common.h"
 #include "profile.h"
 #include "../../../include/capmi.h"
+#include "gemm_lc_body.h"      // (r4: the decode GEMM's body, for the fused select + GEMM launch)
 
 using namespace capmi;
 
@@ -411,6 +412,27 @@ __device__ __forceinline__ void select_reg_body(const SelArgs &A, const int r, f
 }
 #undef s_tok
 
+// r4 -- select + GEMM in ONE grid.  The select of step t keeps 60 CUs busy for ~14.5 us (a latency chain: slabs -> max / sum-exp ->
+// Gumbel arg-max -> embedding gather) while the other 196 idle; two thirds of the NEXT step's attention-LSTM gate GEMM -- the K
+// segments fed by h_lang(t) and h_att(t), 32 MB of weights -- depend on nothing this select produces.  Workgroups 0 .. n_sel-1 run the
+// select body, the rest run gemm_lc's body on that part (threads >= 768 leave at once: s_barrier counts surviving waves only); the
+// following gate GEMM is left with the token-embedding segment and the LSTM cell sums both slab sets.  One launch, no stream, no
+// event, no flag: the two halves never talk.  The select's scratch sits behind the ring in the dynamic LDS (static LDS would
+// misalign the ring's ds_read_b128).
+template <int NQ>
+__global__ __launch_bounds__(SEL_THREADS) void select_gemm_kernel(const SelArgs A, const capmi_gemm::KArgs g, int n_sel, int gx, int gy) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
+    if ((int)blockIdx.x < n_sel) {
+        unsigned char *scr = fused_lds + capmi_gemm::LC_NS * capmi_gemm::LC_STAGE;
+        select_reg_body<NQ>(A, blockIdx.x, reinterpret_cast<float *>(scr), reinterpret_cast<int *>(scr + 128),
+                            reinterpret_cast<float *>(scr + 256));
+        return;
+    }
+    if ((int)threadIdx.x >= capmi_gemm::LC_NT) return;
+    const int L = (int)blockIdx.x - n_sel;
+    capmi_gemm::gemm_lc_body<true, 2, 0, capmi_gemm::LC_WAUX>(g, L % gx, L / gx, gx, gy, fused_lds);
+}
+
 template <int NQ>
 __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_reg_kernel(const SelArgs A) {
     __shared__ float s_f[32];
@@ -581,6 +603,65 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
                        V1, step, L, mode, row_mode,
                        temperature, gumbel, seed, forced, forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished,
                        seq_logp, sel_logp, live, ne, top_k, top_p, 0);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_logsoftmax_select_partial_gemm(const float *partial, int splits, int64_t slab_stride, const float *bias, int N,
+                                         int V1, int step, int L, int mode, const uint8_t *row_mode, float temperature,
+                                         const float *gumbel, uint64_t seed, const int64_t *forced, int forced_ld,
+                                         int no_finish_mask, int64_t *seq, int seq_ld, int64_t *it_next, uint8_t *unfinished,
+                                         float *seq_logp, float *sel_logp, uint8_t *live, const capmi_next_embed *next,
+                                         const capmi_sample_filter *filter, capmi_gemm_desc *ahead, void *stream) {
+    if (!ahead) return CAPMI_EINVAL;
+    // what the stand-alone select would run on these arguments
+    const int top_k = filter ? filter->top_k : 0;
+    const float top_p = filter ? filter->top_p : 0.f;
+    const bool al = ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(gumbel) |
+                      reinterpret_cast<uintptr_t>(seq_logp)) & 15) == 0 && (slab_stride % 4 == 0);
+    const bool reg_path = partial && splits >= 1 && N > 0 && al && V1 > 0 && V1 % 4 == 0 && V1 <= 3 * 4 * SEL_THREADS &&
+                          (!next || !next->x || (next->E && next->Edim > 0 && !(next->x_planes && N > 64)));
+    capmi_gemm::LcCapture cap{};
+    capmi_gemm::g_lc_capture = &cap;
+    const int rc = capmi_gemm_f32(ahead, stream);          // plans the GEMM; launches it only if it is not a loader / consumer GEMM
+    capmi_gemm::g_lc_capture = nullptr;
+    if (rc) return rc;
+    const bool fuse = cap.filled && reg_path && cap.tm == 2 && cap.b_layout == 0 && N + cap.grid_x * cap.grid_y <= 256 &&
+                      step >= 0 && step < L && seq && it_next && (no_finish_mask || unfinished) && !(mode == 2 && !forced) &&
+                      !(mode == 1 && !(temperature > 0.f)) && top_k >= 0 && top_p >= 0.f && top_p < 1.f && !(top_k > 0 && top_p > 0.f);
+    if (!fuse) {
+        if (cap.filled) {                                   // planned but not fusable here: launch it the ordinary way
+            const int rc2 = capmi_gemm_f32(ahead, stream);
+            if (rc2) return rc2;
+        }
+        return capmi_logsoftmax_select_partial(partial, splits, slab_stride, bias, N, V1, step, L, mode, row_mode, temperature, gumbel,
+                                               seed, forced, forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp,
+                                               sel_logp, live, next, filter, stream);
+    }
+    NextEmbed ne{};
+    if (next && next->x)
+        ne = NextEmbed{next->E, next->mask, next->x, next->it_save, next->Edim, next->relu, static_cast<unsigned char *>(next->x_planes),
+                       nullptr};
+    if (next) ne.alive = next->alive;
+    const SelArgs sa{partial, splits, (size_t)slab_stride, bias, V1, step, L, mode, row_mode, temperature, gumbel, seed, forced,
+                     forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live, ne, top_k, top_p, 0};
+    const size_t lds = (size_t)capmi_gemm::LC_NS * capmi_gemm::LC_STAGE + 512;
+    const dim3 grid(N + cap.grid_x * cap.grid_y);
+#define CAPMI_FUSED(NQ)                                                                                                     \
+    do {                                                                                                                    \
+        static bool set = false;                                                                                            \
+        if (!set) {                                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&select_gemm_kernel<NQ>),                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
+            set = true;                                                                                                     \
+        }                                                                                                                   \
+        hipLaunchKernelGGL(select_gemm_kernel<NQ>, grid, dim3(SEL_THREADS), lds, (hipStream_t)stream, sa, cap.a, N, cap.grid_x, \
+                           cap.grid_y);                                                                                     \
+    } while (0)
+    if (V1 <= 4 * SEL_THREADS) CAPMI_FUSED(1);
+    else if (V1 <= 8 * SEL_THREADS) CAPMI_FUSED(2);
+    else CAPMI_FUSED(3);
+#undef CAPMI_FUSED
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

@@ -197,6 +197,12 @@ class Rollout:
             nb = int(lib.capmi_updown_planes_bytes(R, E))
             self.planes = ops.planes_scratch(dev, ('updown_fwd', R, E), nb)
             r.planes, r.planes_bytes = self.planes.data_ptr(), nb
+            if not teacher and os.environ.get('CAPMI_FUSED_SELECT', '1') != '0':
+                # r4: slab workspace of the part of the next step's attention-LSTM gate GEMM that is computed inside the select
+                # launch (capmi.h capmi_updown_rollout.pre_partial): [ticket words | up to 8 K-slice slabs of N x 4R]
+                per = ops.Workspace.COUNTER_FLOATS + 8 * 64 * 4 * R
+                self.pre = ops.planes_scratch(dev, ('updown_pre', R), per * 4).view(torch.float32)
+                r.pre_partial, r.pre_capacity = self.pre.data_ptr(), per
         # early exit of free-running rollouts (AttModel.py:349-350): behind steps early_exit_from + k * early_exit - 1 (7, 11, 15 by
         # default) the driver looks, two steps later, at a pinned word the select kernels set and stops enqueuing once every row
         # has emitted its EOS (CAPMI_EARLY_EXIT=0: never)

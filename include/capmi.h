@@ -285,6 +285,17 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
                                     int64_t *seq, int seq_ld, int64_t *it_next, uint8_t *unfinished,
                                     float *seq_logp, float *sel_logp, uint8_t *live,
                                     const capmi_next_embed *next, const capmi_sample_filter *filter, void *stream);
+/* r4: the same select with a GEMM riding in the idle workgroups of ITS launch.  `ahead` describes a loader / consumer decode GEMM
+ * (M <= 64, every segment with A planes, defer_reduce = 1: K-slice slabs in ahead->partial, ahead->splits_used on return) that
+ * depends on nothing this select writes -- in the rollout: the h_lang / h_att segments of the NEXT step's attention-LSTM gates
+ * (AttModel.py:626-627), 2/3 of that GEMM's weights.  N select workgroups + the GEMM's workgroups must fit 256; when they do
+ * not, or the GEMM / select take another kernel, both are launched one after the other with identical results. */
+int capmi_logsoftmax_select_partial_gemm(const float *partial, int splits, int64_t slab_stride, const float *bias, int N,
+                                         int V1, int step, int L, int mode, const uint8_t *row_mode, float temperature,
+                                         const float *gumbel, uint64_t seed, const int64_t *forced, int forced_ld,
+                                         int no_finish_mask, int64_t *seq, int seq_ld, int64_t *it_next, uint8_t *unfinished,
+                                         float *seq_logp, float *sel_logp, uint8_t *live, const capmi_next_embed *next,
+                                         const capmi_sample_filter *filter, capmi_gemm_desc *ahead, void *stream);
 
 /* gradient of the dense log-probs w.r.t. the logits for ALL steps at once:
  *   dlogits[r,t,:] = g[r,t,:] - exp(logp[r,t,:]) * sum_v g[r,t,v]      (rows where logp was masked
@@ -515,6 +526,13 @@ typedef struct capmi_updown_rollout {
     int early_exit_from;
     int32_t *alive_host;
     int steps_run;
+    /* r4, optional (needs `planes`, free-running rollouts): K-slice slab workspace (pre_capacity floats, laid out like `partial`:
+     * CAPMI_WS_COUNTER_FLOATS zeroed words + slabs) of the AHEAD part of the attention-LSTM gate GEMM.  The K segments fed by
+     * h_lang(t) and h_att(t) -- 2/3 of the next step's gate GEMM, independent of the token being chosen -- are computed inside the
+     * select launch of step t (capmi_logsoftmax_select_partial_gemm: the select keeps 60 of 256 CUs busy); the gate GEMM of
+     * step t+1 keeps the token-embedding segment and the LSTM cell sums both slab sets.  NULL: one gate GEMM per step. */
+    float *pre_partial;
+    int64_t pre_capacity;
 } capmi_updown_rollout;
 
 int64_t capmi_updown_planes_bytes(int R, int E);
