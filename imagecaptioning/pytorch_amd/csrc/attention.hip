@@ -44,6 +44,15 @@ inline int pick_rpb(int B, int n) {
     if (rpb > NMAX) rpb = NMAX;
     return rpb;
 }
+// forward (r4): round UP, so that B * n in (256, 512] rows (XE at bs64 x 5 = 320) becomes <= 256 workgroups of two rows and stays on
+// the register-resident kernel instead of 320 one-row workgroups of the streaming one
+inline int pick_rpb_fwd(int B, int n) {
+    int rpb = (int)(((long long)B * n + 255) / 256);
+    if (rpb < 1) rpb = 1;
+    if (rpb > n) rpb = n;
+    if (rpb > NMAX) rpb = NMAX;
+    return rpb;
+}
 
 // Latency note: at decode sizes these kernels are a chain of dependent memory round trips, so every
 // phase issues ALL its loads for a group of regions before touching the data (a rolled `for k` loop
@@ -882,7 +891,7 @@ static int attention_fwd_launch(const float *att_h, int h_splits, int64_t h_stri
     if (lds > 64 * 1024) return CAPMI_EINVAL;
     // unique (algorithmic) bytes: image tiles once + per-row att_h in, ctx and alpha out
     const double abytes = 4.0 * ((double)B * K * (A + R) + (double)N * (A + R + K));
-    const int rpb = row_img ? 1 : pick_rpb(B, n), chunks = row_img ? 1 : (n + rpb - 1) / rpb;
+    const int rpb = row_img ? 1 : pick_rpb_fwd(B, n), chunks = row_img ? 1 : (n + rpb - 1) / rpb;
     hipEvent_t e0, e1;
     // round-2 kernel: all loads up front, one memory round trip (BASELINE shapes: K = 36, A = 512, R = 1000)
     static const int env_v2 = capmi::research("CAPMI_ATT_V2", 1);
