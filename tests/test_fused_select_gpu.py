@@ -55,7 +55,8 @@ def test_gate_gemm_part_inside_the_select_launch_agrees_with_the_plain_step(monk
 
 
 
-def test_fused_launch_is_bit_identical_to_the_two_launches():
+@pytest.mark.parametrize('mode,top_k,top_p', [(1, 0, 0.0), (0, 0, 0.0), (1, 7, 0.0), (1, 0, 0.8)])
+def test_fused_launch_is_bit_identical_to_the_two_launches(mode, top_k, top_p):
     """capmi_logsoftmax_select_partial_gemm == capmi_gemm_f32 (loader / consumer kernel, slabs) followed by capmi_logsoftmax_select_partial
     on the same inputs: the two halves of the fused grid run the same bodies, so tokens, dense log-probs, the embedded next input and
     the GEMM's K-slice slabs are the same BITS; a GEMM that cannot ride along (N rows + its workgroups > 256) falls back to the two
@@ -97,8 +98,11 @@ def test_fused_launch_is_bit_identical_to_the_two_launches():
         d.a_planes[0], d.a_planes[1] = pl1.data_ptr(), pl2.data_ptr()
         d.M, d.N, d.C, d.ldc = N, 4 * R, ws.buf.data_ptr(), 4 * R
         d.partial, d.partial_capacity, d.splits, d.defer_reduce = ws.buf.data_ptr(), ws.capacity, splits_hint, 1
-        sel_args = (logit_slabs.data_ptr(), 3, N * V1, bias.data_ptr(), N, V1, step, L, 1, None, 1.0, None, 1234, None, 0, 0,
-                    seq.data_ptr(), L, it.data_ptr(), unf.data_ptr(), slp.data_ptr(), sel.data_ptr(), live.data_ptr(), C.byref(ne), None)
+        flt = _lib.SampleFilter()
+        flt.top_k, flt.top_p = top_k, top_p
+        sel_args = (logit_slabs.data_ptr(), 3, N * V1, bias.data_ptr(), N, V1, step, L, mode, None, 1.0, None, 1234, None, 0, 0,
+                    seq.data_ptr(), L, it.data_ptr(), unf.data_ptr(), slp.data_ptr(), sel.data_ptr(), live.data_ptr(), C.byref(ne),
+                    C.byref(flt) if (top_k or top_p) else None)
         if fused:
             check(lib.capmi_logsoftmax_select_partial_gemm(*sel_args, C.byref(d), stream_ptr()), 'fused')
         else:
