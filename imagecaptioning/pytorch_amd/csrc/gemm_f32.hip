@@ -436,7 +436,9 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     const double flops = 2.0 * d->M * (double)d->N * ksum;
     int pcls = (d->M <= 64 && d->a_layout == 0) ? (d->b_layout == 0 ? CAPMI_PROF_GEMM_DECODE : CAPMI_PROF_GEMM_BPTT)
                                                  : CAPMI_PROF_GEMM_FAT;
-    if (pcls == CAPMI_PROF_GEMM_DECODE && bytes >= 16e6) pcls = CAPMI_PROF_GEMM_DECODE_STREAM;
+    // (r4: >= 24 MB.  The 17-MB token-embedding segment that is left of the attention-LSTM gate GEMM when its other two segments ride in
+    //  the select launch is a short, latency-dominated launch: it is accounted with the small decode GEMMs, class 0)
+    if (pcls == CAPMI_PROF_GEMM_DECODE && bytes >= 24e6) pcls = CAPMI_PROF_GEMM_DECODE_STREAM;
 
     static const int env_path = capmi::research("CAPMI_GEMM_PATH", 0);
     static const int env_blocks = capmi::research("CAPMI_GEMM_BLOCKS", 512);

@@ -17,8 +17,8 @@ enum CapmiProfClass {
     CAPMI_PROF_LSTM_CELL = 6,
     CAPMI_PROF_CIDERD = 7,
     CAPMI_PROF_ADAM = 8,
-    CAPMI_PROF_GEMM_DECODE_STREAM = 9,   // the decode-step GEMMs that stream >= 16 MB of weights (LSTM gates, logit): ONE kernel
-                                         // instance, gemm_ares_kernel<true,6,2,x3>, the dominant row of the rocprofv3 table
+    CAPMI_PROF_GEMM_DECODE_STREAM = 9,   // the decode-step GEMMs that stream >= 24 MB of weights (LSTM gates, logit): ONE kernel
+                                         // instance, gemm_lc_kernel<true,2>, the dominant row of the rocprofv3 table
     CAPMI_PROF_NCLASS = 10
 };
 

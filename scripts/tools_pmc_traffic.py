@@ -23,7 +23,7 @@ def load(d, counter):
                         wgs = int(r['Grid_Size']) // max(1, int(r['Workgroup_Size']))
                     except (KeyError, ValueError):
                         wgs = 0
-                    name = name[:name.rfind('(')] + (' [stream]' if wgs >= 128 else ' [small]') + '('
+                    name = name[:name.rfind('(')] + (' [stream]' if wgs >= 128 else ' [small]') + '('      # (r4: the 17-MB segment GEMMs count as stream here)
                 rows[name].append(float(r['Counter_Value']))
     return rows
 
