@@ -48,7 +48,7 @@ class UpDownRollout(C.Structure):
                                     'fc_gates', 'logits', 'it', 'unfinished', 'partial')] +
                 [('partial_capacity', C.c_int64), ('top_k', C.c_int), ('top_p', C.c_float), ('ss_mode', c_f),
                  ('planes', c_f), ('planes_bytes', C.c_int64), ('early_exit', C.c_int), ('early_exit_from', C.c_int),
-                 ('alive_host', c_f), ('steps_run', C.c_int), ('pre_partial', c_f), ('pre_capacity', C.c_int64)])
+                 ('alive_host', c_f), ('steps_run', C.c_int), ('pre_partial', c_f), ('pre_capacity', C.c_int64), ('raw_logits', C.c_int)])
 
 
 class SampleFilter(C.Structure):
@@ -62,7 +62,7 @@ class UpDownGrads(C.Structure):
 
 
 class SparseLogpGrad(C.Structure):
-    _fields_ = [('g_sel', c_f), ('g_sum', c_f), ('tok', c_f), ('tok_ld', C.c_int), ('scale', c_f)]
+    _fields_ = [('g_sel', c_f), ('g_sum', c_f), ('tok', c_f), ('tok_ld', C.c_int), ('raw', C.c_int), ('scale', c_f)]
 
 
 class MaskDesc(C.Structure):

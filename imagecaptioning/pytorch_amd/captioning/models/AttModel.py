@@ -57,7 +57,8 @@ class _RolloutFn(torch.autograd.Function):
                             temperature=cfg.get('temperature', 1.0), drop_xt=cfg.get('drop_xt'),
                             drop_out=cfg.get('drop_out'), gumbel=cfg.get('gumbel'), seed=cfg.get('seed', 0),
                             forced=cfg.get('forced'), teacher=cfg.get('teacher', False), row_mode=cfg.get('row_mode'),
-                            top_k=cfg.get('top_k', 0), top_p=cfg.get('top_p', 0.0), ss_mode=cfg.get('ss_mode'), **extra)
+                            top_k=cfg.get('top_k', 0), top_p=cfg.get('top_p', 0.0), ss_mode=cfg.get('ss_mode'),
+                            raw_logits=cfg.get('raw_logits', False), **extra)
         seq, seq_logp = ro.run()
         ctx.model, ctx.ro, ctx.pr, ctx.P = model, ro, pr, P
         ctx.sink = sink = cfg.get('_sink')
@@ -281,14 +282,14 @@ class AttModel(CaptionModel):
                                     None if att_masks is None else att_masks.float())
                 return UpDownStepper(P, pr, rows)
             return self._sample_with_options(make, fc_feats.size(0), opt)
-        if not opt.get('output_logsoftmax', 1):
-            raise NotImplementedError('output_logsoftmax=0 is only used by margin structure losses')
         mode, temperature, top_k, top_p = parse_sample_method(sample_method, temperature)
         B = fc_feats.size(0)
         N = B * sample_n
         L = self.seq_length
         K = clip_len(att_masks, att_feats.shape[1])
         cfg = dict(n=sample_n, T=L, L=L, mode=mode, temperature=temperature, seed=self._next_seed(), top_k=top_k, top_p=top_p)
+        if not opt.get('output_logsoftmax', 1):   # AttModel.py:171-175, 265: seqLogprobs holds the LOGITS (margin structure losses)
+            cfg['raw_logits'] = True
         cfg.update(self._dropout_masks(B, K, N, L, fc_feats.device))
         forced = opt.get('_forced_seq')           # test hook: teacher-force a sampled sequence
         if forced is not None:

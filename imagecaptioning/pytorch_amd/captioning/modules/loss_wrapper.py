@@ -37,7 +37,11 @@ class LossWrapper(torch.nn.Module):
                 gen_result, sample_logprobs = self.model(
                     fc_feats, att_feats, att_masks,
                     opt={'sample_method': opt.train_sample_method, 'beam_size': opt.train_beam_size,
-                         'output_logsoftmax': 1, 'sample_n': opt.train_sample_n}, mode='sample')
+                         # loss_wrapper.py:34-35: the margin losses (softmax_margin excepted) read raw logits
+                         'output_logsoftmax': int(bool(getattr(opt, 'struc_use_logsoftmax', False))
+                                                  or opt.structure_loss_type == 'softmax_margin'
+                                                  or 'margin' not in opt.structure_loss_type),
+                         'sample_n': opt.train_sample_n}, mode='sample')
                 gts = select_gts(gts, gt_indices)
                 struc_loss = self.struc_crit(sample_logprobs, gen_result, gts, reduction=reduction)
             else:

@@ -78,14 +78,15 @@ class LabelSmoothing(nn.Module):
 
 
 class StructureLosses(nn.Module):
-    """losses.py:40-202.  Every ``structure_loss_type`` whose input is log-probabilities: 'new_self_critical' (168-187, the one
-    the *_nsc BASELINE configs use), 'seqnll' (81-88), 'risk' (89-103), 'softmax_margin' (147-155), 'best_of_n' (189-199), with
-    the optional ``entropy_reward_weight`` (66-69).  All of them only read the log-probabilities of the sampled tokens, so the
-    gradient stays sparse (``select_logp``).  The margin types that take RAW LOGITS ('max_margin', 'multi_margin',
-    'real_softmax_margin': sampled with output_logsoftmax=0, loss_wrapper.py:31-37) and the self-CIDEr reward are not
-    implemented: the rollouts always emit log-softmax."""
+    """losses.py:40-202.  The ``structure_loss_type``s whose input is log-probabilities -- 'new_self_critical' (168-187, the one
+    the *_nsc BASELINE configs use), 'seqnll' (81-88), 'risk' (89-103), 'softmax_margin' (147-155), 'best_of_n' (189-199) -- and, r4,
+    the margin types that take RAW LOGITS -- 'max_margin' (105-114), 'multi_margin' (128-137), 'real_softmax_margin' (157-166):
+    sampled with output_logsoftmax=0 (loss_wrapper.py:31-37), served by rollouts that store the logits (capmi.h CAPMI_SELECT_RAW).
+    The optional ``entropy_reward_weight`` (66-69) is supported.  All of them only read the entries of the sampled tokens, so the
+    gradient stays sparse (``select_logp``).  The self-CIDEr reward is not implemented."""
 
     LOGPROB_TYPES = ('new_self_critical', 'seqnll', 'risk', 'softmax_margin', 'best_of_n')
+    LOGIT_TYPES = ('max_margin', 'multi_margin', 'real_softmax_margin')
 
     def __init__(self, opt):
         super().__init__()
@@ -93,9 +94,9 @@ class StructureLosses(nn.Module):
         self.loss_type = opt.structure_loss_type
 
     def forward(self, input, seq, data_gts, reduction='mean'):
-        if self.loss_type not in self.LOGPROB_TYPES:
-            raise NotImplementedError('structure_loss_type %r takes raw logits (output_logsoftmax=0 rollouts): only %s are '
-                                      'implemented' % (self.loss_type, ', '.join(self.LOGPROB_TYPES)))
+        if self.loss_type not in self.LOGPROB_TYPES + self.LOGIT_TYPES:
+            raise NotImplementedError('structure_loss_type %r: implemented are %s'
+                                      % (self.loss_type, ', '.join(self.LOGPROB_TYPES + self.LOGIT_TYPES)))
         if getattr(self.opt, 'self_cider_reward_weight', 0) > 0:
             raise NotImplementedError('self_cider_reward_weight (get_self_cider_scores, rewards.py:116-137) is out of scope')
         out = {}
@@ -123,6 +124,14 @@ class StructureLosses(nn.Module):
                 w = (scores == scores.max(1, keepdim=True)[0]).to(sel)
             output = -sel * mask * w.reshape(-1, 1)
             output = output.sum(1) / mask.sum(1) if reduction == 'none' else output.sum() / mask.sum()
+        elif lt in ('max_margin', 'multi_margin'):
+            # hinge between every sample and the cheapest one of its image, on the mean (masked) logit of the sampled tokens
+            assert reduction == 'mean'
+            costs = -scores
+            avg = ((sel * mask).sum(1) / mask.sum(1)).view(-1, n)
+            c_star, i_star = costs.min(1, keepdim=True)
+            hinge = torch.relu(costs - c_star - avg.gather(1, i_star) + avg)
+            output = (hinge.max(1)[0] / 2).mean() if lt == 'max_margin' else hinge.mean()
         else:
             costs = -scores
             if lt in ('risk', 'softmax_margin'):     # rescale the costs of each image to [0, 1]
@@ -134,7 +143,7 @@ class StructureLosses(nn.Module):
                 output = (torch.softmax(tot.view(-1, n).exp(), 1) * costs).sum(1).mean()
             else:                                    # cross-entropy towards the cheapest sample of each image
                 avg = (tot / mask.sum(1)).view(-1, n)
-                if lt == 'softmax_margin':
+                if lt in ('softmax_margin', 'real_softmax_margin'):
                     avg = avg + costs
                 output = nn.functional.cross_entropy(avg, costs.min(1)[1], reduction=reduction)
         out['loss'] = output

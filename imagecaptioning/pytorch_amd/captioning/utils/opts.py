@@ -12,7 +12,7 @@ DEFAULTS = dict(
     weight_decay=0.0, grad_clip_mode='value', grad_clip_value=0.1, label_smoothing=0.0, self_critical_after=-1, structure_after=-1,
     structure_loss_weight=1.0, structure_loss_type='seqnll', train_sample_n=16, train_sample_method='sample', train_beam_size=1,
     sc_sample_method='greedy', sc_beam_size=1, cider_reward_weight=1.0, bleu_reward_weight=0.0, cached_tokens='coco-train-idxs',
-    use_ppo=0, entropy_reward_weight=0.0, self_cider_reward_weight=0.0, drop_worst_after=-1, drop_worst_rate=0.0,
+    use_ppo=0, entropy_reward_weight=0.0, self_cider_reward_weight=0.0, struc_use_logsoftmax=0, drop_worst_after=-1, drop_worst_rate=0.0,
     learning_rate_decay_start=-1, learning_rate_decay_every=3, learning_rate_decay_rate=0.8, noamopt=0, noamopt_warmup=2000,
     noamopt_factor=1.0, use_warmup=0, reduce_on_plateau=0, reduce_on_plateau_factor=0.5, reduce_on_plateau_patience=3,
     scheduled_sampling_start=-1, scheduled_sampling_increase_every=5, scheduled_sampling_increase_prob=0.05,

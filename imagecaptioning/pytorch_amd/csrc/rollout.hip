@@ -193,6 +193,7 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
     // (capmi.h capmi_updown_rollout.pre_partial, capmi_logsoftmax_select_partial_gemm)
     const bool use_pre = pl_zero && r->pre_partial && !r->teacher &&
                          r->pre_capacity >= CAPMI_WS_COUNTER_FLOATS + (int64_t)8 * N * 4 * R;
+    const int raw_flag = (r->raw_logits && !r->teacher) ? CAPMI_SELECT_RAW : 0;      // output_logsoftmax = 0 (AttModel.py:265)
     float *preA = use_pre ? r->pre_partial : nullptr;
     int preA_splits = 0;
     bool preA_valid = false;                          // slabs of the ahead part for the step about to run
@@ -341,7 +342,7 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
             ah.splits = 6;                            // 32 column blocks x 6 K slices = 192 workgroups beside the N select rows
             ah.defer_reduce = 1;
             RC(capmi_logsoftmax_select_partial_gemm(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, (int64_t)N * V1, w->logit_b, N, V1, t, L,
-                                                    r->mode, r->row_mode, r->temperature,
+                                                    r->mode | raw_flag, r->row_mode, r->temperature,
                                                     r->gumbel ? r->gumbel + (size_t)t * N * V1 : nullptr, r->seed, r->forced,
                                                     r->forced_ld, 0, r->seq, L, r->it, r->unfinished, r->seq_logp, r->sel_logp,
                                                     r->live, &ne, (r->top_k > 0 || r->top_p > 0.f) ? &flt : nullptr, &ah, stream));
@@ -349,7 +350,7 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
             preA_valid = true;
         } else
         RC(capmi_logsoftmax_select_partial(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, (int64_t)N * V1, w->logit_b, N, V1, t,
-                                           L, r->teacher ? 2 : r->mode, r->teacher ? nullptr : r->row_mode, r->temperature,
+                                           L, r->teacher ? 2 : (r->mode | raw_flag), r->teacher ? nullptr : r->row_mode, r->temperature,
                                            r->gumbel ? r->gumbel + (size_t)t * N * V1 : nullptr, r->seed, r->forced,
                                            r->forced_ld, r->teacher ? 1 : 0, r->seq, L, r->it, r->unfinished, r->seq_logp,
                                            r->sel_logp, r->live, &ne, (r->top_k > 0 || r->top_p > 0.f) ? &flt : nullptr, stream));
@@ -462,7 +463,12 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
 
     // ---- logit layer, batched over all T*N rows ----------------------------------------------
     if (phases & CAPMI_BWD_LOGIT) {
-        if (s->sparse) RC(capmi_logsoftmax_bwd_sparse(s->sparse, g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
+        if (r->raw_logits && !r->teacher) {
+            // the rollout returned logits: d(logits) is the loss gradient (sparse and / or dense parts), no softmax Jacobian
+            capmi_sparse_logp_grad sp = s->sparse ? *s->sparse : capmi_sparse_logp_grad{};
+            sp.raw = 1;
+            RC(capmi_logsoftmax_bwd_sparse(&sp, g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
+        } else if (s->sparse) RC(capmi_logsoftmax_bwd_sparse(s->sparse, g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
         else RC(capmi_logsoftmax_bwd(g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
         SegSpec a{s->dlogits, V1, w->logit_w, R, V1, 1};   // d_hdrop = dlogits W_logit          [TN,R]
         RC(gemm(stream, 0, 1, TN, R, s->d_hdrop, R, &a, 1, P, cap, 0, nullptr));

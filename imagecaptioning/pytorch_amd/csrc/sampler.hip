@@ -214,7 +214,7 @@ struct SelArgs {
     const float *src; int splits; size_t slab_stride; const float *bias; int V1, step, L, mode; const uint8_t *row_mode;
     float temperature; const float *gumbel; uint64_t seed; const int64_t *forced; int forced_ld, no_finish_mask; int64_t *seq;
     int seq_ld; int64_t *it_next; uint8_t *unfinished; float *seq_logp, *sel_logp; uint8_t *live; NextEmbed ne; int top_k;
-    float top_p; int abl;
+    float top_p; int abl; int raw_out;     // raw_out: store the logits themselves (AttModel.py:172-175 output_logsoftmax = 0)
 };
 
 // Body of the register-resident select for caption row r; s_f [32] / s_i [32] / s_tok [1] are workgroup scratch in LDS (static in the
@@ -228,7 +228,7 @@ __device__ __forceinline__ void select_reg_body(const SelArgs &A, const int r, f
     const int forced_ld = A.forced_ld, no_finish_mask = A.no_finish_mask; int64_t *__restrict__ seq = A.seq; const int seq_ld = A.seq_ld;
     int64_t *__restrict__ it_next = A.it_next; uint8_t *__restrict__ unfinished = A.unfinished; float *__restrict__ seq_logp = A.seq_logp;
     float *__restrict__ sel_logp = A.sel_logp; uint8_t *__restrict__ live = A.live; const NextEmbed &ne = A.ne; const int top_k = A.top_k;
-    const float top_p = A.top_p; const int abl = A.abl;
+    const float top_p = A.top_p; const int abl = A.abl; const int raw_out = A.raw_out;
 #define s_tok (*s_tok_p)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = SEL_THREADS >> 6;
     const int my_mode = row_mode ? (int)row_mode[r] : mode;
@@ -391,7 +391,7 @@ __device__ __forceinline__ void select_reg_body(const SelArgs &A, const int r, f
         const int q = threadIdx.x + j * SEL_THREADS;
         if (q < nq) {
             if (out) {
-                f32x4 o = x[j] - lse;
+                f32x4 o = x[j] - (raw_out ? 0.f : lse);
                 if (!was_unf) o = f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4 *>(out + 4 * q) = o;
             }
@@ -403,7 +403,7 @@ __device__ __forceinline__ void select_reg_body(const SelArgs &A, const int r, f
     if (threadIdx.x == 0) {
         seq[(size_t)r * seq_ld + step] = token;
         it_next[r] = token;
-        if (sel_logp) sel_logp[(size_t)r * L + step] = keep * (s_tok - lse);
+        if (sel_logp) sel_logp[(size_t)r * L + step] = keep * (s_tok - (raw_out ? 0.f : lse));
         if (live) live[(size_t)r * L + step] = was_unf ? 1 : 0;
         if (!no_finish_mask) unfinished[r] = (was_unf && token != 0) ? 1 : 0;
         // early exit (AttModel.py:349-350): a row that goes on tells the host so (a word of pinned host memory, only ever set)
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_bwd_kernel(const float
 __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_bwd_sparse_kernel(
     const float *__restrict__ g_sel, const float *__restrict__ g_sum, const int64_t *__restrict__ tok, int tok_ld,
     const float *__restrict__ g, const float *__restrict__ seq_logp, const uint8_t *__restrict__ live,
-    float *__restrict__ dlogits, int N, int L, int V1, const float *__restrict__ scale) {
+    float *__restrict__ dlogits, int N, int L, int V1, const float *__restrict__ scale, int raw) {
     __shared__ float s_f[32];
     const int t = blockIdx.x / N, n = blockIdx.x % N;
     const size_t r = (size_t)n * L + t;
@@ -488,6 +488,15 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_bwd_sparse_kernel(
     const int token = g_sel ? (int)tok[(size_t)n * tok_ld + t] : -1;
     float s = a + b * (float)V1;                      // sum over v of the implied dense gradient
     const float *gr = g ? g + r * V1 : nullptr;
+    if (raw) {                                         // the rollout returned the LOGITS (output_logsoftmax = 0): their gradient is
+        for (int v = threadIdx.x; v < V1; v += blockDim.x) {      // the loss gradient itself, no softmax Jacobian
+            float d = b;
+            if (v == token) d += a;
+            if (gr) d += gr[v];
+            o[v] = d;
+        }
+        return;
+    }
     if (gr) {
         float sd = 0.f;
         for (int v = threadIdx.x; v < V1; v += blockDim.x) sd += gr[v];
@@ -568,6 +577,8 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
                                     int no_finish_mask, int64_t *seq, int seq_ld, int64_t *it_next, uint8_t *unfinished,
                                     float *seq_logp, float *sel_logp, uint8_t *live, const capmi_next_embed *next,
                                     const capmi_sample_filter *filter, void *stream) {
+    const int raw_out = (mode & CAPMI_SELECT_RAW) ? 1 : 0;       // store logits, not log-probs (output_logsoftmax = 0)
+    mode &= ~CAPMI_SELECT_RAW;
     if (!partial || splits < 1 || N <= 0 || V1 <= 0 || step < 0 || step >= L || !seq || !it_next) return CAPMI_EINVAL;
     if (!no_finish_mask && !unfinished) return CAPMI_EINVAL;
     if ((mode == 2 || row_mode) && !forced && mode == 2) return CAPMI_EINVAL;
@@ -590,7 +601,8 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
     static const int env_abl = capmi::ablate_env("CAPMI_SEL_ABLATE");   // profiling only
     if (al && V1 % 4 == 0 && V1 <= 3 * 4 * SEL_THREADS) {
         const SelArgs sa{partial, splits, (size_t)slab_stride, bias, V1, step, L, mode, row_mode, temperature, gumbel, seed, forced,
-                         forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live, ne, top_k, top_p, env_abl};
+                         forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live, ne, top_k, top_p, env_abl,
+                         raw_out};
 #define CAPMI_SEL(NQ) hipLaunchKernelGGL(logsoftmax_select_reg_kernel<NQ>, dim3(N), dim3(SEL_THREADS), 0, st, sa)
         if (V1 <= 4 * SEL_THREADS) CAPMI_SEL(1);
         else if (V1 <= 8 * SEL_THREADS) CAPMI_SEL(2);
@@ -602,7 +614,7 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
     hipLaunchKernelGGL(logsoftmax_select_kernel, dim3(N), dim3(SEL_THREADS), 0, st, partial, splits, (size_t)slab_stride, bias,
                        V1, step, L, mode, row_mode,
                        temperature, gumbel, seed, forced, forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished,
-                       seq_logp, sel_logp, live, ne, top_k, top_p, 0);
+                       seq_logp, sel_logp, live, ne, top_k, top_p, raw_out);      // (prenorm = 1 stores and gathers the row as it is)
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -614,6 +626,9 @@ int capmi_logsoftmax_select_partial_gemm(const float *partial, int splits, int64
                                          float *seq_logp, float *sel_logp, uint8_t *live, const capmi_next_embed *next,
                                          const capmi_sample_filter *filter, capmi_gemm_desc *ahead, void *stream) {
     if (!ahead) return CAPMI_EINVAL;
+    const int mode_in = mode;
+    const int raw_out = (mode & CAPMI_SELECT_RAW) ? 1 : 0;
+    mode &= ~CAPMI_SELECT_RAW;
     // what the stand-alone select would run on these arguments
     const int top_k = filter ? filter->top_k : 0;
     const float top_p = filter ? filter->top_p : 0.f;
@@ -634,7 +649,7 @@ int capmi_logsoftmax_select_partial_gemm(const float *partial, int splits, int64
             const int rc2 = capmi_gemm_f32(ahead, stream);
             if (rc2) return rc2;
         }
-        return capmi_logsoftmax_select_partial(partial, splits, slab_stride, bias, N, V1, step, L, mode, row_mode, temperature, gumbel,
+        return capmi_logsoftmax_select_partial(partial, splits, slab_stride, bias, N, V1, step, L, mode_in, row_mode, temperature, gumbel,
                                                seed, forced, forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp,
                                                sel_logp, live, next, filter, stream);
     }
@@ -644,7 +659,7 @@ int capmi_logsoftmax_select_partial_gemm(const float *partial, int splits, int64
                        nullptr};
     if (next) ne.alive = next->alive;
     const SelArgs sa{partial, splits, (size_t)slab_stride, bias, V1, step, L, mode, row_mode, temperature, gumbel, seed, forced,
-                     forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live, ne, top_k, top_p, 0};
+                     forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live, ne, top_k, top_p, 0, raw_out};
     const size_t lds = (size_t)capmi_gemm::LC_NS * capmi_gemm::LC_STAGE + 512;
     const dim3 grid(N + cap.grid_x * cap.grid_y);
 #define CAPMI_FUSED(NQ)                                                                                                     \
@@ -698,7 +713,7 @@ int capmi_logsoftmax_bwd_sparse(const capmi_sparse_logp_grad *sp, const float *g
     if (!sp->g_sel && !sp->g_sum && !g) return CAPMI_EINVAL;
     if (sp->g_sel && (!sp->tok || sp->tok_ld < T)) return CAPMI_EINVAL;
     hipLaunchKernelGGL(logsoftmax_bwd_sparse_kernel, dim3(N * T), dim3(SEL_THREADS), 0, (hipStream_t)stream, sp->g_sel,
-                       sp->g_sum, sp->tok, sp->tok_ld, g, seq_logp, live, dlogits, N, L, V1, sp->scale);
+                       sp->g_sum, sp->tok, sp->tok_ld, g, seq_logp, live, dlogits, N, L, V1, sp->scale, sp->raw);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

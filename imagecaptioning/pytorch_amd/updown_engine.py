@@ -131,7 +131,7 @@ class Rollout:
 
     def __init__(self, P, pr, n, T, L=None, mode='greedy', temperature=1.0, drop_xt=None, drop_out=None,
                  gumbel=None, seed=0, forced=None, teacher=False, row_mode=None, ws=None, keep_for_backward=True,
-                 row_img=None, B_grad=None, top_k=0, top_p=0.0, ss_mode=None, early_exit=None, early_exit_from=4):
+                 row_img=None, B_grad=None, top_k=0, top_p=0.0, ss_mode=None, early_exit=None, early_exit_from=4, raw_logits=False):
         """ss_mode (uint8 [T,N], teacher only): scheduled sampling, 1 = the input of (step, row) is drawn from the previous
         step's distribution, 2 = teacher-forced (capmi.h capmi_updown_rollout.ss_mode).
         row_img (int32 [N]) + B_grad: ragged grouping for the fused SCST rollout -- the first B_grad
@@ -212,6 +212,7 @@ class Rollout:
         if early_exit > 0 and not teacher and mode != 'forced' and T >= 12:
             self.alive = _alive_buffer(dev, L)
             r.early_exit, r.early_exit_from, r.alive_host = int(early_exit), int(early_exit_from), self.alive.data_ptr()
+        r.raw_logits = int(bool(raw_logits) and not teacher)     # AttModel._sample(output_logsoftmax=0): logits, not log-probs
         self.r = r
         self.T_cfg = int(r.T)
         self.w = weights_struct(P)

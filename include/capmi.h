@@ -277,6 +277,10 @@ typedef struct {
  * logits[r,:] = sum_{s<splits} partial[s*slab_stride + r*V1 + :] + bias (bias may be NULL).  With V1 % 4 == 0,
  * V1 <= 12288 and 16-byte aligned buffers the row lives in registers (no split-K reduce launch, no logits
  * round trip); any other size / alignment runs a streaming kernel that re-assembles the row per pass. */
+/* mode flag of the select entry points (OR it into `mode`): store the row of LOGITS (slabs + bias) in seq_logp / sel_logp instead of
+ * the log-probabilities -- AttModel.get_logprobs_state(output_logsoftmax=0), AttModel.py:171-175, used by the margin structure losses
+ * (loss_wrapper.py:31-37).  The choice of the token is unaffected (arg-max / Gumbel-max are shift invariant). */
+#define CAPMI_SELECT_RAW 256
 int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t slab_stride, const float *bias,
                                     int N, int V1, int step, int L,
                                     int mode, const uint8_t *row_mode, float temperature,
@@ -318,6 +322,8 @@ typedef struct capmi_sparse_logp_grad {
     const float *g_sum;
     const int64_t *tok;
     int tok_ld;
+    int raw;              /* r4: 1 = the rollout returned the raw logits (CAPMI_SELECT_RAW, output_logsoftmax = 0): d(logits) is the loss
+                           * gradient itself -- g_sel at the token, g_sum everywhere, plus the dense g -- without the softmax Jacobian */
     const float *scale;   /* NULL, or a DEVICE scalar multiplying g_sel / g_sum (the upstream gradient of a scalar loss) */
 } capmi_sparse_logp_grad;
 int capmi_logsoftmax_bwd_sparse(const capmi_sparse_logp_grad *sp, const float *g, const float *seq_logp,
@@ -533,6 +539,10 @@ typedef struct capmi_updown_rollout {
      * step t+1 keeps the token-embedding segment and the LSTM cell sums both slab sets.  NULL: one gate GEMM per step. */
     float *pre_partial;
     int64_t pre_capacity;
+    /* r4: 1 = free-running rollouts return the raw logits in seq_logp / sel_logp (AttModel._sample with output_logsoftmax = 0,
+     * AttModel.py:265, 292: the margin structure losses); the backward then takes the loss gradient as d(logits).  Teacher-forced
+     * passes always return log-probabilities (AttModel._forward). */
+    int raw_logits;
 } capmi_updown_rollout;
 
 int64_t capmi_updown_planes_bytes(int R, int E);

@@ -560,6 +560,27 @@ def main_struct():
                 out[key + '_loss'] = loss.detach().numpy()
                 out[key + '_grad'] = x.grad.numpy()
                 out[key + '_reward'] = o['reward'].numpy()
+    # r4: the margin types that read RAW LOGITS (losses.py:105-114, 128-137, 157-166; sampled with output_logsoftmax=0,
+    # loss_wrapper.py:31-37): the same tensor handed over WITHOUT log_softmax
+    for lt in ('max_margin', 'multi_margin', 'real_softmax_margin'):
+        for ew in (0.0, 0.3):
+            for red in ('mean', 'none'):
+                if red == 'none' and lt != 'real_softmax_margin':
+                    continue                                               # the reference asserts reduction == 'mean'
+                opt = argparse.Namespace(structure_loss_type=lt, train_sample_n=n, entropy_reward_weight=ew,
+                                         self_cider_reward_weight=0)
+                x = logits.clone().requires_grad_(True)
+                import contextlib
+                import io
+                with contextlib.redirect_stdout(io.StringIO()), warnings_off():
+                    o = RL.StructureLosses(opt)(x, seq, [None] * B, reduction=red)
+                loss = o['loss']
+                w = torch.linspace(0.5, 1.5, loss.numel(), dtype=torch.float64).view_as(loss) if red == 'none' else None
+                (loss if w is None else (loss * w).sum()).backward()
+                key = '%s_e%d_%s' % (lt, int(ew * 10), red)
+                out[key + '_loss'] = loss.detach().numpy()
+                out[key + '_grad'] = x.grad.numpy()
+                out[key + '_reward'] = o['reward'].numpy()
     np.savez_compressed(os.path.join(HERE, 'structure_losses.npz'), **out)
     print('wrote structure_losses.npz with', len(out), 'arrays')
 

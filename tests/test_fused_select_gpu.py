@@ -118,3 +118,81 @@ def test_fused_launch_is_bit_identical_to_the_two_launches(mode, top_k, top_p):
         for x, y in zip(a[:5] + a[6:], b[:5] + b[6:]):
             assert torch.equal(x, y)
     assert int(a[0].max()) > 0
+
+
+def test_raw_logit_rollouts_and_a_margin_structure_loss_vs_oracle():
+    """VERDICT r3 missing #7 -- AttModel._sample(output_logsoftmax=0) (AttModel.py:171-175, 265; loss_wrapper.py:31-37): the rollout
+    stores the LOGITS (CAPMI_SELECT_RAW) and its backward takes the loss gradient as d(logits).  Against oracle/att_lstm.py with the
+    same Gumbel noise: tokens equal, stored rows == the oracle's logits (<= 2e-5; zero rows after the end), raw - logsumexp(raw) ==
+    the log-prob rollout's rows; the 'max_margin' structure loss (sparse gradient route) and every parameter gradient match the
+    oracle's autograd (<= 1e-3 relative)."""
+    import argparse
+    from oracle import att_lstm as O
+    from test_model_api_gpu import golden_model, DEV
+    from imagecaptioning.pytorch_amd.captioning.modules import losses as Lm
+    z, model = golden_model(False)
+    model.eval()                                   # no dropout: the same masks (none) on both sides
+    fc, att = torch.from_numpy(z['fc']), torch.from_numpy(z['att'])
+    B, n, L = fc.shape[0], 3, model.seq_length
+    N, V1 = B * n, model.vocab_size + 1
+    g = torch.Generator().manual_seed(9)
+    gum = -torch.log(-torch.log(torch.rand(L, N, V1, generator=g).clamp_min(1e-20)))
+    scores = torch.rand(N, generator=g)
+    o = {'sample_method': 'sample', 'sample_n': n, '_gumbel': gum.to(DEV)}
+    with torch.no_grad():
+        seq_lp, lp = model(fc.to(DEV), att.to(DEV), None, opt=dict(o, output_logsoftmax=1), mode='sample')
+    seq, raw = model(fc.to(DEV), att.to(DEV), None, opt=dict(o, output_logsoftmax=0), mode='sample')
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    seq_o, raw_o = O.rollout(P, fc, att, None, method='sample', sample_n=n, max_len=L, gumbel=gum, output_logsoftmax=False)
+    assert torch.equal(seq.cpu(), seq_o) and torch.equal(seq_lp.cpu(), seq_o)
+    assert float((raw.detach().cpu() - raw_o.detach()).abs().max()) < 2e-5
+    live = torch.cat([torch.ones(N, 1, dtype=torch.bool), seq_o[:, :-1] > 0], 1)
+    assert float((torch.log_softmax(raw.detach().cpu(), 2) - lp.cpu())[live].abs().max()) < 2e-5
+    assert float(raw.detach().cpu()[~live].abs().max() if (~live).any() else 0.0) == 0.0
+    opt = argparse.Namespace(structure_loss_type='max_margin', train_sample_n=n, entropy_reward_weight=0, self_cider_reward_weight=0,
+                             cider_reward_weight=1)
+    saved = Lm.get_scores
+    Lm.get_scores = lambda data_gts, gen_result, op, as_tensor=False: scores.clone().to(gen_result.device)
+    try:
+        loss = Lm.StructureLosses(opt)(raw, seq, [None] * B)['loss']
+        loss_o = Lm.StructureLosses(opt)(raw_o, seq_o, [None] * B)['loss']
+    finally:
+        Lm.get_scores = saved
+    assert abs(loss.item() - loss_o.item()) < 1e-5 and loss.item() > 0
+    model.zero_grad()
+    loss.backward()
+    loss_o.backward()
+    for k, p in model.named_parameters():
+        ref = P[k].grad
+        if k.endswith('alpha_net.bias') or ref is None:
+            continue
+        err = float((p.grad.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+        assert err < 1e-3, (k, err)
+
+
+def test_raw_logit_rollout_at_baseline_size_register_resident_select():
+    """the same at R = E = 1000, V1 = 9488 (the register-resident select, inside the fused select + GEMM launch): tokens equal the
+    log-prob rollout's, log_softmax(stored logits) == its rows, the selected entries line up"""
+    from imagecaptioning.pytorch_amd import updown_engine as E
+    from shapes import full_size_params
+    dev = torch.device('cuda:0')
+    torch.manual_seed(2)
+    B, n, K, L, V1 = 4, 5, 36, 20, 9488
+    P = {k: v.to(dev).contiguous() for k, v in full_size_params(seed=8).items()}
+    P['logit.bias'] = P['logit.bias'].clone()
+    P['logit.bias'][0] += 3.0                       # some captions end: rows of zeros behind the end in both rollouts
+    fc = torch.randn(B, 2048, device=dev).clamp_min(0)
+    att = torch.randn(B, K, 2048, device=dev).clamp_min(0)
+    pr = E.prepare(P, fc, att, None)
+    gum = torch.rand(L, B * n, V1, device=dev).clamp_min(1e-12).log().neg().log().neg()
+    a = E.Rollout(P, pr, n=n, T=L, mode='sample', gumbel=gum)
+    seq_a, lp = a.run()
+    b = E.Rollout(P, pr, n=n, T=L, mode='sample', gumbel=gum, raw_logits=True)
+    seq_b, raw = b.run()
+    torch.cuda.synchronize()
+    assert torch.equal(seq_a, seq_b)
+    live = torch.cat([torch.ones(B * n, 1, dtype=torch.bool, device=dev), seq_a[:, :-1] > 0], 1)
+    assert float((torch.log_softmax(raw, 2) - lp)[live].abs().max()) < 2e-5
+    assert float(raw[~live].abs().max()) == 0.0 if bool((~live).any()) else True
+    sel_raw = raw.gather(2, seq_b.unsqueeze(2)).squeeze(2)
+    assert torch.equal(b.sel_logp, sel_raw * live.float())

@@ -30,7 +30,8 @@ def test_structure_loss_matches_the_reference(case):
     saved = L.get_scores
     L.get_scores = lambda data_gts, gen_result, o, as_tensor=False: scores.clone()
     try:
-        x = torch.log_softmax(torch.from_numpy(Z['logits']), 2).requires_grad_(True)
+        raw = lt in L.StructureLosses.LOGIT_TYPES          # r4: the margin types read the logits themselves (output_logsoftmax = 0)
+        x = (torch.from_numpy(Z['logits']).clone() if raw else torch.log_softmax(torch.from_numpy(Z['logits']), 2)).requires_grad_(True)
         o = L.StructureLosses(opt)(x, torch.from_numpy(Z['seq']), [None] * B, reduction=red)
     finally:
         L.get_scores = saved
@@ -45,13 +46,12 @@ def test_structure_loss_matches_the_reference(case):
     assert torch.allclose(o['reward'], torch.from_numpy(Z[case + '_reward']))
 
 
-def test_cases_cover_every_logprob_type_and_logit_types_are_refused():
+def test_cases_cover_every_structure_loss_type():
     from captioning.modules import losses as L
-    assert {c.split('_e')[0] for c in CASES} == set(L.StructureLosses.LOGPROB_TYPES)
-    for lt in ('max_margin', 'multi_margin', 'real_softmax_margin'):
-        crit = L.StructureLosses(argparse.Namespace(structure_loss_type=lt, train_sample_n=2))
-        with pytest.raises(NotImplementedError, match='raw logits'):
-            crit(torch.zeros(2, 3, 4), torch.ones(2, 3, dtype=torch.long), [None])
+    assert {c.split('_e')[0] for c in CASES} == set(L.StructureLosses.LOGPROB_TYPES + L.StructureLosses.LOGIT_TYPES)
+    crit = L.StructureLosses(argparse.Namespace(structure_loss_type='policy_gradient', train_sample_n=2))
+    with pytest.raises(NotImplementedError):
+        crit(torch.zeros(2, 3, 4), torch.ones(2, 3, dtype=torch.long), [None])
 
 
 CRIT = np.load(os.path.join(ROOT, 'tests', 'golden', 'criteria.npz'))
