@@ -517,7 +517,7 @@ def main():
         ai = g_flops / g_bytes if g_bytes else 0.0
         mfma_bound = ai > mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
         all_ach = (all_bytes / all_n) / (all_ms / all_n * 1e-3) / 1e9 if all_n else 0.0
-        lc = os.environ.get('CAPMI_LC', '1') != '0' and os.environ.get('CAPMI_APL', '1') != '0' and x3
+        lc = os.environ.get('CAPMI_LC', '1') != '0' and os.environ.get('CAPMI_PLANES', '1') != '0' and x3
         roofline = {'kernel': ('gemm_lc_kernel<true,2> (LSTM-gate / logit GEMMs of the decode step: weight streaming, M<=64; loader waves '
                                'copy producer-written bf16x3 activation planes + fp32 weight tiles into a 5-stage LDS ring by LDS-DMA, '
                                'consumer waves split the weights and run v_mfma_f32_32x32x16_bf16)') if lc else
