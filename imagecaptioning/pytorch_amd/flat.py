@@ -61,15 +61,36 @@ class FlatParams:
         self._bw_expected, self._bw_seen = 1, 0
 
     # ---- optimizer state (the reference's optimizer.pth, misc.py:87-102 / tools/train.py:112-119) --------------------
+    def _natural_offsets(self):
+        """segment offsets of the layout WITHOUT groups (model.parameters() order): what checkpoints written before round 4 used"""
+        out, off = {}, 0
+        for n, p in zip(self.names, self.params):
+            out[n] = off
+            off += (p.numel() + 3) // 4 * 4
+        return out
+
     def state_dict(self):
         return {'exp_avg': self.exp_avg.detach().cpu().clone(), 'exp_avg_sq': self.exp_avg_sq.detach().cpu().clone(),
-                'step_count': int(self.step_count), 'total': int(self.total)}
+                'step_count': int(self.step_count), 'total': int(self.total),
+                'offsets': {n: int(o) for n, o in zip(self.names, self.offsets)}}      # r4: the layout the moments were saved in
 
     def load_state_dict(self, sd):
         if int(sd['total']) != self.total:
             raise ValueError('optimizer state is for %d flat elements, the model has %d' % (int(sd['total']), self.total))
-        self.exp_avg.copy_(sd['exp_avg'])
-        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        mine = {n: int(o) for n, o in zip(self.names, self.offsets)}
+        theirs = sd.get('offsets') or self._natural_offsets()       # (no table: a checkpoint of rounds 1-3, natural order)
+        if theirs == mine:
+            self.exp_avg.copy_(sd['exp_avg'])
+            self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        else:
+            # the buffer layout changed (r4 lays out a model's _flat_groups() back to back): move every parameter's moments by NAME
+            if set(theirs) != set(mine):
+                raise ValueError('optimizer state names do not match this model: %s' % sorted(set(theirs) ^ set(mine))[:4])
+            ea, es = sd['exp_avg'], sd['exp_avg_sq']
+            for n, p in zip(self.names, self.params):
+                k, a, b = p.numel(), theirs[n], mine[n]
+                self.exp_avg[b:b + k].copy_(ea[a:a + k])
+                self.exp_avg_sq[b:b + k].copy_(es[a:a + k])
         self.step_count = int(sd['step_count'])
 
     def load_torch_adam_state(self, sd):

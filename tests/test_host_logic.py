@@ -186,3 +186,40 @@ def test_option_defaults_are_the_references():
     assert len(shared) > 60
     wrong = {k: (opts.DEFAULTS[k], ref[k]) for k in shared if k not in deliberate and opts.DEFAULTS[k] != ref[k]}
     assert not wrong, wrong
+
+
+def test_flat_optimizer_state_survives_a_layout_change():
+    """r4: FlatParams lays a model's _flat_groups() back to back, so the moment buffers of a Transformer / AoA checkpoint written
+    before round 4 (model.parameters() order, no 'offsets' table) are permuted relative to today's buffers: load_state_dict moves
+    every parameter's moments by name; a state_dict of today carries its own table and round-trips."""
+    import torch
+    from imagecaptioning.pytorch_amd.flat import FlatParams
+
+    class Net(torch.nn.Module):
+        def __init__(self, grouped):
+            super().__init__()
+            self.a, self.b, self.c, self.d = (torch.nn.Linear(4, 4) for _ in range(4))
+            self.grouped = grouped
+
+        def _flat_groups(self):
+            return [['a.weight', 'c.weight', 'd.weight'], ['a.bias', 'c.bias', 'd.bias']] if self.grouped else []
+
+    torch.manual_seed(0)
+    old, new = FlatParams(Net(False)), FlatParams(Net(True))
+    assert old.offsets != new.offsets and sorted(old.offsets) == sorted(new.offsets) or old.total == new.total
+    for n, p, o in zip(old.names, old.params, old.offsets):              # moments that identify their parameter
+        old.exp_avg[o:o + p.numel()] = float(old.names.index(n) + 1)
+        old.exp_avg_sq[o:o + p.numel()] = float(old.names.index(n) + 1) * 10
+    old.step_count = 7
+    sd = old.state_dict()
+    sd.pop('offsets')                                                    # a checkpoint of rounds 1-3
+    new.load_state_dict(sd)
+    for n, p, o in zip(new.names, new.params, new.offsets):
+        assert float(new.exp_avg[o]) == new.names.index(n) + 1 and float(new.exp_avg_sq[o + p.numel() - 1]) == (new.names.index(n) + 1) * 10
+    assert new.step_count == 7
+    back = FlatParams(Net(True))
+    back.load_state_dict(new.state_dict())                              # same layout: plain copy
+    assert torch.equal(back.exp_avg, new.exp_avg)
+    older = FlatParams(Net(False))
+    older.load_state_dict(new.state_dict())                             # and the other way, through the table
+    assert torch.equal(older.exp_avg, old.exp_avg)
