@@ -18,15 +18,34 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace capmi {
 
+// Wave-wide reductions on the DPP cross-lane path.  r4: the __shfl_xor butterflies these replace were six ds_bpermute round trips
+// through the LDS crossbar each (about 100 cycles apiece, serialised by s_waitcnt): the softmax of the short-sequence MHA spent
+// 2 000 cycles per query row in them (scripts/mha_ablate.py).  Here: xor 1 / xor 2 are quad permutes, xor 4 / xor 8 the half-row and
+// row mirrors (after the quad steps every quad is uniform, so the mirrored lane holds the xor partner's value), and the four row
+// results are combined through v_readlane.  Callers must be wave-converged, as __shfl required.  The result is wave-uniform and
+// the reduction tree is the bottom-up butterfly (1, 2, 4, 8, 16, 32).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+__device__ __forceinline__ float lane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f<DPP_XOR1>(v);
+    v += dpp_f<DPP_XOR2>(v);
+    v += dpp_f<DPP_HALF_MIRROR>(v);
+    v += dpp_f<DPP_ROW_MIRROR>(v);
+    return (lane_f(v, 0) + lane_f(v, 16)) + (lane_f(v, 32) + lane_f(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll

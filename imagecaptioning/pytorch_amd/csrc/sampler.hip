@@ -27,15 +27,16 @@ __device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {
     if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
     return a;
 }
+template <int CTRL>
+__device__ __forceinline__ ArgMax dpp_better(ArgMax x) { return better(x, ArgMax{dpp_f<CTRL>(x.v), dpp_i<CTRL>(x.i)}); }
+__device__ __forceinline__ ArgMax lane_am(ArgMax x, int l) { return ArgMax{lane_f(x.v, l), __builtin_amdgcn_readlane(x.i, l)}; }
+// better() is associative, commutative and breaks ties by index, so any reduction tree gives the same winner (capmi_common.h: DPP path)
 __device__ __forceinline__ ArgMax wave_argmax(ArgMax x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        ArgMax y;
-        y.v = __shfl_xor(x.v, o, 64);
-        y.i = __shfl_xor(x.i, o, 64);
-        x = better(x, y);
-    }
-    return x;
+    x = dpp_better<DPP_XOR1>(x);
+    x = dpp_better<DPP_XOR2>(x);
+    x = dpp_better<DPP_HALF_MIRROR>(x);
+    x = dpp_better<DPP_ROW_MIRROR>(x);
+    return better(better(lane_am(x, 0), lane_am(x, 16)), better(lane_am(x, 32), lane_am(x, 48)));
 }
 
 // order-preserving map float -> uint32 (a < b  <=>  key(a) < key(b); -inf -> smallest)

@@ -166,64 +166,274 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reg_kernel(const float *__r
 }
 
 // ---------------------------------------------------------------- short-sequence MHA
-constexpr int MHA_T = 256;
+constexpr int MHA_T = 256, MHA_T_BIG = 512, MHA_T_MAX = 1024;
+// phase ablation for profiling (scripts/mha_ablate.py): only the research build (-DCAPMI_VARIANTS) has the switch
+#ifdef CAPMI_VARIANTS
+__device__ int g_mha_abl = 0;
+#define MHA_ABL(b) (g_mha_abl & (b))
+#else
+#define MHA_ABL(b) false
+#endif
+static void mha_sync_ablation() {
+#ifdef CAPMI_VARIANTS
+    static int last = 0;
+    const int a = capmi::research("CAPMI_MHA_ABL", 0);
+    if (a != last) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mha_abl), &a, sizeof(int)); last = a; }
+#endif
+}
+// Launch shape (profiles/r04_mha_phases.md; CAPMI_MHA_MFMA, CAPMI_MHA_THREADS, CAPMI_MHA_LDS_KB force them in the research build):
+//  * the contraction phases go to the matrix pipe when a pass has at least one 16-row tile of query rows; a decode step's 5 rows
+//    stay on the vector loops;
+//  * 8 waves per workgroup from 1 536 scores per pass up (a cross-attention's 105 x 36), 4 below (2 560 workgroups of 21 x 21
+//    are faster small); a grid with fewer workgroups than the chip has CUs (AoA: 10 images x 8 heads) gets 8 or, from 1 024
+//    scores up, 16 -- there the waves of ONE workgroup are all the parallelism a CU has;
+//  * the query rows of a pass take what fits in 80 KB next to K/V (two workgroups per CU); when they do not fit, occupancy is 1
+//    anyway and the pass takes the whole 160 KB.
+static int mha_on_mfma(int rows) {
+    const int f = capmi::research("CAPMI_MHA_MFMA", -1);
+    return f >= 0 ? f : (rows >= 16);
+}
+static int mha_threads(int rows, int Tk, int64_t wgs) {
+    const int f = capmi::research("CAPMI_MHA_THREADS", 0);
+    if (f > 0) return f;
+    const int64_t scores = (int64_t)rows * Tk;
+    if (wgs < 256) return scores >= 1024 ? MHA_T_MAX : MHA_T_BIG;
+    return scores >= 1536 ? MHA_T_BIG : MHA_T;
+}
+// query rows per pass: all of them when they fit the budget next to K/V, else equal chunks of whole 16-row tiles
+static int mha_chunk(int total, int64_t fixed_f, int64_t per_f) {
+    const int kb = capmi::research("CAPMI_MHA_LDS_KB", 0);
+    const int64_t two_per_cu = (kb > 0 ? kb : 80) * 1024 / 4;
+    if (fixed_f + total * per_f <= two_per_cu) return total;
+    const int64_t budget = (kb > 0 ? kb : 160) * 1024 / 4;
+    const int64_t room = budget > fixed_f ? (budget - fixed_f) / per_f : 0;
+    if (total <= room) return total;
+    if (room < 1) return 1;
+    const int64_t n = (total + room - 1) / room;
+    int64_t ch = (total + n - 1) / n;
+    if (((ch + 15) & ~15) <= room) ch = (ch + 15) & ~15;
+    return (int)ch;
+}
 
 // workgroup = (kv row, head): the K/V tile of one image (or caption) and head is staged in LDS once and serves ALL
 // q_per_kv * Tq query rows that attend to it.  The query rows are flattened (caption-major) and processed CH at a time --
 // as many as fit in LDS next to K/V, normally all of them -- so a decode step (Tq = 1, 5 captions per image) or a
 // cross-attention (5 x 21 rows per image) is ONE pass of four block-wide phases instead of q_per_kv sequential passes.
-// Every inner product runs on 16-byte LDS reads along the head dimension (dk % 4 == 0, row pitch dk + 4 floats: the
-// 16 lanes of a ds_read_b128 phase hit 64 distinct banks), i.e. 2 LDS instructions per 4 FMAs instead of 8; the
-// phases of these short-sequence kernels are LDS-instruction bound.
-// LDS: K [Tk][dk+4], V [Tk][dk+4], Q [CH][dk+4], S [CH][Tk+1]
+// r4 (scripts/mha_ablate.py, profiles/r04_mha_phases.md): with 4-8 waves per CU these phases are bound by the instructions a wave
+// issues, not by a pipe: the global row / caption / position of a query row come from a table in LDS instead of two integer
+// divisions per element, row-shaped loops give 16 lanes to a row (no division by Tk, reductions inside a DPP row), and the large
+// contractions run on the f32 MFMA.  The vector contractions read 16 bytes of LDS per instruction along the head dimension
+// (dk % 4 == 0, row pitch dk + 4 floats: the 16 lanes of a ds_read_b128 phase hit 64 distinct banks).
+// LDS: K [Tk][dk+4], V [Tk][dk+4], Q [CH][dk+4], S [CH][Tk+1], row tables 3 x [CH]
 __device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 #define LDS4(p) (*reinterpret_cast<const f32x4 *>(p))
+__device__ __forceinline__ int pow2_shift(int d) { return (d & (d - 1)) ? -1 : __builtin_ctz(d); }
+__device__ __forceinline__ int idiv(int i, int d, int sh) { return sh >= 0 ? i >> sh : i / d; }
 
-__global__ __launch_bounds__(MHA_T) void mha_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k,
-                                                       const float *__restrict__ v, int ldkv, int kstride,
-                                                       const uint8_t *__restrict__ mask, int mask_tq, int mask_per_q,
-                                                       int causal, int q_pos0, const float *__restrict__ drop,
-                                                       float *__restrict__ o, float *__restrict__ p, int q_per_kv, int Tq,
-                                                       int Tk, int h, int dk, int CH, int qstride) {
+// C[M,N] = sum_k A(i,k) B(k,j) with both operands in LDS behind arbitrary strides, on v_mfma_f32_16x16x4_f32 (f32 in, f32
+// accumulate: bitwise an fmaf chain over k).  One 16x16 tile per wave at a time, tiles strided over the waves; the operands of
+// 8 k-steps are requested before the 8 MFMAs that consume them.  Lane l feeds A[i0 + l%16][k + l/16] and B[k + l/16][j0 + l%16]
+// and owns C[i0 + 4 (l/16) + r][j0 + l%16], r = 0..3.  pre(i, j) is evaluated for the owned entries BEFORE the k loop (a global
+// or LDS value the epilogue needs: its latency hides under the tile), ep(i, j, value, pre) after it, both for in-range entries
+// only.  Out-of-range rows / columns read a clamped (valid, finite) address and are dropped; k past K reads a clamped address
+// and A is zeroed.
+template <typename Pre, typename Ep>
+__device__ __forceinline__ void lds_mfma16(const float *a, int sa_i, int sa_k, const float *b, int sb_k, int sb_j, int M, int N, int K,
+                                           Pre pre, Ep ep) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int tn = (N + 15) >> 4, tiles = ((M + 15) >> 4) * tn;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int t = wid; t < tiles; t += nw) {
+        const int ti = t / tn, i0 = ti << 4, j0 = (t - ti * tn) << 4;
+        const int j = j0 + li;
+        float pv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 4 * lk + r;
+            pv[r] = (i < M && j < N) ? pre(i, j) : 0.f;
+        }
+        const float *ap = a + min(i0 + li, M - 1) * sa_i + lk * sa_k;
+        const float *bp = b + min(j, N - 1) * sb_j + lk * sb_k;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            float av[8], bv[8];
+            if (k0 + 32 <= K) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    av[u] = ap[(k0 + 4 * u) * sa_k];
+                    bv[u] = bp[(k0 + 4 * u) * sb_k];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + 4 * u + lk, kc = min(k, K - 1) - lk;
+                    av[u] = ap[kc * sa_k];
+                    bv[u] = bp[kc * sb_k];
+                    if (k >= K) av[u] = 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k0 + 4 * u < K) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 4 * lk + r;
+            if (i < M && j < N) ep(i, j, acc[r], pv[r]);
+        }
+    }
+}
+// reductions over the 16 lanes of a DPP row (every lane of the row gets the result); capmi_common.h: the cross-lane path
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<DPP_XOR1>(v);
+    v += dpp_f<DPP_XOR2>(v);
+    v += dpp_f<DPP_HALF_MIRROR>(v);
+    return v + dpp_f<DPP_ROW_MIRROR>(v);
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_f<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_f<DPP_HALF_MIRROR>(v));
+    return fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+}
+
+// K and V (and, in the backward, zeroed dK / dV) of (kv row, head) -> LDS, four trips of loads in flight
+template <bool ZERO>
+__device__ __forceinline__ void mha_stage_kv(const float *__restrict__ k, const float *__restrict__ v, size_t base, int kstride, int Tk,
+                                             int d4, int d4sh, int P1, float *sK, float *sV, float *sdK, float *sdV) {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = threadIdx.x; i0 < Tk * d4; i0 += 4 * blockDim.x) {
+        f32x4 kk[4], vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * (int)blockDim.x, Tk * d4 - 1), j = idiv(i, d4, d4sh), c = (i - j * d4) * 4;
+            const size_t gi = base + (size_t)j * kstride + c;
+            kk[u] = *reinterpret_cast<const f32x4 *>(k + gi);
+            vv[u] = *reinterpret_cast<const f32x4 *>(v + gi);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * (int)blockDim.x;
+            if (i < Tk * d4) {
+                const int j = idiv(i, d4, d4sh), c = (i - j * d4) * 4;
+                *reinterpret_cast<f32x4 *>(sK + j * P1 + c) = kk[u];
+                *reinterpret_cast<f32x4 *>(sV + j * P1 + c) = vv[u];
+                if (ZERO) {
+                    *reinterpret_cast<f32x4 *>(sdK + j * P1 + c) = zero4;
+                    *reinterpret_cast<f32x4 *>(sdV + j * P1 + c) = zero4;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(MHA_T_MAX) void mha_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                           const float *__restrict__ v, int ldkv, int kstride,
+                                                           const uint8_t *__restrict__ mask, int mask_tq, int mask_per_q,
+                                                           int causal, int q_pos0, const float *__restrict__ drop,
+                                                           float *__restrict__ o, float *__restrict__ p, int q_per_kv, int Tq,
+                                                           int Tk, int h, int dk, int CH, int qstride, int mfma) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int D = h * dk, P1 = dk + 4, S1 = Tk + 1, d4 = dk >> 2;
+    const int D = h * dk, P1 = dk + 4, S1 = Tk + 1, d4 = dk >> 2, d4sh = pow2_shift(d4);
     float *sK = lds, *sV = sK + Tk * P1, *sQ = sV + Tk * P1, *sS = sQ + CH * P1;
+    int *sRT = reinterpret_cast<int *>(sS + CH * S1), *sTT = sRT + CH, *sMR = sTT + CH;   // query row -> r * Tq + t, t, mask row
     const int kvr = blockIdx.x, hd = blockIdx.y;
     const float scale = rsqrtf((float)dk);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int i = threadIdx.x; i < Tk * d4; i += blockDim.x) {
-        const int j = i / d4, c = (i - j * d4) * 4;
-        const size_t gi = (size_t)kvr * ldkv + (size_t)j * kstride + hd * dk + c;
-        *reinterpret_cast<f32x4 *>(sK + j * P1 + c) = *reinterpret_cast<const f32x4 *>(k + gi);
-        *reinterpret_cast<f32x4 *>(sV + j * P1 + c) = *reinterpret_cast<const f32x4 *>(v + gi);
-    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, l16 = lane & 15, sub = lane >> 4;
+    if (!MHA_ABL(1)) mha_stage_kv<false>(k, v, (size_t)kvr * ldkv + hd * dk, kstride, Tk, d4, d4sh, P1, sK, sV, nullptr, nullptr);
     const int R_all = q_per_kv * Tq;
     for (int row0 = 0; row0 < R_all; row0 += CH) {
         const int rows = min(CH, R_all - row0);
-        __syncthreads();                    // K/V staged (first trip); the previous chunk's readers are done
-        for (int i = threadIdx.x; i < rows * d4; i += blockDim.x) {
-            const int lr = i / d4, c = (i - lr * d4) * 4, gr = row0 + lr;
-            const int r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
-            *reinterpret_cast<f32x4 *>(sQ + lr * P1 + c) = *reinterpret_cast<const f32x4 *>(q + ((size_t)r * Tq + t) * qstride + hd * dk + c);
+        if (row0) __syncthreads();          // the previous chunk's readers are done
+        for (int lr = threadIdx.x; lr < rows; lr += blockDim.x) {
+            const int gr = row0 + lr, r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
+            sRT[lr] = r * Tq + t;
+            sTT[lr] = t;
+            sMR[lr] = (mask_per_q ? r : kvr) * mask_tq + (mask_tq > 1 ? t : 0);
+        }
+        __syncthreads();                    // row tables (and, first trip, K / V) visible
+        if (!MHA_ABL(2))
+        for (int i0 = threadIdx.x; i0 < rows * d4; i0 += 4 * blockDim.x) {
+            f32x4 qq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u * (int)blockDim.x, rows * d4 - 1), lr = idiv(i, d4, d4sh), c = (i - lr * d4) * 4;
+                qq[u] = *reinterpret_cast<const f32x4 *>(q + (size_t)sRT[lr] * qstride + hd * dk + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * (int)blockDim.x;
+                if (i < rows * d4) {
+                    const int lr = idiv(i, d4, d4sh), c = (i - lr * d4) * 4;
+                    *reinterpret_cast<f32x4 *>(sQ + lr * P1 + c) = qq[u];
+                }
+            }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < rows * Tk; i += blockDim.x) {
-            const int lr = i / Tk, j = i - lr * Tk, gr = row0 + lr;
-            const int r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
-            const float *qa = sQ + lr * P1, *ka = sK + j * P1;
-            float s = 0.f;
-            for (int c = 0; c < dk; c += 4) s += dot4(LDS4(qa + c), LDS4(ka + c));
-            s *= scale;
-            bool ok = true;
-            if (mask) ok = mask[((size_t)(mask_per_q ? r : kvr) * mask_tq + (mask_tq > 1 ? t : 0)) * Tk + j] != 0;
-            if (causal && j > q_pos0 + t) ok = false;
-            sS[lr * S1 + j] = ok ? s : -INFINITY;
+        // scores = scale * Q K^T, masked
+        if (mfma) {
+            if (!MHA_ABL(4))
+            lds_mfma16(sQ, P1, 1, sK, 1, P1, rows, Tk, dk,
+                       [&](int lr, int j) { return (mask && !MHA_ABL(8)) ? (float)mask[(size_t)sMR[lr] * Tk + j] : 1.f; },
+                       [&](int lr, int j, float acc, float mk) {
+                           const bool ok = mk != 0.f && !(causal && j > q_pos0 + sTT[lr]);
+                           sS[lr * S1 + j] = ok ? acc * scale : -INFINITY;
+                       });
+        } else {
+            for (int lr = wid * 4 + sub; lr < rows; lr += nw * 4) {        // 16 lanes per query row
+                const float *qa = sQ + lr * P1;
+                const size_t mrow = (size_t)sMR[lr] * Tk;
+                const int jmax = causal ? q_pos0 + sTT[lr] : Tk;
+                for (int j = l16; j < Tk; j += 16) {
+                    bool ok = j <= jmax;
+                    if (mask && !MHA_ABL(8)) ok = ok && mask[mrow + j] != 0;          // (requested before the arithmetic)
+                    const float *ka = sK + j * P1;
+                    float s = 0.f;
+                    if (!MHA_ABL(4))
+                    for (int c = 0; c < dk; c += 4) s += dot4(LDS4(qa + c), LDS4(ka + c));
+                    sS[lr * S1 + j] = ok ? s * scale : -INFINITY;
+                }
+            }
         }
         __syncthreads();
-        for (int lr = wid; lr < rows; lr += nw) {          // softmax: one wave per query row
-            const int gr = row0 + lr;
-            const int r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
+        if (Tk <= 64 && !MHA_ABL(16)) {
+            // softmax with 16 lanes per query row: a lane holds keys l16 + 16 e (e < 4) in registers, four rows per wave instruction
+            for (int lr0 = wid * 4; lr0 < rows; lr0 += nw * 4) {
+                const int lr = lr0 + sub, lrc = min(lr, rows - 1), t = sTT[lrc];
+                const size_t pi0 = ((size_t)(sRT[lrc] - t) * h + (size_t)hd * Tq + t) * Tk;
+                float x[4], dr[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = l16 + 16 * e;
+                    const bool ok = lr < rows && j < Tk;
+                    x[e] = ok ? sS[lrc * S1 + j] : -INFINITY;
+                    dr[e] = (drop && ok && !MHA_ABL(32)) ? drop[pi0 + j] : 1.f;
+                }
+                const float m = row16_max(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+                float sum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[e] = (l16 + 16 * e < Tk) ? __expf(x[e] - m) : 0.f;
+                    sum += x[e];
+                }
+                const float is = 1.f / row16_sum(sum);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = l16 + 16 * e;
+                    if (lr < rows && j < Tk) {
+                        const float pr = x[e] * is;
+                        if (p && !MHA_ABL(32)) p[pi0 + j] = pr;
+                        sS[lr * S1 + j] = pr * dr[e];
+                    }
+                }
+            }
+        } else if (!MHA_ABL(16))
+        for (int lr = wid; lr < rows; lr += nw) {          // softmax: one wave per query row, any Tk
             float *row = sS + lr * S1;
+            const int t = sTT[lr];
+            const size_t pi0 = ((size_t)(sRT[lr] - t) * h + (size_t)hd * Tq + t) * Tk;
             float m = -INFINITY;
             for (int j = lane; j < Tk; j += 64) m = fmaxf(m, row[j]);
             m = wave_max(m);
@@ -237,80 +447,141 @@ __global__ __launch_bounds__(MHA_T) void mha_fwd_kernel(const float *__restrict_
             const float is = 1.f / sum;
             for (int j = lane; j < Tk; j += 64) {
                 float pr = row[j] * is;
-                const size_t pi = (((size_t)r * h + hd) * Tq + t) * Tk + j;
-                if (p) p[pi] = pr;
-                if (drop) pr *= drop[pi];
+                if (p) p[pi0 + j] = pr;
+                if (drop) pr *= drop[pi0 + j];
                 row[j] = pr;
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < rows * d4; i += blockDim.x) {      // o = P V: 4 head columns per thread
-            const int lr = i / d4, c = (i - lr * d4) * 4, gr = row0 + lr;
-            const int r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
+        // o = P V
+        if (mfma) {
+            if (!MHA_ABL(64))
+            lds_mfma16(sS, S1, 1, sV, P1, 1, rows, dk, Tk, [](int, int) { return 0.f; },
+                       [&](int lr, int c, float acc, float) { if (!MHA_ABL(128)) o[(size_t)sRT[lr] * D + hd * dk + c] = acc; });
+        } else
+        for (int i = threadIdx.x; i < rows * d4; i += blockDim.x) {      // 4 head columns per thread
+            const int lr = idiv(i, d4, d4sh), c = (i - lr * d4) * 4;
             const float *pr = sS + lr * S1;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (!MHA_ABL(64))
             for (int j = 0; j < Tk; ++j) acc += pr[j] * LDS4(sV + j * P1 + c);
-            *reinterpret_cast<f32x4 *>(o + ((size_t)r * Tq + t) * D + hd * dk + c) = acc;
+            if (!MHA_ABL(128))
+            *reinterpret_cast<f32x4 *>(o + (size_t)sRT[lr] * D + hd * dk + c) = acc;
         }
     }
 }
 
 // backward, same decomposition; dK/dV accumulate over the chunks in LDS and are written once.
-// LDS: K, V, dK, dV [Tk][dk+4]; Q, dO [CH][dk+4]; P, P*drop, dS [CH][Tk+1]
-__global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict__ d_o, const float *__restrict__ q,
-                                                       const float *__restrict__ k, const float *__restrict__ v, int ldkv,
-                                                       int kstride, const float *__restrict__ p,
-                                                       const float *__restrict__ drop, float *__restrict__ dq,
-                                                       float *__restrict__ dk_out, float *__restrict__ dv_out, int dkv_ld,
-                                                       int dkv_stride, int accumulate, int q_per_kv, int Tq, int Tk, int h,
-                                                       int dk, int CH, int qstride, int dq_stride) {
+// LDS: K, V, dK, dV [Tk][dk+4]; Q, dO [CH][dk+4]; P, P*drop, dS [CH][Tk+1]; row tables 2 x [CH]
+__global__ __launch_bounds__(MHA_T_MAX) void mha_bwd_kernel(const float *__restrict__ d_o, const float *__restrict__ q,
+                                                           const float *__restrict__ k, const float *__restrict__ v, int ldkv,
+                                                           int kstride, const float *__restrict__ p,
+                                                           const float *__restrict__ drop, float *__restrict__ dq,
+                                                           float *__restrict__ dk_out, float *__restrict__ dv_out, int dkv_ld,
+                                                           int dkv_stride, int accumulate, int q_per_kv, int Tq, int Tk, int h,
+                                                           int dk, int CH, int qstride, int dq_stride, int mfma) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int D = h * dk, P1 = dk + 4, S1 = Tk + 1, d4 = dk >> 2;
+    const int D = h * dk, P1 = dk + 4, S1 = Tk + 1, d4 = dk >> 2, d4sh = pow2_shift(d4);
     float *sK = lds, *sV = sK + Tk * P1, *sdK = sV + Tk * P1, *sdV = sdK + Tk * P1;
     float *sQ = sdV + Tk * P1, *sdO = sQ + CH * P1, *sP = sdO + CH * P1, *sPd = sP + CH * S1, *sdS = sPd + CH * S1;
+    int *sRT = reinterpret_cast<int *>(sdS + CH * S1), *sTT = sRT + CH;
     const int kvr = blockIdx.x, hd = blockIdx.y;
     const float scale = rsqrtf((float)dk);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < Tk * d4; i += blockDim.x) {
-        const int j = i / d4, c = (i - j * d4) * 4;
-        const size_t gi = (size_t)kvr * ldkv + (size_t)j * kstride + hd * dk + c;
-        *reinterpret_cast<f32x4 *>(sK + j * P1 + c) = *reinterpret_cast<const f32x4 *>(k + gi);
-        *reinterpret_cast<f32x4 *>(sV + j * P1 + c) = *reinterpret_cast<const f32x4 *>(v + gi);
-        *reinterpret_cast<f32x4 *>(sdK + j * P1 + c) = zero4;
-        *reinterpret_cast<f32x4 *>(sdV + j * P1 + c) = zero4;
-    }
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    mha_stage_kv<true>(k, v, (size_t)kvr * ldkv + hd * dk, kstride, Tk, d4, d4sh, P1, sK, sV, sdK, sdV);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, l16 = lane & 15, sub = lane >> 4;
     const int R_all = q_per_kv * Tq;
     for (int row0 = 0; row0 < R_all; row0 += CH) {
         const int rows = min(CH, R_all - row0);
-        __syncthreads();
-        for (int i = threadIdx.x; i < rows * d4; i += blockDim.x) {
-            const int lr = i / d4, c = (i - lr * d4) * 4, gr = row0 + lr;
-            const size_t gi = ((size_t)(kvr * q_per_kv + gr / Tq) * Tq + gr % Tq) * D + hd * dk + c;
-            const size_t gq = ((size_t)(kvr * q_per_kv + gr / Tq) * Tq + gr % Tq) * qstride + hd * dk + c;
-            *reinterpret_cast<f32x4 *>(sQ + lr * P1 + c) = *reinterpret_cast<const f32x4 *>(q + gq);
-            *reinterpret_cast<f32x4 *>(sdO + lr * P1 + c) = *reinterpret_cast<const f32x4 *>(d_o + gi);
+        if (row0) __syncthreads();
+        for (int lr = threadIdx.x; lr < rows; lr += blockDim.x) {
+            const int gr = row0 + lr, r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
+            sRT[lr] = r * Tq + t;
+            sTT[lr] = t;
         }
-        for (int i = threadIdx.x; i < rows * Tk; i += blockDim.x) {
-            const int lr = i / Tk, j = i - lr * Tk, gr = row0 + lr;
-            const size_t pi = (((size_t)(kvr * q_per_kv + gr / Tq) * h + hd) * Tq + gr % Tq) * Tk + j;
-            const float pr = p[pi];
-            const float dm = drop ? drop[pi] : 1.f;
-            sP[lr * S1 + j] = pr;
-            sPd[lr * S1 + j] = pr * dm;
-            sdS[lr * S1 + j] = dm;               // parked here until dP is formed below
+        __syncthreads();
+        for (int i0 = threadIdx.x; i0 < rows * d4; i0 += 4 * blockDim.x) {
+            f32x4 qq[4], oo[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u * (int)blockDim.x, rows * d4 - 1), lr = idiv(i, d4, d4sh), c = (i - lr * d4) * 4;
+                const size_t rt = (size_t)sRT[lr];
+                qq[u] = *reinterpret_cast<const f32x4 *>(q + rt * qstride + hd * dk + c);
+                oo[u] = *reinterpret_cast<const f32x4 *>(d_o + rt * D + hd * dk + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * (int)blockDim.x;
+                if (i < rows * d4) {
+                    const int lr = idiv(i, d4, d4sh), c = (i - lr * d4) * 4;
+                    *reinterpret_cast<f32x4 *>(sQ + lr * P1 + c) = qq[u];
+                    *reinterpret_cast<f32x4 *>(sdO + lr * P1 + c) = oo[u];
+                }
+            }
+        }
+        // P, P * dropout and (parked in dS until dP is formed) the dropout mask: 16 lanes per row, two rows' loads in flight
+        if (!MHA_ABL(4096))
+        for (int lr0 = wid * 8; lr0 < rows; lr0 += nw * 8) {
+            for (int j0 = 0; j0 < Tk; j0 += 32) {
+                float pv[4], dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int lr = min(lr0 + sub + 4 * (u >> 1), rows - 1), j = min(j0 + l16 + 16 * (u & 1), Tk - 1), t = sTT[lr];
+                    const size_t pi = ((size_t)(sRT[lr] - t) * h + (size_t)hd * Tq + t) * Tk + j;
+                    pv[u] = p[pi];
+                    dv[u] = drop ? drop[pi] : 1.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int lr = lr0 + sub + 4 * (u >> 1), j = j0 + l16 + 16 * (u & 1);
+                    if (lr < rows && j < Tk) {
+                        sP[lr * S1 + j] = pv[u];
+                        sPd[lr * S1 + j] = pv[u] * dv[u];
+                        sdS[lr * S1 + j] = dv[u];
+                    }
+                }
+            }
         }
         __syncthreads();
         // dP_drop = dO V^T ; dP = dP_drop * drop
-        for (int i = threadIdx.x; i < rows * Tk; i += blockDim.x) {
-            const int lr = i / Tk, j = i - lr * Tk;
-            const float *da = sdO + lr * P1, *va = sV + j * P1;
-            float acc = 0.f;
-            for (int c = 0; c < dk; c += 4) acc += dot4(LDS4(da + c), LDS4(va + c));
-            sdS[lr * S1 + j] *= acc;             // dP (w.r.t. the pre-dropout probabilities)
+        if (mfma) {
+            if (!MHA_ABL(256))
+            lds_mfma16(sdO, P1, 1, sV, 1, P1, rows, Tk, dk, [&](int lr, int j) { return sdS[lr * S1 + j]; },
+                       [&](int lr, int j, float acc, float dm) { sdS[lr * S1 + j] = dm * acc; });
+        } else {
+            for (int lr = wid * 4 + sub; lr < rows; lr += nw * 4) {
+                const float *da = sdO + lr * P1;
+                for (int j = l16; j < Tk; j += 16) {
+                    const float *va = sV + j * P1;
+                    float acc = 0.f;
+                    if (!MHA_ABL(256))
+                    for (int c = 0; c < dk; c += 4) acc += dot4(LDS4(da + c), LDS4(va + c));
+                    sdS[lr * S1 + j] *= acc;             // dP (w.r.t. the pre-dropout probabilities)
+                }
+            }
         }
         __syncthreads();
         // softmax backward per row: dS = P * (dP - sum_j P dP) * scale
+        if (Tk <= 64 && !MHA_ABL(512)) {          // 16 lanes per row, as the forward softmax
+            for (int lr0 = wid * 4; lr0 < rows; lr0 += nw * 4) {
+                const int lr = lr0 + sub, lrc = min(lr, rows - 1);
+                float pp[4], dp[4], sacc = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = l16 + 16 * e;
+                    const bool ok = lr < rows && j < Tk;
+                    pp[e] = ok ? sP[lrc * S1 + j] : 0.f;
+                    dp[e] = ok ? sdS[lrc * S1 + j] : 0.f;
+                    sacc += pp[e] * dp[e];
+                }
+                sacc = row16_sum(sacc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = l16 + 16 * e;
+                    if (lr < rows && j < Tk) sdS[lr * S1 + j] = pp[e] * (dp[e] - sacc) * scale;
+                }
+            }
+        } else if (!MHA_ABL(512))
         for (int lr = wid; lr < rows; lr += nw) {
             float s = 0.f;
             for (int j = lane; j < Tk; j += 64) s += sP[lr * S1 + j] * sdS[lr * S1 + j];
@@ -318,15 +589,30 @@ __global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict_
             for (int j = lane; j < Tk; j += 64) sdS[lr * S1 + j] = sP[lr * S1 + j] * (sdS[lr * S1 + j] - s) * scale;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < rows * d4; i += blockDim.x) {     // dQ = dS K: 4 head columns per thread
-            const int lr = i / d4, c = (i - lr * d4) * 4, gr = row0 + lr;
+        // dQ = dS K ; dK += dS^T Q ; dV += (P*drop)^T dO
+        if (mfma) {
+            if (!MHA_ABL(1024))
+            lds_mfma16(sdS, S1, 1, sK, P1, 1, rows, dk, Tk, [](int, int) { return 0.f; },
+                       [&](int lr, int c, float acc, float) { dq[(size_t)sRT[lr] * dq_stride + hd * dk + c] = acc; });
+            if (!MHA_ABL(2048)) {
+                lds_mfma16(sdS, 1, S1, sQ, P1, 1, Tk, dk, rows, [&](int j, int c) { return sdK[j * P1 + c]; },
+                           [&](int j, int c, float acc, float old) { sdK[j * P1 + c] = old + acc; });
+                lds_mfma16(sPd, 1, S1, sdO, P1, 1, Tk, dk, rows, [&](int j, int c) { return sdV[j * P1 + c]; },
+                           [&](int j, int c, float acc, float old) { sdV[j * P1 + c] = old + acc; });
+            }
+            continue;
+        }
+        for (int i = threadIdx.x; i < rows * d4; i += blockDim.x) {     // 4 head columns per thread
+            const int lr = idiv(i, d4, d4sh), c = (i - lr * d4) * 4;
             const float *ds = sdS + lr * S1;
             f32x4 acc = zero4;
+            if (!MHA_ABL(1024))
             for (int j = 0; j < Tk; ++j) acc += ds[j] * LDS4(sK + j * P1 + c);
-            *reinterpret_cast<f32x4 *>(dq + ((size_t)(kvr * q_per_kv + gr / Tq) * Tq + gr % Tq) * dq_stride + hd * dk + c) = acc;
+            *reinterpret_cast<f32x4 *>(dq + (size_t)sRT[lr] * dq_stride + hd * dk + c) = acc;
         }
-        for (int i = threadIdx.x; i < Tk * d4; i += blockDim.x) {       // dK += dS^T Q ; dV += (P*drop)^T dO
-            const int j = i / d4, c = (i - j * d4) * 4;
+        if (!MHA_ABL(2048))
+        for (int i = threadIdx.x; i < Tk * d4; i += blockDim.x) {
+            const int j = idiv(i, d4, d4sh), c = (i - j * d4) * 4;
             f32x4 ak = zero4, av = zero4;
             for (int lr = 0; lr < rows; ++lr) {
                 ak += sdS[lr * S1 + j] * LDS4(sQ + lr * P1 + c);
@@ -338,7 +624,7 @@ __global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict_
     }
     __syncthreads();
     for (int i = threadIdx.x; i < Tk * d4; i += blockDim.x) {
-        const int j = i / d4, c = (i - j * d4) * 4;
+        const int j = idiv(i, d4, d4sh), c = (i - j * d4) * 4;
         const size_t oi = (size_t)kvr * dkv_ld + (size_t)j * dkv_stride + hd * dk + c;
         f32x4 gk = LDS4(sdK + j * P1 + c), gv = LDS4(sdV + j * P1 + c);
         if (accumulate) {
@@ -562,14 +848,9 @@ int capmi_mha_fwd_s(const float *q, int qstride, const float *k, const float *v,
     if (dk % 4 || ldkv % 4 || kstride % 4 || ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
                                                 reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(o)) & 15))
         return CAPMI_EINVAL;
-    // query rows per pass: all q_per_kv * Tq of them when they fit in ~64 KB next to K/V (two workgroups per CU), else as many
-    // as do; K/V alone may take up to the full 160 KB
-    const int64_t fixed_f = (int64_t)2 * Tk * (dk + 4), per_f = (int64_t)(dk + 4) + (Tk + 1);
-    int CH = q_per_kv * Tq;
-    {
-        const int64_t budget = 64 * 1024 / 4, room = budget > fixed_f ? (budget - fixed_f) / per_f : 0;
-        if (CH > room) CH = (int)(room > 0 ? room : 1);
-    }
+    const int64_t fixed_f = (int64_t)2 * Tk * (dk + 4), per_f = (int64_t)(dk + 4) + (Tk + 1) + 3;
+    const int64_t wgs = (int64_t)(Nq / q_per_kv) * h;
+    const int CH = mha_chunk(q_per_kv * Tq, fixed_f, per_f);
     const size_t lds = (size_t)(fixed_f + (int64_t)CH * per_f) * sizeof(float);
     if (lds > 160 * 1024) return CAPMI_EINVAL;
     static bool attr_f = false;      // more than 64 KB of dynamic LDS needs the opt-in (36 regions x 64 dims already do in bwd)
@@ -577,8 +858,9 @@ int capmi_mha_fwd_s(const float *q, int qstride, const float *k, const float *v,
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mha_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_f = true;
     }
-    hipLaunchKernelGGL(mha_fwd_kernel, dim3(Nq / q_per_kv, h), dim3(MHA_T), lds, (hipStream_t)stream, q, k, v, ldkv, kstride,
-                       mask, mask_tq, mask_per_q, causal, q_pos0, drop, o, p, q_per_kv, Tq, Tk, h, dk, CH, qstride);
+    mha_sync_ablation();
+    hipLaunchKernelGGL(mha_fwd_kernel, dim3(Nq / q_per_kv, h), dim3(mha_threads(CH, Tk, wgs)), lds, (hipStream_t)stream, q, k, v, ldkv, kstride,
+                       mask, mask_tq, mask_per_q, causal, q_pos0, drop, o, p, q_per_kv, Tq, Tk, h, dk, CH, qstride, mha_on_mfma(CH));
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -606,12 +888,9 @@ int capmi_mha_bwd_s(const float *d_o, const float *q, int qstride, const float *
           reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dk_out) |
           reinterpret_cast<uintptr_t>(dv_out)) & 15))
         return CAPMI_EINVAL;
-    const int64_t fixed_b = (int64_t)4 * Tk * (dk + 4), per_b = (int64_t)2 * (dk + 4) + 3 * (Tk + 1);
-    int CH = q_per_kv * Tq;
-    {
-        const int64_t budget = 96 * 1024 / 4, room = budget > fixed_b ? (budget - fixed_b) / per_b : 0;
-        if (CH > room) CH = (int)(room > 0 ? room : 1);
-    }
+    const int64_t fixed_b = (int64_t)4 * Tk * (dk + 4), per_b = (int64_t)2 * (dk + 4) + 3 * (Tk + 1) + 2;
+    const int64_t wgs = (int64_t)(Nq / q_per_kv) * h;
+    const int CH = mha_chunk(q_per_kv * Tq, fixed_b, per_b);
     const size_t lds = (size_t)(fixed_b + (int64_t)CH * per_b) * sizeof(float);
     if (lds > 160 * 1024) return CAPMI_EINVAL;
     static bool attr_b = false;
@@ -619,8 +898,10 @@ int capmi_mha_bwd_s(const float *d_o, const float *q, int qstride, const float *
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mha_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_b = true;
     }
-    hipLaunchKernelGGL(mha_bwd_kernel, dim3(Nq / q_per_kv, h), dim3(MHA_T), lds, (hipStream_t)stream, d_o, q, k, v, ldkv, kstride,
-                       p, drop, dq, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, q_per_kv, Tq, Tk, h, dk, CH, qstride, dq_stride);
+    mha_sync_ablation();
+    hipLaunchKernelGGL(mha_bwd_kernel, dim3(Nq / q_per_kv, h), dim3(mha_threads(CH, Tk, wgs)), lds, (hipStream_t)stream, d_o, q, k, v, ldkv, kstride,
+                       p, drop, dq, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, q_per_kv, Tq, Tk, h, dk, CH, qstride, dq_stride,
+                       mha_on_mfma(CH));
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

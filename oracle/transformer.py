@@ -52,9 +52,19 @@ def mha(P: Params, pre: str, q_in, k_in, v_in, mask, h: int, drop: Drop, tag: st
     return x @ P[pre + '.linears.3.weight'].t() + P[pre + '.linears.3.bias']
 
 
+# test probe: when a dict, ffn() records per FFN the hidden units whose ReLU input came within RELU_TIE_MARGIN of zero for some
+# token.  ReLU's derivative jumps there: two fp32 implementations whose pre-activations differ by rounding can take different
+# sides, and the unit's row of dW1 / db1 then differs by that token's whole term (tests/test_full_size_parity_gpu.py)
+RELU_TIES: Optional[Dict[str, torch.Tensor]] = None
+RELU_TIE_MARGIN = 1e-4
+
+
 def ffn(P: Params, pre: str, x, drop: Drop, tag: str):
     """PositionwiseFeedForward (:205-206)."""
-    hdn = _d(drop, tag + '.ff', F.relu(x @ P[pre + '.w_1.weight'].t() + P[pre + '.w_1.bias']))
+    a = x @ P[pre + '.w_1.weight'].t() + P[pre + '.w_1.bias']
+    if RELU_TIES is not None:
+        RELU_TIES[pre] = (a.detach().abs() < RELU_TIE_MARGIN).reshape(-1, a.shape[-1]).any(0)
+    hdn = _d(drop, tag + '.ff', F.relu(a))
     return hdn @ P[pre + '.w_2.weight'].t() + P[pre + '.w_2.bias']
 
 

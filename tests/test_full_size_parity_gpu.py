@@ -109,8 +109,12 @@ def _labels(B, n, L, V1, seed):
     return labels, masks
 
 
-def _compare_model_with_oracle(model, forward_ref, greedy_ref, att, am, labels, masks, fc=None):
-    """teacher-forced log-probs / XE loss / all gradients and the greedy decode of `model` (HIP) vs oracle callables"""
+def _compare_model_with_oracle(model, forward_ref, greedy_ref, att, am, labels, masks, fc=None, relu_ties=None):
+    """teacher-forced log-probs / XE loss / all gradients and the greedy decode of `model` (HIP) vs oracle callables.
+    relu_ties: dict filled by the oracle's forward ({ffn prefix: bool [d_ff]}, oracle/transformer.py RELU_TIES): hidden units whose
+    ReLU input is within 1e-4 of zero for some token.  With 2048 units x 24 tokens x 12 layers a handful always are, some within
+    1e-6, and which side an fp32 implementation lands on is rounding: that unit's row of dW1 / db1 then differs by one token's
+    whole term (seen as 1.6e-3 of the largest entry).  Those rows are held to 5e-2, every other row to 1e-3."""
     from oracle import att_lstm as O
     from imagecaptioning.pytorch_amd.captioning.modules.losses import LanguageModelCriterion
     P = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -135,7 +139,18 @@ def _compare_model_with_oracle(model, forward_ref, greedy_ref, att, am, labels, 
             # mathematically zero and pure rounding noise on both sides
             assert float(p.grad.abs().max()) < 1e-5 and float(ref.abs().max()) < 1e-5, k
             continue
-        worst[k] = rel(p.grad, ref)
+        tie = None
+        if relu_ties and (k.endswith('.w_1.weight') or k.endswith('.w_1.bias')):
+            tie = relu_ties.get(k.rsplit('.w_1.', 1)[0])
+        if tie is not None and bool(tie.any()):
+            scale = float(ref.abs().max())
+            err = (p.grad.detach().cpu().double() - ref.double()).abs()
+            err = err.reshape(err.shape[0], -1).max(1)[0] / scale          # per hidden unit
+            assert float(err[tie].max()) < 5e-2, (k, 'rows with a ReLU tie', float(err[tie].max()))
+            assert int(tie.sum()) < 0.05 * tie.numel(), (k, int(tie.sum()))
+            worst[k] = float(err[~tie].max())
+        else:
+            worst[k] = rel(p.grad, ref)
     bad = {k: v for k, v in worst.items() if v >= 1e-3}
     assert not bad, bad
     model.eval()
@@ -171,9 +186,16 @@ def test_transformer_baseline_size_vs_oracle(masked):
         am[0, 30:] = 0
         am[1, 17:] = 0
     labels, masks = _labels(B, n, L, synthetic.VOCAB + 1, seed=8)
-    _compare_model_with_oracle(
-        model, lambda P: T.forward_teacher(P, att, labels[..., :-1], am, h=8, n_enc=6, n_dec=6),
-        lambda P: T.greedy(P, att, am, h=8, n_enc=6, n_dec=6, max_len=L), att, am, labels, masks)
+    ties = {}
+
+    def forward_ref(P):
+        T.RELU_TIES = ties
+        try:
+            return T.forward_teacher(P, att, labels[..., :-1], am, h=8, n_enc=6, n_dec=6)
+        finally:
+            T.RELU_TIES = None
+    _compare_model_with_oracle(model, forward_ref, lambda P: T.greedy(P, att, am, h=8, n_enc=6, n_dec=6, max_len=L), att, am, labels,
+                               masks, relu_ties=ties)
 
 
 @pytest.mark.parametrize('masked', [False, True])
