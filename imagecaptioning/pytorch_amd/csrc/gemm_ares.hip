@@ -441,7 +441,7 @@ __global__ __launch_bounds__(AR_NT) void gemm_ares_kernel(const KArgs a) {
             if (a.row_bias) v += a.row_bias[(size_t)(row / a.row_bias_div) * a.N + col];
             if (a.relu) v = fmaxf(v, 0.f);
             if (a.mul_mask) v *= a.mul_mask[(size_t)row * a.N + col];
-            if (a.accumulate) v += a.C[(size_t)row * a.ldc + col];
+            if (a.accumulate) v += a.addend[(size_t)row * a.ldc + col];
             a.C[(size_t)row * a.ldc + col] = v;
         }
     }

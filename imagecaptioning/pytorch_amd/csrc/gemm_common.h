@@ -31,6 +31,7 @@ struct KArgs {
     int row_bias_div;
     const float *mul_mask;
     int relu, accumulate;
+    const float *addend;   // what `accumulate` adds: the descriptor's addend, else C (row pitch ldc either way)
     float *partial;
     int splits;
     int to_partial;      // write raw K-slice sums to `partial` (split-K and/or fused consumer)

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const KArgs a) {
                     if (a.row_bias) v += a.row_bias[(size_t)(row / a.row_bias_div) * a.N + col];
                     if (a.relu) v = fmaxf(v, 0.f);
                     if (a.mul_mask) v *= a.mul_mask[(size_t)row * a.N + col];
-                    if (a.accumulate) v += out[(size_t)row * ldo + col];
+                    if (a.accumulate) v += a.addend[(size_t)row * a.ldc + col];      // (not to_partial: out == C)
                     out[(size_t)row * ldo + col] = v;
                 } else if (a.self_reduce) {
                     // write-through (sc1) slab store: visible to the last-arriving workgroup without a release fence
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const KArgs a) {
             if (a.row_bias) v += a.row_bias[(size_t)(row / a.row_bias_div) * a.N + col];
             if (a.relu) v = fmaxf(v, 0.f);
             if (a.mul_mask) v *= a.mul_mask[(size_t)row * a.N + col];
-            if (a.accumulate) v += a.C[(size_t)row * a.ldc + col];
+            if (a.accumulate) v += a.addend[(size_t)row * a.ldc + col];
             a.C[(size_t)row * a.ldc + col] = v;
         }
     }
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const KArgs a) {
 
 __global__ void splitk_reduce_kernel(const float *__restrict__ partial, int splits, float *__restrict__ C, int ldc,
                                      int M, int N, const float *bias, const float *bias2, const float *row_bias,
-                                     int row_bias_div, const float *mul_mask, int relu, int accumulate) {
+                                     int row_bias_div, const float *mul_mask, int relu, int accumulate,
+                                     const float *__restrict__ addend) {
     const size_t total = (size_t)M * N;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(i / N), col = (int)(i % N);
@@ -301,7 +302,7 @@ __global__ void splitk_reduce_kernel(const float *__restrict__ partial, int spli
         if (relu) v = fmaxf(v, 0.f);
         if (mul_mask) v *= mul_mask[i];
         float *o = C + (size_t)row * ldc + col;
-        if (accumulate) v += *o;
+        if (accumulate) v += addend[(size_t)row * ldc + col];
         *o = v;
     }
 }
@@ -370,17 +371,24 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-extern "C" int capmi_splitk_reduce(const float *partial, int splits, float *C, int ldc, int M, int N,
-                                   const float *bias, const float *bias2, const float *row_bias, int row_bias_div,
-                                   const float *mul_mask, int relu, int accumulate, void *stream) {
+static int splitk_reduce_addend(const float *partial, int splits, float *C, int ldc, int M, int N, const float *bias, const float *bias2,
+                                const float *row_bias, int row_bias_div, const float *mul_mask, int relu, int accumulate,
+                                const float *addend, void *stream) {
     if (!partial || !C || splits < 1 || M <= 0 || N <= 0) return CAPMI_EINVAL;
     const size_t total = (size_t)M * N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, splits, C, ldc, M,
-                       N, bias, bias2, row_bias, row_bias_div > 0 ? row_bias_div : 1, mul_mask, relu, accumulate);
+                       N, bias, bias2, row_bias, row_bias_div > 0 ? row_bias_div : 1, mul_mask, relu, accumulate, addend ? addend : C);
     CAPMI_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int capmi_splitk_reduce(const float *partial, int splits, float *C, int ldc, int M, int N,
+                                   const float *bias, const float *bias2, const float *row_bias, int row_bias_div,
+                                   const float *mul_mask, int relu, int accumulate, void *stream) {
+    return splitk_reduce_addend(partial, splits, C, ldc, M, N, bias, bias2, row_bias, row_bias_div, mul_mask, relu, accumulate, nullptr,
+                                stream);
 }
 
 extern "C" int capmi_splitk_reduce_batch(const capmi_reduce_item *items, int n_items, void *stream) {
@@ -422,6 +430,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     a.bias = d->bias; a.bias2 = d->bias2; a.row_bias = d->row_bias;
     a.row_bias_div = d->row_bias_div > 0 ? d->row_bias_div : 1;
     a.mul_mask = d->mul_mask; a.relu = d->relu; a.accumulate = d->accumulate;
+    a.addend = d->addend ? d->addend : d->C;
     // workspace layout: [CAPMI_WS_COUNTER_FLOATS ints of tile tickets (zero between launches)][K-slice slabs]
     const int64_t slab_cap = d->partial ? d->partial_capacity - CAPMI_WS_COUNTER_FLOATS : 0;
     a.partial = d->partial ? d->partial + CAPMI_WS_COUNTER_FLOATS : nullptr;
@@ -469,8 +478,8 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
                 int rc = launch_lc(a, d->b_layout, st, pcls, bytes, flops);
                 if (rc) return rc;
                 if (splits > 1 && !d->defer_reduce)
-                    return capmi_splitk_reduce(a.partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,
-                                               a.row_bias_div, d->mul_mask, d->relu, d->accumulate, stream);
+                    return splitk_reduce_addend(a.partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,
+                                               a.row_bias_div, d->mul_mask, d->relu, d->accumulate, d->addend, stream);
                 return 0;
             }
         }
@@ -517,8 +526,8 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
             int rc = launch_ares(a, d->b_layout, ts_max, use_x3, st, pcls, bytes, flops);
             if (rc) return rc;
             if (splits > 1 && !d->defer_reduce)
-                return capmi_splitk_reduce(a.partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,
-                                           a.row_bias_div, d->mul_mask, d->relu, d->accumulate, stream);
+                return splitk_reduce_addend(a.partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,
+                                           a.row_bias_div, d->mul_mask, d->relu, d->accumulate, d->addend, stream);
             return 0;
         }
     }
@@ -595,7 +604,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     else rc = launch_cfg<128, 128, 2, 2, 2>(a, d->a_layout, d->b_layout, grid, st, pi);
     if (rc) return rc;
     if (splits > 1 && !d->defer_reduce && !a.self_reduce)
-        return capmi_splitk_reduce(a.partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,
-                                   a.row_bias_div, d->mul_mask, d->relu, d->accumulate, stream);
+        return splitk_reduce_addend(a.partial, splits, d->C, d->ldc, d->M, d->N, d->bias, d->bias2, d->row_bias,
+                                   a.row_bias_div, d->mul_mask, d->relu, d->accumulate, d->addend, stream);
     return 0;
 }

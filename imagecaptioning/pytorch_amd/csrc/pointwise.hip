@@ -456,6 +456,12 @@ __device__ __forceinline__ void colsum_item_body(const capmi_colsum_item &it) {
             if (vec) {
                 const float *p = it.in + col;
                 int r = ry;
+                for (; r + 7 * CS_R < it.rows; r += 8 * CS_R) {          // 8 rows in flight per thread
+                    f32x4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + u * CS_R) * it.ld);
+                    s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                }
                 for (; r + 3 * CS_R < it.rows; r += 4 * CS_R) {
                     const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (size_t)r * it.ld);
                     const f32x4 b = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + CS_R) * it.ld);
@@ -835,7 +841,10 @@ int capmi_colsum(const float *in, int rows, int cols, int ld, float *out, int ac
 
 int capmi_colsum_batch(const capmi_colsum_item *items, int n_items, void *stream) {
     if (!items || n_items <= 0) return CAPMI_EINVAL;
-    hipLaunchKernelGGL(colsum_batch_kernel, dim3(32, n_items), dim3(CS_Q * CS_R), 0, (hipStream_t)stream, items);
+    // the column counts live on the device: 160 column blocks per item cover a vocabulary-wide bias (9 488 columns = 149 blocks) in
+    // one round; workgroups past an item's last block leave at once.  (r4: with 32 the logit bias of a Transformer XE step --
+    // 255 MB -- was walked by 32 workgroups while the chip idled: 520 us for the launch)
+    hipLaunchKernelGGL(colsum_batch_kernel, dim3(160, n_items), dim3(CS_Q * CS_R), 0, (hipStream_t)stream, items);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

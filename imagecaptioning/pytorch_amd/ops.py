@@ -50,10 +50,12 @@ def default_workspace(device):
 
 
 def gemm(segs, M, N, out, ldc=None, a_layout=0, b_layout=0, bias=None, bias2=None, row_bias=None, row_bias_div=1,
-         mul_mask=None, relu=False, accumulate=False, ws=None, splits=0, defer_reduce=False, a_planes=None):
+         mul_mask=None, relu=False, accumulate=False, ws=None, splits=0, defer_reduce=False, a_planes=None, addend=None):
     """segs: list of (A, lda, B, ldb, K, a_row_div) with tensors (or (tensor, element_offset) pairs).
     a_planes: optional list (one uint8 tensor per segment, see planes_from_f32) -- the activations also delivered pre-split,
-    staged by LDS-DMA in the M <= 64 decode kernel.  Returns splits_used."""
+    staged by LDS-DMA in the M <= 64 decode kernel.
+    addend: out = addend + epilogue(...) (a residual stream added without copying it into `out` first; row pitch ldc).
+    Returns splits_used."""
     d = _lib.GemmDesc()
     d.nseg = len(segs)
     if a_planes is not None:
@@ -70,7 +72,8 @@ def gemm(segs, M, N, out, ldc=None, a_layout=0, b_layout=0, bias=None, bias2=Non
     d.bias, d.bias2, d.row_bias = ptr(bias), ptr(bias2), ptr(row_bias)
     d.row_bias_div = row_bias_div
     d.mul_mask = ptr(mul_mask)
-    d.relu, d.accumulate = int(relu), int(accumulate)
+    d.relu, d.accumulate = int(relu), int(accumulate or addend is not None)
+    d.addend = ptr(addend)
     if ws is None:
         ws = default_workspace(_dev(out))
     d.partial, d.partial_capacity = ws.buf.data_ptr(), ws.capacity

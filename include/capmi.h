@@ -49,7 +49,7 @@ const char *capmi_arch(void);            /* "gfx950" */
  *            replaces models/utils.py:3-14 repeat_tensors; a_layout 0 only, >= 1).
  * epilogue (applied when the K reduction is complete):
  *   v = acc + bias[n] + bias2[n] + row_bias[(m / row_bias_div) * N + n]
- *   if relu: v = max(v, 0);  if mul_mask: v *= mul_mask[m * N + n];  if accumulate: v += C[m*ldc+n]
+ *   if relu: v = max(v, 0);  if mul_mask: v *= mul_mask[m * N + n];  if accumulate: v += (addend ? addend : C)[m*ldc+n]
  * split-K: splits > 1 writes raw K-slice sums to the workspace `partial` (layout: see
  *   CAPMI_WS_COUNTER_FLOATS; slabs are [splits][M][N]).  Unless defer_reduce, the slices are combined
  *   and the epilogue applied INSIDE the launch by the last-arriving workgroup of each tile (skinny
@@ -89,6 +89,10 @@ typedef struct capmi_gemm_desc {
      * capmi_planes_from_f32); with planes for every segment the loader / consumer kernel stages them by LDS-DMA instead of
      * splitting them inside every workgroup.  Same result bit for bit. */
     const void *a_planes[CAPMI_MAX_SEG];
+    /* optional, with accumulate: v += addend[m*ldc+n] instead of C's previous content -- a residual stream that has to stay
+     * intact for the backward (x + sublayer(norm(x)), TransformerModel.py:99-102) is added in the epilogue without a copy of it
+     * into C first.  Same row pitch as C; may not overlap C. */
+    const float *addend;
 } capmi_gemm_desc;
 
 int capmi_gemm_f32(capmi_gemm_desc *d, void *stream);

@@ -1,8 +1,5 @@
-export CAPMI_LIB=$PWD/variants/libcapmi.so PYTHONPATH=$PWD
-python scripts/mha_ablate.py 0 2>&1 | grep "^abl" > gpurun_out/mha_ablate8.log
-unset CAPMI_LIB
-python -m pytest tests/test_full_size_parity_gpu.py tests/test_model_api_gpu.py tests/test_kernels_gpu.py -q -x 2>&1 | tail -3 >> gpurun_out/mha_ablate8.log
+python -m pytest tests/test_kernels_gpu.py tests/test_full_size_parity_gpu.py tests/test_model_api_gpu.py -q -x 2>&1 | tail -4 > gpurun_out/add_t.log
 bash scripts/prof_config.sh mh_txe transformer_xe > /dev/null 2>&1
-bash scripts/prof_config.sh mh_aoa aoa_nsc > /dev/null 2>&1
-rm -rf gpurun_out/prof_mh_txe gpurun_out/prof_mh_aoa
-cat gpurun_out/mha_ablate8.log; head -22 gpurun_out/mh_txe_kernel_stats.md | cut -c1-150;  head -24 gpurun_out/mh_aoa_kernel_stats.md | cut -c1-150
+bash scripts/prof_config.sh mh_uxe updown_xe > /dev/null 2>&1
+rm -rf gpurun_out/prof_mh_txe gpurun_out/prof_mh_uxe
+cat gpurun_out/add_t.log; head -14 gpurun_out/mh_txe_kernel_stats.md | cut -c1-150; grep -o '"ms_per_step": [0-9.]*' gpurun_out/prof_mh_txe.log | head -1;  head -14 gpurun_out/mh_uxe_kernel_stats.md | cut -c1-150; grep -o '"ms_per_step": [0-9.]*' gpurun_out/prof_mh_uxe.log | head -1

@@ -38,6 +38,30 @@ def test_gemm_nt_linear(dev, M, N, K):
     assert rel_err(out, ref) < (2e-6 if K <= 4096 else 6e-6)
 
 
+@pytest.mark.parametrize('M,N,K,splits', [(2304, 512, 2048, 0), (6720, 512, 512, 0), (50, 1000, 1000, 0), (50, 1000, 3000, 6), (300, 260, 4096, 4),
+                                          (33, 70, 50, 0)])
+def test_gemm_addend_adds_a_residual_without_touching_it(dev, M, N, K, splits):
+    """capmi_gemm_desc.addend (x + sublayer(norm(x)), TransformerModel.py:99-102): out = addend + relu(A W^T + b) * mask must be
+    bit-identical to the copy-then-accumulate form on every GEMM path (fat bf16x3, decode, split-K + reduce), and must leave the
+    residual as it was"""
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    mask = ((torch.rand(M, N, generator=g) < 0.5).float() * 2).to(dev)
+    keep = res.clone()
+    want = res.clone()
+    ops.gemm([(x, K, w, K, K, 1)], M, N, want, bias=b, relu=True, mul_mask=mask, accumulate=True, splits=splits)
+    out = torch.full((M, N), float('nan'), device=dev)
+    ops.gemm([(x, K, w, K, K, 1)], M, N, out, bias=b, relu=True, mul_mask=mask, addend=res, splits=splits)
+    assert torch.equal(out, want)
+    assert torch.equal(res, keep)
+    ref = keep.double() + torch.relu(x.double() @ w.double().t() + b.double()) * mask.double()
+    assert rel_err(out, ref) < 3e-6
+
+
 @pytest.mark.parametrize('M,N,K,al,bl', [(4000, 1000, 1200, 1, 1), (1200, 1000, 4000, 0, 1), (512, 768, 4096, 0, 0),
                                         (520, 260, 1028, 1, 0)])
 def test_gemm_fat_bf16x3_is_fp32_grade(dev, M, N, K, al, bl):
