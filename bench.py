@@ -423,16 +423,31 @@ def main():
         sampled = {args.steps // 3, (2 * args.steps) // 3}
     else:
         sampled = {args.steps // 2}
+    host_prof = None
+    if os.environ.get('CAPMI_BENCH_CPROFILE'):      # where the HOST spends the timed steps (scripts/prof_host_top.py); perturbs the timing
+        import cProfile
+        host_prof = cProfile.Profile()
     sync()
     t0 = time.perf_counter()
+    if host_prof is not None:
+        host_prof.enable()
     for i in range(args.steps):
         if i in sampled:
             lib.capmi_prof_enable(prof_mask)
         loss = step()
         if i in sampled:
             lib.capmi_prof_enable(0)
+    if host_prof is not None:
+        host_prof.disable()
     sync()
     dt = time.perf_counter() - t0
+    if host_prof is not None and rank == 0:
+        import io
+        import pstats
+        for key in ('tottime', 'cumulative'):
+            buf = io.StringIO()
+            pstats.Stats(host_prof, stream=buf).sort_stats(key).print_stats(30)
+            print('\n'.join(l[:160] for l in buf.getvalue().split('\n') if l.strip()), file=sys.stderr)
     lib.capmi_prof_enable(0)
     n_sampled = max(1, len(sampled))
     allreduce_ms = None

@@ -109,7 +109,7 @@ class AoAModel(CaptionModel):
 
     @property
     def _param_names(self):
-        return [n for n, _ in self.named_parameters()]
+        return self._param_name_list()
 
     def _flat_groups(self):
         """Wq | Wk | Wv (and biases) of every refiner layer back to back in the flat buffers: one fused projection GEMM each"""
@@ -132,7 +132,7 @@ class AoAModel(CaptionModel):
         if att_masks is not None and not clipped:
             ml = clip_len(att_masks)
             att_feats, att_masks = att_feats[:, :ml], att_masks[:, :ml].float().contiguous()
-        params = [p for _, p in self.named_parameters()]
+        params = self._param_list()
         from imagecaptioning.pytorch_amd import sparse_logp
         cfg = dict(cfg)
         cfg['_sink'] = sink = sparse_logp.LogpSink()
@@ -161,7 +161,7 @@ class AoAModel(CaptionModel):
                 ml = clip_len(att_masks)
                 att_feats, att_masks = att_feats[:, :ml], att_masks[:, :ml].float().contiguous()
             with torch.no_grad():
-                P = dict(zip(self._param_names, [p.detach() for _, p in self.named_parameters()]))
+                P = dict(zip(self._param_names, [p.detach() for p in self._param_list()]))
                 return engine.sample_beam(self, P, att_feats.float().contiguous(), att_masks, self.num_heads, self.seq_length, opt)
         from .utils import parse_sample_method
         from imagecaptioning.pytorch_amd import decode
@@ -171,7 +171,7 @@ class AoAModel(CaptionModel):
             if att_masks is not None:
                 ml = clip_len(att_masks)
                 att_feats, att_masks = att_feats[:, :ml], att_masks[:, :ml].float().contiguous()
-            P = dict(zip(self._param_names, [p.detach() for _, p in self.named_parameters()]))
+            P = dict(zip(self._param_names, [p.detach() for p in self._param_list()]))
 
             def make(rows):
                 g = engine.AoAGraph(P, {}, self.num_heads, 0.0, 0.0, False, 0)

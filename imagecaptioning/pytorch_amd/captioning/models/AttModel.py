@@ -173,7 +173,7 @@ class AttModel(CaptionModel):
     # ------------------------------------------------------------------ parameter plumbing
     @property
     def _param_names(self):
-        return [n for n, _ in self.named_parameters()]
+        return self._param_name_list()
 
     def flatten_parameters_(self):
         """Move all parameters into one flat buffer (+ flat grads, Adam state).  Call after .cuda()."""
@@ -215,7 +215,7 @@ class AttModel(CaptionModel):
 
     def _run(self, cfg, fc_feats, att_feats, att_masks):
         self._device_check(fc_feats)
-        params = [p for _, p in self.named_parameters()]
+        params = self._param_list()
         fc_feats = fc_feats.float().contiguous()
         att_feats = att_feats.float().contiguous()
         if att_masks is not None:
@@ -227,7 +227,7 @@ class AttModel(CaptionModel):
     # ------------------------------------------------------------------ reference API
     def _prepare_feature(self, fc_feats, att_feats, att_masks):
         """AttModel.py:114-124 (eval-mode numerics; training dropout is applied inside the rollouts)."""
-        P = {k: v.detach() for k, v in self.named_parameters()}
+        P = {k: v.detach() for k, v in self._named_param_list()}
         pr = engine.prepare(P, fc_feats.float().contiguous(), att_feats.float().contiguous(),
                             None if att_masks is None else att_masks.float())
         return pr.fc, pr.att, pr.p_att, pr.att_masks
@@ -277,7 +277,7 @@ class AttModel(CaptionModel):
             # _diverse_sample (AttModel.py:270-271) / decoding constraints (:293-330): host-stepped, same kernels
             def make(rows):
                 from imagecaptioning.pytorch_amd.step import UpDownStepper
-                P = {k: v.detach() for k, v in self.named_parameters()}
+                P = {k: v.detach() for k, v in self._named_param_list()}
                 pr = engine.prepare(P, fc_feats.float().contiguous(), att_feats.float().contiguous(),
                                     None if att_masks is None else att_masks.float())
                 return UpDownStepper(P, pr, rows)

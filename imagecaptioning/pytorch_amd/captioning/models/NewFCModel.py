@@ -68,7 +68,7 @@ class NewFCModel(CaptionModel):
 
     @property
     def _param_names(self):
-        return [n for n, _ in self.named_parameters()]
+        return self._param_name_list()
 
     def flatten_parameters_(self):
         from imagecaptioning.pytorch_amd.flat import FlatParams
@@ -86,7 +86,7 @@ class NewFCModel(CaptionModel):
         if self.training and self.drop_prob_lm > 0:
             cfg['drop_out'] = ops.dropout_mask((T, N, self.rnn_size), self.drop_prob_lm, self._next_seed(), 0,
                                                fc_feats.device)
-        params = [p for _, p in self.named_parameters()]
+        params = self._param_list()
         cfg['_sink'] = sink = sparse_logp.LogpSink()
         seq, logp = _RolloutFn.apply(self, cfg, fc_feats.float().contiguous(), *params)
         return seq, sparse_logp.attach(logp, sink)
@@ -111,7 +111,7 @@ class NewFCModel(CaptionModel):
         from imagecaptioning.pytorch_amd.step import NewFCStepper
         if not fc_feats.is_cuda:
             raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
-        P = dict(zip(self._param_names, [p.detach() for _, p in self.named_parameters()]))
+        P = dict(zip(self._param_names, [p.detach() for p in self._param_list()]))
         if opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search'):
             # AttModel._sample_beam on the single-step decoder (the image step is taken once per image, AttModel.py:925-927)
             with torch.no_grad():

@@ -156,7 +156,7 @@ class TransformerModel(CaptionModel):
     # ---- plumbing
     @property
     def _param_names(self):
-        return [n for n, _ in self.named_parameters()]
+        return self._param_name_list()
 
     def _pdict(self, params):
         P = dict(zip(self._param_names, [p.detach() for p in params]))
@@ -213,7 +213,7 @@ class TransformerModel(CaptionModel):
         seq = seq.long().contiguous()
         att_feats, att_masks = self._clip(att_feats, att_masks)
         n = seq.shape[0] // att_feats.shape[0]
-        params = [p for _, p in self.named_parameters()]
+        params = self._param_list()
         from imagecaptioning.pytorch_amd import sparse_logp
         sink = sparse_logp.LogpSink()
         return sparse_logp.attach(_Fn.apply(self, att_feats, att_masks, seq, n, sink, *params), sink)
@@ -233,13 +233,13 @@ class TransformerModel(CaptionModel):
         if opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search'):
             att_feats, att_masks = self._clip(att_feats, att_masks)
             with torch.no_grad():
-                P = self._pdict([p for _, p in self.named_parameters()])
+                P = self._pdict(self._param_list())
                 return engine.sample_beam(self, P, att_feats, att_masks, self.h, self.N_enc, self.N_dec, self.seq_length, opt)
         from .utils import parse_sample_method
         from imagecaptioning.pytorch_amd import decode
         if decode.wants_options(opt):
             att_feats, att_masks = self._clip(att_feats, att_masks)
-            P = self._pdict([p for _, p in self.named_parameters()])
+            P = self._pdict(self._param_list())
             return self._sample_with_options(
                 lambda rows: engine.Decoder(P, att_feats, att_masks, self.h, self.N_enc, self.N_dec, self.seq_length, rows),
                 att_feats.size(0), opt)
@@ -252,7 +252,7 @@ class TransformerModel(CaptionModel):
             drop_seed = self._next_seed()
             drop = (self.drop_prob_lm, self.dropout, drop_seed)
         with torch.no_grad():
-            P = self._pdict([p for _, p in self.named_parameters()])
+            P = self._pdict(self._param_list())
             if mode == 'greedy' and opt.get('_graph', True) and not self.training:
                 # deterministic and launch-bound on the host (~1300 launches): replay a captured hipGraph
                 if not hasattr(self, '_graphs'):

@@ -1,16 +1,12 @@
 #!/usr/bin/env python3
-"""cProfile of bench.py --config <cfg>: the functions the HOST spends its time in while issuing a step (cumulative and own time)"""
-import cProfile, pstats, sys, io
+"""cProfile of the TIMED steps of bench.py --config <cfg> (CAPMI_BENCH_CPROFILE): the functions the host spends its time in while
+issuing a step, by own and by cumulative time.    python scripts/prof_host_top.py [config] [steps]"""
+import os
+import subprocess
+import sys
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'aoa_nsc'
-sys.argv = ['bench.py', '--config', cfg, '--steps', '30', '--warmup', '2', '--no-cpu-baseline', '--no-prof', '--brief']
-pr = cProfile.Profile()
-pr.enable()
-try:
-    exec(compile(open('bench.py').read(), 'bench.py', 'exec'), {'__name__': '__main__', '__file__': 'bench.py'})
-except SystemExit:
-    pass
-pr.disable()
-for key in ('tottime', 'cumulative'):
-    s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(28)
-    print('\n'.join(l[:150] for l in s.getvalue().split('\n') if l.strip())[:5500])
+steps = sys.argv[2] if len(sys.argv) > 2 else '20'
+env = dict(os.environ, CAPMI_BENCH_CPROFILE='1')
+r = subprocess.run([sys.executable, 'bench.py', '--config', cfg, '--steps', steps, '--warmup', '2', '--no-cpu-baseline', '--no-prof', '--brief'],
+                   env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+print('\n'.join(l for l in r.stderr.split('\n') if 'amdgpu.ids' not in l))
