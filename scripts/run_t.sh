@@ -1,9 +1,7 @@
-python -m pytest tests -m gpu -q -x 2>&1 | tail -3 > gpurun_out/full_t.log
-python bench.py > gpurun_out/bench_f.json 2> gpurun_out/bench_f.err
-cat gpurun_out/full_t.log
-python - <<'PY'
-import json
-d=json.loads([l for l in open('gpurun_out/bench_f.json') if l.startswith('{')][-1])
-print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['avg_launch_us'])
-for k,v in d['other_configs'].items(): print(k, v.get('ms_per_step'), v.get('captions_per_s'), v.get('error'))
-PY
+cd /tmp && export TMPDIR=/tmp
+out=$GRAFT_REPO_ROOT/gpurun_out/prof_g; rm -rf $out
+rocprofv3 --kernel-trace --stats -d $out -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-prof --no-other-configs > /dev/null 2>&1
+db=$(find $out -name "*.db" | head -1)
+python $GRAFT_REPO_ROOT/scripts/prof_gaps.py $db 3 30 > $GRAFT_REPO_ROOT/gpurun_out/gaps_scst.log
+rm -rf $out
+cd $GRAFT_REPO_ROOT; cat gpurun_out/gaps_scst.log

@@ -361,6 +361,13 @@ def test_deferred_grads_batched_reduce_and_colsum(dev):
     (4, 5, 1, 36, 8, 128, 'per_kv', 0, False),     # AoA decode step: one query per caption
     (2, 6, 21, 36, 2, 64, None, 0, True),          # 126 query rows per workgroup: more than one LDS pass (chunking)
     (2, 1, 7, 7, 4, 16, None, 1, False),           # causal flag instead of a mask tensor
+    # r4 launch shapes (transformer.hip mha_threads / mha_chunk / mha_on_mfma): the cases above are all small grids (8-16 waves)
+    (2, 1, 40, 70, 2, 32, 'per_kv', 0, True),      # more than 64 keys: the wave-per-row softmax, MFMA contractions with K = 70
+    (1, 8, 40, 36, 2, 128, 'per_kv', 0, True),     # 320 query rows x dk 128: forward AND backward in several LDS passes of whole tiles
+    (40, 1, 21, 21, 8, 16, 'per_q', 1, True),      # 320 workgroups: 4 waves, one 16-row tile and a 5-row remainder
+    (40, 5, 21, 36, 8, 16, 'per_kv', 0, True),     # 320 workgroups of 105 x 36 scores: 8 waves
+    (64, 5, 1, 36, 8, 32, 'per_kv', 0, False),     # 512 workgroups of 5 rows: the vector loops
+    (3, 2, 9, 11, 2, 24, None, 1, True),           # head size 24: 6 float4 per row (no power-of-two shift), 18 rows
 ])
 def test_mha_fwd_bwd_matches_torch(dev, Nkv, q_per_kv, Tq, Tk, h, dk, mask_mode, causal, use_drop):
     """capmi_mha_fwd/bwd (MultiHeadedAttention, TransformerModel.py:152-195) vs a float64 torch restatement, all layouts the
