@@ -679,6 +679,36 @@ __global__ __launch_bounds__(1024) void log_softmax_rows_kernel(const float *__r
     const float lse = m + __logf(s);
     for (int v = threadIdx.x; v < V1; v += blockDim.x) out[r * V1 + v] = x[v] - lse;
 }
+// the same with the row in registers (V1 <= 1024 NE): one read of the logits, all of a thread's loads in flight at once; element
+// assignment and summation order as above (bit-identical).  r4: the three-pass form above ran at 2.4 TB/s on [6 720, 9 488].
+template <int NE>
+__global__ __launch_bounds__(1024) void log_softmax_rows_reg_kernel(const float *__restrict__ logits, float *__restrict__ out,
+                                                                    int V1) {
+    __shared__ float s_f[32];
+    const size_t r = blockIdx.x;
+    const float *x = logits + r * V1;
+    float xv[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int v = threadIdx.x + 1024 * i;
+        xv[i] = v < V1 ? x[v] : -INFINITY;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) m = fmaxf(m, xv[i]);
+    m = block_max(m, s_f);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+        if (threadIdx.x + 1024 * i < V1) s += __expf(xv[i] - m);
+    s = block_sum(s, s_f);
+    const float lse = m + __logf(s);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int v = threadIdx.x + 1024 * i;
+        if (v < V1) out[r * V1 + v] = xv[i] - lse;
+    }
+}
 
 __global__ void glu_fwd_kernel(const float *__restrict__ pre, const float *__restrict__ mask,
                                const float *__restrict__ residual, float *__restrict__ out, int M, int R) {
@@ -975,7 +1005,12 @@ int capmi_meanpool_bwd(const float *dmean, const float *mask, float *dx, int acc
 
 int capmi_log_softmax_rows(const float *logits, float *out, int rows, int V1, void *stream) {
     if (!logits || !out || rows <= 0 || V1 <= 0) return CAPMI_EINVAL;
-    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, out, V1);
+    if (V1 <= 10 * 1024)
+        hipLaunchKernelGGL(log_softmax_rows_reg_kernel<10>, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, out, V1);
+    else if (V1 <= 16 * 1024)
+        hipLaunchKernelGGL(log_softmax_rows_reg_kernel<16>, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, out, V1);
+    else
+        hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, logits, out, V1);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

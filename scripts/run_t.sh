@@ -1,7 +1,4 @@
-cd /tmp && export TMPDIR=/tmp
-out=$GRAFT_REPO_ROOT/gpurun_out/prof_g; rm -rf $out
-rocprofv3 --kernel-trace --stats -d $out -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-prof --no-other-configs > /dev/null 2>&1
-db=$(find $out -name "*.db" | head -1)
-python $GRAFT_REPO_ROOT/scripts/prof_gaps.py $db 3 30 > $GRAFT_REPO_ROOT/gpurun_out/gaps_scst.log
-rm -rf $out
-cd $GRAFT_REPO_ROOT; cat gpurun_out/gaps_scst.log
+python -m pytest tests/test_kernels_gpu.py tests/test_full_size_parity_gpu.py tests/test_model_api_gpu.py -q -x 2>&1 | tail -3 > gpurun_out/add_t.log
+bash scripts/prof_config.sh mh_txe transformer_xe > /dev/null 2>&1
+rm -rf gpurun_out/prof_mh_txe
+cat gpurun_out/add_t.log; grep -E "log_softmax|kernel time" gpurun_out/mh_txe_kernel_stats.md | cut -c1-150

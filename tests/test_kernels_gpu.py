@@ -412,3 +412,16 @@ def test_mha_fwd_bwd_matches_torch(dev, Nkv, q_per_kv, Tq, Tk, h, dk, mask_mode,
     assert rel_err(dq.cpu().double(), qd.grad) < 5e-6
     assert rel_err(dk_.cpu().double(), kd.grad) < 5e-6
     assert rel_err(dv2.cpu().double(), vd.grad) < 5e-6
+
+
+@pytest.mark.parametrize('rows,V1', [(7, 31), (50, 9488), (3, 1024), (5, 10241), (2, 16385), (4, 20000)])
+def test_log_softmax_rows(dev, rows, V1):
+    """capmi_log_softmax_rows (Generator, TransformerModel.py:47-48) vs float64 torch: the register-resident kernels (V1 <= 10 240,
+    <= 16 384) and the three-pass one behind them"""
+    from imagecaptioning.pytorch_amd._lib import lib, check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(rows + V1)
+    x = (torch.randn(rows, V1, generator=g) * 4).to(dev)
+    out = torch.empty_like(x)
+    check(lib.capmi_log_softmax_rows(ptr(x), ptr(out), rows, V1, stream_ptr()), 'capmi_log_softmax_rows')
+    want = torch.log_softmax(x.double().cpu(), -1)
+    assert float((out.double().cpu() - want).abs().max()) < 1e-5          # values around -20: a few fp32 ulps
