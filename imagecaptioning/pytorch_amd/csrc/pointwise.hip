@@ -361,9 +361,17 @@ __global__ void dropout_masks_kernel(const MaskSegs sg, float p, uint64_t seed) 
         const size_t count = sg.count[i], quads = (count + 3) / 4;
         float *mask = sg.mask[i];
         const int row_len = sg.row_len[i], rows = sg.rows[i], keep_from = sg.keep_from[i];
+        const bool vec = keep_from >= rows && (reinterpret_cast<uintptr_t>(mask) & 15) == 0;      // no eval-mode rows, aligned
         for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (size_t)gridDim.x * blockDim.x) {
             uint32_t o[4];
             rng.gen(sg.offset[i] + q, 0x6d61736bULL, o);
+            if (vec && q * 4 + 3 < count) {       // one 16-byte store (r4: four 4-byte stores 16 bytes apart ran at 2.4 TB/s)
+                f32x4 v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = (u01(o[k]) < p) ? 0.f : scale;
+                *reinterpret_cast<f32x4 *>(mask + q * 4) = v;
+                continue;
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const size_t e = q * 4 + k;
@@ -443,35 +451,38 @@ __global__ __launch_bounds__(CS_Q * CS_R) void colsum_kernel(const float *__rest
 }
 
 // Many column sums in one launch (all bias gradients of a backward): blockIdx.y = item, blockIdx.x walks the item's
-// 64-column blocks; every block sums ALL rows of its columns (deterministic, no atomics, no zero-fill launch).
+// 64-column blocks; every block sums ALL rows of its columns (deterministic, no atomics, no zero-fill launch).  1024 threads =
+// 16 column quads x 64 row slices.  (r4: 2.7 TB/s on the Transformer step's 1.5 GB; 128-column blocks -- 512-byte row segments, half
+// the workgroups -- were measured and are SLOWER, 790 vs 550 us: the launch lives on the number of CUs that have a block to walk.)
+constexpr int CB_Q = 16, CB_R = 64;
 __device__ __forceinline__ void colsum_item_body(const capmi_colsum_item &it) {
-    __shared__ f32x4 red[CS_R][CS_Q];
-    const int cq = threadIdx.x % CS_Q, ry = threadIdx.x / CS_Q;
-    const int cblocks = (it.cols + 4 * CS_Q - 1) / (4 * CS_Q);
+    __shared__ f32x4 red[CB_R][CB_Q];
+    const int cq = threadIdx.x % CB_Q, ry = threadIdx.x / CB_Q;
+    const int cblocks = (it.cols + 4 * CB_Q - 1) / (4 * CB_Q);
     const bool vec = (reinterpret_cast<uintptr_t>(it.in) & 15) == 0 && it.ld % 4 == 0 && it.cols % 4 == 0;
     for (int cb = blockIdx.x; cb < cblocks; cb += gridDim.x) {
-        const int col = (cb * CS_Q + cq) * 4;
+        const int col = (cb * CB_Q + cq) * 4;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         if (col < it.cols) {
             if (vec) {
                 const float *p = it.in + col;
                 int r = ry;
-                for (; r + 7 * CS_R < it.rows; r += 8 * CS_R) {          // 8 rows in flight per thread
+                for (; r + 7 * CB_R < it.rows; r += 8 * CB_R) {          // 8 rows in flight per thread
                     f32x4 v[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + u * CS_R) * it.ld);
+                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + u * CB_R) * it.ld);
                     s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                 }
-                for (; r + 3 * CS_R < it.rows; r += 4 * CS_R) {
+                for (; r + 3 * CB_R < it.rows; r += 4 * CB_R) {
                     const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (size_t)r * it.ld);
-                    const f32x4 b = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + CS_R) * it.ld);
-                    const f32x4 c = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + 2 * CS_R) * it.ld);
-                    const f32x4 d = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + 3 * CS_R) * it.ld);
+                    const f32x4 b = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + CB_R) * it.ld);
+                    const f32x4 c = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + 2 * CB_R) * it.ld);
+                    const f32x4 d = *reinterpret_cast<const f32x4 *>(p + (size_t)(r + 3 * CB_R) * it.ld);
                     s += (a + b) + (c + d);
                 }
-                for (; r < it.rows; r += CS_R) s += *reinterpret_cast<const f32x4 *>(p + (size_t)r * it.ld);
+                for (; r < it.rows; r += CB_R) s += *reinterpret_cast<const f32x4 *>(p + (size_t)r * it.ld);
             } else {
-                for (int r = ry; r < it.rows; r += CS_R)
+                for (int r = ry; r < it.rows; r += CB_R)
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (col + k < it.cols) s[k] += it.in[(size_t)r * it.ld + col + k];
@@ -479,7 +490,7 @@ __device__ __forceinline__ void colsum_item_body(const capmi_colsum_item &it) {
         }
         red[ry][cq] = s;
         __syncthreads();
-        if (ry < 4) {
+        if (ry < CB_R / 16) {
             f32x4 t = red[ry * 16][cq];
 #pragma unroll
             for (int k = 1; k < 16; ++k) t += red[ry * 16 + k][cq];
@@ -487,6 +498,7 @@ __device__ __forceinline__ void colsum_item_body(const capmi_colsum_item &it) {
         }
         __syncthreads();
         if (ry == 0 && col < it.cols) {
+            static_assert(CB_R == 64, "four folded groups");
             const f32x4 t = (red[0][cq] + red[16][cq]) + (red[32][cq] + red[48][cq]);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -499,13 +511,13 @@ __device__ __forceinline__ void colsum_item_body(const capmi_colsum_item &it) {
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(CS_Q * CS_R) void colsum_batch_kernel(const capmi_colsum_item *__restrict__ items) {
+__global__ __launch_bounds__(CB_Q * CB_R) void colsum_batch_kernel(const capmi_colsum_item *__restrict__ items) {
     colsum_item_body(items[blockIdx.y]);
 }
 struct ColsumArgs {
     capmi_colsum_item items[CAPMI_COLSUM_ARGS_MAX];
 };
-__global__ __launch_bounds__(CS_Q * CS_R) void colsum_batch_args_kernel(const ColsumArgs a) {
+__global__ __launch_bounds__(CB_Q * CB_R) void colsum_batch_args_kernel(const ColsumArgs a) {
     // (static indices: a dynamically indexed kernel-argument array would be copied to scratch)
     capmi_colsum_item it = a.items[0];
 #pragma unroll
@@ -844,7 +856,7 @@ int capmi_colsum_batch(const capmi_colsum_item *items, int n_items, void *stream
     // the column counts live on the device: 160 column blocks per item cover a vocabulary-wide bias (9 488 columns = 149 blocks) in
     // one round; workgroups past an item's last block leave at once.  (r4: with 32 the logit bias of a Transformer XE step --
     // 255 MB -- was walked by 32 workgroups while the chip idled: 520 us for the launch)
-    hipLaunchKernelGGL(colsum_batch_kernel, dim3(160, n_items), dim3(CS_Q * CS_R), 0, (hipStream_t)stream, items);
+    hipLaunchKernelGGL(colsum_batch_kernel, dim3(160, n_items), dim3(CB_Q * CB_R), 0, (hipStream_t)stream, items);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -856,10 +868,10 @@ int capmi_colsum_batch_args(const capmi_colsum_item *host_items, int n_items, vo
     for (int i = 0; i < n_items; ++i) {
         a.items[i] = host_items[i];
         if (!a.items[i].in || !a.items[i].out || a.items[i].rows <= 0 || a.items[i].cols <= 0) return CAPMI_EINVAL;
-        const int cb = (a.items[i].cols + 4 * CS_Q - 1) / (4 * CS_Q);
+        const int cb = (a.items[i].cols + 4 * CB_Q - 1) / (4 * CB_Q);
         if (cb > max_cb) max_cb = cb;
     }
-    hipLaunchKernelGGL(colsum_batch_args_kernel, dim3(max_cb < 64 ? max_cb : 64, n_items), dim3(CS_Q * CS_R), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(colsum_batch_args_kernel, dim3(max_cb < 64 ? max_cb : 64, n_items), dim3(CB_Q * CB_R), 0, (hipStream_t)stream, a);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
