@@ -821,37 +821,53 @@ __global__ __launch_bounds__(DATT_T) void attn_datt_kernel(const float *__restri
 // d_w: alpha_net weight gradient, summed over every (image, region) workgroup.  dw_part ([B*K, A], optional): each workgroup
 // writes its own row there and the caller column-sums it -- 184 000 atomicAdds on 512 addresses (360 per address, serialised
 // in L2) were most of this kernel's 52 us.
+template <int KB>
 __global__ void attn_dpatt_kernel(const float *__restrict__ att_h_all, const float *__restrict__ d_e_all,
                                   const float *__restrict__ p_att, const float *__restrict__ w,
                                   float *__restrict__ d_p_att, float *__restrict__ d_w, float *__restrict__ dw_part, int T, int N,
                                   int n, int K, int A) {
-    // grid (B*K); threads over a.  The T*n rows of an image are walked 8 at a time: the 16 loads of a group are issued before the
-    // first tanh (one memory round trip per 8 rows instead of one per row: 51 -> 15 us at T*n = 100), the sums keep their order.
-    const int b = blockIdx.x / K, k = blockIdx.x % K;
+    // grid (B * ceil(K / KB)); threads over a; a workgroup serves KB regions of its image.  The T*n rows of an image are walked 8 at a
+    // time: the loads of a group are issued before the first tanh (one memory round trip per 8 rows instead of one per row: 51 ->
+    // 15 us at T*n = 100), the sums keep their order.  KB = 4 (r4) when the grid stays above two workgroups per CU: every region's
+    // workgroup re-read the image's att_h rows -- 36 x 13.8 MB through L2 at the XE batch, 176 us.
+    const int kblocks = (K + KB - 1) / KB;
+    const int b = blockIdx.x / kblocks, k0 = (blockIdx.x % kblocks) * KB;
     const int total = T * n;
     for (int a = threadIdx.x; a < A; a += blockDim.x) {
-        const float p = p_att[((size_t)b * K + k) * A + a];
-        float acc = 0.f, accw = 0.f;
+        float p[KB], acc[KB], accw[KB];
+#pragma unroll
+        for (int q = 0; q < KB; ++q) {
+            p[q] = p_att[((size_t)b * K + min(k0 + q, K - 1)) * A + a];
+            acc[q] = accw[q] = 0.f;
+        }
         for (int i0 = 0; i0 < total; i0 += 8) {
-            float de[8], ah[8];
+            float de[8][KB], ah[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = min(i0 + u, total - 1);
                 const size_t row = (size_t)(i / n) * N + b * n + (i % n);
-                de[u] = d_e_all[row * K + k];
+#pragma unroll
+                for (int q = 0; q < KB; ++q) de[u][q] = d_e_all[row * K + min(k0 + q, K - 1)];
                 ah[u] = att_h_all[row * A + a];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (i0 + u < total) {
-                    const float th = tanh_f(p + ah[u]);
-                    acc += de[u] * (1.f - th * th);
-                    accw += de[u] * th;
+#pragma unroll
+                    for (int q = 0; q < KB; ++q) {
+                        const float th = tanh_f(p[q] + ah[u]);
+                        acc[q] += de[u][q] * (1.f - th * th);
+                        accw[q] += de[u][q] * th;
+                    }
                 }
         }
-        d_p_att[((size_t)b * K + k) * A + a] = w[a] * acc;
-        if (dw_part) dw_part[(size_t)blockIdx.x * A + a] = accw;
-        else atomicAdd(&d_w[a], accw);
+#pragma unroll
+        for (int q = 0; q < KB; ++q) {
+            if (k0 + q >= K) break;
+            d_p_att[((size_t)b * K + k0 + q) * A + a] = w[a] * acc[q];
+            if (dw_part) dw_part[((size_t)b * K + k0 + q) * A + a] = accw[q];
+            else atomicAdd(&d_w[a], accw[q]);
+        }
     }
 }
 
@@ -1046,8 +1062,12 @@ int capmi_attention_bwd_batched_ws(const float *d_ctx_all, int ld_dctx, const fl
         hipError_t e = hipMemsetAsync(d_w, 0, (size_t)A * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(attn_dpatt_kernel, dim3(B * K), dim3(A >= 512 ? 512 : 256), 0, st, att_h_all, d_e_all, p_att, w,
-                       d_p_att, d_w, dw_partial, T, N, n, K, A);
+    if ((B * ((K + 3) / 4)) >= 512)
+        hipLaunchKernelGGL(attn_dpatt_kernel<4>, dim3(B * ((K + 3) / 4)), dim3(A >= 512 ? 512 : 256), 0, st, att_h_all, d_e_all, p_att, w,
+                           d_p_att, d_w, dw_partial, T, N, n, K, A);
+    else
+        hipLaunchKernelGGL(attn_dpatt_kernel<1>, dim3(B * K), dim3(A >= 512 ? 512 : 256), 0, st, att_h_all, d_e_all, p_att, w,
+                           d_p_att, d_w, dw_partial, T, N, n, K, A);
     CAPMI_CHECK_LAUNCH();
     hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(1024), 0, st, d_e_all, (size_t)T * N * K, d_b);
     CAPMI_CHECK_LAUNCH();
