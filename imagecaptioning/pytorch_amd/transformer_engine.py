@@ -120,7 +120,7 @@ class Lin:
             fresh = True
         d = Lin.deferred
         if d is not None:
-            d.dw(dy, self.x, self.grads[self.wn])
+            d.dw(dy, self.x, self.grads[self.wn], final=fresh)
             if fresh:
                 d.colsum(dy, self.grads[self.bn])
             else:

@@ -1,4 +1,5 @@
-python -m pytest tests/test_kernels_gpu.py tests/test_full_size_parity_gpu.py tests/test_updown_gpu.py -q -x 2>&1 | tail -3 > gpurun_out/add_t.log
-bash scripts/prof_config.sh mh_uxe updown_xe > /dev/null 2>&1
-rm -rf gpurun_out/prof_mh_uxe
-cat gpurun_out/add_t.log; grep -E "dpatt|colsum|kernel time" gpurun_out/mh_uxe_kernel_stats.md | cut -c1-150
+for rep in 1 2; do for v in 12 100000; do
+echo "DW_BATCH=$v transformer_xe $(CAPMI_DW_BATCH=$v python bench.py --config transformer_xe --steps 12 --warmup 3 --no-cpu-baseline --no-prof --brief 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1)" >> gpurun_out/dws.log
+done; done
+python -m pytest tests/test_kernels_gpu.py -q -x -k deferred 2>&1 | tail -2 >> gpurun_out/dws.log
+cat gpurun_out/dws.log

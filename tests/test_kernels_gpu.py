@@ -325,16 +325,21 @@ def test_group_rowsum(dev, T, groups, group, cols, pad):
     assert rel_err(out, ref) < 2e-6
 
 
-def test_deferred_grads_batched_reduce_and_colsum(dev):
+@pytest.mark.parametrize('side', [False, True])
+def test_deferred_grads_batched_reduce_and_colsum(dev, side, monkeypatch):
     """ops.DeferredGrads: weight-gradient GEMMs leave their K-slice slabs, bias column sums are only recorded, flush() finishes
-    everything with one capmi_splitk_reduce_batch + one capmi_colsum_batch launch.  Shapes of the Transformer backward (fat
-    bf16x3 GEMMs with 4..15 K slices), a vocabulary-wide bias, an unaligned pair (scalar paths), and a second round with other
-    shapes on the same arena (regions landing on former slab data)."""
+    everything with one capmi_splitk_reduce_batch + one capmi_colsum_batch launch -- or (side, r4) everything runs on a side stream
+    behind its operands and goes out in batches (here of 3 items, so that partial batches and the forced last one both occur).
+    Shapes of the Transformer backward (fat bf16x3 GEMMs with 4..15 K slices), a vocabulary-wide bias, an unaligned pair (scalar
+    paths), and a second round with other shapes on the same arena (regions landing on former slab data)."""
     ops = ops_mod()
     g = torch.Generator().manual_seed(5)
+    monkeypatch.setenv('CAPMI_DW_STREAM', '1' if side else '0')
+    monkeypatch.setattr(ops.DeferredGrads, 'SIDE_BATCH', 3)
 
     def one_round(shapes):
         d = ops.DeferredGrads(dev)
+        assert (d.side is not None) == side
         want = []
         for K, M, N in shapes:
             dy = torch.randn(K, M, generator=g).to(dev)
@@ -345,7 +350,10 @@ def test_deferred_grads_batched_reduce_and_colsum(dev):
             d.colsum(dy, db)
             want.append((dW, dy.double().t() @ x.double(), db, dy.double().sum(0)))
             del dy, x                                   # the collector keeps what it still has to read
-        assert len(d.red) == len(shapes) and len(d.col) == len(shapes)
+        if not side:
+            assert len(d.red) == len(shapes) and len(d.col) == len(shapes)
+        else:
+            assert not d.red and not d.col and len(d.red_side) + len(d.col_side) < 3 and d.side_batches >= 2
         d.flush()
         for dW, rW, db, rb in want:
             assert rel_err(dW, rW) < 4e-6
