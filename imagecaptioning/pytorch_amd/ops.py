@@ -200,7 +200,7 @@ class DeferredGrads:
     14.3 ms per step with the GEMMs alone (A/B inside one gpurun call; CAPMI_DW_STREAM=0 restores one stream and one flush)."""
 
     _arenas = {}
-    SIDE_BATCH = 12            # (batches of 12 vs one flush at the end: 14.37 vs 14.44 ms per Transformer XE step)
+    SIDE_BATCH = 64            # (batches of 12 vs one flush at the end: 14.37 vs 14.44 ms per Transformer XE step -- and 46 more launches; 64: +6)
 
     def __init__(self, device):
         self.dev = device
