@@ -473,7 +473,10 @@ __global__ __launch_bounds__(MHA_T_MAX) void mha_fwd_kernel(const float *__restr
 
 // backward, same decomposition; dK/dV accumulate over the chunks in LDS and are written once.
 // LDS: K, V, dK, dV [Tk][dk+4]; Q, dO [CH][dk+4]; P, P*drop, dS [CH][Tk+1]; row tables 2 x [CH]
-__global__ __launch_bounds__(MHA_T_MAX) void mha_bwd_kernel(const float *__restrict__ d_o, const float *__restrict__ q,
+// MAXT: 1024 threads cap a thread at 128 registers, which this kernel exceeds (17 spilled, 72 bytes of scratch per lane); only the
+// small-grid launch shape needs them, every other shape runs the 512-thread instance
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void mha_bwd_kernel(const float *__restrict__ d_o, const float *__restrict__ q,
                                                            const float *__restrict__ k, const float *__restrict__ v, int ldkv,
                                                            int kstride, const float *__restrict__ p,
                                                            const float *__restrict__ drop, float *__restrict__ dq,
@@ -925,13 +928,20 @@ int capmi_mha_bwd_s(const float *d_o, const float *q, int qstride, const float *
     if (lds > 160 * 1024) return CAPMI_EINVAL;
     static bool attr_b = false;
     if (!attr_b) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mha_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mha_bwd_kernel<MHA_T_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mha_bwd_kernel<MHA_T_MAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_b = true;
     }
+    const int threads = mha_threads(CH, Tk, wgs);
     mha_sync_ablation();
-    hipLaunchKernelGGL(mha_bwd_kernel, dim3(Nq / q_per_kv, h), dim3(mha_threads(CH, Tk, wgs)), lds, (hipStream_t)stream, d_o, q, k, v, ldkv, kstride,
-                       p, drop, dq, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, q_per_kv, Tq, Tk, h, dk, CH, qstride, dq_stride,
-                       mha_on_mfma(CH));
+    if (threads > MHA_T_BIG)
+        hipLaunchKernelGGL(mha_bwd_kernel<MHA_T_MAX>, dim3(Nq / q_per_kv, h), dim3(threads), lds, (hipStream_t)stream, d_o, q, k, v, ldkv,
+                           kstride, p, drop, dq, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, q_per_kv, Tq, Tk, h, dk, CH, qstride,
+                           dq_stride, mha_on_mfma(CH));
+    else
+        hipLaunchKernelGGL(mha_bwd_kernel<MHA_T_BIG>, dim3(Nq / q_per_kv, h), dim3(threads), lds, (hipStream_t)stream, d_o, q, k, v, ldkv,
+                           kstride, p, drop, dq, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, q_per_kv, Tq, Tk, h, dk, CH, qstride,
+                           dq_stride, mha_on_mfma(CH));
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
