@@ -1,8 +1,13 @@
-export PYTHONPATH=$PWD
-for rep in 1 2; do
-echo "prev (one instance, 128 VGPRs + spills)" >> gpurun_out/mb.log
-CAPMI_LIB=$PWD/variants/libcapmi_prev.so python scripts/mha_ablate.py 0 2>&1 | grep "^abl" >> gpurun_out/mb.log
-echo "new (512-thread instance 160 VGPRs)" >> gpurun_out/mb.log
-python scripts/mha_ablate.py 0 2>&1 | grep "^abl" >> gpurun_out/mb.log
-done
-cat gpurun_out/mb.log
+#!/bin/bash
+# the round's verification in one gpurun call: GPU suite, smoke(), the default bench line (-> gpurun_out/)
+python -m pytest tests -m gpu -q -x 2>&1 | tail -3 > gpurun_out/verify_tests.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/verify_smoke.log 2>&1
+python bench.py > gpurun_out/verify_bench.json 2> gpurun_out/verify_bench.err
+cat gpurun_out/verify_tests.log; tail -1 gpurun_out/verify_smoke.log
+python - <<'PY'
+import json
+d = json.loads([l for l in open('gpurun_out/verify_bench.json') if l.startswith('{')][-1])
+print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['avg_launch_us'])
+for k, v in d['other_configs'].items():
+    print(k, v.get('ms_per_step'), v.get('captions_per_s'), v.get('error'))
+PY
