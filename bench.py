@@ -112,7 +112,7 @@ def pmc_traffic(instance=False):
         return None
 
 
-PMC_FILE = 'r04_pmc_traffic.json'
+PMC_FILE = 'r04g_pmc_traffic.json'
 
 
 def prof_read(lib, cls):

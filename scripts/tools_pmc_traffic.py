@@ -10,27 +10,41 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 
-def load(d, counter):
+def load(d, counter, classes=None):
+    """{kernel name: [counter value per launch]} in dispatch order.  The loader / consumer instance gemm_lc_kernel<true,..> serves three
+    launch classes (bench.py's): [small] (< 128 workgroups: h2att), [stream] (>= 24 MB of weights: LSTM gates) and, r4, [segment]
+    (the 17-MB token-embedding segment left of the attention-LSTM gate GEMM).  The class of a launch is decided by its FETCH_SIZE;
+    the WRITE_SIZE pass -- a separate run of the same deterministic launch sequence -- takes the classes by position (`classes`)."""
     rows = defaultdict(list)
+    recs = []
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] == counter:
-                name = r['Kernel_Name']
-                # round 3: one loader / consumer instance serves the weight-streaming decode GEMMs (LSTM gates, logit: >= 128
-                # workgroups) AND the small h2att launches; keep the streaming launches apart (they are the roofline kernel)
-                if 'gemm_lc_kernel<true' in name:
-                    try:
-                        wgs = int(r['Grid_Size']) // max(1, int(r['Workgroup_Size']))
-                    except (KeyError, ValueError):
-                        wgs = 0
-                    name = name[:name.rfind('(')] + (' [stream]' if wgs >= 128 else ' [small]') + '('      # (r4: the 17-MB segment GEMMs count as stream here)
-                rows[name].append(float(r['Counter_Value']))
-    return rows
+                recs.append(r)
+    recs.sort(key=lambda r: int(r.get('Dispatch_Id', 0)))
+    seq, i = [], 0
+    for r in recs:
+        name = r['Kernel_Name']
+        if 'gemm_lc_kernel<true' in name:
+            try:
+                wgs = int(r['Grid_Size']) // max(1, int(r['Workgroup_Size']))
+            except (KeyError, ValueError):
+                wgs = 0
+            if classes is not None and i < len(classes):
+                cls = classes[i]
+            else:
+                cls = ' [small]' if wgs < 128 else (' [stream]' if float(r['Counter_Value']) * 2048 >= 22e6 else ' [segment]')
+            i += 1
+            seq.append(cls)
+            name = name[:name.rfind('(')] + cls + '('
+        rows[name].append(float(r['Counter_Value']))
+    return rows, seq
 
 
 def main():
     fetch, write, out = sys.argv[1:4]
-    F, W = load(fetch, 'FETCH_SIZE'), load(write, 'WRITE_SIZE')
+    F, seq = load(fetch, 'FETCH_SIZE')
+    W, _ = load(write, 'WRITE_SIZE', classes=seq)
     res = {'unit': 'bytes per launch', 'corrections': 'FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read halving); WRITE_SIZE KiB x 1024', 'kernels': {}}
     for name in sorted(set(F) | set(W)):
         short = name.replace('(anonymous namespace)::', '').split('(')[0][-100:]
