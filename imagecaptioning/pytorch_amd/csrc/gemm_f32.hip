@@ -281,11 +281,38 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const KArgs a) {
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
 }
 
+// VEC: 4 outputs of a row per thread on 16-byte accesses (N, ldc % 4 == 0 and every operand 16-byte aligned: the host checks); the
+// slab sums keep the scalar kernel's order per element (8 slabs requested at a time), so both give the same bits
+template <bool VEC>
 __global__ void splitk_reduce_kernel(const float *__restrict__ partial, int splits, float *__restrict__ C, int ldc,
                                      int M, int N, const float *bias, const float *bias2, const float *row_bias,
                                      int row_bias_div, const float *mul_mask, int relu, int accumulate,
                                      const float *__restrict__ addend) {
     const size_t total = (size_t)M * N;
+    if (VEC) {
+        const unsigned quads = (unsigned)(total >> 2), nq = (unsigned)N >> 2;          // (host: total < 2^32)
+        for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += gridDim.x * blockDim.x) {
+            const unsigned row = q / nq, col = (q - row * nq) * 4;
+            const size_t i = (size_t)q * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int s0 = 0; s0 < splits; s0 += 8) {
+                f32x4 tv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    tv[u] = (s0 + u < splits) ? *reinterpret_cast<const f32x4 *>(partial + (size_t)(s0 + u) * total + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += tv[u];
+            }
+            if (bias) v += *reinterpret_cast<const f32x4 *>(bias + col);
+            if (bias2) v += *reinterpret_cast<const f32x4 *>(bias2 + col);
+            if (row_bias) v += *reinterpret_cast<const f32x4 *>(row_bias + (size_t)(row / row_bias_div) * N + col);
+            if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (mul_mask) v *= *reinterpret_cast<const f32x4 *>(mul_mask + i);
+            if (accumulate) v += *reinterpret_cast<const f32x4 *>(addend + (size_t)row * ldc + col);
+            *reinterpret_cast<f32x4 *>(C + (size_t)row * ldc + col) = v;
+        }
+        return;
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int row = (int)(i / N), col = (int)(i % N);
         float v = 0.f;
@@ -376,10 +403,20 @@ static int splitk_reduce_addend(const float *partial, int splits, float *C, int 
                                 const float *addend, void *stream) {
     if (!partial || !C || splits < 1 || M <= 0 || N <= 0) return CAPMI_EINVAL;
     const size_t total = (size_t)M * N;
-    int blocks = (int)((total + 255) / 256);
+    const float *ad = addend ? addend : C;
+    const bool vec = N % 4 == 0 && ldc % 4 == 0 && total < (1ull << 32) &&
+                     ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias) |
+                       reinterpret_cast<uintptr_t>(bias2) | reinterpret_cast<uintptr_t>(row_bias) | reinterpret_cast<uintptr_t>(mul_mask) |
+                       reinterpret_cast<uintptr_t>(ad)) & 15) == 0;
+    const size_t work = vec ? total / 4 : total;
+    int blocks = (int)((work + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, splits, C, ldc, M,
-                       N, bias, bias2, row_bias, row_bias_div > 0 ? row_bias_div : 1, mul_mask, relu, accumulate, addend ? addend : C);
+    if (vec)
+        hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, splits, C, ldc, M, N, bias,
+                           bias2, row_bias, row_bias_div > 0 ? row_bias_div : 1, mul_mask, relu, accumulate, ad);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partial, splits, C, ldc, M, N, bias,
+                           bias2, row_bias, row_bias_div > 0 ? row_bias_div : 1, mul_mask, relu, accumulate, ad);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
