@@ -12,14 +12,11 @@ MI355X-first differences from the reference's dataflow (same numbers):
  * sampling uses a real KV cache written in place by the K/V GEMMs (ldc = Lmax*D) instead of re-decoding the
    whole prefix every step (TransformerModel.core :351-362 -- sum_t t = 210 token-steps per row instead of 20).
 """
-import ctypes as C
-import math
-
 import os
 
 import torch
 
-from . import _lib, ops
+from . import ops
 from ._lib import lib, ptr, check, stream_ptr
 
 _f32 = torch.float32
