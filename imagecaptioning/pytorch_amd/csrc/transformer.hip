@@ -224,7 +224,8 @@ static int mha_chunk(int total, int64_t fixed_f, int64_t per_f) {
 // divisions per element, row-shaped loops give 16 lanes to a row (no division by Tk, reductions inside a DPP row), and the large
 // contractions run on the f32 MFMA.  The vector contractions read 16 bytes of LDS per instruction along the head dimension
 // (dk % 4 == 0, row pitch dk + 4 floats: the 16 lanes of a ds_read_b128 phase hit 64 distinct banks).
-// LDS: K [Tk][dk+4], V [Tk][dk+4], Q [CH][dk+4], S [CH][Tk+1], row tables 3 x [CH]
+// LDS: K [Tk][dk+4], V [Tk][dk+4], Q [CH][dk+4], S [CH][Tk+1], row tables 2 x [CH] (position, mask row; the global row of a
+// query is kvr * q_per_kv * Tq + its flat index: consecutive)
 __device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 #define LDS4(p) (*reinterpret_cast<const f32x4 *>(p))
 __device__ __forceinline__ int pow2_shift(int d) { return (d & (d - 1)) ? -1 : __builtin_ctz(d); }
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(MHA_T_MAX) void mha_fwd_kernel(const float *__restr
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int D = h * dk, P1 = dk + 4, S1 = Tk + 1, d4 = dk >> 2, d4sh = pow2_shift(d4);
     float *sK = lds, *sV = sK + Tk * P1, *sQ = sV + Tk * P1, *sS = sQ + CH * P1;
-    int *sRT = reinterpret_cast<int *>(sS + CH * S1), *sTT = sRT + CH, *sMR = sTT + CH;   // query row -> r * Tq + t, t, mask row
+    int *sTT = reinterpret_cast<int *>(sS + CH * S1), *sMR = sTT + CH;       // query row -> position t, mask row
     const int kvr = blockIdx.x, hd = blockIdx.y;
     const float scale = rsqrtf((float)dk);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, l16 = lane & 15, sub = lane >> 4;
@@ -349,18 +350,19 @@ __global__ __launch_bounds__(MHA_T_MAX) void mha_fwd_kernel(const float *__restr
         if (row0) __syncthreads();          // the previous chunk's readers are done
         for (int lr = threadIdx.x; lr < rows; lr += blockDim.x) {
             const int gr = row0 + lr, r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
-            sRT[lr] = r * Tq + t;
             sTT[lr] = t;
             sMR[lr] = (mask_per_q ? r : kvr) * mask_tq + (mask_tq > 1 ? t : 0);
         }
-        __syncthreads();                    // row tables (and, first trip, K / V) visible
+        // (the query rows of a kv row are consecutive rows of q: row = kvr * R_all + row0 + lr -- the staging needs no table, so its
+        //  loads go out with the K / V loads and one barrier covers tables, K / V and Q)
+        const size_t qrow0 = (size_t)kvr * R_all + row0;
         if (!MHA_ABL(2))
         for (int i0 = threadIdx.x; i0 < rows * d4; i0 += 4 * blockDim.x) {
             f32x4 qq[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = min(i0 + u * (int)blockDim.x, rows * d4 - 1), lr = idiv(i, d4, d4sh), c = (i - lr * d4) * 4;
-                qq[u] = *reinterpret_cast<const f32x4 *>(q + (size_t)sRT[lr] * qstride + hd * dk + c);
+                qq[u] = *reinterpret_cast<const f32x4 *>(q + (qrow0 + lr) * qstride + hd * dk + c);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(MHA_T_MAX) void mha_fwd_kernel(const float *__restr
             // softmax with 16 lanes per query row: a lane holds keys l16 + 16 e (e < 4) in registers, four rows per wave instruction
             for (int lr0 = wid * 4; lr0 < rows; lr0 += nw * 4) {
                 const int lr = lr0 + sub, lrc = min(lr, rows - 1), t = sTT[lrc];
-                const size_t pi0 = ((size_t)(sRT[lrc] - t) * h + (size_t)hd * Tq + t) * Tk;
+                const size_t pi0 = ((qrow0 + lrc - t) * h + (size_t)hd * Tq + t) * Tk;
                 float x[4], dr[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(MHA_T_MAX) void mha_fwd_kernel(const float *__restr
         for (int lr = wid; lr < rows; lr += nw) {          // softmax: one wave per query row, any Tk
             float *row = sS + lr * S1;
             const int t = sTT[lr];
-            const size_t pi0 = ((size_t)(sRT[lr] - t) * h + (size_t)hd * Tq + t) * Tk;
+            const size_t pi0 = ((qrow0 + lr - t) * h + (size_t)hd * Tq + t) * Tk;
             float m = -INFINITY;
             for (int j = lane; j < Tk; j += 64) m = fmaxf(m, row[j]);
             m = wave_max(m);
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(MHA_T_MAX) void mha_fwd_kernel(const float *__restr
         if (mfma) {
             if (!MHA_ABL(64))
             lds_mfma16(sS, S1, 1, sV, P1, 1, rows, dk, Tk, [](int, int) { return 0.f; },
-                       [&](int lr, int c, float acc, float) { if (!MHA_ABL(128)) o[(size_t)sRT[lr] * D + hd * dk + c] = acc; });
+                       [&](int lr, int c, float acc, float) { if (!MHA_ABL(128)) o[(qrow0 + lr) * D + hd * dk + c] = acc; });
         } else
         for (int i = threadIdx.x; i < rows * d4; i += blockDim.x) {      // 4 head columns per thread
             const int lr = idiv(i, d4, d4sh), c = (i - lr * d4) * 4;
@@ -466,13 +468,13 @@ __global__ __launch_bounds__(MHA_T_MAX) void mha_fwd_kernel(const float *__restr
             if (!MHA_ABL(64))
             for (int j = 0; j < Tk; ++j) acc += pr[j] * LDS4(sV + j * P1 + c);
             if (!MHA_ABL(128))
-            *reinterpret_cast<f32x4 *>(o + (size_t)sRT[lr] * D + hd * dk + c) = acc;
+            *reinterpret_cast<f32x4 *>(o + (qrow0 + lr) * D + hd * dk + c) = acc;
         }
     }
 }
 
 // backward, same decomposition; dK/dV accumulate over the chunks in LDS and are written once.
-// LDS: K, V, dK, dV [Tk][dk+4]; Q, dO [CH][dk+4]; P, P*drop, dS [CH][Tk+1]; row tables 2 x [CH]
+// LDS: K, V, dK, dV [Tk][dk+4]; Q, dO [CH][dk+4]; P, P*drop, dS [CH][Tk+1]; row table [CH] (position)
 // MAXT: 1024 threads cap a thread at 128 registers, which this kernel exceeds (17 spilled, 72 bytes of scratch per lane); only the
 // small-grid launch shape needs them, every other shape runs the 512-thread instance
 template <int MAXT>
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(MAXT) void mha_bwd_kernel(const float *__restrict__
     const int D = h * dk, P1 = dk + 4, S1 = Tk + 1, d4 = dk >> 2, d4sh = pow2_shift(d4);
     float *sK = lds, *sV = sK + Tk * P1, *sdK = sV + Tk * P1, *sdV = sdK + Tk * P1;
     float *sQ = sdV + Tk * P1, *sdO = sQ + CH * P1, *sP = sdO + CH * P1, *sPd = sP + CH * S1, *sdS = sPd + CH * S1;
-    int *sRT = reinterpret_cast<int *>(sdS + CH * S1), *sTT = sRT + CH;
+    int *sTT = reinterpret_cast<int *>(sdS + CH * S1);
     const int kvr = blockIdx.x, hd = blockIdx.y;
     const float scale = rsqrtf((float)dk);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -498,17 +500,16 @@ __global__ __launch_bounds__(MAXT) void mha_bwd_kernel(const float *__restrict__
         const int rows = min(CH, R_all - row0);
         if (row0) __syncthreads();
         for (int lr = threadIdx.x; lr < rows; lr += blockDim.x) {
-            const int gr = row0 + lr, r = kvr * q_per_kv + gr / Tq, t = gr % Tq;
-            sRT[lr] = r * Tq + t;
-            sTT[lr] = t;
+            sTT[lr] = (row0 + lr) % Tq;
         }
-        __syncthreads();
+        // (as in the forward: the staging below addresses rows without the table -- one barrier per pass)
+        const size_t qrow0 = (size_t)kvr * R_all + row0;
         for (int i0 = threadIdx.x; i0 < rows * d4; i0 += 4 * blockDim.x) {
             f32x4 qq[4], oo[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = min(i0 + u * (int)blockDim.x, rows * d4 - 1), lr = idiv(i, d4, d4sh), c = (i - lr * d4) * 4;
-                const size_t rt = (size_t)sRT[lr];
+                const size_t rt = qrow0 + lr;
                 qq[u] = *reinterpret_cast<const f32x4 *>(q + rt * qstride + hd * dk + c);
                 oo[u] = *reinterpret_cast<const f32x4 *>(d_o + rt * D + hd * dk + c);
             }
@@ -529,8 +530,8 @@ __global__ __launch_bounds__(MAXT) void mha_bwd_kernel(const float *__restrict__
                 float pv[4], dv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int lr = min(lr0 + sub + 4 * (u >> 1), rows - 1), j = min(j0 + l16 + 16 * (u & 1), Tk - 1), t = sTT[lr];
-                    const size_t pi = ((size_t)(sRT[lr] - t) * h + (size_t)hd * Tq + t) * Tk + j;
+                    const int lr = min(lr0 + sub + 4 * (u >> 1), rows - 1), j = min(j0 + l16 + 16 * (u & 1), Tk - 1), t = (row0 + lr) % Tq;
+                    const size_t pi = ((qrow0 + lr - t) * h + (size_t)hd * Tq + t) * Tk + j;
                     pv[u] = p[pi];
                     dv[u] = drop ? drop[pi] : 1.f;
                 }
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(MAXT) void mha_bwd_kernel(const float *__restrict__
         if (mfma) {
             if (!MHA_ABL(1024))
             lds_mfma16(sdS, S1, 1, sK, P1, 1, rows, dk, Tk, [](int, int) { return 0.f; },
-                       [&](int lr, int c, float acc, float) { dq[(size_t)sRT[lr] * dq_stride + hd * dk + c] = acc; });
+                       [&](int lr, int c, float acc, float) { dq[(qrow0 + lr) * dq_stride + hd * dk + c] = acc; });
             if (!MHA_ABL(2048)) {
                 lds_mfma16(sdS, 1, S1, sQ, P1, 1, Tk, dk, rows, [&](int j, int c) { return sdK[j * P1 + c]; },
                            [&](int j, int c, float acc, float old) { sdK[j * P1 + c] = old + acc; });
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(MAXT) void mha_bwd_kernel(const float *__restrict__
             f32x4 acc = zero4;
             if (!MHA_ABL(1024))
             for (int j = 0; j < Tk; ++j) acc += ds[j] * LDS4(sK + j * P1 + c);
-            *reinterpret_cast<f32x4 *>(dq + (size_t)sRT[lr] * dq_stride + hd * dk + c) = acc;
+            *reinterpret_cast<f32x4 *>(dq + (qrow0 + lr) * dq_stride + hd * dk + c) = acc;
         }
         if (!MHA_ABL(2048))
         for (int i = threadIdx.x; i < Tk * d4; i += blockDim.x) {
@@ -881,7 +882,7 @@ int capmi_mha_fwd_s(const float *q, int qstride, const float *k, const float *v,
     if (dk % 4 || ldkv % 4 || kstride % 4 || ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) |
                                                 reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(o)) & 15))
         return CAPMI_EINVAL;
-    const int64_t fixed_f = (int64_t)2 * Tk * (dk + 4), per_f = (int64_t)(dk + 4) + (Tk + 1) + 3;
+    const int64_t fixed_f = (int64_t)2 * Tk * (dk + 4), per_f = (int64_t)(dk + 4) + (Tk + 1) + 2;
     const int64_t wgs = (int64_t)(Nq / q_per_kv) * h;
     const int CH = mha_chunk(q_per_kv * Tq, fixed_f, per_f);
     const size_t lds = (size_t)(fixed_f + (int64_t)CH * per_f) * sizeof(float);
@@ -921,7 +922,7 @@ int capmi_mha_bwd_s(const float *d_o, const float *q, int qstride, const float *
           reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dk_out) |
           reinterpret_cast<uintptr_t>(dv_out)) & 15))
         return CAPMI_EINVAL;
-    const int64_t fixed_b = (int64_t)4 * Tk * (dk + 4), per_b = (int64_t)2 * (dk + 4) + 3 * (Tk + 1) + 2;
+    const int64_t fixed_b = (int64_t)4 * Tk * (dk + 4), per_b = (int64_t)2 * (dk + 4) + 3 * (Tk + 1) + 1;
     const int64_t wgs = (int64_t)(Nq / q_per_kv) * h;
     const int CH = mha_chunk(q_per_kv * Tq, fixed_b, per_b);
     const size_t lds = (size_t)(fixed_b + (int64_t)CH * per_b) * sizeof(float);
