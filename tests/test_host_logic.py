@@ -255,3 +255,27 @@ def test_cached_parameter_walk_follows_the_module():
         else:
             model.att_embed = nn.Sequential(nn.Linear(2048, 32), nn.ReLU(), nn.Dropout(0.1), nn.Linear(32, 32))   # one more parameter pair
         same()
+
+
+def test_collect_grads_adopts_copies_and_zeroes():
+    """FlatParams.collect_grads makes the flat gradient buffer authoritative: a .grad that already IS the flat view (what autograd
+    adopts from the native backwards) is left alone (r4: no per-parameter re-assignment), a foreign .grad is copied in, a missing one
+    becomes zero -- and afterwards every p.grad is the flat view's memory"""
+    import torch
+    from imagecaptioning.pytorch_amd.flat import FlatParams
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2))
+    flat = FlatParams(net)
+    names = flat.names
+    flat.grad.fill_(7.0)                                   # stale content of an earlier step
+    flat.zero_grad()
+    p0, p1, p2, p3 = flat.params
+    flat.grad_views[names[0]].fill_(1.5)
+    p0.grad = flat.grad_views[names[0]]                    # adopted view (native backward wrote in place)
+    p1.grad = torch.full_like(p1, 2.5)                     # a gradient torch autograd produced elsewhere
+    p2.grad = None                                         # a parameter the loss did not reach
+    p3.grad = flat.grad_views[names[3]].clone() * 0 + 4.0  # foreign again
+    flat.collect_grads()
+    for p, n, want in zip(flat.params, names, (1.5, 2.5, 0.0, 4.0)):
+        assert p.grad.data_ptr() == flat.grad_views[n].data_ptr()
+        assert bool((p.grad == want).all()) and bool((flat.grad_views[n] == want).all())
