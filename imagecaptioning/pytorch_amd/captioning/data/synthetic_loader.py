@@ -25,6 +25,11 @@ class SyntheticLoader:
         n_img = opt.synthetic_images
         self.refs = [synthetic.zipf_rows(rng, 5, self.seq_length, vocab=self.vocab_size) for _ in range(n_img)]
         self.seeds = rng.integers(0, 2 ** 31, size=n_img)
+        # this rank's share of a pass: every world-th image, the tail padded from the head of the pass (as FeatureLoader._mine
+        # does) so that all ranks hold ceil(n / world) images and wrap -- advance the epoch, hence lr decay / ss_prob / the
+        # XE -> SCST switch -- on the same batch
+        share = -(-n_img // self.world)
+        self.mine = [(self.rank + self.world * j) % n_img for j in range(share)]
         self.pos = {'train': 0, 'val': 0, 'test': 0}
         self.epoch_wrapped = False
 
@@ -41,8 +46,8 @@ class SyntheticLoader:
     def get_batch(self, split, batch_size=None):
         B = batch_size or self.batch_size
         n, L, opt = self.seq_per_img, self.seq_length, self.opt
-        mine = len(range(self.rank, len(self.refs), self.world))       # images of this rank
-        idx = [self.rank + self.world * ((self.pos[split] + i) % mine) for i in range(B)]
+        mine = len(self.mine)                                          # images of this rank (equal on every rank)
+        idx = [self.mine[(self.pos[split] + i) % mine] for i in range(B)]
         wrapped = self.pos[split] + B >= mine
         self.pos[split] = (self.pos[split] + B) % mine
         fc = np.zeros((B, opt.fc_feat_size), dtype=np.float32)

@@ -154,6 +154,11 @@ class AoAModel(CaptionModel):
 
     def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
         method = opt.get('sample_method', 'greedy')
+        if not opt.get('output_logsoftmax', 1):
+            # AttModel.py:171-175: the margin structure losses read raw LOGITS.  Only the UpDown rollout stores them (capmi.h
+            # CAPMI_SELECT_RAW); training a margin loss on this family's log-softmax output would be silently wrong
+            raise NotImplementedError('output_logsoftmax=0 (max_margin / multi_margin / real_softmax_margin structure losses) '
+                                      'is implemented for the UpDown rollout only; %s returns log-probabilities' % type(self).__name__)
         if opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search'):
             if not att_feats.is_cuda:
                 raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')

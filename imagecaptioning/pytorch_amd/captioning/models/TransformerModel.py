@@ -227,6 +227,11 @@ class TransformerModel(CaptionModel):
         step, TransformerModel.py:351-362, and so redraws the masks of earlier positions each step; here a position keeps its
         masks for the whole rollout -- the KV cache's meaning -- which is the same policy-gradient estimator for a slightly
         different, equally valid, noise model.)"""
+        if not opt.get('output_logsoftmax', 1):
+            # AttModel.py:171-175: the margin structure losses read raw LOGITS.  Only the UpDown rollout stores them (capmi.h
+            # CAPMI_SELECT_RAW); training a margin loss on this family's log-softmax output would be silently wrong
+            raise NotImplementedError('output_logsoftmax=0 (max_margin / multi_margin / real_softmax_margin structure losses) '
+                                      'is implemented for the UpDown rollout only; %s returns log-probabilities' % type(self).__name__)
         if not att_feats.is_cuda:
             raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
         method = opt.get('sample_method', 'greedy')

@@ -25,6 +25,7 @@ DEFAULTS = dict(
     beam_size=1, sample_method='greedy', temperature=1.0, suppress_UNK=1, length_penalty='', num_images=20, device='cuda',
     group_size=1, diversity_lambda=0.5, decoding_constraint=0, block_trigrams=0, remove_bad_endings=0, sample_n=1,
     sample_n_method='sample', verbose_beam=0,                                # opts.py:288-330 add_eval_sample_opts
+    split='test',                                                            # opts.py:314 add_eval_options
     # data (synthetic only: the reference's h5/lmdb loaders are outside the hot path)
     input_synthetic=1, vocab_size=9487, synthetic_regions=36, synthetic_images=200,
     # real precomputed features (captioning/data/feature_loader.py; opts.py:23-37 of the reference)

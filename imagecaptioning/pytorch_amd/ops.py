@@ -304,6 +304,15 @@ class DeferredGrads:
             check(lib.capmi_colsum_batch(t.data_ptr(), len(self.col), stream_ptr()), 'capmi_colsum_batch')
         self.red, self.col, self.keep = [], [], []
 
+    def abandon(self):
+        """the backward raised: nothing is finished, but GEMMs already enqueued on the side stream may still be reading the dy / x
+        tensors in `keep`.  The main stream must wait for them before those blocks return to the caching allocator (a caller
+        that catches the error -- an OOM retry -- would otherwise be handed memory a side-stream kernel still reads)."""
+        if self.side is not None and self.ev_used:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self.red, self.col, self.keep = [], [], []
+        self.red_side, self.col_side = [], []
+
 
 def linear(x, weight, bias=None, relu=False, mul_mask=None, row_div=1, rows=None, ws=None, out=None):
     """y = act(x @ weight.T + bias) (* mask); x [M0,K] read as row r -> r // row_div.  out: optional [M,N] contiguous target."""

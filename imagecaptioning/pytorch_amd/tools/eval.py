@@ -79,12 +79,15 @@ def eval_split(model, crit, loader, opt):
         # eval_utils.py:200-207: ix1 = min(it_max, num_images) -- never more than the split holds (a larger request would make the
         # non-wrapping loader start the split over and every image would be predicted twice)
         num_images = data['bounds']['it_max'] if num_images < 0 else min(num_images, data['bounds']['it_max'])
+        # eval_utils.py:157-159: fc_feats, att_feats, labels, masks AND att_masks go to the device -- with 10..100 adaptive
+        # regions per image the padded rows of att_feats must stay out of the attention (None when the batch is not ragged)
         fc, att, labels, masks = (data[k].to(dev) for k in ('fc_feats', 'att_feats', 'labels', 'masks'))
+        att_masks = None if data.get('att_masks') is None else data['att_masks'].to(dev)
         kw = eval_kwargs_of(opt)
         kw['sample_n'] = 1                                                                                     # :169-170
         with torch.no_grad():
-            loss = crit(model(fc, att, labels[..., :-1], None), labels[..., 1:], masks[..., 1:]).item()       # eval_utils.py:163
-            seq, seq_logp = model(fc, att, None, mode='sample', opt=kw)                                        # :171
+            loss = crit(model(fc, att, labels[..., :-1], att_masks), labels[..., 1:], masks[..., 1:]).item()  # eval_utils.py:163
+            seq, seq_logp = model(fc, att, att_masks, mode='sample', opt=kw)                                   # :171
         loss_sum += loss
         loss_n += 1
         if seq_logp.dim() == 3:
@@ -105,21 +108,41 @@ def eval_split(model, crit, loader, opt):
             preds.append({'image_id': data['infos'][k // rows_per_image]['id'], 'caption': s, 'perplexity': perplexity[k].item(),
                           'entropy': entropy[k].item()})
         if opt.sample_n > 1:                                                                                   # :199-200
-            eval_split_n(model, n_preds, fc, att, None, data, opt)
+            eval_split_n(model, n_preds, fc, att, att_masks, data, opt)                                       # :198
         n += len(data['infos'])
     if n_preds and 'perplexity' in n_preds[0]:
         n_preds = sorted(n_preds, key=lambda x: x['perplexity'])                                               # :217-218
     model.n_predictions = n_preds
+    model.train()                                                                                              # :224-225
     return loss_sum / max(loss_n, 1), preds[:num_images * max(1, len(preds) // max(n, 1))]
+
+
+def build_loader(opt, dev):
+    """tools/eval.py:97-104: the reference evaluates on its DataLoader (precomputed bottom-up features, 10-100 regions per image
+    => ragged batches with att_masks).  --input_json selects the same real-file loader tools/train.py uses (FeatureLoader, kept
+    resident in HBM unless --resident_features 0); without it the synthetic fixed-36-region loader stands in."""
+    if getattr(opt, 'input_json', ''):
+        from captioning.data.feature_loader import FeatureLoader
+        loader = FeatureLoader(opt)
+        opt.vocab_size, opt.seq_length = loader.vocab_size, loader.seq_length
+        if not getattr(opt, 'max_length', None) or opt.max_length > opt.seq_length:
+            opt.max_length = opt.seq_length
+        vocab = loader.get_vocab()
+        if getattr(opt, 'resident_features', 1):
+            from captioning.data.resident import ResidentFeatures
+            budget = int(opt.resident_budget_gb * (1 << 30)) if getattr(opt, 'resident_budget_gb', 0) > 0 else None
+            loader = ResidentFeatures(loader, dev, budget_bytes=budget)
+        return loader, vocab
+    from captioning.data.synthetic_loader import SyntheticLoader
+    loader = SyntheticLoader(opt)
+    return loader, loader.get_vocab()
 
 
 def main(opt):
     from captioning import models
-    from captioning.data.synthetic_loader import SyntheticLoader
     from captioning.modules import losses
     dev = torch.device(opt.device if opt.device != 'cuda' else 'cuda:0')
-    loader = SyntheticLoader(opt)
-    opt.vocab = loader.get_vocab()
+    loader, opt.vocab = build_loader(opt, dev)
     torch.manual_seed(1234)
     model = models.setup(opt).to(dev)
     if opt.start_from:

@@ -19,23 +19,36 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))           # so that `captioning` resolves to the mirror package
 
 
-def validation_loss(lw_model, loader, opt, dev):
-    """XE loss over `val_images` images of the val split, teacher forced, eval mode (eval_utils.py:150-160)."""
+def validation_loss(lw_model, loader, opt, dev, world=1):
+    """XE loss over `val_images` images of the val split, teacher forced, eval mode (eval_utils.py:150-160).  With `world`
+    data-parallel ranks the val split is partitioned like the train split: each rank scores at most its share
+    (val_images / world, never more than its partition holds) and returns (sum of per-image losses, images) so that the caller
+    can all-reduce BOTH and every image counts once, whatever the partition sizes.  A rank whose partition is empty (val split
+    smaller than world) contributes (0, 0)."""
     model = lw_model.model
     model.eval()
     tot, n = 0.0, 0
     if hasattr(loader, 'reset_iterator'):
         loader.reset_iterator('val')                       # eval_utils.py:145: every evaluation starts at the top of the split
+    want = max(opt.val_images, opt.batch_size)
+    if world > 1:
+        want = max(1, -(-want // world))
     with torch.no_grad():
-        while n < max(opt.val_images, opt.batch_size):
-            data = loader.get_batch('val')
+        while n < want:
+            try:
+                data = loader.get_batch('val')
+            except ValueError:                             # this rank's part of the split is empty
+                break
+            it_max = data['bounds'].get('it_max')
+            if it_max is not None:
+                want = min(want, max(int(it_max), 1))      # eval_utils.py:200-207: never more than the split holds
             fc, att, labels, masks = (data[k].to(dev) for k in ('fc_feats', 'att_feats', 'labels', 'masks'))
             att_masks = None if data['att_masks'] is None else data['att_masks'].to(dev)
             logp = model(fc, att, labels[..., :-1], att_masks)
             tot += float(lw_model.crit(logp, labels[..., 1:], masks[..., 1:])) * fc.shape[0]
             n += fc.shape[0]
     model.train()
-    return tot / n
+    return tot, n
 
 
 def train(opt):
@@ -116,7 +129,9 @@ def train(opt):
         if hasattr(base, 'load_state'):
             for split, pos in infos.get('loader_pos', {}).items():
                 base.load_state(split, order=infos.get('loader_order', {}).get(split), pos=pos)
-            base.load_state('train', rng=infos.get('loader_rng'), cap_rng=infos.get('loader_cap_rng'))
+            # only rank 0 writes infos: its caption-choice stream (seed + 104729 * rank, feature_loader.py) is rank 0's own.  The
+            # other ranks keep the stream their constructor derived for THEIR rank instead of collapsing onto rank 0's
+            base.load_state('train', rng=infos.get('loader_rng'), cap_rng=infos.get('loader_cap_rng') if rank == 0 else None)
         else:
             for split, pos in infos.get('loader_pos', {}).items():
                 base.pos[split] = pos
@@ -223,13 +238,15 @@ def train(opt):
             epoch += 1
             epoch_done = True
         if opt.val_every and it % opt.val_every == 0:
-            val_loss = validation_loss(lw_model, loader, opt, dev)          # eval_utils.eval_split's loss half (:228-256)
+            val_sum, val_n = validation_loss(lw_model, loader, opt, dev, world)  # eval_utils.eval_split's loss half (:228-256)
             if world > 1:
-                # every rank evaluates its own images: the plateau decision must see ONE number, or the ranks pick
-                # different learning rates and the replicas drift apart
-                v = torch.tensor([val_loss], dtype=torch.float64, device=dev)
+                # every rank evaluates its own images: the plateau decision must see ONE number, or the ranks pick different
+                # learning rates and the replicas drift apart.  (sum, count) are reduced, not per-rank means: partitions of
+                # unequal size (or an empty one) must not bias the mean
+                v = torch.tensor([val_sum, float(val_n)], dtype=torch.float64, device=dev)
                 dist.all_reduce(v)
-                val_loss = float(v) / world
+                val_sum, val_n = float(v[0]), float(v[1])
+            val_loss = val_sum / max(val_n, 1.0)
             sched.plateau_step(val_loss)
             if best_val_score is None or -val_loss > best_val_score:           # tools/train.py:258-266 (language_eval off: -val_loss)
                 best_val_score = -val_loss

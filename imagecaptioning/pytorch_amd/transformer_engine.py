@@ -148,6 +148,8 @@ class deferred_grads:
         d, Lin.deferred = Lin.deferred, self.prev
         if d is not None and et is None:
             d.flush()
+        elif d is not None:
+            d.abandon()          # error path: the side stream may still read the kept operands
         return False
 
 

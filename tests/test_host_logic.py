@@ -279,3 +279,73 @@ def test_collect_grads_adopts_copies_and_zeroes():
     for p, n, want in zip(flat.params, names, (1.5, 2.5, 0.0, 4.0)):
         assert p.grad.data_ptr() == flat.grad_views[n].data_ptr()
         assert bool((p.grad == want).all()) and bool((flat.grad_views[n] == want).all())
+
+
+@pytest.mark.parametrize('family,extra', [('transformer', dict(N_enc=1, N_dec=1, d_model=16, d_ff=32, num_att_heads=2, dropout=0.1)),
+                                          ('aoa', dict(num_heads=2, num_layers=2)), ('newfc', {})])
+def test_raw_logit_rollouts_are_refused_outside_updown(family, extra):
+    """ADVICE r4 (medium): LossWrapper asks for output_logsoftmax=0 with the margin structure losses (loss_wrapper.py:34-35);
+    only the UpDown rollout stores raw logits.  The other families must refuse instead of silently training a margin loss on
+    log-probabilities -- before touching the device (no GPU needed to see the error)."""
+    import torch
+    from imagecaptioning.pytorch_amd import synthetic
+    from imagecaptioning.pytorch_amd.captioning import models
+    opt = synthetic.updown_opt(caption_model=family, input_encoding_size=16, rnn_size=16, att_hid_size=8, seq_length=5, max_length=5,
+                               vocab_size=20, fc_feat_size=12, att_feat_size=12, vocab={str(i): 'w%d' % i for i in range(1, 21)}, **extra)
+    model = models.setup(opt)
+    fc, att = torch.zeros(2, 12), torch.zeros(2, 3, 12)
+    with pytest.raises(NotImplementedError, match='output_logsoftmax=0'):
+        model(fc, att, None, opt={'sample_method': 'sample', 'sample_n': 2, 'output_logsoftmax': 0}, mode='sample')
+
+
+def test_synthetic_loader_ranks_hold_equal_shares_and_wrap_together():
+    """with synthetic_images % world != 0 the ranks used to hold different counts and raise `wrapped` (=> epoch, lr
+    decay, ss_prob, the XE -> SCST switch) on different iterations.  Each rank now holds ceil(n / world) images, the tail padded
+    from the head of the pass as FeatureLoader._mine does."""
+    import argparse
+    from imagecaptioning.pytorch_amd.captioning.data.synthetic_loader import SyntheticLoader
+    opt = argparse.Namespace(batch_size=2, seq_per_img=2, seq_length=5, vocab_size=20, seed=1, synthetic_images=7, fc_feat_size=4,
+                             att_feat_size=4, synthetic_regions=3)
+    loaders = [SyntheticLoader(opt, rank=r, world=3) for r in range(3)]
+    assert [len(l.mine) for l in loaders] == [3, 3, 3]
+    assert sorted(set(sum((l.mine for l in loaders), []))) == list(range(7))          # every image is somebody's
+    wraps = [[l.get_batch('train')['bounds']['wrapped'] for _ in range(6)] for l in loaders]
+    assert wraps[0] == wraps[1] == wraps[2] and any(wraps[0])
+    assert all(l.get_batch('val')['bounds']['it_max'] == 3 for l in loaders)
+
+
+def test_validation_loss_returns_sum_and_count_and_survives_an_empty_partition():
+    """per-rank validation = (sum of per-image losses, images) so the all-reduce weighs every image once; a rank's
+    share is val_images / world, capped by what its partition holds; an empty partition contributes (0, 0)."""
+    import argparse
+    import torch
+    from imagecaptioning.pytorch_amd.tools import train as T
+
+    class Model:
+        def eval(self): pass
+        def train(self): pass
+        def __call__(self, fc, att, seq, am): return fc.sum(1)
+
+    class LW:
+        model = Model()
+        @staticmethod
+        def crit(logp, labels, masks): return logp.mean()
+
+    class Loader:
+        def __init__(self, n): self.n, self.pos = n, 0
+        def reset_iterator(self, split): self.pos = 0
+        def get_batch(self, split):
+            if self.n == 0:
+                raise ValueError('split has no images')
+            B = min(2, self.n - self.pos) or 2
+            self.pos = (self.pos + B) % self.n if self.pos + B < self.n else 0
+            z = torch.zeros(B, 1, 3)
+            return {'fc_feats': torch.ones(B, 4), 'att_feats': torch.zeros(B, 2, 4), 'labels': z.long(), 'masks': z, 'att_masks': None,
+                    'bounds': {'it_max': self.n}}
+    opt = argparse.Namespace(val_images=40, batch_size=2)
+    tot, n = T.validation_loss(LW, Loader(5), opt, 'cpu', world=4)        # share 10, partition 5: every image once
+    assert n == 5 and abs(tot - 4.0 * 5) < 1e-6
+    tot, n = T.validation_loss(LW, Loader(0), opt, 'cpu', world=4)
+    assert (tot, n) == (0.0, 0)
+    tot, n = T.validation_loss(LW, Loader(100), opt, 'cpu', world=1)
+    assert n == 40
