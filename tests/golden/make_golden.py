@@ -910,9 +910,90 @@ def main_beam5():
     print('beam5_config_size.npz:', len(out), 'arrays')
 
 
+def main_beam5mid():
+    """VERDICT r4 weak #3 / missing #6 -- the two holes of beam5_config_size.npz:
+    (a) beams that END IN THE MIDDLE of the sequence at V1 = 9488 (done-beam lengths 4..16): the -1000 bookkeeping of ended beams
+        (CaptionModel.py:176-198) with live and ended beams mixed in the top 5 of 47 440 candidates over several steps.  A random
+        decoder never does that (its beams end at steps 0-3 or not at all), so tests/shapes.py:mid_state gives every family a
+        clock feature and ties the EOS logit to it; the generator ASSERTS that every 'mid' case has done beams of length 4..16;
+    (b) the Transformer at configs/transformer/transformer.yml size (d = 512, N = 6, h = 8, V1 = 9488, B = 3, beam 5, +- att_masks):
+        KV caches reordered under beam 5 (TransformerModel.py:351-362, CaptionModel.py:90-109); 'tlong' never sees EOS.
+    Same stored fields as main_beam5; output beam5_mid.npz (beam5_config_size.npz stays bit-for-bit what it was)."""
+    sys.path.insert(0, REF)
+    root = os.path.dirname(os.path.dirname(HERE))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    import shapes
+    import captioning.models as models
+    from imagecaptioning.pytorch_amd import synthetic
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    margins = []
+    real_sort = torch.sort
+
+    def spy_sort(x, *a, **k):
+        ys, ix = real_sort(x, *a, **k)
+        if x.dim() == 2 and x.shape[1] > 1000 and len(a) >= 2 and a[1] is True:
+            margins.append((x.shape[1], ys))
+        return ys, ix
+    out = {}
+    B, bs = 3, 5
+    only = os.environ.get('CAPMI_BEAM5MID_ONLY')              # seed scan of one family: nothing is written
+    for name in ('updown', 'aoa', 'transformer'):
+        if only and name != only:
+            continue
+        seed = int(os.environ.get('CAPMI_BEAM5MID_SEED_' + name.upper(), shapes.BEAM5_MID_SEED[name]))
+        opt = synthetic.updown_opt(drop_prob_lm=0.0) if name == 'updown' else shapes.big_opt(name)
+        model = models.setup(opt)
+        shp = {k: v.shape for k, v in model.state_dict().items()}
+        fc, att = shapes.feats(B, seed=seed)
+        am = shapes.ragged_masks(B, seed=seed)
+        cases = [('mid', None, {}, None), ('midm', am, {}, None), ('midn', am, {'sample_n': 5}, None)]
+        if name == 'transformer':
+            cases.append(('tlong', am, {}, (0.0, -60.0, 0.0)))          # EOS never enters the top 5: every beam runs to L
+        with torch.no_grad():
+            for tag, masks, kw, over in cases:
+                model.load_state_dict(shapes.mid_state(name, shp, seed, *(over or (None, None, None))))
+                model.eval()
+                o = {'sample_method': 'beam_search', 'beam_size': bs, 'sample_n': 1}
+                o.update(kw)
+                del margins[:]
+                torch.sort = spy_sort
+                try:
+                    seq, slp = model(fc, att, masks, opt=o, mode='sample')
+                finally:
+                    torch.sort = real_sort
+                t = name + '_' + tag
+                out[t + '_seq'] = seq.numpy()
+                out[t + '_sel_logp'] = slp.gather(2, seq.unsqueeze(2)).squeeze(2).numpy()
+                out[t + '_logp_rows'] = slp[0, :2].numpy()
+                for k, beams in enumerate(model.done_beams):
+                    out['%s_n%d' % (t, k)] = np.array(len(beams))
+                    for j, bm in enumerate(beams):
+                        out['%s_%d_%d_seq' % (t, k, j)] = bm['seq'].numpy()
+                        out['%s_%d_%d_p' % (t, k, j)] = np.array(bm['p'])
+                        out['%s_%d_%d_unaug' % (t, k, j)] = np.array(bm['unaug_p'])
+                gap = min(float(torch.where(ys[:, bs - 1] > -500, ys[:, bs - 1] - ys[:, bs], torch.tensor(1e9)).min())
+                          for w, ys in margins if w > bs)
+                out[t + '_min_gap'] = np.array(gap)
+                lens = [[int((bm['seq'] > 0).sum()) for bm in beams] for beams in model.done_beams]
+                print('%s: %d sorts, smallest live top-%d gap %.3g, lengths of the done beams %s' % (t, len(margins), bs, gap, lens))
+                assert gap >= 1e-4 or os.environ.get('CAPMI_BEAM5_ANY_GAP'), 'near-tie in the fixture: pick the next seed (shapes.BEAM5_MID_SEED)'
+                if tag.startswith('mid'):
+                    inside = [l for ls in lens for l in ls if 4 <= l <= 16]
+                    assert len(inside) >= 5 and len(set(inside)) >= 2, 'no beam ends in the middle of the sequence: %s' % lens
+                else:
+                    assert all(l == 20 for ls in lens for l in ls), lens
+    if only:
+        return
+    np.savez_compressed(os.path.join(HERE, 'beam5_mid.npz'), **out)
+    print('beam5_mid.npz:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'full3':
         main_full3()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'beam5mid':
+        main_beam5mid()
     elif len(sys.argv) > 1 and sys.argv[1] == 'beam5':
         main_beam5()
     elif len(sys.argv) > 1 and sys.argv[1] == 'full2':

@@ -121,3 +121,81 @@ def beam5_state(name, state_shapes, seed, eos='end'):
     st['logit.bias'] = st['logit.bias'].clone()
     st['logit.bias'][0] += BEAM5_EOS_BIAS[(name, eos)]
     return st
+
+
+# ---- beams that END IN THE MIDDLE of the sequence at config size (`make_golden.py beam5mid`).  With a constant
+# EOS bias a random-init decoder ends its beams at steps 0-3 or never (its state reaches a fixed point, so EOS is either in the
+# top 5 from the start or not at all).  A trained model ends a caption because its state counts: the fixture gives every family a
+# CLOCK feature -- one hidden unit (LSTM families: a cell that adds `rate` per step, h = tanh(rate * (t + 1))) or one residual
+# channel (Transformer: a positional-encoding channel of wavelength ~100 that nothing else writes) -- and ties the EOS logit to
+# that unit alone (weight w00, bias b0): EOS climbs into the top 5 somewhere inside the sequence, a beam ends, the others go on
+# (CaptionModel.py:176-198: the -1000 bookkeeping with live and ended beams mixed over 47 440 candidates).
+BEAM5_MID = {'updown': (0.3, -10.0, 0.1), 'aoa': (0.45, -20.0, 0.1), 'transformer': (1.0, -20.0, 0.0)}
+BEAM5_MID_SEED = {'updown': 47, 'aoa': 40, 'transformer': 57}
+
+
+def _lstm_clock(st, pre, R, rate, unit=0):
+    """unit `unit` of the LSTMCell `pre` becomes c_t = c_{t-1} + ~rate (i = f = o ~ 1, g = tanh^-1-ish rate), h = tanh(c_t)"""
+    import math
+    for w in ('weight_ih', 'weight_hh'):
+        W = st[pre + '.' + w] = st[pre + '.' + w].clone()
+        for gate in range(4):
+            W[gate * R + unit] *= 0.02 if gate == 2 else 0.0            # a little state dependence stays in the increment
+    for gate, val in ((0, 10.0), (1, 10.0), (2, math.atanh(rate)), (3, 10.0)):
+        for b in ('bias_ih', 'bias_hh'):
+            v = st[pre + '.' + b] = st[pre + '.' + b].clone()
+            v[gate * R + unit] = val / 2
+
+
+def mid_state(name, state_shapes, seed, w00=None, b0=None, rate=None):
+    """weights of the mid-ending beam fixtures (see above); sharpened logit layer as in beam5_state"""
+    d = BEAM5_MID[name]
+    w00, b0, rate = (d[0] if w00 is None else w00), (d[1] if b0 is None else b0), (d[2] if rate is None else rate)
+    st = full_size_params(seed=seed) if name == 'updown' else seeded_state(state_shapes, seed)
+    lw = 'model.generator.proj.weight' if name == 'transformer' else 'logit.weight'
+    lb = lw[:-6] + 'bias'
+    st[lw] = st[lw] * BEAM5_LOGIT_SCALE
+    st[lb] = st[lb].clone()
+    if name == 'updown':
+        R = st['core.lang_lstm.weight_hh'].shape[1]
+        _lstm_clock(st, 'core.lang_lstm', R, rate)
+        clock = 0
+    elif name == 'aoa':
+        R = st['core.att_lstm.weight_hh'].shape[1]
+        _lstm_clock(st, 'core.att_lstm', R, rate)
+        # out[0] = GLU row 0 = (h_att[0]) * sigmoid(10): the clock passes the att2ctx layer untouched (AoAModel.py:176-181)
+        W, b = st['core.att2ctx.0.weight'].clone(), st['core.att2ctx.0.bias'].clone()
+        W[0] = 0.0
+        W[0, R] = 1.0
+        W[R] = 0.0
+        b[0], b[R] = 0.0, 10.0
+        st['core.att2ctx.0.weight'], st['core.att2ctx.0.bias'] = W, b
+        clock = 0
+    else:
+        # residual channel 154 carries sin(t / 10000^(154/512)) = sin(0.0627 t) from the positional encoding (TransformerModel.py:
+        # 224-240) and nothing else: the word embedding and every decoder sublayer's output projection leave it alone
+        clock = 154
+        import math
+        d = st['model.tgt_embed.1.pe'].shape[-1]           # seeded_state drew noise for the buffer: put the real table back
+        pos = torch.arange(0, st['model.tgt_embed.1.pe'].shape[-2]).unsqueeze(1).float()
+        div = torch.exp(torch.arange(0, d, 2).float() * -(math.log(10000.0) / d))
+        pe = torch.zeros(pos.shape[0], d)
+        pe[:, 0::2], pe[:, 1::2] = torch.sin(pos * div), torch.cos(pos * div)
+        st['model.tgt_embed.1.pe'] = pe.reshape(st['model.tgt_embed.1.pe'].shape)
+        st['model.tgt_embed.0.lut.weight'] = st['model.tgt_embed.0.lut.weight'].clone()
+        st['model.tgt_embed.0.lut.weight'][:, clock] = 0.0
+        for k in list(st):
+            if k.startswith('model.decoder.layers.') and (k.endswith('linears.3.weight') or k.endswith('w_2.weight')):
+                st[k] = st[k].clone()
+                st[k][clock] = 0.0
+            elif k.startswith('model.decoder.layers.') and (k.endswith('linears.3.bias') or k.endswith('w_2.bias')):
+                st[k] = st[k].clone()
+                st[k][clock] = 0.0
+        st['model.decoder.norm.a_2'] = st['model.decoder.norm.a_2'].clone()
+        st['model.decoder.norm.a_2'][clock] = 10.0
+        st['model.decoder.norm.b_2'] = st['model.decoder.norm.b_2'].clone()
+        st['model.decoder.norm.b_2'][clock] = 0.0
+    st[lw][0] = 0.0
+    st[lw][0, clock] = w00 * BEAM5_LOGIT_SCALE
+    st[lb][0] = b0
+    return st

@@ -109,7 +109,7 @@ def _run_case(model, B, n, K, L, masked, seed_feats):
         am[0, K - 3:] = 0                  # every image shorter than K: the clip (AttModel.py:98-105) moves the mask shapes too
         am[1:, K - 2:] = 0
         am[B - 1, K // 2:] = 0
-        Kc = K - 2
+        Kc = int(am.sum(1).max())
     N = B * n
     dv = lambda t: None if t is None else t.to(DEV)                    # noqa: E731
 
