@@ -350,6 +350,7 @@ def main():
     ar_events = None          # (start, end) events around the all-reduce of the steps that measure it
 
     mode_now = {'overlap': overlap, 'sharded': sharded, 'none': False}
+    early_adam = (os.environ.get('CAPMI_EARLY_ADAM', '0') == '1' and dist is None and args.config == 'updown_scst')
     one = torch.ones((), dtype=torch.float32, device=dev)
 
     def step():
@@ -362,11 +363,15 @@ def main():
         if loss.dim():
             loss = loss.mean()
         flat.zero_grad()
-        loss.backward(gradient=one if loss.dim() == 0 else None)       # (a cached 1.0: autograd's ones_like is an ATen fill launch)
-        flat.collect_grads()
         adam = dict(lr=opt.learning_rate, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon,
                     weight_decay=opt.weight_decay, clip_value=opt.grad_clip_value)
-        if overlap:
+        if early_adam:      # experiment (profiles/r05_scst_overlap.md): the logit layer's update under the BPTT loop
+            flat.begin_early_adam(**adam)
+        loss.backward(gradient=one if loss.dim() == 0 else None)       # (a cached 1.0: autograd's ones_like is an ATen fill launch)
+        flat.collect_grads()
+        if early_adam:
+            flat.finish_early_adam()
+        elif overlap:
             # the backward has already launched the all-reduce of every gradient bucket it finished (logit layer before
             # the BPTT loop, LSTM weights before the attention/prefill gradients); reduce the rest and run clip+Adam
             # bucket by bucket as the collectives land

@@ -79,5 +79,7 @@ int launch_lc(const KArgs &a, int b_layout, hipStream_t st, int pcls, double byt
 
 // fat GEMMs through the bf16 pipe by exact 3-way operand splitting; defined in gemm_x3.hip
 int launch_x3(const KArgs &a, int a_layout, int b_layout, dim3 grid, hipStream_t st, int pcls, double bytes, double flops);
+// ... on 256 x 128 tiles (gemm_x3w.hip, r5); grid = (gn, gm of the 256-row tiling, splits)
+int launch_x3w(const KArgs &a, int a_layout, int b_layout, dim3 grid, hipStream_t st, int pcls, double bytes, double flops);
 
 }  // namespace capmi_gemm

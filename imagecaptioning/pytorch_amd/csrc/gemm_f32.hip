@@ -592,19 +592,32 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
                 (uint64_t)(d->a_layout == 0 ? d->M : 1) * (uint64_t)a.seg[s].lda * 4 < (1ull << 32) &&
                 (uint64_t)(d->b_layout == 0 ? d->N : 1) * (uint64_t)a.seg[s].ldb * 4 < (1ull << 32);
     int splits = d->splits;
-    if (splits == 0 && x3_ok) {
+    // r5: the same arithmetic on 256 x 128 tiles (gemm_x3w.hip) when that tiling is cheaper: a wide unit costs X3W_COST / 100 of
+    // two narrow ones per K tile (fewer staging instructions per MFMA) but rounds M up to 256 and halves the number of units.
+    // CAPMI_X3_TILE = 128 / 256 forces one tiling (0: by cost).
+    static const int env_tile = capmi::knob("CAPMI_X3_TILE", 0);
+    static const int env_wcost = capmi::knob("CAPMI_X3W_COST", 150);
+    bool wide = false;
+    const int gmw = (d->M + 255) / 256;
+    if (x3_ok) {
         // persistent kernel, one workgroup per CU: pick the K split that minimises (rounds x K tiles per unit) plus the
-        // slab traffic it causes, in units of one K-tile step (~1.5 us; slabs move at ~4 TB/s)
-        const int out_tiles = gm * gn;
+        // slab traffic it causes, in units of one K-tile step of the narrow kernel (~1.5 us; slabs move at ~4 TB/s)
         double best = 1e30;
-        splits = 1;
-        for (int sp = 1; sp <= 16 && sp <= tiles; ++sp) {
-            if (sp > 1 && (!d->partial || (int64_t)sp * d->M * d->N > slab_cap)) break;
-            const double rounds = (double)((out_tiles * sp + 255) / 256);
-            const double slab_us = sp > 1 ? (2.0 * sp + 1.0) * d->M * (double)d->N * 4.0 / 4.0e6 : 0.0;
-            const double cost = rounds * ((tiles + sp - 1) / sp) + slab_us / 1.5;
-            if (cost < best) { best = cost; splits = sp; }
+        int best_sp = 1;
+        const int sp_lo = splits > 0 ? splits : 1, sp_hi = splits > 0 ? splits : 16;
+        for (int w = 0; w < 2; ++w) {
+            if ((w == 0 && env_tile == 256) || (w == 1 && env_tile == 128)) continue;
+            const int out_tiles = (w ? gmw : gm) * gn;
+            const double step = w ? env_wcost / 100.0 : 1.0;
+            for (int sp = sp_lo; sp <= sp_hi && sp <= tiles; ++sp) {
+                if (splits == 0 && sp > 1 && (!d->partial || (int64_t)sp * d->M * d->N > slab_cap)) break;
+                const double rounds = (double)((out_tiles * sp + 255) / 256);
+                const double slab_us = sp > 1 ? (2.0 * sp + 1.0) * d->M * (double)d->N * 4.0 / 4.0e6 : 0.0;
+                const double cost = rounds * ((tiles + sp - 1) / sp) * step + slab_us / 1.5;
+                if (cost < best) { best = cost; best_sp = sp; wide = (w == 1); }
+            }
         }
+        if (splits == 0) splits = best_sp;
     } else if (splits == 0) {
         // aim for ~2 workgroups per CU (512) but keep >= 4 K tiles per slice
         const int blocks = gm * gn;
@@ -629,12 +642,13 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     d->splits_used = splits;
     static const int env_log = capmi::knob("CAPMI_GEMM_LOG", 0);   // shape census on stderr (profiling)
     if (env_log)
-        fprintf(stderr, "capmi_gemm M=%d N=%d tiles=%d al=%d bl=%d x3=%d splits=%d defer=%d acc=%d\n", d->M, d->N, tiles, d->a_layout,
-                d->b_layout, (int)x3_ok, splits, d->defer_reduce, d->accumulate);
+        fprintf(stderr, "capmi_gemm M=%d N=%d tiles=%d al=%d bl=%d x3=%d wide=%d splits=%d defer=%d acc=%d\n", d->M, d->N, tiles,
+                d->a_layout, d->b_layout, (int)x3_ok, (int)(x3_ok && wide), splits, d->defer_reduce, d->accumulate);
     dim3 grid(gn, gm, splits);
     const ProfInfo pi{pcls, bytes, flops};
     int rc;
-    if (x3_ok) rc = launch_x3(a, d->a_layout, d->b_layout, grid, st, pcls, bytes, flops);
+    if (x3_ok && wide) rc = launch_x3w(a, d->a_layout, d->b_layout, dim3(gn, gmw, splits), st, pcls, bytes, flops);
+    else if (x3_ok) rc = launch_x3(a, d->a_layout, d->b_layout, grid, st, pcls, bytes, flops);
     else if (BM == 32 && BN == 128) rc = launch_cfg<32, 128, 1, 4, 3>(a, d->a_layout, d->b_layout, grid, st, pi);
     else if (BM == 64 && BN == 64) rc = launch_cfg<64, 64, 2, 2, 3>(a, d->a_layout, d->b_layout, grid, st, pi);
         else if (BM == 64 && BN == 128) rc = launch_cfg<64, 128, 1, 4, 2>(a, d->a_layout, d->b_layout, grid, st, pi);

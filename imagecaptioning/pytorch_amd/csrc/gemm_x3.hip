@@ -19,7 +19,7 @@
 // quad (4 consecutive k of one row, 3 planes) is three ds_write_b64.  K-major sources ([K][M] gradients / activations
 // of dW = dG^T X) are fetched as 4x4 blocks (16-byte loads along the contiguous dimension) and transposed in
 // registers, so the same row-quad store applies without an LDS transpose.
-#include "gemm_common.h"
+#include "gemm_x3_common.h"
 #include "profile.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
@@ -29,8 +29,6 @@ namespace {
 
 constexpr int XBM = 128, XBN = 128, XP = 40;       // row pitch in bf16 elements (80 bytes)
 constexpr int XPLANE = 128 * XP;                    // bf16 elements per plane
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 static_assert(BK == 32, "gemm_x3 assumes 32-wide K tiles");
 
@@ -41,10 +39,6 @@ static_assert(BK == 32, "gemm_x3 assumes 32-wide K tiles");
 // The staging waves share their SIMD's issue slots with the MFMA waves (~5 filler slots per 32-cycle MFMA), so the
 // per-tile instruction count matters: row clamps / validity are computed ONCE (Stager), interior tiles (the common
 // case) skip the zeroing multiplies entirely.
-typedef const float __attribute__((address_space(1))) *gcf;
-typedef const f32x4 __attribute__((address_space(1))) *gcf4;
-
-typedef const char __attribute__((address_space(1))) *gcb;
 
 // Addresses are (workgroup-uniform base: src + k0 ...) + (per-lane 32-bit byte offset fixed per output tile), which the
 // compiler turns into SGPR-base global loads: no per-load 64-bit VALU address arithmetic.
@@ -126,11 +120,6 @@ struct Stager {
     }
 };
 
-__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
-__device__ __forceinline__ float bfloat(uint32_t b) { return __builtin_bit_cast(float, b); }
-// upper halves of two fp32 bit patterns -> one dword of two bf16 (v_perm_b32: bytes 2,3 of lo, bytes 2,3 of hi)
-__device__ __forceinline__ uint32_t pack2(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
-
 // registers -> three bf16 planes in LDS
 template <bool KC, bool EDGE>
 __device__ __forceinline__ void x3_r2s(const float (&r)[16], const float (&f)[4], unsigned short *dst, int tid) {
@@ -172,9 +161,6 @@ __device__ __forceinline__ void x3_r2s(const float (&r)[16], const float (&f)[4]
 [[maybe_unused]] constexpr int XNT = 512;   // (ablation builds)
 constexpr int XSTAGE = 6 * XPLANE;            // bf16 elements per stage: 3 planes x (A, B) = 60 KB
 
-struct Unit {
-    int m0, n0, z, t_begin, nt;
-};
 __device__ __forceinline__ Unit unit_of(const KArgs &a, int u, int gm, int gn) {
     const int per = gm * gn;
     // XCD-aware order: workgroup b runs on XCD b % 8 (each XCD has its own L2).  Within a full round of the grid,
@@ -193,80 +179,6 @@ __device__ __forceinline__ Unit unit_of(const KArgs &a, int u, int gm, int gn) {
     r.t_begin = (int)(((long long)a.tiles_total * z) / a.splits);
     r.nt = (int)(((long long)a.tiles_total * (z + 1)) / a.splits) - r.t_begin;
     return r;
-}
-
-// ---- epilogue of one output unit: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-template <int NJ>
-__device__ __forceinline__ void x3_epilogue(const KArgs &a, const Unit &un, const f32x16 (&acc)[2][NJ], int wm0, int wn0, int l31,
-                                            int half) {
-    const bool to_partial = a.to_partial != 0;
-    float *out = to_partial ? a.partial + (size_t)un.z * a.M * a.N : a.C;
-    const int ldo = to_partial ? a.N : a.ldc;
-    const bool plain = to_partial || !(a.bias || a.bias2 || a.row_bias || a.relu || a.mul_mask || a.accumulate);
-    // the column biases of all NJ column blocks are requested up front: read inside the (i, j) loop each was a memory round trip
-    // in front of its block's stores (r4, scripts/tools_epilogue_bench.py: bias + ReLU cost an FFN GEMM 104 -> 134 us)
-    float cbv[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int col = min(un.n0 + wn0 + 32 * j + l31, a.N - 1);
-        cbv[j] = 0.f;
-        if (!plain) {
-            if (a.bias) cbv[j] += a.bias[col];
-            if (a.bias2) cbv[j] += a.bias2[col];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int col = un.n0 + wn0 + 32 * j + l31;
-            if (col >= a.N) continue;
-            if (plain) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = un.m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row < a.M) out[(size_t)row * ldo + col] = acc[i][j][r];
-                }
-                continue;
-            }
-            const float cb = cbv[j];
-            if (!(a.row_bias || a.mul_mask || a.accumulate)) {          // bias / ReLU only: nothing to fetch per element
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = un.m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row >= a.M) continue;
-                    float v = acc[i][j][r] + cb;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    out[(size_t)row * ldo + col] = v;
-                }
-                continue;
-            }
-            // the per-element operands of 8 rows are requested before the first of them is used: the compiler may not move a load
-            // across the store of the previous row (C, the mask and the addend are plain pointers), so the rolled form was one
-            // memory round trip per row with the MFMA pipe of the wave idle (r4: a gate + mask epilogue cost an FFN dX GEMM
-            // 56 -> 83 us)
-#pragma unroll
-            for (int r0 = 0; r0 < 16; r0 += 8) {
-                float mk[8], ad[8], rb[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int r = r0 + u;
-                    const int row = min(un.m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half, a.M - 1);
-                    rb[u] = a.row_bias ? a.row_bias[(size_t)(row / a.row_bias_div) * a.N + col] : 0.f;
-                    mk[u] = a.mul_mask ? a.mul_mask[(size_t)row * a.N + col] : 1.f;
-                    ad[u] = a.accumulate ? a.addend[(size_t)row * a.ldc + col] : 0.f;      // (not to_partial: out == C)
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int r = r0 + u;
-                    const int row = un.m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row >= a.M) continue;
-                    float v = acc[i][j][r] + cb + rb[u];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    out[(size_t)row * ldo + col] = v * mk[u] + ad[u];
-                }
-            }
-        }
 }
 
 // ---------------- staging waves: HBM -> registers -> split -> LDS planes ----------------

@@ -1,0 +1,99 @@
+// Pieces shared by the two bf16x3 fat-GEMM kernels (gemm_x3.hip: 128 x 128 tile; gemm_x3w.hip: 256 x 128 tile): operand-split
+// bit helpers, the unit descriptor of the persistent grids and the epilogue of one output unit.
+#pragma once
+#include "gemm_common.h"
+
+namespace capmi_gemm {
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef const float __attribute__((address_space(1))) *gcf;
+typedef const f32x4 __attribute__((address_space(1))) *gcf4;
+typedef const char __attribute__((address_space(1))) *gcb;
+
+__device__ __forceinline__ uint32_t fbits(float x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ float bfloat(uint32_t b) { return __builtin_bit_cast(float, b); }
+// upper halves of two fp32 bit patterns -> one dword of two bf16 (v_perm_b32: bytes 2,3 of lo, bytes 2,3 of hi)
+__device__ __forceinline__ uint32_t pack2(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
+
+struct Unit {
+    int m0, n0, z, t_begin, nt;
+};
+
+// ---- epilogue of one output unit: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+template <int NJ>
+__device__ __forceinline__ void x3_epilogue(const KArgs &a, const Unit &un, const f32x16 (&acc)[2][NJ], int wm0, int wn0, int l31,
+                                            int half) {
+    const bool to_partial = a.to_partial != 0;
+    float *out = to_partial ? a.partial + (size_t)un.z * a.M * a.N : a.C;
+    const int ldo = to_partial ? a.N : a.ldc;
+    const bool plain = to_partial || !(a.bias || a.bias2 || a.row_bias || a.relu || a.mul_mask || a.accumulate);
+    // the column biases of all NJ column blocks are requested up front: read inside the (i, j) loop each was a memory round trip
+    // in front of its block's stores (r4, scripts/tools_epilogue_bench.py: bias + ReLU cost an FFN GEMM 104 -> 134 us)
+    float cbv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int col = min(un.n0 + wn0 + 32 * j + l31, a.N - 1);
+        cbv[j] = 0.f;
+        if (!plain) {
+            if (a.bias) cbv[j] += a.bias[col];
+            if (a.bias2) cbv[j] += a.bias2[col];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = un.n0 + wn0 + 32 * j + l31;
+            if (col >= a.N) continue;
+            if (plain) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = un.m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row < a.M) out[(size_t)row * ldo + col] = acc[i][j][r];
+                }
+                continue;
+            }
+            const float cb = cbv[j];
+            if (!(a.row_bias || a.mul_mask || a.accumulate)) {          // bias / ReLU only: nothing to fetch per element
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = un.m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row >= a.M) continue;
+                    float v = acc[i][j][r] + cb;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    out[(size_t)row * ldo + col] = v;
+                }
+                continue;
+            }
+            // the per-element operands of 8 rows are requested before the first of them is used: the compiler may not move a load
+            // across the store of the previous row (C, the mask and the addend are plain pointers), so the rolled form was one
+            // memory round trip per row with the MFMA pipe of the wave idle (r4: a gate + mask epilogue cost an FFN dX GEMM
+            // 56 -> 83 us)
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                float mk[8], ad[8], rb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = r0 + u;
+                    const int row = min(un.m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half, a.M - 1);
+                    rb[u] = a.row_bias ? a.row_bias[(size_t)(row / a.row_bias_div) * a.N + col] : 0.f;
+                    mk[u] = a.mul_mask ? a.mul_mask[(size_t)row * a.N + col] : 1.f;
+                    ad[u] = a.accumulate ? a.addend[(size_t)row * a.ldc + col] : 0.f;      // (not to_partial: out == C)
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = r0 + u;
+                    const int row = un.m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row >= a.M) continue;
+                    float v = acc[i][j][r] + cb + rb[u];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    out[(size_t)row * ldo + col] = v * mk[u] + ad[u];
+                }
+            }
+        }
+}
+
+}  // namespace
+}  // namespace capmi_gemm

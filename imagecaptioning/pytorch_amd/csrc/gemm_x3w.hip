@@ -1,0 +1,363 @@
+// bf16x3 fat GEMM, WIDE tile (round 5): 256 x 128 x 32 per workgroup -- the same exact 3-way operand split and the same six
+// v_mfma_f32_32x32x16_bf16 per fp32 MAC tile as gemm_x3.hip (see its header for the arithmetic), other proportions.
+//
+// Why: the 128 x 128 kernel's K loop runs at ~2 500 cycles per K tile against 1 536 of MFMA per SIMD (profiles/r03_x3pl_probe.md,
+// r04_fat_gemm_epilogue.md).  Its SIMDs are ISSUE-bound, not pipe-bound: beside the 48 MFMAs of a K tile a SIMD also has to issue
+// its share of the operand split -- 256 rows x 32 k of fp32 -> three bf16 planes = 5.5 VALU per element, ~230 instructions of the
+// two staging waves -- plus 24 ds_read_b128 of the MFMA wave: ~5.5 issues per MFMA gap where ~5 hide (MI355X_MICROARCH.md,
+// "single-issue instructions HIDDEN per v_mfma gap").  A 256 x 128 tile stages (256 + 128) rows for TWICE the MFMAs:
+//     per SIMD and K tile: 96 MFMAs (two MFMA waves) | 12 loads + 264 split VALU + 36 ds_write_b64 (staging) | 48 ds_read_b128
+//     = ~4.0 issues per MFMA gap, and a fragment set read from LDS still feeds 24 MFMAs.
+// Two MFMA waves share each SIMD: while one waits for its ds_reads the other's MFMAs keep the pipe busy, so the loop needs no
+// software pipelining (and no second fragment register set).
+//
+// LDS: a stage is 3 planes x (256 + 128) rows x 32 k bf16.  With the 80-byte padded rows of gemm_x3.hip two stages would take
+// 184 KB; here a row is exactly 64 bytes and its four 16-byte pieces are XOR-swizzled by (row >> 2) & 3, which makes the 16 lanes
+// of every ds_read_b128 lane group (rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of a 32-row block) hit 16 distinct bank quads:
+// 2 stages = 144 KB, one workgroup per CU, persistent over a unit list like the 128 x 128 kernel.
+//
+// Edges: rows beyond M / N are clamped to a valid address at fetch time and zeroed when the registers are split; the facts needed
+// for that (valid rows of the three 128-row operand blocks, valid k of the tile) are workgroup-uniform and ride along with the
+// register set as scalars -- no per-quad keep-factor registers.
+#include "gemm_x3_common.h"
+#include "profile.h"
+#include <hip/hip_ext.h>
+#include <stdlib.h>
+
+namespace capmi_gemm {
+namespace {
+
+constexpr int WBM = 256, WBN = 128;
+constexpr int WPL_A = WBM * 32, WPL_B = WBN * 32;          // bf16 elements per plane
+constexpr int WSTAGE = 3 * (WPL_A + WPL_B);                // 36 864 elements = 72 KB
+static_assert(BK == 32, "gemm_x3w assumes 32-wide K tiles");
+
+// element index of (row, k) inside a plane: 64-byte rows, 16-byte pieces swizzled by s = (row >> 2) & 3 (reads, above), and the row
+// itself stored in slot row ^ s of its aligned group of four: a [K][rows] operand is staged as 4 x 4 blocks, so the 8 lanes that
+// write one k quad hold rows 4i + p -- 256 bytes apart, i.e. the SAME 16 banks (8-way conflict on every ds_write_b64); with the
+// slot XOR they spread over the four 64-byte windows (2-way, what the padded rows of gemm_x3.hip get).  Reads are unaffected: an
+// aligned group of four rows still covers its own 256 bytes.
+__device__ __forceinline__ int wswz(int row, int k) {
+    const int s = (row >> 2) & 3;
+    return (row ^ s) * 32 + ((((k >> 3) ^ s) & 3) << 3) + (k & 7);
+}
+
+// One 128-row block of an operand: HBM -> 16 floats per thread (4 quads of 4 consecutive k of one row), branch-free with a fixed
+// number of loads (see gemm_x3.hip Stager for why); 256 threads.
+template <bool KC>
+struct WStager {
+    gcb src;
+    unsigned voff[4];     // KC: byte offset of (clamped row, in-tile k) per quad; k-major: voff[0] = (4kg * ld + clamped column) * 4
+    unsigned voff0;       // k-major: the kg = 0 variant of voff[0]
+    int ld, K, kq0, valid_rows;
+    __device__ __forceinline__ void init(const float *src_, int ld_, int K_) {
+        src = (gcb)(uintptr_t)src_;
+        ld = ld_; K = K_;
+    }
+    __device__ __forceinline__ void set_tile(int row0, int nrows, int tid) {
+        valid_rows = min(max(nrows - row0, 0), 128);
+        if (KC) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int idx = p * NT + tid;
+                const int row = row0 + idx / 8;
+                voff[p] = ((unsigned)min(row, nrows - 1) * (unsigned)ld + (unsigned)(idx % 8) * 4u) * 4u;
+            }
+            kq0 = (tid & 7) * 4;
+        } else {
+            const int lane = tid & 63, kg = lane >> 3, mq = (tid >> 6) * 8 + (lane & 7);
+            const int row = row0 + 4 * mq;
+            voff0 = (unsigned)min(row, nrows - 4) * 4u;
+            voff[0] = (unsigned)(4 * kg) * (unsigned)ld * 4u + voff0;
+            kq0 = 4 * kg;
+        }
+    }
+    __device__ __forceinline__ void fetch(float (&r)[16], int k0) const {
+        const bool inside = k0 + kq0 < K;                      // per lane; false only in the last tile of a segment
+        if (KC) {
+            const unsigned back = inside ? 0u : (unsigned)kq0 * 4u;      // -> the tile's first quad of the same row
+            gcb b = src + (size_t)k0 * 4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const f32x4 v = *(gcf4)(b + (voff[p] - back));
+                r[4 * p] = v[0]; r[4 * p + 1] = v[1]; r[4 * p + 2] = v[2]; r[4 * p + 3] = v[3];
+            }
+        } else {
+            const unsigned off = inside ? voff[0] : voff0;
+            const size_t ld4 = (size_t)ld * 4;
+            gcb b = src + (size_t)k0 * ld4;
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = *(gcf4)(b + off);
+                b += ld4;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[4 * i + j] = v[j][i];       // quad i = row 4mq+i, k = 4kg..4kg+3
+        }
+    }
+};
+
+// registers of one 128-row block -> three bf16 planes (plane pitch PLANE elements) at dst = plane 0, first row of the block
+template <bool KC, bool EDGE, int PLANE>
+__device__ __forceinline__ void w_r2s(const float (&r)[16], unsigned short *dst, int tid, int valid_rows, int valid_k) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int row, kq;
+        if (KC) {
+            const int idx = p * NT + tid;
+            row = idx / 8;
+            kq = (idx % 8) * 4;
+        } else {
+            const int lane = tid & 63;
+            row = 4 * ((tid >> 6) * 8 + (lane & 7)) + p;
+            kq = 4 * (lane >> 3);
+        }
+        // K % 4 == 0 (host checks): a quad of k is entirely inside or outside K
+        const float fac = (!EDGE || (row < valid_rows && kq < valid_k)) ? 1.f : 0.f;
+        uint32_t h[4], m[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = EDGE ? r[4 * p + j] * fac : r[4 * p + j];
+            h[j] = fbits(x);
+            const float r1 = x - bfloat(h[j] & 0xffff0000u);            // exact
+            m[j] = fbits(r1);
+            l[j] = fbits(r1 - bfloat(m[j] & 0xffff0000u));              // exact, <= 8 significant bits
+        }
+        unsigned short *o = dst + wswz(row, kq);
+        *reinterpret_cast<u32x2 *>(o) = u32x2{pack2(h[0], h[1]), pack2(h[2], h[3])};
+        *reinterpret_cast<u32x2 *>(o + PLANE) = u32x2{pack2(m[0], m[1]), pack2(m[2], m[3])};
+        *reinterpret_cast<u32x2 *>(o + 2 * PLANE) = u32x2{pack2(l[0], l[1]), pack2(l[2], l[3])};
+    }
+}
+
+__device__ __forceinline__ Unit wunit_of(const KArgs &a, int u, int gm, int gn) {
+    const int per = gm * gn;
+    {   // XCD-aware order (see gemm_x3.hip unit_of): every XCD walks a contiguous run of output tiles
+        const int G = gridDim.x, total = per * a.splits;
+        const int b = u % G, r = u / G;
+        if ((G & 7) == 0 && (r + 1) * G <= total) u = (b & 7) * (G >> 3) + (b >> 3) + r * G;
+    }
+    const int z = u / per, tile = u - z * per;
+    Unit r;
+    r.z = z;
+    r.m0 = (tile / gn) * WBM;
+    r.n0 = (tile % gn) * WBN;
+    r.t_begin = (int)(((long long)a.tiles_total * z) / a.splits);
+    r.nt = (int)(((long long)a.tiles_total * (z + 1)) / a.splits) - r.t_begin;
+    return r;
+}
+
+// uniform facts of one staged K tile, carried beside its register set
+struct WEdge {
+    int va0, va1, vb, vk;     // valid rows of A block 0 / 1 and of B, valid k of the tile
+    bool edge;                // any of them short of a full block
+};
+
+// DOA / DOB: this wave stages the A blocks / the B block (NSW = 4: one staging wave per SIMD does both; NSW = 8: two per SIMD, the
+// first takes A -- two thirds of the split -- the second B)
+template <bool AKC, bool BKC, bool DOA, bool DOB>
+__device__ __forceinline__ void w_staging(const KArgs &a, int gm, int gn, int units, int tid, unsigned short *smem) {
+    // ONE register set (A block 0, A block 1, B: 48 floats per thread): the loads of K tile g+2 are issued right behind the split of
+    // tile g+1 and consumed a whole K-tile period later -- >= 3 072 MFMA cycles per SIMD, the prefetch distance the 128 x 128
+    // kernel gets from two sets (2 x 1 536).  Two sets (96 floats + 12 offsets + the split's temporaries) do not fit the 168
+    // registers that 3 waves per SIMD leave: the compiler spilled, and every wait degenerated to vmcnt(0).
+    float ra[16], rc[16], rb[16];
+    WEdge e{};
+    WStager<AKC> sa0, sa1;
+    WStager<BKC> sb;
+    auto bind = [&](int sidx, int m0_, int n0_) {
+#define CAPMI_X3W_SEG(I)                                                  \
+    case I:                                                               \
+        sa0.init(a.seg[I].A, a.seg[I].lda, a.seg[I].K);                   \
+        sa1.init(a.seg[I].A, a.seg[I].lda, a.seg[I].K);                   \
+        sb.init(a.seg[I].B, a.seg[I].ldb, a.seg[I].K);                    \
+        break;
+        switch (sidx) {
+            CAPMI_X3W_SEG(0) CAPMI_X3W_SEG(1) CAPMI_X3W_SEG(2) CAPMI_X3W_SEG(3)
+        }
+#undef CAPMI_X3W_SEG
+        sa0.set_tile(m0_, a.M, tid);
+        sa1.set_tile(m0_ + 128, a.M, tid);
+        sb.set_tile(n0_, a.N, tid);
+    };
+    int fu = blockIdx.x, f_left = 0, f_sleft = 0, f_k0 = 0, f_s = 0, f_m0 = 0, f_n0 = 0;
+    auto open_unit = [&]() {
+        const Unit un = wunit_of(a, fu, gm, gn);
+        int sidx, k0;
+        locate(a, un.t_begin, sidx, k0);
+        f_s = __builtin_amdgcn_readfirstlane(sidx);
+        f_k0 = k0; f_left = un.nt; f_m0 = un.m0; f_n0 = un.n0;
+        bind(f_s, f_m0, f_n0);
+        f_sleft = (sa0.K - k0 + BK - 1) / BK;
+    };
+    if (fu < units) open_unit();
+    else bind(0, 0, 0);                                  // (never fetched for real: steps == 0)
+    auto fetch = [&](float (&xa0)[16], float (&xa1)[16], float (&xb)[16], WEdge &ed) {
+        if (DOA) sa0.fetch(xa0, f_k0);
+        if (DOA) sa1.fetch(xa1, f_k0);
+        if (DOB) sb.fetch(xb, f_k0);
+        ed.va0 = sa0.valid_rows; ed.va1 = sa1.valid_rows; ed.vb = sb.valid_rows;
+        ed.vk = min(sa0.K - f_k0, BK);
+        ed.edge = (DOA && (ed.va0 < 128 || ed.va1 < 128)) || (DOB && ed.vb < 128) || ed.vk < BK;
+        if (f_left > 0) {                              // workgroup-uniform
+            if (--f_left == 0) {
+                fu += gridDim.x;
+                if (fu < units) open_unit();
+            } else if (--f_sleft == 0) {
+                bind(++f_s, f_m0, f_n0);
+                f_k0 = 0;
+                f_sleft = (sa0.K + BK - 1) / BK;
+            } else {
+                f_k0 += BK;
+            }
+        }
+    };
+    int steps = 0;
+    for (int u = blockIdx.x; u < units; u += gridDim.x) steps += wunit_of(a, u, gm, gn).nt;
+    auto store = [&](const float (&xa0)[16], const float (&xa1)[16], const float (&xb)[16], const WEdge &ed, int g) {
+        unsigned short *st = smem + (g & 1) * WSTAGE;
+        if (ed.edge) {
+            if (DOA) w_r2s<AKC, true, WPL_A>(xa0, st, tid, ed.va0, ed.vk);
+            if (DOA) w_r2s<AKC, true, WPL_A>(xa1, st + 128 * 32, tid, ed.va1, ed.vk);
+            if (DOB) w_r2s<BKC, true, WPL_B>(xb, st + 3 * WPL_A, tid, ed.vb, ed.vk);
+        } else {
+            if (DOA) w_r2s<AKC, false, WPL_A>(xa0, st, tid, 128, BK);
+            if (DOA) w_r2s<AKC, false, WPL_A>(xa1, st + 128 * 32, tid, 128, BK);
+            if (DOB) w_r2s<BKC, false, WPL_B>(xb, st + 3 * WPL_A, tid, 128, BK);
+        }
+    };
+    fetch(ra, rc, rb, e);                              // step 0
+    if (steps > 0) store(ra, rc, rb, e, 0);
+    fetch(ra, rc, rb, e);                              // step 1
+    __syncthreads();                                   // stage 0 ready
+    for (int g = 0; g < steps; ++g) {
+        if (g + 1 < steps) store(ra, rc, rb, e, g + 1);   // into the stage the MFMA waves released at the previous barrier
+        fetch(ra, rc, rb, e);                             // step g + 2
+        __syncthreads();
+    }
+}
+
+// Waves 0-7 are MFMA waves (64 x 64 each: 4 along M x 2 along N), waves 8.. staging waves.  Waves are dealt to the SIMDs round
+// robin, so every SIMD holds two MFMA waves and NSW / 4 staging waves.
+template <bool AKC, bool BKC, int NSW>
+__global__ __launch_bounds__(512 + 64 * NSW) void gemm_x3w_kernel(const KArgs a, int gm, int gn, int prio) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];      // 2 stages = 144 KB
+    const int units = gm * gn * a.splits;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+
+    if (wid >= 8) {
+        // (experiment knob CAPMI_X3W_PRIO: the staging waves are the youngest of their SIMD and lose the VALU arbitration by age)
+        if (prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (prio == 3) __builtin_amdgcn_s_setprio(3);
+        if (NSW == 4) w_staging<AKC, BKC, true, true>(a, gm, gn, units, threadIdx.x - 512, smem);
+        else if (wid < 12) w_staging<AKC, BKC, true, false>(a, gm, gn, units, threadIdx.x - 512, smem);
+        else w_staging<AKC, BKC, false, true>(a, gm, gn, units, threadIdx.x - 768, smem);
+        return;
+    }
+    const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
+    const int l31 = lane & 31, half = lane >> 5;
+    // fragment offsets inside a plane (elements), fixed for the whole kernel: [q][ks]
+    int offA[2][2], offB[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            offA[q][ks] = wswz(wm0 + 32 * q + l31, 16 * ks + 8 * half);
+            offB[q][ks] = wswz(wn0 + 32 * q + l31, 16 * ks + 8 * half);
+        }
+    __syncthreads();                                       // stage 0 ready
+    int g = 0;
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        const Unit un = wunit_of(a, u, gm, gn);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int i = 0; i < un.nt; ++i, ++g) {
+            const unsigned short *As = smem + (g & 1) * WSTAGE, *Bs = As + 3 * WPL_A;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 av[2][3], bv[2][3];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        av[q][pl] = *reinterpret_cast<const bf16x8 *>(As + pl * WPL_A + offA[q][ks]);
+                        bv[q][pl] = *reinterpret_cast<const bf16x8 *>(Bs + pl * WPL_B + offB[q][ks]);
+                    }
+                // six of the nine cross terms, small ones first (planes: 0 = h, 1 = m, 2 = l) -- the order of gemm_x3.hip
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][2], bv[j][0], acc[q][j], 0, 0, 0);
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][2], acc[q][j], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][1], acc[q][j], 0, 0, 0);
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][0], acc[q][j], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][1], acc[q][j], 0, 0, 0);
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][0], acc[q][j], 0, 0, 0);
+                    }
+            }
+            __syncthreads();                               // stage g&1 released, stage (g+1)&1 ready
+        }
+        x3_epilogue<2>(a, un, acc, wm0, wn0, l31, half);
+    }
+}
+
+}  // namespace
+
+int launch_x3w(const KArgs &a, int a_layout, int b_layout, dim3 tiles, hipStream_t st, int pcls, double bytes, double flops) {
+    // tiles = (gn, gm, splits) of the 256 x 128 tiling; persistent grid: one workgroup per CU walks the unit list
+    const int gn = tiles.x, gm = tiles.y;
+    const int units = gn * gm * a.splits;
+    const dim3 grid(units < 256 ? units : 256);
+    hipEvent_t e0, e1;
+    const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
+    constexpr size_t lds = 2 * (size_t)WSTAGE * sizeof(unsigned short);
+    static_assert(lds <= 160 * 1024, "two stages must fit the CU's LDS");
+    static const int env_nsw = capmi::knob("CAPMI_X3W_NSW", 4), env_prio = capmi::knob("CAPMI_X3W_PRIO", 0);
+#define CAPMI_X3W_N(AK, BK_, NSW_)                                                                              \
+    do {                                                                                                        \
+        static bool attr_set = false;                                                                           \
+        if (!attr_set) {                                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_x3w_kernel<AK, BK_, NSW_>),          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+            attr_set = true;                                                                                    \
+        }                                                                                                       \
+        const dim3 blk(512 + 64 * NSW_);                                                                        \
+        if (prof) hipExtLaunchKernelGGL((gemm_x3w_kernel<AK, BK_, NSW_>), grid, blk, lds, st, e0, e1, 0, a, gm, gn, env_prio); \
+        else hipLaunchKernelGGL((gemm_x3w_kernel<AK, BK_, NSW_>), grid, blk, lds, st, a, gm, gn, env_prio);     \
+    } while (0)
+#define CAPMI_X3W_GO(AK, BK_)                                                                                   \
+    do {                                                                                                        \
+        if (env_nsw == 8) CAPMI_X3W_N(AK, BK_, 8);                                                              \
+        else CAPMI_X3W_N(AK, BK_, 4);                                                                           \
+    } while (0)
+    if (a_layout == 0 && b_layout == 0) CAPMI_X3W_GO(true, true);
+    else if (a_layout == 0 && b_layout == 1) CAPMI_X3W_GO(true, false);
+    else if (a_layout == 1 && b_layout == 1) CAPMI_X3W_GO(false, false);
+    else CAPMI_X3W_GO(false, true);
+#undef CAPMI_X3W_GO
+#undef CAPMI_X3W_N
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace capmi_gemm

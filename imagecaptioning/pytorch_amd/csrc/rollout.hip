@@ -228,6 +228,23 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
     int ee_pending = -1, ee_slot = 0, steps_run = T;
     const int ee_from = r->early_exit_from > 0 ? r->early_exit_from : 0;
 
+    // r5: teacher forcing knows every INPUT token up front too (AttModel.py:140-164): the token-embedding third of the attention-LSTM
+    // gates, xt(t) . W_ih[:, 2R:]^T, of all T steps is ONE fat GEMM over T*N rows before the loop instead of a K segment of each of the
+    // T per-step gate GEMMs (at N = 320 those are 192 units on 256 CUs; at N <= 64 each streamed the 16 MB weight slice again).  The
+    // product lands in gates_att[t] -- the slot the cell of step t overwrites with the activated gates -- and that cell reads it as a
+    // second slab set (every thread reads exactly the elements it then writes).
+    static const int env_bxt = capmi::knob("CAPMI_BATCHED_XT", 1);
+    const bool batched_xt = env_bxt && r->teacher && !sched && r->gates_att && r->xt &&
+                            (int64_t)T * N * 4 * R < ((int64_t)1 << 31);
+    if (batched_xt) {
+        for (int t = 0; t < T; ++t)
+            RC(capmi_embed_fwd_pl(r->forced + t, r->forced_ld, r->it_all ? r->it_all + (size_t)t * N : nullptr, w->embed,
+                                  r->drop_xt ? r->drop_xt + (size_t)t * N * E : nullptr, r->xt + (size_t)t * N * E, N, E, 1, nullptr,
+                                  stream));
+        SegSpec sx{r->xt, E, w->att_w_ih + 2 * R, ld_att_ih, E, 1};
+        RC(gemm(stream, 0, 0, T * N, 4 * R, r->gates_att, 4 * R, &sx, 1, r->partial, r->partial_capacity, 0, nullptr));
+    }
+
     static const bool ee_trace = capmi::research("CAPMI_EE_TRACE", 0) != 0;
     const auto ee_t0 = std::chrono::steady_clock::now();
     double ee_wait_us = 0;
@@ -256,7 +273,8 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
 
         // 1. token embedding (+ReLU +dropout).  Free-running rollouts: only step 0 launches it (BOS); afterwards the
         //    select kernel of step t-1 has already written xt (the workgroup that chose the token embeds it).
-        if (r->teacher && (!sched || t == 0))
+        if (batched_xt) {
+        } else if (r->teacher && (!sched || t == 0))
             RC(capmi_embed_fwd_pl(r->forced + t, r->forced_ld, r->it_all ? r->it_all + (size_t)t * N : nullptr, w->embed,
                                   r->drop_xt ? r->drop_xt + (size_t)t * N * E : nullptr, xt, N, E, 1, pl_xt, stream));
         else if (t == 0)
@@ -268,16 +286,23 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
             SegSpec s[3] = {{h_lang_prev, R, w->att_w_ih, ld_att_ih, R, 1, t ? pl_h_lang : pl_zero},
                             {xt, E, w->att_w_ih + 2 * R, ld_att_ih, E, 1, pl_xt},
                             {h_att_prev, R, w->att_w_hh, R, R, 1, t ? pl_h_att : pl_zero}};
-            if (preA_valid)     // the h_lang / h_att segments were computed inside the previous step's select launch
+            const float *slabs2 = preA_valid ? preA + CAPMI_WS_COUNTER_FLOATS : nullptr;
+            int splits2 = preA_valid ? preA_splits : 0;
+            if (batched_xt) {   // the token-embedding segment of every step was multiplied before the loop (into gates_att[t])
+                SegSpec s2[2] = {s[0], s[2]};
+                RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s2, 2, r->partial, r->partial_capacity, 1, &splits, nullptr,
+                        nullptr, 0, pl_zero));
+                slabs2 = r->gates_att + (size_t)t * N * 4 * R;
+                splits2 = 1;
+            } else if (preA_valid)     // the h_lang / h_att segments were computed inside the previous step's select launch
                 RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s + 1, 1, r->partial, r->partial_capacity, 1, &splits, nullptr,
                         nullptr, 0, pl_zero));
             else
                 RC(gemm(stream, 0, 0, N, 4 * R, r->partial, 4 * R, s, 3, r->partial, r->partial_capacity, 1, &splits, nullptr,
                         nullptr, 0, pl_zero));
-            RC(capmi_lstm_cell_fwd_pl2(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, preA_valid ? preA + CAPMI_WS_COUNTER_FLOATS : nullptr,
-                                       preA_valid ? preA_splits : 0, w->att_b_ih, w->att_b_hh, r->fc_gates, n, r->row_img,
-                                       c_att_prev, h_att, c_att, r->gates_att + (size_t)t * N * 4 * R, nullptr, nullptr, N, R,
-                                       pl_h_att, nullptr, stream));
+            RC(capmi_lstm_cell_fwd_pl2(r->partial + CAPMI_WS_COUNTER_FLOATS, splits, slabs2, splits2, w->att_b_ih, w->att_b_hh,
+                                       r->fc_gates, n, r->row_img, c_att_prev, h_att, c_att,
+                                       r->gates_att + (size_t)t * N * 4 * R, nullptr, nullptr, N, R, pl_h_att, nullptr, stream));
         }
         // 4-5. att_h = h_att W_h2att^T + b left as K-slice slabs; the fused region attention finishes the reduction
         //      (+ bias), keeps att_h for the backward pass and runs score + softmax + context
@@ -444,9 +469,14 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
     // bias gradients (column sums over all T*N rows): with every phase in this one call they are recorded and finished by ONE
     // launch at the end (4 launches + 3 zero-fills + 2 copies otherwise); a phased call (DDP bucket overlap) keeps each phase
     // complete when it returns
-    const bool batch_cols = (phases & CAPMI_BWD_ALL) == CAPMI_BWD_ALL;
+    // (r5: any call that covers two or more of the phases that produce column sums batches them -- the two-call form of the
+    //  early-Adam experiment, logit | everything else, keeps one batched launch for the second call)
+    const int col_phases = ((phases & CAPMI_BWD_LOGIT) ? 1 : 0) + ((phases & CAPMI_BWD_ATT_LSTM) ? 1 : 0) +
+                           ((phases & CAPMI_BWD_LANG_LSTM) ? 1 : 0) + ((phases & CAPMI_BWD_ATTENTION) ? 1 : 0);
+    const bool batch_cols = col_phases >= 2;
     capmi_colsum_item cols[CAPMI_COLSUM_ARGS_MAX];
     int n_cols = 0;
+    hipEvent_t side_join = nullptr;                 // set when a side-stream launch must be joined before returning
     auto colsum = [&](const float *in, int rows, int ncol, float *out, float *out2) -> int {
         if (batch_cols) {
             cols[n_cols++] = capmi_colsum_item{in, out, out2, rows, ncol, ncol, 0};
@@ -473,6 +503,25 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         SegSpec a{s->dlogits, V1, w->logit_w, R, V1, 1};   // d_hdrop = dlogits W_logit          [TN,R]
         RC(gemm(stream, 0, 1, TN, R, s->d_hdrop, R, &a, 1, P, cap, 0, nullptr));
         SegSpec b{s->dlogits, V1, a_hdrop, R, TN, 1};       // dW_logit = dlogits^T h_drop         [V1,R]
+        // r5 experiment (profiles/r05_scst_overlap.md): nothing reads dW_logit before the optimizer, so it can go to a side stream
+        // beside the time loop (CAPMI_BWD_SIDE=1; no split-K workspace: the loop owns P).  Off by default: measured.
+        static const int env_side = capmi::knob("CAPMI_BWD_SIDE", 0);
+        if (env_side && (phases & CAPMI_BWD_ALL) == CAPMI_BWD_ALL) {
+            int dev_i = 0;
+            if (hipGetDevice(&dev_i) != hipSuccess || dev_i < 0 || dev_i >= 16) return CAPMI_EINVAL;
+            static thread_local hipStream_t side_st[16] = {};
+            static thread_local hipEvent_t side_ev[16][2] = {};
+            if (!side_st[dev_i]) {
+                if (hipStreamCreateWithFlags(&side_st[dev_i], hipStreamNonBlocking) != hipSuccess) return CAPMI_EINVAL;
+                for (int i = 0; i < 2; ++i)
+                    if (hipEventCreateWithFlags(&side_ev[dev_i][i], hipEventDisableTiming) != hipSuccess) return CAPMI_EINVAL;
+            }
+            if (hipEventRecord(side_ev[dev_i][0], st) != hipSuccess) return CAPMI_EINVAL;          // dlogits, h_drop (packed) are ready
+            if (hipStreamWaitEvent(side_st[dev_i], side_ev[dev_i][0], 0) != hipSuccess) return CAPMI_EINVAL;
+            RC(gemm((void *)side_st[dev_i], 1, 1, V1, R, g->logit_w, R, &b, 1, nullptr, 0, 0, nullptr));
+            if (hipEventRecord(side_ev[dev_i][1], side_st[dev_i]) != hipSuccess) return CAPMI_EINVAL;
+            side_join = side_ev[dev_i][1];
+        } else
         RC(gemm(stream, 1, 1, V1, R, g->logit_w, R, &b, 1, P, cap, 0, nullptr));
         RC(colsum(s->dlogits, TN, V1, g->logit_b, nullptr));
     }
@@ -627,6 +676,7 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         if (dw_part) RC(colsum(dw_part, B * K, A, g->alpha_w, nullptr));
     }
     if (n_cols) RC(capmi_colsum_batch_args(cols, n_cols, stream));
+    if (side_join && hipStreamWaitEvent(st, side_join, 0) != hipSuccess) return CAPMI_EINVAL;
     return 0;
 }
 
