@@ -311,9 +311,13 @@ class AoAGraph:
         ops.matmul_tn(dg2, self.h_att[:T].reshape(TN, R), out=g['core.att_lstm.weight_hh'])
         ops.colsum(dg2, out=g['core.att_lstm.bias_ih'])
         g['core.att_lstm.bias_hh'].copy_(g['core.att_lstm.bias_ih'])
-        d_mean = ops.matmul_nn(sum_dg, W_ih[:, E:].contiguous())                      # [B,R]
+        # (r5: the W_ih column blocks are read in place -- [K = 4R][N] operands of pitch E + R -- instead of through
+        #  .contiguous() copies of 16 MB each: 2 copy launches, ~135 us per step)
+        d_mean = z(B, R)
+        ops.gemm([(sum_dg, 4 * R, (W_ih, E), ld_ih, 4 * R, 1)], B, R, d_mean, a_layout=0, b_layout=1)          # [B,R]
         # embedding
-        d_xt = ops.matmul_nn(dg2, W_ih[:, :E].contiguous())
+        d_xt = z(TN, E)
+        ops.gemm([(dg2, 4 * R, W_ih, ld_ih, 4 * R, 1)], TN, E, d_xt, a_layout=0, b_layout=1)
         g['embed.0.weight'].zero_()
         masks_xt = self.m_xt_all
         check(lib.capmi_embed_bwd(ptr(self.it_all), ptr(d_xt), ptr(self.xt), ptr(masks_xt), ptr(g['embed.0.weight']), TN, E, 1, st),

@@ -596,7 +596,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     // two narrow ones per K tile (fewer staging instructions per MFMA) but rounds M up to 256 and halves the number of units.
     // CAPMI_X3_TILE = 128 / 256 forces one tiling (0: by cost).
     static const int env_tile = capmi::knob("CAPMI_X3_TILE", 0);
-    static const int env_wcost = capmi::knob("CAPMI_X3W_COST", 150);
+    static const int env_wcost = capmi::knob("CAPMI_X3W_COST", 165);
     bool wide = false;
     const int gmw = (d->M + 255) / 256;
     if (x3_ok) {
@@ -607,6 +607,9 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
         const int sp_lo = splits > 0 ? splits : 1, sp_hi = splits > 0 ? splits : 16;
         for (int w = 0; w < 2; ++w) {
             if ((w == 0 && env_tile == 256) || (w == 1 && env_tile == 128)) continue;
+            // measured (profiles/r05_fat_gemm_wide.md): with fewer than four row tiles the wide tiling loses -- its last tile is mostly
+            // padding and takes the edge path of the split on every K tile ([320 x 4000]: 72 vs 69 us)
+            if (w == 1 && env_tile != 256 && gmw < 4) continue;
             const int out_tiles = (w ? gmw : gm) * gn;
             const double step = w ? env_wcost / 100.0 : 1.0;
             for (int sp = sp_lo; sp <= sp_hi && sp <= tiles; ++sp) {

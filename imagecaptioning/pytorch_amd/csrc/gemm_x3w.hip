@@ -9,7 +9,8 @@
 //     per SIMD and K tile: 96 MFMAs (two MFMA waves) | 12 loads + 264 split VALU + 36 ds_write_b64 (staging) | 48 ds_read_b128
 //     = ~4.0 issues per MFMA gap, and a fragment set read from LDS still feeds 24 MFMAs.
 // Two MFMA waves share each SIMD: while one waits for its ds_reads the other's MFMAs keep the pipe busy, so the loop needs no
-// software pipelining (and no second fragment register set).
+// software pipelining (and no second fragment register set).  Staging: one wave per SIMD (768 threads) or -- the default, measured
+// 3-7 % faster -- two (1 024 threads, 124 registers): the first splits the two A blocks, the second B.
 //
 // LDS: a stage is 3 planes x (256 + 128) rows x 32 k bf16.  With the 80-byte padded rows of gemm_x3.hip two stages would take
 // 184 KB; here a row is exactly 64 bytes and its four 16-byte pieces are XOR-swizzled by (row >> 2) & 3, which makes the 16 lanes
@@ -332,7 +333,7 @@ int launch_x3w(const KArgs &a, int a_layout, int b_layout, dim3 tiles, hipStream
     const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
     constexpr size_t lds = 2 * (size_t)WSTAGE * sizeof(unsigned short);
     static_assert(lds <= 160 * 1024, "two stages must fit the CU's LDS");
-    static const int env_nsw = capmi::knob("CAPMI_X3W_NSW", 4), env_prio = capmi::knob("CAPMI_X3W_PRIO", 0);
+    static const int env_nsw = capmi::knob("CAPMI_X3W_NSW", 8), env_prio = capmi::knob("CAPMI_X3W_PRIO", 0);
 #define CAPMI_X3W_N(AK, BK_, NSW_)                                                                              \
     do {                                                                                                        \
         static bool attr_set = false;                                                                           \

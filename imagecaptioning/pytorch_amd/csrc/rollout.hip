@@ -476,7 +476,61 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
     const bool batch_cols = col_phases >= 2;
     capmi_colsum_item cols[CAPMI_COLSUM_ARGS_MAX];
     int n_cols = 0;
-    hipEvent_t side_join = nullptr;                 // set when a side-stream launch must be joined before returning
+    // r5: weight-gradient GEMMs that nothing reads before the optimizer run on a SIDE STREAM beside the latency-bound time loop
+    // (CAPMI_BWD_SIDE = k > 0, single-call backward only): dW_logit as soon as d(logits) exists, and the LSTM / h2att weight
+    // gradients of the LAST (k - 1) of k time chunks as soon as the loop has walked past them; the first chunk follows on the
+    // main stream behind the loop and accumulates.  profiles/r05_scst_overlap.md: 4.24 -> 4.13 ms with k = 1.
+    static const int env_side = capmi::knob("CAPMI_BWD_SIDE", 2);
+    hipStream_t side_st = nullptr;
+    hipEvent_t *side_ev = nullptr;
+    bool side_used = false;
+    if (env_side > 0 && (phases & CAPMI_BWD_ALL) == CAPMI_BWD_ALL && T >= 4) {
+        int dev_i = 0;
+        if (hipGetDevice(&dev_i) != hipSuccess || dev_i < 0 || dev_i >= 16) return CAPMI_EINVAL;
+        static thread_local hipStream_t side_sts[16] = {};
+        static thread_local hipEvent_t side_evs[16][2] = {};
+        if (!side_sts[dev_i]) {
+            if (hipStreamCreateWithFlags(&side_sts[dev_i], hipStreamNonBlocking) != hipSuccess) return CAPMI_EINVAL;
+            for (int i = 0; i < 2; ++i)
+                if (hipEventCreateWithFlags(&side_evs[dev_i][i], hipEventDisableTiming) != hipSuccess) return CAPMI_EINVAL;
+        }
+        side_st = side_sts[dev_i];
+        side_ev = side_evs[dev_i];
+    }
+    const int side_chunks = side_st ? (env_side < 4 ? env_side : 4) : 1;       // time chunks of the LSTM weight gradients
+    // LSTM / h2att weight gradients of the time steps [t0, t1): K = (t1 - t0) * N rows of the time-batched operands
+    const float *x_hatt_same = a_hatt + (compact ? NR : NRf);                   // h_att of the SAME step (slots 1..T)
+    auto dw_chunk = [&](void *strm, int t0, int t1, int acc, float *Pw, int64_t capw) -> int {
+        const int Kc = (t1 - t0) * N;
+        const size_t o4 = (size_t)t0 * N * 4 * R, oR = (size_t)t0 * N * R, oE = (size_t)t0 * N * E, oA = (size_t)t0 * N * A;
+        if (phases & CAPMI_BWD_ATT_LSTM) {
+            SegSpec a{s->dg_att + o4, 4 * R, a_hlang + oR, R, Kc, 1};            // x h_lang_prev  (slots 0..T-1)
+            RC(gemm(strm, 1, 1, 4 * R, R, g->att_w_ih, ld_att_ih, &a, 1, Pw, capw, 0, nullptr, nullptr, nullptr, acc));
+            SegSpec b{s->dg_att + o4, 4 * R, a_xt + oE, E, Kc, 1};               // x xt
+            RC(gemm(strm, 1, 1, 4 * R, E, g->att_w_ih + 2 * R, ld_att_ih, &b, 1, Pw, capw, 0, nullptr, nullptr, nullptr, acc));
+            SegSpec c{s->dg_att + o4, 4 * R, a_hatt + oR, R, Kc, 1};             // x h_att_prev
+            RC(gemm(strm, 1, 1, 4 * R, R, g->att_w_hh, R, &c, 1, Pw, capw, 0, nullptr, nullptr, nullptr, acc));
+        }
+        if (phases & CAPMI_BWD_LANG_LSTM) {
+            SegSpec a{s->dg_lang + o4, 4 * R, a_ctx + oR, R, Kc, 1};
+            RC(gemm(strm, 1, 1, 4 * R, R, g->lang_w_ih, 2 * R, &a, 1, Pw, capw, 0, nullptr, nullptr, nullptr, acc));
+            SegSpec b{s->dg_lang + o4, 4 * R, x_hatt_same + oR, R, Kc, 1};
+            RC(gemm(strm, 1, 1, 4 * R, R, g->lang_w_ih + R, 2 * R, &b, 1, Pw, capw, 0, nullptr, nullptr, nullptr, acc));
+            SegSpec c{s->dg_lang + o4, 4 * R, a_hlang + oR, R, Kc, 1};
+            RC(gemm(strm, 1, 1, 4 * R, R, g->lang_w_hh, R, &c, 1, Pw, capw, 0, nullptr, nullptr, nullptr, acc));
+        }
+        if (phases & CAPMI_BWD_ATTENTION) {
+            SegSpec a{s->d_att_h_all + oA, A, x_hatt_same + oR, R, Kc, 1};
+            RC(gemm(strm, 1, 1, A, R, g->h2att_w, R, &a, 1, Pw, capw, 0, nullptr, nullptr, nullptr, acc));
+        }
+        return 0;
+    };
+    int dw_done_from = T;           // time steps [dw_done_from, T) already have their weight gradients (on the side stream)
+    auto chunk_boundary = [&](int t) {              // t = c * T / side_chunks for some c in [1, side_chunks)
+        for (int c = 1; c < side_chunks; ++c)
+            if ((c * T) / side_chunks == t) return true;
+        return false;
+    };
     auto colsum = [&](const float *in, int rows, int ncol, float *out, float *out2) -> int {
         if (batch_cols) {
             cols[n_cols++] = capmi_colsum_item{in, out, out2, rows, ncol, ncol, 0};
@@ -503,24 +557,13 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         SegSpec a{s->dlogits, V1, w->logit_w, R, V1, 1};   // d_hdrop = dlogits W_logit          [TN,R]
         RC(gemm(stream, 0, 1, TN, R, s->d_hdrop, R, &a, 1, P, cap, 0, nullptr));
         SegSpec b{s->dlogits, V1, a_hdrop, R, TN, 1};       // dW_logit = dlogits^T h_drop         [V1,R]
-        // r5 experiment (profiles/r05_scst_overlap.md): nothing reads dW_logit before the optimizer, so it can go to a side stream
-        // beside the time loop (CAPMI_BWD_SIDE=1; no split-K workspace: the loop owns P).  Off by default: measured.
-        static const int env_side = capmi::knob("CAPMI_BWD_SIDE", 0);
-        if (env_side && (phases & CAPMI_BWD_ALL) == CAPMI_BWD_ALL) {
-            int dev_i = 0;
-            if (hipGetDevice(&dev_i) != hipSuccess || dev_i < 0 || dev_i >= 16) return CAPMI_EINVAL;
-            static thread_local hipStream_t side_st[16] = {};
-            static thread_local hipEvent_t side_ev[16][2] = {};
-            if (!side_st[dev_i]) {
-                if (hipStreamCreateWithFlags(&side_st[dev_i], hipStreamNonBlocking) != hipSuccess) return CAPMI_EINVAL;
-                for (int i = 0; i < 2; ++i)
-                    if (hipEventCreateWithFlags(&side_ev[dev_i][i], hipEventDisableTiming) != hipSuccess) return CAPMI_EINVAL;
-            }
-            if (hipEventRecord(side_ev[dev_i][0], st) != hipSuccess) return CAPMI_EINVAL;          // dlogits, h_drop (packed) are ready
-            if (hipStreamWaitEvent(side_st[dev_i], side_ev[dev_i][0], 0) != hipSuccess) return CAPMI_EINVAL;
-            RC(gemm((void *)side_st[dev_i], 1, 1, V1, R, g->logit_w, R, &b, 1, nullptr, 0, 0, nullptr));
-            if (hipEventRecord(side_ev[dev_i][1], side_st[dev_i]) != hipSuccess) return CAPMI_EINVAL;
-            side_join = side_ev[dev_i][1];
+        // r5 (profiles/r05_scst_overlap.md): nothing reads dW_logit before the optimizer: it runs on the side stream beside the
+        // time loop (no split-K workspace there: the loop owns P)
+        if (side_st) {
+            if (hipEventRecord(side_ev[0], st) != hipSuccess) return CAPMI_EINVAL;          // dlogits, h_drop (packed) are ready
+            if (hipStreamWaitEvent(side_st, side_ev[0], 0) != hipSuccess) return CAPMI_EINVAL;
+            RC(gemm((void *)side_st, 1, 1, V1, R, g->logit_w, R, &b, 1, nullptr, 0, 0, nullptr));
+            side_used = true;
         } else
         RC(gemm(stream, 1, 1, V1, R, g->logit_w, R, &b, 1, P, cap, 0, nullptr));
         RC(colsum(s->dlogits, TN, V1, g->logit_b, nullptr));
@@ -622,19 +665,26 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
             SegSpec a{dg_att, 4 * R, s->w_att_cat, 2 * R, 4 * R, 1, pl_dg_att};
             RC(gemm(stream, 0, 1, N, 2 * R, P1, 2 * R, &a, 1, P1, cap1, 1, &x1_splits, nullptr, nullptr, 0, pl_zero));
         }
+        // chunk boundaries at t = c * T / side_chunks, c = side_chunks - 1 .. 1: steps [t, dw_done_from) are complete
+        if (side_chunks > 1 && t > 0 && t < dw_done_from && chunk_boundary(t)) {
+            if (hipEventRecord(side_ev[0], st) != hipSuccess) return CAPMI_EINVAL;
+            if (hipStreamWaitEvent(side_st, side_ev[0], 0) != hipSuccess) return CAPMI_EINVAL;
+            RC(dw_chunk((void *)side_st, t, dw_done_from, dw_done_from < T ? 1 : 0, nullptr, 0));
+            dw_done_from = t;
+            side_used = true;
+        }
     }
 
     }   // CAPMI_BWD_RECURRENT
 
     // ---- time-batched parameter / feature gradients --------------------------------------------
+    if (side_used) {                                   // the side stream's GEMMs wrote (parts of) the gradients the chunk below adds to
+        if (hipEventRecord(side_ev[1], side_st) != hipSuccess) return CAPMI_EINVAL;
+        if (hipStreamWaitEvent(st, side_ev[1], 0) != hipSuccess) return CAPMI_EINVAL;
+    }
+    RC(dw_chunk(stream, 0, dw_done_from, dw_done_from < T ? 1 : 0, P, cap));
     // attention LSTM
     if (phases & CAPMI_BWD_ATT_LSTM) {
-        SegSpec a{s->dg_att, 4 * R, a_hlang, R, TN, 1};            // x h_lang_prev  (slots 0..T-1)
-        RC(gemm(stream, 1, 1, 4 * R, R, g->att_w_ih, ld_att_ih, &a, 1, P, cap, 0, nullptr));
-        SegSpec b{s->dg_att, 4 * R, a_xt, E, TN, 1};               // x xt
-        RC(gemm(stream, 1, 1, 4 * R, E, g->att_w_ih + 2 * R, ld_att_ih, &b, 1, P, cap, 0, nullptr));
-        SegSpec c{s->dg_att, 4 * R, a_hatt, R, TN, 1};             // x h_att_prev
-        RC(gemm(stream, 1, 1, 4 * R, R, g->att_w_hh, R, &c, 1, P, cap, 0, nullptr));
         RC(colsum(s->dg_att, TN, 4 * R, g->att_b_ih, g->att_b_hh));
         hipError_t e;
         // fc columns: sum over time and over the n rows of an image first
@@ -653,22 +703,12 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         RC(capmi_embed_bwd(a_it, s->d_xt_all, a_xt, a_dropxt, g->embed, TN, E, 1, stream));
     }
     // language LSTM
-    if (phases & CAPMI_BWD_LANG_LSTM) {
-        SegSpec a{s->dg_lang, 4 * R, a_ctx, R, TN, 1};
-        RC(gemm(stream, 1, 1, 4 * R, R, g->lang_w_ih, 2 * R, &a, 1, P, cap, 0, nullptr));
-        SegSpec b{s->dg_lang, 4 * R, a_hatt + (compact ? NR : NRf), R, TN, 1};      // h_att of the same step (slots 1..T)
-        RC(gemm(stream, 1, 1, 4 * R, R, g->lang_w_ih + R, 2 * R, &b, 1, P, cap, 0, nullptr));
-        SegSpec c{s->dg_lang, 4 * R, a_hlang, R, TN, 1};
-        RC(gemm(stream, 1, 1, 4 * R, R, g->lang_w_hh, R, &c, 1, P, cap, 0, nullptr));
-        RC(colsum(s->dg_lang, TN, 4 * R, g->lang_b_ih, g->lang_b_hh));
-    }
+    if (phases & CAPMI_BWD_LANG_LSTM) RC(colsum(s->dg_lang, TN, 4 * R, g->lang_b_ih, g->lang_b_hh));
     // attention parameters / features
     if (phases & CAPMI_BWD_ATTENTION) {
-        SegSpec a{s->d_att_h_all, A, a_hatt + (compact ? NR : NRf), R, TN, 1};
-        RC(gemm(stream, 1, 1, A, R, g->h2att_w, R, &a, 1, P, cap, 0, nullptr));
         RC(colsum(s->d_att_h_all, TN, A, g->h2att_b, nullptr));
-        // alpha_net's weight gradient: one partial row per (image, region) in the workspace (free again: the GEMM above has
-        // finished its own slabs), summed by the batched column-sum launch below instead of 184 000 atomicAdds on 512 words
+        // alpha_net's weight gradient: one partial row per (image, region) in the workspace (free again: the GEMMs above have
+        // finished their own slabs), summed by the batched column-sum launch below instead of 184 000 atomicAdds on 512 words
         float *dw_part = (batch_cols && n_cols < CAPMI_COLSUM_ARGS_MAX && cap >= CAPMI_WS_COUNTER_FLOATS + (int64_t)B * K * A)
                              ? P + CAPMI_WS_COUNTER_FLOATS : nullptr;
         RC(capmi_attention_bwd_batched_ws(s->d_x2, 3 * R, a_atth, a_alpha, s->d_e_all, r->p_att, w->alpha_w, g->d_att,
@@ -676,7 +716,6 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         if (dw_part) RC(colsum(dw_part, B * K, A, g->alpha_w, nullptr));
     }
     if (n_cols) RC(capmi_colsum_batch_args(cols, n_cols, stream));
-    if (side_join && hipStreamWaitEvent(st, side_join, 0) != hipSuccess) return CAPMI_EINVAL;
     return 0;
 }
 
