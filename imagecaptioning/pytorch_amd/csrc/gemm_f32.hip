@@ -610,6 +610,11 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
             // measured (profiles/r05_fat_gemm_wide.md): with fewer than four row tiles the wide tiling loses -- its last tile is mostly
             // padding and takes the edge path of the split on every K tile ([320 x 4000]: 72 vs 69 us)
             if (w == 1 && env_tile != 256 && gmw < 4) continue;
+            // ... and it is not used for GEMMs whose reduction is deferred: those are the weight gradients that run on a SIDE stream
+            // beside the backward chain (ops.DeferredGrads).  A wide workgroup is 16 waves x 124 registers + 144 KB of LDS -- it
+            // owns its CU -- and a persistent grid of them beside another stream's kernels starved both (Transformer XE 14.3 ->
+            // 36.5 ms); the 128 x 128 kernel leaves room for the chain's small kernels.
+            if (w == 1 && env_tile != 256 && d->defer_reduce) continue;
             const int out_tiles = (w ? gmw : gm) * gn;
             const double step = w ? env_wcost / 100.0 : 1.0;
             for (int sp = sp_lo; sp <= sp_hi && sp <= tiles; ++sp) {

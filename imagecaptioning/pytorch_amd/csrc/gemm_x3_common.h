@@ -67,10 +67,8 @@ __device__ __forceinline__ void x3_epilogue(const KArgs &a, const Unit &un, cons
                 }
                 continue;
             }
-            // the per-element operands of 8 rows are requested before the first of them is used: the compiler may not move a load
-            // across the store of the previous row (C, the mask and the addend are plain pointers), so the rolled form was one
-            // memory round trip per row with the MFMA pipe of the wave idle (r4: a gate + mask epilogue cost an FFN dX GEMM
-            // 56 -> 83 us)
+            if (!a.row_bias) continue;       // mask / addend only: handled below, pipelined over all blocks
+            // (with a per-row bias: 8 rows per round trip, as in r4)
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 8) {
                 float mk[8], ad[8], rb[8];
@@ -78,7 +76,7 @@ __device__ __forceinline__ void x3_epilogue(const KArgs &a, const Unit &un, cons
                 for (int u = 0; u < 8; ++u) {
                     const int r = r0 + u;
                     const int row = min(un.m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half, a.M - 1);
-                    rb[u] = a.row_bias ? a.row_bias[(size_t)(row / a.row_bias_div) * a.N + col] : 0.f;
+                    rb[u] = a.row_bias[(size_t)(row / a.row_bias_div) * a.N + col];
                     mk[u] = a.mul_mask ? a.mul_mask[(size_t)row * a.N + col] : 1.f;
                     ad[u] = a.accumulate ? a.addend[(size_t)row * a.ldc + col] : 0.f;      // (not to_partial: out == C)
                 }
@@ -93,6 +91,48 @@ __device__ __forceinline__ void x3_epilogue(const KArgs &a, const Unit &un, cons
                 }
             }
         }
+    if (plain || a.row_bias || !(a.mul_mask || a.accumulate)) return;
+    // Dropout mask / residual addend: one value per output element, a memory round trip per group of loads with the wave's share
+    // of the matrix pipe idle (r4: 8 rows at a time = 8 round trips per 64 x 64 wave tile; mask + addend took an FFN GEMM from 83
+    // to 111 us).  r5: the groups are software-pipelined -- the operands of group g+1 are requested BEFORE group g is combined and
+    // stored (the compiler may not move a load across a store to a plain pointer in either direction, so the written order is the
+    // issued order), which leaves one exposed round trip per tile.  Two register sets of 8 rows x {mask, addend}.
+    constexpr int G = 4 * NJ;                              // (i, j, row half) groups of the wave tile
+    auto issue = [&](int gi, float (&mk)[8], float (&ad)[8]) {
+        const int i = gi / (2 * NJ), j = (gi / 2) % NJ, r0 = (gi & 1) * 8;
+        const int col = min(un.n0 + wn0 + 32 * j + l31, a.N - 1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + u;
+            const int row = min(un.m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half, a.M - 1);
+            mk[u] = a.mul_mask ? a.mul_mask[(size_t)row * a.N + col] : 1.f;
+            ad[u] = a.accumulate ? a.addend[(size_t)row * a.ldc + col] : 0.f;      // (not to_partial: out == C)
+        }
+    };
+    auto finish = [&](int gi, const float (&mk)[8], const float (&ad)[8]) {
+        const int i = gi / (2 * NJ), j = (gi / 2) % NJ, r0 = (gi & 1) * 8;
+        const int col = un.n0 + wn0 + 32 * j + l31;
+        if (col >= a.N) return;
+        const float cb = cbv[j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + u;
+            const int row = un.m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row >= a.M) continue;
+            float v = acc[i][j][r] + cb;
+            if (a.relu) v = fmaxf(v, 0.f);
+            out[(size_t)row * ldo + col] = v * mk[u] + ad[u];
+        }
+    };
+    float mk0[8], ad0[8], mk1[8], ad1[8];
+    issue(0, mk0, ad0);
+#pragma unroll
+    for (int gi = 0; gi < G; gi += 2) {
+        issue(gi + 1, mk1, ad1);
+        finish(gi, mk0, ad0);
+        if (gi + 2 < G) issue(gi + 2, mk0, ad0);
+        finish(gi + 1, mk1, ad1);
+    }
 }
 
 }  // namespace

@@ -251,9 +251,9 @@ __global__ __launch_bounds__(512 + 64 * NSW) void gemm_x3w_kernel(const KArgs a,
 
     if (wid >= 8) {
         // (experiment knob CAPMI_X3W_PRIO: the staging waves are the youngest of their SIMD and lose the VALU arbitration by age)
-        if (prio == 1) __builtin_amdgcn_s_setprio(1);
-        else if (prio == 2) __builtin_amdgcn_s_setprio(2);
-        else if (prio == 3) __builtin_amdgcn_s_setprio(3);
+        if ((prio & 3) == 1) __builtin_amdgcn_s_setprio(1);
+        else if ((prio & 3) == 2) __builtin_amdgcn_s_setprio(2);
+        else if ((prio & 3) == 3) __builtin_amdgcn_s_setprio(3);
         if (NSW == 4) w_staging<AKC, BKC, true, true>(a, gm, gn, units, threadIdx.x - 512, smem);
         else if (wid < 12) w_staging<AKC, BKC, true, false>(a, gm, gn, units, threadIdx.x - 512, smem);
         else w_staging<AKC, BKC, false, true>(a, gm, gn, units, threadIdx.x - 768, smem);

@@ -479,8 +479,10 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
     // r5: weight-gradient GEMMs that nothing reads before the optimizer run on a SIDE STREAM beside the latency-bound time loop
     // (CAPMI_BWD_SIDE = k > 0, single-call backward only): dW_logit as soon as d(logits) exists, and the LSTM / h2att weight
     // gradients of the LAST (k - 1) of k time chunks as soon as the loop has walked past them; the first chunk follows on the
-    // main stream behind the loop and accumulates.  profiles/r05_scst_overlap.md: 4.24 -> 4.13 ms with k = 1.
-    static const int env_side = capmi::knob("CAPMI_BWD_SIDE", 2);
+    // main stream behind the loop and accumulates.  OFF by default -- measured (profiles/r05_scst_overlap.md): k = 1 between -2.5 % and
+    // 0 on the SCST step depending on the box, k = 2 / 3 +3 % / +14 % (a fat GEMM owns the CUs it lands on: 120-144 KB of LDS; the
+    // loop's weight-streaming GEMMs then wait for whole persistent workgroups), UpDown XE 12.1 -> 15.8 ms.
+    static const int env_side = capmi::knob("CAPMI_BWD_SIDE", 0);
     hipStream_t side_st = nullptr;
     hipEvent_t *side_ev = nullptr;
     bool side_used = false;
