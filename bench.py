@@ -350,7 +350,6 @@ def main():
     ar_events = None          # (start, end) events around the all-reduce of the steps that measure it
 
     mode_now = {'overlap': overlap, 'sharded': sharded, 'none': False}
-    early_adam = (os.environ.get('CAPMI_EARLY_ADAM', '0') == '1' and dist is None and args.config == 'updown_scst')
     one = torch.ones((), dtype=torch.float32, device=dev)
 
     def step():
@@ -365,13 +364,9 @@ def main():
         flat.zero_grad()
         adam = dict(lr=opt.learning_rate, betas=(opt.optim_alpha, opt.optim_beta), eps=opt.optim_epsilon,
                     weight_decay=opt.weight_decay, clip_value=opt.grad_clip_value)
-        if early_adam:      # experiment (profiles/r05_scst_overlap.md): the logit layer's update under the BPTT loop
-            flat.begin_early_adam(**adam)
         loss.backward(gradient=one if loss.dim() == 0 else None)       # (a cached 1.0: autograd's ones_like is an ATen fill launch)
         flat.collect_grads()
-        if early_adam:
-            flat.finish_early_adam()
-        elif overlap:
+        if overlap:
             # the backward has already launched the all-reduce of every gradient bucket it finished (logit layer before
             # the BPTT loop, LSTM weights before the attention/prefill gradients); reduce the rest and run clip+Adam
             # bucket by bucket as the collectives land
@@ -721,51 +716,54 @@ def early_exit_line(model, flat, lw, pf, gt_indices, opt, B, n, steps=20):
 
 def cpu_baseline_other(config, opt, model, B, L, brief=False):
     """CPU baseline of the non-headline configurations: the matching oracle (oracle/att_lstm.py, transformer.py, aoa.py: ports of
-    the reference's CPU path) on a BOUNDED sample of the same workload -- teacher-forced forward + criterion + autograd backward +
-    value clip + Adam on `Bc` images x 5 captions, scaled to captions/s.  (aoa_nsc: the teacher-forced pass over the 50 sampled rows
-    plus a no-grad 20-step decode of the same rows stands in for the sampled rollouts; the CIDEr-D scorer is not timed.)"""
-    from oracle import att_lstm as O, transformer as T, aoa as A
+    the reference's CPU path) running the SAME workload at the SAME batch as the GPU step beside it --
+    XE configurations: teacher-forced forward + criterion + autograd backward + value clip + Adam on B images x 5 captions;
+    aoa_nsc: the actual new-self-critical iteration (loss_wrapper.py:25-48, losses.py:168-187): a SAMPLED rollout of
+    train_sample_n rows per image with its autograd graph, CIDEr-D scores on the host, the structure loss, backward, clip, Adam.
+    ONE timed iteration after a warm-up on 2 images (threads, allocator): a bs64 iteration takes 10-30 s of host time."""
+    from oracle import att_lstm as O, transformer as T, aoa as A, ciderd as OC
     from imagecaptioning.pytorch_amd import synthetic
     cores = min(os.cpu_count() or 1, int(os.environ.get('CAPMI_CPU_THREADS', '16')))
     torch.set_num_threads(cores)
-    Bc = min(B, 4 if brief else 8)
     P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-    fc, att = synthetic.batch(Bc, seed=1234)
-    labels, masks = synthetic.xe_labels(Bc, n=5, L=L)
     optim = torch.optim.Adam(list(P.values()), lr=opt.learning_rate)
+    n = 5
+    scorer = None
+    if config == 'aoa_nsc':
+        df, ref_len = synthetic.document_frequency(synthetic.corpus(DF_IMAGES, seed=7))
+        scorer = OC.CiderD(df, ref_len)
 
-    def fwd():
-        if config == 'updown_xe':
-            return O.forward_teacher(P, fc, att, labels[..., :-1], None)
-        if config == 'newfc_xe':
-            return O.newfc_forward_teacher(P, fc, labels[..., :-1])
-        if config == 'transformer_xe':
-            return T.forward_teacher(P, att, labels[..., :-1], None, h=8, n_enc=6, n_dec=6)
-        return A.forward_teacher(P, att, labels[..., :-1], None, h=8)
-
-    def it():
+    def it(Bc):
+        fc, att = synthetic.batch(Bc, seed=1234)
         if config == 'aoa_nsc':
-            with torch.no_grad():
-                A.greedy({k: v.detach() for k, v in P.items()}, att.repeat_interleave(5, 0), None, 8, L)
-        logp = fwd()
-        loss = O.lm_criterion(logp, labels[..., 1:], masks[..., 1:])
+            gts = synthetic.corpus(Bc, seed=100)
+            seq, logp = A.sample(P, att, None, 8, L, n=n)
+            scores = OC.sample_scores(scorer, gts, seq.numpy())                  # rewards.py:83-114 get_scores, on the host
+            loss = O.new_self_critical_loss(logp, seq, torch.as_tensor(scores).double().reshape(-1), n)
+        else:
+            labels, masks = synthetic.xe_labels(Bc, n=5, L=L)
+            if config == 'updown_xe':
+                logp = O.forward_teacher(P, fc, att, labels[..., :-1], None)
+            elif config == 'newfc_xe':
+                logp = O.newfc_forward_teacher(P, fc, labels[..., :-1])
+            else:
+                logp = T.forward_teacher(P, att, labels[..., :-1], None, h=8, n_enc=6, n_dec=6)
+            loss = O.lm_criterion(logp, labels[..., 1:], masks[..., 1:])
         optim.zero_grad()
         loss.backward()
         torch.nn.utils.clip_grad_value_(list(P.values()), opt.grad_clip_value)
         optim.step()
 
-    it()
-    ts = []
-    for _ in range(1 if brief else 2):
-        t0 = time.perf_counter()
-        it()
-        ts.append(time.perf_counter() - t0)
-    sec = sorted(ts)[0]
-    return {'value': round(Bc * 5 / sec, 2), 'unit': 'captions/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d timed iterations (best) after 1 warm-up of the %s oracle on %d images x 5 captions (the GPU step runs %d): '
-                      'teacher-forced forward + criterion + autograd backward + clip + Adam%s; torch fp32 on %d threads'
-                      % (len(ts), config, Bc, B, ' + a no-grad 20-step decode of the 5x repeated images standing in for the sampled rollouts'
-                         if config == 'aoa_nsc' else '', cores), 'sec_per_iteration': round(sec, 3)}
+    it(2)
+    t0 = time.perf_counter()
+    it(B)
+    sec = time.perf_counter() - t0
+    what = ('a sampled rollout of 5 rows per image with its autograd graph + CIDEr-D scores on the host + new_self_critical loss'
+            if config == 'aoa_nsc' else 'teacher-forced forward + criterion')
+    return {'value': round(B * 5 / sec, 2), 'unit': 'captions/s', 'cores': cores, 'kind': 'port',
+            'sample': 'ONE timed iteration of the %s oracle at the GPU step\'s own batch (%d images x 5 captions) after a 2-image warm-up: '
+                      '%s + autograd backward + clip + Adam; torch fp32 on %d threads' % (config, B, what, cores),
+            'sec_per_iteration': round(sec, 3)}
 
 
 if __name__ == '__main__':

@@ -77,9 +77,7 @@ class _RolloutFn(torch.autograd.Function):
         grads = model._grad_targets(P)
         g_logp, sparse, keep = sparse_logp.split_grad(g_logp, ctx.sink, ro.seq_logp)       # the criteria hand their gradient over sparse
         ro._sparse_keep = keep
-        on_ready = flat.on_grads_ready if (flat is not None and flat.overlap_allowed(stash)) else None
-        d_fc, d_att, d_p_att = ro.backward(g_logp, grads, sparse=sparse, on_ready=on_ready,
-                                           phase_groups=getattr(flat, 'bwd_phase_groups', None) if on_ready is not None else None)
+        d_fc, d_att, d_p_att = ro.backward(g_logp, grads, sparse=sparse, on_ready=flat.on_grads_ready if (flat is not None and flat.overlap_allowed(stash)) else None)
         engine.prepare_backward(P, pr, d_fc, d_att, d_p_att, grads)
         if flat is not None:
             flat.end_backward(stash)

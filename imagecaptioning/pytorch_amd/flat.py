@@ -59,7 +59,6 @@ class FlatParams:
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_count = 0
         self.on_grads_ready = None      # set by begin_overlap(); native backwards call it per finished bucket
-        self.bwd_phase_groups = None    # 'logit_first': two backward calls (logit layer | everything else) instead of one per phase
         self._bw_expected, self._bw_seen = 1, 0
 
     # ---- optimizer state (the reference's optimizer.pth, misc.py:87-102 / tools/train.py:112-119) --------------------
@@ -238,56 +237,6 @@ class FlatParams:
         self.last_collectives = len(ov['works'])
         ov['works'], ov['done'] = [], []
         return scale
-
-    # ---- single GPU: clip + Adam of the logit layer under the BPTT loop (r5 experiment) -----------------
-    # The logit layer's gradient is final before the time loop starts (updown_engine.Rollout.BWD_PHASES); its elementwise update
-    # can run on a side stream while the latency-bound loop walks the steps.  Everything else becomes final after the loop and is
-    # updated by ONE launch over the rest of the buffer.  Elementwise => the same update as adam_step().
-    def begin_early_adam(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=0.0, first_only=True):
-        if getattr(self, '_ea_side', None) is None:
-            self._ea_side, self._ea_ev = torch.cuda.Stream(device=self.flat.device), torch.cuda.Event()
-        self._ea = dict(args=(lr, betas, eps, weight_decay, clip_value), done=[], first_only=first_only, calls=0)
-        self.step_count += 1
-        self.on_grads_ready = self._early_adam
-        self.bwd_phase_groups = 'logit_first'
-
-    def _ranges(self, names):
-        segs = sorted((self.offsets[i], self.offsets[i] + (self.params[i].numel() + 3) // 4 * 4)
-                      for i in (self.names.index(n) for n in names))
-        out = [list(segs[0])]
-        for a, b in segs[1:]:
-            if a == out[-1][1]:
-                out[-1][1] = b
-            else:
-                out.append([a, b])
-        return [tuple(r) for r in out]
-
-    def _adam_range(self, lo, hi):
-        lr, betas, eps, wd, clip = self._ea['args']
-        ops.adam_step(self.flat[lo:hi], self.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], lr, betas[0], betas[1], eps,
-                      wd, clip, 1.0, self.step_count)
-
-    def _early_adam(self, names):
-        ea = self._ea
-        ea['calls'] += 1
-        if ea['first_only'] and ea['calls'] > 1:
-            return                       # later buckets finish with the backward: one launch for all of them at the end
-        self._ea_ev.record()             # the launches that complete these gradients are enqueued on the current stream
-        self._ea_side.wait_event(self._ea_ev)
-        with torch.cuda.stream(self._ea_side):
-            for lo, hi in self._ranges(names):
-                self._adam_range(lo, hi)
-                ea['done'].append((lo, hi))
-
-    def finish_early_adam(self):
-        ea = self._ea
-        pos = 0
-        for lo, hi in sorted(ea['done']) + [(self.total, self.total)]:
-            if lo > pos:
-                self._adam_range(pos, lo)
-            pos = max(pos, hi)
-        torch.cuda.current_stream().wait_stream(self._ea_side)
-        self.on_grads_ready, self.bwd_phase_groups, self._ea = None, None, None
 
     def all_reduce(self, group=None, world_size=None):
         """ONE collective for the whole model (RCCL over xGMI when backend == 'nccl'); averages."""

@@ -234,10 +234,7 @@ class Rollout:
                   (16, ('core.attention.h2att.weight', 'core.attention.h2att.bias', 'core.attention.alpha_net.weight',
                         'core.attention.alpha_net.bias')))
 
-    # the same phases in two calls: what is final before the time loop | the loop and everything behind it
-    BWD_PHASES_LOGIT_FIRST = ((1, BWD_PHASES[0][1]), (2 | 4 | 8 | 16, sum((names for _, names in BWD_PHASES[1:]), ())))
-
-    def backward(self, g_seq_logp, grads, on_ready=None, sparse=None, phase_groups=None):
+    def backward(self, g_seq_logp, grads, on_ready=None, sparse=None):
         """g_seq_logp [N,L,V1] (None when `sparse`, a _lib.SparseLogpGrad, carries the loss gradient).  grads: dict name -> preallocated fp32 tensor (overwritten) for every
         PARAM_KEYS entry.  Also returns (d_fc, d_att, d_p_att) consumed by prepare_backward.
         on_ready(names): called after the launches that complete the gradients `names` have been enqueued, so a
@@ -275,7 +272,7 @@ class Rollout:
             check(lib.capmi_updown_rollout_bwd(C.byref(self.w), C.byref(self.r), ptr(g_seq_logp), C.byref(s), C.byref(g),
                                                stream_ptr()), 'capmi_updown_rollout_bwd')
         else:
-            for mask, names in (self.BWD_PHASES_LOGIT_FIRST if phase_groups == 'logit_first' else self.BWD_PHASES):
+            for mask, names in self.BWD_PHASES:
                 check(lib.capmi_updown_rollout_bwd_phases(C.byref(self.w), C.byref(self.r), ptr(g_seq_logp), C.byref(s),
                                                           C.byref(g), mask, stream_ptr()), 'capmi_updown_rollout_bwd_phases')
                 if names:

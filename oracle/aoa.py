@@ -129,3 +129,37 @@ def greedy(P, att_feats, att_masks, h, max_len):
         if int(unf.sum()) == 0:
             break
     return seq, slp
+
+
+def sample(P, att_feats, att_masks, h, max_len, n=1, gen=None, drop=None):
+    """AttModel._sample (AttModel.py:258-352) for AoAModel with sample_method='sample', sample_n=n: n rows per image drawn from
+    torch.distributions-style multinomial of exp(logprobs) (CaptionModel.sample_next_word, :388-395), WITH the autograd graph
+    (the new_self_critical step differentiates the rollout it sampled, loss_wrapper.py:25-48).  Returns seq [B*n, L] and the
+    dense log-probs [B*n, L, V1] filled like AttModel.py:347."""
+    B = att_feats.shape[0]
+    mean, att, p_att, masks = prepare(P, att_feats, att_masks, h, drop)
+    if n > 1:
+        mean, p_att = mean.repeat_interleave(n, 0), p_att.repeat_interleave(n, 0)
+        masks = None if masks is None else masks.repeat_interleave(n, 0)
+    N, R = B * n, mean.shape[1]
+    V1 = P['logit.weight'].shape[0]
+    state = (mean.new_zeros(2, N, R), mean.new_zeros(2, N, R))
+    seq = torch.zeros(N, max_len, dtype=torch.long)
+    slp = mean.new_zeros(N, max_len, V1)
+    it = torch.zeros(N, dtype=torch.long)
+    unf = None
+    for t in range(max_len):
+        logp, state = step(P, it, mean, p_att, masks, state, h, drop, t)
+        with torch.no_grad():
+            it = torch.multinomial(logp.detach().exp(), 1, generator=gen).squeeze(1)
+        if t == 0:
+            unf = it != 0
+        else:
+            it = it * unf.long()
+            logp = logp * unf.unsqueeze(1).to(logp)
+            unf = unf & (it != 0)
+        seq[:, t] = it
+        slp[:, t] = logp
+        if int(unf.sum()) == 0:
+            break
+    return seq, slp
