@@ -37,6 +37,23 @@ def mul_mask(x, mask):
     return x if mask is None else ops.relu_mask_bwd(x.contiguous(), None, mask)
 
 
+def dcat_halves(d_pre, W, M, R, mask_lo=None, mask_hi=None, ws=None):
+    """(d_lo, d_hi) = the two [M,R] halves of d_pre [M,2R] @ W [2R,2R] (backward of a Linear over cat([att, query], -1),
+    AoAModel.py:92,174), each through its dropout mask.  The GEMM leaves its K-slice slabs, capmi_split_halves finishes them into
+    the two contiguous operands the consumers want: 2 launches instead of GEMM + reduction + 2 slice copies (+ 2 mask kernels)."""
+    dev = d_pre.device
+    ws = ws or ops.default_workspace(dev)
+    lo, hi = torch.empty(M, R, dtype=_f32, device=dev), torch.empty(M, R, dtype=_f32, device=dev)
+    if ws.capacity - ops.Workspace.COUNTER_FLOATS >= M * 2 * R:
+        sp = ops.gemm([(d_pre, 2 * R, W, 2 * R, 2 * R, 1)], M, 2 * R, ws.buf, a_layout=0, b_layout=1, ws=ws, defer_reduce=True)
+        src, stride = ws.slabs, M * 2 * R
+    else:                                    # (a product larger than the workspace: finished by the GEMM itself)
+        src, sp, stride = ops.matmul_nn(d_pre, W), 1, 0
+    check(lib.capmi_split_halves(src.data_ptr(), sp, stride, ptr(mask_lo), ptr(mask_hi), ptr(lo), ptr(hi), M, R, stream_ptr()),
+          'split_halves')
+    return lo, hi
+
+
 _dh_ws = {}
 
 
@@ -269,9 +286,7 @@ class AoAGraph:
         for t in range(T - 1, -1, -1):
             # out_{t+1}: from the logit (through out_drop) and -- accumulated by step t+1 -- from its ctx input
             check(lib.capmi_glu_bwd(ptr(d_out_all[t]), None, ptr(self.pre2[t]), ptr(d_pre2_all[t]), N, R, st), 'glu_bwd')
-            d_cat = ops.matmul_nn(d_pre2_all[t], Wc)                                   # [N,2R] = [d_att | d_h_att]
-            d_att = d_cat[:, :R].contiguous()
-            dh = d_cat[:, R:].contiguous()
+            d_att, dh = dcat_halves(d_pre2_all[t], Wc, N, R)                          # [d_att | d_h_att] of [N,2R] = d_pre2 Wc
             # attention: dq, dK/dV accumulated into the two halves of d_p_att across rows of an image and across time
             dq = dq_all[t]                                               # [N,R] = [N,1,R], written in place
             check(lib.capmi_mha_bwd(ptr(d_att), ptr(self.q[t]), self.p_att.data_ptr() + 4 * R, ptr(self.p_att), K * 2 * R, 2 * R,
@@ -347,9 +362,7 @@ class AoAGraph:
             ops.gemm([(d_pre, 2 * R, lay['od'], R, BK, 1)], 2 * R, R, gW2, ldc=2 * R, a_layout=1, b_layout=1)
             ops.gemm([(d_pre, 2 * R, lay['yd'], R, BK, 1)], 2 * R, R, (gW2, R), ldc=2 * R, a_layout=1, b_layout=1)
             ops.colsum(d_pre, out=g[pre + '.self_attn.aoa_layer.0.bias'])
-            d_cat = ops.matmul_nn(d_pre, W)                                            # [BK,2R] = [d_od | d_yd]
-            d_o = mul_mask(d_cat[:, :R].contiguous(), lay['m_o'])
-            d_y = mul_mask(d_cat[:, R:].contiguous(), lay['m_y'])
+            d_o, d_y = dcat_halves(d_pre, W, BK, R, lay['m_o'], lay['m_y'])            # [d_od | d_yd] of [BK,2R] = d_pre W
             if lay['lqkv'] is not None:
                 dqkv = torch.empty(BK, 3 * R, dtype=_f32, device=dev)
                 mha_bwd(d_o.view(B, K, R), lay['q'], lay['k'], lay['v'], K * 3 * R, lay['p'], lay['dp'], B, 1, K, K, h, kstride=3 * R,

@@ -14,9 +14,11 @@
 // way from HBM to LDS; the decode-step GEMMs (each weight used by one wave only) stay on the exact fp32 pipe.
 // CAPMI_GEMM_X3=0 routes the fat GEMMs back to the exact-fp32 kernel.
 //
-// Layout: 128x128x32 tile per 512-thread workgroup.  LDS holds three bf16 planes per operand, [128 rows][32 k] with
-// an 80-byte row pitch: a lane's MFMA operand (8 consecutive k of one row) is one conflict-free ds_read_b128; a staged
-// quad (4 consecutive k of one row, 3 planes) is three ds_write_b64.  K-major sources ([K][M] gradients / activations
+// Layout: 128x128x32 tile per workgroup.  LDS holds three bf16 planes per operand, [128 rows][32 k]; r5: rows are 64 bytes, their
+// 16-byte pieces XOR-swizzled (wswz, gemm_x3_common.h) -- the 80-byte padded rows of rounds 2-4 kept the ds_read_b128 of a lane's
+// MFMA operand conflict-free but not the staging stores (PMC, profiles/r05_fat_gemm_wide.md: SQ_LDS_BANK_CONFLICT = 46 % of the
+// LDS-active cycles against 13 % for the swizzled 256 x 128 kernel).  A staged quad (4 consecutive k of one row, 3 planes) is
+// three ds_write_b64.  K-major sources ([K][M] gradients / activations
 // of dW = dG^T X) are fetched as 4x4 blocks (16-byte loads along the contiguous dimension) and transposed in
 // registers, so the same row-quad store applies without an LDS transpose.
 #include "gemm_x3_common.h"
@@ -27,7 +29,7 @@
 namespace capmi_gemm {
 namespace {
 
-constexpr int XBM = 128, XBN = 128, XP = 40;       // row pitch in bf16 elements (80 bytes)
+constexpr int XBM = 128, XBN = 128, XP = 32;       // r5: 64-byte rows, XOR-swizzled (wswz, gemm_x3_common.h) instead of padded to 80
 constexpr int XPLANE = 128 * XP;                    // bf16 elements per plane
 
 static_assert(BK == 32, "gemm_x3 assumes 32-wide K tiles");
@@ -146,7 +148,7 @@ __device__ __forceinline__ void x3_r2s(const float (&r)[16], const float (&f)[4]
             m[j] = fbits(r1);
             l[j] = fbits(r1 - bfloat(m[j] & 0xffff0000u));              // exact, <= 8 significant bits: truncation is lossless
         }
-        unsigned short *o = dst + row * XP + kq;
+        unsigned short *o = dst + wswz(row, kq);
         *reinterpret_cast<u32x2 *>(o) = u32x2{pack2(h[0], h[1]), pack2(h[2], h[3])};
         *reinterpret_cast<u32x2 *>(o + XPLANE) = u32x2{pack2(m[0], m[1]), pack2(m[2], m[3])};
         *reinterpret_cast<u32x2 *>(o + 2 * XPLANE) = u32x2{pack2(l[0], l[1]), pack2(l[2], l[3])};
@@ -308,8 +310,8 @@ __global__ __launch_bounds__(256 + 64 * NSW) void gemm_x3_kernel(const KArgs a, 
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                av[q][pl] = *reinterpret_cast<const bf16x8 *>(As + pl * XPLANE + (wm0 + 32 * q + l31) * XP + 16 * ks + 8 * half);
-                bv[q][pl] = *reinterpret_cast<const bf16x8 *>(Bs + pl * XPLANE + (wn0 + 32 * q + l31) * XP + 16 * ks + 8 * half);
+                av[q][pl] = *reinterpret_cast<const bf16x8 *>(As + pl * XPLANE + wswz(wm0 + 32 * q + l31, 16 * ks + 8 * half));
+                bv[q][pl] = *reinterpret_cast<const bf16x8 *>(Bs + pl * XPLANE + wswz(wn0 + 32 * q + l31, 16 * ks + 8 * half));
             }
     };
     __syncthreads();                                       // stage 0 ready

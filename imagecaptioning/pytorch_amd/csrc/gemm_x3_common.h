@@ -17,6 +17,16 @@ __device__ __forceinline__ float bfloat(uint32_t b) { return __builtin_bit_cast(
 // upper halves of two fp32 bit patterns -> one dword of two bf16 (v_perm_b32: bytes 2,3 of lo, bytes 2,3 of hi)
 __device__ __forceinline__ uint32_t pack2(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
 
+// element index of (row, k) inside a plane: 64-byte rows, 16-byte pieces swizzled by s = (row >> 2) & 3 (conflict-free ds_read_b128: the 16 lanes of a hardware lane group -- rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of a 32-row block -- hit 16 distinct bank quads), and the row
+// itself stored in slot row ^ s of its aligned group of four: a [K][rows] operand is staged as 4 x 4 blocks, so the 8 lanes that
+// write one k quad hold rows 4i + p -- 256 bytes apart, i.e. the SAME 16 banks (8-way conflict on every ds_write_b64); with the
+// slot XOR they spread over the four 64-byte windows (2-way, what the padded rows of gemm_x3.hip get).  Reads are unaffected: an
+// aligned group of four rows still covers its own 256 bytes.
+__device__ __forceinline__ int wswz(int row, int k) {
+    const int s = (row >> 2) & 3;
+    return (row ^ s) * 32 + ((((k >> 3) ^ s) & 3) << 3) + (k & 7);
+}
+
 struct Unit {
     int m0, n0, z, t_begin, nt;
 };

@@ -33,16 +33,6 @@ constexpr int WPL_A = WBM * 32, WPL_B = WBN * 32;          // bf16 elements per 
 constexpr int WSTAGE = 3 * (WPL_A + WPL_B);                // 36 864 elements = 72 KB
 static_assert(BK == 32, "gemm_x3w assumes 32-wide K tiles");
 
-// element index of (row, k) inside a plane: 64-byte rows, 16-byte pieces swizzled by s = (row >> 2) & 3 (reads, above), and the row
-// itself stored in slot row ^ s of its aligned group of four: a [K][rows] operand is staged as 4 x 4 blocks, so the 8 lanes that
-// write one k quad hold rows 4i + p -- 256 bytes apart, i.e. the SAME 16 banks (8-way conflict on every ds_write_b64); with the
-// slot XOR they spread over the four 64-byte windows (2-way, what the padded rows of gemm_x3.hip get).  Reads are unaffected: an
-// aligned group of four rows still covers its own 256 bytes.
-__device__ __forceinline__ int wswz(int row, int k) {
-    const int s = (row >> 2) & 3;
-    return (row ^ s) * 32 + ((((k >> 3) ^ s) & 3) << 3) + (k & 7);
-}
-
 // One 128-row block of an operand: HBM -> 16 floats per thread (4 quads of 4 consecutive k of one row), branch-free with a fixed
 // number of loads (see gemm_x3.hip Stager for why); 256 threads.
 template <bool KC>

@@ -793,6 +793,25 @@ __global__ void glu_bwd_kernel(const float *__restrict__ d_out, const float *__r
     }
 }
 
+// [lo | hi] halves of a [M, 2R] product that is still K-slice slabs (or a finished matrix: splits = 1), each times its mask
+__global__ void split_halves_kernel(const float *__restrict__ slabs, int splits, size_t stride, const float *__restrict__ mask_lo,
+                                    const float *__restrict__ mask_hi, float *__restrict__ out_lo, float *__restrict__ out_hi,
+                                    int M, int R) {
+    const size_t total = (size_t)M * 2 * R;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / (2 * R), c = i % (2 * R);
+        float v = 0.f;
+        for (int sp = 0; sp < splits; ++sp) v += slabs[(size_t)sp * stride + i];
+        if (c < (size_t)R) {
+            const size_t o = r * R + c;
+            out_lo[o] = mask_lo ? v * mask_lo[o] : v;
+        } else {
+            const size_t o = r * R + (c - R);
+            out_hi[o] = mask_hi ? v * mask_hi[o] : v;
+        }
+    }
+}
+
 __global__ void meanpool_fwd_kernel(const float *__restrict__ x, const float *__restrict__ mask, float *__restrict__ mean,
                                     int K, int D) {
     const int b = blockIdx.x;
@@ -995,6 +1014,15 @@ int capmi_glu_bwd(const float *d_out, const float *mask, const float *pre, float
     if (!d_out || !pre || !d_pre || M <= 0 || R <= 0) return CAPMI_EINVAL;
     hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for((size_t)M * R)), dim3(256), 0, (hipStream_t)stream, d_out, mask, pre, d_pre,
                        M, R);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_split_halves(const float *slabs, int splits, int64_t stride, const float *mask_lo, const float *mask_hi, float *out_lo,
+                       float *out_hi, int M, int R, void *stream) {
+    if (!slabs || !out_lo || !out_hi || splits < 1 || M <= 0 || R <= 0) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(split_halves_kernel, dim3(grid_for((size_t)M * 2 * R)), dim3(256), 0, (hipStream_t)stream, slabs, splits,
+                       (size_t)stride, mask_lo, mask_hi, out_lo, out_hi, M, R);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

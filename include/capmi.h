@@ -765,6 +765,13 @@ int capmi_glu_fwd_fused(const float *slabs, int splits, int64_t stride, const fl
                         int M, int R, void *stream);
 /* d_pre [M,2R] from d_out [M,R] (mask applied first) */
 int capmi_glu_bwd(const float *d_out, const float *mask, const float *pre, float *d_pre, int M, int R, void *stream);
+/* out_lo [M,R] = mask_lo * sum_s slabs[s][:, 0:R], out_hi [M,R] = mask_hi * sum_s slabs[s][:, R:2R]: the two halves of a [M,2R]
+ * product that is still `splits` K-slice slabs of pitch `stride` floats (or a finished matrix, splits = 1), each through its
+ * dropout mask (NULL = none).  The backward of torch.cat([att, query], -1) in the AoA blocks (AoAModel.py:92,174): d_cat = d_pre W
+ * feeds two consumers that want contiguous [M,R] operands -- one launch instead of a split-K reduction, two slice copies and
+ * two mask multiplies. */
+int capmi_split_halves(const float *slabs, int splits, int64_t stride, const float *mask_lo, const float *mask_hi, float *out_lo,
+                       float *out_hi, int M, int R, void *stream);
 /* masked mean over regions (AoAModel.py:214-219): mean[b,:] = sum_k m[b,k] x[b,k,:] / sum_k m[b,k] (m NULL = ones) */
 int capmi_meanpool_fwd(const float *x, const float *mask, float *mean, int B, int K, int D, void *stream);
 /* dx[b,k,:] (+)= m[b,k]/cnt * dmean[b,:] */

@@ -1,5 +1,6 @@
 """Kernel-level parity on a real MI355X: every C-ABI entry point against a plain PyTorch fp32/fp64
 reference of the same op (the oracle functions where one exists)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -433,3 +434,20 @@ def test_log_softmax_rows(dev, rows, V1):
     check(lib.capmi_log_softmax_rows(ptr(x), ptr(out), rows, V1, stream_ptr()), 'capmi_log_softmax_rows')
     want = torch.log_softmax(x.double().cpu(), -1)
     assert float((out.double().cpu() - want).abs().max()) < 1e-5          # values around -20: a few fp32 ulps
+
+
+@pytest.mark.parametrize('tile', ['128', '256'])
+def test_gemm_fat_both_tilings_edge_shapes_vs_fp64(tile):
+    """r5: the bf16x3 fat GEMM on 128 x 128 tiles (gemm_x3.hip) and on 256 x 128 tiles (gemm_x3w.hip: swizzled 64-byte LDS rows, 8
+    MFMA + 8 staging waves, valid-row / valid-k scalars instead of keep factors) against an fp64 product -- every operand layout
+    ([rows][K] / [K][rows] for A and B), M / N / K off every tile multiple (a 256-row tile with 4 valid rows, a second A block with
+    none), several K segments, and the pipelined mask / addend epilogue; relative error <= 2e-6 of max |ref| (fp32-grade).
+    The tiling is a per-process switch (CAPMI_X3_TILE, read once by libcapmi), hence the child process."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, CAPMI_X3_TILE=tile)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'tools_x3w_bench.py'), '--check'], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'all shapes ok' in r.stdout and 'BAD' not in r.stdout, r.stdout[-2000:]
