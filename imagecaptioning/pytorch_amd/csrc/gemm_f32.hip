@@ -596,7 +596,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     // two narrow ones per K tile (fewer staging instructions per MFMA) but rounds M up to 256 and halves the number of units.
     // CAPMI_X3_TILE = 128 / 256 forces one tiling (0: by cost).
     static const int env_tile = capmi::knob("CAPMI_X3_TILE", 0);
-    static const int env_wcost = capmi::knob("CAPMI_X3W_COST", 165);
+    static const int env_wcost = capmi::research("CAPMI_X3W_COST", 165);
     bool wide = false;
     const int gmw = (d->M + 255) / 256;
     if (x3_ok) {

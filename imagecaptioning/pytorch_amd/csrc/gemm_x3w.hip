@@ -323,7 +323,8 @@ int launch_x3w(const KArgs &a, int a_layout, int b_layout, dim3 tiles, hipStream
     const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
     constexpr size_t lds = 2 * (size_t)WSTAGE * sizeof(unsigned short);
     static_assert(lds <= 160 * 1024, "two stages must fit the CU's LDS");
-    static const int env_nsw = capmi::knob("CAPMI_X3W_NSW", 8), env_prio = capmi::knob("CAPMI_X3W_PRIO", 0);
+    // (research switches of a -DCAPMI_VARIANTS build; the product build compiles the measured best: 8 staging waves, priority 0)
+    static const int env_nsw = capmi::research("CAPMI_X3W_NSW", 8), env_prio = capmi::research("CAPMI_X3W_PRIO", 0);
 #define CAPMI_X3W_N(AK, BK_, NSW_)                                                                              \
     do {                                                                                                        \
         static bool attr_set = false;                                                                           \
