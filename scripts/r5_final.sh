@@ -11,4 +11,5 @@ cd /tmp && export TMPDIR=/tmp; rm -rf $R/gpurun_out/prof_r05_attn
 timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_r05_attn -- python $R/scripts/tools_attn_large.py > $R/$out/attn_large.log 2>&1
 cd $R; tail -1 $out/attn_large.log | cut -c1-400
 db=$(find gpurun_out/prof_r05_attn -name "*.db" | head -1); python scripts/tools_prof.py $db 1 "rocprofv3 --kernel-trace --stats -- python scripts/tools_attn_large.py" > gpurun_out/r05_attention_large_batch_trace.md; grep attention_fwd gpurun_out/r05_attention_large_batch_trace.md | cut -c1-200
-find gpurun_out -name "*.db" -size +30M -delete 2>/dev/null; du -sh gpurun_out | tail -1
+# keep the merged-back payload small (gpurun copies back at most 64 MiB): the summaries are what is kept
+find gpurun_out -name "*.db" -delete 2>/dev/null; find gpurun_out -name "*.csv" -size +512k -delete 2>/dev/null; rm -rf gpurun_out/prof_r05_* ; du -sh gpurun_out | tail -1
