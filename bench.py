@@ -112,7 +112,7 @@ def pmc_traffic(instance=False):
         return None
 
 
-PMC_FILE = 'r04g_pmc_traffic.json'
+PMC_FILE = 'r05_pmc_traffic.json'
 
 
 def prof_read(lib, cls):
@@ -520,7 +520,7 @@ def main():
                      'gemm_decode_stream': {'ms_per_step': round(g_ms / n_sampled, 4), 'launches_per_step': g_n / n_sampled},
                      'gemm_decode_small': {'ms_per_step': round(s_ms / n_sampled, 4), 'launches_per_step': s_n / n_sampled},
                      'attention_fwd': {'ms_per_step': round(a_ms / n_sampled, 4), 'launches_per_step': a_n / n_sampled},
-                     'note': 'full per-kernel table: profiles/r04_scst_kernel_stats.md (rocprofv3 --kernel-trace --stats)'}
+                     'note': 'full per-kernel table: profiles/r05_scst_kernel_stats.md (rocprofv3 --kernel-trace --stats)'}
         ach = (g_bytes / g_n) / (g_ms / g_n * 1e-3) / 1e9 if g_n else 0.0
         tfl = g_flops / (g_ms * 1e-3) / 1e12 if g_ms else 0.0
         # which roof bounds this launch mix.  The decode GEMMs compute fp32 through the bf16 pipe by the exact 3-way
@@ -576,8 +576,9 @@ def main():
             # dominate and are matrix-pipe problems: bf16 MFMA through the exact 3-way split, fp32-equivalent peak 2500 / 6 TF
             peak = MFMA_BF16_PEAK_TFLOPS / 6.0
             tf = f_flops / (f_ms * 1e-3) / 1e12 if f_ms else 0.0
-            roofline = {'kernel': 'gemm_x3_kernel (all fat GEMMs of the step: fp32 operands split exactly into 3 bf16 planes in the '
-                                  'kernel, v_mfma_f32_32x32x16_bf16, 6 MFMAs per fp32 MAC tile)',
+            roofline = {'kernel': 'gemm_x3_kernel / gemm_x3w_kernel (all fat GEMMs of the step, 128 x 128 or 256 x 128 tiles as the planner '
+                                  'costs them: fp32 operands split exactly into 3 bf16 planes in the kernel, v_mfma_f32_32x32x16_bf16, '
+                                  '6 MFMAs per fp32 MAC tile)',
                         'launches_per_step': f_n / n_sampled, 'sampled_launches': f_n, 'bound': 'mfma', 'achieved': round(tf, 2),
                         'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(tf / peak, 4), 'traffic': None,
                         'avg_launch_us': round(f_ms / max(f_n, 1) * 1e3, 2),
