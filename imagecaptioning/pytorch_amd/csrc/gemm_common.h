@@ -40,6 +40,8 @@ struct KArgs {
     int self_reduce;     // last-arriving K slice of a tile reduces all slices and applies the epilogue
     int sl;              // loader / consumer kernel: K chunks per workgroup slice (runtime)
     int ablate;          // experiments only (CAPMI_GEMM_ABLATE): 1 = skip MFMA phase, 2 = skip global loads, 4 = skip LDS writes
+    int transposed;      // r5 (gemm_x3w only): the kernel computes C^T -- seg A/B, M/N and the layouts arrive SWAPPED, C / ldc / bias /
+                         // row_bias / mask / addend keep C's own orientation ([N rows of this struct][M columns]); see x3_epilogue_t
 };
 
 // flat K-tile index -> (segment, k0)

@@ -597,32 +597,38 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     // CAPMI_X3_TILE = 128 / 256 forces one tiling (0: by cost).
     static const int env_tile = capmi::knob("CAPMI_X3_TILE", 0);
     static const int env_wcost = capmi::research("CAPMI_X3W_COST", 165);
-    bool wide = false;
-    const int gmw = (d->M + 255) / 256;
+    static const int env_swap = capmi::knob("CAPMI_X3_SWAP", 1);      // 0: never plan the swapped-operand (C^T) form
+    int tiling = 0;                   // 0: 128 x 128, 1: 256 (rows of C) x 128, 2: 128 x 256 (columns of C): the wide kernel on C^T
+    const int gmw = (d->M + 255) / 256, gnw = (d->N + 255) / 256;
     if (x3_ok) {
         // persistent kernel, one workgroup per CU: pick the K split that minimises (rounds x K tiles per unit) plus the
         // slab traffic it causes, in units of one K-tile step of the narrow kernel (~1.5 us; slabs move at ~4 TB/s)
         double best = 1e30;
         int best_sp = 1;
         const int sp_lo = splits > 0 ? splits : 1, sp_hi = splits > 0 ? splits : 16;
-        for (int w = 0; w < 2; ++w) {
-            if ((w == 0 && env_tile == 256) || (w == 1 && env_tile == 128)) continue;
-            // measured (profiles/r05_fat_gemm_wide.md): with fewer than four row tiles the wide tiling loses -- its last tile is mostly
-            // padding and takes the edge path of the split on every K tile ([320 x 4000]: 72 vs 69 us)
+        for (int w = 0; w < 3; ++w) {
+            if ((w == 0 && env_tile == 256) || (w >= 1 && env_tile == 128)) continue;
+            // measured (profiles/r05_fat_gemm_wide.md): with fewer than four 256-row tiles the wide tiling loses -- its last tile is
+            // mostly padding and takes the edge path of the split on every K tile ([320 x 4000]: 72 vs 69 us)
             if (w == 1 && env_tile != 256 && gmw < 4) continue;
             // ... and it is not used for GEMMs whose reduction is deferred: those are the weight gradients that run on a SIDE stream
             // beside the backward chain (ops.DeferredGrads).  A wide workgroup is 16 waves x 124 registers + 144 KB of LDS -- it
             // owns its CU -- and a persistent grid of them beside another stream's kernels starved both (Transformer XE 14.3 ->
             // 36.5 ms); the 128 x 128 kernel leaves room for the chain's small kernels.
             if (w == 1 && env_tile != 256 && d->defer_reduce) continue;
-            const int out_tiles = (w ? gmw : gm) * gn;
+            // w == 2: SKINNY products (few rows, many columns: the per-step gate / dX GEMMs of a teacher-forced XE step at bs64,
+            // [320 x 4000]) on the wide kernel with the operands SWAPPED -- the 256-row side of the tile runs along the WEIGHTS, the
+            // activations are the 128-row operand, the epilogue writes C^T back as C in 16-byte pieces (x3_epilogue_t).  Row-major
+            // activations only ([K][rows] A operands are the side-stream weight gradients, see above), at least four 256-column tiles.
+            if (w == 2 && (env_swap == 0 || d->a_layout != 0 || gnw < 4 || gmw >= 4)) continue;
+            const int out_tiles = w == 0 ? gm * gn : w == 1 ? gmw * gn : gnw * gm;
             const double step = w ? env_wcost / 100.0 : 1.0;
             for (int sp = sp_lo; sp <= sp_hi && sp <= tiles; ++sp) {
                 if (splits == 0 && sp > 1 && (!d->partial || (int64_t)sp * d->M * d->N > slab_cap)) break;
                 const double rounds = (double)((out_tiles * sp + 255) / 256);
                 const double slab_us = sp > 1 ? (2.0 * sp + 1.0) * d->M * (double)d->N * 4.0 / 4.0e6 : 0.0;
                 const double cost = rounds * ((tiles + sp - 1) / sp) * step + slab_us / 1.5;
-                if (cost < best) { best = cost; best_sp = sp; wide = (w == 1); }
+                if (cost < best) { best = cost; best_sp = sp; tiling = w; }
             }
         }
         if (splits == 0) splits = best_sp;
@@ -651,12 +657,23 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
     static const int env_log = capmi::knob("CAPMI_GEMM_LOG", 0);   // shape census on stderr (profiling)
     if (env_log)
         fprintf(stderr, "capmi_gemm M=%d N=%d tiles=%d al=%d bl=%d x3=%d wide=%d splits=%d defer=%d acc=%d\n", d->M, d->N, tiles,
-                d->a_layout, d->b_layout, (int)x3_ok, (int)(x3_ok && wide), splits, d->defer_reduce, d->accumulate);
+                d->a_layout, d->b_layout, (int)x3_ok, x3_ok ? tiling : 0, splits, d->defer_reduce, d->accumulate);
     dim3 grid(gn, gm, splits);
     const ProfInfo pi{pcls, bytes, flops};
     int rc;
-    if (x3_ok && wide) rc = launch_x3w(a, d->a_layout, d->b_layout, dim3(gn, gmw, splits), st, pcls, bytes, flops);
-    else if (x3_ok) rc = launch_x3(a, d->a_layout, d->b_layout, grid, st, pcls, bytes, flops);
+    if (x3_ok && tiling == 1) rc = launch_x3w(a, d->a_layout, d->b_layout, dim3(gn, gmw, splits), st, pcls, bytes, flops);
+    else if (x3_ok && tiling == 2) {
+        KArgs t = a;                                     // C^T = B A^T: operands, shapes and layouts swapped; C, its pitch and
+        for (int s2 = 0; s2 < CAPMI_MAX_SEG; ++s2) {     // the epilogue operands keep C's orientation (KArgs.transposed)
+            t.seg[s2].A = a.seg[s2].B; t.seg[s2].B = a.seg[s2].A;
+            t.seg[s2].lda = a.seg[s2].ldb; t.seg[s2].ldb = a.seg[s2].lda;
+            t.seg[s2].vecA = a.seg[s2].vecB; t.seg[s2].vecB = a.seg[s2].vecA;
+            t.seg[s2].Apl = nullptr;
+        }
+        t.M = a.N; t.N = a.M;
+        t.transposed = 1;
+        rc = launch_x3w(t, d->b_layout, d->a_layout, dim3(gm, gnw, splits), st, pcls, bytes, flops);
+    } else if (x3_ok) rc = launch_x3(a, d->a_layout, d->b_layout, grid, st, pcls, bytes, flops);
     else if (BM == 32 && BN == 128) rc = launch_cfg<32, 128, 1, 4, 3>(a, d->a_layout, d->b_layout, grid, st, pi);
     else if (BM == 64 && BN == 64) rc = launch_cfg<64, 64, 2, 2, 3>(a, d->a_layout, d->b_layout, grid, st, pi);
         else if (BM == 64 && BN == 128) rc = launch_cfg<64, 128, 1, 4, 2>(a, d->a_layout, d->b_layout, grid, st, pi);

@@ -31,6 +31,66 @@ struct Unit {
     int m0, n0, z, t_begin, nt;
 };
 
+// ---- epilogue of a unit of the TRANSPOSED product (r5, KArgs.transposed): the kernel multiplied with the operands swapped, so a
+// unit's rows are C's COLUMNS.  In the 32x32 MFMA's C/D layout a lane holds 4 CONSECUTIVE rows of the product per register group
+// (rows (r&3) + 8*(r>>2) + 4*(lane>>5)) = 4 consecutive columns of C: every access -- store, column bias, row bias, mask, addend -- is
+// one 16-byte piece per lane (lanes differ in C's row: 64 rows x 16 bytes per instruction; L2 assembles the 128-byte lines from the
+// 8 pieces the same wave writes).  Here a.M = columns of C, a.N = rows of C.
+template <int NJ>
+__device__ __forceinline__ void x3_epilogue_t(const KArgs &a, const Unit &un, const f32x16 (&acc)[2][NJ], int wm0, int wn0, int l31,
+                                              int half) {
+    const int Cr = a.N, Cc = a.M;                          // C's own shape
+    const bool to_partial = a.to_partial != 0;
+    float *out = to_partial ? a.partial + (size_t)un.z * Cr * Cc : a.C;
+    const int ldo = to_partial ? Cc : a.ldc;
+    const bool plain = to_partial || !(a.bias || a.bias2 || a.row_bias || a.relu || a.mul_mask || a.accumulate);
+    // 16-byte accesses need Cc % 4 == 0 (columns come in aligned quads: tile offsets are multiples of 4), 16-byte aligned pointers
+    // and pitches; otherwise element by element
+    auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool v4 = (Cc % 4 == 0) && (ldo % 4 == 0) && al16(out) &&
+                    (plain || ((!a.bias || al16(a.bias)) && (!a.bias2 || al16(a.bias2)) && (!a.row_bias || al16(a.row_bias)) &&
+                               (!a.mul_mask || al16(a.mul_mask)) && (!a.accumulate || (al16(a.addend) && a.ldc % 4 == 0))));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int m = un.n0 + wn0 + 32 * j + l31;      // C's row
+            if (m >= Cr) continue;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int n = un.m0 + wm0 + 32 * i + 8 * rg + 4 * half;        // first of 4 consecutive columns of C
+                if (n >= Cc) continue;
+                f32x4 v = {acc[i][j][4 * rg], acc[i][j][4 * rg + 1], acc[i][j][4 * rg + 2], acc[i][j][4 * rg + 3]};
+                if (v4) {
+                    if (!plain) {
+                        if (a.bias) v += *reinterpret_cast<const f32x4 *>(a.bias + n);
+                        if (a.bias2) v += *reinterpret_cast<const f32x4 *>(a.bias2 + n);
+                        if (a.row_bias) v += *reinterpret_cast<const f32x4 *>(a.row_bias + (size_t)(m / a.row_bias_div) * Cc + n);
+                        if (a.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                        if (a.mul_mask) v *= *reinterpret_cast<const f32x4 *>(a.mul_mask + (size_t)m * Cc + n);
+                        if (a.accumulate) v += *reinterpret_cast<const f32x4 *>(a.addend + (size_t)m * a.ldc + n);
+                    }
+                    *reinterpret_cast<f32x4 *>(out + (size_t)m * ldo + n) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e >= Cc) continue;
+                        float x = v[e];
+                        if (!plain) {
+                            if (a.bias) x += a.bias[n + e];
+                            if (a.bias2) x += a.bias2[n + e];
+                            if (a.row_bias) x += a.row_bias[(size_t)(m / a.row_bias_div) * Cc + n + e];
+                            if (a.relu) x = fmaxf(x, 0.f);
+                            if (a.mul_mask) x *= a.mul_mask[(size_t)m * Cc + n + e];
+                            if (a.accumulate) x += a.addend[(size_t)m * a.ldc + n + e];
+                        }
+                        out[(size_t)m * ldo + n + e] = x;
+                    }
+                }
+            }
+        }
+}
+
 // ---- epilogue of one output unit: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 template <int NJ>
 __device__ __forceinline__ void x3_epilogue(const KArgs &a, const Unit &un, const f32x16 (&acc)[2][NJ], int wm0, int wn0, int l31,

@@ -308,7 +308,8 @@ __global__ __launch_bounds__(512 + 64 * NSW) void gemm_x3w_kernel(const KArgs a,
             }
             __syncthreads();                               // stage g&1 released, stage (g+1)&1 ready
         }
-        x3_epilogue<2>(a, un, acc, wm0, wn0, l31, half);
+        if (a.transposed) x3_epilogue_t<2>(a, un, acc, wm0, wn0, l31, half);
+        else x3_epilogue<2>(a, un, acc, wm0, wn0, l31, half);
     }
 }
 

@@ -81,6 +81,10 @@ if short:
     run('txe dX ffn1 dH W    [6720x512]  K=2048', 6720, 512, [2048], 0, 1)
     run('uxe dW lstm dG^T X  [4000x1000] K=6720', 4000, 1000, [6720], 1, 1)
     run('square              [4096x4096] K=1024', 4096, 4096, [1024], 0, 0)
+    run('uxe gates  [h|x|h]  [320x4000]  K=3x1000', 320, 4000, [1000, 1000, 1000], 0, 0)
+    run('uxe gates  [h|h]    [320x4000]  K=2x1000', 320, 4000, [1000, 1000], 0, 0)
+    run('uxe dX gates dG W   [320x3000]  K=4000', 320, 3000, [4000], 0, 1)
+    run('aoa prefill         [360x2048]  K=1024', 360, 2048, [1024], 0, 0)
     sys.exit(0)
 worst = 0.0
 # ---- edge shapes, every layout (correctness only)
@@ -88,6 +92,15 @@ for al in (0, 1):
     for bl in (0, 1):
         for M, N, Ks in ((260, 1156, [36]), (516, 644, [100, 68]), (512, 512, [32]), (772, 520, [40, 32, 36]), (1028, 640, [1000])):
             worst = max(worst, run('edge al=%d bl=%d [%dx%d] K=%s' % (al, bl, M, N, Ks), M, N, Ks, al, bl, time_it=False))
+# skinny products (few rows, many columns): planned on the wide kernel with the operands swapped (C^T, x3_epilogue_t) -- 16-byte and
+# element-wise epilogue paths (N % 4 != 0), every epilogue operand, both B layouts, several K segments
+for bl in (0, 1):
+    for M, N, Ks in ((320, 4000, [100, 60]), (260, 1156, [36]), (300, 1032, [64, 32, 32]), (130, 2052, [40])):
+        worst = max(worst, run('skinny al=0 bl=%d [%dx%d] K=%s' % (bl, M, N, Ks), M, N, Ks, 0, bl, time_it=False))
+worst = max(worst, run('skinny al=0 bl=0 [300x1030] K=[64] (N % 4 != 0)', 300, 1030, [64], 0, 0, time_it=False))
+for epi in ('relu', 'add'):
+    worst = max(worst, run('skinny epilogue %s [320x1100] K=200' % epi, 320, 1100, [200], 0, 0, epi=epi, time_it=False))
+    worst = max(worst, run('skinny epilogue %s [300x1030] K=64 (element-wise)' % epi, 300, 1030, [64], 0, 0, epi=epi, time_it=False))
 worst = max(worst, run('edge epilogue relu+mask [772x520] K=200', 772, 520, [200], 0, 0, epi='relu', time_it=False))
 worst = max(worst, run('edge epilogue mask+addend [772x520] K=200', 772, 520, [200], 0, 1, epi='add', time_it=False))
 assert worst < 2e-6, worst
