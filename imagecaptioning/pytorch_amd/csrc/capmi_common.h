@@ -122,7 +122,7 @@ __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5
 
 // Environment switches of the library, all read once per process through these three helpers:
 //  * knob():     the documented product switches: CAPMI_GEMM_X3, CAPMI_ARES_X3, CAPMI_LC, CAPMI_GEMM_LOG and -- r5 --
-//                CAPMI_X3_TILE (fat-GEMM tiling: 0 by cost / 128 / 256), CAPMI_BATCHED_XT, CAPMI_BWD_SIDE.
+//                CAPMI_X3_TILE (fat-GEMM tiling: 0 by cost / 128 / 256), CAPMI_X3_SWAP, CAPMI_BATCHED_XT, CAPMI_BWD_SIDE.
 //  * research(): tuning constants of experiments (grid sizes, kernel flavours).  The product build compiles them to their
 //                measured-best defaults; only a -DCAPMI_VARIANTS build (scripts/build_variants.sh) reads the environment,
 //                and says so on stderr for every variable it finds set.
