@@ -537,7 +537,9 @@ def test_transformer_and_aoa_at_the_baseline_batch_vs_the_reference_itself(tag, 
     check_grads_against_fixture(z, tag, grads, skip=skip)
 
 
-def test_transformer_scst_train_mode_differentiates_the_pass_it_sampled():
+@pytest.mark.parametrize('d,h,dff,nl,K,V1,B,n,L,F', [(48, 4, 100, 2, 7, 101, 3, 2, 6, 44),
+                                                   (512, 8, 2048, 6, 36, 9488, 2, 2, 5, 2048)])      # r5: configs/transformer sizes
+def test_transformer_scst_train_mode_differentiates_the_pass_it_sampled(d, h, dff, nl, K, V1, B, n, L, F):
     """Train-mode Transformer SCST (loss_wrapper.py:63-68): the KV-cached rollout and the teacher-forced pass
     that carries the gradient run under ONE dropout realisation.  With the masks of that realisation injected into
     oracle/transformer.py: (a) the log-probs the rollout sampled from == the differentiated log-probs == the oracle's
@@ -547,7 +549,6 @@ def test_transformer_scst_train_mode_differentiates_the_pass_it_sampled():
     from imagecaptioning.pytorch_amd import synthetic, transformer_engine as E
     from imagecaptioning.pytorch_amd.captioning import models
     from imagecaptioning.pytorch_amd.captioning.modules import losses as Lm
-    d, h, dff, nl, K, V1, B, n, L, F = 48, 4, 100, 2, 7, 101, 3, 2, 6, 44
     p_embed, p_drop = 0.3, 0.2
     opt = synthetic.updown_opt(caption_model='transformer', input_encoding_size=d, rnn_size=dff, d_model=d, d_ff=dff, N_enc=nl,
                                N_dec=nl, num_att_heads=h, dropout=p_drop, drop_prob_lm=p_embed, seq_length=L, max_length=L,
@@ -604,7 +605,11 @@ def test_transformer_scst_train_mode_differentiates_the_pass_it_sampled():
     P['model.tgt_embed.1.pe'] = model.model.tgt_embed[1].pe.cpu()
     seq_c = seq.cpu()
     inp = torch.cat([seq_c.new_zeros(N, 1), seq_c[:, :-1]], 1)
-    want = T.forward_teacher(P, att, inp, am, h=h, n_enc=nl, n_dec=nl, drop=drop)
+    T.RELU_TIES = ties = {}                 # hidden units whose ReLU input is within 1e-4 of zero for some token (see _compare_model_with_oracle)
+    try:
+        want = T.forward_teacher(P, att, inp, am, h=h, n_enc=nl, n_dec=nl, drop=drop)
+    finally:
+        T.RELU_TIES = None
     assert used == set(named)
     live = torch.cat([seq_c.new_ones(N, 1), (seq_c[:, :-1] > 0).long()], 1).cumprod(1).bool()
     # (a) differentiated log-probs == oracle under the same realisation, on the live steps
@@ -621,7 +626,14 @@ def test_transformer_scst_train_mode_differentiates_the_pass_it_sampled():
     want_loss.backward()
     for k, prm in model.named_parameters():
         w = P[k].grad
-        assert float((prm.grad.cpu() - w).abs().max()) <= 1e-3 * float(w.abs().max()) + 1e-6, k
+        tie = ties.get(k.rsplit('.w_1.', 1)[0]) if (k.endswith('.w_1.weight') or k.endswith('.w_1.bias')) else None
+        err = (prm.grad.cpu() - w).abs()
+        if tie is not None and bool(tie.any()):         # a unit on the ReLU's kink takes one token's whole term either way
+            err_rows = err.reshape(err.shape[0], -1).max(1)[0]
+            assert float(err_rows[tie].max()) <= 5e-2 * float(w.abs().max()) + 1e-6, (k, 'rows with a ReLU tie')
+            assert int(tie.sum()) < 0.05 * tie.numel(), (k, int(tie.sum()))
+            err = err_rows[~tie]
+        assert float(err.max()) <= 1e-3 * float(w.abs().max()) + 1e-6, k
 
 
 @pytest.mark.parametrize('tag,seed,masked', [('u', 21, False), ('um', 22, True)])
