@@ -145,6 +145,22 @@ __global__ void teacher_bookkeep_kernel(const float *__restrict__ seq_logp, cons
     if (live) live[i] = 1;
 }
 
+// teacher forcing: the token embeddings (+ ReLU + dropout) of ALL T steps in one launch: x[t][n][:] = relu(E[forced[n][t]]) * mask
+__global__ void embed_fwd_all_steps_kernel(const int64_t *__restrict__ forced, int forced_ld, int64_t *__restrict__ it_all,
+                                           const float *__restrict__ E, const float *__restrict__ mask, float *__restrict__ x,
+                                           int T, int N, int Ed) {
+    const size_t total = (size_t)T * N * Ed;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / Ed;
+        const int c = (int)(i - row * Ed), t = (int)(row / N), n = (int)(row - (size_t)t * N);
+        const int64_t tok = forced[(size_t)n * forced_ld + t];
+        if (it_all && c == 0) it_all[row] = tok;
+        float v = fmaxf(E[(size_t)tok * Ed + c], 0.f);
+        if (mask) v *= mask[i];
+        x[i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -237,10 +253,14 @@ int capmi_updown_rollout_fwd(const capmi_updown_weights *w, capmi_updown_rollout
     const bool batched_xt = env_bxt && r->teacher && !sched && r->gates_att && r->xt &&
                             (int64_t)T * N * 4 * R < ((int64_t)1 << 31);
     if (batched_xt) {
-        for (int t = 0; t < T; ++t)
-            RC(capmi_embed_fwd_pl(r->forced + t, r->forced_ld, r->it_all ? r->it_all + (size_t)t * N : nullptr, w->embed,
-                                  r->drop_xt ? r->drop_xt + (size_t)t * N * E : nullptr, r->xt + (size_t)t * N * E, N, E, 1, nullptr,
-                                  stream));
+        {
+            const size_t total = (size_t)T * N * E;
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(embed_fwd_all_steps_kernel, dim3(blocks), dim3(256), 0, st, r->forced, r->forced_ld, r->it_all, w->embed,
+                               r->drop_xt, r->xt, T, N, E);
+            CAPMI_CHECK_LAUNCH();
+        }
         SegSpec sx{r->xt, E, w->att_w_ih + 2 * R, ld_att_ih, E, 1};
         RC(gemm(stream, 0, 0, T * N, 4 * R, r->gates_att, 4 * R, &sx, 1, r->partial, r->partial_capacity, 0, nullptr));
     }

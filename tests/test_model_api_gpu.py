@@ -354,6 +354,9 @@ def test_baseline_size_xe_step_and_incremental_decode_consistency(which):
     g = model._flat.grad
     assert torch.isfinite(g).all() and float(g.abs().max()) > 0
     for n_, p in model.named_parameters():
+        if n_.endswith('alpha_net.bias'):
+            continue              # the softmax over regions cancels this bias: its gradient is mathematically zero, and with another
+            #                       summation order (CAPMI_X3_TILE=256) the rounding noise that usually stands there is exactly 0.0
         assert float(p.grad.abs().max()) > 0, n_
     model.eval()
     with torch.no_grad():
