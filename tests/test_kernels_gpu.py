@@ -451,3 +451,21 @@ def test_gemm_fat_both_tilings_edge_shapes_vs_fp64(tile):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert 'all shapes ok' in r.stdout and 'BAD' not in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize('M,R,splits,masked', [(50, 1024, 5, False), (360, 1024, 1, True), (7, 12, 3, True)])
+def test_split_halves_vs_torch(dev, M, R, splits, masked):
+    """capmi_split_halves (r5; backward of torch.cat([att, query], -1) in the AoA blocks, AoAModel.py:92,174): out_lo / out_hi = the
+    two [M, R] halves of sum_s slabs[s] [M, 2R], each times its mask -- against torch on the same slabs"""
+    from imagecaptioning.pytorch_amd._lib import lib, ptr, check, stream_ptr
+    g = torch.Generator().manual_seed(3)
+    slabs = torch.randn(splits, M, 2 * R, generator=g).to(dev)
+    mlo = (torch.rand(M, R, generator=g) < 0.7).float().to(dev) / 0.7 if masked else None
+    mhi = (torch.rand(M, R, generator=g) < 0.7).float().to(dev) / 0.7 if masked else None
+    lo, hi = torch.empty(M, R, device=dev), torch.empty(M, R, device=dev)
+    check(lib.capmi_split_halves(ptr(slabs), splits, M * 2 * R, ptr(mlo), ptr(mhi), ptr(lo), ptr(hi), M, R, stream_ptr()), 'split_halves')
+    tot = slabs.sum(0)
+    want_lo, want_hi = tot[:, :R], tot[:, R:]
+    if masked:
+        want_lo, want_hi = want_lo * mlo, want_hi * mhi
+    assert float((lo - want_lo).abs().max()) <= 1e-5 and float((hi - want_hi).abs().max()) <= 1e-5
