@@ -174,3 +174,28 @@ def test_updown_scheduled_sampling_replays_the_reference(tag):
     loss.backward()
     for k, p in P.items():
         np.testing.assert_allclose(p.grad.numpy(), g['%s_grad.%s' % (tag, k)], rtol=2e-4, atol=2e-7, err_msg=k)
+
+
+def test_aoa_sampled_rollout_oracle_is_consistent_with_teacher_forcing():
+    """oracle/aoa.sample (r5: the CPU baseline of bench.py --config aoa_nsc times it) restates AttModel._sample for sample_n rows
+    per image WITH the autograd graph.  Teacher-forcing the tokens it drew (oracle forward_teacher, pinned by aoa_tiny.npz) must
+    give the same log-probs on the live steps, rows after their end are zero, and the new_self_critical loss differentiates."""
+    import numpy as np
+    import torch
+    from oracle import aoa as A, att_lstm as O
+    z = np.load(os.path.join(GOLDEN, 'aoa_tiny.npz'))
+    u = np.load(os.path.join(GOLDEN, 'updown_tiny.npz'))
+    P = {k[2:]: torch.from_numpy(z[k]).clone().requires_grad_(z[k].dtype.kind == 'f') for k in z.files if k.startswith('P.')}
+    att, am = torch.from_numpy(u['att']), torch.from_numpy(u['att_masks'])
+    B, n, L = att.shape[0], 3, 8
+    seq, slp = A.sample(P, att, am, 2, L, n=n, gen=torch.Generator().manual_seed(11))
+    assert seq.shape == (B * n, L) and slp.shape[:2] == (B * n, L) and slp.requires_grad
+    inp = torch.cat([seq.new_zeros(B * n, 1), seq[:, :-1]], 1).view(B, n, L)
+    want = A.forward_teacher(P, att, inp, am, h=2)
+    live = torch.cat([seq.new_ones(B * n, 1), (seq[:, :-1] > 0).long()], 1).cumprod(1).bool()
+    assert float((slp - want)[live].abs().max()) < 1e-5
+    assert float(slp[~live].abs().max() if (~live).any() else 0.0) == 0.0
+    assert bool((seq[~live] == 0).all())
+    loss = O.new_self_critical_loss(slp, seq, torch.rand(B * n, generator=torch.Generator().manual_seed(1)).double(), n)
+    loss.backward()
+    assert float(P['logit.weight'].grad.abs().sum()) > 0 and float(P['refiner.layers.0.self_attn.linears.0.weight'].grad.abs().sum()) > 0
