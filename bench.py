@@ -587,7 +587,7 @@ def main():
                         'ms_per_step': round(f_ms / n_sampled, 4),
                         'note': 'fp32-equivalent FLOPs (2 M N K) over the in-dispatch HIP-event time of every fat GEMM launch of the '
                                 'sampled steps; the bf16 pipe executes 6x as many'}
-            if args.config == 'transformer_xe' and os.environ.get('CAPMI_DW_STREAM', '1') != '0':
+            if args.config == 'transformer_xe' and os.environ.get('CAPMI_DW_STREAM', '0') == '1':
                 roofline['concurrency_note'] = ('r4: the weight-gradient GEMMs run on a side stream beside the dX chain (ops.DeferredGrads), so fat '
                                                 'GEMMs overlap and each launch takes longer than it does alone: the step is 7 % faster, the per-launch '
                                                 'rate reads lower (0.28 with CAPMI_DW_STREAM=0, profiles/r04e_txe_kernel_stats.md)')

@@ -213,11 +213,17 @@ class DeferredGrads:
         self.red, self.col, self.keep = [], [], []
         self.red_side, self.col_side, self.side_batches, self.synced = [], [], 0, None
         self.side = None
-        if os.environ.get('CAPMI_DW_STREAM', '1') != '0' and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        # r5: the side stream is OPT-IN (CAPMI_DW_STREAM=1).  It is worth 3-6 % on most boxes (Transformer XE 13.0 vs 13.5 ms) but its
+        # cross-stream hand-offs stall the chain on some (same binary: 16.7 ms with 128 x 128 tiles only, 36-38 ms once the main
+        # stream's GEMMs use CU-owning 256 x 128 tiles beside the side stream's persistent grids; the GEMM launches themselves keep
+        # their duration, the chip idles between them -- profiles/r05_fat_gemm_wide.md section 7).  One stream is the same on every box.
+        if os.environ.get('CAPMI_DW_STREAM', '0') == '1' and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
             if 'side' not in self.state:
                 self.state['side'] = torch.cuda.Stream(device=device)
                 self.state['events'] = []
             self.side, self.ev_pool, self.ev_used = self.state['side'], self.state['events'], 0
+        # nothing runs beside the deferred GEMMs when there is no side stream: the planner may give them 256 x 128 tiles too
+        self._policy_prev = lib.capmi_gemm_set_policy(1 if self.side is None else 0)
 
     def _side_follows_main(self):
         """the side stream waits for everything enqueued on the current stream so far"""
@@ -303,6 +309,7 @@ class DeferredGrads:
             t, _ = self._table('col', self.col, '<QQQiiii')
             check(lib.capmi_colsum_batch(t.data_ptr(), len(self.col), stream_ptr()), 'capmi_colsum_batch')
         self.red, self.col, self.keep = [], [], []
+        lib.capmi_gemm_set_policy(self._policy_prev)
 
     def abandon(self):
         """the backward raised: nothing is finished, but GEMMs already enqueued on the side stream may still be reading the dy / x
@@ -312,6 +319,7 @@ class DeferredGrads:
             torch.cuda.current_stream().wait_stream(self.side)
         self.red, self.col, self.keep = [], [], []
         self.red_side, self.col_side = [], []
+        lib.capmi_gemm_set_policy(self._policy_prev)
 
 
 def linear(x, weight, bias=None, relu=False, mul_mask=None, row_div=1, rows=None, ws=None, out=None):

@@ -96,6 +96,12 @@ typedef struct capmi_gemm_desc {
 } capmi_gemm_desc;
 
 int capmi_gemm_f32(capmi_gemm_desc *d, void *stream);
+/* r5 planner policy.  The fat GEMMs (bf16x3) run on 128 x 128 or 256 x 128 tiles, whichever the planner costs lower; a 256 x 128
+ * workgroup (16 waves, 144 KB of LDS) owns its CU, so GEMMs whose reduction is DEFERRED -- the weight gradients a trainer may run on
+ * a side stream beside its backward chain (train.py:193 `loss.backward()` has no such notion: autograd runs them in line) -- are
+ * kept on 128 x 128 tiles unless the caller states that nothing runs beside them: allow_wide_deferred != 0.  Process-wide, returns
+ * the previous setting; default 0. */
+int capmi_gemm_set_policy(int allow_wide_deferred);
 
 /* "A planes" of an activation matrix X[M <= 64, K] (row pitch ld): K in chunks of 32, chunk = [3 planes][64 rows][32 bf16],
  * x = h + m + l split exactly into three truncated bf16 values, 16-byte pieces of a row XOR-swizzled by (row >> 2) & 3 -- the
