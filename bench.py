@@ -211,6 +211,7 @@ def other_configs(budget_s=150.0):
             d = json.loads(lines[-1])
             rf, cb = d.get('roofline') or {}, d.get('cpu_baseline') or {}
             out[name] = {'metric': d['metric'], 'baseline_config': d['config']['baseline_config'], 'ms_per_step': d['ms_per_step'],
+                         'step_ms': d.get('step_ms'),
                          'captions_per_s': d['value'], 'steps': d['steps'], 'warmup': d['warmup'], 'dtype': d['dtype'],
                          'roofline': {k: rf.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_us')},
                          'cpu_baseline': {k: cb.get(k) for k in ('value', 'unit', 'cores', 'kind', 'sample')} if cb else None,
@@ -431,12 +432,17 @@ def main():
     t0 = time.perf_counter()
     if host_prof is not None:
         host_prof.enable()
+    # one event per step boundary (r5): the spread of the per-step times says whether a slow run is slow in every step or carries
+    # a few outliers (`step_ms`: min / median / max over the timed steps, by the device's clock)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     for i in range(args.steps):
+        marks[i].record()
         if i in sampled:
             lib.capmi_prof_enable(prof_mask)
         loss = step()
         if i in sampled:
             lib.capmi_prof_enable(0)
+    marks[args.steps].record()
     if host_prof is not None:
         host_prof.disable()
     sync()
@@ -449,6 +455,8 @@ def main():
             pstats.Stats(host_prof, stream=buf).sort_stats(key).print_stats(30)
             print('\n'.join(l[:160] for l in buf.getvalue().split('\n') if l.strip()), file=sys.stderr)
     lib.capmi_prof_enable(0)
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_ms = {'min': round(per_step[0], 3), 'median': round(per_step[len(per_step) // 2], 3), 'max': round(per_step[-1], 3)}
     n_sampled = max(1, len(sampled))
     allreduce_ms = None
     if dist is not None and not overlap and not sharded:
@@ -587,7 +595,7 @@ def main():
                         'ms_per_step': round(f_ms / n_sampled, 4),
                         'note': 'fp32-equivalent FLOPs (2 M N K) over the in-dispatch HIP-event time of every fat GEMM launch of the '
                                 'sampled steps; the bf16 pipe executes 6x as many'}
-            if args.config == 'transformer_xe' and os.environ.get('CAPMI_DW_STREAM', '0') == '1':
+            if args.config == 'transformer_xe' and os.environ.get('CAPMI_DW_STREAM', '1') != '0':
                 roofline['concurrency_note'] = ('r4: the weight-gradient GEMMs run on a side stream beside the dX chain (ops.DeferredGrads), so fat '
                                                 'GEMMs overlap and each launch takes longer than it does alone: the step is 7 % faster, the per-launch '
                                                 'rate reads lower (0.28 with CAPMI_DW_STREAM=0, profiles/r04e_txe_kernel_stats.md)')
@@ -608,7 +616,7 @@ def main():
         line = {
             'metric': names[args.config], 'value': round(value, 2),
             'unit': 'captions/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'init_steps': INIT_STEPS,
-            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'step_ms': step_ms, 'higher_is_better': True,
             'scaling': 'strong' if args.global_batch else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'numerics': 'fp32 storage and accumulation; GEMMs on the bf16 matrix pipe through an exact 3-way operand split '

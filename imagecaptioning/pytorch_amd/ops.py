@@ -213,11 +213,10 @@ class DeferredGrads:
         self.red, self.col, self.keep = [], [], []
         self.red_side, self.col_side, self.side_batches, self.synced = [], [], 0, None
         self.side = None
-        # r5: the side stream is OPT-IN (CAPMI_DW_STREAM=1).  It is worth 3-6 % on most boxes (Transformer XE 13.0 vs 13.5 ms) but its
-        # cross-stream hand-offs stall the chain on some (same binary: 16.7 ms with 128 x 128 tiles only, 36-38 ms once the main
-        # stream's GEMMs use CU-owning 256 x 128 tiles beside the side stream's persistent grids; the GEMM launches themselves keep
-        # their duration, the chip idles between them -- profiles/r05_fat_gemm_wide.md section 7).  One stream is the same on every box.
-        if os.environ.get('CAPMI_DW_STREAM', '0') == '1' and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        # r5: re-measured with the final kernels -- the side stream is worth 2-5 % of the Transformer step (13.45-13.69 vs 13.79-13.90 ms,
+        # 13.0 vs 13.8, 13.85 vs 14.35 on three boxes; profiles/r05_fat_gemm_wide.md section 7); CAPMI_DW_STREAM=0 runs the deferred
+        # GEMMs in line on one stream (they may then use 256 x 128 tiles too, see below)
+        if os.environ.get('CAPMI_DW_STREAM', '1') != '0' and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
             if 'side' not in self.state:
                 self.state['side'] = torch.cuda.Stream(device=device)
                 self.state['events'] = []
