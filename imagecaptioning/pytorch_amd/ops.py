@@ -200,6 +200,7 @@ class DeferredGrads:
     14.3 ms per step with the GEMMs alone (A/B inside one gpurun call; CAPMI_DW_STREAM=0 restores one stream and one flush)."""
 
     _arenas = {}
+    uploads = 0
     SIDE_BATCH = 64            # (batches of 12 vs one flush at the end: 14.37 vs 14.44 ms per Transformer XE step -- and 46 more launches; 64: +6)
 
     def __init__(self, device):
@@ -279,6 +280,7 @@ class DeferredGrads:
         if cached is not None and cached[0] == key:
             return cached[1], False
         raw = b''.join(struct.pack(fmt, *r) for r in rows)
+        DeferredGrads.uploads += 1          # (diagnostic: tables re-uploaded because the item list changed)
         t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory().to(self.dev, non_blocking=True)
         self.state['tables'][name] = (key, t)
         return t, True
