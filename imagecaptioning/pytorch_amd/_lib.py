@@ -191,6 +191,10 @@ SIGNATURES = {
     'capmi_glu_fwd': [_P, _P, _P, _P, _I, _I, _P],
     'capmi_glu_fwd_fused': [_P, _I, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     'capmi_glu_bwd': [_P, _P, _P, _P, _I, _I, _P],
+    'capmi_glu_bwd_add': [_P, _P, _P, _I, _I64, _P, _P, _P, _I, _I, _P],
+    'capmi_layernorm_bwd_slabs': [_P, _I, _I64, _P, _P, _P, _P, _P, _P, _I, _I64, _I, _P, _P, _I, _I, _F, _P],
+    'capmi_mha_fwd_qslabs': [_P, _I, _I, _I64, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'capmi_mha_bwd_slabs': [_P, _I, _I64, _I, _P, _I, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'capmi_gemm_set_policy': [_I],
     'capmi_split_halves': [_P, _I, _I64, _P, _P, _P, _P, _I, _I, _P],
     'capmi_meanpool_fwd': [_P, _P, _P, _I, _I, _I, _P],

@@ -57,12 +57,20 @@ def dcat_halves(d_pre, W, M, R, mask_lo=None, mask_hi=None, ws=None):
 _dh_ws = {}
 
 
-def _dh_workspace(dev):
-    """split-K slabs of d_gates W_hh between two steps of the BPTT (the default workspace is reused by the GEMMs in between)"""
-    key = str(dev)
+def _dh_workspace(dev, tag='dh'):
+    """split-K slabs that outlive the next GEMM launch (the default workspace is reused by the GEMMs in between): 'dh' -- d_gates W_hh
+    between two steps of the BPTT; r5, slab consumers: 'ctx' -- d_gates W_ih[:, E:] until the previous step's GLU backward,
+    'dqn' -- dq Wq until the LayerNorm backward (which also reads the query half of d_cat from the default workspace)"""
+    key = (str(dev), tag)
     if key not in _dh_ws:
         _dh_ws[key] = ops.Workspace(dev, floats=2 * 1024 * 1024)
     return _dh_ws[key]
+
+
+# r5: the decode step's three remaining stand-alone split-K reductions (query projection, dq Wq, the context-input gradient) and the
+# split of d_cat into its halves are done by the kernels that consume them (capmi_mha_fwd_qslabs, capmi_layernorm_bwd_slabs,
+# capmi_mha_bwd_slabs, capmi_glu_bwd_add): 4 launches fewer per step and direction, same bits.  CAPMI_AOA_SLABS=0: the r4 launches.
+SLAB_CONSUMERS = os.environ.get('CAPMI_AOA_SLABS', '1') != '0'
 
 
 class AoAGraph:
@@ -217,10 +225,16 @@ class AoAGraph:
                       'lstm_cell_fwd')
             check(lib.capmi_layernorm_fwd(ptr(self.h_att[t + 1]), ptr(a_n), ptr(b_n), ptr(self.qn[t]), ptr(self.q_ln_mean[t]),
                                           ptr(self.q_ln_inv[t]), N, R, EPS, st), 'layernorm_fwd')
-            ops.gemm([(self.qn[t], R, Wq, R, R, 1)], N, R, self.q[t], bias=bq)
             # keys = second half of p_att rows, values = first half (AoAModel.py:168); per image, stride 2R
-            check(lib.capmi_mha_fwd(ptr(self.q[t]), self.p_att.data_ptr() + 4 * R, ptr(self.p_att), K * 2 * R, 2 * R, ptr(self.smask),
-                                    1, 0, 0, 0, ptr(m_p), ptr(self.att_o[t]), ptr(self.p_dec[t]), N, n, 1, K, h, R // h, st), 'mha_fwd')
+            if SLAB_CONSUMERS:
+                spq = ops.gemm([(self.qn[t], R, Wq, R, R, 1)], N, R, ws.buf, ws=ws, defer_reduce=True)
+                check(lib.capmi_mha_fwd_qslabs(ws.slabs.data_ptr(), R, spq, N * R, ptr(bq), ptr(self.q[t]), self.p_att.data_ptr() + 4 * R,
+                                               ptr(self.p_att), K * 2 * R, 2 * R, ptr(self.smask), 1, 0, 0, 0, ptr(m_p), ptr(self.att_o[t]),
+                                               ptr(self.p_dec[t]), N, n, 1, K, h, R // h, st), 'mha_fwd_qslabs')
+            else:
+                ops.gemm([(self.qn[t], R, Wq, R, R, 1)], N, R, self.q[t], bias=bq)
+                check(lib.capmi_mha_fwd(ptr(self.q[t]), self.p_att.data_ptr() + 4 * R, ptr(self.p_att), K * 2 * R, 2 * R, ptr(self.smask),
+                                        1, 0, 0, 0, ptr(m_p), ptr(self.att_o[t]), ptr(self.p_dec[t]), N, n, 1, K, h, R // h, st), 'mha_fwd')
             c_segs = [(self.att_o[t], R, Wc, 2 * R, R, 1), (self.h_att[t + 1], R, (Wc, R), 2 * R, R, 1)]
             if use_pl:
                 sp2 = ops.gemm(c_segs, N, 2 * R, ws.buf, ws=ws, defer_reduce=True)
@@ -283,18 +297,39 @@ class AoAGraph:
         pl_dg = ops.planes_scratch(dev, ('aoa_dg', 4 * R), int(lib.capmi_planes_bytes(4 * R))) if use_pl else None
         ws2 = _dh_workspace(dev)
         dh_slabs, dh_splits = None, 0
+        fuse = SLAB_CONSUMERS
+        ws, ws3, ws4 = ops.default_workspace(dev), _dh_workspace(dev, 'ctx'), _dh_workspace(dev, 'dqn')
+        ctx_splits = 0
         for t in range(T - 1, -1, -1):
             # out_{t+1}: from the logit (through out_drop) and -- accumulated by step t+1 -- from its ctx input
-            check(lib.capmi_glu_bwd(ptr(d_out_all[t]), None, ptr(self.pre2[t]), ptr(d_pre2_all[t]), N, R, st), 'glu_bwd')
-            d_att, dh = dcat_halves(d_pre2_all[t], Wc, N, R)                          # [d_att | d_h_att] of [N,2R] = d_pre2 Wc
-            # attention: dq, dK/dV accumulated into the two halves of d_p_att across rows of an image and across time
             dq = dq_all[t]                                               # [N,R] = [N,1,R], written in place
-            check(lib.capmi_mha_bwd(ptr(d_att), ptr(self.q[t]), self.p_att.data_ptr() + 4 * R, ptr(self.p_att), K * 2 * R, 2 * R,
-                                    ptr(self.p_dec[t]), ptr(self.m_patt[t]), ptr(dq), d_p_att.data_ptr() + 4 * R, ptr(d_p_att),
-                                    K * 2 * R, 2 * R, 1, N, n, 1, K, h, R // h, st), 'mha_bwd')
-            d_qn = ops.matmul_nn(dq_all[t], Wq, out=ln_dy[t])
-            check(lib.capmi_layernorm_bwd(ptr(d_qn), ptr(self.h_att[t + 1]), ptr(a_n), ptr(self.q_ln_mean[t]), ptr(self.q_ln_inv[t]),
-                                          ptr(dh), 1, ptr(ln_g[t]), N, R, EPS, st), 'layernorm_bwd')
+            if fuse:
+                # the ctx-input gradient of step t+1 is still the slabs of its GEMM: this launch finishes them (mask, + d_out)
+                check(lib.capmi_glu_bwd_add(ptr(d_out_all[t]), None, ws3.slabs.data_ptr() if ctx_splits else None, ctx_splits, N * R,
+                                            ptr(self.m_ctx[t + 1]) if ctx_splits else None, ptr(self.pre2[t]), ptr(d_pre2_all[t]), N, R, st),
+                      'glu_bwd_add')
+                # [d_att | d_h_att] = d_pre2 Wc stays K-slice slabs of pitch 2R: the attention backward sums the first half while
+                # staging d_o, the LayerNorm backward the second as the gradient it adds its own term to
+                sp = ops.gemm([(d_pre2_all[t], 2 * R, Wc, 2 * R, 2 * R, 1)], N, 2 * R, ws.buf, a_layout=0, b_layout=1, ws=ws, defer_reduce=True)
+                check(lib.capmi_mha_bwd_slabs(ws.slabs.data_ptr(), sp, N * 2 * R, 2 * R, ptr(self.q[t]), 0, self.p_att.data_ptr() + 4 * R,
+                                              ptr(self.p_att), K * 2 * R, 2 * R, ptr(self.p_dec[t]), ptr(self.m_patt[t]), ptr(dq), 0,
+                                              d_p_att.data_ptr() + 4 * R, ptr(d_p_att), K * 2 * R, 2 * R, 1, N, n, 1, K, h, R // h, st),
+                      'mha_bwd_slabs')
+                spq = ops.gemm([(dq, R, Wq, R, R, 1)], N, R, ws4.buf, a_layout=0, b_layout=1, ws=ws4, defer_reduce=True)
+                dh = z(N, R)
+                check(lib.capmi_layernorm_bwd_slabs(ws4.slabs.data_ptr(), spq, N * R, ptr(ln_dy[t]), ptr(self.h_att[t + 1]), ptr(a_n),
+                                                    ptr(self.q_ln_mean[t]), ptr(self.q_ln_inv[t]), ws.slabs.data_ptr() + 4 * R, sp,
+                                                    N * 2 * R, 2 * R, ptr(dh), ptr(ln_g[t]), N, R, EPS, st), 'layernorm_bwd_slabs')
+            else:
+                check(lib.capmi_glu_bwd(ptr(d_out_all[t]), None, ptr(self.pre2[t]), ptr(d_pre2_all[t]), N, R, st), 'glu_bwd')
+                d_att, dh = dcat_halves(d_pre2_all[t], Wc, N, R)                          # [d_att | d_h_att] of [N,2R] = d_pre2 Wc
+                # attention: dq, dK/dV accumulated into the two halves of d_p_att across rows of an image and across time
+                check(lib.capmi_mha_bwd(ptr(d_att), ptr(self.q[t]), self.p_att.data_ptr() + 4 * R, ptr(self.p_att), K * 2 * R, 2 * R,
+                                        ptr(self.p_dec[t]), ptr(self.m_patt[t]), ptr(dq), d_p_att.data_ptr() + 4 * R, ptr(d_p_att),
+                                        K * 2 * R, 2 * R, 1, N, n, 1, K, h, R // h, st), 'mha_bwd')
+                d_qn = ops.matmul_nn(dq_all[t], Wq, out=ln_dy[t])
+                check(lib.capmi_layernorm_bwd(ptr(d_qn), ptr(self.h_att[t + 1]), ptr(a_n), ptr(self.q_ln_mean[t]), ptr(self.q_ln_inv[t]),
+                                              ptr(dh), 1, ptr(ln_g[t]), N, R, EPS, st), 'layernorm_bwd')
             # LSTM cell: dh = (att2ctx + query path) + the slabs of d_gates(t+1) W_hh
             dc_prev = z(N, R)
             dh_b = None if dh_slabs is None else dh_slabs.data_ptr()
@@ -309,8 +344,12 @@ class AoAGraph:
             dc_next = dc_prev
             if t > 0:
                 pl = [pl_dg] if use_pl else None
-                ops.gemm([(dg_all[t], 4 * R, (W_ih, E), ld_ih, 4 * R, 1)], N, R, d_out_all[t - 1], a_layout=0, b_layout=1,
-                         mul_mask=self.m_ctx[t], accumulate=True, a_planes=pl)
+                if fuse:
+                    ctx_splits = ops.gemm([(dg_all[t], 4 * R, (W_ih, E), ld_ih, 4 * R, 1)], N, R, ws3.buf, a_layout=0, b_layout=1, ws=ws3,
+                                          defer_reduce=True, a_planes=pl)
+                else:
+                    ops.gemm([(dg_all[t], 4 * R, (W_ih, E), ld_ih, 4 * R, 1)], N, R, d_out_all[t - 1], a_layout=0, b_layout=1,
+                             mul_mask=self.m_ctx[t], accumulate=True, a_planes=pl)
                 dh_splits = ops.gemm([(dg_all[t], 4 * R, W_hh, R, 4 * R, 1)], N, R, ws2.buf, a_layout=0, b_layout=1, ws=ws2,
                                      defer_reduce=True, a_planes=pl)
                 dh_slabs = ws2.slabs

@@ -165,6 +165,86 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reg_kernel(const float *__r
     }
 }
 
+// The same backward for a decode step of the AoA core (AoAModel.py:163-186), where BOTH inputs are still K-slice slabs of the GEMMs
+// that produced them: dy = sum_s dy_slabs[s] (the query projection's dX, also written out: its column sums are the b_2 gradient)
+// and the running gradient dx = sum_s acc_slabs[s] (row pitch acc_ld: the query half of d_cat) + the LayerNorm term.  Slabs are
+// added in slab order starting from 0.f like splitk_reduce_kernel / split_halves_kernel do, so the results carry the same bits as
+// reduce + split + capmi_layernorm_bwd -- two launches fewer per step.
+template <int NE>
+__global__ __launch_bounds__(256) void layernorm_bwd_slabs_kernel(const float *__restrict__ dy_slabs, int dy_splits, size_t dy_stride,
+                                                                  float *__restrict__ dy_out, const float *__restrict__ x,
+                                                                  const float *__restrict__ a, const float *__restrict__ mean,
+                                                                  const float *__restrict__ inv, const float *__restrict__ acc_slabs,
+                                                                  int acc_splits, size_t acc_stride, int acc_ld,
+                                                                  float *__restrict__ dx, float *__restrict__ g_scaled, int M, int D,
+                                                                  float eps) {
+    // One workgroup per row (50 rows in a decode step: waves, not workgroups, are scarce).  Phase 1, all 256 threads: a thread owns
+    // 16-byte pieces of the row and requests 8 slabs of each input before it adds the first (a slab per round trip was 145 us per
+    // launch, four per round trip with a wave per row 18 us); the finished dy and dx-input rows go to LDS, dy also to dy_out.
+    // Phase 2, wave 0: layernorm_bwd_reg_kernel's arithmetic on the LDS rows with ITS lane -> column mapping and reduction order,
+    // so dx / g_scaled carry its bits.  Missing slabs add 0.f like splitk_reduce_kernel does.
+    __shared__ __attribute__((aligned(16))) float s_dy[64 * NE], s_acc[64 * NE];
+    const int r = blockIdx.x, lane = threadIdx.x & 63;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float *dyp = dy_slabs + (size_t)r * D, *acp = acc_slabs + (size_t)r * acc_ld;
+    for (int q = threadIdx.x; q < (D >> 2); q += blockDim.x) {
+        f32x4 d = zero4, o = zero4;
+        for (int s0 = 0; s0 < max(dy_splits, acc_splits); s0 += 8) {
+            f32x4 td[8], ta[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                td[u] = s0 + u < dy_splits ? *reinterpret_cast<const f32x4 *>(dyp + (size_t)(s0 + u) * dy_stride + 4 * q) : zero4;
+                ta[u] = s0 + u < acc_splits ? *reinterpret_cast<const f32x4 *>(acp + (size_t)(s0 + u) * acc_stride + 4 * q) : zero4;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                d += td[u];
+                o += ta[u];
+            }
+        }
+        *reinterpret_cast<f32x4 *>(s_dy + 4 * q) = d;
+        *reinterpret_cast<f32x4 *>(s_acc + 4 * q) = o;
+        if (dy_out) *reinterpret_cast<f32x4 *>(dy_out + (size_t)r * D + 4 * q) = d;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const float mu = mean[r], iv = inv[r];
+    float dv[NE], xc[NE], ov[NE], av[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int c = lane + 64 * i;
+        av[i] = c < D ? a[c] : 0.f;
+        xc[i] = c < D ? x[(size_t)r * D + c] : 0.f;
+        dv[i] = c < D ? s_dy[c] : 0.f;
+        ov[i] = c < D ? s_acc[c] : 0.f;
+    }
+    const float sd = 1.f / iv - eps;
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        if (lane + 64 * i < D) {
+            const float g = dv[i] * av[i];
+            xc[i] -= mu;
+            sg += g;
+            sgx += g * xc[i];
+        }
+    }
+    sg = wave_sum(sg);
+    sgx = wave_sum(sgx);
+    const float mg = sg / D;
+    const float k2 = sd > 0.f ? iv * iv / ((D - 1) * sd) * sgx : 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) {
+            const size_t j = (size_t)r * D + c;
+            const float v = iv * (dv[i] * av[i] - mg) - k2 * xc[i];
+            dx[j] = ov[i] + v;
+            if (g_scaled) g_scaled[j] = dv[i] * xc[i] * iv;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- short-sequence MHA
 constexpr int MHA_T = 256, MHA_T_BIG = 512, MHA_T_MAX = 1024;
 // phase ablation for profiling (scripts/mha_ablate.py): only the research build (-DCAPMI_VARIANTS) has the switch
@@ -330,12 +410,18 @@ __device__ __forceinline__ void mha_stage_kv(const float *__restrict__ k, const 
     }
 }
 
+template <bool QSLABS>
 __global__ __launch_bounds__(MHA_T_MAX) void mha_fwd_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                            const float *__restrict__ v, int ldkv, int kstride,
                                                            const uint8_t *__restrict__ mask, int mask_tq, int mask_per_q,
                                                            int causal, int q_pos0, const float *__restrict__ drop,
                                                            float *__restrict__ o, float *__restrict__ p, int q_per_kv, int Tq,
-                                                           int Tk, int h, int dk, int CH, int qstride, int mfma) {
+                                                           int Tk, int h, int dk, int CH, int qstride, int mfma, int q_splits,
+                                                           size_t q_slab_stride, const float *__restrict__ q_bias,
+                                                           float *__restrict__ q_out) {
+    // q_splits > 0 (r5): q is still `q_splits` K-slice slabs (row pitch qstride, q_slab_stride floats apart) of the query projection
+    // of an AoA decode step; each workgroup finishes its head's columns -- slabs in order from 0.f, then the bias, the bits of
+    // splitk_reduce_kernel -- and writes them to q_out (pitch D) for the backward
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int D = h * dk, P1 = dk + 4, S1 = Tk + 1, d4 = dk >> 2, d4sh = pow2_shift(d4);
     float *sK = lds, *sV = sK + Tk * P1, *sQ = sV + Tk * P1, *sS = sQ + CH * P1;
@@ -363,6 +449,28 @@ __global__ __launch_bounds__(MHA_T_MAX) void mha_fwd_kernel(const float *__restr
             for (int u = 0; u < 4; ++u) {
                 const int i = min(i0 + u * (int)blockDim.x, rows * d4 - 1), lr = idiv(i, d4, d4sh), c = (i - lr * d4) * 4;
                 qq[u] = *reinterpret_cast<const f32x4 *>(q + (qrow0 + lr) * qstride + hd * dk + c);
+            }
+            if constexpr (QSLABS) {
+                // (a decode step has fewer 16-byte pieces than threads: pieces one at a time, 8 slabs of a piece in flight)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * (int)blockDim.x;
+                    if (i >= rows * d4) continue;
+                    const int lr = idiv(i, d4, d4sh), c = (i - lr * d4) * 4;
+                    const float *src = q + (qrow0 + lr) * qstride + hd * dk + c;
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    for (int s0 = 0; s0 < q_splits; s0 += 8) {
+                        f32x4 tv[8];
+#pragma unroll
+                        for (int w = 0; w < 8; ++w)
+                            tv[w] = s0 + w < q_splits ? *reinterpret_cast<const f32x4 *>(src + (size_t)(s0 + w) * q_slab_stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) acc += tv[w];
+                    }
+                    if (q_bias) acc += *reinterpret_cast<const f32x4 *>(q_bias + hd * dk + c);
+                    if (q_out) *reinterpret_cast<f32x4 *>(q_out + (qrow0 + lr) * D + hd * dk + c) = acc;
+                    qq[u] = acc;
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -477,16 +585,19 @@ __global__ __launch_bounds__(MHA_T_MAX) void mha_fwd_kernel(const float *__restr
 // LDS: K, V, dK, dV [Tk][dk+4]; Q, dO [CH][dk+4]; P, P*drop, dS [CH][Tk+1]; row table [CH] (position)
 // MAXT: 1024 threads cap a thread at 128 registers, which this kernel exceeds (17 spilled, 72 bytes of scratch per lane); only the
 // small-grid launch shape needs them, every other shape runs the 512-thread instance
-template <int MAXT>
+template <int MAXT, bool DOSLABS = false>
 __global__ __launch_bounds__(MAXT) void mha_bwd_kernel(const float *__restrict__ d_o, const float *__restrict__ q,
                                                            const float *__restrict__ k, const float *__restrict__ v, int ldkv,
                                                            int kstride, const float *__restrict__ p,
                                                            const float *__restrict__ drop, float *__restrict__ dq,
                                                            float *__restrict__ dk_out, float *__restrict__ dv_out, int dkv_ld,
                                                            int dkv_stride, int accumulate, int q_per_kv, int Tq, int Tk, int h,
-                                                           int dk, int CH, int qstride, int dq_stride, int mfma) {
+                                                           int dk, int CH, int qstride, int dq_stride, int mfma, int do_ld,
+                                                           int do_splits, size_t do_stride) {
+    // do_ld / do_splits / do_stride (r5): d_o has row pitch do_ld and may still be `do_splits` K-slice slabs `do_stride` floats apart
+    // (the attention half of d_cat in an AoA decode step); summed in slab order from 0.f like split_halves_kernel
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int D = h * dk, P1 = dk + 4, S1 = Tk + 1, d4 = dk >> 2, d4sh = pow2_shift(d4);
+    const int D = DOSLABS ? do_ld : h * dk, P1 = dk + 4, S1 = Tk + 1, d4 = dk >> 2, d4sh = pow2_shift(d4);      // D: row pitch of d_o
     float *sK = lds, *sV = sK + Tk * P1, *sdK = sV + Tk * P1, *sdV = sdK + Tk * P1;
     float *sQ = sdV + Tk * P1, *sdO = sQ + CH * P1, *sP = sdO + CH * P1, *sPd = sP + CH * S1, *sdS = sPd + CH * S1;
     int *sTT = reinterpret_cast<int *>(sdS + CH * S1);
@@ -512,6 +623,25 @@ __global__ __launch_bounds__(MAXT) void mha_bwd_kernel(const float *__restrict__
                 const size_t rt = qrow0 + lr;
                 qq[u] = *reinterpret_cast<const f32x4 *>(q + rt * qstride + hd * dk + c);
                 oo[u] = *reinterpret_cast<const f32x4 *>(d_o + rt * D + hd * dk + c);
+            }
+            if constexpr (DOSLABS) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * (int)blockDim.x;
+                    if (i >= rows * d4) continue;
+                    const int lr = idiv(i, d4, d4sh), c = (i - lr * d4) * 4;
+                    const float *src = d_o + (qrow0 + lr) * D + hd * dk + c;
+                    f32x4 acc = zero4;
+                    for (int s0 = 0; s0 < do_splits; s0 += 8) {
+                        f32x4 tv[8];
+#pragma unroll
+                        for (int w = 0; w < 8; ++w)
+                            tv[w] = s0 + w < do_splits ? *reinterpret_cast<const f32x4 *>(src + (size_t)(s0 + w) * do_stride) : zero4;
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) acc += tv[w];
+                    }
+                    oo[u] = acc;
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -781,12 +911,25 @@ __global__ __launch_bounds__(256) void glu_fwd_fused_kernel(const float *__restr
 }
 
 __global__ void glu_bwd_kernel(const float *__restrict__ d_out, const float *__restrict__ mask, const float *__restrict__ pre,
-                               float *__restrict__ d_pre, int M, int R) {
+                               float *__restrict__ d_pre, int M, int R, const float *__restrict__ add_slabs, int add_splits,
+                               size_t add_stride, const float *__restrict__ add_mask) {
     const size_t total = (size_t)M * R;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t r = i / R, c = i % R;
         float g = d_out[i];
         if (mask) g *= mask[i];
+        if (add_slabs) {         // + add_mask * sum_s add_slabs[s]: a second gradient source still in K-slice slabs (splitk_reduce's order)
+            float v = 0.f;
+            for (int s0 = 0; s0 < add_splits; s0 += 8) {
+                float tv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tv[u] = s0 + u < add_splits ? add_slabs[(size_t)(s0 + u) * add_stride + i] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += tv[u];
+            }
+            if (add_mask) v *= add_mask[i];
+            g = v + g;
+        }
         const float a = pre[r * 2 * R + c], sg = sigmoid_f(pre[r * 2 * R + R + c]);
         d_pre[r * 2 * R + c] = g * sg;
         d_pre[r * 2 * R + R + c] = g * a * sg * (1.f - sg);
@@ -881,6 +1024,28 @@ int capmi_layernorm_bwd(const float *dy, const float *x, const float *a, const f
     return 0;
 }
 
+int capmi_layernorm_bwd_slabs(const float *dy_slabs, int dy_splits, int64_t dy_stride, float *dy_out, const float *x, const float *a,
+                              const float *mean, const float *inv, const float *acc_slabs, int acc_splits, int64_t acc_stride,
+                              int acc_ld, float *dx, float *g_scaled, int M, int D, float eps, void *stream) {
+    if (!dy_slabs || !x || !a || !mean || !inv || !acc_slabs || !dx || M <= 0 || D < 2 || D > 2048 || dy_splits < 1 || acc_splits < 1 ||
+        acc_ld < D)
+        return CAPMI_EINVAL;
+    if ((dy_splits > 1 && dy_stride < (int64_t)M * D) || (acc_splits > 1 && acc_stride < (int64_t)(M - 1) * acc_ld + D)) return CAPMI_EINVAL;
+    // 16-byte pieces of both inputs
+    if (D % 4 || acc_ld % 4 || dy_stride % 4 || acc_stride % 4 ||
+        ((reinterpret_cast<uintptr_t>(dy_slabs) | reinterpret_cast<uintptr_t>(acc_slabs) | reinterpret_cast<uintptr_t>(dy_out)) & 15))
+        return CAPMI_EINVAL;
+    const int blocks = M;
+#define CAPMI_LNS(NE_) hipLaunchKernelGGL(layernorm_bwd_slabs_kernel<NE_>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy_slabs, dy_splits, (size_t)dy_stride, dy_out, x, a, mean, inv, acc_slabs, acc_splits, (size_t)acc_stride, acc_ld, dx, g_scaled, M, D, eps)
+    if (D <= 256) CAPMI_LNS(4);
+    else if (D <= 512) CAPMI_LNS(8);
+    else if (D <= 1024) CAPMI_LNS(16);
+    else CAPMI_LNS(32);
+#undef CAPMI_LNS
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
 int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, int kstride, const uint8_t *mask, int mask_tq,
                   int mask_per_q, int causal, int q_pos0, const float *drop, float *o, float *p, int Nq, int q_per_kv,
                   int Tq, int Tk, int h, int dk, void *stream) {
@@ -891,6 +1056,17 @@ int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, int 
 int capmi_mha_fwd_s(const float *q, int qstride, const float *k, const float *v, int ldkv, int kstride, const uint8_t *mask,
                     int mask_tq, int mask_per_q, int causal, int q_pos0, const float *drop, float *o, float *p, int Nq,
                     int q_per_kv, int Tq, int Tk, int h, int dk, void *stream) {
+    return capmi_mha_fwd_qslabs(q, qstride, 0, 0, nullptr, nullptr, k, v, ldkv, kstride, mask, mask_tq, mask_per_q, causal, q_pos0, drop,
+                                o, p, Nq, q_per_kv, Tq, Tk, h, dk, stream);
+}
+
+int capmi_mha_fwd_qslabs(const float *q, int qstride, int q_splits, int64_t q_slab_stride, const float *q_bias, float *q_out,
+                         const float *k, const float *v, int ldkv, int kstride, const uint8_t *mask, int mask_tq, int mask_per_q,
+                         int causal, int q_pos0, const float *drop, float *o, float *p, int Nq, int q_per_kv, int Tq, int Tk, int h,
+                         int dk, void *stream) {
+    if (q_splits < 0 || (q_splits > 1 && (q_slab_stride % 4 || q_slab_stride < (int64_t)Nq * Tq * (qstride > 0 ? qstride : h * dk))))
+        return CAPMI_EINVAL;
+    if (q_splits > 0 && ((reinterpret_cast<uintptr_t>(q_bias) | reinterpret_cast<uintptr_t>(q_out)) & 15)) return CAPMI_EINVAL;
     if (qstride <= 0) qstride = h * dk;
     if (qstride % 4) return CAPMI_EINVAL;
     if (kstride <= 0) kstride = h * dk;
@@ -908,12 +1084,19 @@ int capmi_mha_fwd_s(const float *q, int qstride, const float *k, const float *v,
     if (lds > 160 * 1024) return CAPMI_EINVAL;
     static bool attr_f = false;      // more than 64 KB of dynamic LDS needs the opt-in (36 regions x 64 dims already do in bwd)
     if (!attr_f) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mha_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mha_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mha_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_f = true;
     }
     mha_sync_ablation();
-    hipLaunchKernelGGL(mha_fwd_kernel, dim3(Nq / q_per_kv, h), dim3(mha_threads(CH, Tk, wgs)), lds, (hipStream_t)stream, q, k, v, ldkv, kstride,
-                       mask, mask_tq, mask_per_q, causal, q_pos0, drop, o, p, q_per_kv, Tq, Tk, h, dk, CH, qstride, mha_on_mfma(CH));
+    if (q_splits > 0)
+        hipLaunchKernelGGL(mha_fwd_kernel<true>, dim3(Nq / q_per_kv, h), dim3(mha_threads(CH, Tk, wgs)), lds, (hipStream_t)stream, q, k, v, ldkv,
+                           kstride, mask, mask_tq, mask_per_q, causal, q_pos0, drop, o, p, q_per_kv, Tq, Tk, h, dk, CH, qstride,
+                           mha_on_mfma(CH), q_splits, (size_t)q_slab_stride, q_bias, q_out);
+    else
+        hipLaunchKernelGGL(mha_fwd_kernel<false>, dim3(Nq / q_per_kv, h), dim3(mha_threads(CH, Tk, wgs)), lds, (hipStream_t)stream, q, k, v, ldkv,
+                           kstride, mask, mask_tq, mask_per_q, causal, q_pos0, drop, o, p, q_per_kv, Tq, Tk, h, dk, CH, qstride,
+                           mha_on_mfma(CH), 0, (size_t)0, nullptr, nullptr);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -928,6 +1111,16 @@ int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float 
 int capmi_mha_bwd_s(const float *d_o, const float *q, int qstride, const float *k, const float *v, int ldkv, int kstride,
                     const float *p, const float *drop, float *dq, int dq_stride, float *dk_out, float *dv_out, int dkv_ld,
                     int dkv_stride, int accumulate, int Nq, int q_per_kv, int Tq, int Tk, int h, int dk, void *stream) {
+    return capmi_mha_bwd_slabs(d_o, 1, 0, h * dk, q, qstride, k, v, ldkv, kstride, p, drop, dq, dq_stride, dk_out, dv_out, dkv_ld,
+                               dkv_stride, accumulate, Nq, q_per_kv, Tq, Tk, h, dk, stream);
+}
+
+int capmi_mha_bwd_slabs(const float *d_o, int do_splits, int64_t do_stride, int do_ld, const float *q, int qstride, const float *k,
+                        const float *v, int ldkv, int kstride, const float *p, const float *drop, float *dq, int dq_stride,
+                        float *dk_out, float *dv_out, int dkv_ld, int dkv_stride, int accumulate, int Nq, int q_per_kv, int Tq,
+                        int Tk, int h, int dk, void *stream) {
+    if (do_splits < 1 || do_ld < h * dk || do_ld % 4 || (do_splits > 1 && (do_stride % 4 || do_stride < (int64_t)Nq * Tq * do_ld)))
+        return CAPMI_EINVAL;
     if (qstride <= 0) qstride = h * dk;
     if (dq_stride <= 0) dq_stride = h * dk;
     if (qstride % 4 || dq_stride % 4) return CAPMI_EINVAL;
@@ -950,18 +1143,29 @@ int capmi_mha_bwd_s(const float *d_o, const float *q, int qstride, const float *
     if (!attr_b) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mha_bwd_kernel<MHA_T_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mha_bwd_kernel<MHA_T_MAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mha_bwd_kernel<MHA_T_BIG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mha_bwd_kernel<MHA_T_MAX, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_b = true;
     }
     const int threads = mha_threads(CH, Tk, wgs);
     mha_sync_ablation();
-    if (threads > MHA_T_BIG)
+    if (do_splits > 1 || do_ld != h * dk) {             // d_o in slabs / with a pitch: instances of their own, the plain ones keep their code
+        if (threads > MHA_T_BIG)
+            hipLaunchKernelGGL((mha_bwd_kernel<MHA_T_MAX, true>), dim3(Nq / q_per_kv, h), dim3(threads), lds, (hipStream_t)stream, d_o, q, k, v,
+                               ldkv, kstride, p, drop, dq, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, q_per_kv, Tq, Tk, h, dk, CH,
+                               qstride, dq_stride, mha_on_mfma(CH), do_ld, do_splits, (size_t)do_stride);
+        else
+            hipLaunchKernelGGL((mha_bwd_kernel<MHA_T_BIG, true>), dim3(Nq / q_per_kv, h), dim3(threads), lds, (hipStream_t)stream, d_o, q, k, v,
+                               ldkv, kstride, p, drop, dq, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, q_per_kv, Tq, Tk, h, dk, CH,
+                               qstride, dq_stride, mha_on_mfma(CH), do_ld, do_splits, (size_t)do_stride);
+    } else if (threads > MHA_T_BIG)
         hipLaunchKernelGGL(mha_bwd_kernel<MHA_T_MAX>, dim3(Nq / q_per_kv, h), dim3(threads), lds, (hipStream_t)stream, d_o, q, k, v, ldkv,
                            kstride, p, drop, dq, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, q_per_kv, Tq, Tk, h, dk, CH, qstride,
-                           dq_stride, mha_on_mfma(CH));
+                           dq_stride, mha_on_mfma(CH), do_ld, do_splits, (size_t)do_stride);
     else
         hipLaunchKernelGGL(mha_bwd_kernel<MHA_T_BIG>, dim3(Nq / q_per_kv, h), dim3(threads), lds, (hipStream_t)stream, d_o, q, k, v, ldkv,
                            kstride, p, drop, dq, dk_out, dv_out, dkv_ld, dkv_stride, accumulate, q_per_kv, Tq, Tk, h, dk, CH, qstride,
-                           dq_stride, mha_on_mfma(CH));
+                           dq_stride, mha_on_mfma(CH), do_ld, do_splits, (size_t)do_stride);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -1011,9 +1215,15 @@ int capmi_glu_fwd_fused(const float *slabs, int splits, int64_t stride, const fl
 }
 
 int capmi_glu_bwd(const float *d_out, const float *mask, const float *pre, float *d_pre, int M, int R, void *stream) {
+    return capmi_glu_bwd_add(d_out, mask, nullptr, 0, 0, nullptr, pre, d_pre, M, R, stream);
+}
+
+int capmi_glu_bwd_add(const float *d_out, const float *mask, const float *add_slabs, int add_splits, int64_t add_stride,
+                      const float *add_mask, const float *pre, float *d_pre, int M, int R, void *stream) {
     if (!d_out || !pre || !d_pre || M <= 0 || R <= 0) return CAPMI_EINVAL;
+    if (add_slabs && (add_splits < 1 || (add_splits > 1 && add_stride < (int64_t)M * R))) return CAPMI_EINVAL;
     hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for((size_t)M * R)), dim3(256), 0, (hipStream_t)stream, d_out, mask, pre, d_pre,
-                       M, R);
+                       M, R, add_slabs, add_splits, (size_t)add_stride, add_mask);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

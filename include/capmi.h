@@ -726,6 +726,14 @@ int capmi_layernorm_fwd(const float *x, const float *a, const float *b, float *y
  * for d_a; column-sum dy for d_b). */
 int capmi_layernorm_bwd(const float *dy, const float *x, const float *a, const float *mean, const float *inv,
                         float *dx, int accumulate, float *g_scaled, int M, int D, float eps, void *stream);
+/* r5, AoA decode step (AoAModel.py:163-186): the same backward when BOTH inputs are still K-slice slabs of the GEMMs that made
+ * them -- dy = sum_s dy_slabs[s] ([M,D] slabs dy_stride floats apart; the finished dy is also written to dy_out when not NULL: its
+ * column sums are d_b) and the running gradient the LayerNorm term is added to, dx = sum_s acc_slabs[s] + ..., slabs of row pitch
+ * acc_ld (a column block of a wider product: the query half of d_cat, AoAModel.py:174) acc_stride floats apart.  Slabs are added
+ * in slab order from 0.f, the bits of capmi_splitk_reduce / capmi_split_halves followed by capmi_layernorm_bwd(accumulate=1). */
+int capmi_layernorm_bwd_slabs(const float *dy_slabs, int dy_splits, int64_t dy_stride, float *dy_out, const float *x, const float *a,
+                              const float *mean, const float *inv, const float *acc_slabs, int acc_splits, int64_t acc_stride,
+                              int acc_ld, float *dx, float *g_scaled, int M, int D, float eps, void *stream);
 /* multi-head scaled-dot-product attention for short sequences (TransformerModel.py:152-195), one workgroup
  * per (key/value batch row, head).  q [Nq,Tq,D], k,v rows of pitch ldkv floats ([Nkv,Tk,D] or a KV cache
  * [Nkv,Lmax,D]), D = h*dk, heads interleaved along D exactly like `.view(N,-1,h,dk)`.  Query row r attends
@@ -744,6 +752,13 @@ int capmi_mha_fwd(const float *q, const float *k, const float *v, int ldkv, int 
 int capmi_mha_fwd_s(const float *q, int qstride, const float *k, const float *v, int ldkv, int kstride, const uint8_t *mask,
                     int mask_tq, int mask_per_q, int causal, int q_pos0, const float *drop, float *o, float *p, int Nq,
                     int q_per_kv, int Tq, int Tk, int h, int dk, void *stream);
+/* r5: q still as the K-slice slabs of its projection GEMM (q_splits >= 1 slabs of row pitch qstride, q_slab_stride floats apart):
+ * every workgroup finishes its head's columns -- slabs in order from 0.f, + q_bias (NULL = none): the bits of capmi_splitk_reduce --
+ * and writes them to q_out [Nq,Tq,D] (NULL = not wanted) for the backward.  q_splits = 0: plain capmi_mha_fwd_s. */
+int capmi_mha_fwd_qslabs(const float *q, int qstride, int q_splits, int64_t q_slab_stride, const float *q_bias, float *q_out,
+                         const float *k, const float *v, int ldkv, int kstride, const uint8_t *mask, int mask_tq, int mask_per_q,
+                         int causal, int q_pos0, const float *drop, float *o, float *p, int Nq, int q_per_kv, int Tq, int Tk, int h,
+                         int dk, void *stream);
 /* backward: d_o [Nq,Tq,D] -> dq [Nq,Tq,D], dk/dv summed over the q_per_kv query rows of a kv row, written at
  * out + kv_row*dkv_ld + key*dkv_stride (+= when accumulate: BPTT over time steps) */
 int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float *v, int ldkv, int kstride, const float *p,
@@ -754,6 +769,12 @@ int capmi_mha_bwd(const float *d_o, const float *q, const float *k, const float 
 int capmi_mha_bwd_s(const float *d_o, const float *q, int qstride, const float *k, const float *v, int ldkv, int kstride,
                     const float *p, const float *drop, float *dq, int dq_stride, float *dk_out, float *dv_out, int dkv_ld,
                     int dkv_stride, int accumulate, int Nq, int q_per_kv, int Tq, int Tk, int h, int dk, void *stream);
+/* r5: d_o with a row pitch do_ld >= D and possibly still `do_splits` K-slice slabs do_stride floats apart (the attention half of
+ * d_cat in an AoA decode step), summed in slab order from 0.f like capmi_split_halves.  do_splits = 1, do_ld = D: capmi_mha_bwd_s. */
+int capmi_mha_bwd_slabs(const float *d_o, int do_splits, int64_t do_stride, int do_ld, const float *q, int qstride, const float *k,
+                        const float *v, int ldkv, int kstride, const float *p, const float *drop, float *dq, int dq_stride,
+                        float *dk_out, float *dv_out, int dkv_ld, int dkv_stride, int accumulate, int Nq, int q_per_kv, int Tq,
+                        int Tk, int h, int dk, void *stream);
 /* x[r,t,:] = E[tok[r,t]]*sqrt(D) + pe[pos0+t,:], then * drop (TransformerModel.py:215, 231-233) */
 int capmi_embed_pe_fwd(const int64_t *tok, int tok_ld, const float *E, const float *pe, const float *drop, float *x,
                        int N, int T, int D, int pos0, void *stream);
@@ -771,6 +792,12 @@ int capmi_glu_fwd_fused(const float *slabs, int splits, int64_t stride, const fl
                         int M, int R, void *stream);
 /* d_pre [M,2R] from d_out [M,R] (mask applied first) */
 int capmi_glu_bwd(const float *d_out, const float *mask, const float *pre, float *d_pre, int M, int R, void *stream);
+/* r5: the same with a second gradient source that is still K-slice slabs: g = mask * d_out + add_mask * sum_s add_slabs[s]
+ * ([M,R] slabs add_stride floats apart, added in slab order from 0.f, then the mask, then the sum: the bits of a split-K reduction
+ * with mul_mask + accumulate into d_out).  In an AoA BPTT step it is the gradient reaching out_t through step t+1's context input
+ * (AoAModel.py:165-166), whose GEMM then needs no reduce launch. */
+int capmi_glu_bwd_add(const float *d_out, const float *mask, const float *add_slabs, int add_splits, int64_t add_stride,
+                      const float *add_mask, const float *pre, float *d_pre, int M, int R, void *stream);
 /* out_lo [M,R] = mask_lo * sum_s slabs[s][:, 0:R], out_hi [M,R] = mask_hi * sum_s slabs[s][:, R:2R]: the two halves of a [M,2R]
  * product that is still `splits` K-slice slabs of pitch `stride` floats (or a finished matrix, splits = 1), each through its
  * dropout mask (NULL = none).  The backward of torch.cat([att, query], -1) in the AoA blocks (AoAModel.py:92,174): d_cat = d_pre W

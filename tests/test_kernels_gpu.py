@@ -469,3 +469,109 @@ def test_split_halves_vs_torch(dev, M, R, splits, masked):
     if masked:
         want_lo, want_hi = want_lo * mlo, want_hi * mhi
     assert float((lo - want_lo).abs().max()) <= 1e-5 and float((hi - want_hi).abs().max()) <= 1e-5
+
+
+# ---- r5: consumers of K-slice slabs in the AoA decode step -- each must carry the bits of the launches it replaces
+def _seq_sum(slabs):
+    v = torch.zeros_like(slabs[0])
+    for s in range(slabs.shape[0]):                  # slab order from 0.f, as capmi_splitk_reduce / capmi_split_halves do
+        v = v + slabs[s]
+    return v
+
+
+@pytest.mark.parametrize('M,D,s_dy,s_acc', [(50, 1024, 4, 8), (50, 1024, 1, 1), (7, 48, 3, 2), (360, 512, 2, 5), (13, 2000, 2, 2)])
+def test_layernorm_bwd_slabs_equals_reduce_split_layernorm_bwd(dev, M, D, s_dy, s_acc):
+    from imagecaptioning.pytorch_amd._lib import lib, ptr, check, stream_ptr
+    from imagecaptioning.pytorch_amd import transformer_engine as TE
+    g = torch.Generator().manual_seed(M + D)
+    x = torch.randn(M, D, generator=g).to(dev)
+    a, b = (torch.rand(D, generator=g) + 0.5).to(dev), torch.randn(D, generator=g).to(dev)
+    _, mean, inv = TE.layernorm_fwd(x, a, b)
+    dy_slabs = torch.randn(s_dy, M, D, generator=g).to(dev)
+    acc_slabs = torch.randn(s_acc, M, 2 * D, generator=g).to(dev)               # [att | query] halves: the query half is the input
+    st = stream_ptr()
+    # the launches it replaces: split-K reduce of dy, split of d_cat, LayerNorm backward accumulating into the query half
+    dy = torch.empty(M, D, device=dev)
+    check(lib.capmi_splitk_reduce(ptr(dy_slabs), s_dy, ptr(dy), D, M, D, None, None, None, 1, None, 0, 0, st), 'reduce')
+    lo, hi = torch.empty(M, D, device=dev), torch.empty(M, D, device=dev)
+    check(lib.capmi_split_halves(ptr(acc_slabs), s_acc, M * 2 * D, None, None, ptr(lo), ptr(hi), M, D, st), 'split')
+    gs = torch.empty(M, D, device=dev)
+    check(lib.capmi_layernorm_bwd(ptr(dy), ptr(x), ptr(a), ptr(mean), ptr(inv), ptr(hi), 1, ptr(gs), M, D, TE.EPS, st), 'ln_bwd')
+    # one launch
+    dy2, dx2, gs2 = torch.empty(M, D, device=dev), torch.empty(M, D, device=dev), torch.empty(M, D, device=dev)
+    check(lib.capmi_layernorm_bwd_slabs(ptr(dy_slabs), s_dy, M * D, ptr(dy2), ptr(x), ptr(a), ptr(mean), ptr(inv),
+                                        acc_slabs.data_ptr() + 4 * D, s_acc, M * 2 * D, 2 * D, ptr(dx2), ptr(gs2), M, D, TE.EPS, st), 'ln_bwd_slabs')
+    assert torch.equal(dy2, dy) and torch.equal(dy2, _seq_sum(dy_slabs))
+    assert torch.equal(dx2, hi) and torch.equal(gs2, gs)
+
+
+@pytest.mark.parametrize('Nkv,n,K,h,dk,splits,use_drop', [(10, 5, 36, 8, 128, 6, True), (10, 5, 36, 8, 128, 1, False), (3, 2, 7, 2, 8, 3, True),
+                                                          (2, 1, 100, 4, 64, 4, False)])
+def test_mha_slab_consumers_equal_reduce_then_attention(dev, Nkv, n, K, h, dk, splits, use_drop):
+    """AoA decode attention (one query per caption row over its image's K regions, keys / values the two halves of p_att rows,
+    AoAModel.py:163-175): capmi_mha_fwd_qslabs == split-K reduce (+ bias) then capmi_mha_fwd, capmi_mha_bwd_slabs == capmi_split_halves
+    then capmi_mha_bwd -- outputs, probabilities, the finished q and all three gradients bit for bit."""
+    from imagecaptioning.pytorch_amd._lib import lib, ptr, check, stream_ptr
+    D, N = h * dk, Nkv * n
+    g = torch.Generator().manual_seed(N + K)
+    p_att = torch.randn(Nkv, K, 2 * D, generator=g).to(dev)                     # [value | key] per region
+    q_slabs = (torch.randn(splits, N, D, generator=g) * 0.3).to(dev)
+    bq = torch.randn(D, generator=g).to(dev)
+    mask = torch.ones(Nkv, K, dtype=torch.uint8)
+    mask[0, K - 2:] = 0
+    mask = mask.to(dev)
+    drop = ((torch.rand(N, h, 1, K, generator=g) < 0.9).float() / 0.9).to(dev) if use_drop else None
+    st = stream_ptr()
+    keys, vals = p_att.data_ptr() + 4 * D, p_att.data_ptr()
+    q = torch.empty(N, D, device=dev)
+    check(lib.capmi_splitk_reduce(ptr(q_slabs), splits, ptr(q), D, N, D, ptr(bq), None, None, 1, None, 0, 0, st), 'reduce')
+    o, p = torch.empty(N, D, device=dev), torch.empty(N, h, 1, K, device=dev)
+    check(lib.capmi_mha_fwd(ptr(q), keys, vals, K * 2 * D, 2 * D, ptr(mask), 1, 0, 0, 0, ptr(drop), ptr(o), ptr(p), N, n, 1, K, h, dk, st), 'fwd')
+    q2, o2, p2 = torch.empty(N, D, device=dev), torch.empty(N, D, device=dev), torch.empty(N, h, 1, K, device=dev)
+    check(lib.capmi_mha_fwd_qslabs(ptr(q_slabs), D, splits, N * D, ptr(bq), ptr(q2), keys, vals, K * 2 * D, 2 * D, ptr(mask), 1, 0, 0, 0, ptr(drop),
+                                   ptr(o2), ptr(p2), N, n, 1, K, h, dk, st), 'fwd_qslabs')
+    assert torch.equal(q2, q) and torch.equal(o2, o) and torch.equal(p2, p)
+    assert float((q - (q_slabs.sum(0) + bq)).abs().max()) < 1e-5
+    # backward: d_o = the first half of d_cat, still slabs of pitch 2D
+    dcat = torch.randn(splits, N, 2 * D, generator=g).to(dev)
+    lo, hi = torch.empty(N, D, device=dev), torch.empty(N, D, device=dev)
+    check(lib.capmi_split_halves(ptr(dcat), splits, N * 2 * D, None, None, ptr(lo), ptr(hi), N, D, st), 'split')
+    outs = []
+    for fused in (False, True):
+        dq = torch.empty(N, D, device=dev)
+        dkv = torch.full((Nkv, K, 2 * D), 0.25, device=dev)                     # accumulate = 1: += over time steps
+        common = (ptr(q), 0, keys, vals, K * 2 * D, 2 * D, ptr(p), ptr(drop), ptr(dq), 0, dkv.data_ptr() + 4 * D, ptr(dkv), K * 2 * D, 2 * D, 1,
+                  N, n, 1, K, h, dk, st)
+        if fused:
+            check(lib.capmi_mha_bwd_slabs(ptr(dcat), splits, N * 2 * D, 2 * D, *common), 'bwd_slabs')
+        else:
+            check(lib.capmi_mha_bwd_s(ptr(lo), *common), 'bwd')
+        outs.append((dq, dkv))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][0].abs().max()) > 0
+
+
+@pytest.mark.parametrize('M,R,splits,masked', [(50, 1024, 7, True), (50, 1024, 1, False), (9, 20, 3, True)])
+def test_glu_bwd_add_equals_masked_accumulating_reduce_then_glu_bwd(dev, M, R, splits, masked):
+    from imagecaptioning.pytorch_amd._lib import lib, ptr, check, stream_ptr
+    g = torch.Generator().manual_seed(M * R + splits)
+    d_out = torch.randn(M, R, generator=g).to(dev)
+    slabs = torch.randn(splits, M, R, generator=g).to(dev)
+    mask = ((torch.rand(M, R, generator=g) < 0.5).float() * 2).to(dev) if masked else None
+    pre = torch.randn(M, 2 * R, generator=g).to(dev)
+    st = stream_ptr()
+    acc = d_out.clone()
+    check(lib.capmi_splitk_reduce(ptr(slabs), splits, ptr(acc), R, M, R, None, None, None, 1, ptr(mask), 0, 1, st), 'reduce')
+    want = torch.empty(M, 2 * R, device=dev)
+    check(lib.capmi_glu_bwd(ptr(acc), None, ptr(pre), ptr(want), M, R, st), 'glu_bwd')
+    got = torch.empty(M, 2 * R, device=dev)
+    check(lib.capmi_glu_bwd_add(ptr(d_out), None, ptr(slabs), splits, M * R, ptr(mask), ptr(pre), ptr(got), M, R, st), 'glu_bwd_add')
+    assert torch.equal(got, want)
+    tot = slabs.sum(0) * (mask if masked else 1.0) + d_out
+    sg = torch.sigmoid(pre[:, R:])
+    ref = torch.cat([tot * sg, tot * pre[:, :R] * sg * (1 - sg)], 1)
+    assert float((got - ref).abs().max()) < 1e-4
+    plain = torch.empty(M, 2 * R, device=dev)
+    check(lib.capmi_glu_bwd_add(ptr(d_out), None, None, 0, 0, None, ptr(pre), ptr(plain), M, R, st), 'glu_bwd_add')
+    check(lib.capmi_glu_bwd(ptr(d_out), None, ptr(pre), ptr(want), M, R, st), 'glu_bwd')
+    assert torch.equal(plain, want)

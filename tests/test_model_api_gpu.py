@@ -510,3 +510,38 @@ def test_step_api_embed_core_logit_are_callable_like_the_reference():
     for r in range(B):                                # rows agree with the reference's greedy decode up to the first EOS
         n_ = int((ref[r] > 0).sum())
         assert (got[r, :n_] == ref[r, :n_]).all()
+
+
+def test_aoa_slab_consumers_give_the_gradients_of_the_separate_reduce_launches(monkeypatch):
+    """r5: in an AoA decode step the query projection, dq Wq, the context-input gradient and d_cat stay K-slice slabs that their
+    consumers finish (aoa_engine.SLAB_CONSUMERS; capmi_mha_fwd_qslabs, capmi_mha_bwd_slabs, capmi_layernorm_bwd_slabs,
+    capmi_glu_bwd_add).  Config sizes of BASELINE configs[4], train mode, the same dropout masks through both code paths: same
+    loss and gradients (the kernels are bit-identical to the launches they replace, tests/test_kernels_gpu.py; the GEMM planner may
+    cut K differently for a deferred reduction, hence a tolerance of a few ulps of the largest gradient here)."""
+    from imagecaptioning.pytorch_amd import synthetic, aoa_engine as AE
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import LanguageModelCriterion
+    B = 10
+    opt = synthetic.updown_opt(caption_model='aoa', input_encoding_size=1024, rnn_size=1024, att_hid_size=512, num_heads=8,
+                               multi_head_scale=1, use_multi_head=2, refine=1, refine_aoa=1, use_ff=0, decoder_type='AoA',
+                               mean_feats=1, ctx_drop=1, dropout_aoa=0.3)
+    torch.manual_seed(12)
+    model = models.setup(opt).to(DEV)
+    model.flatten_parameters_()
+    fc, att = synthetic.batch(B, seed=8, device=DEV)
+    labels, masks = synthetic.xe_labels(B, n=5, L=20)
+    labels, masks = labels.to(DEV), masks.to(DEV)
+    model.train()
+    runs = []
+    for fused in (True, False):
+        monkeypatch.setattr(AE, 'SLAB_CONSUMERS', fused)
+        model._rng_calls = 50
+        model._flat.zero_grad()
+        out = model(fc, att, labels[..., :-1], None)
+        loss = LanguageModelCriterion()(out, labels[..., 1:], masks[..., 1:])
+        loss.backward()
+        runs.append((out.detach().clone(), float(loss.detach()), model._flat.grad.clone()))
+    (o1, l1, g1), (o0, l0, g0) = runs
+    assert float((o1 - o0).abs().max()) <= 2e-5 and abs(l1 - l0) <= 1e-6
+    scale = float(g0.abs().max())
+    assert scale > 0 and float((g1 - g0).abs().max()) <= 2e-5 * scale
