@@ -31,6 +31,12 @@ class GemmDesc(C.Structure):
                 ('defer_reduce', C.c_int), ('splits_used', C.c_int), ('a_planes', c_f * MAX_SEG), ('addend', c_f)]
 
 
+class NextEmbed(C.Structure):
+    """capmi_next_embed (include/capmi.h): the next step's token embedding written by the select launch"""
+    _fields_ = [('E', c_f), ('mask', c_f), ('x', c_f), ('it_save', c_f), ('Edim', C.c_int), ('relu', C.c_int), ('x_planes', c_f),
+                ('alive', c_f)]
+
+
 class UpDownWeights(C.Structure):
     _fields_ = [(k, c_f) for k in (
         'embed', 'att_w_ih', 'att_w_hh', 'att_b_ih', 'att_b_hh', 'lang_w_ih', 'lang_w_hh', 'lang_b_ih', 'lang_b_hh',

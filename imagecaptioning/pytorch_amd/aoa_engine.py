@@ -198,10 +198,15 @@ class AoAGraph:
             pl_ctx, pl_h, pl_od = (ops.planes_scratch(dev, ('aoa_' + k, R), nbR) for k in ('ctx', 'h', 'od'))
             pl_zero = ops.zero_planes(dev, max(nbR, nbE) // 12288)
             self.ctx_in[0].zero_()                               # out_0 = 0 (AoAModel.py:127-129)
+        # r5: a free-running rollout gets the embedding of step t+1 from the select launch of step t (capmi_next_embed, as the UpDown
+        # driver does): one launch fewer per step; a teacher-forced one knows its tokens and keeps the per-step launch
+        fold_embed = SLAB_CONSUMERS and use_pl and not teacher
         for t in range(T):
             m_xt, m_ctx, m_out, m_p = self.m_xt[t], self.m_ctx[t], self.m_out[t], self.m_patt[t]
             tok_src = (forced.data_ptr() + 8 * t, forced.shape[1]) if teacher else (ptr(it), 1)
-            if use_pl:
+            if fold_embed and t > 0:
+                pass                                              # written by the select launch of step t-1
+            elif use_pl:
                 check(lib.capmi_embed_fwd_pl(tok_src[0], tok_src[1], ptr(self.it_all[t]), ptr(P['embed.0.weight']), ptr(m_xt),
                                              ptr(self.xt[t]), N, E, 1, ptr(pl_xt), st), 'embed_fwd_pl')
             else:
@@ -255,9 +260,12 @@ class AoAGraph:
             # the logit GEMM leaves its K-slice slabs; log-softmax + select finishes them with the bias (no reduce launch)
             sp = ops.gemm([(self.out_drop[t], R, P['logit.weight'], R, R, 1)], N, V1, ws.buf, ws=ws, defer_reduce=True,
                           a_planes=[pl_od] if use_pl else None)
+            ne = None
+            if fold_embed and t + 1 < T:
+                ne = dict(E=P['embed.0.weight'], mask=self.m_xt[t + 1], x=self.xt[t + 1], it_save=self.it_all[t + 1], relu=1, x_planes=pl_xt)
             ops.logsoftmax_select(ws.slabs, t, L, mode_i, temperature, None if gumbel is None else gumbel[t], seed, forced,
                                   1 if teacher else 0, self.seq, it, unf, self.seq_logp, self.sel, self.live, top_k, top_p,
-                                  splits=sp, stride=N * V1, bias=P['logit.bias'], shape=(N, V1))
+                                  splits=sp, stride=N * V1, bias=P['logit.bias'], shape=(N, V1), next_embed=ne)
         return self.seq, self.seq_logp
 
     # ------------------------------------------------------------------ backward

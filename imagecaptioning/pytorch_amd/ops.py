@@ -499,17 +499,24 @@ def logsoftmax_bwd(g_dense, sparse, seq_logp, live, dlogits, N, L, T, V1):
 
 
 def logsoftmax_select(logits, step, L, mode, temperature, gumbel, seed, forced, no_finish_mask, seq, it_next, unfinished,
-                      seq_logp, sel_logp, live, top_k=0, top_p=0.0, splits=1, stride=0, bias=None, shape=None):
+                      seq_logp, sel_logp, live, top_k=0, top_p=0.0, splits=1, stride=0, bias=None, shape=None, next_embed=None):
     """capmi_logsoftmax_select_partial with the optional top-k / nucleus filter; used by the host-stepped decoders
     (Transformer, AoA).  logits: finished [N,V1] (one slab, no bias), or -- with shape=(N,V1) -- the `splits` K-slice slabs a
-    deferred logit GEMM left `stride` floats apart, finished here together with `bias`."""
+    deferred logit GEMM left `stride` floats apart, finished here together with `bias`.
+    next_embed: dict(E, mask, x, it_save, relu, x_planes) -- the workgroup that chose a row's token also writes the NEXT step's
+    input embedding x[r] = relu?(E[token]) * mask[r] (+ its planes) and it_save[r] = token (capmi_next_embed)."""
     N, V1 = logits.shape if shape is None else shape
     flt = _lib.SampleFilter(int(top_k), float(top_p))
+    ne = None
+    if next_embed is not None:
+        ne = _lib.NextEmbed(ptr(next_embed['E']), ptr(next_embed.get('mask')), ptr(next_embed['x']), ptr(next_embed.get('it_save')),
+                            int(next_embed['E'].shape[1]), int(next_embed.get('relu', 1)), ptr(next_embed.get('x_planes')), None)
     check(lib.capmi_logsoftmax_select_partial(ptr(logits), int(splits), int(stride), ptr(bias), N, V1, step, L, mode, None,
                                               float(temperature),
                                               ptr(gumbel), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(forced),
                                               0 if forced is None else forced.shape[1], int(no_finish_mask), ptr(seq), L,
-                                              ptr(it_next), ptr(unfinished), ptr(seq_logp), ptr(sel_logp), ptr(live), None,
+                                              ptr(it_next), ptr(unfinished), ptr(seq_logp), ptr(sel_logp), ptr(live),
+                                              None if ne is None else C.byref(ne),
                                               C.byref(flt) if (top_k or top_p) else None, stream_ptr()),
           'capmi_logsoftmax_select_partial')
 

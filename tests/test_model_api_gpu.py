@@ -545,3 +545,14 @@ def test_aoa_slab_consumers_give_the_gradients_of_the_separate_reduce_launches(m
     assert float((o1 - o0).abs().max()) <= 2e-5 and abs(l1 - l0) <= 1e-6
     scale = float(g0.abs().max())
     assert scale > 0 and float((g1 - g0).abs().max()) <= 2e-5 * scale
+    # a free-running sampled rollout in train mode (the new-self-critical step's): with the slab consumers the embedding of step t+1
+    # is also written by the select launch of step t (capmi_next_embed) -- same tokens, same log-probabilities
+    sampled = []
+    for fused in (True, False):
+        monkeypatch.setattr(AE, 'SLAB_CONSUMERS', fused)
+        model._rng_calls = 60
+        with torch.no_grad():
+            seq, lp = model(fc, att, None, opt={'sample_method': 'sample', 'sample_n': 5, 'temperature': 1.0}, mode='sample')
+        sampled.append((seq.clone(), lp.clone()))
+    assert torch.equal(sampled[0][0], sampled[1][0]) and sampled[0][0][:, 0].unique().numel() > 1
+    assert float((sampled[0][1] - sampled[1][1]).abs().max()) <= 2e-5
