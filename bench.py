@@ -414,13 +414,15 @@ def main():
     # The roofline's per-launch durations come from in-dispatch HIP events (start / stop events attached to the launch itself, on
     # the stream the kernel runs on) INSIDE the timed region -- but only on a sample of its steps: bracketing all ~100 decode-GEMM
     # and attention launches of every step costs 0.48 ms per step (5.18 vs 4.70 ms measured back to back), 10 % of the metric.
-    # Two of the K timed steps (one when K < 10) carry the events: >= 120 samples of the dominant kernel, < 1 % perturbation.
+    # ONE of the K timed steps (two from K = 40 up) carries the events: a whole step is every launch position of the dominant kernel
+    # exactly once (41 of the streaming decode GEMMs in the SCST step), and its 0.5 ms is 0.6 % of a 20-step region (r5: two sampled
+    # steps were 1.2 %: 4.16 vs 4.21 ms with and without `--no-prof`, `scripts/r5_ab12.sh`).
     prof_mask = (1 << 0) | (1 << 3) | (1 << 9)          # decode GEMMs (small / streaming) + fused attention
     if args.config in ('updown_xe', 'transformer_xe', 'newfc_xe'):
         prof_mask |= (1 << 2)                           # the time-batched fat GEMMs are the dominant kernels of the XE steps
     if args.no_prof:
         sampled = set()
-    elif args.steps >= 10:
+    elif args.steps >= 40:
         sampled = {args.steps // 3, (2 * args.steps) // 3}
     else:
         sampled = {args.steps // 2}
