@@ -65,7 +65,7 @@ def test_struct_layouts_match_header():
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
 
     def fields(struct):
-        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (struct, struct), src, flags=re.S).group(1)
+        body = re.search(r'typedef struct (?:%s )?\{([^{}]*?)\} %s;' % (struct, struct), src, flags=re.S).group(1)
         names = []
         for stmt in body.split(';'):
             stmt = stmt.strip()
@@ -80,7 +80,7 @@ def test_struct_layouts_match_header():
              'capmi_updown_rollout': _lib.UpDownRollout, 'capmi_updown_grads': _lib.UpDownGrads,
              'capmi_updown_bwd_scratch': _lib.UpDownBwdScratch, 'capmi_sparse_logp_grad': _lib.SparseLogpGrad, 'capmi_mask_desc': _lib.MaskDesc,
              'capmi_reduce_item': _lib.ReduceItem, 'capmi_colsum_item': _lib.ColsumItem,
-             'capmi_newfc_bwd_scratch': _lib.NewFCBwdScratch}
+             'capmi_newfc_bwd_scratch': _lib.NewFCBwdScratch, 'capmi_next_embed': _lib.NextEmbed, 'capmi_sample_filter': _lib.SampleFilter}
     for cname, cls in pairs.items():
         assert fields(cname) == [f[0] for f in cls._fields_], cname
 
