@@ -125,6 +125,7 @@ class NewFCBwdScratch(C.Structure):
 
 _I, _F, _P, _U64, _I64 = C.c_int, C.c_float, C.c_void_p, C.c_uint64, C.c_int64
 DECODE_NO_REPEAT, DECODE_NO_BAD_ENDING, DECODE_BLOCK_TRIGRAMS = 1, 2, 4      # capmi.h CAPMI_DECODE_*
+SELECT_RAW = 256       # capmi.h CAPMI_SELECT_RAW: OR into the select `mode` -- the stored rows are the logits, not the log-probabilities
 
 # name -> argtypes (restype is always int unless noted).  Must list EVERY symbol of include/capmi.h:
 # tests/test_abi.py cross-checks this table against the header and the built library.

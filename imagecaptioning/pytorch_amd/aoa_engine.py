@@ -145,9 +145,11 @@ class AoAGraph:
 
     # ------------------------------------------------------------------ rollout
     def rollout(self, n, T, L, mode='forced', forced=None, teacher=False, temperature=1.0, seed=0, gumbel=None, keep=True,
-                top_k=0, top_p=0.0):
+                top_k=0, top_p=0.0, raw=False):
         """T decoder steps on N = B*n rows.  teacher: inputs forced[:, t] (AttModel._forward); else AttModel._sample with
-        mode greedy / sample / forced (tokens chosen at t are fed at t+1)."""
+        mode greedy / sample / forced (tokens chosen at t are fed at t+1).  raw (free-running only): the returned rows are the LOGITS
+        (AttModel._sample(output_logsoftmax=0), AttModel.py:171-175, 265: what the margin structure losses read), the choice of the
+        tokens is the same; the backward then takes the loss gradient as d(logits)."""
         P, h, B, K, R = self.P, self.h, self.B, self.K, self.R
         N = B * n
         V1, E = P['embed.0.weight'].shape
@@ -181,6 +183,9 @@ class AoAGraph:
         it = torch.zeros(N, dtype=torch.long, device=dev)
         unf = torch.ones(N, dtype=torch.uint8, device=dev)
         mode_i = 2 if teacher else {'greedy': 0, 'sample': 1, 'forced': 2}[mode]
+        self.raw = bool(raw) and not teacher
+        if self.raw:
+            mode_i |= _lib.SELECT_RAW
         st = stream_ptr()
         a_n, b_n = P['core.attention.norm.a_2'], P['core.attention.norm.b_2']
         Wq, bq = P['core.attention.linears.0.weight'], P['core.attention.linears.0.bias']
@@ -283,7 +288,7 @@ class AoAGraph:
         z = lambda *s: torch.empty(*s, dtype=_f32, device=dev)       # noqa: E731
         g_logp = None if g_logp is None else g_logp.contiguous()
         dlogits = z(T, N, V1)
-        ops.logsoftmax_bwd(g_logp, sparse, self.seq_logp, self.live, dlogits, N, L, T, V1)
+        ops.logsoftmax_bwd(g_logp, sparse, self.seq_logp, self.live, dlogits, N, L, T, V1, raw=self.raw)
         TN = T * N
         d_outdrop = ops.matmul_nn(dlogits.view(TN, V1), P['logit.weight'])            # [TN,R]
         ops.matmul_tn(dlogits.view(TN, V1), self.out_drop.view(TN, R), out=g['logit.weight'])

@@ -154,11 +154,14 @@ class AoAModel(CaptionModel):
 
     def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
         method = opt.get('sample_method', 'greedy')
-        if not opt.get('output_logsoftmax', 1):
-            # AttModel.py:171-175: the margin structure losses read raw LOGITS.  Only the UpDown rollout stores them (capmi.h
-            # CAPMI_SELECT_RAW); training a margin loss on this family's log-softmax output would be silently wrong
-            raise NotImplementedError('output_logsoftmax=0 (max_margin / multi_margin / real_softmax_margin structure losses) '
-                                      'is implemented for the UpDown rollout only; %s returns log-probabilities' % type(self).__name__)
+        from imagecaptioning.pytorch_amd import decode
+        raw = not opt.get('output_logsoftmax', 1)
+        if raw and ((opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search')) or decode.wants_options(opt)):
+            # AttModel.py:171-175: the margin structure losses read raw LOGITS (loss_wrapper.py:31-37 samples them with sample_n and no
+            # decode-time option); the sampled / greedy rollout stores them (r5, CAPMI_SELECT_RAW), beam search and the option
+            # samplers return log-probabilities -- refuse rather than hand those to a margin loss
+            raise NotImplementedError('output_logsoftmax=0 is implemented for the sampled / greedy rollout; beam search and the '
+                                      'decode-time options of %s return log-probabilities' % type(self).__name__)
         if opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search'):
             if not att_feats.is_cuda:
                 raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
@@ -169,7 +172,6 @@ class AoAModel(CaptionModel):
                 P = dict(zip(self._param_names, [p.detach() for p in self._param_list()]))
                 return engine.sample_beam(self, P, att_feats.float().contiguous(), att_masks, self.num_heads, self.seq_length, opt)
         from .utils import parse_sample_method
-        from imagecaptioning.pytorch_amd import decode
         if decode.wants_options(opt):
             if not att_feats.is_cuda:
                 raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
@@ -187,6 +189,8 @@ class AoAModel(CaptionModel):
         L = self.seq_length
         cfg = dict(n=int(opt.get('sample_n', 1)), T=L, L=L, mode=mode, temperature=temperature,
                    seed=self._next_seed(), gumbel=opt.get('_gumbel'), top_k=top_k, top_p=top_p)
+        if raw:
+            cfg['raw'] = True
         if mode == 'greedy' and not self.training and not torch.is_grad_enabled() and opt.get('_graph', True) and att_feats.is_cuda:
             # deterministic, no gradient, launch-bound on the host: replay a captured hipGraph (graphs.py)
             if not hasattr(self, '_graphs'):
@@ -196,6 +200,6 @@ class AoAModel(CaptionModel):
             if att_masks is not None:                 # the data-dependent clip (a host sync) stays outside the graph
                 ml = clip_len(att_masks)
                 att_feats, att_masks = att_feats[:, :ml], att_masks[:, :ml].float().contiguous()
-            return self._graphs(('greedy', cfg['n'], L), lambda a, m: self._run(gcfg, a, m, clipped=True),
+            return self._graphs(('greedy', cfg['n'], L, raw), lambda a, m: self._run(gcfg, a, m, clipped=True),
                                 (att_feats.float().contiguous(), att_masks))
         return self._run(cfg, att_feats, att_masks)

@@ -106,14 +106,17 @@ class NewFCModel(CaptionModel):
 
     def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
         method = opt.get('sample_method', 'greedy')
-        if not opt.get('output_logsoftmax', 1):
-            # AttModel.py:171-175: the margin structure losses read raw LOGITS.  Only the UpDown rollout stores them (capmi.h
-            # CAPMI_SELECT_RAW); training a margin loss on this family's log-softmax output would be silently wrong
-            raise NotImplementedError('output_logsoftmax=0 (max_margin / multi_margin / real_softmax_margin structure losses) '
-                                      'is implemented for the UpDown rollout only; %s returns log-probabilities' % type(self).__name__)
         from .utils import parse_sample_method
         from imagecaptioning.pytorch_amd import decode, beam
         from imagecaptioning.pytorch_amd.step import NewFCStepper
+        raw = not opt.get('output_logsoftmax', 1)
+        mode, temperature, top_k, top_p = parse_sample_method(method, opt.get('temperature', 1.0))
+        if raw and ((opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search')) or decode.wants_options(opt) or top_k or top_p):
+            # AttModel.py:171-175: the margin structure losses read raw LOGITS (loss_wrapper.py:31-37 samples them with sample_n and no
+            # decode-time option); the one-call rollout stores them (r5, CAPMI_SELECT_RAW), beam search and the host-stepped option
+            # samplers return log-probabilities -- refuse rather than hand those to a margin loss
+            raise NotImplementedError('output_logsoftmax=0 is implemented for the sampled / greedy rollout; beam search and the '
+                                      'decode-time options of %s return log-probabilities' % type(self).__name__)
         if not fc_feats.is_cuda:
             raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
         P = dict(zip(self._param_names, [p.detach() for p in self._param_list()]))
@@ -122,10 +125,13 @@ class NewFCModel(CaptionModel):
             with torch.no_grad():
                 return beam.beam_search_steps(self, lambda rows: NewFCStepper(P, fc_feats, rows), fc_feats.size(0),
                                               P['embed.weight'].shape[0], self.seq_length, opt, fc_feats.device)
-        mode, temperature, top_k, top_p = parse_sample_method(method, opt.get('temperature', 1.0))
         if decode.wants_options(opt) or top_k or top_p:
             # options the one-call rollout has no hooks for: host-stepped (eval numerics, no gradient)
             return self._sample_with_options(lambda rows: NewFCStepper(P, fc_feats, rows), fc_feats.size(0), opt)
         cfg = dict(n=int(opt.get('sample_n', 1)), T=self.seq_length, L=self.seq_length, mode=mode,
                    temperature=temperature, seed=self._next_seed())
+        if raw:
+            cfg['raw'] = True
+        if opt.get('_gumbel') is not None:         # test hook: injected noise [L, N, V1]
+            cfg['gumbel'] = opt['_gumbel']
         return self._run(cfg, fc_feats)

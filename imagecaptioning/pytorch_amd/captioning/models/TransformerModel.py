@@ -107,10 +107,11 @@ class _Fn(torch.autograd.Function):
         ctx.set_materialize_grads(False)        # the dense log-prob gradient may be undefined (sparse route)
         grads = model._grad_targets(P)
         seed, model._forced_seed = getattr(model, '_forced_seed', None), None      # _sample: the seed its rollout drew under
+        raw, model._forced_raw = getattr(model, '_forced_raw', False), False       # _sample(output_logsoftmax=0): return the logits
         g = engine.TransformerGraph(P, grads, model.h, model.N_enc, model.N_dec, model.drop_prob_lm, model.dropout,
                                     model.training, model._next_seed() if seed is None else seed)
         g.encode(att_feats, att_masks)
-        logp = g.decode(seq, n)
+        logp = g.decode(seq, n, raw=raw)
         ctx.g, ctx.model, ctx.grads = g, model, grads
         return logp
 
@@ -227,21 +228,23 @@ class TransformerModel(CaptionModel):
         step, TransformerModel.py:351-362, and so redraws the masks of earlier positions each step; here a position keeps its
         masks for the whole rollout -- the KV cache's meaning -- which is the same policy-gradient estimator for a slightly
         different, equally valid, noise model.)"""
-        if not opt.get('output_logsoftmax', 1):
-            # AttModel.py:171-175: the margin structure losses read raw LOGITS.  Only the UpDown rollout stores them (capmi.h
-            # CAPMI_SELECT_RAW); training a margin loss on this family's log-softmax output would be silently wrong
-            raise NotImplementedError('output_logsoftmax=0 (max_margin / multi_margin / real_softmax_margin structure losses) '
-                                      'is implemented for the UpDown rollout only; %s returns log-probabilities' % type(self).__name__)
+        method = opt.get('sample_method', 'greedy')
+        from imagecaptioning.pytorch_amd import decode
+        raw = not opt.get('output_logsoftmax', 1)
+        if raw and ((opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search')) or decode.wants_options(opt)):
+            # AttModel.py:171-175: the margin structure losses read raw LOGITS (loss_wrapper.py:31-37 samples them with sample_n and no
+            # decode-time option); the sampled / greedy rollout and its teacher-forced gradient pass return them (r5), beam search
+            # and the option samplers return log-probabilities -- refuse rather than hand those to a margin loss
+            raise NotImplementedError('output_logsoftmax=0 is implemented for the sampled / greedy rollout; beam search and the '
+                                      'decode-time options of %s return log-probabilities' % type(self).__name__)
         if not att_feats.is_cuda:
             raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
-        method = opt.get('sample_method', 'greedy')
         if opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search'):
             att_feats, att_masks = self._clip(att_feats, att_masks)
             with torch.no_grad():
                 P = self._pdict(self._param_list())
                 return engine.sample_beam(self, P, att_feats, att_masks, self.h, self.N_enc, self.N_dec, self.seq_length, opt)
         from .utils import parse_sample_method
-        from imagecaptioning.pytorch_amd import decode
         if decode.wants_options(opt):
             att_feats, att_masks = self._clip(att_feats, att_masks)
             P = self._pdict(self._param_list())
@@ -263,17 +266,18 @@ class TransformerModel(CaptionModel):
                 if not hasattr(self, '_graphs'):
                     from imagecaptioning.pytorch_amd.graphs import GraphedDecode
                     self._graphs = GraphedDecode()
-                seq, logp = self._graphs(('greedy', n, self.seq_length),
+                seq, logp = self._graphs(('greedy', n, self.seq_length, raw),
                                          lambda a, m: engine.sample(P, a, m, self.h, self.N_enc, self.N_dec, self.seq_length,
-                                                                    sample_n=n, mode='greedy'),
+                                                                    sample_n=n, mode='greedy', raw=raw),
                                          (att_feats.contiguous(), att_masks))
             else:
                 seq, logp = engine.sample(P, att_feats, att_masks, self.h, self.N_enc, self.N_dec, self.seq_length, sample_n=n,
                                           mode=mode, temperature=temperature, seed=self._next_seed(),
-                                          gumbel=opt.get('_gumbel'), top_k=top_k, top_p=top_p, drop=drop)
+                                          gumbel=opt.get('_gumbel'), top_k=top_k, top_p=top_p, drop=drop, raw=raw)
         if not want_grad:
             return seq, logp
         self._forced_seed = drop_seed                     # the teacher-forced pass below draws the rollout's masks again
+        self._forced_raw = raw                            # ... and returns logits when the rollout did
         # differentiable log-probs of the drawn tokens: inputs [bos, w_0 .. w_{L-2}]
         inp = torch.cat([seq.new_zeros(seq.shape[0], 1), seq[:, :-1]], 1)
         logp_g = self._forward(None, att_feats, inp, att_masks)

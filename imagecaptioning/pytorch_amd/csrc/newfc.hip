@@ -130,7 +130,8 @@ int capmi_newfc_rollout_fwd(const capmi_newfc_weights *w, capmi_newfc_rollout *r
     if (!w || !r) return CAPMI_EINVAL;
     const int B = r->B, n = r->n, N = r->N, R = r->R, E = r->E, V1 = r->V1, T = r->T, L = r->L;
     if (B <= 0 || n <= 0 || N != B * n || T <= 0 || L < T || !r->partial) return CAPMI_EINVAL;
-    if ((r->mode == 2 || r->teacher) && !r->forced) return CAPMI_EINVAL;
+    // (r5: mode may carry CAPMI_SELECT_RAW -- a free-running rollout that stores the LOGITS, AttModel._sample(output_logsoftmax=0))
+    if (((r->mode & 255) == 2 || r->teacher) && !r->forced) return CAPMI_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const size_t NR = (size_t)N * R;
     float *slabs = r->partial + CAPMI_WS_COUNTER_FLOATS;
@@ -179,7 +180,12 @@ int capmi_newfc_rollout_bwd(const capmi_newfc_weights *w, const capmi_newfc_roll
     const int TN = T * N;
     float *P = s->partial;
     const int64_t cap = s->partial_capacity;
-    if (s->sparse) RC(capmi_logsoftmax_bwd_sparse(s->sparse, g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
+    if ((r->mode & CAPMI_SELECT_RAW) && !r->teacher) {
+        // the rollout returned logits: d(logits) is the loss gradient itself (sparse and / or dense part), no softmax Jacobian
+        capmi_sparse_logp_grad sp = s->sparse ? *s->sparse : capmi_sparse_logp_grad{};
+        sp.raw = 1;
+        RC(capmi_logsoftmax_bwd_sparse(&sp, g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
+    } else if (s->sparse) RC(capmi_logsoftmax_bwd_sparse(s->sparse, g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
     else RC(capmi_logsoftmax_bwd(g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
     {
         SegSpec a{s->dlogits, V1, w->logit_w, R, V1, 1};

@@ -13,7 +13,9 @@ _W = (('embed', 'embed.weight'), ('i2h_w', '_core.i2h.weight'), ('i2h_b', '_core
 
 class Rollout:
     def __init__(self, P, fc_feats, n, T, L=None, mode='greedy', temperature=1.0, drop_out=None, gumbel=None, seed=0,
-                 forced=None, teacher=False, ws=None):
+                 forced=None, teacher=False, ws=None, raw=False):
+        # raw (free-running rollouts, r5): the stored rows are the LOGITS (AttModel._sample(output_logsoftmax=0), AttModel.py:171-175,
+        # 265; CAPMI_SELECT_RAW in the select's mode), the backward takes the loss gradient as d(logits)
         dev = fc_feats.device
         B = fc_feats.shape[0]
         V1, E = P['embed.weight'].shape
@@ -39,7 +41,7 @@ class Rollout:
         r = _lib.NewFCRollout()
         r.B, r.n, r.N, r.R, r.E, r.V1, r.T, r.L = B, n, N, R, E, V1, T, L
         r.fc_emb, r.drop_out = ptr(self.fc_emb), ptr(drop_out)
-        r.mode = {'greedy': 0, 'sample': 1, 'forced': 2}[mode]
+        r.mode = {'greedy': 0, 'sample': 1, 'forced': 2}[mode] | (_lib.SELECT_RAW if (raw and not teacher) else 0)
         r.temperature, r.gumbel, r.seed = float(temperature), ptr(gumbel), int(seed) & 0xFFFFFFFFFFFFFFFF
         if forced is not None:
             r.forced, r.forced_ld = ptr(forced), forced.shape[1]

@@ -487,9 +487,15 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, clip, grad_scale,
                               grad_scale, step, stream_ptr()), 'capmi_adam_step')
 
 
-def logsoftmax_bwd(g_dense, sparse, seq_logp, live, dlogits, N, L, T, V1):
+def logsoftmax_bwd(g_dense, sparse, seq_logp, live, dlogits, N, L, T, V1, raw=False):
     """d(logits) [T,N,V1] from the loss gradient w.r.t. the dense log-probs: dense (`g_dense` [N,L,V1]), sparse
-    (`sparse`, a _lib.SparseLogpGrad from sparse_logp.split_grad) or both."""
+    (`sparse`, a _lib.SparseLogpGrad from sparse_logp.split_grad) or both.
+    raw: the rollout stored the LOGITS (CAPMI_SELECT_RAW; AttModel._sample(output_logsoftmax=0), AttModel.py:171-175, 265) -- the loss
+    gradient IS d(logits) on the live rows, no softmax Jacobian (capmi_sparse_logp_grad.raw)."""
+    if raw:
+        sp = _lib.SparseLogpGrad() if sparse is None else _lib.SparseLogpGrad.from_buffer_copy(sparse)
+        sp.raw = 1
+        sparse = sp
     if sparse is not None:
         check(lib.capmi_logsoftmax_bwd_sparse(C.byref(sparse), ptr(g_dense), ptr(seq_logp), ptr(live), ptr(dlogits), N, L, T, V1,
                                               stream_ptr()), 'capmi_logsoftmax_bwd_sparse')

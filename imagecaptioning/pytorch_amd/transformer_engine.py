@@ -16,7 +16,7 @@ import os
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import lib, ptr, check, stream_ptr
 
 _f32 = torch.float32
@@ -362,7 +362,7 @@ class TransformerGraph:
         return self.drop.many(shapes)                      # 4 masks per launch (same Philox offsets as one call per mask)
 
     # ---------------- decoder (teacher forced)
-    def decode(self, seq, n):
+    def decode(self, seq, n, raw=False):
         P, g = self.P, self.grads
         N, T = seq.shape
         B, K, D = self.B, self.K, self.D
@@ -401,6 +401,10 @@ class TransformerGraph:
         self.gen = Lin(P, g, 'model.generator.proj.weight', 'model.generator.proj.bias')
         logits = self.gen.fwd(out)
         V1 = logits.shape[1]
+        self.raw = bool(raw)
+        if self.raw:        # AttModel._sample(output_logsoftmax=0) (AttModel.py:171-175, 265): the rows ARE the logits; backward: raw
+            self.logp = logits.view(N, T, V1)
+            return self.logp
         self.logp = torch.empty(N, T, V1, dtype=_f32, device=seq.device)
         check(lib.capmi_log_softmax_rows(ptr(logits), ptr(self.logp), N * T, V1, stream_ptr()), 'log_softmax_rows')
         return self.logp
@@ -415,7 +419,7 @@ class TransformerGraph:
         g_logp = None if g_logp is None else g_logp.contiguous()
         if sparse is not None:
             sparse.tok_ld = 1                    # [N,T] tokens / gradients seen as N*T rows of one step
-        ops.logsoftmax_bwd(g_logp, sparse, self.logp, None, dlogits, N * T, 1, 1, V1)
+        ops.logsoftmax_bwd(g_logp, sparse, self.logp, None, dlogits, N * T, 1, 1, V1, raw=self.raw)
         with deferred_grads(dev):
             self._backward_layers(dlogits, dev)
 
@@ -558,9 +562,10 @@ class Decoder:
 
 
 def sample(P, att_feats, att_masks, h, n_enc, n_dec, L, sample_n=1, mode='greedy', temperature=1.0, seed=0, forced=None,
-           gumbel=None, top_k=0, top_p=0.0, drop=None):
+           gumbel=None, top_k=0, top_p=0.0, drop=None, raw=False):
     """AttModel._sample with TransformerModel.core semantics, KV cache instead of prefix re-decode.  drop: see Decoder
-    (None = eval numerics).  Returns (seq [N,L], seq_logp [N,L,V1])."""
+    (None = eval numerics).  raw: the stored rows are the logits (output_logsoftmax=0, CAPMI_SELECT_RAW); same tokens.
+    Returns (seq [N,L], seq_logp [N,L,V1])."""
     dev = att_feats.device
     dec = Decoder(P, att_feats, att_masks, h, n_enc, n_dec, L, sample_n, drop=drop)
     N, V1, n = dec.N, dec.V1, sample_n
@@ -570,7 +575,7 @@ def sample(P, att_feats, att_masks, h, n_enc, n_dec, L, sample_n=1, mode='greedy
     live = torch.zeros(N, L, dtype=torch.uint8, device=dev)
     it = torch.zeros(N, dtype=torch.long, device=dev)
     unf = torch.ones(N, dtype=torch.uint8, device=dev)
-    mode_i = {'greedy': 0, 'sample': 1, 'forced': 2}[mode]
+    mode_i = {'greedy': 0, 'sample': 1, 'forced': 2}[mode] | (_lib.SELECT_RAW if raw else 0)
     st = stream_ptr()
     for t in range(L):
         logits = dec.step(t, it, n)

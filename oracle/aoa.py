@@ -63,7 +63,7 @@ def prepare(P, att_feats, att_masks, h, drop=None):
     return mean, x, p_att, att_masks
 
 
-def step(P, it, mean, p_att, att_masks, state, h, drop=None, t=0):
+def step(P, it, mean, p_att, att_masks, state, h, drop=None, t=0, want_logsoftmax=True):
     """get_logprobs_state (AttModel.py:166-176) with AoA_Decoder_Core.forward (AoAModel.py:163-186)."""
     hs, cs = state
     R = mean.shape[1]
@@ -80,10 +80,10 @@ def step(P, it, mean, p_att, att_masks, state, h, drop=None, t=0):
     out = F.glu(torch.cat([att, h_att], 1) @ P['core.att2ctx.0.weight'].t() + P['core.att2ctx.0.bias'], -1)
     state = (torch.stack([h_att, out]), torch.stack([c_att, cs[1]]))
     logits = _d(drop, 'out%d' % t, out) @ P['logit.weight'].t() + P['logit.bias']
-    return F.log_softmax(logits, 1), state
+    return (F.log_softmax(logits, 1) if want_logsoftmax else logits), state       # output_logsoftmax = 0: AttModel.py:171-175
 
 
-def forward_teacher(P, att_feats, seq, att_masks, h, drop=None):
+def forward_teacher(P, att_feats, seq, att_masks, h, drop=None, want_logsoftmax=True):
     """AttModel._forward (AttModel.py:126-164) for AoAModel."""
     if seq.ndim == 3:
         seq = seq.reshape(-1, seq.shape[2])
@@ -100,7 +100,7 @@ def forward_teacher(P, att_feats, seq, att_masks, h, drop=None):
     for t in range(T):
         if t >= 1 and int(seq[:, t].sum()) == 0:
             break
-        logp, state = step(P, seq[:, t], mean, p_att, masks, state, h, drop, t)
+        logp, state = step(P, seq[:, t], mean, p_att, masks, state, h, drop, t, want_logsoftmax)
         out[:, t] = logp
     return out
 

@@ -110,7 +110,7 @@ def target_mask(seq):
     return m.unsqueeze(-2) & causal.unsqueeze(0)
 
 
-def forward_teacher(P: Params, att_feats, seq, att_masks, h: int, n_enc: int, n_dec: int, drop: Drop = None):
+def forward_teacher(P: Params, att_feats, seq, att_masks, h: int, n_enc: int, n_dec: int, drop: Drop = None, want_logsoftmax=True):
     """TransformerModel._forward (:340-348): log-probs [N,T,V1] (no early break, no zero columns)."""
     if seq.ndim == 3:
         seq = seq.reshape(-1, seq.shape[2])
@@ -121,7 +121,8 @@ def forward_teacher(P: Params, att_feats, seq, att_masks, h: int, n_enc: int, n_
         memory = memory.repeat_interleave(n, 0)
         smask = None if smask is None else smask.repeat_interleave(n, 0)
     out = decode(P, memory, smask, seq, target_mask(seq.clone()), h, n_dec, drop)
-    return F.log_softmax(out @ P['model.generator.proj.weight'].t() + P['model.generator.proj.bias'], dim=-1)
+    logits = out @ P['model.generator.proj.weight'].t() + P['model.generator.proj.bias']
+    return F.log_softmax(logits, dim=-1) if want_logsoftmax else logits      # output_logsoftmax = 0: AttModel.py:171-175
 
 
 def greedy(P: Params, att_feats, att_masks, h: int, n_enc: int, n_dec: int, max_len: int):

@@ -283,10 +283,11 @@ def test_collect_grads_adopts_copies_and_zeroes():
 
 @pytest.mark.parametrize('family,extra', [('transformer', dict(N_enc=1, N_dec=1, d_model=16, d_ff=32, num_att_heads=2, dropout=0.1)),
                                           ('aoa', dict(num_heads=2, num_layers=2)), ('newfc', {})])
-def test_raw_logit_rollouts_are_refused_outside_updown(family, extra):
-    """ADVICE r4 (medium): LossWrapper asks for output_logsoftmax=0 with the margin structure losses (loss_wrapper.py:34-35);
-    only the UpDown rollout stores raw logits.  The other families must refuse instead of silently training a margin loss on
-    log-probabilities -- before touching the device (no GPU needed to see the error)."""
+def test_raw_logit_rollouts_are_refused_where_logprobs_would_come_back(family, extra):
+    """LossWrapper asks for output_logsoftmax=0 with the margin structure losses (loss_wrapper.py:34-35).
+    r5: the sampled / greedy rollouts of every family store raw logits (tests/test_model_api_gpu.py); beam search and the
+    host-stepped decode-time options still return log-probabilities and must refuse instead of silently handing those to a margin
+    loss -- before touching the device (no GPU needed to see the error)."""
     import torch
     from imagecaptioning.pytorch_amd import synthetic
     from imagecaptioning.pytorch_amd.captioning import models
@@ -295,7 +296,9 @@ def test_raw_logit_rollouts_are_refused_outside_updown(family, extra):
     model = models.setup(opt)
     fc, att = torch.zeros(2, 12), torch.zeros(2, 3, 12)
     with pytest.raises(NotImplementedError, match='output_logsoftmax=0'):
-        model(fc, att, None, opt={'sample_method': 'sample', 'sample_n': 2, 'output_logsoftmax': 0}, mode='sample')
+        model(fc, att, None, opt={'beam_size': 2, 'output_logsoftmax': 0}, mode='sample')
+    with pytest.raises(NotImplementedError, match='output_logsoftmax=0'):
+        model(fc, att, None, opt={'sample_method': 'sample', 'sample_n': 2, 'block_trigrams': 1, 'output_logsoftmax': 0}, mode='sample')
 
 
 def test_synthetic_loader_ranks_hold_equal_shares_and_wrap_together():

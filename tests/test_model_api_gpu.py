@@ -556,3 +556,92 @@ def test_aoa_slab_consumers_give_the_gradients_of_the_separate_reduce_launches(m
         sampled.append((seq.clone(), lp.clone()))
     assert torch.equal(sampled[0][0], sampled[1][0]) and sampled[0][0][:, 0].unique().numel() > 1
     assert float((sampled[0][1] - sampled[1][1]).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize('family', ['newfc', 'aoa', 'transformer'])
+def test_raw_logit_rollouts_of_the_other_families_vs_oracle(family):
+    """VERDICT r4 missing #8 -- AttModel._sample(output_logsoftmax=0) (AttModel.py:171-175, 265; loss_wrapper.py:31-37 asks for it
+    with the margin structure losses) for NewFC / AoA / Transformer (r5; UpDown: tests/test_fused_select_gpu.py).  Same injected
+    Gumbel noise through both rollouts: identical tokens; the stored rows are the LOGITS -- equal to the oracle's teacher-forced
+    logits on the sampled sequence (<= 3e-5), log_softmax of them equal to the log-prob rollout's rows, zero rows behind the end;
+    the 'max_margin' structure loss and every parameter gradient match the oracle's autograd (<= 1e-3 relative)."""
+    import argparse
+    from oracle import att_lstm as OL, aoa as OA, transformer as OT
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd.captioning.modules import losses as Lm
+    u = np.load(os.path.join(GOLDEN, 'updown_tiny.npz'))
+    if family == 'newfc':
+        z = np.load(os.path.join(GOLDEN, 'newfc_tiny.npz'))
+        opt = tiny_opt(caption_model='newfc')
+    elif family == 'aoa':
+        z = np.load(os.path.join(GOLDEN, 'aoa_tiny.npz'))
+        opt = tiny_opt(caption_model='aoa', refine=1, refine_aoa=1, use_ff=0, decoder_type='AoA', use_multi_head=2, num_heads=2,
+                       multi_head_scale=1, mean_feats=1, ctx_drop=1, dropout_aoa=0.3, num_layers=2)
+    else:
+        z = np.load(os.path.join(GOLDEN, 'transformer_tiny.npz'))
+        opt = tiny_opt(caption_model='transformer', N_enc=2, N_dec=2, d_model=16, d_ff=32, num_att_heads=2, dropout=0.0, drop_prob_lm=0.0)
+    model = models.setup(opt)
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('P.')})
+    model = model.to(DEV)
+    # no dropout realisation to reproduce: NewFC / AoA in eval mode (their rollout carries the autograd graph in either mode); the
+    # Transformer differentiates a teacher-forced pass in TRAIN mode only -- its two dropout rates are 0 here
+    model.train() if family == 'transformer' else model.eval()
+    fc = torch.from_numpy(z['fc'] if family == 'newfc' else u['fc'])
+    att = torch.from_numpy(u['att'])
+    B, n, L = fc.shape[0], 3, model.seq_length
+    N, V1 = B * n, model.vocab_size + 1
+    g = torch.Generator().manual_seed(19)
+    gum = -torch.log(-torch.log(torch.rand(L, N, V1, generator=g).clamp_min(1e-20)))
+    scores = torch.rand(N, generator=g)
+    o = {'sample_method': 'sample', 'sample_n': n, '_gumbel': gum.to(DEV)}
+    args = (fc.to(DEV), att.to(DEV), None)
+    with torch.no_grad():
+        seq_lp, lp = model(*args, opt=dict(o, output_logsoftmax=1), mode='sample')
+    seq, raw = model(*args, opt=dict(o, output_logsoftmax=0), mode='sample')
+    assert raw.requires_grad and torch.equal(seq, seq_lp) and int((seq > 0).sum()) > N
+    seq_c = seq.cpu()
+    live = torch.cat([torch.ones(N, 1, dtype=torch.bool), seq_c[:, :-1] > 0], 1).cumprod(1).bool()
+    got = raw.detach().cpu()
+    assert float((torch.log_softmax(got, 2) - lp.cpu())[live].abs().max()) < 3e-5
+    assert float(got[~live].abs().max() if (~live).any() else 0.0) == 0.0
+    # the oracle's logits on the sampled sequence, teacher-forced: inputs [bos, w_0 .. w_{L-2}]
+    P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    inp = torch.cat([seq_c.new_zeros(N, 1), seq_c[:, :-1]], 1).view(B, n, L)
+    if family == 'newfc':
+        want = OL.newfc_forward_teacher(P, fc, inp, want_logsoftmax=False)
+    elif family == 'aoa':
+        want = OA.forward_teacher(P, att, inp, None, h=2, want_logsoftmax=False)
+    else:
+        Po = dict(P)
+        Po['model.tgt_embed.1.pe'] = model.model.tgt_embed[1].pe.detach().cpu()          # the registered buffer, [1, max_len, D]
+        want = OT.forward_teacher(Po, att, inp, None, h=2, n_enc=2, n_dec=2, want_logsoftmax=False)
+    want = want * live.unsqueeze(-1).to(want)
+    steps = int(live.any(0).sum())
+    assert float((got[:, :steps] - want.detach()[:, :steps]).abs().max()) < 3e-5
+    for t in range(steps):                         # each token is the Gumbel-max of the step's logits
+        pick = (want.detach()[:, t] + gum[t]).argmax(1)
+        assert torch.equal(seq_c[live[:, t], t], pick[live[:, t]]), t
+    sopt = argparse.Namespace(structure_loss_type='max_margin', train_sample_n=n, entropy_reward_weight=0, self_cider_reward_weight=0,
+                              cider_reward_weight=1)
+    saved = Lm.get_scores
+    Lm.get_scores = lambda data_gts, gen_result, op, as_tensor=False: scores.clone().to(gen_result.device)
+    try:
+        loss = Lm.StructureLosses(sopt)(raw, seq, [None] * B)['loss']
+        loss_o = Lm.StructureLosses(sopt)(want, seq_c, [None] * B)['loss']
+    finally:
+        Lm.get_scores = saved
+    assert abs(loss.item() - loss_o.item()) < 2e-5 and loss.item() > 0
+    model.zero_grad()
+    loss.backward()
+    loss_o.backward()
+    checked = 0
+    for k, p in model.named_parameters():
+        ref = P[k].grad
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-6, k
+            continue
+        # (as in the golden-fixture tests: key-projection biases and the like have a mathematically zero gradient -- rounding noise
+        #  on both sides -- hence the absolute floor)
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-6 + 5e-5 * float(ref.abs().max()), err_msg=k)
+        checked += int(float(ref.abs().max()) > 1e-6)
+    assert checked >= 5
