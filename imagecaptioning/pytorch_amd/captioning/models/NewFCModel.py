@@ -110,8 +110,9 @@ class NewFCModel(CaptionModel):
         from imagecaptioning.pytorch_amd import decode, beam
         from imagecaptioning.pytorch_amd.step import NewFCStepper
         raw = not opt.get('output_logsoftmax', 1)
-        mode, temperature, top_k, top_p = parse_sample_method(method, opt.get('temperature', 1.0))
-        if raw and ((opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search')) or decode.wants_options(opt) or top_k or top_p):
+        is_beam = opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search')
+        mode, temperature, top_k, top_p = (None, 1.0, 0, 0.0) if is_beam else parse_sample_method(method, opt.get('temperature', 1.0))
+        if raw and (is_beam or decode.wants_options(opt) or top_k or top_p):
             # AttModel.py:171-175: the margin structure losses read raw LOGITS (loss_wrapper.py:31-37 samples them with sample_n and no
             # decode-time option); the one-call rollout stores them (r5, CAPMI_SELECT_RAW), beam search and the host-stepped option
             # samplers return log-probabilities -- refuse rather than hand those to a margin loss
@@ -120,7 +121,7 @@ class NewFCModel(CaptionModel):
         if not fc_feats.is_cuda:
             raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
         P = dict(zip(self._param_names, [p.detach() for p in self._param_list()]))
-        if opt.get('beam_size', 1) > 1 and method in ('greedy', 'beam_search'):
+        if is_beam:
             # AttModel._sample_beam on the single-step decoder (the image step is taken once per image, AttModel.py:925-927)
             with torch.no_grad():
                 return beam.beam_search_steps(self, lambda rows: NewFCStepper(P, fc_feats, rows), fc_feats.size(0),
