@@ -60,7 +60,10 @@ class _Fn(torch.autograd.Function):
         seq, logp = g.rollout(**cfg)
         ctx.g, ctx.model, ctx.grads = g, model, grads
         ctx.mark_non_differentiable(seq)
-        return seq, logp
+        # (an ALIAS of the engine's tensor is returned: autograd hangs this Function on the returned object, and returning the very
+        #  tensor the saved engine holds would close a reference cycle ctx -> engine -> tensor -> grad_fn -> ctx -- every activation
+        #  of the step then lives until the interpreter's cyclic collector happens to run, not until the step's graph is dropped)
+        return seq, logp.detach()
 
     @staticmethod
     def backward(ctx, _gs, g_logp):

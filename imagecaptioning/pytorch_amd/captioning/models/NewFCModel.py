@@ -30,7 +30,10 @@ class _RolloutFn(torch.autograd.Function):
         seq, logp = ro.run()
         ctx.model, ctx.ro, ctx.P = model, ro, P
         ctx.mark_non_differentiable(seq)
-        return seq, logp
+        # (an ALIAS of the engine's tensor is returned: autograd hangs this Function on the returned object, and returning the very
+        #  tensor the saved engine holds would close a reference cycle ctx -> engine -> tensor -> grad_fn -> ctx -- every activation
+        #  of the step then lives until the interpreter's cyclic collector happens to run, not until the step's graph is dropped)
+        return seq, logp.detach()
 
     @staticmethod
     def backward(ctx, _g, g_logp):

@@ -113,7 +113,10 @@ class _Fn(torch.autograd.Function):
         g.encode(att_feats, att_masks)
         logp = g.decode(seq, n, raw=raw)
         ctx.g, ctx.model, ctx.grads = g, model, grads
-        return logp
+        # (an ALIAS of the engine's tensor is returned: autograd hangs this Function on the returned object, and returning the very
+        #  tensor the saved engine holds would close a reference cycle ctx -> engine -> tensor -> grad_fn -> ctx -- every activation
+        #  of the step then lives until the interpreter's cyclic collector happens to run, not until the step's graph is dropped)
+        return logp.detach()
 
     @staticmethod
     def backward(ctx, g_logp):

@@ -645,3 +645,54 @@ def test_raw_logit_rollouts_of_the_other_families_vs_oracle(family):
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-6 + 5e-5 * float(ref.abs().max()), err_msg=k)
         checked += int(float(ref.abs().max()) > 1e-6)
     assert checked >= 5
+
+
+@pytest.mark.parametrize('which', ['transformer', 'aoa', 'newfc'])
+def test_a_training_step_frees_its_activations_without_the_cyclic_collector(which):
+    """r5: the rollout / teacher-forcing Functions used to return the very tensor their saved engine object holds -- a reference
+    cycle (ctx -> engine -> tensor -> grad_fn -> ctx), so every activation of a step lived until the interpreter's cyclic collector
+    happened to run: memory (and the allocator's segment count) depended on collector timing, and a bench run could carry a 95 ms
+    step among 13.5 ms ones.  With the collector switched off, a step must return the device memory it took."""
+    import gc
+    from imagecaptioning.pytorch_amd import synthetic
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd.captioning.modules.losses import LanguageModelCriterion
+    B = 8
+    if which == 'transformer':
+        opt = synthetic.updown_opt(caption_model='transformer', input_encoding_size=512, rnn_size=2048, d_model=512, d_ff=2048,
+                                   N_enc=6, N_dec=6, num_att_heads=8, dropout=0.1)
+    elif which == 'aoa':
+        opt = synthetic.updown_opt(caption_model='aoa', input_encoding_size=1024, rnn_size=1024, att_hid_size=512, num_heads=8,
+                                   multi_head_scale=1, use_multi_head=2, refine=1, refine_aoa=1, use_ff=0, decoder_type='AoA',
+                                   mean_feats=1, ctx_drop=1, dropout_aoa=0.3)
+    else:
+        opt = synthetic.updown_opt(caption_model='newfc')
+    torch.manual_seed(3)
+    model = models.setup(opt).to(DEV)
+    model.flatten_parameters_()
+    fc, att = synthetic.batch(B, seed=2, device=DEV)
+    labels, masks = synthetic.xe_labels(B, n=5, L=20)
+    labels, masks = labels.to(DEV), masks.to(DEV)
+    model.train()
+    crit = LanguageModelCriterion()
+
+    def step():
+        model._flat.zero_grad()
+        loss = crit(model(fc, att, labels[..., :-1], None), labels[..., 1:], masks[..., 1:])
+        loss.backward()
+        return float(loss.detach())
+
+    step()
+    step()                                   # lazily created scratch (workspaces, planes, tables) exists now
+    torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()
+    try:
+        base = torch.cuda.memory_allocated()
+        step()
+        step()
+        torch.cuda.synchronize()
+        held = torch.cuda.memory_allocated() - base
+    finally:
+        gc.enable()
+    assert held <= (1 << 20), 'two steps left %.1f MB of device memory to the cyclic collector' % (held / 2 ** 20)
