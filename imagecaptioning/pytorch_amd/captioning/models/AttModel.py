@@ -67,7 +67,9 @@ class _RolloutFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)        # the dense log-prob gradient may be undefined (sparse route)
         ctx.mark_non_differentiable(seq)
         model._last_rollout = ro
-        return seq, seq_logp
+        # (an alias: returning the tensor the saved rollout holds would close a reference cycle ctx -> rollout -> tensor -> grad_fn ->
+        #  ctx, and the step's activations would wait for the cyclic collector; see TransformerModel._Fn)
+        return seq, seq_logp.detach()
 
     @staticmethod
     def backward(ctx, _g_seq, g_logp):

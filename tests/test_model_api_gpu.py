@@ -647,7 +647,7 @@ def test_raw_logit_rollouts_of_the_other_families_vs_oracle(family):
     assert checked >= 5
 
 
-@pytest.mark.parametrize('which', ['transformer', 'aoa', 'newfc'])
+@pytest.mark.parametrize('which', ['transformer', 'aoa', 'newfc', 'updown'])
 def test_a_training_step_frees_its_activations_without_the_cyclic_collector(which):
     """r5: the rollout / teacher-forcing Functions used to return the very tensor their saved engine object holds -- a reference
     cycle (ctx -> engine -> tensor -> grad_fn -> ctx), so every activation of a step lived until the interpreter's cyclic collector
@@ -665,8 +665,10 @@ def test_a_training_step_frees_its_activations_without_the_cyclic_collector(whic
         opt = synthetic.updown_opt(caption_model='aoa', input_encoding_size=1024, rnn_size=1024, att_hid_size=512, num_heads=8,
                                    multi_head_scale=1, use_multi_head=2, refine=1, refine_aoa=1, use_ff=0, decoder_type='AoA',
                                    mean_feats=1, ctx_drop=1, dropout_aoa=0.3)
-    else:
+    elif which == 'newfc':
         opt = synthetic.updown_opt(caption_model='newfc')
+    else:
+        opt = synthetic.updown_opt()           # (the model keeps its LAST rollout on purpose, model._last_rollout: one, not one per step)
     torch.manual_seed(3)
     model = models.setup(opt).to(DEV)
     model.flatten_parameters_()
