@@ -199,3 +199,34 @@ def test_aoa_sampled_rollout_oracle_is_consistent_with_teacher_forcing():
     loss = O.new_self_critical_loss(slp, seq, torch.rand(B * n, generator=torch.Generator().manual_seed(1)).double(), n)
     loss.backward()
     assert float(P['logit.weight'].grad.abs().sum()) > 0 and float(P['refiner.layers.0.self_attn.linears.0.weight'].grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize('family', ['newfc', 'transformer', 'aoa'])
+def test_raw_logit_mode_of_the_oracles_is_the_reference_logprobs_before_the_softmax(family):
+    """`want_logsoftmax=False` (AttModel.get_logprobs_state(output_logsoftmax=0), AttModel.py:171-175: `logprobs = self.logit(output)`)
+    of the three restatements that gained it in r5: log_softmax of the returned rows == the REFERENCE's teacher-forced log-probs of
+    the fixtures, the rows themselves are not normalised, and the switch changes nothing else (same zero columns)."""
+    u = np.load(os.path.join(GOLDEN, 'updown_tiny.npz'))
+    if family == 'newfc':
+        z, P = load('newfc_tiny.npz')
+        labels = torch.from_numpy(z['labels'])
+        raw = O.newfc_forward_teacher(P, torch.from_numpy(z['fc']), labels[..., :-1], want_logsoftmax=False)
+        want = z['xe_logp']
+    else:
+        z = np.load(os.path.join(GOLDEN, family + '_tiny.npz'))
+        P = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith('P.')}
+        labels, att = torch.from_numpy(u['labels']), torch.from_numpy(u['att'])
+        if family == 'transformer':
+            from oracle import transformer as T
+            raw = T.forward_teacher(P, att, labels[..., :-1], None, h=2, n_enc=2, n_dec=2, want_logsoftmax=False)
+        else:
+            from oracle import aoa as A
+            raw = A.forward_teacher(P, att, labels[..., :-1], None, h=2, want_logsoftmax=False)
+        want = z['xe_logp_nomask']
+    with torch.no_grad():
+        written = torch.from_numpy(np.abs(want).sum(-1) > 0)                 # steps the reference ran (AttModel.py:140-143 breaks early)
+        lp = torch.log_softmax(raw, -1) * written.unsqueeze(-1)
+        np.testing.assert_allclose(lp.numpy(), want, rtol=1e-5, atol=3e-6)
+        assert float((torch.logsumexp(raw, -1)[written]).abs().max()) > 1e-3   # logits, not log-probabilities
+        if family != 'transformer':                                          # (TransformerModel._forward has no early break)
+            assert float(raw[~written].abs().max() if bool((~written).any()) else 0.0) == 0.0
