@@ -352,3 +352,30 @@ def test_validation_loss_returns_sum_and_count_and_survives_an_empty_partition()
     assert (tot, n) == (0.0, 0)
     tot, n = T.validation_loss(LW, Loader(100), opt, 'cpu', world=1)
     assert n == 40
+
+
+@pytest.mark.parametrize('family,extra', [('transformer', dict(N_enc=1, N_dec=1, d_model=16, d_ff=32, num_att_heads=2, dropout=0.1)),
+                                          ('aoa', dict(num_heads=2, num_layers=2)), ('newfc', {}), ('updown', {})])
+def test_every_sample_option_reaches_the_device_check(family, extra):
+    """The option handling of `_sample` (beam search incl. sample_method='beam_search', the sampling methods, raw logits, decode
+    constraints, diverse sampling) is plain host logic in front of the kernels: on CPU tensors every combination must arrive at
+    the loud "HIP device only" error -- not at a NameError / a parse error of its own making (r5: moving one parse call in
+    NewFCModel._sample broke sample_method='beam_search', and only the GPU suite noticed)."""
+    import torch
+    from imagecaptioning.pytorch_amd import synthetic
+    from imagecaptioning.pytorch_amd.captioning import models
+    from imagecaptioning.pytorch_amd._lib import CapmiError
+    opt = synthetic.updown_opt(caption_model=family, input_encoding_size=16, rnn_size=16, att_hid_size=8, seq_length=5, max_length=5,
+                               vocab_size=20, fc_feat_size=12, att_feat_size=12, vocab={str(i): 'w%d' % i for i in range(1, 21)}, **extra)
+    model = models.setup(opt)
+    fc, att = torch.zeros(2, 12), torch.zeros(2, 3, 12)
+    combos = [dict(), dict(beam_size=2), dict(sample_method='beam_search', beam_size=2), dict(sample_method='sample', sample_n=2),
+              dict(sample_method='top3', sample_n=2), dict(sample_method='top0.8'), dict(sample_method='gumbel', sample_n=2),
+              dict(sample_method='sample', sample_n=2, output_logsoftmax=0), dict(sample_method='greedy', output_logsoftmax=0),
+              dict(block_trigrams=1), dict(decoding_constraint=1, remove_bad_endings=1), dict(group_size=2, sample_method='sample'),
+              dict(beam_size=2, group_size=2, diversity_lambda=0.5)]
+    for o in combos:
+        for train in (False, True):
+            model.train(train)
+            with pytest.raises(CapmiError, match='HIP device only'):
+                model(fc, att, None, opt=o, mode='sample')
