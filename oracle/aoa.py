@@ -131,11 +131,12 @@ def greedy(P, att_feats, att_masks, h, max_len):
     return seq, slp
 
 
-def sample(P, att_feats, att_masks, h, max_len, n=1, gen=None, drop=None):
+def sample(P, att_feats, att_masks, h, max_len, n=1, gen=None, drop=None, forced=None):
     """AttModel._sample (AttModel.py:258-352) for AoAModel with sample_method='sample', sample_n=n: n rows per image drawn from
     torch.distributions-style multinomial of exp(logprobs) (CaptionModel.sample_next_word, :388-395), WITH the autograd graph
     (the new_self_critical step differentiates the rollout it sampled, loss_wrapper.py:25-48).  Returns seq [B*n, L] and the
-    dense log-probs [B*n, L, V1] filled like AttModel.py:347."""
+    dense log-probs [B*n, L, V1] filled like AttModel.py:347.  forced [B*n, L]: use these tokens instead of drawing (teacher-forcing a
+    sequence the reference sampled: the parity protocol for stochastic decoding, as att_lstm.rollout)."""
     B = att_feats.shape[0]
     mean, att, p_att, masks = prepare(P, att_feats, att_masks, h, drop)
     if n > 1:
@@ -151,7 +152,7 @@ def sample(P, att_feats, att_masks, h, max_len, n=1, gen=None, drop=None):
     for t in range(max_len):
         logp, state = step(P, it, mean, p_att, masks, state, h, drop, t)
         with torch.no_grad():
-            it = torch.multinomial(logp.detach().exp(), 1, generator=gen).squeeze(1)
+            it = forced[:, t].clone() if forced is not None else torch.multinomial(logp.detach().exp(), 1, generator=gen).squeeze(1)
         if t == 0:
             unf = it != 0
         else:

@@ -68,14 +68,21 @@ def ffn(P: Params, pre: str, x, drop: Drop, tag: str):
     return hdn @ P[pre + '.w_2.weight'].t() + P[pre + '.w_2.bias']
 
 
-def encode(P: Params, att_feats, att_masks, h: int, n_layers: int, drop: Drop = None):
-    """att_embed (TransformerModel.py:280-285) + Encoder (:61-74) with pre-norm residual sublayers (:89-102)."""
+def encode(P: Params, att_feats, att_masks, h: int, n_layers: int, drop: Drop = None, rows_per_image: int = 1):
+    """att_embed (TransformerModel.py:280-285) + Encoder (:61-74) with pre-norm residual sublayers (:89-102).
+
+    rows_per_image > 1 is TransformerModel._forward's order (:316-321, 343-345): att_embed (and its Dropout) runs on the B images,
+    the embedded regions are THEN repeated seq_per_img times and the ENCODER runs on all B * seq_per_img rows -- in train mode
+    every caption row draws its own encoder dropout masks (pinned by tests/golden/train_mode.npz: the reference's attention
+    mask of encoder layer 0 is [B * n, h, K, K]).  With dropout off the rows of one image are identical copies.  _sample goes
+    through _prepare_feature (:306-311) instead: it encodes the B images and repeats the memory (callers pass 1)."""
     x = _d(drop, 'att_embed', F.relu(att_feats @ P['att_embed.0.weight'].t() + P['att_embed.0.bias']))
     if att_masks is not None:
         x = x * att_masks.unsqueeze(-1).to(x)              # pack_wrapper zero-pads (AttModel.py:44-49)
-        smask = att_masks.unsqueeze(-2)
-    else:
-        smask = None
+    if rows_per_image > 1:
+        x = x.repeat_interleave(rows_per_image, 0)
+        att_masks = None if att_masks is None else att_masks.repeat_interleave(rows_per_image, 0)
+    smask = None if att_masks is None else att_masks.unsqueeze(-2)
     for i in range(n_layers):
         pre = 'model.encoder.layers.%d' % i
         y = layer_norm(P, pre + '.sublayer.0.norm', x)
@@ -110,14 +117,19 @@ def target_mask(seq):
     return m.unsqueeze(-2) & causal.unsqueeze(0)
 
 
-def forward_teacher(P: Params, att_feats, seq, att_masks, h: int, n_enc: int, n_dec: int, drop: Drop = None, want_logsoftmax=True):
-    """TransformerModel._forward (:340-348): log-probs [N,T,V1] (no early break, no zero columns)."""
+def forward_teacher(P: Params, att_feats, seq, att_masks, h: int, n_enc: int, n_dec: int, drop: Drop = None, want_logsoftmax=True,
+                    encode_per_caption: bool = True):
+    """TransformerModel._forward (:340-348): log-probs [N,T,V1] (no early break, no zero columns).
+
+    encode_per_caption=True is _forward's own order (regions repeated BEFORE the encoder, see encode()).  False restates the
+    teacher-forced re-run of a rollout that AttModel._sample produced: _sample encodes the B images once (_prepare_feature,
+    :306-311) and repeats the memory, so its dropout realisation has per-IMAGE encoder masks.  Same numbers when dropout is off."""
     if seq.ndim == 3:
         seq = seq.reshape(-1, seq.shape[2])
     B = att_feats.shape[0]
     n = seq.shape[0] // B
-    memory, smask = encode(P, att_feats, att_masks, h, n_enc, drop)
-    if n > 1:
+    memory, smask = encode(P, att_feats, att_masks, h, n_enc, drop, rows_per_image=n if encode_per_caption else 1)
+    if n > 1 and not encode_per_caption:
         memory = memory.repeat_interleave(n, 0)
         smask = None if smask is None else smask.repeat_interleave(n, 0)
     out = decode(P, memory, smask, seq, target_mask(seq.clone()), h, n_dec, drop)

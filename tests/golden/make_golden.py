@@ -989,8 +989,109 @@ def main_beam5mid():
     print('beam5_mid.npz:', len(out), 'arrays')
 
 
+class DropRecorder:
+    """Stand-in for ``torch.nn.functional.dropout`` while the REFERENCE runs in train() mode.  nn.Dropout.forward and the
+    reference's direct F.dropout calls (AttModel.py:637) both resolve ``F.dropout`` at call time, so one patch sees every
+    site.  Each call draws a Bernoulli(1-p) keep mask from a private seeded generator, applies it pre-scaled like the real
+    op (x * keep / (1-p)) and appends (p, keep) in CALL ORDER -- the order, the shapes and which tensors get a mask are the
+    reference's own; only the random bits are ours."""
+
+    def __init__(self, seed):
+        self.gen = torch.Generator().manual_seed(seed)
+        self.calls = []
+
+    def __call__(self, input, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return input
+        keep = torch.rand(input.shape, generator=self.gen) < (1.0 - p)
+        self.calls.append((float(p), keep.numpy().copy()))
+        return input * (keep.to(input.dtype) / (1.0 - p))
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self._saved, F.dropout = F.dropout, self
+        return self
+
+    def __exit__(self, *a):
+        import torch.nn.functional as F
+        F.dropout = self._saved
+
+    def dump(self, out, tag):
+        out[tag + '.drop_p'] = np.array([p for p, _ in self.calls], np.float32)
+        for i, (_, k) in enumerate(self.calls):
+            out['%s.drop%03d' % (tag, i)] = np.packbits(k.reshape(-1))
+            out['%s.drop%03d.shape' % (tag, i)] = np.array(k.shape, np.int64)
+
+
+def main_train():
+    """TRAIN-MODE fixture: the reference in ``train()`` with drop_prob_lm 0.5 / Transformer dropout 0.1 / dropout_aoa 0.3
+    (AoA's hard-coded 0.1s are what the reference has), every dropout call recorded by DropRecorder.  Per family
+    (updown, newfc, transformer, aoa; the weights and inputs of <family>_tiny.npz): teacher-forced log-probs, XE loss and
+    every parameter gradient, with and without att_masks; for updown and aoa also a sampled rollout (sample_n 2) in train
+    mode with its dense log-probs, RewardCriterion loss and gradients.  tests/test_oracle_golden.py replays the masks in
+    call order through the oracles' drop hooks -> which tensors the reference drops is pinned, not read."""
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    import captioning.models as models
+    from captioning.modules import losses
+    z = np.load(os.path.join(HERE, 'updown_tiny.npz'))
+    fc, att, am = (torch.from_numpy(z[k]) for k in ('fc', 'att', 'att_masks'))
+    labels, masks = torch.from_numpy(z['labels']), torch.from_numpy(z['masks'])
+    out = {}
+    for fi, name in enumerate(('updown', 'newfc', 'transformer', 'aoa')):
+        model = family_model(models, name)
+        # family_model builds with every rate 0; set the training rates where the reference keeps them
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout) and m.p == 0.0:
+                m.p = 0.5                                   # embed / fc_embed / att_embed / out_drop / ctx_drop / LSTMCore.dropout
+        if name == 'updown':
+            model.core.drop_prob_lm = 0.5                   # F.dropout(h_lang, self.drop_prob_lm, ...) AttModel.py:637
+        if name == 'transformer':
+            # TransformerModel.make_model threads ONE rate to every SublayerConnection / attention / FFN / PositionalEncoding
+            for m in model.model.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.1
+        model.train()
+        rates = sorted({round(m.p, 3) for m in model.modules() if isinstance(m, torch.nn.Dropout)})
+        print(name, 'dropout rates in the reference model:', rates)
+        for ti, (tag, m_) in enumerate((('nomask', None), ('mask', am))):
+            key = '%s.xe_%s' % (name, tag)
+            model.zero_grad()
+            with DropRecorder(1000 + 10 * fi + ti) as rec:
+                logp = model(fc, att, labels[..., :-1], m_)
+            loss = losses.LanguageModelCriterion()(logp, labels[..., 1:], masks[..., 1:])
+            loss.backward()
+            out[key + '.logp'] = logp.detach().numpy()
+            out[key + '.loss'] = loss.detach().numpy()
+            for k, p in model.named_parameters():
+                out['%s.grad.%s' % (key, k)] = (torch.zeros_like(p) if p.grad is None else p.grad).numpy().copy()
+            rec.dump(out, key)
+            print(' ', key, len(rec.calls), 'dropout calls, loss', float(loss))
+        if name in ('updown', 'aoa'):
+            key = name + '.sample'
+            model.zero_grad()
+            torch.manual_seed(500 + fi)
+            with DropRecorder(2000 + fi) as rec:
+                seq, slp = model(fc, att, am, opt={'sample_method': 'sample', 'beam_size': 1, 'sample_n': 2}, mode='sample')
+            reward = torch.randn(seq.shape[0], 1).repeat(1, seq.shape[1])
+            rl = losses.RewardCriterion()(slp, seq.data, reward)
+            rl.backward()
+            out[key + '.seq'] = seq.numpy()
+            out[key + '.logp'] = slp.detach().numpy()
+            out[key + '.reward'] = reward.numpy()
+            out[key + '.loss'] = rl.detach().numpy()
+            for k, p in model.named_parameters():
+                out['%s.grad.%s' % (key, k)] = (torch.zeros_like(p) if p.grad is None else p.grad).numpy().copy()
+            rec.dump(out, key)
+            print(' ', key, len(rec.calls), 'dropout calls, lengths', (seq > 0).sum(1).tolist())
+    np.savez_compressed(os.path.join(HERE, 'train_mode.npz'), **out)
+    print('train_mode.npz:', len(out), 'arrays')
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'full3':
+    if len(sys.argv) > 1 and sys.argv[1] == 'train':
+        main_train()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'full3':
         main_full3()
     elif len(sys.argv) > 1 and sys.argv[1] == 'beam5mid':
         main_beam5mid()

@@ -607,7 +607,8 @@ def test_transformer_scst_train_mode_differentiates_the_pass_it_sampled(d, h, df
     inp = torch.cat([seq_c.new_zeros(N, 1), seq_c[:, :-1]], 1)
     T.RELU_TIES = ties = {}                 # hidden units whose ReLU input is within 1e-4 of zero for some token (see _compare_model_with_oracle)
     try:
-        want = T.forward_teacher(P, att, inp, am, h=h, n_enc=nl, n_dec=nl, drop=drop)
+        # the rollout came from _sample: the B images are encoded once and the memory repeated (TransformerModel.py:306-311)
+        want = T.forward_teacher(P, att, inp, am, h=h, n_enc=nl, n_dec=nl, drop=drop, encode_per_caption=False)
     finally:
         T.RELU_TIES = None
     assert used == set(named)
