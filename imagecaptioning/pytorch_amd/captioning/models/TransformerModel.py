@@ -101,17 +101,22 @@ class _EncDec(nn.Module):
 
 class _Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, att_feats, att_masks, seq, n, sink, *params):
+    def forward(ctx, model, att_feats, att_masks, seq, n, sink, seed, raw, *params):
+        """seed / raw: None / False for the reference's _forward; _sample's teacher-forced gradient pass hands in the seed its
+        rollout drew under and whether that rollout returned logits (explicit arguments: nothing is left on the model)."""
         P = model._pdict(params)
         ctx.sink = sink
         ctx.set_materialize_grads(False)        # the dense log-prob gradient may be undefined (sparse route)
         grads = model._grad_targets(P)
-        seed, model._forced_seed = getattr(model, '_forced_seed', None), None      # _sample: the seed its rollout drew under
-        raw, model._forced_raw = getattr(model, '_forced_raw', False), False       # _sample(output_logsoftmax=0): return the logits
         g = engine.TransformerGraph(P, grads, model.h, model.N_enc, model.N_dec, model.drop_prob_lm, model.dropout,
                                     model.training, model._next_seed() if seed is None else seed)
-        g.encode(att_feats, att_masks)
-        logp = g.decode(seq, n, raw=raw)
+        # TransformerModel._forward repeats the embedded regions BEFORE the encoder (TransformerModel.py:316-321,343-345): in train
+        # mode every caption row has its own encoder dropout masks.  A rollout's gradient pass (seed given) re-runs _sample, which
+        # encodes per image (:306-311).  With dropout off the rows of an image are identical copies: encode once per image.
+        per_caption = (seed is None and n > 1 and model.training and model.dropout > 0
+                       and not getattr(model, 'tie_encoder_dropout', False))
+        g.encode(att_feats, att_masks, rows_per_image=n if per_caption else 1)
+        logp = g.decode(seq, 1 if per_caption else n, raw=raw)
         ctx.g, ctx.model, ctx.grads = g, model, grads
         # (an ALIAS of the engine's tensor is returned: autograd hangs this Function on the returned object, and returning the very
         #  tensor the saved engine holds would close a reference cycle ctx -> engine -> tensor -> grad_fn -> ctx -- every activation
@@ -128,8 +133,8 @@ class _Fn(torch.autograd.Function):
         ctx.g.backward(g_logp, sparse=sparse)
         if flat is not None:
             flat.end_backward(stash)
-            return (None,) * (6 + len(ctx.model._param_names))
-        return (None, None, None, None, None, None) + tuple(ctx.grads[k] for k in ctx.model._param_names)
+            return (None,) * (8 + len(ctx.model._param_names))
+        return (None,) * 8 + tuple(ctx.grads[k] for k in ctx.model._param_names)
 
 
 class TransformerModel(CaptionModel):
@@ -154,6 +159,10 @@ class TransformerModel(CaptionModel):
         for p in self.model.parameters():              # TransformerModel.py:256-258
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
+        # opt-in optimisation (NOT the reference's train-mode dataflow): one encoder pass per image in _forward even when dropout is
+        # on -- the n caption rows of an image then share their encoder dropout masks (same expected gradient, correlated noise)
+        import os
+        self.tie_encoder_dropout = bool(getattr(opt, 'tie_encoder_dropout', 0)) or os.environ.get('CAPMI_TIE_ENC') == '1'
         self._flat = None
         self._rng_calls = 0
 
@@ -208,7 +217,7 @@ class TransformerModel(CaptionModel):
         return att_feats.float().contiguous(), att_masks
 
     # ---- reference API
-    def _forward(self, fc_feats, att_feats, seq, att_masks=None):
+    def _forward(self, fc_feats, att_feats, seq, att_masks=None, _seed=None, _raw=False):
         """TransformerModel._forward (:340-348): log-probs [N,T,V1]."""
         if not att_feats.is_cuda:
             raise CapmiError('the capmi backend runs on a HIP device only; there is no CPU path')
@@ -220,7 +229,7 @@ class TransformerModel(CaptionModel):
         params = self._param_list()
         from imagecaptioning.pytorch_amd import sparse_logp
         sink = sparse_logp.LogpSink()
-        return sparse_logp.attach(_Fn.apply(self, att_feats, att_masks, seq, n, sink, *params), sink)
+        return sparse_logp.attach(_Fn.apply(self, att_feats, att_masks, seq, n, sink, _seed, bool(_raw), *params), sink)
 
     def _sample(self, fc_feats, att_feats, att_masks=None, opt={}):
         """AttModel._sample for the Transformer.  Tokens are drawn with the KV-cached decoder under no_grad; when a
@@ -279,11 +288,11 @@ class TransformerModel(CaptionModel):
                                           gumbel=opt.get('_gumbel'), top_k=top_k, top_p=top_p, drop=drop, raw=raw)
         if not want_grad:
             return seq, logp
-        self._forced_seed = drop_seed                     # the teacher-forced pass below draws the rollout's masks again
-        self._forced_raw = raw                            # ... and returns logits when the rollout did
-        # differentiable log-probs of the drawn tokens: inputs [bos, w_0 .. w_{L-2}]
+        # differentiable log-probs of the drawn tokens: inputs [bos, w_0 .. w_{L-2}]; the teacher-forced pass draws the rollout's
+        # masks again (its seed) and returns logits when the rollout did
         inp = torch.cat([seq.new_zeros(seq.shape[0], 1), seq[:, :-1]], 1)
-        logp_g = self._forward(None, att_feats, inp, att_masks)
+        logp_g = self._forward(None, att_feats, inp, att_masks, _seed=drop_seed if drop_seed is not None else self._next_seed(),
+                               _raw=raw)
         live = torch.cat([seq.new_ones(seq.shape[0], 1), (seq[:, :-1] > 0).long()], 1).cumprod(1)     # unfinished-before-step
         from imagecaptioning.pytorch_amd import sparse_logp
         return seq, sparse_logp.attach_masked(logp_g * live.unsqueeze(-1).to(logp_g), logp_g, live)

@@ -316,11 +316,17 @@ class TransformerGraph:
         self.drop = Dropper(dropout, seed ^ 0x5bd1e995, self.dev, training)
 
     # ---------------- encoder
-    def encode(self, att_feats, att_masks):
+    def encode(self, att_feats, att_masks, rows_per_image=1):
+        """rows_per_image = n > 1: TransformerModel._forward's train-mode dataflow (TransformerModel.py:316-321, 343-345) -- att_embed
+        and ITS dropout run on the B images, the embedded regions are then repeated n times and the encoder runs on all B * n rows,
+        each caption row under its own dropout masks (pinned by tests/golden/train_mode.npz).  From here on the graph's `B` is
+        B * n and decode() must be called with n = 1.  With dropout off the n copies are identical: callers pass 1 (one encoder
+        pass per image, same numbers)."""
         P, g = self.P, self.grads
         B, K, F = att_feats.shape
         D = P['att_embed.0.weight'].shape[0]
         self.B, self.K, self.D = B, K, D
+        self.enc_rep = int(rows_per_image)
         m = self.drop_embed(B * K, D)
         if att_masks is not None:
             mm = att_masks.reshape(B * K, 1).expand(B * K, D)
@@ -330,6 +336,12 @@ class TransformerGraph:
             self.smask = None
         self.embed = Lin(P, g, 'att_embed.0.weight', 'att_embed.0.bias')
         x = self.embed.fwd(att_feats.reshape(B * K, F), relu=True, mask=m)
+        if self.enc_rep > 1:
+            n = self.enc_rep
+            x = x.view(B, 1, K * D).expand(B, n, K * D).reshape(B * n * K, D)
+            if self.smask is not None:
+                self.smask = self.smask.view(B, 1, K).expand(B, n, K).reshape(B * n, K)
+            self.B = B = B * n
         self.enc = []
         shapes = []
         for i in range(self.n_enc):                      # the encoder's masks, 4 per launch, in the order they are consumed
@@ -451,7 +463,9 @@ class TransformerGraph:
             n1.bwd(ff.bwd(dxe), dxe)
             dself, _ = at.bwd(dxe)
             n0.bwd(dself, dxe)
-        self.embed.bwd(dxe, need_dx=False)
+        if self.enc_rep > 1:                             # the n encoder rows of an image share one att_embed output
+            dxe = dxe.view(B // self.enc_rep, self.enc_rep, K * D).sum(1).view(-1, D)
+        self.embed.bwd(dxe, need_dx=False, fresh=self.enc_rep > 1)
 
 
 # --------------------------------------------------------------------------- KV-cached sampling
