@@ -118,6 +118,12 @@ class NewFCGrads(C.Structure):
     _fields_ = [(k, c_f) for k in ('embed', 'i2h_w', 'i2h_b', 'h2h_w', 'h2h_b', 'logit_w', 'logit_b', 'd_fc_emb')]
 
 
+class StepState(C.Structure):
+    """capmi_step_state (include/capmi.h): the per-iteration record a captured training step reads from DEVICE memory"""
+    _fields_ = [('epoch', C.c_uint64), ('adam_step', C.c_int32), ('lr', C.c_float), ('bc1', C.c_float), ('bc2_sqrt', C.c_float),
+                ('reserved', C.c_float * 2)]
+
+
 class NewFCBwdScratch(C.Structure):
     _fields_ = ([(k, c_f) for k in ('dlogits', 'd_hdrop', 'd_sums', 'dh_prev', 'dc', 'd_x_all', 'd_ximg', 'partial')] +
                 [('partial_capacity', C.c_int64), ('sparse', C.POINTER(SparseLogpGrad))])
@@ -172,6 +178,11 @@ SIGNATURES = {
     'capmi_group_rowsum': [_P, _I, _I64, _I, _I, _I, _P, _P],
     'capmi_relu_mask_bwd': [_P, _P, _P, _P, _I64, _P],
     'capmi_adam_step': [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _I, _P],
+    'capmi_upload_async': [_P, _P, _I64, _P],
+    'capmi_step_advance': [_P, _F, _F, _P],
+    'capmi_step_set_lr': [_P, _F, _P],
+    'capmi_rng_bind_epoch': [_P, _P],
+    'capmi_adam_step_dyn': [_P, _P, _P, _P, _I64, _P, _F, _F, _F, _F, _F, _F, _P],
     'capmi_ciderd_score': [_P, _I, _I, _P, _P, _P, _I, _I, _P, _P, C.c_uint32, C.c_double, _P, _P],
     'capmi_ciderd_cook_refs': [_P, _P, _I, _I, _I, _P, _P, C.c_uint32, C.c_double, _P, _P],
     'capmi_ciderd_score_cooked': [_P, _I, _I, _P, _P, _P, _I, _P, _P, C.c_uint32, C.c_double, _P, _P],

@@ -80,6 +80,8 @@ class _Fn(torch.autograd.Function):
 
 
 class AoAModel(CaptionModel):
+    graph_step = True      # graph_step.TrainStep captures this family's training iteration into a hipGraph (no host sync in it)
+
     def __init__(self, opt):
         super().__init__()
         for k, want in (('refine', 1), ('refine_aoa', 1), ('use_ff', 0), ('use_multi_head', 2), ('multi_head_scale', 1)):

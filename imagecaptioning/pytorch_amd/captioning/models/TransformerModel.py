@@ -138,6 +138,8 @@ class _Fn(torch.autograd.Function):
 
 
 class TransformerModel(CaptionModel):
+    graph_step = True      # graph_step.TrainStep captures this family's training iteration into a hipGraph (no host sync in it)
+
     def __init__(self, opt):
         super().__init__()
         self.vocab_size = opt.vocab_size

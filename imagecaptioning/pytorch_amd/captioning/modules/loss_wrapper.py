@@ -32,7 +32,8 @@ class LossWrapper(torch.nn.Module):
                 lm_loss = self.crit(self.model(fc_feats, att_feats, labels[..., :-1], att_masks), labels[..., 1:],
                                     masks[..., 1:], reduction=reduction)
             else:
-                lm_loss = torch.tensor(0).type_as(fc_feats)
+                # (a device fill: the reference's torch.tensor(0).type_as(fc_feats) is a blocking host -> device copy)
+                lm_loss = (att_feats if att_feats is not None else fc_feats).new_zeros(())
             if w > 0:
                 gen_result, sample_logprobs = self.model(
                     fc_feats, att_feats, att_masks,
@@ -45,7 +46,8 @@ class LossWrapper(torch.nn.Module):
                 gts = select_gts(gts, gt_indices)
                 struc_loss = self.struc_crit(sample_logprobs, gen_result, gts, reduction=reduction)
             else:
-                struc_loss = {'loss': torch.tensor(0).type_as(fc_feats), 'reward': torch.tensor(0).type_as(fc_feats)}
+                z = (att_feats if att_feats is not None else fc_feats).new_zeros(())
+                struc_loss = {'loss': z, 'reward': z}
             loss = (1 - w) * lm_loss + w * struc_loss['loss']
             out['lm_loss'] = lm_loss
             out['struc_loss'] = struc_loss['loss']

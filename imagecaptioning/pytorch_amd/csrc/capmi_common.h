@@ -117,6 +117,11 @@ struct Philox {
         out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
     }
 };
+// The random stream of a kernel launched with `seed` while an epoch word is bound (capmi_rng_bind_epoch, capmi.h): a captured
+// hipGraph freezes the seed argument, the epoch word in device memory moves on every replay (capmi_step_advance).
+__device__ __forceinline__ uint64_t epoch_seed(uint64_t seed, const uint64_t *__restrict__ epoch) {
+    return epoch ? seed + 0x9E3779B97F4A7C15ull * *epoch : seed;
+}
 // uniform in (0,1): never 0 so log() is finite
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
@@ -128,6 +133,8 @@ __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5
 //                and says so on stderr for every variable it finds set.
 //  * ablate_env(): profiling ablations (CAPMI_*_ABLATE) drop parts of a kernel's work to time the rest: results are WRONG
 //                by design; -DCAPMI_VARIANTS builds only, loud on stderr.
+// the epoch word bound by capmi_rng_bind_epoch (defined in pointwise.hip); every launch of a seed-taking kernel passes it on
+const uint64_t *rng_epoch();
 static inline int knob(const char *name, int dflt) {
     const char *e = getenv(name);
     return e ? atoi(e) : dflt;

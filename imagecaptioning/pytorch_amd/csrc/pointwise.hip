@@ -5,9 +5,17 @@
 #include "capmi_common.h"
 #include <cstdlib>
 #include "profile.h"
+#include "embed_bwd_det.h"
 #include "../../../include/capmi.h"
 
 using namespace capmi;
+
+#include <atomic>
+// the epoch word of the random streams (capmi_rng_bind_epoch): process-wide, one process per GPU
+static std::atomic<const uint64_t *> g_rng_epoch{nullptr};
+namespace capmi {
+const uint64_t *rng_epoch() { return g_rng_epoch.load(std::memory_order_relaxed); }
+}
 
 namespace {
 
@@ -56,6 +64,25 @@ __global__ void embed_bwd_kernel(const int64_t *__restrict__ it, const float *__
         }
         if (g != 0.f) atomicAdd(&dE[(size_t)it[r] * Ed + c], g);
     }
+}
+
+struct EmbedGrad {       // gradient reaching x = relu(E[tok]) * mask at (position, 4 columns)
+    const float *dx, *x_saved, *mask; int Ed, relu;
+    __device__ __forceinline__ f32x4 operator()(size_t pos, int c) const {
+        const size_t o = pos * Ed + c;
+        f32x4 g = *reinterpret_cast<const f32x4 *>(dx + o);
+        if (mask) g *= *reinterpret_cast<const f32x4 *>(mask + o);
+        if (relu) {
+            const f32x4 xs = *reinterpret_cast<const f32x4 *>(x_saved + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (!(xs[e] > 0.f)) g[e] = 0.f;
+        }
+        return g;
+    }
+};
+__global__ __launch_bounds__(EBD_THREADS) void embed_bwd_det_kernel(const int64_t *__restrict__ it, int rows, int Ed,
+                                                                   float *__restrict__ dE, const EmbedGrad g) {
+    embed_bwd_det_body(it, rows, 0, rows, Ed, dE, g);
 }
 
 // ---------------------------------------------------------------- LSTM cell
@@ -329,8 +356,9 @@ __global__ __launch_bounds__(64) void lstm_cell_bwd_vec_kernel(
 }
 
 // ---------------------------------------------------------------- misc
-__global__ void dropout_mask_kernel(float *__restrict__ mask, size_t count, float p, uint64_t seed, uint64_t offset) {
-    const Philox rng(seed);
+__global__ void dropout_mask_kernel(float *__restrict__ mask, size_t count, float p, uint64_t seed, uint64_t offset,
+                                    const uint64_t *__restrict__ epoch) {
+    const Philox rng(epoch_seed(seed, epoch));
     const float scale = 1.f / (1.f - p);
     const size_t quads = (count + 3) / 4;
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (size_t)gridDim.x * blockDim.x) {
@@ -354,8 +382,8 @@ struct MaskSegs {
     int row_len[CAPMI_MAX_MASKS], rows[CAPMI_MAX_MASKS], keep_from[CAPMI_MAX_MASKS];
     int n;
 };
-__global__ void dropout_masks_kernel(const MaskSegs sg, float p, uint64_t seed) {
-    const Philox rng(seed);
+__global__ void dropout_masks_kernel(const MaskSegs sg, float p, uint64_t seed, const uint64_t *__restrict__ epoch) {
+    const Philox rng(epoch_seed(seed, epoch));
     const float scale = 1.f / (1.f - p);
     for (int i = 0; i < sg.n; ++i) {
         const size_t count = sg.count[i], quads = (count + 3) / 4;
@@ -587,9 +615,10 @@ __global__ void relu_mask_bwd_kernel(const float *__restrict__ dy, const float *
 
 __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                             float *__restrict__ v, size_t count, float lr, float b1, float b2, float eps, float wd,
-                            float clip, float gscale, float bc1, float bc2_sqrt) {
+                            float clip, float gscale, float bc1, float bc2_sqrt, const capmi_step_state *__restrict__ dyn) {
     // torch.optim.Adam (non-amsgrad): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
     // p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+    if (dyn) { lr = dyn->lr; bc1 = dyn->bc1; bc2_sqrt = dyn->bc2_sqrt; }      // capmi_adam_step_dyn: the step record in device memory
     const size_t quads = count / 4;
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g);
     f32x4 *p4 = reinterpret_cast<f32x4 *>(p), *m4 = reinterpret_cast<f32x4 *>(m), *v4 = reinterpret_cast<f32x4 *>(v);
@@ -628,9 +657,10 @@ __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, 
 template <bool NT>
 __global__ void adam2_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                              float *__restrict__ v, size_t quads, float lr, float b1, float b2, float eps, float wd,
-                             float clip, float gscale, float bc1, float bc2_sqrt) {
+                             float clip, float gscale, float bc1, float bc2_sqrt, const capmi_step_state *__restrict__ dyn) {
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g);
     f32x4 *p4 = reinterpret_cast<f32x4 *>(p), *m4 = reinterpret_cast<f32x4 *>(m), *v4 = reinterpret_cast<f32x4 *>(v);
+    if (dyn) { lr = dyn->lr; bc1 = dyn->bc1; bc2_sqrt = dyn->bc2_sqrt; }      // capmi_adam_step_dyn: the step record in device memory
     const float step_size = lr / bc1;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t q0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < quads; q0 += 2 * stride) {
@@ -667,6 +697,16 @@ __global__ void adam2_kernel(float *__restrict__ p, const float *__restrict__ g,
         }
     }
 }
+
+// the per-iteration record of a captured training step (capmi.h capmi_step_state): one thread, first launch of every iteration
+__global__ void step_advance_kernel(capmi_step_state *st, float b1, float b2) {
+    st->epoch += 1;
+    const int step = st->adam_step + 1;
+    st->adam_step = step;
+    st->bc1 = (float)(1.0 - pow((double)b1, (double)step));
+    st->bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
+}
+__global__ void step_set_lr_kernel(capmi_step_state *st, float lr) { st->lr = lr; }
 
 // one workgroup: N <= a few thousand rows.  reward[N] (written when N > 0 rows exist and mean_out is given) = mean advantage, what
 // LossWrapper reports as out['reward'] (loss_wrapper.py:72) -- an ATen mean launch otherwise
@@ -706,6 +746,16 @@ int capmi_embed_fwd(const int64_t *it, int it_stride, int64_t *it_save, const fl
 int capmi_embed_bwd(const int64_t *it, const float *dx, const float *x_saved, const float *mask, float *dE, int rows,
                     int Edim, int relu, void *stream) {
     if (!it || !dx || !dE || rows <= 0 || Edim <= 0 || (relu && !x_saved)) return CAPMI_EINVAL;
+    static const int det = capmi::knob("CAPMI_EMBED_BWD_DET", 1);
+    if (det && Edim % 4 == 0 && rows <= EBD_MAX_ROWS &&
+        ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(x_saved) | reinterpret_cast<uintptr_t>(mask) |
+          reinterpret_cast<uintptr_t>(dE)) & 15) == 0) {
+        // r6: ordered sums instead of atomicAdd -- the same bits on every run (embed_bwd_det.h)
+        hipLaunchKernelGGL(embed_bwd_det_kernel, dim3(rows, (Edim + 255) / 256), dim3(EBD_THREADS), embed_bwd_det_lds(rows),
+                           (hipStream_t)stream, it, rows, Edim, dE, EmbedGrad{dx, x_saved, mask, Edim, relu});
+        CAPMI_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((size_t)rows * Edim)), dim3(256), 0, (hipStream_t)stream, it, dx,
                        x_saved, mask, dE, rows, Edim, relu);
     CAPMI_CHECK_LAUNCH();
@@ -797,7 +847,7 @@ int capmi_lstm_cell_bwd(const float *dh_a, int ld_a, const float *dh_a_mask, con
 int capmi_dropout_mask(float *mask, int64_t count, float p, uint64_t seed, uint64_t offset, void *stream) {
     if (!mask || count <= 0 || p < 0.f || p >= 1.f) return CAPMI_EINVAL;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((size_t)(count + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       mask, (size_t)count, p, seed, offset);
+                       mask, (size_t)count, p, seed, offset, capmi::rng_epoch());
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -816,7 +866,7 @@ int capmi_dropout_masks(const capmi_mask_desc *descs, int n, float p, uint64_t s
         sg.keep_from[i] = (d.keep_from >= 0 && d.rows > 0) ? d.keep_from : sg.rows[i];
         if ((size_t)d.count > most) most = (size_t)d.count;
     }
-    hipLaunchKernelGGL(dropout_masks_kernel, dim3(grid_for((most + 3) / 4)), dim3(256), 0, (hipStream_t)stream, sg, p, seed);
+    hipLaunchKernelGGL(dropout_masks_kernel, dim3(grid_for((most + 3) / 4)), dim3(256), 0, (hipStream_t)stream, sg, p, seed, capmi::rng_epoch());
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -900,23 +950,62 @@ int capmi_relu_mask_bwd(const float *dy, const float *y_ref, const float *mask, 
     return 0;
 }
 
-int capmi_adam_step(float *p, const float *g, float *m, float *v, int64_t count, float lr, float beta1, float beta2,
-                    float eps, float weight_decay, float clip, float grad_scale, int step, void *stream) {
-    if (!p || !g || !m || !v || count <= 0 || step < 1) return CAPMI_EINVAL;
+static int adam_launch(float *p, const float *g, float *m, float *v, int64_t count, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, float clip, float grad_scale, float bc1, float bc2_sqrt, const capmi_step_state *dyn,
+                       void *stream) {
     if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
          reinterpret_cast<uintptr_t>(v)) & 15)
         return CAPMI_EINVAL;
-    const double bc1 = 1.0 - pow((double)beta1, step);
-    const double bc2 = 1.0 - pow((double)beta2, step);
     if (count % 4 == 0) {                           // the flat buffers are padded to 64 floats (flat.py): always this branch on the path
         const size_t quads = (size_t)count / 4;
         hipLaunchKernelGGL(adam2_kernel<true>, dim3(grid_for(quads / 2 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, quads, lr,
-                           beta1, beta2, eps, weight_decay, clip, grad_scale, (float)bc1, (float)sqrt(bc2));
+                           beta1, beta2, eps, weight_decay, clip, grad_scale, bc1, bc2_sqrt, dyn);
     } else {                                        // any other count: plain quads + scalar tail
         hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)count / 4 + 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                           (size_t)count, lr, beta1, beta2, eps, weight_decay, clip, grad_scale, (float)bc1, (float)sqrt(bc2));
+                           (size_t)count, lr, beta1, beta2, eps, weight_decay, clip, grad_scale, bc1, bc2_sqrt, dyn);
     }
     CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_adam_step(float *p, const float *g, float *m, float *v, int64_t count, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, float clip, float grad_scale, int step, void *stream) {
+    if (!p || !g || !m || !v || count <= 0 || step < 1) return CAPMI_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    return adam_launch(p, g, m, v, count, lr, beta1, beta2, eps, weight_decay, clip, grad_scale, (float)bc1, (float)sqrt(bc2), nullptr,
+                       stream);
+}
+
+int capmi_adam_step_dyn(float *p, const float *g, float *m, float *v, int64_t count, const capmi_step_state *state, float beta1,
+                        float beta2, float eps, float weight_decay, float clip, float grad_scale, void *stream) {
+    if (!p || !g || !m || !v || count <= 0 || !state) return CAPMI_EINVAL;
+    return adam_launch(p, g, m, v, count, 0.f, beta1, beta2, eps, weight_decay, clip, grad_scale, 1.f, 1.f, state, stream);
+}
+
+int capmi_upload_async(void *dst, const void *src_pinned, int64_t bytes, void *stream) {
+    if (!dst || !src_pinned || bytes <= 0) return CAPMI_EINVAL;
+    const hipError_t e = hipMemcpyAsync(dst, src_pinned, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int capmi_step_advance(capmi_step_state *state, float beta1, float beta2, void *stream) {
+    if (!state) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, beta1, beta2);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_step_set_lr(capmi_step_state *state, float lr, void *stream) {
+    if (!state) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(step_set_lr_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, lr);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_rng_bind_epoch(const uint64_t *epoch, const uint64_t **prev) {
+    const uint64_t *old = g_rng_epoch.exchange(epoch);
+    if (prev) *prev = old;
     return 0;
 }
 

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
     float temperature, const float *__restrict__ gumbel, uint64_t seed, const int64_t *__restrict__ forced,
     int forced_ld, int no_finish_mask, int64_t *__restrict__ seq, int seq_ld, int64_t *__restrict__ it_next,
     uint8_t *__restrict__ unfinished, float *__restrict__ seq_logp, float *__restrict__ sel_logp,
-    uint8_t *__restrict__ live, const NextEmbed ne, int top_k, float top_p, int prenorm) {
+    uint8_t *__restrict__ live, const NextEmbed ne, int top_k, float top_p, int prenorm, const uint64_t *__restrict__ epoch) {
     __shared__ float s_f[32];
     __shared__ int s_i[32];
     const int r = blockIdx.x;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(SEL_THREADS) void logsoftmax_select_kernel(
                     if (order_key(xt_) >= thr_key) best = better(best, ArgMax{xt_ + g[v], v});
                 }
             } else {
-                const Philox rng(seed);
+                const Philox rng(capmi::epoch_seed(seed, epoch));
                 // one Philox call yields 4 uniforms: thread handles quads of vocabulary entries
                 for (int q = threadIdx.x; q * 4 < V1; q += blockDim.x) {
                     uint32_t o[4];
@@ -216,6 +216,7 @@ struct SelArgs {
     float temperature; const float *gumbel; uint64_t seed; const int64_t *forced; int forced_ld, no_finish_mask; int64_t *seq;
     int seq_ld; int64_t *it_next; uint8_t *unfinished; float *seq_logp, *sel_logp; uint8_t *live; NextEmbed ne; int top_k;
     float top_p; int abl; int raw_out;     // raw_out: store the logits themselves (AttModel.py:172-175 output_logsoftmax = 0)
+    const uint64_t *epoch;                 // capmi_rng_bind_epoch (NULL: the seed alone)
 };
 
 // Body of the register-resident select for caption row r; s_f [32] / s_i [32] / s_tok [1] are workgroup scratch in LDS (static in the
@@ -345,7 +346,7 @@ __device__ __forceinline__ void select_reg_body(const SelArgs &A, const int r, f
                 // >= p, so the kept set starts right above it ... unless even the largest token alone has it (cur stays 0)
                 thr_key = top_k > 0 ? cur : cur + 1;
             }
-            const Philox rng(seed);
+            const Philox rng(capmi::epoch_seed(seed, A.epoch));
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 const int q = threadIdx.x + j * SEL_THREADS;
@@ -603,7 +604,7 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
     if (al && V1 % 4 == 0 && V1 <= 3 * 4 * SEL_THREADS) {
         const SelArgs sa{partial, splits, (size_t)slab_stride, bias, V1, step, L, mode, row_mode, temperature, gumbel, seed, forced,
                          forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live, ne, top_k, top_p, env_abl,
-                         raw_out};
+                         raw_out, capmi::rng_epoch()};
 #define CAPMI_SEL(NQ) hipLaunchKernelGGL(logsoftmax_select_reg_kernel<NQ>, dim3(N), dim3(SEL_THREADS), 0, st, sa)
         if (V1 <= 4 * SEL_THREADS) CAPMI_SEL(1);
         else if (V1 <= 8 * SEL_THREADS) CAPMI_SEL(2);
@@ -615,7 +616,7 @@ int capmi_logsoftmax_select_partial(const float *partial, int splits, int64_t sl
     hipLaunchKernelGGL(logsoftmax_select_kernel, dim3(N), dim3(SEL_THREADS), 0, st, partial, splits, (size_t)slab_stride, bias,
                        V1, step, L, mode, row_mode,
                        temperature, gumbel, seed, forced, forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished,
-                       seq_logp, sel_logp, live, ne, top_k, top_p, raw_out);      // (prenorm = 1 stores and gathers the row as it is)
+                       seq_logp, sel_logp, live, ne, top_k, top_p, raw_out, capmi::rng_epoch());      // (prenorm = 1 stores and gathers the row as it is)
     CAPMI_CHECK_LAUNCH();
     return 0;
 }
@@ -660,7 +661,7 @@ int capmi_logsoftmax_select_partial_gemm(const float *partial, int splits, int64
                        nullptr};
     if (next) ne.alive = next->alive;
     const SelArgs sa{partial, splits, (size_t)slab_stride, bias, V1, step, L, mode, row_mode, temperature, gumbel, seed, forced,
-                     forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live, ne, top_k, top_p, 0, raw_out};
+                     forced_ld, no_finish_mask, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp, live, ne, top_k, top_p, 0, raw_out, capmi::rng_epoch()};
     const size_t lds = (size_t)capmi_gemm::LC_NS * capmi_gemm::LC_STAGE + 512;
     const dim3 grid(N + cap.grid_x * cap.grid_y);
 #define CAPMI_FUSED(NQ)                                                                                                     \
@@ -694,7 +695,7 @@ int capmi_select_logp(const float *logp, int N, int V1, int step, int L, int mod
     hipLaunchKernelGGL(logsoftmax_select_kernel, dim3(N), dim3(SEL_THREADS), 0, (hipStream_t)stream, logp, 1, (size_t)0,
                        (const float *)nullptr, V1, step, L, mode, (const uint8_t *)nullptr, temperature, gumbel, seed,
                        (const int64_t *)nullptr, 0, 0, seq, seq_ld, it_next, unfinished, seq_logp, sel_logp,
-                       (uint8_t *)nullptr, NextEmbed{}, top_k, top_p, sel_unmasked ? 2 : 1);
+                       (uint8_t *)nullptr, NextEmbed{}, top_k, top_p, sel_unmasked ? 2 : 1, capmi::rng_epoch());
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

@@ -4,6 +4,7 @@
 // position, row log-softmax.  Cross-attention reads the per-image memory K/V once per image and serves the n
 // caption rows of that image from LDS (no repeat_tensors, TransformerModel.py:330-334).
 #include "capmi_common.h"
+#include "embed_bwd_det.h"
 #include "../../../include/capmi.h"
 
 using namespace capmi;
@@ -799,6 +800,21 @@ __global__ void embed_pe_bwd_kernel(const int64_t *__restrict__ tok, int tok_ld,
     }
 }
 
+struct EmbedPeGrad {     // gradient reaching x = (E[tok] * sqrt(D) + pe) * drop at (position, 4 columns)
+    const float *dx, *drop; int D; float scale;
+    __device__ __forceinline__ f32x4 operator()(size_t pos, int c) const {
+        const size_t o = pos * D + c;
+        f32x4 g = *reinterpret_cast<const f32x4 *>(dx + o) * scale;
+        if (drop) g *= *reinterpret_cast<const f32x4 *>(drop + o);
+        return g;
+    }
+};
+__global__ __launch_bounds__(capmi::EBD_THREADS) void embed_pe_bwd_det_kernel(const int64_t *__restrict__ tok, int T, int tok_ld,
+                                                                             int rows, int D, float *__restrict__ dE,
+                                                                             const EmbedPeGrad g) {
+    capmi::embed_bwd_det_body(tok, T, tok_ld, rows, D, dE, g);
+}
+
 __global__ __launch_bounds__(1024) void log_softmax_rows_kernel(const float *__restrict__ logits, float *__restrict__ out,
                                                                 int V1) {
     __shared__ float s_f[32];
@@ -1182,6 +1198,16 @@ int capmi_embed_pe_fwd(const int64_t *tok, int tok_ld, const float *E, const flo
 int capmi_embed_pe_bwd(const int64_t *tok, int tok_ld, const float *dx, const float *drop, float *dE, int N, int T, int D,
                        void *stream) {
     if (!tok || !dx || !dE || N <= 0 || T <= 0 || D <= 0) return CAPMI_EINVAL;
+    static const int det = capmi::knob("CAPMI_EMBED_BWD_DET", 1);
+    if (det && D % 4 == 0 && (int64_t)N * T <= capmi::EBD_MAX_ROWS &&
+        ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(drop) | reinterpret_cast<uintptr_t>(dE)) & 15) == 0) {
+        // r6: ordered sums instead of atomicAdd -- the same bits on every run (embed_bwd_det.h)
+        hipLaunchKernelGGL(embed_pe_bwd_det_kernel, dim3(N * T, (D + 255) / 256), dim3(capmi::EBD_THREADS),
+                           capmi::embed_bwd_det_lds(N * T), (hipStream_t)stream, tok, T, tok_ld, N * T, D, dE,
+                           EmbedPeGrad{dx, drop, D, sqrtf((float)D)});
+        CAPMI_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(embed_pe_bwd_kernel, dim3(grid_for((size_t)N * T * D)), dim3(256), 0, (hipStream_t)stream, tok, tok_ld,
                        dx, drop, dE, N, T, D, sqrtf((float)D));
     CAPMI_CHECK_LAUNCH();

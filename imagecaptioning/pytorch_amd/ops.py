@@ -189,6 +189,37 @@ class SlabArena:
         self.off += (floats + 63) // 64 * 64
 
 
+_pinned_arena = {'buf': None, 'off': 0}
+
+
+def reserve_pinned_arena(nbytes=8 << 20):
+    """Pinned host memory for the small tables a graph CAPTURE uploads (pinning inside a capture is refused by the runtime): call
+    before capturing.  A slot is handed out once and never recycled -- the captured memcpy node re-reads it at every replay."""
+    a = _pinned_arena
+    if a['buf'] is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('the pinned table arena must be reserved before a graph capture starts')
+        a['buf'], a['off'] = torch.empty(int(nbytes), dtype=torch.uint8, pin_memory=True), 0
+    return a
+
+
+def upload_bytes(raw, device):
+    """host bytes -> uint8 device tensor on the current stream, valid under graph capture"""
+    import numpy as np
+    n = len(raw)
+    if not torch.cuda.is_current_stream_capturing():
+        return torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory().to(device, non_blocking=True)
+    a = _pinned_arena
+    if a['buf'] is None or a['off'] + n > a['buf'].numel():
+        raise RuntimeError('pinned table arena missing or full (%d bytes wanted): ops.reserve_pinned_arena() before the capture' % n)
+    slot = a['buf'][a['off']:a['off'] + n]
+    a['off'] += (n + 63) // 64 * 64
+    slot.numpy()[:] = np.frombuffer(raw, dtype=np.uint8)
+    t = torch.empty(n, dtype=torch.uint8, device=device)
+    check(lib.capmi_upload_async(t.data_ptr(), slot.data_ptr(), n, stream_ptr()), 'capmi_upload_async')
+    return t
+
+
 class DeferredGrads:
     """Parameter gradients of a layer-by-layer backward that nothing reads before the optimizer: the weight-gradient GEMMs
     leave their K-slice slabs in a SlabArena and the bias-gradient column sums are only recorded; batched launches finish them
@@ -281,7 +312,7 @@ class DeferredGrads:
             return cached[1], False
         raw = b''.join(struct.pack(fmt, *r) for r in rows)
         DeferredGrads.uploads += 1          # (diagnostic: tables re-uploaded because the item list changed)
-        t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory().to(self.dev, non_blocking=True)
+        t = upload_bytes(raw, self.dev)
         self.state['tables'][name] = (key, t)
         return t, True
 
@@ -485,6 +516,52 @@ def relu_mask_bwd(dy, y_ref, mask):
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, clip, grad_scale, step):
     check(lib.capmi_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, clip,
                               grad_scale, step, stream_ptr()), 'capmi_adam_step')
+
+
+class StepState:
+    """The per-iteration record of a graph-capturable training step in device memory (capmi.h capmi_step_state): the epoch of the
+    random streams, Adam's step count with its bias corrections, the learning rate.  `advance()` is the first launch of every
+    iteration (stepped or captured); while `bound()` every dropout / sampling kernel offsets its seed argument by the epoch."""
+
+    def __init__(self, device, adam_step=0, epoch=0, lr=0.0):
+        import numpy as np
+        self.buf = torch.zeros(32, dtype=torch.uint8, device=device)
+        host = _lib.StepState(epoch=int(epoch), adam_step=int(adam_step), lr=float(lr), bc1=1.0, bc2_sqrt=1.0)
+        self.buf.copy_(torch.from_numpy(np.frombuffer(bytes(host), dtype=np.uint8).copy()))
+        self.lr = float(lr)
+
+    def advance(self, beta1, beta2):
+        check(lib.capmi_step_advance(self.buf.data_ptr(), beta1, beta2, stream_ptr()), 'capmi_step_advance')
+
+    def set_lr(self, lr):
+        """outside the captured graph; a launch only when the schedule moved the rate (misc.py set_lr)"""
+        if float(lr) != self.lr:
+            check(lib.capmi_step_set_lr(self.buf.data_ptr(), float(lr), stream_ptr()), 'capmi_step_set_lr')
+            self.lr = float(lr)
+
+    def read(self):
+        """host copy (a synchronisation: tests / checkpoints only)"""
+        return _lib.StepState.from_buffer_copy(bytes(self.buf.cpu().numpy().tobytes()))
+
+    class _Bound:
+        def __init__(self, st):
+            self.st = st
+
+        def __enter__(self):
+            self.prev = C.c_void_p()
+            check(lib.capmi_rng_bind_epoch(self.st.buf.data_ptr(), C.byref(self.prev)), 'capmi_rng_bind_epoch')
+
+        def __exit__(self, *a):
+            check(lib.capmi_rng_bind_epoch(self.prev.value, None), 'capmi_rng_bind_epoch')
+            return False
+
+    def bound(self):
+        return StepState._Bound(self)
+
+
+def adam_step_dyn(p, g, m, v, state, beta1, beta2, eps, weight_decay, clip, grad_scale):
+    check(lib.capmi_adam_step_dyn(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), state.buf.data_ptr(), beta1, beta2, eps, weight_decay,
+                                  clip, grad_scale, stream_ptr()), 'capmi_adam_step_dyn')
 
 
 def logsoftmax_bwd(g_dense, sparse, seq_logp, live, dlogits, N, L, T, V1, raw=False):

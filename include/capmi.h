@@ -413,6 +413,37 @@ int capmi_adam_step(float *p, const float *g, float *m, float *v, int64_t count,
                     void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Per-step state in DEVICE memory, so that a whole training iteration (tools/train.py:185-196: forward, loss, backward,
+ * clip + Adam) can be captured ONCE into a hipGraph and replayed: what changes from one iteration to the next -- the
+ * dropout / sampling random stream and Adam's step count (bias corrections) and learning rate -- is read from this record
+ * by the kernels instead of arriving as kernel arguments, which a graph would freeze.
+ *   capmi_step_advance   one thread: epoch += 1; adam_step += 1; bc1 = 1 - beta1^adam_step; bc2_sqrt = sqrt(1 - beta2^adam_step)
+ *                        (double arithmetic, like capmi_adam_step does on the host).  First launch of every iteration.
+ *   capmi_step_set_lr    lr = value (launched outside the graph, when the schedule changes it: misc.py set_lr)
+ *   capmi_rng_bind_epoch every kernel that takes a Philox `seed` (dropout masks, token sampling) uses
+ *                        seed + 0x9E3779B97F4A7C15 * (*epoch) while a non-NULL epoch pointer is bound (process-wide; one
+ *                        process per GPU).  NULL (the default) = the seed argument alone, as before.  Returns the
+ *                        previous binding through *prev when prev != NULL.
+ *   capmi_adam_step_dyn  capmi_adam_step with lr, bc1, bc2_sqrt read from the record.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct capmi_step_state {
+    uint64_t epoch;
+    int32_t adam_step;
+    float lr, bc1, bc2_sqrt;
+    float reserved[2];
+} capmi_step_state;
+/* hipMemcpyAsync host -> device on `stream` from PINNED host memory the caller keeps alive and unchanged (inside a graph capture
+ * this becomes a memcpy node that re-reads `src` at every replay: the item tables of capmi_splitk_reduce_batch /
+ * capmi_colsum_batch of a captured backward). */
+int capmi_upload_async(void *dst, const void *src_pinned, int64_t bytes, void *stream);
+int capmi_step_advance(capmi_step_state *state, float beta1, float beta2, void *stream);
+int capmi_step_set_lr(capmi_step_state *state, float lr, void *stream);
+int capmi_rng_bind_epoch(const uint64_t *epoch, const uint64_t **prev);
+int capmi_adam_step_dyn(float *p, const float *g, float *m, float *v, int64_t count, const capmi_step_state *state,
+                        float beta1, float beta2, float eps, float weight_decay, float clip, float grad_scale,
+                        void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * CIDEr-D reward (external pyciderevalcap.ciderD -- see oracle/ciderd.py for the provenance note;
  * call sites rewards.py:41-81, 83-114).  float64 arithmetic on device.
  *   table: open-addressing hash of the document-frequency pickle; keys = n-gram of <= 4 token ids

@@ -575,3 +575,43 @@ def test_glu_bwd_add_equals_masked_accumulating_reduce_then_glu_bwd(dev, M, R, s
     check(lib.capmi_glu_bwd_add(ptr(d_out), None, None, 0, 0, None, ptr(pre), ptr(plain), M, R, st), 'glu_bwd_add')
     check(lib.capmi_glu_bwd(ptr(d_out), None, ptr(pre), ptr(want), M, R, st), 'glu_bwd')
     assert torch.equal(plain, want)
+
+
+@pytest.mark.parametrize('rows,D,V,hot', [(1200, 1000, 9488, 0.3), (6720, 512, 9488, 0.5), (7, 48, 11, 0.0), (6720, 1000, 9488, 0.9)])
+def test_embedding_gradients_are_ordered_sums_the_same_bits_every_run(rows, D, V, hot):
+    """r6 (csrc/embed_bwd_det.h): capmi_embed_bwd / capmi_embed_pe_bwd sum the positions of a token in ascending order instead of by
+    atomicAdd -- equal to the fp64 scatter-add within fp32 rounding, bit-identical between launches, adding into dE like before.
+    `hot`: fraction of the positions holding ONE token (BOS / a frequent word: the leader's list is then thousands long)."""
+    from imagecaptioning.pytorch_amd._lib import lib, ptr, check, stream_ptr
+    DEV = 'cuda:0'
+    g = torch.Generator().manual_seed(rows + D)
+    tok = torch.randint(0, V, (rows,), generator=g)
+    tok[torch.rand(rows, generator=g) < hot] = 3
+    dx = torch.randn(rows, D, generator=g)
+    xs = torch.randn(rows, D, generator=g)
+    mask = (torch.rand(rows, D, generator=g) < 0.5).float() * 2
+    want = torch.zeros(V, D, dtype=torch.float64)
+    want.index_add_(0, tok, (dx * mask * (xs > 0)).double())
+    tok_d, dx_d, xs_d, m_d = tok.to(DEV), dx.to(DEV), xs.to(DEV), mask.to(DEV)
+    outs = []
+    for _ in range(3):
+        dE = torch.full((V, D), 0.25, device=DEV)                 # += semantics: the fill must survive
+        check(lib.capmi_embed_bwd(ptr(tok_d), ptr(dx_d), ptr(xs_d), ptr(m_d), ptr(dE), rows, D, 1, stream_ptr()), 'embed_bwd')
+        outs.append(dE.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert float((outs[0].double() - 0.25 - want).abs().max()) <= 2e-6 * max(1.0, float(want.abs().max()))
+    # the Transformer's: positions [N, T] with a row pitch, x = (E[tok] * sqrt(D) + pe) * drop
+    N, T = (rows // 21, 21) if rows % 21 == 0 else (rows, 1)
+    ld = T + 2
+    tok2 = torch.zeros(N, ld, dtype=torch.long)
+    tok2[:, :T] = tok.view(N, T)
+    want2 = torch.zeros(V, D, dtype=torch.float64)
+    want2.index_add_(0, tok, (dx * mask).double() * float(np.sqrt(np.float32(D))))
+    tok2_d = tok2.to(DEV)
+    outs = []
+    for _ in range(2):
+        dE = torch.zeros(V, D, device=DEV)
+        check(lib.capmi_embed_pe_bwd(ptr(tok2_d), ld, ptr(dx_d), ptr(m_d), ptr(dE), N, T, D, stream_ptr()), 'embed_pe_bwd')
+        outs.append(dE.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0].double() - want2).abs().max()) <= 2e-6 * max(1.0, float(want2.abs().max()))
