@@ -353,7 +353,31 @@ def main():
     mode_now = {'overlap': overlap, 'sharded': sharded, 'none': False}
     one = torch.ones((), dtype=torch.float32, device=dev)
 
+    # r6: the iteration itself is graph_step.TrainStep -- the trainer's own step object (tools/train.py uses the same): stepped launch
+    # by launch for UpDown / NewFC (native rollouts), captured into a hipGraph and replayed for the Transformer and AoA families
+    # (CAPMI_GRAPH_STEP=0: stepped everywhere).  N > 1: the graph ends at the flat gradient; all-reduce + clip/Adam follow un-captured.
+    from imagecaptioning.pytorch_amd.graph_step import TrainStep
+
+    def _all_reduce():
+        if mode_now['none']:
+            return 1.0
+        ev = ar_events
+        if ev is not None:
+            ev[0].record()
+        scale = flat.all_reduce()
+        if ev is not None:
+            ev[1].record()
+        return scale
+    ts = TrainStep(lw, flat, opt, dev, world=world, all_reduce=_all_reduce if multi else None)
+
     def step():
+        if not (mode_now['overlap'] or mode_now['sharded']):
+            loss, _ = ts(pf.get_batch('train'), sc_flag, struc_flag)
+            return loss
+        return step_legacy()
+
+    def step_legacy():
+        """the opt-in exchange modes (bucketed overlap, reduce-scatter + sharded Adam): launch by launch, host-side Adam step count"""
         nonlocal_ar = ar_events
         overlap, sharded = mode_now['overlap'], mode_now['sharded']
         data = pf.get_batch('train')
@@ -638,6 +662,8 @@ def main():
                                                    {k: round(v - mode_ms['none'], 3) for k, v in mode_ms.items() if isinstance(v, float) and k != 'none'},
                                                    'note': 'ms_per_step_by_mode: the default mode over the K timed steps, the others over 6 extra steps each; '
                                                            '"none" = no gradient exchange (compute only); exposed = mode - none'},
+            'step_issue': {'mode': 'hipGraph replay (graph_step.TrainStep)' if ts.replays else 'stepped launch by launch',
+                           'captures': ts.captures, 'replays': ts.replays, 'stepped': ts.stepped, 'capture_failed': ts.failed},
             'loss': float(loss.detach()), 'roofline': roofline, 'attention': attention, 'kernel_ms_per_step': per_class,
             'early_exit_eos_biased': early, 'cpu_baseline': cpu}
         WATCH['line'] = line

@@ -248,7 +248,11 @@ class DeferredGrads:
         # r5: re-measured with the final kernels -- the side stream is worth 2-5 % of the Transformer step (13.45-13.69 vs 13.79-13.90 ms,
         # 13.0 vs 13.8, 13.85 vs 14.35 on three boxes; profiles/r05_fat_gemm_wide.md section 7); CAPMI_DW_STREAM=0 runs the deferred
         # GEMMs in line on one stream (they may then use 256 x 128 tiles too, see below)
-        if os.environ.get('CAPMI_DW_STREAM', '1') != '0' and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        # (r6: inside a graph capture the side stream CAN join -- its first event wait forks it into the capture, flush() joins it
+        #  back, the deferred GEMMs become a parallel branch of the graph -- but replayed that branch LOSES: Transformer XE 23.24 vs
+        #  22.76 ms, AoA nsc 7.03 vs 6.43 (gpurun_out/r6d, same box); CAPMI_DW_STREAM_CAPTURE=1 opts in)
+        if os.environ.get('CAPMI_DW_STREAM', '1') != '0' and torch.cuda.is_available() and \
+                (not torch.cuda.is_current_stream_capturing() or os.environ.get('CAPMI_DW_STREAM_CAPTURE', '0') == '1'):
             if 'side' not in self.state:
                 self.state['side'] = torch.cuda.Stream(device=device)
                 self.state['events'] = []
