@@ -81,6 +81,11 @@ class ReduceItem(C.Structure):
                 ('ldc', C.c_int32), ('accumulate', C.c_int32), ('reserved', C.c_int32)]
 
 
+class GroupGemm(C.Structure):
+    _fields_ = [('A', c_f), ('B', c_f), ('C', c_f), ('lda', C.c_int32), ('ldb', C.c_int32), ('ldc', C.c_int32), ('K', C.c_int32),
+                ('M', C.c_int32), ('N', C.c_int32), ('accumulate', C.c_int32), ('splits_used', C.c_int32)]
+
+
 class ColsumItem(C.Structure):
     _fields_ = [('in', c_f), ('out', c_f), ('out2', c_f), ('rows', C.c_int32), ('cols', C.c_int32), ('ld', C.c_int32),
                 ('accumulate', C.c_int32)]
@@ -214,6 +219,7 @@ SIGNATURES = {
     'capmi_mha_fwd_qslabs': [_P, _I, _I, _I64, _P, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'capmi_mha_bwd_slabs': [_P, _I, _I64, _I, _P, _I, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'capmi_gemm_set_policy': [_I],
+    'capmi_gemm_group_tn': [_P, _I, _P, _I64, _P],
     'capmi_split_halves': [_P, _I, _I64, _P, _P, _P, _P, _I, _I, _P],
     'capmi_meanpool_fwd': [_P, _P, _P, _I, _I, _I, _P],
     'capmi_meanpool_bwd': [_P, _P, _P, _I, _I, _I, _I, _P],

@@ -84,4 +84,28 @@ int launch_x3(const KArgs &a, int a_layout, int b_layout, dim3 grid, hipStream_t
 // ... on 256 x 128 tiles (gemm_x3w.hip, r5); grid = (gn, gm of the 256-row tiling, splits)
 int launch_x3w(const KArgs &a, int a_layout, int b_layout, dim3 grid, hipStream_t st, int pcls, double bytes, double flops);
 
+// ---- r6: grouped launch of independent weight-gradient GEMMs C_i = A_i^T B_i ([K][M] x [K][N] operands) on the 256 x 128 kernel ----
+// One table entry = a run of output tiles of one GEMM (row-major tile order of its 256 x 128 tiling).  Entries with splits == 1 write
+// (or add to) C directly; the tail entries of a launch are cut into K slices that leave [256 x 128] pieces in `slab`
+// (piece (tile_local, z) at slab + (tile_local * splits + z) * 32768 floats), summed into C by group_reduce.
+struct GItem {
+    const float *A, *B;
+    float *C;
+    float *slab;
+    int lda, ldb, ldc, K, M, N;
+    int kt;            // ceil(K / BK)
+    int gn;            // column tiles of the GEMM
+    int tile0, ntiles; // tile range of this entry
+    int splits;
+    int unit0;         // first unit of this entry in the launch's unit list (ntiles * splits units, z-major)
+    int rtile0;        // first piece-set of this entry in the reduction launch's list (splits > 1 only)
+    int accumulate;    // C += instead of C =
+};
+constexpr int GROUP_MAX = 44;      // entries per launch: the table travels BY VALUE in the kernel arguments (44 x 88 B + 16 < 4 KB)
+struct GTab {
+    GItem it[GROUP_MAX];
+    int n, units, rtiles, reserved;
+};
+int launch_x3w_group(const GTab &t, hipStream_t st, int pcls, double bytes, double flops);
+
 }  // namespace capmi_gemm

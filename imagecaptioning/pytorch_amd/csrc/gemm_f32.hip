@@ -694,3 +694,98 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
                                    a.row_bias_div, d->mul_mask, d->relu, d->accumulate, d->addend, stream);
     return 0;
 }
+
+// ---- r6: grouped weight-gradient GEMMs (capmi.h capmi_gemm_group_tn; kernel in gemm_x3w.hip) -------------------------------------
+extern "C" int capmi_gemm_group_tn(capmi_group_gemm *items, int n, float *slabs, int64_t slab_floats, void *stream) {
+    if (!items || n <= 0) return CAPMI_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    static const int env_group = capmi::knob("CAPMI_GEMM_GROUP", 1);      // 0: every item through capmi_gemm_f32 (A/B switch)
+    constexpr int TILE = 256 * 128;
+    // eligible items, longest K first (a round of the grid then holds units of one length; a stable order keeps the plan a
+    // function of the shapes alone)
+    int order[1024], n_ok = 0, rest[1024], n_rest = 0;
+    if (n > 1024) return CAPMI_EINVAL;
+    for (int i = 0; i < n; ++i) {
+        capmi_group_gemm &g = items[i];
+        if (!g.A || !g.B || !g.C || g.K <= 0 || g.M <= 0 || g.N <= 0) return CAPMI_EINVAL;
+        const bool ok = env_group && BK == 32 && g.M % 4 == 0 && g.N % 4 == 0 && g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
+                        g.ldc % 4 == 0 && aligned16(g.A) && aligned16(g.B) && aligned16(g.C) &&
+                        (uint64_t)g.lda * 16 * 4 + (uint64_t)g.M * 4 < (1ull << 32) && (uint64_t)g.ldb * 16 * 4 + (uint64_t)g.N * 4 < (1ull << 32);
+        if (ok) order[n_ok++] = i;
+        else rest[n_rest++] = i;
+    }
+    for (int i = 1; i < n_ok; ++i) {                     // insertion sort by K tiles, descending, stable
+        const int v = order[i], kv = (items[v].K + BK - 1) / BK;
+        int j = i - 1;
+        while (j >= 0 && (items[order[j]].K + BK - 1) / BK < kv) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = v;
+    }
+    int pos = 0;
+    while (pos < n_ok) {
+        // one launch: as many items as fit the table, one entry kept free for the item the round boundary cuts in two
+        int cnt = n_ok - pos < GROUP_MAX - 1 ? n_ok - pos : GROUP_MAX - 1;
+        long long U = 0;
+        for (int j = 0; j < cnt; ++j) {
+            const capmi_group_gemm &g = items[order[pos + j]];
+            U += (long long)((g.M + 255) / 256) * ((g.N + 127) / 128);
+        }
+        const long long F = (U / 256) * 256;             // tiles of the full rounds: whole-K, straight into C
+        const long long R = U - F;                        // tiles of the last, partial round: K-sliced so that they fill it
+        GTab t{};
+        int ne = 0, unit = 0, rt = 0;
+        long long seen = 0;
+        int64_t slab_off = 0;
+        double bytes = 0, flops = 0;
+        for (int j = 0; j < cnt; ++j) {
+            capmi_group_gemm &g = items[order[pos + j]];
+            const int gm = (g.M + 255) / 256, gn = (g.N + 127) / 128, ot = gm * gn, kt = (g.K + BK - 1) / BK;
+            bytes += 4.0 * ((double)g.K * (g.M + g.N) + (double)g.M * g.N);
+            flops += 2.0 * g.M * (double)g.N * g.K;
+            g.splits_used = 1;
+            const int whole = seen >= F ? 0 : (int)(F - seen < ot ? F - seen : ot);     // tiles of this item inside the full rounds
+            for (int part = 0; part < 2; ++part) {
+                const int t0 = part ? whole : 0, nt = part ? ot - whole : whole;
+                if (nt <= 0) continue;
+                GItem &e = t.it[ne++];
+                e.A = g.A; e.B = g.B; e.C = g.C; e.slab = nullptr;
+                e.lda = g.lda; e.ldb = g.ldb; e.ldc = g.ldc; e.K = g.K; e.M = g.M; e.N = g.N;
+                e.kt = kt; e.gn = gn; e.tile0 = t0; e.ntiles = nt; e.accumulate = g.accumulate ? 1 : 0;
+                int sp = 1;
+                if (part) {
+                    sp = (int)(256 / R);                 // R tiles x sp slices ~ one round of the grid
+                    if (sp > kt / 4) sp = kt / 4;        // >= 4 K tiles per slice
+                    if (sp > 32) sp = 32;
+                    while (sp > 1 && (!slabs || slab_off + (int64_t)nt * sp * TILE > slab_floats)) --sp;
+                    if (sp < 1) sp = 1;
+                }
+                e.splits = sp;
+                e.unit0 = unit;
+                unit += nt * sp;
+                if (sp > 1) {
+                    e.slab = slabs + slab_off;
+                    slab_off += (int64_t)nt * sp * TILE;
+                    e.rtile0 = rt;
+                    rt += nt;
+                    g.splits_used = sp;
+                }
+            }
+            seen += ot;
+        }
+        t.n = ne; t.units = unit; t.rtiles = rt;
+        int rc = launch_x3w_group(t, st, CAPMI_PROF_GEMM_FAT, bytes, flops);
+        if (rc) return rc;
+        pos += cnt;
+    }
+    for (int j = 0; j < n_rest; ++j) {
+        capmi_group_gemm &g = items[rest[j]];
+        capmi_gemm_desc d{};
+        d.nseg = 1;
+        d.seg[0].A = g.A; d.seg[0].B = g.B; d.seg[0].lda = g.lda; d.seg[0].ldb = g.ldb; d.seg[0].K = g.K; d.seg[0].a_row_div = 1;
+        d.a_layout = 1; d.b_layout = 1; d.M = g.M; d.N = g.N; d.C = g.C; d.ldc = g.ldc; d.accumulate = g.accumulate;
+        // (no K split here: `slabs` holds pieces of the group, not the zeroed ticket words a capmi_gemm_f32 workspace starts with)
+        int rc = capmi_gemm_f32(&d, stream);
+        if (rc) return rc;
+        g.splits_used = -1;
+    }
+    return 0;
+}

@@ -313,6 +313,247 @@ __global__ __launch_bounds__(512 + 64 * NSW) void gemm_x3w_kernel(const KArgs a,
     }
 }
 
+
+// ============================================================ r6: GROUPED launch ============================================================
+// N independent GEMMs (the weight gradients dW_i = dY_i^T X_i that nothing reads before the optimizer) as ONE persistent grid: the
+// units of all table entries form one list, a workgroup walks every gridDim.x-th unit and its staging waves run ahead across entry
+// boundaries exactly as across the units of one GEMM.  Why (profiles/r05_scst_kernel_stats.md, r05_txe_kernel_stats.md): launched one
+// by one these GEMMs are sub-wave grids -- [4000 x 1000] is 128 wide tiles on 256 CUs, [512 x 512] is 8 -- so each either ran on the
+// 128 x 128 kernel (MFMA busy 0.45 against 0.59) or needed a 16-32-way K split with its slab traffic, and each paid its own
+// prologue / tail.  In a group the full rounds run whole-K tiles straight into C; only the LAST partial round of a launch is cut
+// into K slices (<= 256 pieces of 128 KB) so that it spreads over all CUs, and one small launch sums those pieces.
+// The table travels by value in the kernel arguments (s_load with a computed offset: no device table, no upload, capturable).
+
+// The table is read THROUGH THE KERNEL-ARGUMENT SEGMENT (address space 4, scalar loads with a computed offset): taken from the by-value
+// parameter the compiler copied all 3.9 KB of it into scratch first (a dynamically indexed aggregate; .private_segment_fixed_size 3896).
+typedef const GTab __attribute__((address_space(4))) *GTabK;
+typedef const GItem __attribute__((address_space(4))) *GItemK;
+
+struct GUnit {
+    int e;                  // table entry
+    int m0, n0, t_begin, nt, z, tl;
+};
+
+// the unit a workgroup handles in round r (XCD-aware inside full rounds, see wunit_of)
+__device__ __forceinline__ int g_unit_index(int r, int units) {
+    const int G = gridDim.x, b = blockIdx.x;
+    if ((G & 7) == 0 && (r + 1) * G <= units) return (b & 7) * (G >> 3) + (b >> 3) + r * G;
+    return b + r * G;
+}
+
+// `e` only moves forward: a workgroup's unit indices grow with the round
+__device__ __forceinline__ GUnit g_unit_of(GTabK t, int u, int &e) {
+    while (e + 1 < t->n && u >= t->it[e + 1].unit0) ++e;
+    GItemK it = &t->it[e];
+    const int local = u - it->unit0;
+    GUnit r;
+    r.e = e;
+    r.z = local / it->ntiles;
+    r.tl = local - r.z * it->ntiles;
+    const int tile = it->tile0 + r.tl;
+    r.m0 = (tile / it->gn) * WBM;
+    r.n0 = (tile % it->gn) * WBN;
+    r.t_begin = (int)(((long long)it->kt * r.z) / it->splits);
+    r.nt = (int)(((long long)it->kt * (r.z + 1)) / it->splits) - r.t_begin;
+    return r;
+}
+
+template <bool AKC, bool BKC, bool DOA, bool DOB>
+__device__ __forceinline__ void wg_staging(GTabK t, int tid, unsigned short *smem) {
+    float ra[16], rc[16], rb[16];
+    WEdge e{};
+    WStager<AKC> sa0, sa1;
+    WStager<BKC> sb;
+    const int G = gridDim.x;
+    int steps = 0, rounds = 0;
+    {
+        int ent = 0;
+        for (int r = 0; blockIdx.x + r * G < t->units; ++r) {
+            steps += g_unit_of(t, g_unit_index(r, t->units), ent).nt;
+            ++rounds;
+        }
+    }
+    int f_ent = 0, f_round = 0, f_left = 0, f_k0 = 0;
+    auto open_unit = [&]() {
+        const GUnit un = g_unit_of(t, g_unit_index(f_round, t->units), f_ent);
+        GItemK it = &t->it[un.e];
+        sa0.init(it->A, it->lda, it->K);
+        sa1.init(it->A, it->lda, it->K);
+        sb.init(it->B, it->ldb, it->K);
+        sa0.set_tile(un.m0, it->M, tid);
+        sa1.set_tile(un.m0 + 128, it->M, tid);
+        sb.set_tile(un.n0, it->N, tid);
+        f_k0 = un.t_begin * BK;
+        f_left = un.nt;
+    };
+    if (rounds > 0) open_unit();
+    else {                                                 // (never fetched for real: steps == 0)
+        GItemK it = &t->it[0];
+        sa0.init(it->A, it->lda, it->K); sa1.init(it->A, it->lda, it->K); sb.init(it->B, it->ldb, it->K);
+        sa0.set_tile(0, it->M, tid); sa1.set_tile(0, it->M, tid); sb.set_tile(0, it->N, tid);
+    }
+    auto fetch = [&](float (&xa0)[16], float (&xa1)[16], float (&xb)[16], WEdge &ed) {
+        if (DOA) sa0.fetch(xa0, f_k0);
+        if (DOA) sa1.fetch(xa1, f_k0);
+        if (DOB) sb.fetch(xb, f_k0);
+        ed.va0 = sa0.valid_rows; ed.va1 = sa1.valid_rows; ed.vb = sb.valid_rows;
+        ed.vk = min(sa0.K - f_k0, BK);
+        ed.edge = (DOA && (ed.va0 < 128 || ed.va1 < 128)) || (DOB && ed.vb < 128) || ed.vk < BK;
+        if (f_left > 0) {                              // workgroup-uniform
+            if (--f_left == 0) {
+                if (++f_round < rounds) open_unit();
+            } else {
+                f_k0 += BK;
+            }
+        }
+    };
+    auto store = [&](const float (&xa0)[16], const float (&xa1)[16], const float (&xb)[16], const WEdge &ed, int g) {
+        unsigned short *st = smem + (g & 1) * WSTAGE;
+        if (ed.edge) {
+            if (DOA) w_r2s<AKC, true, WPL_A>(xa0, st, tid, ed.va0, ed.vk);
+            if (DOA) w_r2s<AKC, true, WPL_A>(xa1, st + 128 * 32, tid, ed.va1, ed.vk);
+            if (DOB) w_r2s<BKC, true, WPL_B>(xb, st + 3 * WPL_A, tid, ed.vb, ed.vk);
+        } else {
+            if (DOA) w_r2s<AKC, false, WPL_A>(xa0, st, tid, 128, BK);
+            if (DOA) w_r2s<AKC, false, WPL_A>(xa1, st + 128 * 32, tid, 128, BK);
+            if (DOB) w_r2s<BKC, false, WPL_B>(xb, st + 3 * WPL_A, tid, 128, BK);
+        }
+    };
+    fetch(ra, rc, rb, e);                              // step 0
+    if (steps > 0) store(ra, rc, rb, e, 0);
+    fetch(ra, rc, rb, e);                              // step 1
+    __syncthreads();                                   // stage 0 ready
+    for (int g = 0; g < steps; ++g) {
+        if (g + 1 < steps) store(ra, rc, rb, e, g + 1);
+        fetch(ra, rc, rb, e);
+        __syncthreads();
+    }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(1024) void gemm_x3w_group_kernel(const GTab table) {
+    GTabK t = (GTabK)__builtin_amdgcn_kernarg_segment_ptr();              // = &table, where the dispatch put it
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];      // 2 stages = 144 KB
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (wid >= 8) {
+        if (wid < 12) wg_staging<AKC, BKC, true, false>(t, threadIdx.x - 512, smem);
+        else wg_staging<AKC, BKC, false, true>(t, threadIdx.x - 768, smem);
+        return;
+    }
+    const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
+    const int l31 = lane & 31, half = lane >> 5;
+    int offA[2][2], offB[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            offA[q][ks] = wswz(wm0 + 32 * q + l31, 16 * ks + 8 * half);
+            offB[q][ks] = wswz(wn0 + 32 * q + l31, 16 * ks + 8 * half);
+        }
+    __syncthreads();                                       // stage 0 ready
+    int g = 0, ent = 0;
+    for (int r = 0; blockIdx.x + r * (int)gridDim.x < t->units; ++r) {
+        const GUnit un = g_unit_of(t, g_unit_index(r, t->units), ent);
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+        for (int i = 0; i < un.nt; ++i, ++g) {
+            const unsigned short *As = smem + (g & 1) * WSTAGE, *Bs = As + 3 * WPL_A;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 av[2][3], bv[2][3];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        av[q][pl] = *reinterpret_cast<const bf16x8 *>(As + pl * WPL_A + offA[q][ks]);
+                        bv[q][pl] = *reinterpret_cast<const bf16x8 *>(Bs + pl * WPL_B + offB[q][ks]);
+                    }
+                // the six cross terms in the order of gemm_x3.hip / gemm_x3w_kernel: a K slice sums to the same bits in all three
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][2], bv[j][0], acc[q][j], 0, 0, 0);
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][2], acc[q][j], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][1], acc[q][j], 0, 0, 0);
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][0], acc[q][j], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][1], acc[q][j], 0, 0, 0);
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][0], acc[q][j], 0, 0, 0);
+                    }
+            }
+            __syncthreads();                               // stage g&1 released, stage (g+1)&1 ready
+        }
+        // ---- epilogue: whole-K units write (or add to) C; K slices leave their [256 x 128] piece in the entry's slab
+        GItemK it = &t->it[un.e];
+        const bool piece = it->splits > 1;
+        float *out = piece ? it->slab + ((size_t)un.tl * it->splits + un.z) * (size_t)(WBM * WBN)
+                           : it->C + (size_t)un.m0 * it->ldc + un.n0;
+        const int ldo = piece ? WBN : it->ldc;
+        const int vr = it->M - un.m0, vc = it->N - un.n0;                 // valid rows / columns of the tile (may exceed 256 / 128)
+        const bool add = !piece && it->accumulate;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = wn0 + 32 * j + l31;
+                if (col >= vc) continue;
+#pragma unroll
+                for (int x = 0; x < 16; ++x) {
+                    const int row = wm0 + 32 * i + (x & 3) + 8 * (x >> 2) + 4 * half;
+                    if (row >= vr) continue;
+                    float *o = out + (size_t)row * ldo + col;
+                    *o = add ? *o + acc[i][j][x] : acc[i][j][x];
+                }
+            }
+    }
+}
+
+// blockIdx.x = one split tile of the launch: C tile (+)= sum of its `splits` pieces, in the order of splitk_reduce_batch_kernel
+// (four pieces per pass, (p0 + p1) + (p2 + p3) added to the running sum) so that a grouped GEMM and the same GEMM launched alone
+// with the same K split agree bit for bit.
+__global__ __launch_bounds__(256) void x3w_group_reduce_kernel(const GTab table) {
+    GTabK t = (GTabK)__builtin_amdgcn_kernarg_segment_ptr();
+    int e = 0;
+    while (e < t->n && !(t->it[e].splits > 1 && (int)blockIdx.x >= t->it[e].rtile0 && (int)blockIdx.x < t->it[e].rtile0 + t->it[e].ntiles)) ++e;
+    if (e >= t->n) return;
+    GItemK it = &t->it[e];
+    const int tl = blockIdx.x - it->rtile0, tile = it->tile0 + tl;
+    const int m0 = (tile / it->gn) * WBM, n0 = (tile % it->gn) * WBN;
+    const int vr = min(it->M - m0, WBM), vc = min(it->N - n0, WBN);
+    const float *p = it->slab + (size_t)tl * it->splits * (size_t)(WBM * WBN);
+    for (int q = threadIdx.x; q < WBM * WBN / 4; q += 256) {
+        const int row = q / (WBN / 4), c4 = (q % (WBN / 4)) * 4;
+        if (row >= vr || c4 >= vc) continue;                 // (N % 4 == 0: a quad of columns is entirely inside or outside)
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < it->splits; s0 += 4) {
+            f32x4 tv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                tv[u] = (s0 + u < it->splits) ? *reinterpret_cast<const f32x4 *>(p + (size_t)(s0 + u) * (WBM * WBN) + (size_t)row * WBN + c4)
+                                             : f32x4{0.f, 0.f, 0.f, 0.f};
+            v += (tv[0] + tv[1]) + (tv[2] + tv[3]);
+        }
+        f32x4 *o = reinterpret_cast<f32x4 *>(it->C + (size_t)(m0 + row) * it->ldc + n0 + c4);
+        if (it->accumulate) v += *o;
+        *o = v;
+    }
+}
+
 }  // namespace
 
 int launch_x3w(const KArgs &a, int a_layout, int b_layout, dim3 tiles, hipStream_t st, int pcls, double bytes, double flops) {
@@ -350,6 +591,28 @@ int launch_x3w(const KArgs &a, int a_layout, int b_layout, dim3 tiles, hipStream
 #undef CAPMI_X3W_GO
 #undef CAPMI_X3W_N
     CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_x3w_group(const GTab &t, hipStream_t st, int pcls, double bytes, double flops) {
+    if (t.n < 1 || t.n > GROUP_MAX || t.units < 1) return CAPMI_EINVAL;
+    const dim3 grid(t.units < 256 ? t.units : 256);
+    hipEvent_t e0, e1;
+    const bool prof = capmi_prof::take_events(pcls, &e0, &e1, bytes, flops);
+    constexpr size_t lds = 2 * (size_t)WSTAGE * sizeof(unsigned short);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_x3w_group_kernel<false, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (prof) hipExtLaunchKernelGGL((gemm_x3w_group_kernel<false, false>), grid, dim3(1024), lds, st, e0, e1, 0, t);
+    else hipLaunchKernelGGL((gemm_x3w_group_kernel<false, false>), grid, dim3(1024), lds, st, t);
+    CAPMI_CHECK_LAUNCH();
+    if (t.rtiles > 0) {
+        hipLaunchKernelGGL(x3w_group_reduce_kernel, dim3(t.rtiles), dim3(256), 0, st, t);
+        CAPMI_CHECK_LAUNCH();
+    }
     return 0;
 }
 

@@ -522,29 +522,39 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
     const int side_chunks = side_st ? (env_side < 4 ? env_side : 4) : 1;       // time chunks of the LSTM weight gradients
     // LSTM / h2att weight gradients of the time steps [t0, t1): K = (t1 - t0) * N rows of the time-batched operands
     const float *x_hatt_same = a_hatt + (compact ? NR : NRf);                   // h_att of the SAME step (slots 1..T)
+    // r6: in a single-call backward without the side stream the eight weight gradients nothing reads before the optimizer (dW_logit and
+    // the LSTM / h2att ones) are only LISTED where they become computable and go out together at the end as ONE grouped persistent
+    // launch (capmi_gemm_group_tn: 256 x 128 tiles, whole-K tiles of the full rounds straight into the gradient buffers, a K-sliced
+    // tail) instead of eight sub-wave grids (profiles/r05_scst_kernel_stats.md: 10 launches of gemm_x3_kernel<false,false>, 446 us).
+    // CAPMI_GEMM_GROUP=0 restores them.
+    static const int env_group = capmi::knob("CAPMI_GEMM_GROUP", 1);
+    capmi_group_gemm grp[8];
+    int n_grp = 0;
+    const bool grouped = env_group && (phases & CAPMI_BWD_ALL) == CAPMI_BWD_ALL && !side_st;
+    auto dw_one = [&](void *strm, int Mw, int Nw, float *Cw, int ldcw, const float *Aw, int ldaw, const float *Bw, int ldbw, int Kw, int acc,
+                      float *Pw, int64_t capw) -> int {
+        if (grouped && !acc && n_grp < 8) {
+            grp[n_grp++] = capmi_group_gemm{Aw, Bw, Cw, ldaw, ldbw, ldcw, Kw, Mw, Nw, 0, 0};
+            return 0;
+        }
+        SegSpec a{Aw, ldaw, Bw, ldbw, Kw, 1};
+        return gemm(strm, 1, 1, Mw, Nw, Cw, ldcw, &a, 1, Pw, capw, 0, nullptr, nullptr, nullptr, acc);
+    };
     auto dw_chunk = [&](void *strm, int t0, int t1, int acc, float *Pw, int64_t capw) -> int {
         const int Kc = (t1 - t0) * N;
         const size_t o4 = (size_t)t0 * N * 4 * R, oR = (size_t)t0 * N * R, oE = (size_t)t0 * N * E, oA = (size_t)t0 * N * A;
         if (phases & CAPMI_BWD_ATT_LSTM) {
-            SegSpec a{s->dg_att + o4, 4 * R, a_hlang + oR, R, Kc, 1};            // x h_lang_prev  (slots 0..T-1)
-            RC(gemm(strm, 1, 1, 4 * R, R, g->att_w_ih, ld_att_ih, &a, 1, Pw, capw, 0, nullptr, nullptr, nullptr, acc));
-            SegSpec b{s->dg_att + o4, 4 * R, a_xt + oE, E, Kc, 1};               // x xt
-            RC(gemm(strm, 1, 1, 4 * R, E, g->att_w_ih + 2 * R, ld_att_ih, &b, 1, Pw, capw, 0, nullptr, nullptr, nullptr, acc));
-            SegSpec c{s->dg_att + o4, 4 * R, a_hatt + oR, R, Kc, 1};             // x h_att_prev
-            RC(gemm(strm, 1, 1, 4 * R, R, g->att_w_hh, R, &c, 1, Pw, capw, 0, nullptr, nullptr, nullptr, acc));
+            RC(dw_one(strm, 4 * R, R, g->att_w_ih, ld_att_ih, s->dg_att + o4, 4 * R, a_hlang + oR, R, Kc, acc, Pw, capw));          // x h_lang_prev (slots 0..T-1)
+            RC(dw_one(strm, 4 * R, E, g->att_w_ih + 2 * R, ld_att_ih, s->dg_att + o4, 4 * R, a_xt + oE, E, Kc, acc, Pw, capw));      // x xt
+            RC(dw_one(strm, 4 * R, R, g->att_w_hh, R, s->dg_att + o4, 4 * R, a_hatt + oR, R, Kc, acc, Pw, capw));                    // x h_att_prev
         }
         if (phases & CAPMI_BWD_LANG_LSTM) {
-            SegSpec a{s->dg_lang + o4, 4 * R, a_ctx + oR, R, Kc, 1};
-            RC(gemm(strm, 1, 1, 4 * R, R, g->lang_w_ih, 2 * R, &a, 1, Pw, capw, 0, nullptr, nullptr, nullptr, acc));
-            SegSpec b{s->dg_lang + o4, 4 * R, x_hatt_same + oR, R, Kc, 1};
-            RC(gemm(strm, 1, 1, 4 * R, R, g->lang_w_ih + R, 2 * R, &b, 1, Pw, capw, 0, nullptr, nullptr, nullptr, acc));
-            SegSpec c{s->dg_lang + o4, 4 * R, a_hlang + oR, R, Kc, 1};
-            RC(gemm(strm, 1, 1, 4 * R, R, g->lang_w_hh, R, &c, 1, Pw, capw, 0, nullptr, nullptr, nullptr, acc));
+            RC(dw_one(strm, 4 * R, R, g->lang_w_ih, 2 * R, s->dg_lang + o4, 4 * R, a_ctx + oR, R, Kc, acc, Pw, capw));
+            RC(dw_one(strm, 4 * R, R, g->lang_w_ih + R, 2 * R, s->dg_lang + o4, 4 * R, x_hatt_same + oR, R, Kc, acc, Pw, capw));
+            RC(dw_one(strm, 4 * R, R, g->lang_w_hh, R, s->dg_lang + o4, 4 * R, a_hlang + oR, R, Kc, acc, Pw, capw));
         }
-        if (phases & CAPMI_BWD_ATTENTION) {
-            SegSpec a{s->d_att_h_all + oA, A, x_hatt_same + oR, R, Kc, 1};
-            RC(gemm(strm, 1, 1, A, R, g->h2att_w, R, &a, 1, Pw, capw, 0, nullptr, nullptr, nullptr, acc));
-        }
+        if (phases & CAPMI_BWD_ATTENTION)
+            RC(dw_one(strm, A, R, g->h2att_w, R, s->d_att_h_all + oA, A, x_hatt_same + oR, R, Kc, acc, Pw, capw));
         return 0;
     };
     int dw_done_from = T;           // time steps [dw_done_from, T) already have their weight gradients (on the side stream)
@@ -586,8 +596,8 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
             if (hipStreamWaitEvent(side_st, side_ev[0], 0) != hipSuccess) return CAPMI_EINVAL;
             RC(gemm((void *)side_st, 1, 1, V1, R, g->logit_w, R, &b, 1, nullptr, 0, 0, nullptr));
             side_used = true;
-        } else
-        RC(gemm(stream, 1, 1, V1, R, g->logit_w, R, &b, 1, P, cap, 0, nullptr));
+        } else if (grouped) grp[n_grp++] = capmi_group_gemm{s->dlogits, a_hdrop, g->logit_w, V1, R, R, TN, V1, R, 0, 0};
+        else RC(gemm(stream, 1, 1, V1, R, g->logit_w, R, &b, 1, P, cap, 0, nullptr));
         RC(colsum(s->dlogits, TN, V1, g->logit_b, nullptr));
     }
 
@@ -705,6 +715,7 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         if (hipStreamWaitEvent(st, side_ev[1], 0) != hipSuccess) return CAPMI_EINVAL;
     }
     RC(dw_chunk(stream, 0, dw_done_from, dw_done_from < T ? 1 : 0, P, cap));
+    if (n_grp) RC(capmi_gemm_group_tn(grp, n_grp, P + CAPMI_WS_COUNTER_FLOATS, cap - CAPMI_WS_COUNTER_FLOATS, stream));
     // attention LSTM
     if (phases & CAPMI_BWD_ATT_LSTM) {
         RC(colsum(s->dg_att, TN, 4 * R, g->att_b_ih, g->att_b_hh));

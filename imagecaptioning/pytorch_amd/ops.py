@@ -189,6 +189,36 @@ class SlabArena:
         self.off += (floats + 63) // 64 * 64
 
 
+_group_cache = {}
+
+
+def gemm_group_tn(items, ws=None, cache_key=None):
+    """capmi_gemm_group_tn: items = [(dy [K,M], x [K,N], out [M,N] contiguous, accumulate)] -- out_i (+)= dy_i^T x_i for all i in
+    ONE persistent launch (+ one small reduction launch for the K-sliced tail).  Returns the per-item splits_used.
+    cache_key: any hashable; the ctypes table of an identical item list (same pointers, same shapes) is built once."""
+    dev = items[0][2].device
+    key = tuple((dy.data_ptr(), x.data_ptr(), out.data_ptr(), dy.shape[0], dy.shape[1], x.shape[1], bool(acc)) for dy, x, out, acc in items)
+    hit = _group_cache.get(cache_key) if cache_key is not None else None
+    if hit is not None and hit[0] == key:
+        arr = hit[1]
+    else:
+        arr = (_lib.GroupGemm * len(items))()
+        for g, (dy, x, out, acc) in zip(arr, items):
+            _chk(dy, x, out)
+            K, M = dy.shape
+            N = x.shape[1]
+            if x.shape[0] != K or tuple(out.shape) != (M, N):
+                raise _lib.CapmiError('gemm_group_tn: shapes %s^T %s -> %s' % (tuple(dy.shape), tuple(x.shape), tuple(out.shape)))
+            g.A, g.B, g.C, g.lda, g.ldb, g.ldc, g.K, g.M, g.N, g.accumulate = dy.data_ptr(), x.data_ptr(), out.data_ptr(), M, N, N, K, M, N, int(acc)
+        if cache_key is not None:
+            _group_cache[cache_key] = (key, arr)
+    if ws is None:
+        ws = default_workspace(dev)
+    slabs = ws.buf[Workspace.COUNTER_FLOATS:] if isinstance(ws, Workspace) else ws.buf
+    check(lib.capmi_gemm_group_tn(arr, len(items), slabs.data_ptr(), slabs.numel(), stream_ptr()), 'capmi_gemm_group_tn')
+    return [g.splits_used for g in arr]
+
+
 _pinned_arena = {'buf': None, 'off': 0}
 
 
@@ -259,6 +289,9 @@ class DeferredGrads:
             self.side, self.ev_pool, self.ev_used = self.state['side'], self.state['events'], 0
         # nothing runs beside the deferred GEMMs when there is no side stream: the planner may give them 256 x 128 tiles too
         self._policy_prev = lib.capmi_gemm_set_policy(1 if self.side is None else 0)
+        # r6: without a side stream the weight-gradient GEMMs are only RECORDED and go out at flush() as one grouped persistent launch
+        # (capmi_gemm_group_tn); CAPMI_DW_GROUP=0 keeps one launch + deferred reduction per GEMM
+        self.group = [] if (self.side is None and os.environ.get('CAPMI_DW_GROUP', '1') != '0') else None
 
     def _side_follows_main(self):
         """the side stream waits for everything enqueued on the current stream so far"""
@@ -278,6 +311,9 @@ class DeferredGrads:
         cf = Workspace.COUNTER_FLOATS
         if cf + 2 * M * N > SlabArena.CHUNK:            # a gradient this large needs no K split to fill the chip
             gemm([(dy, M, x, N, K, 1)], M, N, out, a_layout=1, b_layout=1)
+            return
+        if self.group is not None and final:
+            self.group.append((dy, x, out, False))
             return
         region = self.arena.take(min(cf + 16 * M * N, SlabArena.CHUNK))      # (the GEMM limits its K split to the region)
         on_side = self.side is not None and final
@@ -338,6 +374,9 @@ class DeferredGrads:
         if self.side is not None and self.ev_used:
             self._flush_side(force=True)
             torch.cuda.current_stream().wait_stream(self.side)
+        if self.group:
+            gemm_group_tn(self.group, cache_key=('deferred', str(self.dev)))
+            self.group = []
         if self.red:
             t, _ = self._table('red', self.red, '<QQQiiiiii')
             check(lib.capmi_splitk_reduce_batch(t.data_ptr(), len(self.red), stream_ptr()), 'capmi_splitk_reduce_batch')
@@ -355,6 +394,8 @@ class DeferredGrads:
             torch.cuda.current_stream().wait_stream(self.side)
         self.red, self.col, self.keep = [], [], []
         self.red_side, self.col_side = [], []
+        if self.group is not None:
+            self.group = []
         lib.capmi_gemm_set_policy(self._policy_prev)
 
 

@@ -103,6 +103,27 @@ int capmi_gemm_f32(capmi_gemm_desc *d, void *stream);
  * the previous setting; default 0. */
 int capmi_gemm_set_policy(int allow_wide_deferred);
 
+/* r6: n INDEPENDENT weight-gradient GEMMs in one launch,
+ *     C_i [M_i, N_i] (row pitch ldc) (+)= A_i^T B_i,   A_i [K_i, M_i] (pitch lda), B_i [K_i, N_i] (pitch ldb)
+ * -- the dW = dY^T X products that autograd's backward (train.py:193 `loss.backward()`; nn.Linear / nn.LSTMCell weight gradients
+ * behind AttModel.py:615-640, TransformerModel.py:84-160, AoAModel.py:100-186) produces one by one and that nothing reads before the
+ * optimizer.  All their output tiles form ONE persistent grid on the 256 x 128 bf16x3 kernel: the full rounds of the grid write whole-K
+ * tiles straight into C, the last partial round is cut into K slices ([256 x 128] pieces in `slabs`, <= 256 of them per launch)
+ * that a small second launch sums -- instead of n sub-wave grids with a K split, a slab round trip and a prologue / tail each.
+ * The item table travels in the kernel arguments (no device table, no upload: the call is capturable into a hipGraph); more than
+ * ~40 items go out as several launches, longest K first.  Items the fat kernel cannot take (M, N or K not a multiple of 4, unaligned
+ * operands / pitches) are issued through capmi_gemm_f32 behind the group.  Same numbers, bit for bit, as capmi_gemm_f32 on each
+ * item with the K split reported in splits_used (0: written whole-K).
+ * slabs / slab_floats: scratch for the K-slice pieces (>= 8.4 M floats serves any group; less only limits the tail's K split). */
+typedef struct capmi_group_gemm {
+    const float *A, *B;
+    float *C;
+    int32_t lda, ldb, ldc, K, M, N;
+    int32_t accumulate;          /* C += instead of C = */
+    int32_t splits_used;         /* out: K slices of this item's tail tiles (1 when every tile was written whole-K); -1: went through capmi_gemm_f32 */
+} capmi_group_gemm;
+int capmi_gemm_group_tn(capmi_group_gemm *items, int n, float *slabs, int64_t slab_floats, void *stream);
+
 /* "A planes" of an activation matrix X[M <= 64, K] (row pitch ld): K in chunks of 32, chunk = [3 planes][64 rows][32 bf16],
  * x = h + m + l split exactly into three truncated bf16 values, 16-byte pieces of a row XOR-swizzled by (row >> 2) & 3 -- the
  * LDS image the decode GEMM reads its MFMA fragments from.  The buffer (capmi_planes_bytes(K) bytes, 16-byte aligned) must
