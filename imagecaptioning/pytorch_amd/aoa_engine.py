@@ -73,6 +73,18 @@ def _dh_workspace(dev, tag='dh'):
 SLAB_CONSUMERS = os.environ.get('CAPMI_AOA_SLABS', '1') != '0'
 
 
+def _dw(dy, x, out, ldc=None, off=0, accumulate=False):
+    """out (+)= dy^T x, a weight gradient nothing reads before the optimizer: recorded for the grouped launch at the end of the
+    backward (ops.DeferredGrads, r6) or issued at once"""
+    d = Lin.deferred
+    if d is not None:
+        d.dw(dy, x, out, final=True, ldc=ldc, out_off=off, accumulate=accumulate)
+        return
+    K, M = dy.shape
+    N = x.shape[1]
+    ops.gemm([(dy, M, x, N, K, 1)], M, N, (out, off), ldc=N if ldc is None else ldc, a_layout=1, b_layout=1, accumulate=accumulate)
+
+
 class AoAGraph:
     def __init__(self, P, grads, h, drop_prob_lm, dropout_aoa, training, seed):
         self.P, self.g, self.h = P, grads, h
@@ -291,7 +303,7 @@ class AoAGraph:
         ops.logsoftmax_bwd(g_logp, sparse, self.seq_logp, self.live, dlogits, N, L, T, V1, raw=self.raw)
         TN = T * N
         d_outdrop = ops.matmul_nn(dlogits.view(TN, V1), P['logit.weight'])            # [TN,R]
-        ops.matmul_tn(dlogits.view(TN, V1), self.out_drop.view(TN, R), out=g['logit.weight'])
+        _dw(dlogits.view(TN, V1), self.out_drop.view(TN, R), g['logit.weight'])
         ops.colsum(dlogits.view(TN, V1), out=g['logit.bias'])
         d_outdrop = d_outdrop.view(T, N, R)
         W_ih, W_hh = P['core.att_lstm.weight_ih'], P['core.att_lstm.weight_hh']
@@ -370,14 +382,15 @@ class AoAGraph:
                 dh_slabs = ws2.slabs
         # ---- time-batched core gradients
         dg2 = dg_all.view(TN, 4 * R)
-        ops.gemm([(dg2, 4 * R, self.xt.view(TN, E), E, TN, 1)], 4 * R, E, g['core.att_lstm.weight_ih'], ldc=ld_ih, a_layout=1, b_layout=1)
+        _dw(dg2, self.xt.view(TN, E), g['core.att_lstm.weight_ih'], ldc=ld_ih)
         # columns E: of W_ih multiply (mean + ctx_in): ctx_in part time-batched, mean part through the per-image sum
         sum_dg = z(B, 4 * R)
         check(lib.capmi_group_rowsum(ptr(dg_all), T, N * 4 * R, B, n, 4 * R, ptr(sum_dg), st), 'group_rowsum')
         gW = g['core.att_lstm.weight_ih']
-        ops.gemm([(dg2, 4 * R, self.ctx_in.view(TN, R), R, TN, 1)], 4 * R, R, (gW, E), ldc=ld_ih, a_layout=1, b_layout=1)
-        ops.gemm([(sum_dg, 4 * R, self.mean, R, B, 1)], 4 * R, R, (gW, E), ldc=ld_ih, a_layout=1, b_layout=1, accumulate=True)
-        ops.matmul_tn(dg2, self.h_att[:T].reshape(TN, R), out=g['core.att_lstm.weight_hh'])
+        # (the small per-image product is written first, the time-batched one is added to it -- possibly at the end of the backward)
+        ops.gemm([(sum_dg, 4 * R, self.mean, R, B, 1)], 4 * R, R, (gW, E), ldc=ld_ih, a_layout=1, b_layout=1)
+        _dw(dg2, self.ctx_in.view(TN, R), gW, ldc=ld_ih, off=E, accumulate=True)
+        _dw(dg2, self.h_att[:T].reshape(TN, R), g['core.att_lstm.weight_hh'])
         ops.colsum(dg2, out=g['core.att_lstm.bias_ih'])
         g['core.att_lstm.bias_hh'].copy_(g['core.att_lstm.bias_ih'])
         # (r5: the W_ih column blocks are read in place -- [K = 4R][N] operands of pitch E + R -- instead of through
@@ -392,15 +405,15 @@ class AoAGraph:
         check(lib.capmi_embed_bwd(ptr(self.it_all), ptr(d_xt), ptr(self.xt), ptr(masks_xt), ptr(g['embed.0.weight']), TN, E, 1, st),
               'embed_bwd')
         # attention query path
-        ops.matmul_tn(dq_all.view(TN, R), self.qn.view(TN, R), out=g['core.attention.linears.0.weight'])
+        _dw(dq_all.view(TN, R), self.qn.view(TN, R), g['core.attention.linears.0.weight'])
         ops.colsum(dq_all.view(TN, R), out=g['core.attention.linears.0.bias'])
         ops.colsum(ln_g.view(TN, R), out=g['core.attention.norm.a_2'])
         ops.colsum(ln_dy.view(TN, R), out=g['core.attention.norm.b_2'])
         # att2ctx
         gWc = g['core.att2ctx.0.weight']
         dp2 = d_pre2_all.view(TN, 2 * R)
-        ops.gemm([(dp2, 2 * R, self.att_o.view(TN, R), R, TN, 1)], 2 * R, R, gWc, ldc=2 * R, a_layout=1, b_layout=1)
-        ops.gemm([(dp2, 2 * R, self.h_att[1:].reshape(TN, R), R, TN, 1)], 2 * R, R, (gWc, R), ldc=2 * R, a_layout=1, b_layout=1)
+        _dw(dp2, self.att_o.view(TN, R), gWc, ldc=2 * R)
+        _dw(dp2, self.h_att[1:].reshape(TN, R), gWc, ldc=2 * R, off=R)
         ops.colsum(dp2, out=g['core.att2ctx.0.bias'])
         # ---- prefill backward
         d_att = self.ctx2att.bwd(d_p_att)                                              # [B*K,R]
@@ -413,8 +426,8 @@ class AoAGraph:
             W = P[pre + '.self_attn.aoa_layer.0.weight']
             gW2 = g[pre + '.self_attn.aoa_layer.0.weight']
             BK = B * K
-            ops.gemm([(d_pre, 2 * R, lay['od'], R, BK, 1)], 2 * R, R, gW2, ldc=2 * R, a_layout=1, b_layout=1)
-            ops.gemm([(d_pre, 2 * R, lay['yd'], R, BK, 1)], 2 * R, R, (gW2, R), ldc=2 * R, a_layout=1, b_layout=1)
+            _dw(d_pre, lay['od'], gW2, ldc=2 * R)
+            _dw(d_pre, lay['yd'], gW2, ldc=2 * R, off=R)
             ops.colsum(d_pre, out=g[pre + '.self_attn.aoa_layer.0.bias'])
             d_o, d_y = dcat_halves(d_pre, W, BK, R, lay['m_o'], lay['m_y'])            # [d_od | d_yd] of [BK,2R] = d_pre W
             if lay['lqkv'] is not None:

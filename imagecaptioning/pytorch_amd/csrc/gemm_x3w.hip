@@ -430,6 +430,39 @@ __device__ __forceinline__ void wg_staging(GTabK t, int tid, unsigned short *sme
     }
 }
 
+// one wave's 64 x 64 block of a finished unit -> memory (C/D layout of the 32x32 MFMA: column = lane & 31, rows (x & 3) + 8 (x >> 2) +
+// 4 (lane >> 5)); out points at the tile's origin
+template <bool ADD, bool EDGE>
+__device__ __forceinline__ void g_store(const f32x16 (&acc)[2][2], float *out, int ldo, int vr, int vc, int wm0, int wn0, int l31, int half) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wn0 + 32 * j + l31;
+            const int ccol = EDGE ? min(col, vc - 1) : col;
+            float *o = out + (size_t)(wm0 + 32 * i + 4 * half) * ldo + ccol;
+            const int r0 = wm0 + 32 * i + 4 * half;
+#pragma unroll
+            for (int xg = 0; xg < 16; xg += 4) {                 // (four rows at a time: 16 more live registers spilled)
+                float old[4];
+                if (ADD) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int dr = u + 2 * xg;                          // = ((xg + u) & 3) + 8 * ((xg + u) >> 2)
+                        const int cdr = EDGE ? min(r0 + dr, vr - 1) - r0 : dr;          // (clamped: always a valid address)
+                        old[u] = o[(ptrdiff_t)cdr * ldo];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int dr = u + 2 * xg;
+                    const float v = ADD ? acc[i][j][xg + u] + old[u] : acc[i][j][xg + u];
+                    if (!EDGE || (col < vc && r0 + dr < vr)) o[(size_t)dr * ldo] = v;
+                }
+            }
+        }
+}
+
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(1024) void gemm_x3w_group_kernel(const GTab table) {
     GTabK t = (GTabK)__builtin_amdgcn_kernarg_segment_ptr();              // = &table, where the dispatch put it
@@ -506,26 +539,21 @@ __global__ __launch_bounds__(1024) void gemm_x3w_group_kernel(const GTab table) 
         const int ldo = piece ? WBN : it->ldc;
         const int vr = it->M - un.m0, vc = it->N - un.n0;                 // valid rows / columns of the tile (may exceed 256 / 128)
         const bool add = !piece && it->accumulate;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = wn0 + 32 * j + l31;
-                if (col >= vc) continue;
-#pragma unroll
-                for (int x = 0; x < 16; ++x) {
-                    const int row = wm0 + 32 * i + (x & 3) + 8 * (x >> 2) + 4 * half;
-                    if (row >= vr) continue;
-                    float *o = out + (size_t)row * ldo + col;
-                    *o = add ? *o + acc[i][j][x] : acc[i][j][x];
-                }
-            }
+        // four straight-line variants behind workgroup-uniform branches (a per-element `add ? load : -` and per-element bounds tests
+        // compiled to a branch and an s_waitcnt vmcnt(0) in front of every one of the 64 stores)
+        const bool edge = vr < WBM || vc < WBN;
+        if (add) {
+            if (edge) g_store<true, true>(acc, out, ldo, vr, vc, wm0, wn0, l31, half);
+            else g_store<true, false>(acc, out, ldo, vr, vc, wm0, wn0, l31, half);
+        } else {
+            if (edge) g_store<false, true>(acc, out, ldo, vr, vc, wm0, wn0, l31, half);
+            else g_store<false, false>(acc, out, ldo, vr, vc, wm0, wn0, l31, half);
+        }
     }
 }
 
-// blockIdx.x = one split tile of the launch: C tile (+)= sum of its `splits` pieces, in the order of splitk_reduce_batch_kernel
-// (four pieces per pass, (p0 + p1) + (p2 + p3) added to the running sum) so that a grouped GEMM and the same GEMM launched alone
-// with the same K split agree bit for bit.
+// blockIdx.x = one split tile of the launch: C tile (+)= sum of its `splits` pieces in slice order -- the order of splitk_reduce_kernel
+// (gemm_f32.hip), so that a grouped GEMM and the same GEMM launched alone through capmi_gemm_f32 with the same K split agree bit for bit.
 __global__ __launch_bounds__(256) void x3w_group_reduce_kernel(const GTab table) {
     GTabK t = (GTabK)__builtin_amdgcn_kernarg_segment_ptr();
     int e = 0;
@@ -540,13 +568,14 @@ __global__ __launch_bounds__(256) void x3w_group_reduce_kernel(const GTab table)
         const int row = q / (WBN / 4), c4 = (q % (WBN / 4)) * 4;
         if (row >= vr || c4 >= vc) continue;                 // (N % 4 == 0: a quad of columns is entirely inside or outside)
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int s0 = 0; s0 < it->splits; s0 += 4) {
-            f32x4 tv[4];
+        for (int s0 = 0; s0 < it->splits; s0 += 8) {         // 8 independent loads in flight, summed in slice order
+            f32x4 tv[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 8; ++u)
                 tv[u] = (s0 + u < it->splits) ? *reinterpret_cast<const f32x4 *>(p + (size_t)(s0 + u) * (WBM * WBN) + (size_t)row * WBN + c4)
-                                             : f32x4{0.f, 0.f, 0.f, 0.f};
-            v += (tv[0] + tv[1]) + (tv[2] + tv[3]);
+                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += tv[u];
         }
         f32x4 *o = reinterpret_cast<f32x4 *>(it->C + (size_t)(m0 + row) * it->ldc + n0 + c4);
         if (it->accumulate) v += *o;

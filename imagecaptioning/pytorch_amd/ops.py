@@ -193,23 +193,29 @@ _group_cache = {}
 
 
 def gemm_group_tn(items, ws=None, cache_key=None):
-    """capmi_gemm_group_tn: items = [(dy [K,M], x [K,N], out [M,N] contiguous, accumulate)] -- out_i (+)= dy_i^T x_i for all i in
-    ONE persistent launch (+ one small reduction launch for the K-sliced tail).  Returns the per-item splits_used.
+    """capmi_gemm_group_tn: items = [(dy [K,M], x [K,N], out, accumulate[, ldc, out_off])] -- out_i (+)= dy_i^T x_i for all i in ONE
+    persistent launch (+ one small reduction launch for the K-sliced tail).  out: [M,N] contiguous, or -- with ldc / out_off -- the
+    tensor whose elements out_off + m * ldc + n receive the product (a column block of a wider gradient).
+    Returns the per-item splits_used.
     cache_key: any hashable; the ctypes table of an identical item list (same pointers, same shapes) is built once."""
     dev = items[0][2].device
-    key = tuple((dy.data_ptr(), x.data_ptr(), out.data_ptr(), dy.shape[0], dy.shape[1], x.shape[1], bool(acc)) for dy, x, out, acc in items)
+    key = tuple((it[0].data_ptr(), it[1].data_ptr(), it[2].data_ptr(), it[0].shape[0], it[0].shape[1], it[1].shape[1], bool(it[3])) + tuple(it[4:])
+                for it in items)
     hit = _group_cache.get(cache_key) if cache_key is not None else None
     if hit is not None and hit[0] == key:
         arr = hit[1]
     else:
         arr = (_lib.GroupGemm * len(items))()
-        for g, (dy, x, out, acc) in zip(arr, items):
+        for g, it in zip(arr, items):
+            dy, x, out, acc = it[:4]
             _chk(dy, x, out)
             K, M = dy.shape
             N = x.shape[1]
-            if x.shape[0] != K or tuple(out.shape) != (M, N):
-                raise _lib.CapmiError('gemm_group_tn: shapes %s^T %s -> %s' % (tuple(dy.shape), tuple(x.shape), tuple(out.shape)))
-            g.A, g.B, g.C, g.lda, g.ldb, g.ldc, g.K, g.M, g.N, g.accumulate = dy.data_ptr(), x.data_ptr(), out.data_ptr(), M, N, N, K, M, N, int(acc)
+            ldc = it[4] if len(it) > 4 and it[4] is not None else N
+            off = it[5] if len(it) > 5 else 0
+            if x.shape[0] != K or ldc < N or off + (M - 1) * ldc + N > out.numel():
+                raise _lib.CapmiError('gemm_group_tn: shapes %s^T %s -> %s (ldc %d, offset %d)' % (tuple(dy.shape), tuple(x.shape), tuple(out.shape), ldc, off))
+            g.A, g.B, g.C, g.lda, g.ldb, g.ldc, g.K, g.M, g.N, g.accumulate = dy.data_ptr(), x.data_ptr(), out.data_ptr() + 4 * off, M, N, ldc, K, M, N, int(bool(acc))
         if cache_key is not None:
             _group_cache[cache_key] = (key, arr)
     if ws is None:
@@ -302,18 +308,21 @@ class DeferredGrads:
         ev.record()
         self.side.wait_event(ev)
 
-    def dw(self, dy, x, out, final=True):
-        """out[M,N] = dy[K,M]^T x[K,N] (contiguous out), reduction deferred.  final: nobody writes `dy` after this call (a running
-        gradient accumulator that the caller keeps adding to must be read in stream order: no side stream)."""
+    def dw(self, dy, x, out, final=True, ldc=None, out_off=0, accumulate=False):
+        """out[M,N] (+)= dy[K,M]^T x[K,N], reduction deferred.  out: contiguous [M,N], or with ldc / out_off a column block of a wider
+        gradient (elements out_off + m * ldc + n).  final: nobody writes `dy` after this call (a running gradient accumulator that the
+        caller keeps adding to must be read in stream order: no side stream, no grouping).  accumulate: the caller has ALREADY
+        written the addend into `out` (in stream order)."""
         _chk(dy, x, out)
         K, M = dy.shape
         N = x.shape[1]
+        ldc = N if ldc is None else ldc
         cf = Workspace.COUNTER_FLOATS
-        if cf + 2 * M * N > SlabArena.CHUNK:            # a gradient this large needs no K split to fill the chip
-            gemm([(dy, M, x, N, K, 1)], M, N, out, a_layout=1, b_layout=1)
-            return
         if self.group is not None and final:
-            self.group.append((dy, x, out, False))
+            self.group.append((dy, x, out, accumulate, ldc, out_off))
+            return
+        if cf + 2 * M * N > SlabArena.CHUNK:            # a gradient this large needs no K split to fill the chip
+            gemm([(dy, M, x, N, K, 1)], M, N, (out, out_off), ldc=ldc, a_layout=1, b_layout=1, accumulate=accumulate)
             return
         region = self.arena.take(min(cf + 16 * M * N, SlabArena.CHUNK))      # (the GEMM limits its K split to the region)
         on_side = self.side is not None and final
@@ -324,7 +333,8 @@ class DeferredGrads:
         splits = gemm([(dy, M, x, N, K, 1)], M, N, out, a_layout=1, b_layout=1, ws=_WsView(region), defer_reduce=True,
                       stream=self.side.cuda_stream if on_side else None)
         self.arena.commit(cf + splits * M * N)
-        (self.red_side if on_side else self.red).append((region.data_ptr() + 4 * cf, out.data_ptr(), 0, splits, M, N, N, 0, 0))
+        (self.red_side if on_side else self.red).append((region.data_ptr() + 4 * cf, out.data_ptr() + 4 * out_off, 0, splits, M, N, ldc,
+                                                         int(bool(accumulate)), 0))
         if on_side:
             self._flush_side()
 

@@ -36,8 +36,9 @@ SETS = {
     'scst': [(4000, 1000, 1000)] * 6 + [(512, 1000, 1000), (9488, 1000, 1000)],
     # one Transformer decoder layer at bs64 x 5, T = 21: eight d x d projections + the two FFN matrices
     'txe_layer': [(512, 512, 6720)] * 8 + [(2048, 512, 6720), (512, 2048, 6720)],
-    # fewer tiles than CUs: everything is tail (K-sliced)
-    'small': [(512, 512, 2304), (256, 128, 640)],
+    # fewer tiles than CUs: everything is tail (K-sliced).  (M * N >= 256 K: the single launches the bitwise test compares with take
+    # the bf16x3 kernel too -- smaller products go to the exact-fp32 tile kernel there)
+    'small': [(512, 512, 2304), (1024, 256, 640)],
     # ragged edges, mixed K, an item the fat kernel cannot take (N % 4 != 0 -> capmi_gemm_f32 behind the group)
     'ragged': [(260, 132, 100), (1028, 516, 1000), (300, 200, 36), (128, 130, 64), (4, 4, 4)],
     # more items than one table holds (two launches, longest K first)
