@@ -772,6 +772,8 @@ extern "C" int capmi_gemm_group_tn(capmi_group_gemm *items, int n, float *slabs,
             seen += ot;
         }
         t.n = ne; t.units = unit; t.rtiles = rt;
+        static const int env_abl = capmi::ablate_env("CAPMI_GROUP_ABLATE");      // (variants builds only)
+        t.reserved = env_abl;
         int rc = launch_x3w_group(t, st, CAPMI_PROF_GEMM_FAT, bytes, flops);
         if (rc) return rc;
         pos += cnt;

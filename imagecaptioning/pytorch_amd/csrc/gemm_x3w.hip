@@ -231,6 +231,54 @@ __device__ __forceinline__ void w_staging(const KArgs &a, int gm, int gn, int un
     }
 }
 
+// One K tile of an MFMA wave: two halves (ks) of 12 ds_read_b128 + 24 MFMAs.  six of the nine cross terms, small ones first (planes:
+// 0 = h, 1 = m, 2 = l) -- the order of gemm_x3.hip, so that a K slice sums to the same bits in every fat kernel.
+// r6: the workgroup barrier of the K tile sits BETWEEN the second half's reads and its MFMAs (as in gemm_x3.hip's pipelined loop), not
+// behind them.  Two MFMA waves share a SIMD and alternate -- one multiplies while the other waits for its fragments -- so they are
+// half a phase apart; a barrier at the END of the tile made the leading wave wait a whole MFMA phase (768 cycles of an idle matrix
+// pipe per K tile and SIMD, ~20 % of the tile: CAPMI_GROUP_ABLATE staging-off run 2.08 us per tile against 1.28 of MFMA work).  At the
+// early barrier every wave still holds 24 MFMAs to issue, so the pipe has work queued while the waves wait for each other; the stage
+// is released to the staging waves 24 MFMAs sooner too.  `late` (research switch) restores the barrier at the end.
+__device__ __forceinline__ void w_ktile(f32x16 (&acc)[2][2], const unsigned short *As, const unsigned short *Bs, const int (&offA)[2][2],
+                                        const int (&offB)[2][2], bool late, bool no_mfma) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 av[2][3], bv[2][3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                av[q][pl] = *reinterpret_cast<const bf16x8 *>(As + pl * WPL_A + offA[q][ks]);
+                bv[q][pl] = *reinterpret_cast<const bf16x8 *>(Bs + pl * WPL_B + offB[q][ks]);
+            }
+        if (ks == 1 && !late) __syncthreads();             // every read of this stage has landed (the barrier's lgkmcnt(0)): stage released,
+                                                           // next stage ready
+        if (no_mfma) continue;                             // (profiling ablation)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][2], bv[j][0], acc[q][j], 0, 0, 0);
+                acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][2], acc[q][j], 0, 0, 0);
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][1], acc[q][j], 0, 0, 0);
+                acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][0], acc[q][j], 0, 0, 0);
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][1], acc[q][j], 0, 0, 0);
+                acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][0], acc[q][j], 0, 0, 0);
+            }
+    }
+    if (late) __syncthreads();                             // stage g&1 released, stage (g+1)&1 ready
+}
+
 // Waves 0-7 are MFMA waves (64 x 64 each: 4 along M x 2 along N), waves 8.. staging waves.  Waves are dealt to the SIMDs round
 // robin, so every SIMD holds two MFMA waves and NSW / 4 staging waves.
 template <bool AKC, bool BKC, int NSW>
@@ -273,40 +321,7 @@ __global__ __launch_bounds__(512 + 64 * NSW) void gemm_x3w_kernel(const KArgs a,
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int i = 0; i < un.nt; ++i, ++g) {
             const unsigned short *As = smem + (g & 1) * WSTAGE, *Bs = As + 3 * WPL_A;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 av[2][3], bv[2][3];
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        av[q][pl] = *reinterpret_cast<const bf16x8 *>(As + pl * WPL_A + offA[q][ks]);
-                        bv[q][pl] = *reinterpret_cast<const bf16x8 *>(Bs + pl * WPL_B + offB[q][ks]);
-                    }
-                // six of the nine cross terms, small ones first (planes: 0 = h, 1 = m, 2 = l) -- the order of gemm_x3.hip
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][2], bv[j][0], acc[q][j], 0, 0, 0);
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][2], acc[q][j], 0, 0, 0);
-                    }
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][1], acc[q][j], 0, 0, 0);
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][0], acc[q][j], 0, 0, 0);
-                    }
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][1], acc[q][j], 0, 0, 0);
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][0], acc[q][j], 0, 0, 0);
-                    }
-            }
-            __syncthreads();                               // stage g&1 released, stage (g+1)&1 ready
+            w_ktile(acc, As, Bs, offA, offB, (prio & 4) ? true : (prio & 8) ? wid < 4 : false, false);
         }
         if (a.transposed) x3_epilogue_t<2>(a, un, acc, wm0, wn0, l31, half);
         else x3_epilogue<2>(a, un, acc, wm0, wn0, l31, half);
@@ -409,6 +424,7 @@ __device__ __forceinline__ void wg_staging(GTabK t, int tid, unsigned short *sme
     };
     auto store = [&](const float (&xa0)[16], const float (&xa1)[16], const float (&xb)[16], const WEdge &ed, int g) {
         unsigned short *st = smem + (g & 1) * WSTAGE;
+        if (t->reserved & 4) return;                      // (ablation: no split, no LDS stores)
         if (ed.edge) {
             if (DOA) w_r2s<AKC, true, WPL_A>(xa0, st, tid, ed.va0, ed.vk);
             if (DOA) w_r2s<AKC, true, WPL_A>(xa1, st + 128 * 32, tid, ed.va1, ed.vk);
@@ -484,6 +500,7 @@ __global__ __launch_bounds__(1024) void gemm_x3w_group_kernel(const GTab table) 
             offB[q][ks] = wswz(wn0 + 32 * q + l31, 16 * ks + 8 * half);
         }
     __syncthreads();                                       // stage 0 ready
+    const int abl = t->reserved;                            // (CAPMI_GROUP_ABLATE, variants builds: profiling ablations; 0 otherwise)
     int g = 0, ent = 0;
     for (int r = 0; blockIdx.x + r * (int)gridDim.x < t->units; ++r) {
         const GUnit un = g_unit_of(t, g_unit_index(r, t->units), ent);
@@ -496,40 +513,7 @@ __global__ __launch_bounds__(1024) void gemm_x3w_group_kernel(const GTab table) 
                 for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
         for (int i = 0; i < un.nt; ++i, ++g) {
             const unsigned short *As = smem + (g & 1) * WSTAGE, *Bs = As + 3 * WPL_A;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 av[2][3], bv[2][3];
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        av[q][pl] = *reinterpret_cast<const bf16x8 *>(As + pl * WPL_A + offA[q][ks]);
-                        bv[q][pl] = *reinterpret_cast<const bf16x8 *>(Bs + pl * WPL_B + offB[q][ks]);
-                    }
-                // the six cross terms in the order of gemm_x3.hip / gemm_x3w_kernel: a K slice sums to the same bits in all three
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][2], bv[j][0], acc[q][j], 0, 0, 0);
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][2], acc[q][j], 0, 0, 0);
-                    }
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][1], acc[q][j], 0, 0, 0);
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][1], bv[j][0], acc[q][j], 0, 0, 0);
-                    }
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][1], acc[q][j], 0, 0, 0);
-                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[q][0], bv[j][0], acc[q][j], 0, 0, 0);
-                    }
-            }
-            __syncthreads();                               // stage g&1 released, stage (g+1)&1 ready
+            w_ktile(acc, As, Bs, offA, offB, (abl & 8) ? true : (abl & 16) ? wid < 4 : false, (abl & 2) != 0);
         }
         // ---- epilogue: whole-K units write (or add to) C; K slices leave their [256 x 128] piece in the entry's slab
         GItemK it = &t->it[un.e];
@@ -542,6 +526,7 @@ __global__ __launch_bounds__(1024) void gemm_x3w_group_kernel(const GTab table) 
         // four straight-line variants behind workgroup-uniform branches (a per-element `add ? load : -` and per-element bounds tests
         // compiled to a branch and an s_waitcnt vmcnt(0) in front of every one of the 64 stores)
         const bool edge = vr < WBM || vc < WBN;
+        if (abl & 1) continue;                            // (ablation: the K loop without the epilogue)
         if (add) {
             if (edge) g_store<true, true>(acc, out, ldo, vr, vc, wm0, wn0, l31, half);
             else g_store<true, false>(acc, out, ldo, vr, vc, wm0, wn0, l31, half);
