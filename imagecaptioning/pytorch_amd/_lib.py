@@ -83,7 +83,7 @@ class ReduceItem(C.Structure):
 
 class GroupGemm(C.Structure):
     _fields_ = [('A', c_f), ('B', c_f), ('C', c_f), ('lda', C.c_int32), ('ldb', C.c_int32), ('ldc', C.c_int32), ('K', C.c_int32),
-                ('M', C.c_int32), ('N', C.c_int32), ('accumulate', C.c_int32), ('splits_used', C.c_int32)]
+                ('M', C.c_int32), ('N', C.c_int32), ('accumulate', C.c_int32), ('splits_used', C.c_int32), ('colsum', c_f)]
 
 
 class ColsumItem(C.Structure):
@@ -182,6 +182,7 @@ SIGNATURES = {
     'capmi_splitk_reduce_batch': [_P, _I, _P],
     'capmi_group_rowsum': [_P, _I, _I64, _I, _I, _I, _P, _P],
     'capmi_relu_mask_bwd': [_P, _P, _P, _P, _I64, _P],
+    'capmi_relu_scale_bwd': [_P, _P, _F, _P, _I64, _P],
     'capmi_adam_step': [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _I, _P],
     'capmi_upload_async': [_P, _P, _I64, _P],
     'capmi_step_advance': [_P, _F, _F, _P],
@@ -207,6 +208,8 @@ SIGNATURES = {
     'capmi_select_logp': [_P, _I, _I, _I, _I, _I, _F, _P, _U64, _P, _I, _P, _P, _P, _P, _I, _P, _P],
     'capmi_layernorm_fwd': [_P] * 6 + [_I, _I, _F, _P],
     'capmi_layernorm_bwd': [_P] * 6 + [_I, _P, _I, _I, _F, _P],
+    'capmi_layernorm_bwd_parts_rows': [_I],
+    'capmi_layernorm_bwd_parts': [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _F, _P],
     'capmi_mha_fwd': [_P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'capmi_mha_bwd': [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'capmi_mha_fwd_s': [_P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -92,6 +92,9 @@ struct GItem {
     const float *A, *B;
     float *C;
     float *slab;
+    float *cs;         // optional: cs[m] = sum_k A[k][m] (the bias gradient beside the weight gradient), taken by the staging waves of the
+                       // entry's first column tiles from the operand they stage anyway; K-sliced entries leave [256]-float pieces
+                       // behind their tile pieces (slab + ntiles * splits * 32768 + (tile_local * splits + z) * 256)
     int lda, ldb, ldc, K, M, N;
     int kt;            // ceil(K / BK)
     int gn;            // column tiles of the GEMM
@@ -101,7 +104,7 @@ struct GItem {
     int rtile0;        // first piece-set of this entry in the reduction launch's list (splits > 1 only)
     int accumulate;    // C += instead of C =
 };
-constexpr int GROUP_MAX = 44;      // entries per launch: the table travels BY VALUE in the kernel arguments (44 x 88 B + 16 < 4 KB)
+constexpr int GROUP_MAX = 42;      // entries per launch: the table travels BY VALUE in the kernel arguments (42 x 96 B + 16 < 4 KB)
 struct GTab {
     GItem it[GROUP_MAX];
     int n, units, rtiles, reserved;

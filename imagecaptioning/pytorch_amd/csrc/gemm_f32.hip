@@ -709,7 +709,7 @@ extern "C" int capmi_gemm_group_tn(capmi_group_gemm *items, int n, float *slabs,
         capmi_group_gemm &g = items[i];
         if (!g.A || !g.B || !g.C || g.K <= 0 || g.M <= 0 || g.N <= 0) return CAPMI_EINVAL;
         const bool ok = env_group && BK == 32 && g.M % 4 == 0 && g.N % 4 == 0 && g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
-                        g.ldc % 4 == 0 && aligned16(g.A) && aligned16(g.B) && aligned16(g.C) &&
+                        g.ldc % 4 == 0 && aligned16(g.A) && aligned16(g.B) && aligned16(g.C) && aligned16(g.colsum) &&
                         (uint64_t)g.lda * 16 * 4 + (uint64_t)g.M * 4 < (1ull << 32) && (uint64_t)g.ldb * 16 * 4 + (uint64_t)g.N * 4 < (1ull << 32);
         if (ok) order[n_ok++] = i;
         else rest[n_rest++] = i;
@@ -747,7 +747,7 @@ extern "C" int capmi_gemm_group_tn(capmi_group_gemm *items, int n, float *slabs,
                 const int t0 = part ? whole : 0, nt = part ? ot - whole : whole;
                 if (nt <= 0) continue;
                 GItem &e = t.it[ne++];
-                e.A = g.A; e.B = g.B; e.C = g.C; e.slab = nullptr;
+                e.A = g.A; e.B = g.B; e.C = g.C; e.slab = nullptr; e.cs = g.colsum;
                 e.lda = g.lda; e.ldb = g.ldb; e.ldc = g.ldc; e.K = g.K; e.M = g.M; e.N = g.N;
                 e.kt = kt; e.gn = gn; e.tile0 = t0; e.ntiles = nt; e.accumulate = g.accumulate ? 1 : 0;
                 int sp = 1;
@@ -755,7 +755,7 @@ extern "C" int capmi_gemm_group_tn(capmi_group_gemm *items, int n, float *slabs,
                     sp = (int)(256 / R);                 // R tiles x sp slices ~ one round of the grid
                     if (sp > kt / 4) sp = kt / 4;        // >= 4 K tiles per slice
                     if (sp > 32) sp = 32;
-                    while (sp > 1 && (!slabs || slab_off + (int64_t)nt * sp * TILE > slab_floats)) --sp;
+                    while (sp > 1 && (!slabs || slab_off + (int64_t)nt * sp * (TILE + 256) > slab_floats)) --sp;
                     if (sp < 1) sp = 1;
                 }
                 e.splits = sp;
@@ -763,7 +763,7 @@ extern "C" int capmi_gemm_group_tn(capmi_group_gemm *items, int n, float *slabs,
                 unit += nt * sp;
                 if (sp > 1) {
                     e.slab = slabs + slab_off;
-                    slab_off += (int64_t)nt * sp * TILE;
+                    slab_off += (int64_t)nt * sp * (TILE + 256);      // tile pieces, then the [256]-float column-sum pieces
                     e.rtile0 = rt;
                     rt += nt;
                     g.splits_used = sp;
@@ -787,6 +787,10 @@ extern "C" int capmi_gemm_group_tn(capmi_group_gemm *items, int n, float *slabs,
         // (no K split here: `slabs` holds pieces of the group, not the zeroed ticket words a capmi_gemm_f32 workspace starts with)
         int rc = capmi_gemm_f32(&d, stream);
         if (rc) return rc;
+        if (g.colsum) {
+            const capmi_colsum_item ci{g.A, g.colsum, nullptr, g.K, g.M, g.lda, 0};
+            if ((rc = capmi_colsum_batch_args(&ci, 1, stream)) != 0) return rc;
+        }
         g.splits_used = -1;
     }
     return 0;

@@ -373,10 +373,18 @@ __device__ __forceinline__ GUnit g_unit_of(GTabK t, int u, int &e) {
     return r;
 }
 
+// uniform facts of one staged K tile of a GROUPED launch: WEdge + where the tile's column sums go
+struct GEdge {
+    WEdge w;
+    float *cs;                // null: no column sums from this tile; else the destination of the unit's 256 sums (tile origin)
+    int cs_cols;              // valid columns from the tile origin
+    bool last;                // last K tile of its unit: the sums are complete
+};
+
 template <bool AKC, bool BKC, bool DOA, bool DOB>
 __device__ __forceinline__ void wg_staging(GTabK t, int tid, unsigned short *smem) {
     float ra[16], rc[16], rb[16];
-    WEdge e{};
+    GEdge e{};
     WStager<AKC> sa0, sa1;
     WStager<BKC> sb;
     const int G = gridDim.x;
@@ -388,7 +396,8 @@ __device__ __forceinline__ void wg_staging(GTabK t, int tid, unsigned short *sme
             ++rounds;
         }
     }
-    int f_ent = 0, f_round = 0, f_left = 0, f_k0 = 0;
+    int f_ent = 0, f_round = 0, f_left = 0, f_k0 = 0, f_cols = 0;
+    float *f_cs = nullptr;
     auto open_unit = [&]() {
         const GUnit un = g_unit_of(t, g_unit_index(f_round, t->units), f_ent);
         GItemK it = &t->it[un.e];
@@ -400,6 +409,13 @@ __device__ __forceinline__ void wg_staging(GTabK t, int tid, unsigned short *sme
         sb.set_tile(un.n0, it->N, tid);
         f_k0 = un.t_begin * BK;
         f_left = un.nt;
+        // column sums of A: by the units of the FIRST column tile only (every column tile stages the same A panel)
+        f_cs = nullptr;
+        if (DOA && !AKC && it->cs && un.n0 == 0) {
+            f_cs = it->splits > 1 ? it->slab + (size_t)it->ntiles * it->splits * (size_t)(WBM * WBN) + ((size_t)un.tl * it->splits + un.z) * WBM
+                                  : it->cs + un.m0;
+            f_cols = it->M - un.m0;
+        }
     };
     if (rounds > 0) open_unit();
     else {                                                 // (never fetched for real: steps == 0)
@@ -407,13 +423,14 @@ __device__ __forceinline__ void wg_staging(GTabK t, int tid, unsigned short *sme
         sa0.init(it->A, it->lda, it->K); sa1.init(it->A, it->lda, it->K); sb.init(it->B, it->ldb, it->K);
         sa0.set_tile(0, it->M, tid); sa1.set_tile(0, it->M, tid); sb.set_tile(0, it->N, tid);
     }
-    auto fetch = [&](float (&xa0)[16], float (&xa1)[16], float (&xb)[16], WEdge &ed) {
+    auto fetch = [&](float (&xa0)[16], float (&xa1)[16], float (&xb)[16], GEdge &ed) {
         if (DOA) sa0.fetch(xa0, f_k0);
         if (DOA) sa1.fetch(xa1, f_k0);
         if (DOB) sb.fetch(xb, f_k0);
-        ed.va0 = sa0.valid_rows; ed.va1 = sa1.valid_rows; ed.vb = sb.valid_rows;
-        ed.vk = min(sa0.K - f_k0, BK);
-        ed.edge = (DOA && (ed.va0 < 128 || ed.va1 < 128)) || (DOB && ed.vb < 128) || ed.vk < BK;
+        ed.w.va0 = sa0.valid_rows; ed.w.va1 = sa1.valid_rows; ed.w.vb = sb.valid_rows;
+        ed.w.vk = min(sa0.K - f_k0, BK);
+        ed.w.edge = (DOA && (ed.w.va0 < 128 || ed.w.va1 < 128)) || (DOB && ed.w.vb < 128) || ed.w.vk < BK;
+        ed.cs = f_cs; ed.cs_cols = f_cols; ed.last = f_left == 1;
         if (f_left > 0) {                              // workgroup-uniform
             if (--f_left == 0) {
                 if (++f_round < rounds) open_unit();
@@ -422,13 +439,42 @@ __device__ __forceinline__ void wg_staging(GTabK t, int tid, unsigned short *sme
             }
         }
     };
-    auto store = [&](const float (&xa0)[16], const float (&xa1)[16], const float (&xb)[16], const WEdge &ed, int g) {
+    // running column sums of this thread's 2 x 4 columns (k-major A: thread (kg, mq) holds k = 4kg..4kg+3 of columns 4mq..4mq+3 of each
+    // 128-column block, r[4 i + j] = A[k0 + 4kg + j][4mq + i]); summed over the unit's K tiles in order, then over kg by lane shuffles
+    float cs0[4] = {0.f, 0.f, 0.f, 0.f}, cs1[4] = {0.f, 0.f, 0.f, 0.f};
+    auto colsum_step = [&](const float (&xa0)[16], const float (&xa1)[16], const GEdge &ed) {
+        const int lane = tid & 63;
+        const float fac = (4 * (lane >> 3) < ed.w.vk) ? 1.f : 0.f;           // a thread's quad of k is entirely inside or outside K
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cs0[i] += ((xa0[4 * i] + xa0[4 * i + 1]) + (xa0[4 * i + 2] + xa0[4 * i + 3])) * fac;
+            cs1[i] += ((xa1[4 * i] + xa1[4 * i + 1]) + (xa1[4 * i + 2] + xa1[4 * i + 3])) * fac;
+        }
+        if (!ed.last) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int sh = 8; sh < 64; sh <<= 1) {
+                cs0[i] += __shfl_xor(cs0[i], sh);
+                cs1[i] += __shfl_xor(cs1[i], sh);
+            }
+        }
+        if (lane < 8) {
+            const int c = 4 * ((tid >> 6) * 8 + lane);                        // first of this thread's four columns inside a block
+            if (c < ed.cs_cols) *reinterpret_cast<f32x4 *>(ed.cs + c) = f32x4{cs0[0], cs0[1], cs0[2], cs0[3]};       // M % 4 == 0
+            if (128 + c < ed.cs_cols) *reinterpret_cast<f32x4 *>(ed.cs + 128 + c) = f32x4{cs1[0], cs1[1], cs1[2], cs1[3]};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cs0[i] = cs1[i] = 0.f;
+    };
+    auto store = [&](const float (&xa0)[16], const float (&xa1)[16], const float (&xb)[16], const GEdge &ed, int g) {
         unsigned short *st = smem + (g & 1) * WSTAGE;
+        if (DOA && !AKC && ed.cs) colsum_step(xa0, xa1, ed);
         if (t->reserved & 4) return;                      // (ablation: no split, no LDS stores)
-        if (ed.edge) {
-            if (DOA) w_r2s<AKC, true, WPL_A>(xa0, st, tid, ed.va0, ed.vk);
-            if (DOA) w_r2s<AKC, true, WPL_A>(xa1, st + 128 * 32, tid, ed.va1, ed.vk);
-            if (DOB) w_r2s<BKC, true, WPL_B>(xb, st + 3 * WPL_A, tid, ed.vb, ed.vk);
+        if (ed.w.edge) {
+            if (DOA) w_r2s<AKC, true, WPL_A>(xa0, st, tid, ed.w.va0, ed.w.vk);
+            if (DOA) w_r2s<AKC, true, WPL_A>(xa1, st + 128 * 32, tid, ed.w.va1, ed.w.vk);
+            if (DOB) w_r2s<BKC, true, WPL_B>(xb, st + 3 * WPL_A, tid, ed.w.vb, ed.w.vk);
         } else {
             if (DOA) w_r2s<AKC, false, WPL_A>(xa0, st, tid, 128, BK);
             if (DOA) w_r2s<AKC, false, WPL_A>(xa1, st + 128 * 32, tid, 128, BK);
@@ -565,6 +611,12 @@ __global__ __launch_bounds__(256) void x3w_group_reduce_kernel(const GTab table)
         f32x4 *o = reinterpret_cast<f32x4 *>(it->C + (size_t)(m0 + row) * it->ldc + n0 + c4);
         if (it->accumulate) v += *o;
         *o = v;
+    }    // the column sums of a K-sliced first-column tile: [splits][256] pieces behind the entry's tile pieces, summed in slice order
+    if (it->cs && n0 == 0 && (int)threadIdx.x < vr) {
+        const float *q = it->slab + (size_t)it->ntiles * it->splits * (size_t)(WBM * WBN) + (size_t)tl * it->splits * WBM + threadIdx.x;
+        float v = 0.f;
+        for (int z = 0; z < it->splits; ++z) v += q[(size_t)z * WBM];
+        it->cs[m0 + threadIdx.x] = v;
     }
 }
 

@@ -613,6 +613,20 @@ __global__ void relu_mask_bwd_kernel(const float *__restrict__ dy, const float *
     }
 }
 
+// dx = y_ref > 0 ? dy * scale : 0 -- the ReLU + dropout Jacobian when y_ref is the layer's output AFTER the mask (y = relu(pre) * mask:
+// y > 0 exactly where the mask kept the element and the ReLU passed it, and there the mask's value is the constant 1 / (1 - p)): the
+// [rows x d_ff] mask is not read again (r6: a quarter of the traffic of the Transformer's 43 launches, 1.04 ms per XE step)
+__global__ void relu_scale_bwd_kernel(const f32x4 *__restrict__ dy, const f32x4 *__restrict__ y_ref, float scale, f32x4 *__restrict__ dx,
+                                      size_t quads) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 g = dy[i], y = y_ref[i];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = y[k] > 0.f ? g[k] * scale : 0.f;
+        dx[i] = o;
+    }
+}
+
 __global__ void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                             float *__restrict__ v, size_t count, float lr, float b1, float b2, float eps, float wd,
                             float clip, float gscale, float bc1, float bc2_sqrt, const capmi_step_state *__restrict__ dyn) {
@@ -946,6 +960,16 @@ int capmi_relu_mask_bwd(const float *dy, const float *y_ref, const float *mask, 
     if (!dy || !dx || count <= 0) return CAPMI_EINVAL;
     hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3(grid_for((size_t)count)), dim3(256), 0, (hipStream_t)stream, dy, y_ref,
                        mask, dx, (size_t)count);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_relu_scale_bwd(const float *dy, const float *y_ref, float scale, float *dx, int64_t count, void *stream) {
+    if (!dy || !y_ref || !dx || count <= 0 || count % 4 != 0) return CAPMI_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y_ref) | reinterpret_cast<uintptr_t>(dx)) & 15) return CAPMI_EINVAL;
+    hipLaunchKernelGGL(relu_scale_bwd_kernel, dim3(grid_for((size_t)count / 4)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4 *>(dy), reinterpret_cast<const f32x4 *>(y_ref), scale, reinterpret_cast<f32x4 *>(dx),
+                       (size_t)count / 4);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

@@ -534,7 +534,7 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
     auto dw_one = [&](void *strm, int Mw, int Nw, float *Cw, int ldcw, const float *Aw, int ldaw, const float *Bw, int ldbw, int Kw, int acc,
                       float *Pw, int64_t capw) -> int {
         if (grouped && !acc && n_grp < 8) {
-            grp[n_grp++] = capmi_group_gemm{Aw, Bw, Cw, ldaw, ldbw, ldcw, Kw, Mw, Nw, 0, 0};
+            grp[n_grp++] = capmi_group_gemm{Aw, Bw, Cw, ldaw, ldbw, ldcw, Kw, Mw, Nw, 0, 0, nullptr};
             return 0;
         }
         SegSpec a{Aw, ldaw, Bw, ldbw, Kw, 1};
@@ -563,7 +563,18 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
             if ((c * T) / side_chunks == t) return true;
         return false;
     };
+    // (r6) a column sum whose input is the A operand of a listed weight-gradient GEMM rides in that GEMM's staging waves
+    // (capmi_group_gemm.colsum); its second copy (nn.LSTMCell's bias_hh gradient) is a 16-KB copy behind the grouped launch
+    struct Copy2 { float *dst; const float *src; size_t bytes; } copies[4];
+    int n_copies = 0;
     auto colsum = [&](const float *in, int rows, int ncol, float *out, float *out2) -> int {
+        for (int i = 0; i < n_grp; ++i)
+            if (grp[i].A == in && grp[i].K == rows && grp[i].M == ncol && grp[i].lda == ncol && !grp[i].colsum && n_copies < 4 &&
+                (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+                grp[i].colsum = out;
+                if (out2) copies[n_copies++] = Copy2{out2, out, (size_t)ncol * sizeof(float)};
+                return 0;
+            }
         if (batch_cols) {
             cols[n_cols++] = capmi_colsum_item{in, out, out2, rows, ncol, ncol, 0};
             return 0;
@@ -596,7 +607,7 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
             if (hipStreamWaitEvent(side_st, side_ev[0], 0) != hipSuccess) return CAPMI_EINVAL;
             RC(gemm((void *)side_st, 1, 1, V1, R, g->logit_w, R, &b, 1, nullptr, 0, 0, nullptr));
             side_used = true;
-        } else if (grouped) grp[n_grp++] = capmi_group_gemm{s->dlogits, a_hdrop, g->logit_w, V1, R, R, TN, V1, R, 0, 0};
+        } else if (grouped) grp[n_grp++] = capmi_group_gemm{s->dlogits, a_hdrop, g->logit_w, V1, R, R, TN, V1, R, 0, 0, nullptr};
         else RC(gemm(stream, 1, 1, V1, R, g->logit_w, R, &b, 1, P, cap, 0, nullptr));
         RC(colsum(s->dlogits, TN, V1, g->logit_b, nullptr));
     }
@@ -715,7 +726,6 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         if (hipStreamWaitEvent(st, side_ev[1], 0) != hipSuccess) return CAPMI_EINVAL;
     }
     RC(dw_chunk(stream, 0, dw_done_from, dw_done_from < T ? 1 : 0, P, cap));
-    if (n_grp) RC(capmi_gemm_group_tn(grp, n_grp, P + CAPMI_WS_COUNTER_FLOATS, cap - CAPMI_WS_COUNTER_FLOATS, stream));
     // attention LSTM
     if (phases & CAPMI_BWD_ATT_LSTM) {
         RC(colsum(s->dg_att, TN, 4 * R, g->att_b_ih, g->att_b_hh));
@@ -747,6 +757,16 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         RC(capmi_attention_bwd_batched_ws(s->d_x2, 3 * R, a_atth, a_alpha, s->d_e_all, r->p_att, w->alpha_w, g->d_att,
                                           g->d_p_att, g->alpha_w, g->alpha_b, T, B, n, N, K, A, R, dw_part, stream));
         if (dw_part) RC(colsum(dw_part, B * K, A, g->alpha_w, nullptr));
+    }
+    if (n_grp) {
+        // the grouped weight gradients (+ the bias gradients folded into them) LAST: every operand is final, and the K-slice pieces go
+        // behind alpha_net's partial rows, which the batched column sum below still has to read
+        const int64_t skip = CAPMI_WS_COUNTER_FLOATS + (((int64_t)B * K * A + 1023) & ~(int64_t)1023);
+        RC(capmi_gemm_group_tn(grp, n_grp, cap > skip ? P + skip : nullptr, cap > skip ? cap - skip : 0, stream));
+        for (int i = 0; i < n_copies; ++i) {
+            hipError_t e = hipMemcpyAsync(copies[i].dst, copies[i].src, copies[i].bytes, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return (int)e;
+        }
     }
     if (n_cols) RC(capmi_colsum_batch_args(cols, n_cols, stream));
     return 0;

@@ -122,11 +122,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reg_kernel(const float *__r
                                                                 const float *__restrict__ a, const float *__restrict__ mean,
                                                                 const float *__restrict__ inv, float *__restrict__ dx,
                                                                 int accumulate, float *__restrict__ g_scaled, int M, int D,
-                                                                float eps) {
+                                                                float eps, float *__restrict__ part_a = nullptr,
+                                                                float *__restrict__ part_b = nullptr) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     float av[NE];
+    // r6 (capmi_layernorm_bwd_parts): the wave's share of the parameter gradients d_a = colsum(dy (x - mean) inv), d_b = colsum(dy),
+    // summed over ITS rows in row order and left as one partial row per wave -- [waves, D] instead of an [M, D] g_scaled written here and
+    // read back (with dy) by a column-sum launch
+    float pa[NE], pb[NE];
 #pragma unroll
-    for (int i = 0; i < NE; ++i) av[i] = lane + 64 * i < D ? a[lane + 64 * i] : 0.f;
+    for (int i = 0; i < NE; ++i) {
+        av[i] = lane + 64 * i < D ? a[lane + 64 * i] : 0.f;
+        pa[i] = pb[i] = 0.f;
+    }
     for (int r = blockIdx.x * nw + wid; r < M; r += gridDim.x * nw) {
         const float mu = mean[r], iv = inv[r];
         float dv[NE], xc[NE], ov[NE];
@@ -161,7 +169,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reg_kernel(const float *__r
                 const float v = iv * (dv[i] * av[i] - mg) - k2 * xc[i];
                 dx[j] = accumulate ? ov[i] + v : v;
                 if (g_scaled) g_scaled[j] = dv[i] * xc[i] * iv;
+                if (part_a) {
+                    pa[i] += dv[i] * xc[i] * iv;
+                    pb[i] += dv[i];
+                }
             }
+        }
+    }
+    if (part_a) {
+        // the four waves' sums -> ONE partial row per workgroup, added in wave order (through LDS, reusing it for b after a)
+        __shared__ float s_part[4][64 * NE];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) s_part[wid][lane + 64 * i] = pass ? pb[i] : pa[i];
+            __syncthreads();
+            float *dst = (pass ? part_b : part_a) + (size_t)blockIdx.x * D;
+            for (int c = threadIdx.x; c < D; c += blockDim.x) dst[c] = ((s_part[0][c] + s_part[1][c]) + s_part[2][c]) + s_part[3][c];
+            __syncthreads();
         }
     }
 }
@@ -1036,6 +1061,29 @@ int capmi_layernorm_bwd(const float *dy, const float *x, const float *a, const f
     else hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, a, mean, inv, dx,
                             accumulate, g_scaled, M, D, eps);
 #undef CAPMI_LNB
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_layernorm_bwd_parts_rows(int M) {
+    // one partial row per workgroup of four waves; a workgroup takes ~8 rows (a wave per 16 rows, the first cut, left 180 workgroups
+    // for 11 520 rows -- fewer than CUs, and the launch got slower than the two column-sum passes it saves)
+    int blocks = (M + 7) / 8;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    return blocks;
+}
+
+int capmi_layernorm_bwd_parts(const float *dy, const float *x, const float *a, const float *mean, const float *inv, float *dx,
+                              int accumulate, float *part_a, float *part_b, int M, int D, float eps, void *stream) {
+    if (!dy || !x || !a || !mean || !inv || !dx || !part_a || !part_b || M <= 0 || D < 2 || D > 2048) return CAPMI_EINVAL;
+    const int blocks = capmi_layernorm_bwd_parts_rows(M);
+#define CAPMI_LNP(NE_) hipLaunchKernelGGL(layernorm_bwd_reg_kernel<NE_>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, a, mean, inv, dx, accumulate, (float *)nullptr, M, D, eps, part_a, part_b)
+    if (D <= 256) CAPMI_LNP(4);
+    else if (D <= 512) CAPMI_LNP(8);
+    else if (D <= 1024) CAPMI_LNP(16);
+    else CAPMI_LNP(32);
+#undef CAPMI_LNP
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

@@ -193,14 +193,15 @@ _group_cache = {}
 
 
 def gemm_group_tn(items, ws=None, cache_key=None):
-    """capmi_gemm_group_tn: items = [(dy [K,M], x [K,N], out, accumulate[, ldc, out_off])] -- out_i (+)= dy_i^T x_i for all i in ONE
-    persistent launch (+ one small reduction launch for the K-sliced tail).  out: [M,N] contiguous, or -- with ldc / out_off -- the
-    tensor whose elements out_off + m * ldc + n receive the product (a column block of a wider gradient).
+    """capmi_gemm_group_tn: items = [(dy [K,M], x [K,N], out, accumulate[, ldc, out_off[, colsum]])] -- out_i (+)= dy_i^T x_i for all i in
+    ONE persistent launch (+ one small reduction launch for the K-sliced tail).  out: [M,N] contiguous, or -- with ldc / out_off -- the
+    tensor whose elements out_off + m * ldc + n receive the product (a column block of a wider gradient).  colsum: optional [M]
+    tensor that receives the column sums of dy (the bias gradient), taken by the GEMM's staging waves.
     Returns the per-item splits_used.
     cache_key: any hashable; the ctypes table of an identical item list (same pointers, same shapes) is built once."""
     dev = items[0][2].device
-    key = tuple((it[0].data_ptr(), it[1].data_ptr(), it[2].data_ptr(), it[0].shape[0], it[0].shape[1], it[1].shape[1], bool(it[3])) + tuple(it[4:])
-                for it in items)
+    key = tuple((it[0].data_ptr(), it[1].data_ptr(), it[2].data_ptr(), it[0].shape[0], it[0].shape[1], it[1].shape[1], bool(it[3])) + tuple(it[4:6])
+                + ((it[6].data_ptr(),) if len(it) > 6 and it[6] is not None else ()) for it in items)
     hit = _group_cache.get(cache_key) if cache_key is not None else None
     if hit is not None and hit[0] == key:
         arr = hit[1]
@@ -213,9 +214,11 @@ def gemm_group_tn(items, ws=None, cache_key=None):
             N = x.shape[1]
             ldc = it[4] if len(it) > 4 and it[4] is not None else N
             off = it[5] if len(it) > 5 else 0
-            if x.shape[0] != K or ldc < N or off + (M - 1) * ldc + N > out.numel():
+            cs = it[6] if len(it) > 6 else None
+            if x.shape[0] != K or ldc < N or off + (M - 1) * ldc + N > out.numel() or (cs is not None and (cs.numel() != M or not cs.is_contiguous())):
                 raise _lib.CapmiError('gemm_group_tn: shapes %s^T %s -> %s (ldc %d, offset %d)' % (tuple(dy.shape), tuple(x.shape), tuple(out.shape), ldc, off))
             g.A, g.B, g.C, g.lda, g.ldb, g.ldc, g.K, g.M, g.N, g.accumulate = dy.data_ptr(), x.data_ptr(), out.data_ptr() + 4 * off, M, N, ldc, K, M, N, int(bool(acc))
+            g.colsum = None if cs is None else cs.data_ptr()
         if cache_key is not None:
             _group_cache[cache_key] = (key, arr)
     if ws is None:
@@ -308,19 +311,28 @@ class DeferredGrads:
         ev.record()
         self.side.wait_event(ev)
 
-    def dw(self, dy, x, out, final=True, ldc=None, out_off=0, accumulate=False):
+    def dw(self, dy, x, out, final=True, ldc=None, out_off=0, accumulate=False, colsum_out=None):
         """out[M,N] (+)= dy[K,M]^T x[K,N], reduction deferred.  out: contiguous [M,N], or with ldc / out_off a column block of a wider
         gradient (elements out_off + m * ldc + n).  final: nobody writes `dy` after this call (a running gradient accumulator that the
         caller keeps adding to must be read in stream order: no side stream, no grouping).  accumulate: the caller has ALREADY
-        written the addend into `out` (in stream order)."""
+        written the addend into `out` (in stream order).  colsum_out: the bias gradient (column sums of dy) that goes with this weight
+        gradient -- in a grouped launch the GEMM's staging waves take it from the operand they stage (no second pass over dy)."""
         _chk(dy, x, out)
         K, M = dy.shape
         N = x.shape[1]
         ldc = N if ldc is None else ldc
         cf = Workspace.COUNTER_FLOATS
         if self.group is not None and final:
-            self.group.append((dy, x, out, accumulate, ldc, out_off))
+            fold = colsum_out is not None and os.environ.get('CAPMI_GROUP_COLSUM', '1') != '0'
+            self.group.append((dy, x, out, accumulate, ldc, out_off, colsum_out if fold else None))
+            if colsum_out is not None and not fold:
+                self.colsum(dy, colsum_out)
             return
+        if colsum_out is not None:
+            if final:
+                self.colsum(dy, colsum_out)
+            else:
+                colsum(dy, out=colsum_out)
         if cf + 2 * M * N > SlabArena.CHUNK:            # a gradient this large needs no K split to fill the chip
             gemm([(dy, M, x, N, K, 1)], M, N, (out, out_off), ldc=ldc, a_layout=1, b_layout=1, accumulate=accumulate)
             return
@@ -515,9 +527,16 @@ def embed_fwd(it, E, mask=None, relu=True):
     return x
 
 
+def _keep_scale(p):
+    """1 / (1 - p) rounded as the mask kernels round it (float32 throughout)"""
+    import numpy as np
+    return float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+
+
 def dropout_mask(shape, p, seed, offset, device):
     m = torch.empty(shape, dtype=_f32, device=device)
     check(lib.capmi_dropout_mask(ptr(m), m.numel(), float(p), int(seed), int(offset), stream_ptr()), 'capmi_dropout_mask')
+    m._capmi_scale = _keep_scale(p)
     return m
 
 
@@ -530,6 +549,8 @@ def dropout_masks(specs, p, seed):
     for i, sp in enumerate(specs):
         shape, offset, keep_from = sp[0], sp[1], sp[2]
         m = torch.empty(shape, dtype=_f32, device=sp[3])
+        if sp[2] is None:                       # (eval-mode rows hold 1.0: not a pure keep-scale mask)
+            m._capmi_scale = _keep_scale(p)
         outs.append(m)
         descs[i].mask, descs[i].count, descs[i].offset = m.data_ptr(), m.numel(), int(offset)
         descs[i].row_len = int(shape[-1])
@@ -563,7 +584,14 @@ def colsum(x, out=None, accumulate=False):
 
 
 def relu_mask_bwd(dy, y_ref, mask):
+    """dx = dy * mask * (y_ref > 0).  When y_ref is the output AFTER the mask and the mask came from dropout_mask(s) (it carries its
+    keep-scale 1 / (1 - p) as `_capmi_scale`), the mask is not read at all: y_ref > 0 says where it kept the element."""
     dx = torch.empty_like(dy)
+    scale = getattr(mask, '_capmi_scale', None) if (mask is not None and y_ref is not None) else None
+    if scale is not None and dy.numel() % 4 == 0 and (dy.data_ptr() | y_ref.data_ptr() | dx.data_ptr()) % 16 == 0 \
+            and os.environ.get('CAPMI_RELU_SCALE', '1') != '0':
+        check(lib.capmi_relu_scale_bwd(ptr(dy), ptr(y_ref), float(scale), ptr(dx), dy.numel(), stream_ptr()), 'capmi_relu_scale_bwd')
+        return dx
     check(lib.capmi_relu_mask_bwd(ptr(dy), ptr(y_ref), ptr(mask), ptr(dx), dy.numel(), stream_ptr()), 'capmi_relu_mask_bwd')
     return dx
 

@@ -37,10 +37,20 @@ def layernorm_bwd(dy, x, a, mean, inv, dx_accum, d_a=None, d_b=None):
     """dx_accum += d(LN)/dx ; d_a, d_b (given or new) receive the gain / bias gradients.  `dy` must not be modified by the
     caller afterwards (inside deferred_grads its column sum is taken at the end of the backward)."""
     M, D = x.shape
+    d = Lin.deferred
+    if d is not None and d_a is not None and D <= 2048 and os.environ.get('CAPMI_LN_PARTS', '1') != '0':
+        # r6: per-wave partial sums of both parameter gradients leave the backward launch itself ([~M/16, D] rows each); the batched
+        # column sum at the end of the backward reads those instead of g_scaled and dy ([M, D] each, g_scaled written here first)
+        W = int(lib.capmi_layernorm_bwd_parts_rows(M))
+        parts = torch.empty(2, W, D, dtype=_f32, device=x.device)
+        check(lib.capmi_layernorm_bwd_parts(ptr(dy), ptr(x), ptr(a), ptr(mean), ptr(inv), ptr(dx_accum), 1, parts[0].data_ptr(),
+                                            parts[1].data_ptr(), M, D, EPS, stream_ptr()), 'layernorm_bwd_parts')
+        d.colsum(parts[0], d_a)
+        d.colsum(parts[1], d_b)
+        return d_a, d_b
     g = torch.empty_like(x)
     check(lib.capmi_layernorm_bwd(ptr(dy), ptr(x), ptr(a), ptr(mean), ptr(inv), ptr(dx_accum), 1, ptr(g), M, D, EPS,
                                   stream_ptr()), 'layernorm_bwd')
-    d = Lin.deferred
     if d is not None and d_a is not None:
         d.colsum(g, d_a)
         d.colsum(dy, d_b)
@@ -117,11 +127,7 @@ class Lin:
             fresh = True
         d = Lin.deferred
         if d is not None:
-            d.dw(dy, self.x, self.grads[self.wn], final=fresh)
-            if fresh:
-                d.colsum(dy, self.grads[self.bn])
-            else:
-                ops.colsum(dy, out=self.grads[self.bn])
+            d.dw(dy, self.x, self.grads[self.wn], final=fresh, colsum_out=self.grads[self.bn])
         else:
             ops.matmul_tn(dy, self.x, out=self.grads[self.wn])
             ops.colsum(dy, out=self.grads[self.bn])

@@ -113,7 +113,7 @@ int capmi_gemm_set_policy(int allow_wide_deferred);
  * The item table travels in the kernel arguments (no device table, no upload: the call is capturable into a hipGraph); more than
  * ~40 items go out as several launches, longest K first.  Items the fat kernel cannot take (M, N or K not a multiple of 4, unaligned
  * operands / pitches) are issued through capmi_gemm_f32 behind the group.  Same numbers, bit for bit, as capmi_gemm_f32 on each
- * item with the K split reported in splits_used (0: written whole-K).
+ * item with the K split reported in splits_used.
  * slabs / slab_floats: scratch for the K-slice pieces (>= 8.4 M floats serves any group; less only limits the tail's K split). */
 typedef struct capmi_group_gemm {
     const float *A, *B;
@@ -121,6 +121,9 @@ typedef struct capmi_group_gemm {
     int32_t lda, ldb, ldc, K, M, N;
     int32_t accumulate;          /* C += instead of C = */
     int32_t splits_used;         /* out: K slices of this item's tail tiles (1 when every tile was written whole-K); -1: went through capmi_gemm_f32 */
+    float *colsum;               /* optional: colsum[m] = sum_k A[k, m] -- the BIAS gradient that goes with the weight gradient (nn.Linear:
+                                  * db = column sums of dY).  Taken by the staging waves from the A panel they stage anyway instead of a
+                                  * second pass over dY (capmi_colsum_batch: 1.0 ms of a Transformer XE step); deterministic (fixed order). */
 } capmi_group_gemm;
 int capmi_gemm_group_tn(capmi_group_gemm *items, int n, float *slabs, int64_t slab_floats, void *stream);
 
@@ -423,6 +426,11 @@ int capmi_group_rowsum(const float *in, int T, int64_t slab, int groups, int gro
 /* y = x * (m ? m : 1) * (gate_on_positive && ref<=0 ? 0 : 1): relu/dropout backward */
 int capmi_relu_mask_bwd(const float *dy, const float *y_ref, const float *mask, float *dx, int64_t count,
                         void *stream);
+/* the same Jacobian when y_ref is the layer's output AFTER its dropout mask (y = relu(pre) * mask, the fused epilogue of the
+ * forward GEMM; nn.Sequential(Linear, ReLU, Dropout): AttModel.py:83-90, TransformerModel.py:215 PositionwiseFeedForward): y > 0
+ * exactly where mask and ReLU both passed, and there mask == 1 / (1 - p) == scale -- the mask tensor is not read.
+ * count % 4 == 0, 16-byte aligned operands. */
+int capmi_relu_scale_bwd(const float *dy, const float *y_ref, float scale, float *dx, int64_t count, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused value-clip + Adam on one flat fp32 buffer (torch.nn.utils.clip_grad_value_ train.py:194-195
@@ -778,6 +786,12 @@ int capmi_layernorm_fwd(const float *x, const float *a, const float *b, float *y
  * for d_a; column-sum dy for d_b). */
 int capmi_layernorm_bwd(const float *dy, const float *x, const float *a, const float *mean, const float *inv,
                         float *dx, int accumulate, float *g_scaled, int M, int D, float eps, void *stream);
+/* r6: the same backward with the PARAMETER gradients started in the launch: every workgroup leaves the sums of dy (x - mean) inv and of
+ * dy over its own rows (fixed order) as one row of part_a / part_b, [capmi_layernorm_bwd_parts_rows(M), D] each; d_a / d_b are their
+ * column sums (capmi_colsum_batch over ~M/8 rows instead of M, and no [M, D] g_scaled is written).  Deterministic.  D <= 2048. */
+int capmi_layernorm_bwd_parts_rows(int M);
+int capmi_layernorm_bwd_parts(const float *dy, const float *x, const float *a, const float *mean, const float *inv, float *dx,
+                              int accumulate, float *part_a, float *part_b, int M, int D, float eps, void *stream);
 /* r5, AoA decode step (AoAModel.py:163-186): the same backward when BOTH inputs are still K-slice slabs of the GEMMs that made
  * them -- dy = sum_s dy_slabs[s] ([M,D] slabs dy_stride floats apart; the finished dy is also written to dy_out when not NULL: its
  * column sums are d_b) and the running gradient the LayerNorm term is added to, dx = sum_s acc_slabs[s] + ..., slabs of row pitch

@@ -60,6 +60,67 @@ def test_group_matches_fp64(dev, name):
         assert e_ours <= 1.5 * e_fp32 + 1e-7, (name, tuple(out.shape), e_ours, e_fp32)
 
 
+@pytest.mark.parametrize('name', ['scst', 'txe_layer', 'small', 'ragged', 'many'])
+def test_group_column_sums_ride_along(dev, name):
+    """capmi_group_gemm.colsum: the bias gradient (column sums of dY) taken by the staging waves of an item's first column tiles --
+    whole-K units, K-sliced tail units (pieces + the reduction launch) and items that fall back to capmi_gemm_f32; the products
+    themselves are unchanged by it, bit for bit"""
+    ops = _ops()
+    plain = _items(SETS[name], dev, seed=23)
+    ops.gemm_group_tn(plain)
+    items = [(dy, x, torch.full_like(out, float('nan')), False, None, 0, torch.full((dy.shape[1],), float('nan'), device=dev))
+             for dy, x, out, _ in plain]
+    ops.gemm_group_tn(items)
+    for (dy, x, out, _, _, _, cs), ref in zip(items, plain):
+        assert torch.equal(out, ref[2])
+        want = dy.double().sum(0)
+        mag = dy.double().abs().sum(0)
+        assert torch.isfinite(cs).all()
+        assert float(((cs.double() - want).abs() / (mag + 1e-30)).max()) < 2e-6, (name, tuple(dy.shape))
+    again = [it[:6] + (torch.empty_like(it[6]),) for it in items]
+    ops.gemm_group_tn(again)
+    for a, b in zip(items, again):
+        assert torch.equal(a[6], b[6])                     # deterministic: fixed summation order, no atomics
+
+
+def test_layernorm_bwd_parts(dev):
+    """capmi_layernorm_bwd_parts: dx bit-identical to capmi_layernorm_bwd; the column sums of the per-wave partial rows are d_a / d_b"""
+    from imagecaptioning.pytorch_amd._lib import lib, ptr, check, stream_ptr
+    g = torch.Generator().manual_seed(3)
+    for M, D in ((6720, 512), (37, 512), (360, 1024), (5, 260)):
+        dy, x, a = (torch.randn(s, generator=g).to(dev) for s in ((M, D), (M, D), (D,)))
+        mean = x.mean(1).contiguous()
+        inv = (1.0 / (x.std(1) + 1e-6)).contiguous()
+        dx1, dx2, gs = torch.zeros(M, D, device=dev), torch.zeros(M, D, device=dev), torch.empty(M, D, device=dev)
+        check(lib.capmi_layernorm_bwd(ptr(dy), ptr(x), ptr(a), ptr(mean), ptr(inv), ptr(dx1), 1, ptr(gs), M, D, 1e-6, stream_ptr()), 'ln')
+        W = int(lib.capmi_layernorm_bwd_parts_rows(M))
+        parts = torch.full((2, W, D), float('nan'), device=dev)
+        check(lib.capmi_layernorm_bwd_parts(ptr(dy), ptr(x), ptr(a), ptr(mean), ptr(inv), ptr(dx2), 1, parts[0].data_ptr(), parts[1].data_ptr(),
+                                            M, D, 1e-6, stream_ptr()), 'ln parts')
+        assert torch.equal(dx1, dx2)
+        for got, want in ((parts[0], gs), (parts[1], dy)):
+            ref = want.double().sum(0)
+            mag = want.double().abs().sum(0)
+            assert float(((got.double().sum(0) - ref).abs() / (mag + 1e-30)).max()) < 2e-6, (M, D)
+
+
+def test_relu_scale_bwd_is_the_masked_jacobian(dev):
+    """capmi_relu_scale_bwd (y_ref = relu(pre) * mask, the mask not read) == capmi_relu_mask_bwd with the mask, bit for bit"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    pre = torch.randn(333, 2048, generator=g).to(dev)
+    dy = torch.randn(333, 2048, generator=g).to(dev)
+    for p in (0.1, 0.3, 0.5):
+        mask = ops.dropout_mask((333, 2048), p, 1234, 5 << 36, dev)
+        assert hasattr(mask, '_capmi_scale') and float(mask.max()) == mask._capmi_scale
+        y = torch.relu(pre) * mask
+        fast = ops.relu_mask_bwd(dy, y, mask)
+        plain = mask.clone()                                   # (no keep-scale attribute: the three-operand kernel)
+        slow = ops.relu_mask_bwd(dy, y, plain)
+        assert torch.equal(fast, slow)
+        assert torch.equal(fast, dy * mask * (pre > 0))
+
+
 def test_group_accumulates(dev):
     ops = _ops()
     items = _items([(512, 512, 800), (1024, 256, 800), (260, 132, 100)], dev, seed=5)

@@ -326,16 +326,19 @@ def test_group_rowsum(dev, T, groups, group, cols, pad):
     assert rel_err(out, ref) < 2e-6
 
 
-@pytest.mark.parametrize('side', [False, True])
-def test_deferred_grads_batched_reduce_and_colsum(dev, side, monkeypatch):
-    """ops.DeferredGrads: weight-gradient GEMMs leave their K-slice slabs, bias column sums are only recorded, flush() finishes
-    everything with one capmi_splitk_reduce_batch + one capmi_colsum_batch launch -- or (side, r4) everything runs on a side stream
-    behind its operands and goes out in batches (here of 3 items, so that partial batches and the forced last one both occur).
+@pytest.mark.parametrize('mode', ['group', 'group_fold', 'single', 'side'])
+def test_deferred_grads_batched_reduce_and_colsum(dev, mode, monkeypatch):
+    """ops.DeferredGrads: weight-gradient GEMMs are only recorded and go out at flush() as ONE grouped launch (r6, `group`; `group_fold`:
+    the bias column sums ride in its staging waves), or leave their K-slice slabs (`single`, CAPMI_DW_GROUP=0), bias column sums are only
+    recorded, flush() finishes everything with one capmi_splitk_reduce_batch + one capmi_colsum_batch launch -- or (side, r4) everything
+    runs on a side stream behind its operands and goes out in batches (here of 3 items, so that partial batches and the forced last one both occur).
     Shapes of the Transformer backward (fat bf16x3 GEMMs with 4..15 K slices), a vocabulary-wide bias, an unaligned pair (scalar
     paths), and a second round with other shapes on the same arena (regions landing on former slab data)."""
     ops = ops_mod()
     g = torch.Generator().manual_seed(5)
+    side = mode == 'side'
     monkeypatch.setenv('CAPMI_DW_STREAM', '1' if side else '0')
+    monkeypatch.setenv('CAPMI_DW_GROUP', '0' if mode == 'single' else '1')
     monkeypatch.setattr(ops.DeferredGrads, 'SIDE_BATCH', 3)
 
     def one_round(shapes):
@@ -347,12 +350,19 @@ def test_deferred_grads_batched_reduce_and_colsum(dev, side, monkeypatch):
             x = torch.randn(K, N, generator=g).to(dev)
             dW = torch.full((M, N), float('nan'), device=dev)
             db = torch.full((M,), float('nan'), device=dev)
-            d.dw(dy, x, dW)
-            d.colsum(dy, db)
+            if mode == 'group_fold':
+                d.dw(dy, x, dW, colsum_out=db)
+            else:
+                d.dw(dy, x, dW)
+                d.colsum(dy, db)
             want.append((dW, dy.double().t() @ x.double(), db, dy.double().sum(0)))
             del dy, x                                   # the collector keeps what it still has to read
-        if not side:
-            assert len(d.red) == len(shapes) and len(d.col) == len(shapes)
+        if mode == 'single':
+            assert len(d.red) == len(shapes) and len(d.col) == len(shapes) and d.group is None
+        elif mode == 'group':
+            assert len(d.group) == len(shapes) and len(d.col) == len(shapes) and not d.red
+        elif mode == 'group_fold':
+            assert len(d.group) == len(shapes) and not d.col and not d.red
         else:
             assert not d.red and not d.col and len(d.red_side) + len(d.col_side) < 3 and d.side_batches >= 2
         d.flush()
