@@ -229,6 +229,7 @@ SIGNATURES = {
     'capmi_embed_pe_fwd': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     'capmi_embed_pe_bwd': [_P, _I, _P, _P, _P, _I, _I, _I, _P],
     'capmi_log_softmax_rows': [_P, _P, _I, _I, _P],
+    'capmi_caption_stats': [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     'capmi_maxout_cell_fwd': [_P, _I] + [_P] * 8 + [_I, _I, _P],
     'capmi_maxout_cell_bwd': [_P] * 9 + [_I, _I, _P],
     'capmi_newfc_rollout_fwd': [C.POINTER(NewFCWeights), C.POINTER(NewFCRollout), _P],

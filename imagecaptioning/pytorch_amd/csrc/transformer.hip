@@ -1030,6 +1030,60 @@ inline int grid_for(size_t work) {
 
 }  // namespace
 
+// ---- caption statistics of the evaluation loop (reference captioning/utils/eval_utils.py:173-174) --------------------------------
+//   entropy[r]    = -sum_t sum_v softmax(lp[r,t,:])_v * lp[r,t,v] / (#tokens(r) + 1)
+//   perplexity[r] = -sum_t lp[r,t,seq[r,t]] / (#tokens(r) + 1),          #tokens = count(seq[r,:] > 0)
+// from the dense [N, L, V1] log-probs a decode returns: one workgroup per (row, step), the step's row read ONCE into registers
+// (max, sum of exponentials and sum of e * lp in one pass over them), the per-step terms left in [N, L] scratch and folded per row by
+// the second kernel -- instead of torch.softmax + mul + nan_to_num + two sums + gather over three dense temporaries.
+// A log-prob of -inf (a token the decoding constraints removed) contributes 0 * -inf := 0, as the ATen path's nan_to_num did.
+template <int NE>
+__global__ __launch_bounds__(1024) void caption_step_stats_kernel(const float *__restrict__ lp, const int64_t *__restrict__ seq, int V1,
+                                                                  float *__restrict__ ent_t, float *__restrict__ sel_t) {
+    __shared__ float s_f[32];
+    const size_t rt = blockIdx.x;
+    const float *x = lp + rt * V1;
+    float xv[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int v = threadIdx.x + 1024 * i;
+        xv[i] = v < V1 ? x[v] : -INFINITY;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) m = fmaxf(m, xv[i]);
+    m = block_max(m, s_f);
+    float z = 0.f, a = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        if (xv[i] > -INFINITY) {
+            const float e = __expf(xv[i] - m);
+            z += e;
+            a += e * xv[i];
+        }
+    }
+    z = block_sum(z, s_f);
+    a = block_sum(a, s_f);
+    if (threadIdx.x == 0) {
+        ent_t[rt] = z > 0.f ? -a / z : 0.f;
+        const int64_t tok = seq[rt];
+        sel_t[rt] = (tok >= 0 && tok < V1) ? x[tok] : 0.f;
+    }
+}
+__global__ void caption_row_stats_kernel(const float *__restrict__ ent_t, const float *__restrict__ sel_t, const int64_t *__restrict__ seq,
+                                         int N, int L, float *__restrict__ entropy, float *__restrict__ perplexity) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    float e = 0.f, p = 0.f, steps = 1.f;
+    for (int t = 0; t < L; ++t) {
+        e += ent_t[(size_t)r * L + t];
+        p += sel_t[(size_t)r * L + t];
+        steps += seq[(size_t)r * L + t] > 0 ? 1.f : 0.f;
+    }
+    entropy[r] = e / steps;
+    perplexity[r] = -p / steps;
+}
+
 extern "C" {
 
 int capmi_layernorm_fwd(const float *x, const float *a, const float *b, float *y, float *mean, float *inv, int M, int D,
@@ -1322,6 +1376,22 @@ int capmi_meanpool_bwd(const float *dmean, const float *mask, float *dx, int acc
     if (!dmean || !dx || B <= 0 || K <= 0 || D <= 0) return CAPMI_EINVAL;
     hipLaunchKernelGGL(meanpool_bwd_kernel, dim3(grid_for((size_t)B * K * D)), dim3(256), 0, (hipStream_t)stream, dmean, mask, dx,
                        accumulate, B, K, D);
+    CAPMI_CHECK_LAUNCH();
+    return 0;
+}
+
+int capmi_caption_stats(const float *seq_logp, const int64_t *seq, int N, int L, int V1, float *scratch, float *entropy, float *perplexity,
+                        void *stream) {
+    if (!seq_logp || !seq || !scratch || !entropy || !perplexity || N <= 0 || L <= 0 || V1 <= 0 || V1 > 32 * 1024) return CAPMI_EINVAL;
+    float *ent_t = scratch, *sel_t = scratch + (size_t)N * L;
+#define CAPMI_CS(NE_) hipLaunchKernelGGL(caption_step_stats_kernel<NE_>, dim3(N * L), dim3(1024), 0, (hipStream_t)stream, seq_logp, seq, V1, ent_t, sel_t)
+    if (V1 <= 10 * 1024) CAPMI_CS(10);
+    else if (V1 <= 16 * 1024) CAPMI_CS(16);
+    else CAPMI_CS(32);
+#undef CAPMI_CS
+    CAPMI_CHECK_LAUNCH();
+    hipLaunchKernelGGL(caption_row_stats_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, ent_t, sel_t, seq, N, L, entropy,
+                       perplexity);
     CAPMI_CHECK_LAUNCH();
     return 0;
 }

@@ -687,6 +687,20 @@ def logsoftmax_select(logits, step, L, mode, temperature, gumbel, seed, forced, 
           'capmi_logsoftmax_select_partial')
 
 
+def caption_stats(seq_logp, seq):
+    """(entropy [N], perplexity [N]) of a decode (eval_utils.py:173-174) from its dense log-probs [N, L, V1] and tokens [N, L]: one
+    pass over seq_logp, nothing dense is built (capmi_caption_stats)."""
+    _chk(seq_logp, seq)
+    N, L, V1 = seq_logp.shape
+    if seq.dtype != torch.int64 or tuple(seq.shape) != (N, L) or seq_logp.dtype != _f32:
+        raise _lib.CapmiError('caption_stats: seq_logp [N,L,V1] float32 and seq [N,L] int64 expected')
+    scratch = torch.empty(2 * N * L, dtype=_f32, device=seq_logp.device)
+    ent = torch.empty(N, dtype=_f32, device=seq_logp.device)
+    ppl = torch.empty(N, dtype=_f32, device=seq_logp.device)
+    check(lib.capmi_caption_stats(ptr(seq_logp), ptr(seq), N, L, V1, ptr(scratch), ptr(ent), ptr(ppl), stream_ptr()), 'capmi_caption_stats')
+    return ent, ppl
+
+
 def clip_len(att_masks, width=None):
     """Longest valid region count of the batch -- the K that clip_att (AttModel.py:106-112) truncates to.
 

@@ -92,10 +92,10 @@ def eval_split(model, crit, loader, opt):
         loss_n += 1
         if seq_logp.dim() == 3:
             # eval_utils.py:173-174: sums over ALL L steps (rows after the end are zero) over (#tokens + 1); the only deviation:
-            # 0 * -inf of a constrained token counts as 0 instead of making the whole caption's entropy NaN
-            steps = (seq > 0).to(seq_logp).sum(1) + 1
-            entropy = -(torch.softmax(seq_logp, 2) * seq_logp).nan_to_num(0.0).sum(2).sum(1) / steps
-            perplexity = -seq_logp.gather(2, seq.unsqueeze(2)).squeeze(2).sum(1) / steps
+            # 0 * -inf of a constrained token counts as 0 instead of making the whole caption's entropy NaN.  r6: one pass of
+            # capmi_caption_stats over the log-probs the decode returned -- the ATen formula built three dense [N, L, V1] temporaries
+            from imagecaptioning.pytorch_amd import ops
+            entropy, perplexity = ops.caption_stats(seq_logp.contiguous(), seq.contiguous())
         else:                                  # _diverse_sample returns the chosen tokens' log-probs only (AttModel.py:449)
             entropy = perplexity = torch.full((seq.shape[0],), float('nan'))
         if opt.beam_size > 1 and getattr(opt, 'verbose_beam', 0):                                              # :177-181

@@ -875,6 +875,14 @@ int capmi_split_halves(const float *slabs, int splits, int64_t stride, const flo
 int capmi_meanpool_fwd(const float *x, const float *mask, float *mean, int B, int K, int D, void *stream);
 /* dx[b,k,:] (+)= m[b,k]/cnt * dmean[b,:] */
 int capmi_meanpool_bwd(const float *dmean, const float *mask, float *dx, int accumulate, int B, int K, int D, void *stream);
+/* r6: caption statistics of the evaluation loop (captioning/utils/eval_utils.py:173-174) from a decode's dense log-probs
+ * seq_logp [N, L, V1] and tokens seq [N, L]:
+ *   entropy[r]    = -sum_t sum_v softmax(seq_logp[r,t,:])_v * seq_logp[r,t,v] / (count(seq[r,:] > 0) + 1)
+ *   perplexity[r] = -sum_t seq_logp[r,t,seq[r,t]]                            / (count(seq[r,:] > 0) + 1)
+ * One pass over seq_logp, no dense temporaries (the ATen formula built three).  A -inf log-prob contributes 0 (0 * -inf := 0).
+ * scratch: 2 * N * L floats.  V1 <= 32768. */
+int capmi_caption_stats(const float *seq_logp, const int64_t *seq, int N, int L, int V1, float *scratch, float *entropy, float *perplexity,
+                        void *stream);
 /* out = log_softmax(logits) row-wise (Generator, TransformerModel.py:50-57) */
 int capmi_log_softmax_rows(const float *logits, float *out, int rows, int V1, void *stream);
 

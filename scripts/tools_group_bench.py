@@ -34,6 +34,9 @@ def main():
     dev = torch.device('cuda:0')
     names = sys.argv[1:] or sorted(SETS)
     for name in names:
+        if 'x' in name:                     # MxNxKxcount: `count` identical GEMMs (unit-length sweeps: time = a + rounds * (K / 32 * s + c))
+            M, N, K, cnt = (int(v) for v in name.split('x'))
+            SETS[name] = [(M, N, K)] * cnt
         shapes = SETS[name]
         g = torch.Generator().manual_seed(1)
         items = [(torch.randn(K, M, generator=g).to(dev), torch.randn(K, N, generator=g).to(dev), torch.empty(M, N, device=dev), False)

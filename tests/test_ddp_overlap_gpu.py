@@ -100,7 +100,10 @@ def test_bench_multi_gpu_code_path_on_rccl_with_one_rank(mode):
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, CAPMI_BENCH_FORCE_DIST='1', CAPMI_BENCH_WATCHDOG_S='150', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    # r6: in the default mode the run also times the two configurations BASELINE.json names for 8-GPU data parallel (Transformer XE, AoA
+    # new-self-critical) on the same process group (bench.ddp_other_configs); the other two modes skip that pass to stay short
+    env = dict(os.environ, CAPMI_BENCH_FORCE_DIST='1', CAPMI_BENCH_WATCHDOG_S='150' if mode != 'allreduce' else '330',
+               HSA_ENABLE_IPC_MODE_LEGACY='0', CAPMI_BENCH_DDP_CONFIGS='1' if mode == 'allreduce' else '0')
     env.pop('CAPMI_DDP_OVERLAP', None)
     env.pop('CAPMI_DDP_MODE', None)
     if mode == 'rsag':
@@ -110,11 +113,20 @@ def test_bench_multi_gpu_code_path_on_rccl_with_one_rank(mode):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '1',
            '--no-cpu-baseline', '--no-prof']
-    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=170)
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=170 if mode != 'allreduce' else 350)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][-1])
     col = line['collective']
     assert col['backend'] == 'nccl' and col['ranks'] == 1 and col['bytes'] > 200e6
+    if mode == 'allreduce':
+        oc = line['other_configs']
+        assert set(oc) == {'transformer_xe', 'aoa_nsc'}, oc
+        for name, d in oc.items():
+            assert 'error' not in d, (name, d)
+            assert d['ms_per_step'] > 0 and np.isfinite(d['loss']) and d['collective']['backend'] == 'nccl' and d['collective']['bytes'] > 1e6
+            assert d['step_issue'].startswith('hipGraph replay'), d        # captured up to the flat gradient, exchange + Adam behind it
+    else:
+        assert 'other_configs' not in line
     assert line['n_gpus'] == 1 and line['value'] > 1000 and np.isfinite(line['loss'])
     if mode == 'allreduce':
         assert col['mode'] == 'one flat all-reduce per step' and col['allreduce_ms'] is not None and col['allreduce_ms'] >= 0
@@ -132,7 +144,8 @@ def test_plain_python_bench_gpus_2_launches_its_own_ranks():
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, CAPMI_DIST_BACKEND='gloo', CAPMI_BENCH_WATCHDOG_S='200', CAPMI_BENCH_MODES='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, CAPMI_DIST_BACKEND='gloo', CAPMI_BENCH_WATCHDOG_S='200', CAPMI_BENCH_MODES='0', CAPMI_BENCH_DDP_CONFIGS='0',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'CAPMI_DDP_OVERLAP', 'CAPMI_DDP_MODE'):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-prof']

@@ -625,3 +625,27 @@ def test_embedding_gradients_are_ordered_sums_the_same_bits_every_run(rows, D, V
         outs.append(dE.cpu())
     assert torch.equal(outs[0], outs[1])
     assert float((outs[0].double() - want2).abs().max()) <= 2e-6 * max(1.0, float(want2.abs().max()))
+
+
+def test_caption_stats_match_the_reference_formula(dev):
+    """capmi_caption_stats == captioning/utils/eval_utils.py:173-174 (entropy / perplexity of a decode from its dense log-probs), with
+    finished rows (all-zero steps after the end token) and constrained tokens (-inf log-probs, 0 * -inf := 0)"""
+    ops = ops_mod()
+    g = torch.Generator().manual_seed(13)
+    for N, L, V1 in ((7, 20, 9488), (3, 5, 1000), (2, 16, 12000)):
+        lp = torch.log_softmax(torch.randn(N, L, V1, generator=g) * 3, 2)
+        seq = torch.randint(1, V1, (N, L), generator=g)
+        for r in range(N):                                   # ragged ends: zeros after the end token, like _sample leaves them
+            e = int(torch.randint(1, L + 1, (1,), generator=g))
+            seq[r, e:] = 0
+            lp[r, e + 1:] = 0.0
+        lp[0, 0, 5:50] = float('-inf')                       # a decoding constraint
+        seq[0, 0] = 3
+        lp, seq = lp.to(dev), seq.to(dev)
+        ent, ppl = ops.caption_stats(lp, seq)
+        steps = (seq > 0).to(lp).sum(1) + 1
+        ref_e = -(torch.softmax(lp.double(), 2) * lp.double()).nan_to_num(0.0).sum(2).sum(1) / steps.double()
+        ref_p = -lp.double().gather(2, seq.unsqueeze(2)).squeeze(2).sum(1) / steps.double()
+        assert torch.isfinite(ent).all() and torch.isfinite(ppl).all()
+        assert float((ent.double() - ref_e).abs().max()) < 2e-5 * float(ref_e.abs().max() + 1)
+        assert float((ppl.double() - ref_p).abs().max()) < 2e-5 * float(ref_p.abs().max() + 1)
