@@ -151,6 +151,11 @@ class TrainStep:
                     self.entries.pop(next(iter(self.entries)))
                 ent = self.entries[sig] = _Entry()
         need_gts = bool(sc_flag or struc_flag)
+        if ent is not None and ent.graph is None and self.captures >= 8 and self.replays < 4 * self.captures:
+            # shape churn (ragged region counts: a new input shape almost every batch): captures cost more than their replays save
+            self.failed = 'input shapes change too often (%d captures for %d replays): stepping launch by launch' % (self.captures, self.replays)
+            print('capmi: ' + self.failed, file=sys.stderr, flush=True)
+            ent = None
         if ent is not None and ent.graph is None and ent.seen >= self.capture_after:
             self._capture(ent, data, sc_flag, struc_flag, need_gts, not multi)
         if ent is not None and ent.graph is not None:

@@ -136,6 +136,12 @@ def train(opt):
             for split, pos in infos.get('loader_pos', {}).items():
                 base.pos[split] = pos
         model._rng_calls = int(infos.get('rng_calls', 0))                        # dropout / sampling Philox stream position
+    # r6: the iteration is graph_step.TrainStep -- forward + loss + backward + (all-reduce) + clip/Adam as one object: launch by launch
+    # for UpDown / NewFC (native rollouts), captured into a hipGraph per input shape and replayed for the Transformer and AoA families
+    # (450-600 launches a step from Python otherwise; CAPMI_GRAPH_STEP=0 steps everywhere).  The bucketed-overlap exchange mode keeps
+    # the explicit loop below.  Built after a resume: it takes Adam's step count and the random streams' epoch from flat / the model.
+    from imagecaptioning.pytorch_amd.graph_step import TrainStep
+    ts = None if overlap else TrainStep(lw_model, flat, opt, dev, world=world)
     sc_ready = False
     epoch_done = True
     train_loss = float('nan')
@@ -148,7 +154,9 @@ def train(opt):
     def checkpoint():
         # the prefetcher runs ahead of the loop: the position to resume from is the one of the last CONSUMED batch
         misc.save_checkpoint(opt, model, {'iter': it, 'epoch': epoch, 'opt': opt, 'vocab': opt.vocab,
-                                          'loader_pos': dict(last_pos), 'rng_calls': int(getattr(model, '_rng_calls', 0)),
+                                          'loader_pos': dict(last_pos),
+                                          # (position of the dropout / sampling streams: the step record's epoch word under TrainStep)
+                                          'rng_calls': ts.state_dict()['epoch'] if ts is not None else int(getattr(model, '_rng_calls', 0)),
                                           'best_val_score': best_val_score, 'histories': histories, **last_loader},
                              optimizer_state={'flat': flat.state_dict(), 'sched': sched.state_dict()})
 
@@ -176,27 +184,26 @@ def train(opt):
         t1 = time.time()
         # tools/train.py:160-165, 187-191: after drop_worst_after the rows with the highest loss are left out of the mean
         drop_worst_flag = opt.drop_worst_after != -1 and epoch >= opt.drop_worst_after
-        out = lw_model(fc, att, labels, masks, att_masks, data['gts'], torch.arange(len(data['gts'])), sc_flag, struc_flag,
-                       drop_worst_flag)
-        if not drop_worst_flag:
-            loss = out['loss'].mean()
-        else:
-            rows = out['loss']
-            loss = torch.topk(rows, k=int(rows.shape[0] * (1 - opt.drop_worst_rate)), largest=False)[0].mean()
-        flat.zero_grad()
-        two = struc_flag and 0 < opt.structure_loss_weight < 1                # XE + structure rollouts: two native backwards
-        flat.expect_backwards(2 if two else 1)
-        loss.backward()
-        flat.collect_grads()
         opt.current_lr = sched.rate(it)
-        clip = opt.grad_clip_value if opt.grad_clip_mode == 'value' else 0.0
-        if overlap:        # buckets finished by the backward are already in flight; clip+Adam follows each as it lands
+        if ts is not None:
+            loss, out = ts(data, sc_flag, struc_flag, lr=opt.current_lr, drop_worst_flag=drop_worst_flag)
+        else:
+            out = lw_model(fc, att, labels, masks, att_masks, data['gts'], torch.arange(len(data['gts'])), sc_flag, struc_flag,
+                           drop_worst_flag)
+            if not drop_worst_flag:
+                loss = out['loss'].mean()
+            else:
+                rows = out['loss']
+                loss = torch.topk(rows, k=int(rows.shape[0] * (1 - opt.drop_worst_rate)), largest=False)[0].mean()
+            flat.zero_grad()
+            two = struc_flag and 0 < opt.structure_loss_weight < 1                # XE + structure rollouts: two native backwards
+            flat.expect_backwards(2 if two else 1)
+            loss.backward()
+            flat.collect_grads()
+            clip = opt.grad_clip_value if opt.grad_clip_mode == 'value' else 0.0
+            # buckets finished by the backward are already in flight; clip+Adam follows each as it lands
             flat.finish_overlap_and_step(opt.current_lr, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
                                          clip_value=clip)
-        else:              # one flat fp32 all-reduce per step; 1/world and the value clip inside the Adam kernel
-            scale = flat.all_reduce() if world > 1 else 1.0
-            flat.adam_step(opt.current_lr, (opt.optim_alpha, opt.optim_beta), opt.optim_epsilon, opt.weight_decay,
-                           clip_value=clip, grad_scale=scale)
         # The reference reads the loss back right here (train.py:197), leaving the GPU idle while the host prepares the next
         # iteration.  Same values, one iteration later: the loss goes to a pinned buffer asynchronously and the host waits for the
         # PREVIOUS iteration's copy, so one iteration is always queued behind the running one (never more: the host stays at most

@@ -101,6 +101,33 @@ def test_transformer_noam_schedule_runs(tmp_path):
     assert opt.current_lr == pytest.approx(32 ** -0.5 * 8 ** -0.5, rel=1e-9)
 
 
+@pytest.mark.parametrize('family', ['transformer', 'aoa'])
+def test_trainer_on_the_captured_step_equals_the_stepped_trainer(tmp_path, monkeypatch, family):
+    """tools/train.py steps through graph_step.TrainStep (r6): for the Transformer and AoA families the iteration is captured into a
+    hipGraph per input shape and replayed.  The SAME training run with CAPMI_GRAPH_STEP=0 (launch by launch) must end with the same
+    loss to the last bit -- moving learning rate (Noam warm-up: capmi_step_set_lr outside the graph), dropout streams, Adam's bias
+    corrections and all."""
+    sys.path.insert(0, PKG)
+    from imagecaptioning.pytorch_amd.tools import train as T
+    common = ['--fc_feat_size', '24', '--att_feat_size', '24', '--vocab_size', '40', '--synthetic_regions', '5', '--seq_length', '6',
+              '--max_length', '6', '--batch_size', '4', '--seq_per_img', '2', '--synthetic_images', '8', '--max_iters', '10',
+              '--losses_log_every', '1']
+    if family == 'transformer':
+        small = ['--caption_model', 'transformer', '--d_model', '32', '--d_ff', '64', '--N_enc', '1', '--N_dec', '1', '--num_att_heads', '4',
+                 '--input_encoding_size', '32', '--rnn_size', '32', '--noamopt', '1', '--noamopt_warmup', '5', '--noamopt_factor', '1.0']
+    else:
+        small = ['--caption_model', 'aoa', '--rnn_size', '32', '--input_encoding_size', '32', '--att_hid_size', '16', '--num_heads', '4',
+                 '--learning_rate', '1e-3']
+    out = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('CAPMI_GRAPH_STEP', mode)
+        torch.manual_seed(0)
+        opt = _opts(small + common + ['--checkpoint_path', str(tmp_path / ('g' + mode))])
+        os.makedirs(opt.checkpoint_path, exist_ok=True)
+        out[mode] = T.train(opt)
+    assert out['1'] == out['1'] and out['1'] == out['0'], out
+
+
 def test_device_prefetcher_delivers_the_same_batches_on_device():
     sys.path.insert(0, PKG)
     from captioning.data.synthetic_loader import SyntheticLoader
