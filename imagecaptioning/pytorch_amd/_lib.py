@@ -28,7 +28,8 @@ class GemmDesc(C.Structure):
                 ('M', C.c_int), ('N', C.c_int), ('C', c_f), ('ldc', C.c_int), ('bias', c_f), ('bias2', c_f),
                 ('row_bias', c_f), ('row_bias_div', C.c_int), ('mul_mask', c_f), ('relu', C.c_int),
                 ('accumulate', C.c_int), ('partial', c_f), ('partial_capacity', C.c_int64), ('splits', C.c_int),
-                ('defer_reduce', C.c_int), ('splits_used', C.c_int), ('a_planes', c_f * MAX_SEG), ('addend', c_f)]
+                ('defer_reduce', C.c_int), ('splits_used', C.c_int), ('a_planes', c_f * MAX_SEG), ('addend', c_f),
+                ('allow_wide_deferred', C.c_int)]
 
 
 class NextEmbed(C.Structure):

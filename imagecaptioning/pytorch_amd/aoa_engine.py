@@ -324,7 +324,8 @@ class AoAGraph:
         pl_dg = ops.planes_scratch(dev, ('aoa_dg', 4 * R), int(lib.capmi_planes_bytes(4 * R))) if use_pl else None
         ws2 = _dh_workspace(dev)
         dh_slabs, dh_splits = None, 0
-        fuse = SLAB_CONSUMERS
+        # (capmi_layernorm_bwd_slabs moves rows in 16-byte pieces of at most 2 048 columns; other sizes take the r4 route)
+        fuse = SLAB_CONSUMERS and R % 4 == 0 and R <= 2048
         ws, ws3, ws4 = ops.default_workspace(dev), _dh_workspace(dev, 'ctx'), _dh_workspace(dev, 'dqn')
         ctx_splits = 0
         for t in range(T - 1, -1, -1):

@@ -66,6 +66,10 @@ def decode_image(att_dir, fc_dir, img_id, use_fc, norm_att_feat):
     return fc, a
 
 
+class EmptySplit(ValueError):
+    """this rank's partition of a split holds no image (a val split smaller than the number of data-parallel ranks)"""
+
+
 class FeatureLoader:
     def __init__(self, opt, workers=4, processes=None, lookahead=3, rank=0, world=1):
         """rank / world: data-parallel partition of every pass (below).  workers: size of the decode pool; processes: worker PROCESSES instead of threads (default: CAPMI_LOADER_PROCS=1).
@@ -201,7 +205,7 @@ class FeatureLoader:
         partial last batch (drop_last=False) and the next get_batch starts the split over (:349-354); never ``wrapped``."""
         order, out, wrapped = self.order[split], [], False
         if not order:
-            raise ValueError('split %r has no images' % split)
+            raise EmptySplit('split %r has no images' % split)
         for _ in range(B):
             if self.pos[split] >= len(order):
                 if split == 'train':

@@ -625,7 +625,7 @@ extern "C" int capmi_gemm_f32(capmi_gemm_desc *d, void *stream) {
             // owns its CU -- and a persistent grid of them beside another stream's kernels starved both (Transformer XE 14.3 ->
             // 36.5 ms); the 128 x 128 kernel leaves room for the chain's small kernels.  (Re-measured at the end of r5 with the final
             // kernels, scripts/r5_ab7.sh: wide deferred GEMMs 13.44-13.71 ms vs 13.31-13.35 -- still a loss, with 4 or 8 staging waves.)
-            if (w == 1 && env_tile != 256 && d->defer_reduce && !g_wide_deferred.load(std::memory_order_relaxed)) continue;
+            if (w == 1 && env_tile != 256 && d->defer_reduce && !d->allow_wide_deferred && !g_wide_deferred.load(std::memory_order_relaxed)) continue;
             // w == 2: SKINNY products (few rows, many columns: the per-step gate / dX GEMMs of a teacher-forced XE step at bs64,
             // [320 x 4000]) on the wide kernel with the operands SWAPPED -- the 256-row side of the tile runs along the WEIGHTS, the
             // activations are the 128-row operand, the epilogue writes C^T back as C in 16-byte pieces (x3_epilogue_t).  Row-major

@@ -90,10 +90,12 @@ __global__ void lstm_cell_fwd_kernel(const float *__restrict__ partial, int spli
                                      const float *__restrict__ b_hh, const float *__restrict__ row_bias,
                                      int row_bias_div, const int *__restrict__ row_bias_idx,
                                      const float *__restrict__ c_prev, float *__restrict__ h,
-                                     float *__restrict__ c, float *__restrict__ gates_act,
+                                     float *__restrict__ c, float *gates_act,
                                      const float *__restrict__ out_mask, float *__restrict__ h_drop, int N, int R,
                                      unsigned char *__restrict__ pl_h, unsigned char *__restrict__ pl_hd,
-                                     const float *__restrict__ partial2, int splits2) {
+                                     const float *partial2, int splits2) {
+    // (gates_act / partial2 carry no __restrict__: the batched-xt rollout hands the SAME buffer in as the second slab set and as the
+    //  activated-gates output -- every thread reads its own elements of all slabs before it stores them)
     const size_t total = (size_t)N * R;
     const size_t slab = (size_t)N * 4 * R;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -159,9 +161,9 @@ __device__ __forceinline__ f32x4 slab_seq8(const float *p, int s0, int splits, s
 __global__ __launch_bounds__(64) void lstm_cell_fwd_vec_kernel(
     const float *__restrict__ partial, int splits, const float *__restrict__ b_ih, const float *__restrict__ b_hh,
     const float *__restrict__ row_bias, int row_bias_div, const int *__restrict__ row_bias_idx,
-    const float *__restrict__ c_prev, float *__restrict__ h, float *__restrict__ c, float *__restrict__ gates_act,
+    const float *__restrict__ c_prev, float *__restrict__ h, float *__restrict__ c, float *gates_act,
     const float *__restrict__ out_mask, float *__restrict__ h_drop, int N, int R, unsigned char *__restrict__ pl_h,
-    unsigned char *__restrict__ pl_hd, const float *__restrict__ partial2, int splits2) {
+    unsigned char *__restrict__ pl_hd, const float *partial2, int splits2) {            // (gates_act may alias partial2, see above)
     const int R4 = R >> 2;
     const int i4 = blockIdx.x * blockDim.x + threadIdx.x;
     if (i4 >= N * R4) return;

@@ -51,7 +51,8 @@ def default_workspace(device):
 
 
 def gemm(segs, M, N, out, ldc=None, a_layout=0, b_layout=0, bias=None, bias2=None, row_bias=None, row_bias_div=1,
-         mul_mask=None, relu=False, accumulate=False, ws=None, splits=0, defer_reduce=False, a_planes=None, addend=None, stream=None):
+         mul_mask=None, relu=False, accumulate=False, ws=None, splits=0, defer_reduce=False, a_planes=None, addend=None, stream=None,
+         allow_wide=False):
     """segs: list of (A, lda, B, ldb, K, a_row_div) with tensors (or (tensor, element_offset) pairs).
     a_planes: optional list (one uint8 tensor per segment, see planes_from_f32) -- the activations also delivered pre-split,
     staged by LDS-DMA in the M <= 64 decode kernel.
@@ -79,6 +80,7 @@ def gemm(segs, M, N, out, ldc=None, a_layout=0, b_layout=0, bias=None, bias2=Non
         ws = default_workspace(_dev(out))
     d.partial, d.partial_capacity = ws.buf.data_ptr(), ws.capacity
     d.splits, d.defer_reduce = splits, int(defer_reduce)
+    d.allow_wide_deferred = int(allow_wide)      # (deferred GEMMs: nothing runs beside this one on another stream)
     check(lib.capmi_gemm_f32(C.byref(d), stream_ptr() if stream is None else stream), 'capmi_gemm_f32')
     return d.splits_used
 
@@ -296,8 +298,9 @@ class DeferredGrads:
                 self.state['side'] = torch.cuda.Stream(device=device)
                 self.state['events'] = []
             self.side, self.ev_pool, self.ev_used = self.state['side'], self.state['events'], 0
-        # nothing runs beside the deferred GEMMs when there is no side stream: the planner may give them 256 x 128 tiles too
-        self._policy_prev = lib.capmi_gemm_set_policy(1 if self.side is None else 0)
+        # nothing runs beside the deferred GEMMs when there is no side stream: the planner may give them 256 x 128 tiles too -- said
+        # per call (capmi_gemm_desc.allow_wide_deferred; r5 flipped the process-wide capmi_gemm_set_policy flag here, which two live
+        # instances could leave stuck: ADVICE r5)
         # r6: without a side stream the weight-gradient GEMMs are only RECORDED and go out at flush() as one grouped persistent launch
         # (capmi_gemm_group_tn); CAPMI_DW_GROUP=0 keeps one launch + deferred reduction per GEMM
         self.group = [] if (self.side is None and os.environ.get('CAPMI_DW_GROUP', '1') != '0') else None
@@ -343,7 +346,7 @@ class DeferredGrads:
             self.synced = dy
             self.keep.extend((dy, x))
         splits = gemm([(dy, M, x, N, K, 1)], M, N, out, a_layout=1, b_layout=1, ws=_WsView(region), defer_reduce=True,
-                      stream=self.side.cuda_stream if on_side else None)
+                      stream=self.side.cuda_stream if on_side else None, allow_wide=self.side is None)
         self.arena.commit(cf + splits * M * N)
         (self.red_side if on_side else self.red).append((region.data_ptr() + 4 * cf, out.data_ptr() + 4 * out_off, 0, splits, M, N, ldc,
                                                          int(bool(accumulate)), 0))
@@ -406,7 +409,6 @@ class DeferredGrads:
             t, _ = self._table('col', self.col, '<QQQiiii')
             check(lib.capmi_colsum_batch(t.data_ptr(), len(self.col), stream_ptr()), 'capmi_colsum_batch')
         self.red, self.col, self.keep = [], [], []
-        lib.capmi_gemm_set_policy(self._policy_prev)
 
     def abandon(self):
         """the backward raised: nothing is finished, but GEMMs already enqueued on the side stream may still be reading the dy / x
@@ -418,7 +420,6 @@ class DeferredGrads:
         self.red_side, self.col_side = [], []
         if self.group is not None:
             self.group = []
-        lib.capmi_gemm_set_policy(self._policy_prev)
 
 
 def linear(x, weight, bias=None, relu=False, mul_mask=None, row_div=1, rows=None, ws=None, out=None):

@@ -25,6 +25,7 @@ def validation_loss(lw_model, loader, opt, dev, world=1):
     (val_images / world, never more than its partition holds) and returns (sum of per-image losses, images) so that the caller
     can all-reduce BOTH and every image counts once, whatever the partition sizes.  A rank whose partition is empty (val split
     smaller than world) contributes (0, 0)."""
+    from captioning.data.feature_loader import EmptySplit
     model = lw_model.model
     model.eval()
     tot, n = 0.0, 0
@@ -37,7 +38,7 @@ def validation_loss(lw_model, loader, opt, dev, world=1):
         while n < want:
             try:
                 data = loader.get_batch('val')
-            except ValueError:                             # this rank's part of the split is empty
+            except EmptySplit:                             # this rank's part of the split is empty; any other error propagates
                 break
             it_max = data['bounds'].get('it_max')
             if it_max is not None:

@@ -93,6 +93,10 @@ typedef struct capmi_gemm_desc {
      * intact for the backward (x + sublayer(norm(x)), TransformerModel.py:99-102) is added in the epilogue without a copy of it
      * into C first.  Same row pitch as C; may not overlap C. */
     const float *addend;
+    /* r6: with defer_reduce, the caller states PER CALL that nothing runs beside this GEMM on another stream, so the planner may give
+     * it 256 x 128 tiles (a wide workgroup owns its CU; see capmi_gemm_set_policy, whose process-wide flag this replaces for callers
+     * that know -- ops.DeferredGrads without its side stream).  0: the process-wide policy decides. */
+    int allow_wide_deferred;
 } capmi_gemm_desc;
 
 int capmi_gemm_f32(capmi_gemm_desc *d, void *stream);

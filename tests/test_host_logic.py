@@ -339,7 +339,8 @@ def test_validation_loss_returns_sum_and_count_and_survives_an_empty_partition()
         def reset_iterator(self, split): self.pos = 0
         def get_batch(self, split):
             if self.n == 0:
-                raise ValueError('split has no images')
+                from captioning.data.feature_loader import EmptySplit
+                raise EmptySplit('split has no images')       # (any other exception must propagate: ADVICE r5)
             B = min(2, self.n - self.pos) or 2
             self.pos = (self.pos + B) % self.n if self.pos + B < self.n else 0
             z = torch.zeros(B, 1, 3)
@@ -352,6 +353,12 @@ def test_validation_loss_returns_sum_and_count_and_survives_an_empty_partition()
     assert (tot, n) == (0.0, 0)
     tot, n = T.validation_loss(LW, Loader(100), opt, 'cpu', world=1)
     assert n == 40
+
+    class Broken(Loader):                                     # a genuine data error is NOT an empty partition
+        def get_batch(self, split):
+            raise ValueError('all input arrays must have the same shape')
+    with pytest.raises(ValueError, match='same shape'):
+        T.validation_loss(LW, Broken(5), opt, 'cpu', world=4)
 
 
 @pytest.mark.parametrize('family,extra', [('transformer', dict(N_enc=1, N_dec=1, d_model=16, d_ff=32, num_att_heads=2, dropout=0.1)),
