@@ -494,7 +494,7 @@ __device__ __forceinline__ void wg_staging(GTabK t, int tid, unsigned short *sme
 
 // one wave's 64 x 64 block of a finished unit -> memory (C/D layout of the 32x32 MFMA: column = lane & 31, rows (x & 3) + 8 (x >> 2) +
 // 4 (lane >> 5)); out points at the tile's origin
-template <bool ADD, bool EDGE>
+template <bool ADD, bool EDGE, bool NT = false>
 __device__ __forceinline__ void g_store(const f32x16 (&acc)[2][2], float *out, int ldo, int vr, int vc, int wm0, int wn0, int l31, int half) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -519,7 +519,10 @@ __device__ __forceinline__ void g_store(const f32x16 (&acc)[2][2], float *out, i
                 for (int u = 0; u < 4; ++u) {
                     const int dr = u + 2 * xg;
                     const float v = ADD ? acc[i][j][xg + u] + old[u] : acc[i][j][xg + u];
-                    if (!EDGE || (col < vc && r0 + dr < vr)) o[(size_t)dr * ldo] = v;
+                    if (!EDGE || (col < vc && r0 + dr < vr)) {
+                        if (NT) __builtin_nontemporal_store(v, o + (size_t)dr * ldo);
+                        else o[(size_t)dr * ldo] = v;
+                    }
                 }
             }
         }
@@ -576,6 +579,9 @@ __global__ __launch_bounds__(1024) void gemm_x3w_group_kernel(const GTab table) 
         if (add) {
             if (edge) g_store<true, true>(acc, out, ldo, vr, vc, wm0, wn0, l31, half);
             else g_store<true, false>(acc, out, ldo, vr, vc, wm0, wn0, l31, half);
+        } else if (abl & 32) {                            // (research: streaming stores)
+            if (edge) g_store<false, true, true>(acc, out, ldo, vr, vc, wm0, wn0, l31, half);
+            else g_store<false, false, true>(acc, out, ldo, vr, vc, wm0, wn0, l31, half);
         } else {
             if (edge) g_store<false, true>(acc, out, ldo, vr, vc, wm0, wn0, l31, half);
             else g_store<false, false>(acc, out, ldo, vr, vc, wm0, wn0, l31, half);

@@ -34,7 +34,7 @@ def main():
     dev = torch.device('cuda:0')
     names = sys.argv[1:] or sorted(SETS)
     for name in names:
-        if 'x' in name:                     # MxNxKxcount: `count` identical GEMMs (unit-length sweeps: time = a + rounds * (K / 32 * s + c))
+        if name not in SETS and name.count('x') == 3:                     # MxNxKxcount: `count` identical GEMMs (unit-length sweeps: time = a + rounds * (K / 32 * s + c))
             M, N, K, cnt = (int(v) for v in name.split('x'))
             SETS[name] = [(M, N, K)] * cnt
         shapes = SETS[name]
