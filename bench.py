@@ -112,7 +112,7 @@ def pmc_traffic(instance=False):
         return None
 
 
-PMC_FILE = 'r05_pmc_traffic.json'
+PMC_FILE = 'r06_pmc_traffic.json'
 
 
 def prof_read(lib, cls):
@@ -561,13 +561,25 @@ def main():
             pstats.Stats(host_prof, stream=buf).sort_stats(key).print_stats(30)
             print('\n'.join(l[:160] for l in buf.getvalue().split('\n') if l.strip()), file=sys.stderr)
     lib.capmi_prof_enable(0)
+    graph_sample = None
+    if sampled and ts.replays and not (mode_now['overlap'] or mode_now['sharded']):
+        # a replayed hipGraph's launches cannot carry per-launch events (they are baked into the graph): for the captured
+        # configurations the roofline sample is ONE extra iteration issued launch by launch right behind the timed region -- the same
+        # launches with the same arguments (tests/test_graph_step_gpu.py), outside the K steps so that its host-bound issue does not
+        # enter ms_per_step
+        lib.capmi_prof_reset()
+        lib.capmi_prof_enable(prof_mask)
+        ts(pf.get_batch('train'), sc_flag, struc_flag, force_stepped=True)
+        torch.cuda.synchronize()
+        lib.capmi_prof_enable(0)
+        graph_sample = 'one stepped iteration right behind the timed region (the timed steps replay a hipGraph)'
     in_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     per_step = sorted(in_order)
     # `first`: the step right behind the opening synchronize -- the device starts it with an empty queue, so a host-stepped
     # configuration shows its issue latency there and nowhere else
     step_ms = {'min': round(per_step[0], 3), 'median': round(per_step[len(per_step) // 2], 3), 'max': round(per_step[-1], 3),
                'first': round(in_order[0], 3)}
-    n_sampled = max(1, len(sampled))
+    n_sampled = 1 if graph_sample else max(1, len(sampled))
     allreduce_ms = None
     if dist is not None and not overlap and not sharded:
         # collective time of the single flat all-reduce: HIP events around it on 5 extra (untimed) steps
@@ -634,11 +646,11 @@ def main():
         all_ms, all_n, all_bytes = s_ms + g_ms, s_n + g_n, s_bytes + g_bytes
         a_ms, a_n, a_bytes, _ = prof_read(lib, 3)
         f_ms, f_n, f_bytes, f_flops = prof_read(lib, 2)      # fat GEMMs (sampled only for the XE configurations)
-        per_class = {'sampled_steps': sorted(sampled),
+        per_class = {'sampled_steps': graph_sample or sorted(sampled),
                      'gemm_decode_stream': {'ms_per_step': round(g_ms / n_sampled, 4), 'launches_per_step': g_n / n_sampled},
                      'gemm_decode_small': {'ms_per_step': round(s_ms / n_sampled, 4), 'launches_per_step': s_n / n_sampled},
                      'attention_fwd': {'ms_per_step': round(a_ms / n_sampled, 4), 'launches_per_step': a_n / n_sampled},
-                     'note': 'full per-kernel table: profiles/r05_scst_kernel_stats.md (rocprofv3 --kernel-trace --stats)'}
+                     'note': 'full per-kernel table: profiles/r06_scst_kernel_stats.md (rocprofv3 --kernel-trace --stats)'}
         ach = (g_bytes / g_n) / (g_ms / g_n * 1e-3) / 1e9 if g_n else 0.0
         tfl = g_flops / (g_ms * 1e-3) / 1e12 if g_ms else 0.0
         # which roof bounds this launch mix.  The decode GEMMs compute fp32 through the bf16 pipe by the exact 3-way
@@ -705,7 +717,7 @@ def main():
                         'ms_per_step': round(f_ms / n_sampled, 4),
                         'note': 'fp32-equivalent FLOPs (2 M N K) over the in-dispatch HIP-event time of every fat GEMM launch of the '
                                 'sampled steps; the bf16 pipe executes 6x as many'}
-            if args.config == 'transformer_xe' and os.environ.get('CAPMI_DW_STREAM', '1') != '0':
+            if args.config == 'transformer_xe' and os.environ.get('CAPMI_DW_STREAM', '0') == '1':
                 roofline['concurrency_note'] = ('r4: the weight-gradient GEMMs run on a side stream beside the dX chain (ops.DeferredGrads), so fat '
                                                 'GEMMs overlap and each launch takes longer than it does alone: the step is 7 % faster, the per-launch '
                                                 'rate reads lower (0.28 with CAPMI_DW_STREAM=0, profiles/r04e_txe_kernel_stats.md)')

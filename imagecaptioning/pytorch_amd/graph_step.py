@@ -134,13 +134,15 @@ class TrainStep:
                 dst.cooked.copy_(packed.cooked, non_blocking=True)
 
     # ------------------------------------------------------------------ public
-    def __call__(self, data, sc_flag=False, struc_flag=False, lr=None, drop_worst_flag=False):
-        """-> (loss 0-dim device tensor, dict of the LossWrapper's tensor outputs).  `data`: the loader's batch dict on the device."""
+    def __call__(self, data, sc_flag=False, struc_flag=False, lr=None, drop_worst_flag=False, force_stepped=False):
+        """-> (loss 0-dim device tensor, dict of the LossWrapper's tensor outputs).  `data`: the loader's batch dict on the device.
+        force_stepped: run THIS iteration launch by launch even when a graph of its shape exists (same numbers; the launches of a
+        replayed graph cannot carry the per-launch HIP events bench.py's roofline sample needs)."""
         o = self.opt
         self.state.set_lr(o.learning_rate if lr is None else lr)
         self.flat.step_count += 1
         multi = self.all_reduce is not None
-        graphable = self.graph and self.failed is None and not drop_worst_flag and getattr(self.model, 'ss_prob', 0.0) == 0.0 \
+        graphable = self.graph and not force_stepped and self.failed is None and not drop_worst_flag and getattr(self.model, 'ss_prob', 0.0) == 0.0 \
             and self.flat.on_grads_ready is None
         ent = None
         if graphable:

@@ -269,7 +269,8 @@ class DeferredGrads:
     before flush(), and every kernel of the chain leaves CUs idle at its tail (212 or 636 tiles of a d_model-wide GEMM on 256 CUs)
     or altogether (MHA, LayerNorm, masks).  The GEMMs follow their operands by an event; the reductions and column sums go out in
     batches of SIDE_BATCH items behind them instead of as two launches at the very end of the backward.  Transformer XE 15.3 ->
-    14.3 ms per step with the GEMMs alone (A/B inside one gpurun call; CAPMI_DW_STREAM=0 restores one stream and one flush)."""
+    14.3 ms per step with the GEMMs alone (A/B inside one gpurun call).
+    r6: superseded as the default by the grouped launch (see __init__); CAPMI_DW_STREAM=1 opts back in."""
 
     _arenas = {}
     uploads = 0
@@ -286,13 +287,12 @@ class DeferredGrads:
         self.red, self.col, self.keep = [], [], []
         self.red_side, self.col_side, self.side_batches, self.synced = [], [], 0, None
         self.side = None
-        # r5: re-measured with the final kernels -- the side stream is worth 2-5 % of the Transformer step (13.45-13.69 vs 13.79-13.90 ms,
-        # 13.0 vs 13.8, 13.85 vs 14.35 on three boxes; profiles/r05_fat_gemm_wide.md section 7); CAPMI_DW_STREAM=0 runs the deferred
-        # GEMMs in line on one stream (they may then use 256 x 128 tiles too, see below)
-        # (r6: inside a graph capture the side stream CAN join -- its first event wait forks it into the capture, flush() joins it
-        #  back, the deferred GEMMs become a parallel branch of the graph -- but replayed that branch LOSES: Transformer XE 23.24 vs
-        #  22.76 ms, AoA nsc 7.03 vs 6.43 (gpurun_out/r6d, same box); CAPMI_DW_STREAM_CAPTURE=1 opts in)
-        if os.environ.get('CAPMI_DW_STREAM', '1') != '0' and torch.cuda.is_available() and \
+        # r5: the side stream was worth 2-5 % of the Transformer step beside one launch + deferred reduction per GEMM (profiles/
+        # r05_fat_gemm_wide.md section 7).  r6: the GROUPED launch at flush() beats it in both issue modes (stepped 20.81 vs 20.98 ms,
+        # captured 20.70 vs 22.78 / 23.24 with the side stream forked into the capture; gpurun_out/r6d, r6e) -- the side stream is
+        # opt-in now (CAPMI_DW_STREAM=1; inside a graph capture additionally CAPMI_DW_STREAM_CAPTURE=1), and the stepped and the
+        # captured step issue exactly the same launches
+        if os.environ.get('CAPMI_DW_STREAM', '0') == '1' and torch.cuda.is_available() and \
                 (not torch.cuda.is_current_stream_capturing() or os.environ.get('CAPMI_DW_STREAM_CAPTURE', '0') == '1'):
             if 'side' not in self.state:
                 self.state['side'] = torch.cuda.Stream(device=device)
