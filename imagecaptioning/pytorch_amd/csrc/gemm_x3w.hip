@@ -24,6 +24,7 @@
 #include "profile.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace capmi_gemm {
 namespace {
@@ -344,6 +345,15 @@ __global__ __launch_bounds__(512 + 64 * NSW) void gemm_x3w_kernel(const KArgs a,
 typedef const GTab __attribute__((address_space(4))) *GTabK;
 typedef const GItem __attribute__((address_space(4))) *GItemK;
 
+#ifdef CAPMI_VARIANTS
+// CAPMI_GROUP_TRACE=1 (variants build): workgroup 0's first MFMA wave stamps s_memtime behind every K tile, before and behind every
+// epilogue; launch_x3w_group synchronises and prints the gaps (where does a unit spend time outside its K loop?)
+__device__ unsigned long long g_group_trace[4096];
+#define GROUP_STAMP(i) do { const int i_ = (i); if (trace && i_ < 4096) g_group_trace[i_] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GROUP_STAMP(i) do { } while (0)
+#endif
+
 struct GUnit {
     int e;                  // table entry
     int m0, n0, t_begin, nt, z, tl;
@@ -550,6 +560,10 @@ __global__ __launch_bounds__(1024) void gemm_x3w_group_kernel(const GTab table) 
         }
     __syncthreads();                                       // stage 0 ready
     const int abl = t->reserved;                            // (CAPMI_GROUP_ABLATE, variants builds: profiling ablations; 0 otherwise)
+#ifdef CAPMI_VARIANTS
+    const bool trace = (abl & 64) && blockIdx.x == 0 && threadIdx.x == 0;
+    int ts = 0;
+#endif
     int g = 0, ent = 0;
     for (int r = 0; blockIdx.x + r * (int)gridDim.x < t->units; ++r) {
         const GUnit un = g_unit_of(t, g_unit_index(r, t->units), ent);
@@ -560,9 +574,11 @@ __global__ __launch_bounds__(1024) void gemm_x3w_group_kernel(const GTab table) 
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+        GROUP_STAMP(ts++);                                  // unit start
         for (int i = 0; i < un.nt; ++i, ++g) {
             const unsigned short *As = smem + (g & 1) * WSTAGE, *Bs = As + 3 * WPL_A;
             w_ktile(acc, As, Bs, offA, offB, (abl & 8) ? true : (abl & 16) ? wid < 4 : false, (abl & 2) != 0);
+            GROUP_STAMP(ts++);                              // behind K tile i
         }
         // ---- epilogue: whole-K units write (or add to) C; K slices leave their [256 x 128] piece in the entry's slab
         GItemK it = &t->it[un.e];
@@ -586,6 +602,7 @@ __global__ __launch_bounds__(1024) void gemm_x3w_group_kernel(const GTab table) 
             if (edge) g_store<false, true>(acc, out, ldo, vr, vc, wm0, wn0, l31, half);
             else g_store<false, false>(acc, out, ldo, vr, vc, wm0, wn0, l31, half);
         }
+        GROUP_STAMP(ts++);                                  // behind the epilogue's stores (issued, not landed)
     }
 }
 
@@ -681,6 +698,26 @@ int launch_x3w_group(const GTab &t, hipStream_t st, int pcls, double bytes, doub
     if (prof) hipExtLaunchKernelGGL((gemm_x3w_group_kernel<false, false>), grid, dim3(1024), lds, st, e0, e1, 0, t);
     else hipLaunchKernelGGL((gemm_x3w_group_kernel<false, false>), grid, dim3(1024), lds, st, t);
     CAPMI_CHECK_LAUNCH();
+#ifdef CAPMI_VARIANTS
+    if (t.reserved & 64) {
+        (void)hipStreamSynchronize(st);
+        static unsigned long long h[4096];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_group_trace), sizeof(h));
+        // unit layout of workgroup 0: [start, K tiles..., after epilogue] per unit; units of workgroup 0 = rounds
+        int idx = 0;
+        fprintf(stderr, "capmi group trace (workgroup 0, s_memtime ticks):\n");
+        for (int r = 0; r * (int)grid.x < t.units && idx < 4000; ++r) {
+            // nt of this unit is not known here: print until the next start marker by scanning for the largest gap pattern is fragile --
+            // so print raw deltas, 16 per line, with the index
+            (void)r;
+        }
+        for (int i = 1; i < 4096 && h[i]; ++i) {
+            if ((i - 1) % 16 == 0) fprintf(stderr, "\n%5d:", i);
+            fprintf(stderr, " %6llu", h[i] - h[i - 1]);
+        }
+        fprintf(stderr, "\n");
+    }
+#endif
     if (t.rtiles > 0) {
         hipLaunchKernelGGL(x3w_group_reduce_kernel, dim3(t.rtiles), dim3(256), 0, st, t);
         CAPMI_CHECK_LAUNCH();
