@@ -708,7 +708,7 @@ extern "C" int capmi_gemm_group_tn(capmi_group_gemm *items, int n, float *slabs,
     for (int i = 0; i < n; ++i) {
         capmi_group_gemm &g = items[i];
         if (!g.A || !g.B || !g.C || g.K <= 0 || g.M <= 0 || g.N <= 0) return CAPMI_EINVAL;
-        const bool ok = env_group && BK == 32 && g.M % 4 == 0 && g.N % 4 == 0 && g.K % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
+        const bool ok = env_group && BK == 32 && g.M % 4 == 0 && g.N % 4 == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 &&       // (any K, r6)
                         g.ldc % 4 == 0 && aligned16(g.A) && aligned16(g.B) && aligned16(g.C) && aligned16(g.colsum) &&
                         (uint64_t)g.lda * 16 * 4 + (uint64_t)g.M * 4 < (1ull << 32) && (uint64_t)g.ldb * 16 * 4 + (uint64_t)g.N * 4 < (1ull << 32);
         if (ok) order[n_ok++] = i;

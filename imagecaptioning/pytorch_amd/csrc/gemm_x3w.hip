@@ -79,10 +79,19 @@ struct WStager {
             const size_t ld4 = (size_t)ld * 4;
             gcb b = src + (size_t)k0 * ld4;
             f32x4 v[4];
+            if ((K & 3) && k0 + BK > K) {
+                // r6: K is not a multiple of 4 and this is its last tile (workgroup-uniform branch; the one register set of this kernel
+                // is waited for as a whole anyway): k rows at or past K are redirected to row K - 1 -- always valid memory -- and zeroed
+                // element by element when the registers are split.  (K = T * N rows of a rollout: 50 rows x an odd step count.)
+                const int kb = inside ? k0 + kq0 : k0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = *(gcf4)(b + off);
-                b += ld4;
+                for (int j = 0; j < 4; ++j) v[j] = *(gcf4)(src + (size_t)min(kb + j, K - 1) * ld4 + voff0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = *(gcf4)(b + off);
+                    b += ld4;
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -107,11 +116,11 @@ __device__ __forceinline__ void w_r2s(const float (&r)[16], unsigned short *dst,
             row = 4 * ((tid >> 6) * 8 + (lane & 7)) + p;
             kq = 4 * (lane >> 3);
         }
-        // K % 4 == 0 (host checks): a quad of k is entirely inside or outside K
-        const float fac = (!EDGE || (row < valid_rows && kq < valid_k)) ? 1.f : 0.f;
+        // element j of the quad is k = kq + j (K % 4 != 0 is allowed for [K][rows] operands: the last quad may be cut)
         uint32_t h[4], m[4], l[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            const float fac = (!EDGE || (row < valid_rows && kq + j < valid_k)) ? 1.f : 0.f;
             const float x = EDGE ? r[4 * p + j] * fac : r[4 * p + j];
             h[j] = fbits(x);
             const float r1 = x - bfloat(h[j] & 0xffff0000u);            // exact
@@ -453,12 +462,14 @@ __device__ __forceinline__ void wg_staging(GTabK t, int tid, unsigned short *sme
     // 128-column block, r[4 i + j] = A[k0 + 4kg + j][4mq + i]); summed over the unit's K tiles in order, then over kg by lane shuffles
     float cs0[4] = {0.f, 0.f, 0.f, 0.f}, cs1[4] = {0.f, 0.f, 0.f, 0.f};
     auto colsum_step = [&](const float (&xa0)[16], const float (&xa1)[16], const GEdge &ed) {
-        const int lane = tid & 63;
-        const float fac = (4 * (lane >> 3) < ed.w.vk) ? 1.f : 0.f;           // a thread's quad of k is entirely inside or outside K
+        const int lane = tid & 63, kq = 4 * (lane >> 3);
+        float f[4];                                                          // k = kq + j inside K?  (all ones except in the last tile)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = kq + j < ed.w.vk ? 1.f : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            cs0[i] += ((xa0[4 * i] + xa0[4 * i + 1]) + (xa0[4 * i + 2] + xa0[4 * i + 3])) * fac;
-            cs1[i] += ((xa1[4 * i] + xa1[4 * i + 1]) + (xa1[4 * i + 2] + xa1[4 * i + 3])) * fac;
+            cs0[i] += (xa0[4 * i] * f[0] + xa0[4 * i + 1] * f[1]) + (xa0[4 * i + 2] * f[2] + xa0[4 * i + 3] * f[3]);
+            cs1[i] += (xa1[4 * i] * f[0] + xa1[4 * i + 1] * f[1]) + (xa1[4 * i + 2] * f[2] + xa1[4 * i + 3] * f[3]);
         }
         if (!ed.last) return;
 #pragma unroll

@@ -187,12 +187,25 @@ int capmi_newfc_rollout_bwd(const capmi_newfc_weights *w, const capmi_newfc_roll
         RC(capmi_logsoftmax_bwd_sparse(&sp, g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
     } else if (s->sparse) RC(capmi_logsoftmax_bwd_sparse(s->sparse, g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
     else RC(capmi_logsoftmax_bwd(g_seq_logp, r->seq_logp, r->live, s->dlogits, N, L, T, V1, stream));
+    static const int env_group = capmi::knob("CAPMI_GEMM_GROUP", 1);
+    const bool grouped = env_group != 0;
+    capmi_group_gemm grp[3];
+    int n_grp = 0;
     {
         SegSpec a{s->dlogits, V1, w->logit_w, R, V1, 1};
         RC(gemm(stream, 0, 1, TN, R, s->d_hdrop, R, &a, 1, P, cap, 0, nullptr));
-        SegSpec b{s->dlogits, V1, r->h_drop, R, TN, 1};
-        RC(gemm(stream, 1, 1, V1, R, g->logit_w, R, &b, 1, P, cap, 0, nullptr));
-        RC(capmi_colsum(s->dlogits, TN, V1, V1, g->logit_b, 0, stream));
+        // r6: the three time-batched weight gradients (logit, i2h, h2h: K = T * N rows -- 1 050 at bs10 x 5, not a multiple of 4, which
+        // sent them to the exact-fp32 tile kernel: 263 us of a 1.9-ms step) are listed and go out as ONE grouped launch at the end;
+        // the logit bias gradient rides in it.  CAPMI_GEMM_GROUP=0: one launch each, as before.
+        if (grouped) {
+            grp[n_grp++] = capmi_group_gemm{s->dlogits, r->h_drop, g->logit_w, V1, R, R, TN, V1, R, 0, 0,
+                                            (reinterpret_cast<uintptr_t>(g->logit_b) & 15) == 0 ? g->logit_b : nullptr};
+            if (!grp[n_grp - 1].colsum) RC(capmi_colsum(s->dlogits, TN, V1, V1, g->logit_b, 0, stream));
+        } else {
+            SegSpec b{s->dlogits, V1, r->h_drop, R, TN, 1};
+            RC(gemm(stream, 1, 1, V1, R, g->logit_w, R, &b, 1, P, cap, 0, nullptr));
+            RC(capmi_colsum(s->dlogits, TN, V1, V1, g->logit_b, 0, stream));
+        }
     }
     for (int t = T - 1; t >= -1; --t) {
         const bool last = (t == T - 1);
@@ -215,10 +228,11 @@ int capmi_newfc_rollout_bwd(const capmi_newfc_weights *w, const capmi_newfc_roll
     const float *ds_words = s->d_sums + (size_t)N * 5 * R;
     {
         SegSpec a{ds_words, 5 * R, r->x, E, TN, 1};                       // dW_i2h (words)
-        RC(gemm(stream, 1, 1, 5 * R, E, g->i2h_w, E, &a, 1, P, cap, 0, nullptr));
+        if (!grouped) RC(gemm(stream, 1, 1, 5 * R, E, g->i2h_w, E, &a, 1, P, cap, 0, nullptr));
         // + image step: x = fc_emb[row / n]  -> materialise d_ximg and use the row-shared operand through a_row_div
+        // (grouped: the image step WRITES the gradient here and the words' product is added to it by the grouped launch)
         capmi_gemm_desc d{};
-        d.nseg = 1; d.a_layout = 1; d.b_layout = 1; d.M = 5 * R; d.N = E; d.C = g->i2h_w; d.ldc = E; d.accumulate = 1;
+        d.nseg = 1; d.a_layout = 1; d.b_layout = 1; d.M = 5 * R; d.N = E; d.C = g->i2h_w; d.ldc = E; d.accumulate = grouped ? 0 : 1;
         d.partial = P; d.partial_capacity = cap;
         // A = d_sums(image) [N,5R] stored [K=N][M]; B must be [K=N][E] = fc_emb repeated: expand once into d_x scratch
         // (N*E floats, tiny) with the embed kernel's gather: rows r -> fc_emb[r / n]
@@ -237,7 +251,10 @@ int capmi_newfc_rollout_bwd(const capmi_newfc_weights *w, const capmi_newfc_roll
         if (e != hipSuccess) return (int)e;
         // dW_h2h: h_prev of word step t is slot t+1; of the image step it is slot 0 (zeros) -> words only
         SegSpec c{ds_words, 5 * R, r->h + NR, R, TN, 1};
-        RC(gemm(stream, 1, 1, 5 * R, R, g->h2h_w, R, &c, 1, P, cap, 0, nullptr));
+        if (grouped) {
+            grp[n_grp++] = capmi_group_gemm{ds_words, r->x, g->i2h_w, 5 * R, E, E, TN, 5 * R, E, 1, 0, nullptr};
+            grp[n_grp++] = capmi_group_gemm{ds_words, r->h + NR, g->h2h_w, 5 * R, R, R, TN, 5 * R, R, 0, 0, nullptr};
+        } else RC(gemm(stream, 1, 1, 5 * R, R, g->h2h_w, R, &c, 1, P, cap, 0, nullptr));
         // word embeddings (plain Embedding: no ReLU, no dropout)
         SegSpec x{ds_words, 5 * R, w->i2h_w, E, 5 * R, 1};
         RC(gemm(stream, 0, 1, TN, E, s->d_x_all, E, &x, 1, P, cap, 0, nullptr));
@@ -245,6 +262,8 @@ int capmi_newfc_rollout_bwd(const capmi_newfc_weights *w, const capmi_newfc_roll
         if (e != hipSuccess) return (int)e;
         RC(capmi_embed_bwd(r->it_all, s->d_x_all, nullptr, nullptr, g->embed, TN, E, 0, stream));
     }
+    if (n_grp) RC(capmi_gemm_group_tn(grp, n_grp, cap > CAPMI_WS_COUNTER_FLOATS ? P + CAPMI_WS_COUNTER_FLOATS : nullptr,
+                                      cap > CAPMI_WS_COUNTER_FLOATS ? cap - CAPMI_WS_COUNTER_FLOATS : 0, stream));
     return 0;
 }
 

@@ -115,7 +115,7 @@ int capmi_gemm_set_policy(int allow_wide_deferred);
  * tiles straight into C, the last partial round is cut into K slices ([256 x 128] pieces in `slabs`, <= 256 of them per launch)
  * that a small second launch sums -- instead of n sub-wave grids with a K split, a slab round trip and a prologue / tail each.
  * The item table travels in the kernel arguments (no device table, no upload: the call is capturable into a hipGraph); more than
- * ~40 items go out as several launches, longest K first.  Items the fat kernel cannot take (M, N or K not a multiple of 4, unaligned
+ * ~40 items go out as several launches, longest K first.  Items the fat kernel cannot take (M or N not a multiple of 4 -- any K is fine --, unaligned
  * operands / pitches) are issued through capmi_gemm_f32 behind the group.  Same numbers, bit for bit, as capmi_gemm_f32 on each
  * item with the K split reported in splits_used.
  * slabs / slab_floats: scratch for the K-slice pieces (>= 8.4 M floats serves any group; less only limits the tail's K split). */

@@ -41,6 +41,8 @@ SETS = {
     'small': [(512, 512, 2304), (1024, 256, 640)],
     # ragged edges, mixed K, an item the fat kernel cannot take (N % 4 != 0 -> capmi_gemm_f32 behind the group)
     'ragged': [(260, 132, 100), (1028, 516, 1000), (300, 200, 36), (128, 130, 64), (4, 4, 4)],
+    # K not a multiple of 4 (r6: T * N rows of a rollout -- 50 rows x an odd number of steps): the last K tile's quads are cut
+    'odd_k': [(4000, 1000, 950), (512, 1000, 1050), (1000, 512, 1050), (256, 128, 37), (128, 128, 3), (512, 512, 2302)],
     # more items than one table holds (two launches, longest K first)
     'many': [(256, 128, 64 * (1 + i % 5)) for i in range(60)],
 }
@@ -57,10 +59,12 @@ def test_group_matches_fp64(dev, name):
         e_ours = float(((out.double() - ref).abs() / (mag + 1e-30)).max())
         e_fp32 = float((((dy.t() @ x).double() - ref).abs() / (mag + 1e-30)).max())
         assert torch.isfinite(out).all()
-        assert e_ours <= 1.5 * e_fp32 + 1e-7, (name, tuple(out.shape), e_ours, e_fp32)
+        # (the dropped cross terms of the 3-way split are <= 3 * 2^-24 |a||b| = 1.8e-7 PER PRODUCT: with a handful of products -- K = 3 --
+        #  nothing averages, the bound itself is what is seen)
+        assert e_ours <= 1.5 * e_fp32 + (1e-7 if dy.shape[0] >= 32 else 4e-7), (name, tuple(out.shape), e_ours, e_fp32)
 
 
-@pytest.mark.parametrize('name', ['scst', 'txe_layer', 'small', 'ragged', 'many'])
+@pytest.mark.parametrize('name', ['scst', 'txe_layer', 'small', 'ragged', 'many', 'odd_k'])
 def test_group_column_sums_ride_along(dev, name):
     """capmi_group_gemm.colsum: the bias gradient (column sums of dY) taken by the staging waves of an item's first column tiles --
     whole-K units, K-sliced tail units (pieces + the reduction launch) and items that fall back to capmi_gemm_f32; the products
