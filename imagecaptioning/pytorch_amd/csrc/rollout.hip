@@ -528,12 +528,12 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
     // tail) instead of eight sub-wave grids (profiles/r05_scst_kernel_stats.md: 10 launches of gemm_x3_kernel<false,false>, 446 us).
     // CAPMI_GEMM_GROUP=0 restores them.
     static const int env_group = capmi::knob("CAPMI_GEMM_GROUP", 1);
-    capmi_group_gemm grp[8];
+    capmi_group_gemm grp[9];
     int n_grp = 0;
     const bool grouped = env_group && (phases & CAPMI_BWD_ALL) == CAPMI_BWD_ALL && !side_st;
     auto dw_one = [&](void *strm, int Mw, int Nw, float *Cw, int ldcw, const float *Aw, int ldaw, const float *Bw, int ldbw, int Kw, int acc,
                       float *Pw, int64_t capw) -> int {
-        if (grouped && !acc && n_grp < 8) {
+        if (grouped && !acc && n_grp < 9) {
             grp[n_grp++] = capmi_group_gemm{Aw, Bw, Cw, ldaw, ldbw, ldcw, Kw, Mw, Nw, 0, 0, nullptr};
             return 0;
         }
@@ -732,8 +732,8 @@ int capmi_updown_rollout_bwd_phases(const capmi_updown_weights *w, const capmi_u
         hipError_t e;
         // fc columns: sum over time and over the n rows of an image first
         RC(capmi_group_rowsum(s->dg_att, T, (int64_t)N * 4 * R, B, n, 4 * R, s->sum_dg_att, stream));
-        SegSpec d{s->sum_dg_att, 4 * R, r->fc, R, B, 1};
-        RC(gemm(stream, 1, 1, 4 * R, R, g->att_w_ih + R, ld_att_ih, &d, 1, P, cap, 0, nullptr));
+        // (K = B rows: listed for the grouped launch like the time-batched ones -- any K since r6)
+        RC(dw_one(stream, 4 * R, R, g->att_w_ih + R, ld_att_ih, s->sum_dg_att, 4 * R, r->fc, R, B, 0, P, cap));
         if (g->d_fc) {
             SegSpec f{s->sum_dg_att, 4 * R, w->att_w_ih + R, ld_att_ih, 4 * R, 1};
             RC(gemm(stream, 0, 1, B, R, g->d_fc, R, &f, 1, P, cap, 0, nullptr));

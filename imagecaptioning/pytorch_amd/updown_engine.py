@@ -90,20 +90,30 @@ def prepare_backward(P, pr, d_fc, d_att, d_p_att, grads, ws=None):
     A = pr.p_att.shape[2]
     dp = d_p_att.view(B * K, A)
     att2d = pr.att.view(B * K, R)
+    # r6: the three weight gradients (K = B * regions rows / B rows) with their bias gradients as ONE grouped launch at the end
+    # (ops.gemm_group_tn: 144 tiles of one round instead of three sub-wave GEMMs + reductions + three column sums);
+    # CAPMI_PREP_GROUP=0: one launch each, as in r5
+    group = [] if os.environ.get('CAPMI_PREP_GROUP', '1') != '0' else None
+
+    def dw(dy, x, wname, bname):
+        if group is not None and grads[bname].data_ptr() % 16 == 0:
+            group.append((dy, x, grads[wname], False, None, 0, grads[bname]))
+        else:
+            ops.matmul_tn(dy, x, out=grads[wname], ws=ws)
+            ops.colsum(dy, out=grads[bname])
     # ctx2att: p_att = att W^T + b
-    ops.matmul_tn(dp, att2d, out=grads['ctx2att.weight'], ws=ws)
-    ops.colsum(dp, out=grads['ctx2att.bias'])
+    dw(dp, att2d, 'ctx2att.weight', 'ctx2att.bias')
     d_att_total = d_att.view(B * K, R)
     ops.gemm([(dp, A, P['ctx2att.weight'], R, A, 1)], B * K, R, d_att_total, a_layout=0, b_layout=1, accumulate=True, ws=ws)
     # att_embed: att = drop(relu(x W^T + b))
     # relu gate: pre-activation > 0  <=>  relu output > 0; with dropout the saved output may be zero for kept
     # units only if relu clipped, and for dropped units the mask already zeroes the gradient.
     d_pre = _relu_drop_bwd(d_att_total, att2d, None if pr.drop_att is None else pr.drop_att.view(B * K, R))
-    ops.matmul_tn(d_pre, pr.att_in.view(B * K, -1), out=grads['att_embed.0.weight'], ws=ws)
-    ops.colsum(d_pre, out=grads['att_embed.0.bias'])
+    dw(d_pre, pr.att_in.view(B * K, -1), 'att_embed.0.weight', 'att_embed.0.bias')
     d_pre_fc = _relu_drop_bwd(d_fc, pr.fc, pr.drop_fc)
-    ops.matmul_tn(d_pre_fc, pr.fc_in, out=grads['fc_embed.0.weight'], ws=ws)
-    ops.colsum(d_pre_fc, out=grads['fc_embed.0.bias'])
+    dw(d_pre_fc, pr.fc_in, 'fc_embed.0.weight', 'fc_embed.0.bias')
+    if group:
+        ops.gemm_group_tn(group, ws=ws, cache_key=('updown_prepare', str(dp.device)))
 
 
 def _relu_drop_bwd(dy, y_saved, mask):
