@@ -521,9 +521,12 @@ def main():
     # ONE of the K timed steps (two from K = 40 up) carries the events: a whole step is every launch position of the dominant kernel
     # exactly once (41 of the streaming decode GEMMs in the SCST step), and its 0.5 ms is 0.6 % of a 20-step region (r5: two sampled
     # steps were 1.2 %: 4.16 vs 4.21 ms with and without `--no-prof`, `scripts/r5_ab12.sh`).
-    prof_mask = (1 << 0) | (1 << 3) | (1 << 9)          # decode GEMMs (small / streaming) + fused attention
-    if args.config in ('updown_xe', 'transformer_xe', 'newfc_xe'):
-        prof_mask |= (1 << 2)                           # the time-batched fat GEMMs are the dominant kernels of the XE steps
+    # r6: INSIDE the timed region only the class of the dominant kernel carries events (41 launches of the SCST step instead of 103:
+    # the sampled step costs 0.2 ms instead of 0.5); the companion objects of the line (`all_decode_gemms`, `attention`) are sampled
+    # on ONE extra step right behind the region (`extra_mask`)
+    xe_cfg = args.config in ('updown_xe', 'transformer_xe', 'newfc_xe')
+    prof_mask = (1 << 2) if xe_cfg else (1 << 9)        # fat GEMMs (XE steps) / the weight-streaming decode GEMMs
+    extra_mask = (1 << 0) | (1 << 3) | ((1 << 9) if xe_cfg else 0)      # small decode GEMMs, fused attention (+ streaming ones of an XE step)
     if args.no_prof:
         sampled = set()
     elif args.steps >= 40:
@@ -568,18 +571,25 @@ def main():
         # launches with the same arguments (tests/test_graph_step_gpu.py), outside the K steps so that its host-bound issue does not
         # enter ms_per_step
         lib.capmi_prof_reset()
-        lib.capmi_prof_enable(prof_mask)
+        lib.capmi_prof_enable(prof_mask | extra_mask)
         ts(pf.get_batch('train'), sc_flag, struc_flag, force_stepped=True)
         torch.cuda.synchronize()
         lib.capmi_prof_enable(0)
         graph_sample = 'one stepped iteration right behind the timed region (the timed steps replay a hipGraph)'
+    elif sampled:
+        lib.capmi_prof_enable(extra_mask)               # the companion classes: one extra step, outside the K timed ones
+        step()
+        torch.cuda.synchronize()
+        lib.capmi_prof_enable(0)
     in_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     per_step = sorted(in_order)
     # `first`: the step right behind the opening synchronize -- the device starts it with an empty queue, so a host-stepped
     # configuration shows its issue latency there and nowhere else
     step_ms = {'min': round(per_step[0], 3), 'median': round(per_step[len(per_step) // 2], 3), 'max': round(per_step[-1], 3),
                'first': round(in_order[0], 3)}
-    n_sampled = 1 if graph_sample else max(1, len(sampled))
+    n_sampled = 1 if graph_sample else max(1, len(sampled))      # steps behind the dominant class's totals
+    n_extra = 1                                                   # ... behind the companion classes'
+    n_g = n_extra if xe_cfg else n_sampled                        # ... behind the streaming decode GEMMs'
     allreduce_ms = None
     if dist is not None and not overlap and not sharded:
         # collective time of the single flat all-reduce: HIP events around it on 5 extra (untimed) steps
@@ -647,9 +657,10 @@ def main():
         a_ms, a_n, a_bytes, _ = prof_read(lib, 3)
         f_ms, f_n, f_bytes, f_flops = prof_read(lib, 2)      # fat GEMMs (sampled only for the XE configurations)
         per_class = {'sampled_steps': graph_sample or sorted(sampled),
-                     'gemm_decode_stream': {'ms_per_step': round(g_ms / n_sampled, 4), 'launches_per_step': g_n / n_sampled},
-                     'gemm_decode_small': {'ms_per_step': round(s_ms / n_sampled, 4), 'launches_per_step': s_n / n_sampled},
-                     'attention_fwd': {'ms_per_step': round(a_ms / n_sampled, 4), 'launches_per_step': a_n / n_sampled},
+                     'gemm_decode_stream': {'ms_per_step': round(g_ms / n_g, 4), 'launches_per_step': g_n / n_g},
+                     'gemm_decode_small': {'ms_per_step': round(s_ms / n_extra, 4), 'launches_per_step': s_n / n_extra},
+                     'attention_fwd': {'ms_per_step': round(a_ms / n_extra, 4), 'launches_per_step': a_n / n_extra},
+                     'companion_sample': 'gemm_decode_small / attention_fwd: one extra step right behind the timed region',
                      'note': 'full per-kernel table: profiles/r06_scst_kernel_stats.md (rocprofv3 --kernel-trace --stats)'}
         ach = (g_bytes / g_n) / (g_ms / g_n * 1e-3) / 1e9 if g_n else 0.0
         tfl = g_flops / (g_ms * 1e-3) / 1e12 if g_ms else 0.0
@@ -668,7 +679,7 @@ def main():
                                'consumer waves split the weights and run v_mfma_f32_32x32x16_bf16)') if lc else
                               ('gemm_ares_kernel<true,6,2> (decode-step GEMMs, activations resident in LDS, %s)'
                                % ('fp32 via exact bf16x3 split, v_mfma_f32_32x32x16_bf16' if x3 else 'v_mfma_f32_32x32x2_f32')),
-                    'launches_per_step': g_n / n_sampled, 'sampled_launches': g_n,
+                    'launches_per_step': g_n / n_g, 'sampled_launches': g_n,
                     'launch_mix_note': 'r4: 41 launches per iteration stream >= 24 MB (this object); 19 attention-LSTM gate GEMMs are down '
                                        'to their 17-MB token-embedding segment because the other 32 MB run inside the select launch '
                                        '(select_gemm_kernel) -- counted in all_decode_gemms; under the round-3 rule (>= 16 MB) frac reads 0.31',
@@ -685,7 +696,7 @@ def main():
                     'algorithmic_flops_per_launch': round(g_flops / max(g_n, 1)),
                     'flop_per_byte': round(ai, 2), 'hbm_gbs': round(ach, 1), 'hbm_frac': round(ach / HBM_PEAK_GBS, 4),
                     'mfma_tflops': round(tfl, 2), 'mfma_frac': round(tfl / mfma_peak, 4), 'mfma_peak_tflops': round(mfma_peak, 1),
-                    'all_decode_gemms': {'launches_per_step': all_n / n_sampled, 'avg_launch_us': round(all_ms / max(all_n, 1) * 1e3, 2),
+                    'all_decode_gemms': {'launches_per_step': s_n / n_extra + g_n / n_g, 'avg_launch_us': round(all_ms / max(all_n, 1) * 1e3, 2),
                                          'algorithmic_bytes_per_launch': round(all_bytes / max(all_n, 1)),
                                          'achieved': round(all_ach, 1), 'frac': round(all_ach / HBM_PEAK_GBS, 4),
                                          'traffic': pmc_traffic(),

