@@ -204,7 +204,9 @@ class TrainStep:
         g = torch.cuda.CUDAGraph()
         try:
             with self.state.bound():
-                with torch.cuda.graph(g, pool=self.pool):
+                # (thread_local: the prefetcher's copy thread and RCCL's watchdog thread keep making runtime calls while this thread
+                #  captures -- event queries, pinned allocations -- which the default global mode would turn into capture errors)
+                with torch.cuda.graph(g, pool=self.pool, capture_error_mode='thread_local'):
                     loss, out = self._body(static, sc_flag, struc_flag, with_adam)
         except Exception as e:          # a family whose step synchronises with the host cannot be captured: keep stepping, say so once
             self.failed = '%s: %s' % (type(e).__name__, e)

@@ -11,7 +11,7 @@ pids=()
 for f in $SRC/*.hip; do
   b=$(basename "$f" .hip)
   extra=""
-  case "$b" in gemm_x3|gemm_lc) extra="-fno-slp-vectorize";; decode_opts) extra="-ffp-contract=off";; esac
+  case "$b" in gemm_x3|gemm_x3w|gemm_lc|sampler) extra="-fno-slp-vectorize";; decode_opts) extra="-ffp-contract=off";; esac       # = build.py EXTRA_FLAGS
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -DCAPMI_VARIANTS $extra -c "$f" -o variants/obj/$b.o &
   pids+=($!)
 done
