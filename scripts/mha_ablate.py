@@ -10,6 +10,7 @@ import sys
 
 SHAPES = {  # name: (Nq, q_per_kv, Tq, Tk, mask_tq, mask_per_q, causal, fused, D)       (h = 8)
     'enc 64x36x36': (64, 1, 36, 36, 1, 0, 0, True, 512),
+    'enc5 320x36x36': (320, 1, 36, 36, 1, 0, 0, True, 512),          # r6: the reference's per-caption encoder (train mode)
     'dec 320x21x21': (320, 1, 21, 21, 21, 1, 1, True, 512),
     'cross 320x21x36': (320, 5, 21, 36, 1, 0, 0, False, 512),
     'aoa_refine 10x36x36': (10, 1, 36, 36, 1, 0, 0, True, 1024),
