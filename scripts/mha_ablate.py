@@ -8,6 +8,8 @@ import os
 import subprocess
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 SHAPES = {  # name: (Nq, q_per_kv, Tq, Tk, mask_tq, mask_per_q, causal, fused, D)       (h = 8)
     'enc 64x36x36': (64, 1, 36, 36, 1, 0, 0, True, 512),
     'enc5 320x36x36': (320, 1, 36, 36, 1, 0, 0, True, 512),          # r6: the reference's per-caption encoder (train mode)
