@@ -73,16 +73,27 @@ def _dh_workspace(dev, tag='dh'):
 SLAB_CONSUMERS = os.environ.get('CAPMI_AOA_SLABS', '1') != '0'
 
 
-def _dw(dy, x, out, ldc=None, off=0, accumulate=False):
+def _dw(dy, x, out, ldc=None, off=0, accumulate=False, bias=None):
     """out (+)= dy^T x, a weight gradient nothing reads before the optimizer: recorded for the grouped launch at the end of the
-    backward (ops.DeferredGrads, r6) or issued at once"""
+    backward (ops.DeferredGrads, r6) or issued at once.  bias: receives the column sums of dy (the bias gradient that goes with it)."""
     d = Lin.deferred
     if d is not None:
-        d.dw(dy, x, out, final=True, ldc=ldc, out_off=off, accumulate=accumulate)
+        d.dw(dy, x, out, final=True, ldc=ldc, out_off=off, accumulate=accumulate, colsum_out=bias)
         return
+    if bias is not None:
+        ops.colsum(dy, out=bias)
     K, M = dy.shape
     N = x.shape[1]
     ops.gemm([(dy, M, x, N, K, 1)], M, N, (out, off), ldc=N if ldc is None else ldc, a_layout=1, b_layout=1, accumulate=accumulate)
+
+
+def _colsum(x, out):
+    """out = column sums of x (which nobody writes any more): one batched launch at the end of the backward, or at once"""
+    d = Lin.deferred
+    if d is not None:
+        d.colsum(x, out)
+    else:
+        ops.colsum(x, out=out)
 
 
 class AoAGraph:
@@ -289,8 +300,11 @@ class AoAGraph:
     def backward(self, g_logp, sparse=None):
         # weight-gradient reductions and bias column sums of the Lin / Norm objects (refiner, att_embed, ctx2att) are finished by
         # two batched launches at the end (ops.DeferredGrads), as in the Transformer's backward
+        self._bias_hh_copy = False
         with deferred_grads(self.dev):
             self._backward(g_logp, sparse)
+        if self._bias_hh_copy:               # (the bias_ih column sums ride in the grouped launch that leaving the block issued)
+            self.g['core.att_lstm.bias_hh'].copy_(self.g['core.att_lstm.bias_ih'])
 
     def _backward(self, g_logp, sparse=None):
         P, g, h, B, K, R, n, N, T, L = self.P, self.g, self.h, self.B, self.K, self.R, self.n, self.N, self.T, self.L
@@ -303,8 +317,7 @@ class AoAGraph:
         ops.logsoftmax_bwd(g_logp, sparse, self.seq_logp, self.live, dlogits, N, L, T, V1, raw=self.raw)
         TN = T * N
         d_outdrop = ops.matmul_nn(dlogits.view(TN, V1), P['logit.weight'])            # [TN,R]
-        _dw(dlogits.view(TN, V1), self.out_drop.view(TN, R), g['logit.weight'])
-        ops.colsum(dlogits.view(TN, V1), out=g['logit.bias'])
+        _dw(dlogits.view(TN, V1), self.out_drop.view(TN, R), g['logit.weight'], bias=g['logit.bias'])
         d_outdrop = d_outdrop.view(T, N, R)
         W_ih, W_hh = P['core.att_lstm.weight_ih'], P['core.att_lstm.weight_hh']
         ld_ih = E + R
@@ -383,7 +396,7 @@ class AoAGraph:
                 dh_slabs = ws2.slabs
         # ---- time-batched core gradients
         dg2 = dg_all.view(TN, 4 * R)
-        _dw(dg2, self.xt.view(TN, E), g['core.att_lstm.weight_ih'], ldc=ld_ih)
+        _dw(dg2, self.xt.view(TN, E), g['core.att_lstm.weight_ih'], ldc=ld_ih, bias=g['core.att_lstm.bias_ih'])
         # columns E: of W_ih multiply (mean + ctx_in): ctx_in part time-batched, mean part through the per-image sum
         sum_dg = z(B, 4 * R)
         check(lib.capmi_group_rowsum(ptr(dg_all), T, N * 4 * R, B, n, 4 * R, ptr(sum_dg), st), 'group_rowsum')
@@ -392,8 +405,7 @@ class AoAGraph:
         ops.gemm([(sum_dg, 4 * R, self.mean, R, B, 1)], 4 * R, R, (gW, E), ldc=ld_ih, a_layout=1, b_layout=1)
         _dw(dg2, self.ctx_in.view(TN, R), gW, ldc=ld_ih, off=E, accumulate=True)
         _dw(dg2, self.h_att[:T].reshape(TN, R), g['core.att_lstm.weight_hh'])
-        ops.colsum(dg2, out=g['core.att_lstm.bias_ih'])
-        g['core.att_lstm.bias_hh'].copy_(g['core.att_lstm.bias_ih'])
+        self._bias_hh_copy = True            # bias_hh's gradient = bias_ih's: copied behind the grouped launch (backward())
         # (r5: the W_ih column blocks are read in place -- [K = 4R][N] operands of pitch E + R -- instead of through
         #  .contiguous() copies of 16 MB each: 2 copy launches, ~135 us per step)
         d_mean = z(B, R)
@@ -406,16 +418,14 @@ class AoAGraph:
         check(lib.capmi_embed_bwd(ptr(self.it_all), ptr(d_xt), ptr(self.xt), ptr(masks_xt), ptr(g['embed.0.weight']), TN, E, 1, st),
               'embed_bwd')
         # attention query path
-        _dw(dq_all.view(TN, R), self.qn.view(TN, R), g['core.attention.linears.0.weight'])
-        ops.colsum(dq_all.view(TN, R), out=g['core.attention.linears.0.bias'])
-        ops.colsum(ln_g.view(TN, R), out=g['core.attention.norm.a_2'])
-        ops.colsum(ln_dy.view(TN, R), out=g['core.attention.norm.b_2'])
+        _dw(dq_all.view(TN, R), self.qn.view(TN, R), g['core.attention.linears.0.weight'], bias=g['core.attention.linears.0.bias'])
+        _colsum(ln_g.view(TN, R), g['core.attention.norm.a_2'])
+        _colsum(ln_dy.view(TN, R), g['core.attention.norm.b_2'])
         # att2ctx
         gWc = g['core.att2ctx.0.weight']
         dp2 = d_pre2_all.view(TN, 2 * R)
-        _dw(dp2, self.att_o.view(TN, R), gWc, ldc=2 * R)
+        _dw(dp2, self.att_o.view(TN, R), gWc, ldc=2 * R, bias=g['core.att2ctx.0.bias'])
         _dw(dp2, self.h_att[1:].reshape(TN, R), gWc, ldc=2 * R, off=R)
-        ops.colsum(dp2, out=g['core.att2ctx.0.bias'])
         # ---- prefill backward
         d_att = self.ctx2att.bwd(d_p_att)                                              # [B*K,R]
         check(lib.capmi_meanpool_bwd(ptr(d_mean), ptr(self.att_masks), ptr(d_att), 1, B, K, R, st), 'meanpool_bwd')
@@ -427,9 +437,8 @@ class AoAGraph:
             W = P[pre + '.self_attn.aoa_layer.0.weight']
             gW2 = g[pre + '.self_attn.aoa_layer.0.weight']
             BK = B * K
-            _dw(d_pre, lay['od'], gW2, ldc=2 * R)
+            _dw(d_pre, lay['od'], gW2, ldc=2 * R, bias=g[pre + '.self_attn.aoa_layer.0.bias'])
             _dw(d_pre, lay['yd'], gW2, ldc=2 * R, off=R)
-            ops.colsum(d_pre, out=g[pre + '.self_attn.aoa_layer.0.bias'])
             d_o, d_y = dcat_halves(d_pre, W, BK, R, lay['m_o'], lay['m_y'])            # [d_od | d_yd] of [BK,2R] = d_pre W
             if lay['lqkv'] is not None:
                 dqkv = torch.empty(BK, 3 * R, dtype=_f32, device=dev)
