@@ -81,7 +81,7 @@ def test_struct_layouts_match_header():
              'capmi_updown_bwd_scratch': _lib.UpDownBwdScratch, 'capmi_sparse_logp_grad': _lib.SparseLogpGrad, 'capmi_mask_desc': _lib.MaskDesc,
              'capmi_reduce_item': _lib.ReduceItem, 'capmi_colsum_item': _lib.ColsumItem,
              'capmi_newfc_bwd_scratch': _lib.NewFCBwdScratch, 'capmi_next_embed': _lib.NextEmbed, 'capmi_sample_filter': _lib.SampleFilter,
-             'capmi_step_state': _lib.StepState}
+             'capmi_step_state': _lib.StepState, 'capmi_group_gemm': _lib.GroupGemm}
     for cname, cls in pairs.items():
         assert fields(cname) == [f[0] for f in cls._fields_], cname
 
