@@ -537,7 +537,7 @@ def _keep_scale(p):
 def dropout_mask(shape, p, seed, offset, device):
     m = torch.empty(shape, dtype=_f32, device=device)
     check(lib.capmi_dropout_mask(ptr(m), m.numel(), float(p), int(seed), int(offset), stream_ptr()), 'capmi_dropout_mask')
-    m._capmi_scale = _keep_scale(p)
+    m._capmi_scale = (_keep_scale(p), m._version)       # (scale, tensor version: an in-place edit by a caller voids it)
     return m
 
 
@@ -551,7 +551,7 @@ def dropout_masks(specs, p, seed):
         shape, offset, keep_from = sp[0], sp[1], sp[2]
         m = torch.empty(shape, dtype=_f32, device=sp[3])
         if sp[2] is None:                       # (eval-mode rows hold 1.0: not a pure keep-scale mask)
-            m._capmi_scale = _keep_scale(p)
+            m._capmi_scale = (_keep_scale(p), m._version)
         outs.append(m)
         descs[i].mask, descs[i].count, descs[i].offset = m.data_ptr(), m.numel(), int(offset)
         descs[i].row_len = int(shape[-1])
@@ -588,7 +588,9 @@ def relu_mask_bwd(dy, y_ref, mask):
     """dx = dy * mask * (y_ref > 0).  When y_ref is the output AFTER the mask and the mask came from dropout_mask(s) (it carries its
     keep-scale 1 / (1 - p) as `_capmi_scale`), the mask is not read at all: y_ref > 0 says where it kept the element."""
     dx = torch.empty_like(dy)
-    scale = getattr(mask, '_capmi_scale', None) if (mask is not None and y_ref is not None) else None
+    tag = getattr(mask, '_capmi_scale', None) if (mask is not None and y_ref is not None) else None
+    # (trusted only while nobody has written the mask in place since the mask kernel made it: tests inject masks with copy_)
+    scale = tag[0] if (tag is not None and tag[1] == mask._version) else None
     if scale is not None and dy.numel() % 4 == 0 and (dy.data_ptr() | y_ref.data_ptr() | dx.data_ptr()) % 16 == 0 \
             and os.environ.get('CAPMI_RELU_SCALE', '1') != '0':
         check(lib.capmi_relu_scale_bwd(ptr(dy), ptr(y_ref), float(scale), ptr(dx), dy.numel(), stream_ptr()), 'capmi_relu_scale_bwd')

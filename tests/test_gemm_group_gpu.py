@@ -116,13 +116,18 @@ def test_relu_scale_bwd_is_the_masked_jacobian(dev):
     dy = torch.randn(333, 2048, generator=g).to(dev)
     for p in (0.1, 0.3, 0.5):
         mask = ops.dropout_mask((333, 2048), p, 1234, 5 << 36, dev)
-        assert hasattr(mask, '_capmi_scale') and float(mask.max()) == mask._capmi_scale
+        assert hasattr(mask, '_capmi_scale') and float(mask.max()) == mask._capmi_scale[0]
         y = torch.relu(pre) * mask
         fast = ops.relu_mask_bwd(dy, y, mask)
         plain = mask.clone()                                   # (no keep-scale attribute: the three-operand kernel)
         slow = ops.relu_mask_bwd(dy, y, plain)
         assert torch.equal(fast, slow)
         assert torch.equal(fast, dy * mask * (pre > 0))
+        # a mask edited in place after the kernel made it no longer vouches for its keep-scale: the three-operand kernel runs
+        edited = ops.dropout_mask((333, 2048), p, 99, 7 << 36, dev)
+        edited.mul_(0.5)
+        y2 = torch.relu(pre) * edited
+        assert torch.equal(ops.relu_mask_bwd(dy, y2, edited), dy * edited * (pre > 0))
 
 
 def test_group_accumulates(dev):
